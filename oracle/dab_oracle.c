@@ -1,0 +1,426 @@
+/*
+ * dab_oracle.c -- CPU restatement of the DAB Mode-I receive chain (see dab_oracle.h).
+ * TEST INFRASTRUCTURE ONLY; PARITY UNPINNED (reference DSP source absent, no reference
+ * tests).  Each function cites the reference call site it stands behind and the
+ * ETSI EN 300 401 clause it restates.  Plain scalar C99, no -ffast-math.
+ */
+#include "dab_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+/* ------------------------------------------------------------------------- */
+/* A0': carrier mapper.  Call site: get_DAB_mapper_ref(span<int>[1536], 2048)   */
+/* /root/reference/src/radio_block.cpp:20-21.  ETSI clause 14.6 (frequency      */
+/* interleaving): PI(0)=0, PI(i)=(13*PI(i-1)+511) mod 2048, keep 256..1792\1024 */
+/* ------------------------------------------------------------------------- */
+void oracle_get_mapper(int32_t *out)
+{
+    int pi = 0, n = 0;
+    for (int i = 0; i < DAB_NB_FFT; i++) {
+        if (i > 0) pi = (13 * pi + 511) % DAB_NB_FFT;
+        if (pi < 256 || pi > 1792 || pi == 1024) continue;
+        /* carrier k = pi-1024 in [-768,768]\{0}; index in the -768..768 sans-DC vector */
+        out[n++] = (pi < 1024) ? (pi - 256) : (pi - 257);
+    }
+}
+
+int oracle_carrier_bin(int i)
+{
+    /* i<768 <-> k=-768+i -> bin 2048+k ; i>=768 <-> k=i-767 -> bin k */
+    return (i < 768) ? (1280 + i) : (i - 767);
+}
+
+/* ------------------------------------------------------------------------- */
+/* A0': phase reference symbol.  Call site: get_DAB_PRS_reference(1, span)      */
+/* /root/reference/src/radio_block.cpp:18-19.  ETSI clause 14.3.2, tables 39/43 */
+/* ------------------------------------------------------------------------- */
+static const uint8_t PRS_H[4][32] = {
+    {0,2,0,0,0,0,1,1,2,0,0,0,2,2,1,1, 0,2,0,0,0,0,1,1,2,0,0,0,2,2,1,1},
+    {0,3,2,3,0,1,3,0,2,1,2,3,2,3,3,0, 0,3,2,3,0,1,3,0,2,1,2,3,2,3,3,0},
+    {0,0,0,2,0,2,1,3,2,2,0,2,2,0,1,3, 0,0,0,2,0,2,1,3,2,2,0,2,2,0,1,3},
+    {0,1,2,1,0,3,3,2,2,3,2,1,2,1,3,2, 0,1,2,1,0,3,3,2,2,3,2,1,2,1,3,2},
+};
+/* (i, n) for the 48 blocks of 32 carriers: k' = -768,-736,...,-32, 1,33,...,737 */
+static const uint8_t PRS_IN[48][2] = {
+    {0,1},{1,2},{2,0},{3,1},{0,3},{1,2},{2,2},{3,3},{0,2},{1,1},{2,2},{3,3},
+    {0,1},{1,2},{2,3},{3,3},{0,2},{1,2},{2,2},{3,1},{0,1},{1,3},{2,1},{3,2},
+    {0,3},{3,1},{2,1},{1,1},{0,2},{3,2},{2,1},{1,0},{0,2},{3,2},{2,3},{1,3},
+    {0,0},{3,2},{2,1},{1,3},{0,3},{3,3},{2,3},{1,0},{0,3},{3,0},{2,1},{1,1},
+};
+
+void oracle_get_prs(float *out)
+{
+    static const float RE[4] = {1.f, 0.f, -1.f, 0.f};
+    static const float IM[4] = {0.f, 1.f, 0.f, -1.f};
+    memset(out, 0, sizeof(float) * 2 * DAB_NB_FFT);
+    for (int blk = 0; blk < 48; blk++) {
+        const int kstart = (blk < 24) ? (-768 + 32 * blk) : (1 + 32 * (blk - 24));
+        for (int j = 0; j < 32; j++) {
+            const int k = kstart + j;
+            const int q = (PRS_H[PRS_IN[blk][0]][j] + PRS_IN[blk][1]) & 3;
+            const int bin = (k + DAB_NB_FFT) % DAB_NB_FFT;
+            out[2 * bin] = RE[q];
+            out[2 * bin + 1] = IM[q];
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* Puncturing (ETSI clause 11.1.2, table 29): V_PI promotes the 8 groups of 4   */
+/* mother bits in the order g0,g4,g2,g6,g1,g5,g3,g7 from 1000 -> 1100 -> 1110   */
+/* -> 1111.  Tail vector V_T = 1100 x 6.                                        */
+/* ------------------------------------------------------------------------- */
+void oracle_puncture_vector(int pi, uint8_t out[32])
+{
+    static const int ORDER[8] = {0, 4, 2, 6, 1, 5, 3, 7};
+    int ones[8];
+    for (int g = 0; g < 8; g++) ones[g] = 1;
+    for (int step = 0; step < pi; step++) ones[ORDER[step % 8]]++;
+    for (int g = 0; g < 8; g++)
+        for (int b = 0; b < 4; b++) out[4 * g + b] = (uint8_t)(b < ones[g]);
+}
+
+static int append_blocks(uint8_t *mask, int pos, int nblocks, int pi)
+{
+    uint8_t v[32];
+    oracle_puncture_vector(pi, v);
+    for (int b = 0; b < nblocks; b++)
+        for (int r = 0; r < 4; r++) { /* one block = 128 mother bits = 4 x V_PI */
+            memcpy(mask + pos, v, 32);
+            pos += 32;
+        }
+    return pos;
+}
+
+static int append_tail(uint8_t *mask, int pos)
+{
+    static const uint8_t VT[4] = {1, 1, 0, 0};
+    for (int i = 0; i < 6; i++) { memcpy(mask + pos, VT, 4); pos += 4; }
+    return pos;
+}
+
+static int count_ones(const uint8_t *m, int n)
+{
+    int c = 0;
+    for (int i = 0; i < n; i++) c += m[i];
+    return c;
+}
+
+/* FIC Mode I (clause 11.2.1): 21 blocks PI=16, 3 blocks PI=15, tail. */
+int oracle_fic_puncture_mask(uint8_t *mask)
+{
+    int pos = 0;
+    pos = append_blocks(mask, pos, 21, 16);
+    pos = append_blocks(mask, pos, 3, 15);
+    pos = append_tail(mask, pos);
+    return (pos == DAB_NB_FIC_MOTHER) ? count_ones(mask, pos) : -1;
+}
+
+/* EEP (clause 11.3.2, tables 32/33). */
+int oracle_eep_puncture_mask(int option, int level, int bitrate, uint8_t *mask, int *out_nsteps, int *out_cu)
+{
+    int L1, L2, P1, P2, cu;
+    if (level < 1 || level > 4 || bitrate <= 0) return -1;
+    if (option == 0) {
+        if (bitrate % 8) return -1;
+        const int n = bitrate / 8;
+        switch (level) {
+        case 1: L1 = 6 * n - 3; L2 = 3; P1 = 24; P2 = 23; cu = 12 * n; break;
+        case 2:
+            if (n == 1) { L1 = 5; L2 = 1; P1 = 13; P2 = 12; }
+            else { L1 = 2 * n - 3; L2 = 4 * n + 3; P1 = 14; P2 = 13; }
+            cu = 8 * n; break;
+        case 3: L1 = 6 * n - 3; L2 = 3; P1 = 8; P2 = 7; cu = 6 * n; break;
+        default: L1 = 4 * n - 3; L2 = 2 * n + 3; P1 = 3; P2 = 2; cu = 4 * n; break;
+        }
+    } else if (option == 1) {
+        if (bitrate % 32) return -1;
+        const int n = bitrate / 32;
+        static const int PB[4][2] = {{10, 9}, {6, 5}, {4, 3}, {2, 1}};
+        static const int CB[4] = {27, 21, 18, 15};
+        L1 = 24 * n - 3; L2 = 3; P1 = PB[level - 1][0]; P2 = PB[level - 1][1];
+        cu = CB[level - 1] * n;
+    } else {
+        return -1;
+    }
+    const int nsteps = bitrate * 24 + 6;
+    int pos = 0;
+    pos = append_blocks(mask, pos, L1, P1);
+    pos = append_blocks(mask, pos, L2, P2);
+    pos = append_tail(mask, pos);
+    if (pos != 4 * nsteps) return -1;
+    if (out_nsteps) *out_nsteps = nsteps;
+    if (out_cu) *out_cu = cu;
+    return count_ones(mask, pos);
+}
+
+/* ------------------------------------------------------------------------- */
+/* A10: energy dispersal PRBS x^9+x^5+1, register all ones (clause 12).        */
+/* ------------------------------------------------------------------------- */
+void oracle_prbs(uint8_t *bits, int n)
+{
+    unsigned reg = 0x1FF;
+    for (int i = 0; i < n; i++) {
+        const unsigned b = ((reg >> 8) ^ (reg >> 4)) & 1u;
+        reg = ((reg << 1) | b) & 0x1FF;
+        bits[i] = (uint8_t)b;
+    }
+}
+
+/* A11: FIB CRC (clause 5.2.1): x^16+x^12+x^5+1, init all ones, complemented. */
+uint16_t oracle_crc16(const uint8_t *bytes, int n)
+{
+    unsigned crc = 0xFFFF;
+    for (int i = 0; i < n; i++) {
+        crc ^= (unsigned)bytes[i] << 8;
+        for (int b = 0; b < 8; b++)
+            crc = (crc & 0x8000) ? ((crc << 1) ^ 0x1021) : (crc << 1);
+        crc &= 0xFFFF;
+    }
+    return (uint16_t)(crc ^ 0xFFFF);
+}
+
+/* ------------------------------------------------------------------------- */
+/* Convolutional code (clause 11.1.1): K=7, rate 1/4, generators 133,171,145,  */
+/* 133 octal (MSB = current bit).  With reg bit k = a[i-k] the tap masks are    */
+/* the bit reversals 109, 79, 83, 109.                                          */
+/* ------------------------------------------------------------------------- */
+static const unsigned POLY[4] = {109, 79, 83, 109};
+
+static inline unsigned parity7(unsigned x)
+{
+    x ^= x >> 4; x ^= x >> 2; x ^= x >> 1;
+    return x & 1u;
+}
+
+void oracle_conv_encode(const uint8_t *bits, int nbits, uint8_t *out)
+{
+    unsigned reg = 0;
+    for (int i = 0; i < nbits + 6; i++) {
+        const unsigned b = (i < nbits) ? (bits[i] & 1u) : 0u;
+        reg = ((reg << 1) | b) & 0x7F;
+        for (int p = 0; p < 4; p++) out[4 * i + p] = (uint8_t)parity7(reg & POLY[p]);
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* A9: Viterbi.  Stands behind the `viterbi` package used by the reference      */
+/* (/root/reference/CMakeLists.txt:53-54).  Exact int32 correlation metric.     */
+/* ------------------------------------------------------------------------- */
+void oracle_viterbi(const int8_t *soft, int nsteps, uint8_t *out_bits)
+{
+    enum { NS = 64 };
+    int32_t ma[NS], mb[NS];
+    int32_t *old = ma, *cur = mb;
+    uint64_t *dec = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)nsteps);
+    /* sign[j][p]: expected bit (+1/-1) of output p on the branch (state j, h=0 i.e. j<32, input 0) */
+    int sgn[32][4];
+    for (int j = 0; j < 32; j++)
+        for (int p = 0; p < 4; p++) sgn[j][p] = parity7(((unsigned)j << 1) & POLY[p]) ? 1 : -1;
+
+    old[0] = 0;
+    for (int s = 1; s < NS; s++) old[s] = -8192;
+
+    for (int t = 0; t < nsteps; t++) {
+        const int8_t *s4 = soft + 4 * t;
+        uint64_t d = 0;
+        for (int j = 0; j < 32; j++) {
+            /* correlation of branch (pred j, input 0); the other three branches of the
+               butterfly are +/- this value because every generator taps a[i] and a[i-6]. */
+            const int32_t c = sgn[j][0] * s4[0] + sgn[j][1] * s4[1] + sgn[j][2] * s4[2] + sgn[j][3] * s4[3];
+            const int32_t a0 = old[j] + c,      a1 = old[j + 32] - c; /* -> state 2j   */
+            const int32_t b0 = old[j] - c,      b1 = old[j + 32] + c; /* -> state 2j+1 */
+            const int d0 = a1 > a0, d1 = b1 > b0;
+            cur[2 * j]     = d0 ? a1 : a0;
+            cur[2 * j + 1] = d1 ? b1 : b0;
+            d |= (uint64_t)d0 << (2 * j);
+            d |= (uint64_t)d1 << (2 * j + 1);
+        }
+        dec[t] = d;
+        int32_t *tmp = old; old = cur; cur = tmp;
+    }
+    /* traceback from the zero state (six zero tail bits) */
+    unsigned s = 0;
+    for (int t = nsteps - 1; t >= 0; t--) {
+        const unsigned b = s & 1u;
+        if (t < nsteps - 6) out_bits[t] = (uint8_t)b;
+        const unsigned h = (unsigned)((dec[t] >> s) & 1u);
+        s = (s >> 1) | (h << 5);
+    }
+    free(dec);
+}
+
+void oracle_depuncture(const int8_t *punct, const uint8_t *mask, int n_mother, int8_t *mother)
+{
+    int j = 0;
+    for (int i = 0; i < n_mother; i++) mother[i] = mask[i] ? punct[j++] : 0;
+}
+
+static void pack_bits(const uint8_t *bits, int nbits, uint8_t *bytes)
+{
+    for (int i = 0; i < nbits / 8; i++) {
+        unsigned v = 0;
+        for (int b = 0; b < 8; b++) v = (v << 1) | (bits[8 * i + b] & 1u);
+        bytes[i] = (uint8_t)v;
+    }
+}
+
+/* A7/A8..A11: FIC.  Stands behind BasicRadio::Process (radio_block.cpp:42), FIC branch. */
+void oracle_fic_decode(const int8_t *soft, uint8_t *fib, uint8_t *crc_ok)
+{
+    uint8_t mask[DAB_NB_FIC_MOTHER], prbs[768], bits[768];
+    int8_t mother[DAB_NB_FIC_MOTHER];
+    oracle_fic_puncture_mask(mask);
+    oracle_prbs(prbs, 768);
+    for (int g = 0; g < DAB_NB_FIC_GROUPS; g++) {
+        oracle_depuncture(soft + g * DAB_NB_FIC_GROUP_BITS, mask, DAB_NB_FIC_MOTHER, mother);
+        oracle_viterbi(mother, DAB_NB_FIC_STEPS, bits);
+        for (int i = 0; i < 768; i++) bits[i] ^= prbs[i];
+        pack_bits(bits, 768, fib + 96 * g);
+        for (int f = 0; f < 3; f++) {
+            const uint8_t *p = fib + 96 * g + 32 * f;
+            const uint16_t crc = oracle_crc16(p, 30);
+            crc_ok[3 * g + f] = (uint8_t)(crc == (((unsigned)p[30] << 8) | p[31]));
+        }
+    }
+}
+
+/* A12: time de-interleaving (clause 12): bit i is delayed by d(i mod 16) CIFs. */
+static const int TDI_DELAY[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
+
+void oracle_time_deinterleave(const int8_t *const cifs[16], int nbits, int8_t *out)
+{
+    for (int i = 0; i < nbits; i++) out[i] = cifs[TDI_DELAY[i & 15]][i];
+}
+
+void oracle_msc_decode_lf(const int8_t *deint, const uint8_t *mask, int nsteps, uint8_t *out_bytes)
+{
+    const int nbits = nsteps - 6;
+    int8_t *mother = (int8_t *)malloc((size_t)4 * nsteps);
+    uint8_t *bits = (uint8_t *)malloc((size_t)nbits);
+    uint8_t *prbs = (uint8_t *)malloc((size_t)nbits);
+    oracle_depuncture(deint, mask, 4 * nsteps, mother);
+    oracle_viterbi(mother, nsteps, bits);
+    oracle_prbs(prbs, nbits);
+    for (int i = 0; i < nbits; i++) bits[i] ^= prbs[i];
+    pack_bits(bits, nbits, out_bytes);
+    free(mother); free(bits); free(prbs);
+}
+
+/* ------------------------------------------------------------------------- */
+/* A3: 2048-point forward FFT, fp32 (the reference calls FFTW3f,               */
+/* /root/reference/CMakeLists.txt:55-64).  Iterative radix-2 DIT; twiddles are  */
+/* generated in double and rounded once.                                        */
+/* ------------------------------------------------------------------------- */
+static float g_tw_re[DAB_NB_FFT / 2], g_tw_im[DAB_NB_FFT / 2];
+static uint16_t g_brev[DAB_NB_FFT];
+static int g_fft_init = 0;
+
+static void fft_init(void)
+{
+    for (int i = 0; i < DAB_NB_FFT / 2; i++) {
+        const double a = -2.0 * M_PI * (double)i / (double)DAB_NB_FFT;
+        g_tw_re[i] = (float)cos(a);
+        g_tw_im[i] = (float)sin(a);
+    }
+    for (int i = 0; i < DAB_NB_FFT; i++) {
+        unsigned r = 0;
+        for (int b = 0; b < 11; b++) r |= ((i >> b) & 1u) << (10 - b);
+        g_brev[i] = (uint16_t)r;
+    }
+    g_fft_init = 1;
+}
+
+void oracle_fft2048(const float *in, float *out)
+{
+    if (!g_fft_init) fft_init();
+    for (int i = 0; i < DAB_NB_FFT; i++) {
+        out[2 * g_brev[i]] = in[2 * i];
+        out[2 * g_brev[i] + 1] = in[2 * i + 1];
+    }
+    for (int len = 2; len <= DAB_NB_FFT; len <<= 1) {
+        const int half = len >> 1, step = DAB_NB_FFT / len;
+        for (int base = 0; base < DAB_NB_FFT; base += len)
+            for (int k = 0; k < half; k++) {
+                const float wr = g_tw_re[k * step], wi = g_tw_im[k * step];
+                float *a = out + 2 * (base + k), *b = out + 2 * (base + k + half);
+                const float tr = b[0] * wr - b[1] * wi;
+                const float ti = b[0] * wi + b[1] * wr;
+                b[0] = a[0] - tr; b[1] = a[1] - ti;
+                a[0] = a[0] + tr; a[1] = a[1] + ti;
+            }
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* A2..A6: OFDM demodulation of one time-aligned frame.  Stands behind the      */
+/* READING_SYMBOLS branch of OFDM_Demod::Process (/root/reference/src/          */
+/* dab_module.cpp:25) up to the On_OFDM_Frame callback (radio_block.cpp:25).    */
+/* ------------------------------------------------------------------------- */
+void oracle_ofdm_demod_frame(const float *iq, float freq_offset, int8_t *soft,
+                             float *spectra, float *cyc, float *dqpsk)
+{
+    const int32_t dphi = (int32_t)lrint((double)freq_offset * 4294967296.0);
+    float *y = (float *)malloc(sizeof(float) * 2 * DAB_NB_SYM_PERIOD);
+    float *X[2];
+    X[0] = (float *)malloc(sizeof(float) * 2 * DAB_NB_FFT);
+    X[1] = (float *)malloc(sizeof(float) * 2 * DAB_NB_FFT);
+    float *d = (float *)malloc(sizeof(float) * 2 * DAB_NB_CARRIERS);
+    int32_t mapper[DAB_NB_CARRIERS];
+    oracle_get_mapper(mapper);
+
+    for (int l = 0; l < DAB_NB_FRAME_SYMBOLS; l++) {
+        /* A2: NCO frequency correction over the whole symbol (CP included) */
+        for (int i = 0; i < DAB_NB_SYM_PERIOD; i++) {
+            const uint32_t n = (uint32_t)(l * DAB_NB_SYM_PERIOD + i);
+            const uint32_t ph = n * (uint32_t)dphi;
+            const double ang = 2.0 * M_PI * ((double)ph / 4294967296.0);
+            const float wr = (float)cos(ang), wi = (float)sin(ang);
+            const float xr = iq[2 * (size_t)n], xi = iq[2 * (size_t)n + 1];
+            y[2 * i] = xr * wr - xi * wi;
+            y[2 * i + 1] = xr * wi + xi * wr;
+        }
+        /* cyclic-prefix correlation (fine frequency error estimator) */
+        if (cyc) {
+            double cr = 0.0, ci = 0.0;
+            for (int i = 0; i < DAB_NB_CP; i++) {
+                const float ar = y[2 * i], ai = y[2 * i + 1];
+                const float br = y[2 * (i + DAB_NB_FFT)], bi = y[2 * (i + DAB_NB_FFT) + 1];
+                cr += (double)(ar * br + ai * bi);   /* conj(a)*b */
+                ci += (double)(ar * bi - ai * br);
+            }
+            cyc[2 * l] = (float)cr;
+            cyc[2 * l + 1] = (float)ci;
+        }
+        /* A3: FFT of the useful part */
+        float *Xc = X[l & 1], *Xp = X[(l & 1) ^ 1];
+        oracle_fft2048(y + 2 * DAB_NB_CP, Xc);
+        if (spectra) memcpy(spectra + (size_t)l * 2 * DAB_NB_FFT, Xc, sizeof(float) * 2 * DAB_NB_FFT);
+        if (l == 0) continue;
+        /* A4: differential demodulation on the 1536 carriers */
+        for (int i = 0; i < DAB_NB_CARRIERS; i++) {
+            const int bin = oracle_carrier_bin(i);
+            const float ar = Xc[2 * bin], ai = Xc[2 * bin + 1];
+            const float br = Xp[2 * bin], bi = Xp[2 * bin + 1];
+            d[2 * i] = ar * br + ai * bi;       /* a * conj(b) */
+            d[2 * i + 1] = ai * br - ar * bi;
+        }
+        if (dqpsk) memcpy(dqpsk + (size_t)(l - 1) * 2 * DAB_NB_CARRIERS, d, sizeof(float) * 2 * DAB_NB_CARRIERS);
+        /* A5+A6: frequency de-interleave + L-infinity normalise + quantise */
+        int8_t *o = soft + (size_t)(l - 1) * DAB_NB_SYM_BITS;
+        for (int n = 0; n < DAB_NB_CARRIERS; n++) {
+            const float re = d[2 * mapper[n]], im = d[2 * mapper[n] + 1];
+            const float A = fmaxf(fabsf(re), fabsf(im));
+            if (A == 0.0f) { o[n] = 0; o[n + DAB_NB_CARRIERS] = 0; continue; }
+            o[n] = (int8_t)(int)(-127.0f * (re / A));
+            o[n + DAB_NB_CARRIERS] = (int8_t)(int)(-127.0f * (im / A));
+        }
+    }
+    free(y); free(X[0]); free(X[1]); free(d);
+}

@@ -1,0 +1,117 @@
+/*
+ * dab_oracle.h -- CPU restatement (the ORACLE) of the DAB Mode-I receive chain.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product path.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load it, and only as the checker / the CPU baseline, never as the thing shipped.
+ *
+ * PARITY UNPINNED.  The reference plugin (/root/reference) vendors its DSP as
+ * git submodules (vendor/DAB-Radio, .../vendor/viterbi_decoder) that are EMPTY in
+ * the snapshot, pins are unrecoverable (.gitmodules has URLs only), FFTW3f is
+ * not installed, and the reference has no tests / golden vectors (SURVEY.md
+ * section 0, 4, 8c).  This file therefore restates the published algorithm (ETSI
+ * EN 300 401) anchored on the reference's own call sites:
+ *   - get_DAB_OFDM_params / get_dab_parameters   src/radio_block.cpp:12-13
+ *   - get_DAB_PRS_reference                      src/radio_block.cpp:18-19
+ *   - get_DAB_mapper_ref                         src/radio_block.cpp:20-21
+ *   - OFDM_Demod::Process -> On_OFDM_Frame       src/dab_module.cpp:25, src/radio_block.cpp:25
+ *   - BasicRadio::Process                        src/radio_block.cpp:42
+ * and is validated by known-answer round trips through an independent numpy
+ * modulator (sdrplusplus-dab-radio-plugin_amd/dabgpu/synth.py) plus the standard's
+ * structural invariants (tests/test_oracle_*.py).
+ *
+ * Conventions this oracle DEFINES (the HIP kernels must reproduce them):
+ *   soft bit   int8, +127 = logical 1, -127 = logical 0, 0 = punctured/erased
+ *   quantiser  soft = (int8)trunc(-127 * component / max(|re|,|im|))
+ *   NCO        y[n] = x[n] * exp(+j*2*pi*phase(n)),  phase(n) = (uint32)(n*dphi)/2^32,
+ *              dphi = (int32)lrint(freq_offset * 2^32), n = 0 at first PRS sample
+ *   Viterbi    K=7, polys {109,79,83,109} (bit k of the mask taps a[i-k]),
+ *              state = last six input bits, newest at LSB, exact integer
+ *              correlation metric (maximise), start metric 0 for state 0 and
+ *              -8192 otherwise, survivor = older-bit-1 predecessor only if its
+ *              candidate is STRICTLY larger, traceback from state 0.
+ *   bits->bytes  first bit is the MSB of byte 0.
+ */
+#ifndef DAB_ORACLE_H
+#define DAB_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- Mode-I constants (ETSI EN 300 401 clause 14.2 / 14.3) ---- */
+enum {
+    DAB_NB_FFT            = 2048,
+    DAB_NB_CP             = 504,
+    DAB_NB_SYM_PERIOD     = 2552,
+    DAB_NB_NULL_PERIOD    = 2656,
+    DAB_NB_FRAME_SYMBOLS  = 76,    /* PRS + 75 data symbols */
+    DAB_NB_CARRIERS       = 1536,
+    DAB_NB_SYM_BITS       = 3072,
+    DAB_NB_FRAME_BITS     = 230400,
+    DAB_NB_FRAME_SAMPLES  = 196608,
+    DAB_NB_FIC_BITS       = 9216,  /* 3 symbols */
+    DAB_NB_FIC_GROUPS     = 4,
+    DAB_NB_FIC_GROUP_BITS = 2304,  /* punctured */
+    DAB_NB_FIC_MOTHER     = 3096,  /* 4*(768+6) */
+    DAB_NB_FIC_STEPS      = 774,
+    DAB_NB_FIBS           = 12,
+    DAB_NB_CIFS           = 4,
+    DAB_NB_CIF_BITS       = 55296, /* 864 CU * 64 */
+    DAB_CU_BITS           = 64,
+    DAB_TIME_DEPTH        = 16
+};
+
+/* ---- tables (A0, A0') ---- */
+/* carrier mapper: out[n], n=0..1535 -> index into the 1536-long carrier vector
+   ordered k=-768..-1,1..768.  Restates get_DAB_mapper_ref (radio_block.cpp:20). */
+void oracle_get_mapper(int32_t *out1536);
+/* FFT-bin of carrier-vector index i: i<768 -> 1280+i, else i-767 */
+int  oracle_carrier_bin(int i);
+/* PRS spectrum on 2048 FFT bins (interleaved re,im); zeros off the 1536 carriers.
+   Restates get_DAB_PRS_reference (radio_block.cpp:18). */
+void oracle_get_prs(float *out_cf32_2048);
+/* puncture vector PI (1..24) as 32 flags */
+void oracle_puncture_vector(int pi, uint8_t out32[32]);
+/* FIC puncturing: flags over 3096 mother bits (1 = transmitted); returns kept count (2304) */
+int  oracle_fic_puncture_mask(uint8_t *mask3096);
+/* EEP puncturing for a subchannel: option 0 = A (8n kb/s), 1 = B (32n kb/s); level 1..4.
+   Writes flags over (bitrate*24+6)*4 mother bits; returns kept count, or <0 if invalid.
+   *out_cu receives the subchannel size in capacity units. */
+int  oracle_eep_puncture_mask(int option, int level, int bitrate_kbps, uint8_t *mask, int *out_nsteps, int *out_cu);
+
+/* ---- bit utilities ---- */
+void     oracle_prbs(uint8_t *bits, int n);            /* x^9+x^5+1, all ones */
+uint16_t oracle_crc16(const uint8_t *bytes, int n);   /* CCITT, init FFFF, complemented */
+void     oracle_conv_encode(const uint8_t *bits, int nbits, uint8_t *out_mother /*4*(nbits+6)*/);
+
+/* ---- channel decoder (A8..A12) ---- */
+/* exact-integer Viterbi over `nsteps` trellis steps; mother_soft has 4*nsteps int8.
+   out_bits gets nsteps-6 decoded bits (one per byte). */
+void oracle_viterbi(const int8_t *mother_soft, int nsteps, uint8_t *out_bits);
+/* depuncture: scatter punctured soft bits into mother positions (erasures 0) */
+void oracle_depuncture(const int8_t *punct, const uint8_t *mask, int n_mother, int8_t *mother);
+/* FIC of one frame: 9216 soft bits -> 12 FIBs x 32 bytes + 12 CRC flags */
+void oracle_fic_decode(const int8_t *soft9216, uint8_t *fib384, uint8_t *crc_ok12);
+/* time de-interleave one logical frame: cifs[k] points at the subchannel bits of
+   CIF (t-15+k), k=0..15 (t = newest); out[i] = cifs[d(i%16)][i]. */
+void oracle_time_deinterleave(const int8_t *const cifs[16], int nbits, int8_t *out);
+/* one logical frame of a subchannel: deinterleaved punctured soft bits -> bytes */
+void oracle_msc_decode_lf(const int8_t *deint, const uint8_t *mask, int nsteps, uint8_t *out_bytes);
+
+/* ---- OFDM front end (A2..A6) ---- */
+void oracle_fft2048(const float *in_cf32, float *out_cf32);  /* forward, unnormalised, fp32 */
+/* one aligned frame: iq = 76*2552 cf32 starting at the first PRS sample.
+   soft: 230400 int8.  Optional outputs (may be NULL):
+   spectra 76*2048 cf32, cyc 76 cf32 (cyclic-prefix correlations), dqpsk 75*1536 cf32
+   (in carrier order -768..768 sans DC, before the mapper). */
+void oracle_ofdm_demod_frame(const float *iq, float freq_offset, int8_t *soft,
+                             float *spectra, float *cyc, float *dqpsk);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

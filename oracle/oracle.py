@@ -1,0 +1,172 @@
+"""ctypes binding of the CPU oracle (oracle/dab_oracle.c).
+
+TEST INFRASTRUCTURE ONLY -- importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product path (sdrplusplus-dab-radio-plugin_amd/)
+never imports this module.  PARITY UNPINNED: see dab_oracle.h.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+NB_FFT = 2048
+NB_CP = 504
+NB_SYM = 2552
+NB_NULL = 2656
+NB_SYMBOLS = 76
+NB_CARRIERS = 1536
+NB_SYM_BITS = 3072
+NB_FRAME_BITS = 230400
+NB_FRAME_SAMPLES = 196608
+NB_FIC_BITS = 9216
+NB_CIF_BITS = 55296
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    src = [os.path.join(_HERE, f) for f in ("dab_oracle.c", "dab_oracle.h")]
+    stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        L = _LIB
+        L.oracle_carrier_bin.restype = C.c_int
+        L.oracle_fic_puncture_mask.restype = C.c_int
+        L.oracle_eep_puncture_mask.restype = C.c_int
+        L.oracle_crc16.restype = C.c_uint16
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def mapper():
+    out = np.zeros(NB_CARRIERS, np.int32)
+    lib().oracle_get_mapper(_p(out))
+    return out
+
+
+def carrier_bins():
+    return np.array([lib().oracle_carrier_bin(i) for i in range(NB_CARRIERS)], np.int32)
+
+
+def prs():
+    out = np.zeros(2 * NB_FFT, np.float32)
+    lib().oracle_get_prs(_p(out))
+    return out.view(np.complex64)
+
+
+def puncture_vector(pi):
+    out = np.zeros(32, np.uint8)
+    lib().oracle_puncture_vector(C.c_int(pi), _p(out))
+    return out
+
+
+def fic_puncture_mask():
+    m = np.zeros(3096, np.uint8)
+    kept = lib().oracle_fic_puncture_mask(_p(m))
+    return m, kept
+
+
+def eep_puncture_mask(option, level, bitrate):
+    m = np.zeros(4 * (bitrate * 24 + 6), np.uint8)
+    nsteps = C.c_int(0)
+    cu = C.c_int(0)
+    kept = lib().oracle_eep_puncture_mask(C.c_int(option), C.c_int(level), C.c_int(bitrate), _p(m),
+                                          C.byref(nsteps), C.byref(cu))
+    if kept < 0:
+        raise ValueError("invalid EEP profile")
+    return m, kept, nsteps.value, cu.value
+
+
+def prbs(n):
+    out = np.zeros(n, np.uint8)
+    lib().oracle_prbs(_p(out), C.c_int(n))
+    return out
+
+
+def crc16(data):
+    a = np.ascontiguousarray(data, np.uint8)
+    return int(lib().oracle_crc16(_p(a), C.c_int(a.size)))
+
+
+def conv_encode(bits):
+    b = np.ascontiguousarray(bits, np.uint8)
+    out = np.zeros(4 * (b.size + 6), np.uint8)
+    lib().oracle_conv_encode(_p(b), C.c_int(b.size), _p(out))
+    return out
+
+
+def viterbi(mother_soft):
+    s = np.ascontiguousarray(mother_soft, np.int8)
+    nsteps = s.size // 4
+    out = np.zeros(nsteps - 6, np.uint8)
+    lib().oracle_viterbi(_p(s), C.c_int(nsteps), _p(out))
+    return out
+
+
+def depuncture(punct, mask):
+    p = np.ascontiguousarray(punct, np.int8)
+    m = np.ascontiguousarray(mask, np.uint8)
+    out = np.zeros(m.size, np.int8)
+    lib().oracle_depuncture(_p(p), _p(m), C.c_int(m.size), _p(out))
+    return out
+
+
+def fic_decode(soft):
+    s = np.ascontiguousarray(soft[:NB_FIC_BITS], np.int8)
+    fib = np.zeros(384, np.uint8)
+    ok = np.zeros(12, np.uint8)
+    lib().oracle_fic_decode(_p(s), _p(fib), _p(ok))
+    return fib.reshape(12, 32), ok
+
+
+def time_deinterleave(cifs16):
+    """cifs16: [16][nbits] int8, row k = CIF (t-15+k)."""
+    a = np.ascontiguousarray(cifs16, np.int8)
+    nbits = a.shape[1]
+    ptrs = (C.c_void_p * 16)(*[a[k].ctypes.data for k in range(16)])
+    out = np.zeros(nbits, np.int8)
+    lib().oracle_time_deinterleave(ptrs, C.c_int(nbits), _p(out))
+    return out
+
+
+def msc_decode_lf(deint, mask, nsteps):
+    d = np.ascontiguousarray(deint, np.int8)
+    m = np.ascontiguousarray(mask, np.uint8)
+    out = np.zeros((nsteps - 6) // 8, np.uint8)
+    lib().oracle_msc_decode_lf(_p(d), _p(m), C.c_int(nsteps), _p(out))
+    return out
+
+
+def fft2048(x):
+    a = np.ascontiguousarray(x, np.complex64)
+    out = np.zeros(NB_FFT, np.complex64)
+    lib().oracle_fft2048(_p(a), _p(out))
+    return out
+
+
+def ofdm_demod_frame(iq, freq_offset=0.0, want_spectra=False, want_cyc=False, want_dqpsk=False):
+    """iq: complex64[76*2552] starting at the first PRS sample."""
+    a = np.ascontiguousarray(iq, np.complex64)
+    assert a.size == NB_SYMBOLS * NB_SYM
+    soft = np.zeros(NB_FRAME_BITS, np.int8)
+    spectra = np.zeros((NB_SYMBOLS, NB_FFT), np.complex64) if want_spectra else None
+    cyc = np.zeros(NB_SYMBOLS, np.complex64) if want_cyc else None
+    dq = np.zeros((NB_SYMBOLS - 1, NB_CARRIERS), np.complex64) if want_dqpsk else None
+    lib().oracle_ofdm_demod_frame(_p(a), C.c_float(freq_offset), _p(soft),
+                                  _p(spectra) if want_spectra else None,
+                                  _p(cyc) if want_cyc else None,
+                                  _p(dq) if want_dqpsk else None)
+    return soft, spectra, cyc, dq

@@ -1,0 +1,270 @@
+"""Synthetic DAB Mode-I transmitter (numpy) -- known-answer generator and bench input.
+
+The reference ships no fixtures or tests; upstream DAB-Radio has a
+`simulate_transmitter` example that is not in /root/reference.  This is an independent
+restatement of the TRANSMIT side of ETSI EN 300 401 (clauses 5.2, 11, 12, 14), written
+without sharing code or tables with oracle/ so that round trips cross-check both.
+
+Frame layout produced: null symbol (2656 zeros) + PRS + 75 data symbols of 2552
+samples = 196608 complex64 samples at 2.048 MSPS (what the plugin's VFO delivers,
+/root/reference/src/dab_module.cpp:144-149).
+"""
+import numpy as np
+
+NB_FFT = 2048
+NB_CP = 504
+NB_SYM = NB_FFT + NB_CP
+NB_NULL = 2656
+NB_SYMBOLS = 76
+NB_CARRIERS = 1536
+NB_SYM_BITS = 2 * NB_CARRIERS
+NB_FRAME_BITS = 75 * NB_SYM_BITS
+NB_FRAME_SAMPLES = NB_NULL + NB_SYMBOLS * NB_SYM
+NB_FIC_BITS = 3 * NB_SYM_BITS
+NB_CIF_BITS = 864 * 64
+TDI_DELAY = np.array([0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15])
+
+# generator polynomials, octal, MSB = current bit (clause 11.1.1)
+_GEN_OCT = (0o133, 0o171, 0o145, 0o133)
+
+
+# ----------------------------------------------------------------------------- tables
+def carrier_of_data_index():
+    """k_n (carrier number in [-768,768]\\{0}) for data index n (clause 14.6)."""
+    pi = np.zeros(NB_FFT, np.int64)
+    for i in range(1, NB_FFT):
+        pi[i] = (13 * pi[i - 1] + 511) % NB_FFT
+    keep = pi[(pi >= 256) & (pi <= 1792) & (pi != 1024)]
+    return keep - 1024
+
+
+def prs_carriers():
+    """z_{1,k} for k=-768..768 (k=0 -> 0): dict-free dense array indexed k+768 (clause 14.3.2)."""
+    h = np.array([
+        [0, 2, 0, 0, 0, 0, 1, 1, 2, 0, 0, 0, 2, 2, 1, 1] * 2,
+        [0, 3, 2, 3, 0, 1, 3, 0, 2, 1, 2, 3, 2, 3, 3, 0] * 2,
+        [0, 0, 0, 2, 0, 2, 1, 3, 2, 2, 0, 2, 2, 0, 1, 3] * 2,
+        [0, 1, 2, 1, 0, 3, 3, 2, 2, 3, 2, 1, 2, 1, 3, 2] * 2,
+    ])
+    # (k', i, n) Mode I, table 39
+    rows = [(-768, 0, 1), (-736, 1, 2), (-704, 2, 0), (-672, 3, 1), (-640, 0, 3), (-608, 1, 2),
+            (-576, 2, 2), (-544, 3, 3), (-512, 0, 2), (-480, 1, 1), (-448, 2, 2), (-416, 3, 3),
+            (-384, 0, 1), (-352, 1, 2), (-320, 2, 3), (-288, 3, 3), (-256, 0, 2), (-224, 1, 2),
+            (-192, 2, 2), (-160, 3, 1), (-128, 0, 1), (-96, 1, 3), (-64, 2, 1), (-32, 3, 2),
+            (1, 0, 3), (33, 3, 1), (65, 2, 1), (97, 1, 1), (129, 0, 2), (161, 3, 2), (193, 2, 1),
+            (225, 1, 0), (257, 0, 2), (289, 3, 2), (321, 2, 3), (353, 1, 3), (385, 0, 0),
+            (417, 3, 2), (449, 2, 1), (481, 1, 3), (513, 0, 3), (545, 3, 3), (577, 2, 3),
+            (609, 1, 0), (641, 0, 3), (673, 3, 0), (705, 2, 1), (737, 1, 1)]
+    z = np.zeros(2 * 768 + 1, np.complex128)
+    for kp, i, n in rows:
+        for j in range(32):
+            z[kp + j + 768] = 1j ** int((h[i][j] + n) % 4)
+    return z
+
+
+def puncture_vector(pi):
+    order = [0, 4, 2, 6, 1, 5, 3, 7]
+    ones = [1] * 8
+    for s in range(pi):
+        ones[order[s % 8]] += 1
+    return np.array([[1 if b < ones[g] else 0 for b in range(4)] for g in range(8)], np.uint8).ravel()
+
+
+def _mask_from_profile(blocks):
+    parts = [np.tile(puncture_vector(pi), 4 * L) for L, pi in blocks if L > 0]
+    parts.append(np.tile(np.array([1, 1, 0, 0], np.uint8), 6))
+    return np.concatenate(parts)
+
+
+def fic_mask():
+    return _mask_from_profile([(21, 16), (3, 15)])
+
+
+def eep_profile(option, level, bitrate):
+    """-> (blocks [(L,PI),...], size_cu).  Clause 11.3.2."""
+    if option == 0:
+        n = bitrate // 8
+        assert bitrate == 8 * n
+        if level == 1:
+            return [(6 * n - 3, 24), (3, 23)], 12 * n
+        if level == 2:
+            if n == 1:
+                return [(5, 13), (1, 12)], 8
+            return [(2 * n - 3, 14), (4 * n + 3, 13)], 8 * n
+        if level == 3:
+            return [(6 * n - 3, 8), (3, 7)], 6 * n
+        if level == 4:
+            return [(4 * n - 3, 3), (2 * n + 3, 2)], 4 * n
+    else:
+        n = bitrate // 32
+        assert bitrate == 32 * n
+        pis = {1: (10, 9), 2: (6, 5), 3: (4, 3), 4: (2, 1)}[level]
+        cu = {1: 27, 2: 21, 3: 18, 4: 15}[level] * n
+        return [(24 * n - 3, pis[0]), (3, pis[1])], cu
+    raise ValueError("bad EEP profile")
+
+
+def eep_mask(option, level, bitrate):
+    blocks, cu = eep_profile(option, level, bitrate)
+    m = _mask_from_profile(blocks)
+    assert m.size == 4 * (bitrate * 24 + 6) and int(m.sum()) == cu * 64
+    return m, cu
+
+
+# ----------------------------------------------------------------------------- bit level
+def prbs(n):
+    reg = [1] * 9  # reg[0] newest
+    out = np.zeros(n, np.uint8)
+    for i in range(n):
+        b = reg[8] ^ reg[4]
+        out[i] = b
+        reg = [b] + reg[:8]
+    return out
+
+
+def crc16(data):
+    crc = 0xFFFF
+    for byte in bytes(data):
+        crc ^= byte << 8
+        for _ in range(8):
+            crc = ((crc << 1) ^ 0x1021) if (crc & 0x8000) else (crc << 1)
+            crc &= 0xFFFF
+    return crc ^ 0xFFFF
+
+
+def make_fibs(rng, n):
+    """n random FIBs: 30 data bytes + CRC16 (clause 5.2.1)."""
+    fibs = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    for f in fibs:
+        c = crc16(f[:30])
+        f[30] = c >> 8
+        f[31] = c & 0xFF
+    return fibs
+
+
+def conv_encode(bits):
+    """rate-1/4 mother code with 6 zero tail bits -> 4*(n+6) bits, order x0,x1,x2,x3 per input."""
+    a = np.concatenate([np.zeros(6, np.uint8), np.asarray(bits, np.uint8), np.zeros(6, np.uint8)])
+    n = a.size - 6
+    out = np.zeros((n, 4), np.uint8)
+    for p, g in enumerate(_GEN_OCT):
+        acc = np.zeros(n, np.uint8)
+        for k in range(7):          # octal MSB (bit 6) multiplies a[i], bit (6-k) multiplies a[i-k]
+            if (g >> (6 - k)) & 1:
+                acc ^= a[6 - k: 6 - k + n]
+        out[:, p] = acc
+    return out.ravel()
+
+
+def fic_encode(fibs12):
+    """12 FIBs -> 9216 punctured coded bits (4 groups of 3 FIBs)."""
+    m = fic_mask().astype(bool)
+    pr = prbs(768)
+    out = []
+    for g in range(4):
+        bits = np.unpackbits(np.asarray(fibs12[3 * g:3 * g + 3], np.uint8).ravel())
+        out.append(conv_encode(bits ^ pr)[m])
+    return np.concatenate(out)
+
+
+def msc_encode_lf(lf_bytes, mask):
+    """one logical frame of a subchannel -> punctured coded bits."""
+    bits = np.unpackbits(np.asarray(lf_bytes, np.uint8))
+    return conv_encode(bits ^ prbs(bits.size))[mask.astype(bool)]
+
+
+def time_interleave(coded, cyclic=True):
+    """coded [R][nbits] logical frames -> tx [R][nbits] CIF contents:
+    tx[(r + d(i%16)) % R][i] = coded[r][i] (cyclic) ; non-cyclic leaves the first CIFs partly zero."""
+    R, nbits = coded.shape
+    tx = np.zeros_like(coded)
+    d = TDI_DELAY[np.arange(nbits) % 16]
+    for r in range(R):
+        dst = r + d
+        if cyclic:
+            tx[dst % R, np.arange(nbits)] = coded[r]
+        else:
+            ok = dst < R
+            tx[dst[ok], np.arange(nbits)[ok]] = coded[r][ok]
+    return tx
+
+
+# ----------------------------------------------------------------------------- OFDM
+_CAR = None
+_PRS = None
+
+
+def _tables():
+    global _CAR, _PRS
+    if _CAR is None:
+        _CAR = carrier_of_data_index()
+        _PRS = prs_carriers()
+    return _CAR, _PRS
+
+
+def modulate_frame(bits):
+    """230400 bits -> complex64[196608] (null + PRS + 75 symbols), unit average symbol power."""
+    car, prs = _tables()
+    bits = np.asarray(bits, np.uint8).reshape(75, NB_SYM_BITS)
+    out = np.zeros(NB_FRAME_SAMPLES, np.complex64)
+    z = prs.copy()                       # indexed k+768
+    pos = NB_NULL
+    scale = NB_FFT / np.sqrt(NB_CARRIERS)
+    for l in range(NB_SYMBOLS):
+        if l > 0:
+            p = bits[l - 1].astype(np.float64)
+            q = ((1 - 2 * p[:NB_CARRIERS]) + 1j * (1 - 2 * p[NB_CARRIERS:])) / np.sqrt(2.0)
+            y = np.ones(2 * 768 + 1, np.complex128)
+            y[car + 768] = q
+            z = z * y
+        spec = np.zeros(NB_FFT, np.complex128)
+        k = np.arange(-768, 769)
+        spec[k % NB_FFT] = z
+        spec[0] = 0
+        t = np.fft.ifft(spec) * scale
+        out[pos:pos + NB_CP] = t[-NB_CP:]
+        out[pos + NB_CP:pos + NB_SYM] = t
+        pos += NB_SYM
+    return out
+
+
+def channel(iq, snr_db=None, cfo=0.0, rng=None, phase0=0.0):
+    """cfo in cycles/sample; AWGN relative to unit signal power."""
+    x = np.asarray(iq, np.complex64).astype(np.complex128)
+    n = np.arange(x.size)
+    if cfo != 0.0 or phase0 != 0.0:
+        x = x * np.exp(2j * np.pi * (cfo * n + phase0))
+    if snr_db is not None:
+        sigma = np.sqrt(0.5 * 10 ** (-snr_db / 10))
+        x = x + sigma * (rng.standard_normal(x.size) + 1j * rng.standard_normal(x.size))
+    return x.astype(np.complex64)
+
+
+class Ensemble:
+    """A small cyclic multiplex: FIC of random FIBs + one EEP subchannel + random filler.
+
+    `n_frames` frames form a cyclically time-interleaved stream (4*n_frames CIFs) so that
+    tiling the frames back to back is a valid continuous transmission."""
+
+    def __init__(self, seed, n_frames=4, option=0, level=3, bitrate=64, start_cu=0):
+        rng = np.random.default_rng(seed)
+        self.n_frames = n_frames
+        self.mask, self.size_cu = eep_mask(option, level, bitrate)
+        self.start_cu = start_cu
+        self.lf_bytes = bitrate * 3
+        R = 4 * n_frames
+        self.fibs = make_fibs(rng, 12 * n_frames).reshape(n_frames, 12, 32)
+        self.msc_bytes = rng.integers(0, 256, size=(R, self.lf_bytes), dtype=np.uint8)
+        coded = np.stack([msc_encode_lf(self.msc_bytes[r], self.mask) for r in range(R)])
+        tx = time_interleave(coded, cyclic=True)
+        cifs = rng.integers(0, 2, size=(R, NB_CIF_BITS), dtype=np.uint8)
+        a = start_cu * 64
+        cifs[:, a:a + self.size_cu * 64] = tx
+        self.frame_bits = np.zeros((n_frames, NB_FRAME_BITS), np.uint8)
+        for f in range(n_frames):
+            self.frame_bits[f, :NB_FIC_BITS] = fic_encode(self.fibs[f])
+            self.frame_bits[f, NB_FIC_BITS:] = cifs[4 * f:4 * f + 4].ravel()
+
+    def iq(self):
+        """[n_frames][196608] complex64."""
+        return np.stack([modulate_frame(self.frame_bits[f]) for f in range(self.n_frames)])
