@@ -1,0 +1,221 @@
+/*
+ * dabgpu.h -- C ABI of the MI355X-native DAB Mode-I receive chain (libdabgpu.so).
+ *
+ * This is the drop-in boundary for the ONE hot path of the SDR++ DAB plugin: the
+ * OFDM front end and the channel decoder that sit behind Radio_Block / OFDM_Demod /
+ * BasicRadio.  Every entry point names the reference interface it replaces
+ * (file:line under /root/reference).  The DSP those interfaces front lives in git
+ * submodules that are empty in the reference snapshot, so the citations are the
+ * plugin's call sites.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types, no exceptions.
+ *   - return 0 (DABGPU_OK) or a negative dabgpu_status; dabgpu_strerror() explains.
+ *   - `_dev` entry points take DEVICE pointers and a hipStream_t passed as void*
+ *     (NULL = the context's own stream); they only enqueue work.  The variants
+ *     without `_dev` take HOST pointers, copy, run and synchronise.
+ *   - the caller owns every buffer; a context is thread-compatible (one caller
+ *     at a time per context), contexts are independent.
+ *   - soft bits are int8: +127 = logical 1, -127 = logical 0, 0 = erased
+ *     (`viterbi_bit_t`, /root/reference/src/radio_block.h:19).
+ *   - the library REQUIRES a gfx950 device for everything except the table
+ *     getters; there is no CPU fallback.
+ */
+#ifndef DABGPU_H
+#define DABGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DABGPU_ABI_VERSION 1
+
+typedef enum dabgpu_status {
+    DABGPU_OK = 0,
+    DABGPU_ERR_ARG = -1,       /* null / out-of-range argument              */
+    DABGPU_ERR_HIP = -2,       /* a HIP runtime call failed                 */
+    DABGPU_ERR_NOMEM = -3,     /* device or host allocation failed          */
+    DABGPU_ERR_NODEVICE = -4,  /* no gfx950 device visible                  */
+    DABGPU_ERR_PROFILE = -5,   /* unsupported transmission mode / profile   */
+    DABGPU_ERR_CAPACITY = -6   /* request exceeds what the context was sized for */
+} dabgpu_status;
+
+/* ------------------------------------------------------------------------ */
+/* A0: constant parameter blocks.                                            */
+/* Replaces get_DAB_OFDM_params(mode)   /root/reference/src/radio_block.cpp:12 */
+/*          get_dab_parameters(mode)    /root/reference/src/radio_block.cpp:13 */
+/* Only transmission mode 1 is supported (radio_block.cpp:9).                 */
+/* ------------------------------------------------------------------------ */
+typedef struct dabgpu_ofdm_params {
+    int32_t nb_frame_symbols;     /* 76  */
+    int32_t nb_symbol_period;     /* 2552 */
+    int32_t nb_null_period;       /* 2656 */
+    int32_t nb_fft;               /* 2048 */
+    int32_t nb_cyclic_prefix;     /* 504 */
+    int32_t nb_data_carriers;     /* 1536 */
+    int32_t freq_carrier_spacing; /* 1000 Hz */
+    int32_t nb_frame_samples;     /* 196608 */
+} dabgpu_ofdm_params;
+
+typedef struct dabgpu_dab_params {
+    int32_t nb_frame_bits;    /* 230400 */
+    int32_t nb_symbols;       /* 75 data symbols */
+    int32_t nb_fic_symbols;   /* 3 */
+    int32_t nb_msc_symbols;   /* 72 */
+    int32_t nb_sym_bits;      /* 3072 */
+    int32_t nb_fic_bits;      /* 9216 */
+    int32_t nb_msc_bits;      /* 221184 */
+    int32_t nb_fibs;          /* 12 */
+    int32_t nb_cifs;          /* 4 */
+    int32_t nb_fib_bits;      /* 256 */
+    int32_t nb_fib_cif_bits;  /* 2304: one punctured FIC group */
+    int32_t nb_fibs_per_cif;  /* 3 */
+    int32_t nb_cif_bits;      /* 55296 */
+} dabgpu_dab_params;
+
+int dabgpu_get_ofdm_params(int transmission_mode, dabgpu_ofdm_params *out);
+int dabgpu_get_dab_params(int transmission_mode, dabgpu_dab_params *out);
+
+/* A0': replaces get_DAB_PRS_reference(mode, span<complex<float>>[nb_fft])
+ * /root/reference/src/radio_block.cpp:18-19.  out = nb_fft interleaved (re,im). */
+int dabgpu_get_prs_reference(int transmission_mode, float *out_cf32, int nb_fft);
+/* A0': replaces get_DAB_mapper_ref(span<int>[nb_data_carriers], nb_fft)
+ * /root/reference/src/radio_block.cpp:20-21. */
+int dabgpu_get_mapper_reference(int32_t *out, int nb_data_carriers, int nb_fft);
+
+/* ------------------------------------------------------------------------ */
+/* Context                                                                   */
+/* ------------------------------------------------------------------------ */
+typedef struct dabgpu_ctx dabgpu_ctx;
+
+typedef struct dabgpu_cfg {
+    int32_t device;          /* HIP device ordinal                                    */
+    int32_t max_frames;      /* largest n_frames any call will pass (scratch sizing)  */
+    int32_t transmission_mode; /* must be 1                                           */
+    int32_t flags;           /* DABGPU_FLAG_*                                         */
+} dabgpu_cfg;
+
+#define DABGPU_FLAG_NONE 0
+
+/* Replaces the construction in Radio_Block::Radio_Block
+ * (/root/reference/src/radio_block.cpp:11-22: params + PRS + mapper + OFDM_Demod). */
+int  dabgpu_create(const dabgpu_cfg *cfg, dabgpu_ctx **out);
+void dabgpu_destroy(dabgpu_ctx *ctx);
+const char *dabgpu_strerror(int status);
+int  dabgpu_abi_version(void);
+/* block until everything enqueued on the context's own stream has finished */
+int  dabgpu_sync(dabgpu_ctx *ctx);
+/* the context's own hipStream_t (as void*) */
+void *dabgpu_stream(dabgpu_ctx *ctx);
+
+/* ------------------------------------------------------------------------ */
+/* A2..A6: OFDM front end on time-aligned frames.                             */
+/* Replaces the READING_SYMBOLS work of OFDM_Demod::Process                    */
+/*   /root/reference/src/dab_module.cpp:25 (call), src/radio_block.cpp:22 (ctor) */
+/* up to the payload of the On_OFDM_Frame callback (src/radio_block.cpp:25).   */
+/*                                                                            */
+/* iq           cf32; frame f starts (first PRS sample, i.e. after the null    */
+/*              symbol) at iq + f*frame_stride complex samples; 76*2552        */
+/*              samples are read per frame.  Must be 16-byte aligned and        */
+/*              frame_stride even.                                              */
+/* freq_offset  [n_frames] correction in cycles/sample applied as               */
+/*              x[n]*exp(+j*2*pi*f*n) (the sum the reference shows as           */
+/*              GetNetFrequencyOffset(), src/render_radio_block.cpp:204).       */
+/*              NULL = no correction.                                           */
+/* soft         [n_frames][230400] int8 (frame bits in transmission order)      */
+/* cyc          optional [n_frames][76] cf32: cyclic-prefix correlations        */
+/*              sum conj(y[i])*y[i+2048]; their mean angle / (2*pi*2048) is the */
+/*              fine frequency error (fine_freq_update_beta loop,               */
+/*              src/render_radio_block.cpp:216).                                */
+/* dqpsk        optional [n_frames][75][1536] cf32 differential symbols in      */
+/*              carrier order -768..768 (GetFrameDataVec(),                     */
+/*              src/render_radio_block.cpp:109).                                */
+/* ------------------------------------------------------------------------ */
+int dabgpu_ofdm_demod_frames_dev(dabgpu_ctx *ctx, const void *d_iq, size_t frame_stride, int n_frames,
+                                 const float *d_freq_offset, int8_t *d_soft, void *d_cyc, void *d_dqpsk,
+                                 void *stream);
+int dabgpu_ofdm_demod_frames(dabgpu_ctx *ctx, const float *iq, size_t frame_stride, int n_frames,
+                             const float *freq_offset, int8_t *soft, float *cyc, float *dqpsk);
+
+/* A2+A3 alone (the unfused "FFT stage"): frequency-corrected 2048-point forward
+ * FFT of the useful part of each of the 76 symbols.  Replaces the FFTW3f plan the
+ * reference links (/root/reference/CMakeLists.txt:55-64).
+ * spectra  [n_frames][76][2048] cf32, unnormalised, natural bin order. */
+int dabgpu_fft_symbols_dev(dabgpu_ctx *ctx, const void *d_iq, size_t frame_stride, int n_frames,
+                           const float *d_freq_offset, void *d_spectra, void *stream);
+int dabgpu_fft_symbols(dabgpu_ctx *ctx, const float *iq, size_t frame_stride, int n_frames,
+                       const float *freq_offset, float *spectra);
+
+/* ------------------------------------------------------------------------ */
+/* A7..A11: FIC.  Replaces the FIC branch of BasicRadio::Process              */
+/*   /root/reference/src/radio_block.cpp:42 (call), :60 (ctor).               */
+/* soft      frame f's bits start at soft + f*soft_stride; the first 9216 are  */
+/*           the FIC (4 groups of 2304).                                       */
+/* fib       [n_frames][12][32] bytes (30 data + CRC16), energy dispersal       */
+/*           removed                                                           */
+/* crc_ok    [n_frames][12] 1 = CRC matches                                    */
+/* ------------------------------------------------------------------------ */
+int dabgpu_fic_decode_dev(dabgpu_ctx *ctx, const int8_t *d_soft, size_t soft_stride, int n_frames,
+                          uint8_t *d_fib, uint8_t *d_crc_ok, void *stream);
+int dabgpu_fic_decode(dabgpu_ctx *ctx, const int8_t *soft, size_t soft_stride, int n_frames,
+                      uint8_t *fib, uint8_t *crc_ok);
+
+/* ------------------------------------------------------------------------ */
+/* A12: one MSC subchannel.  Replaces the per-subchannel branch of             */
+/* BasicRadio::Process (/root/reference/src/radio_block.cpp:42); the           */
+/* descriptor mirrors the Subchannel entity the GUI prints                     */
+/* (/root/reference/src/render_formatters.cpp:9-25).                           */
+/* ------------------------------------------------------------------------ */
+typedef struct dabgpu_subchannel {
+    int32_t start_address;   /* first capacity unit (0..863)                  */
+    int32_t length;          /* size in capacity units                        */
+    int32_t is_uep;          /* must be 0 in this version                     */
+    int32_t eep_type;        /* 0 = A, 1 = B                                  */
+    int32_t protection_level;/* 1..4                                          */
+    int32_t bitrate_kbps;    /* multiple of 8 (A) / 32 (B)                    */
+} dabgpu_subchannel;
+
+/* bytes one CIF of this subchannel decodes to (bitrate*3), or <0 */
+int dabgpu_subchannel_bytes(const dabgpu_subchannel *sc);
+
+/* n_streams independent ensembles, frames_per_stream consecutive frames each;
+ * frame (s,f) is at soft + (s*frames_per_stream+f)*soft_stride.
+ * history_in / history_out  [n_streams][15][length*64] int8: the subchannel's bits of the
+ *           15 CIFs before / at the end of this call (time de-interleaver state, 16-CIF
+ *           depth).  history_in may be NULL (treated as erasures); they must not alias.
+ * out       [n_streams][frames_per_stream*4][bitrate*3] bytes; entry t is the logical
+ *           frame completed by CIF t, i.e. the one transmitted 15 CIFs earlier. */
+int dabgpu_msc_decode_dev(dabgpu_ctx *ctx, const dabgpu_subchannel *sc, const int8_t *d_soft,
+                          size_t soft_stride, int n_streams, int frames_per_stream,
+                          const int8_t *d_history_in, int8_t *d_history_out, uint8_t *d_out, void *stream);
+int dabgpu_msc_decode(dabgpu_ctx *ctx, const dabgpu_subchannel *sc, const int8_t *soft,
+                      size_t soft_stride, int n_streams, int frames_per_stream,
+                      const int8_t *history_in, int8_t *history_out, uint8_t *out);
+
+/* ------------------------------------------------------------------------ */
+/* A9 on its own: batched punctured soft Viterbi (K=7, rate 1/4).             */
+/* Replaces the `viterbi` package (/root/reference/CMakeLists.txt:53-54).     */
+/* punct     [n_codewords][n_punct] int8 punctured soft bits                   */
+/* mask      HOST pointer, 4*nsteps flags (1 = transmitted)                    */
+/* out_bits  [n_codewords][(nsteps-6)/8] bytes, MSB first, NOT descrambled     */
+/* ------------------------------------------------------------------------ */
+int dabgpu_viterbi_dev(dabgpu_ctx *ctx, const int8_t *d_punct, int n_codewords, const uint8_t *mask,
+                       int nsteps, uint8_t *d_out_bytes, void *stream);
+int dabgpu_viterbi(dabgpu_ctx *ctx, const int8_t *punct, int n_codewords, const uint8_t *mask,
+                   int nsteps, uint8_t *out_bytes);
+
+/* ------------------------------------------------------------------------ */
+/* Timing helper: average duration (ms) of the most recent launch of each      */
+/* kernel family, measured with hipEvents on the launch stream when             */
+/* dabgpu_set_timing(ctx,1) is on.  which: 0 = ofdm, 1 = fic, 2 = msc, 3 = fft */
+/* ------------------------------------------------------------------------ */
+int dabgpu_set_timing(dabgpu_ctx *ctx, int enable);
+int dabgpu_last_kernel_ms(dabgpu_ctx *ctx, int which, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

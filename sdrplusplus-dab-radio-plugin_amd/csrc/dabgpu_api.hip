@@ -1,0 +1,559 @@
+// dabgpu_api.hip -- the C ABI of libdabgpu (include/dabgpu.h): context, tables,
+// argument checking and kernel launches.  No CPU fallback: without a gfx950 device
+// dabgpu_create fails with DABGPU_ERR_NODEVICE and every compute entry point needs a
+// context.
+#include "../../include/dabgpu.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <new>
+#include <vector>
+
+#include "dab_tables.hpp"
+#include "kernels.hpp"
+
+using namespace dab;
+
+namespace {
+
+struct DeviceCode {
+    dab::PunctureProfile prof;
+    uint16_t *d_mother_pos = nullptr;
+    uint8_t *d_prbs = nullptr;
+    dabk::CodeTables tables(bool descramble) const {
+        return dabk::CodeTables{d_mother_pos, prof.n_punct, prof.nsteps, descramble ? d_prbs : nullptr};
+    }
+};
+
+struct Timer {
+    hipEvent_t start = nullptr, stop = nullptr;
+    bool valid = false;
+};
+
+}  // namespace
+
+struct dabgpu_ctx {
+    int device = 0;
+    int max_frames = 0;
+    hipStream_t stream = nullptr;
+    float2 *d_twiddle = nullptr;
+    uint16_t *d_bin_of_n = nullptr;
+    DeviceCode fic;
+    std::map<std::vector<uint8_t>, std::unique_ptr<DeviceCode>> codes;   // keyed by puncture mask
+    // staging for the host-pointer entry points
+    void *d_stage[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t stage_bytes[6] = {0, 0, 0, 0, 0, 0};
+    bool timing = false;
+    Timer timers[4];
+    int ofdm_group_override = 0;
+};
+
+namespace {
+
+#define HIP_TRY(expr)                               \
+    do {                                            \
+        hipError_t e_ = (expr);                     \
+        if (e_ != hipSuccess) return DABGPU_ERR_HIP; \
+    } while (0)
+
+template <class T>
+int upload(T **dst, const std::vector<T> &src) {
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(dst), src.size() * sizeof(T)));
+    HIP_TRY(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return DABGPU_OK;
+}
+
+int build_device_code(DeviceCode &dc) {
+    std::vector<uint16_t> pos;
+    pos.reserve(dc.prof.n_punct);
+    for (size_t i = 0; i < dc.prof.mask.size(); i++)
+        if (dc.prof.mask[i]) pos.push_back(uint16_t(i));
+    if (dc.prof.mask.size() > 65535 || int(pos.size()) != dc.prof.n_punct) return DABGPU_ERR_PROFILE;
+    int rc = upload(&dc.d_mother_pos, pos);
+    if (rc) return rc;
+    return upload(&dc.d_prbs, dab::make_prbs_bytes((dc.prof.nsteps - 6 + 7) / 8));
+}
+
+void free_device_code(DeviceCode &dc) {
+    if (dc.d_mother_pos) (void)hipFree(dc.d_mother_pos);
+    if (dc.d_prbs) (void)hipFree(dc.d_prbs);
+    dc.d_mother_pos = nullptr;
+    dc.d_prbs = nullptr;
+}
+
+int get_code(dabgpu_ctx *ctx, dab::PunctureProfile &&prof, DeviceCode **out) {
+    auto it = ctx->codes.find(prof.mask);
+    if (it == ctx->codes.end()) {
+        auto dc = std::make_unique<DeviceCode>();
+        dc->prof = std::move(prof);
+        int rc = build_device_code(*dc);
+        if (rc) { free_device_code(*dc); return rc; }
+        it = ctx->codes.emplace(dc->prof.mask, std::move(dc)).first;
+    }
+    *out = it->second.get();
+    return DABGPU_OK;
+}
+
+int stage(dabgpu_ctx *ctx, int slot, size_t bytes, void **out) {
+    if (ctx->stage_bytes[slot] < bytes) {
+        if (ctx->d_stage[slot]) (void)hipFree(ctx->d_stage[slot]);
+        ctx->d_stage[slot] = nullptr;
+        ctx->stage_bytes[slot] = 0;
+        if (hipMalloc(&ctx->d_stage[slot], bytes) != hipSuccess) return DABGPU_ERR_NOMEM;
+        ctx->stage_bytes[slot] = bytes;
+    }
+    *out = ctx->d_stage[slot];
+    return DABGPU_OK;
+}
+
+struct ScopedTimer {
+    dabgpu_ctx *ctx;
+    int which;
+    hipStream_t s;
+    ScopedTimer(dabgpu_ctx *c, int w, hipStream_t st) : ctx(c), which(w), s(st) {
+        if (ctx->timing) {
+            Timer &t = ctx->timers[which];
+            if (!t.start) { (void)hipEventCreate(&t.start); (void)hipEventCreate(&t.stop); }
+            (void)hipEventRecord(t.start, s);
+        }
+    }
+    ~ScopedTimer() {
+        if (ctx->timing) {
+            Timer &t = ctx->timers[which];
+            (void)hipEventRecord(t.stop, s);
+            t.valid = true;
+        }
+    }
+};
+
+// symbols per workgroup: whole frame per workgroup once there are enough frames to fill
+// 256 CUs several times over, otherwise split the frame (each split re-reads one symbol).
+int pick_group(const dabgpu_ctx *ctx, int n_frames, int total_syms) {
+    if (ctx->ofdm_group_override > 0 && total_syms % ctx->ofdm_group_override == 0)
+        return ctx->ofdm_group_override;
+    static const int DIV75[] = {75, 25, 15, 5, 3, 1};
+    static const int DIV76[] = {76, 38, 19, 4, 2, 1};
+    const int *divs = (total_syms == 75) ? DIV75 : DIV76;
+    for (int i = 0; i < 6; i++) {
+        const long wgs = long(n_frames) * (total_syms / divs[i]);
+        if (wgs >= 2048) return divs[i];
+    }
+    return 1;
+}
+
+hipStream_t pick_stream(dabgpu_ctx *ctx, void *stream) {
+    return stream ? reinterpret_cast<hipStream_t>(stream) : ctx->stream;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dabgpu_abi_version(void) { return DABGPU_ABI_VERSION; }
+
+const char *dabgpu_strerror(int status) {
+    switch (status) {
+    case DABGPU_OK: return "ok";
+    case DABGPU_ERR_ARG: return "invalid argument";
+    case DABGPU_ERR_HIP: return "HIP runtime error";
+    case DABGPU_ERR_NOMEM: return "out of memory";
+    case DABGPU_ERR_NODEVICE: return "no gfx950 device available (libdabgpu has no CPU fallback)";
+    case DABGPU_ERR_PROFILE: return "unsupported transmission mode or protection profile";
+    case DABGPU_ERR_CAPACITY: return "request exceeds context capacity";
+    default: return "unknown status";
+    }
+}
+
+int dabgpu_get_ofdm_params(int mode, dabgpu_ofdm_params *out) {
+    if (!out) return DABGPU_ERR_ARG;
+    if (mode != 1) return DABGPU_ERR_PROFILE;
+    out->nb_frame_symbols = NB_FRAME_SYMBOLS;
+    out->nb_symbol_period = NB_SYM_PERIOD;
+    out->nb_null_period = NB_NULL_PERIOD;
+    out->nb_fft = NB_FFT;
+    out->nb_cyclic_prefix = NB_CP;
+    out->nb_data_carriers = NB_CARRIERS;
+    out->freq_carrier_spacing = 1000;
+    out->nb_frame_samples = NB_FRAME_SAMPLES;
+    return DABGPU_OK;
+}
+
+int dabgpu_get_dab_params(int mode, dabgpu_dab_params *out) {
+    if (!out) return DABGPU_ERR_ARG;
+    if (mode != 1) return DABGPU_ERR_PROFILE;
+    out->nb_frame_bits = NB_FRAME_BITS;
+    out->nb_symbols = NB_DATA_SYMBOLS;
+    out->nb_fic_symbols = NB_FIC_SYMBOLS;
+    out->nb_msc_symbols = NB_DATA_SYMBOLS - NB_FIC_SYMBOLS;
+    out->nb_sym_bits = NB_SYM_BITS;
+    out->nb_fic_bits = NB_FIC_BITS;
+    out->nb_msc_bits = NB_FRAME_BITS - NB_FIC_BITS;
+    out->nb_fibs = NB_FIBS;
+    out->nb_cifs = NB_CIFS;
+    out->nb_fib_bits = 256;
+    out->nb_fib_cif_bits = NB_FIC_GROUP_BITS;
+    out->nb_fibs_per_cif = NB_FIBS / NB_CIFS;
+    out->nb_cif_bits = NB_CIF_BITS;
+    return DABGPU_OK;
+}
+
+int dabgpu_get_prs_reference(int mode, float *out, int nb_fft) {
+    if (!out || nb_fft != NB_FFT) return DABGPU_ERR_ARG;
+    if (mode != 1) return DABGPU_ERR_PROFILE;
+    static const float RE[4] = {1.f, 0.f, -1.f, 0.f}, IM[4] = {0.f, 1.f, 0.f, -1.f};
+    const std::vector<int8_t> q = make_prs_quarter_turns();
+    for (int b = 0; b < NB_FFT; b++) {
+        out[2 * b] = q[b] < 0 ? 0.f : RE[q[b]];
+        out[2 * b + 1] = q[b] < 0 ? 0.f : IM[q[b]];
+    }
+    return DABGPU_OK;
+}
+
+int dabgpu_get_mapper_reference(int32_t *out, int nb_data_carriers, int nb_fft) {
+    if (!out || nb_data_carriers != NB_CARRIERS || nb_fft != NB_FFT) return DABGPU_ERR_ARG;
+    const std::vector<int32_t> m = make_mapper();
+    if (int(m.size()) != NB_CARRIERS) return DABGPU_ERR_PROFILE;
+    std::memcpy(out, m.data(), sizeof(int32_t) * NB_CARRIERS);
+    return DABGPU_OK;
+}
+
+int dabgpu_create(const dabgpu_cfg *cfg, dabgpu_ctx **out) {
+    if (!cfg || !out) return DABGPU_ERR_ARG;
+    *out = nullptr;
+    if (cfg->transmission_mode != 1) return DABGPU_ERR_PROFILE;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return DABGPU_ERR_NODEVICE;
+    if (cfg->device < 0 || cfg->device >= ndev) return DABGPU_ERR_ARG;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return DABGPU_ERR_HIP;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return DABGPU_ERR_NODEVICE;
+    HIP_TRY(hipSetDevice(cfg->device));
+
+    dabgpu_ctx *ctx = new (std::nothrow) dabgpu_ctx();
+    if (!ctx) return DABGPU_ERR_NOMEM;
+    ctx->device = cfg->device;
+    ctx->max_frames = cfg->max_frames;
+    if (const char *g = std::getenv("DABGPU_OFDM_GROUP")) ctx->ofdm_group_override = std::atoi(g);
+    int rc = DABGPU_OK;
+    do {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { rc = DABGPU_ERR_HIP; break; }
+        std::vector<float2> tw(NB_FFT);
+        for (int m = 0; m < NB_FFT; m++) {
+            const double a = -2.0 * M_PI * double(m) / double(NB_FFT);
+            tw[m] = make_float2(float(std::cos(a)), float(std::sin(a)));
+        }
+        if ((rc = upload(&ctx->d_twiddle, tw))) break;
+        const std::vector<int32_t> mapper = make_mapper();
+        std::vector<uint16_t> bins(NB_CARRIERS);
+        for (int n = 0; n < NB_CARRIERS; n++) bins[n] = uint16_t(carrier_bin(mapper[n]));
+        if ((rc = upload(&ctx->d_bin_of_n, bins))) break;
+        ctx->fic.prof = make_fic_profile();
+        if (ctx->fic.prof.nsteps != NB_FIC_STEPS || ctx->fic.prof.n_punct != NB_FIC_GROUP_BITS) { rc = DABGPU_ERR_PROFILE; break; }
+        if ((rc = build_device_code(ctx->fic))) break;
+    } while (0);
+    if (rc) { dabgpu_destroy(ctx); return rc; }
+    *out = ctx;
+    return DABGPU_OK;
+}
+
+void dabgpu_destroy(dabgpu_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->d_twiddle) (void)hipFree(ctx->d_twiddle);
+    if (ctx->d_bin_of_n) (void)hipFree(ctx->d_bin_of_n);
+    free_device_code(ctx->fic);
+    for (auto &kv : ctx->codes) free_device_code(*kv.second);
+    for (void *p : ctx->d_stage) if (p) (void)hipFree(p);
+    for (Timer &t : ctx->timers) {
+        if (t.start) (void)hipEventDestroy(t.start);
+        if (t.stop) (void)hipEventDestroy(t.stop);
+    }
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int dabgpu_sync(dabgpu_ctx *ctx) {
+    if (!ctx) return DABGPU_ERR_ARG;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return DABGPU_OK;
+}
+
+void *dabgpu_stream(dabgpu_ctx *ctx) { return ctx ? reinterpret_cast<void *>(ctx->stream) : nullptr; }
+
+int dabgpu_set_timing(dabgpu_ctx *ctx, int enable) {
+    if (!ctx) return DABGPU_ERR_ARG;
+    ctx->timing = enable != 0;
+    return DABGPU_OK;
+}
+
+int dabgpu_last_kernel_ms(dabgpu_ctx *ctx, int which, float *ms) {
+    if (!ctx || !ms || which < 0 || which > 3) return DABGPU_ERR_ARG;
+    Timer &t = ctx->timers[which];
+    if (!t.valid) return DABGPU_ERR_ARG;
+    HIP_TRY(hipEventSynchronize(t.stop));
+    HIP_TRY(hipEventElapsedTime(ms, t.start, t.stop));
+    return DABGPU_OK;
+}
+
+// ---------------------------------------------------------------------------- OFDM
+static int check_iq(const void *d_iq, size_t frame_stride, int n_frames) {
+    if (!d_iq || n_frames < 0) return DABGPU_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(d_iq) & 15u) || (frame_stride & 1u)) return DABGPU_ERR_ARG;
+    if (n_frames > 1 && frame_stride < size_t(NB_FRAME_SYMBOLS) * NB_SYM_PERIOD) return DABGPU_ERR_ARG;
+    return DABGPU_OK;
+}
+
+int dabgpu_ofdm_demod_frames_dev(dabgpu_ctx *ctx, const void *d_iq, size_t frame_stride, int n_frames,
+                                 const float *d_freq_offset, int8_t *d_soft, void *d_cyc, void *d_dqpsk,
+                                 void *stream) {
+    if (!ctx || !d_soft) return DABGPU_ERR_ARG;
+    int rc = check_iq(d_iq, frame_stride, n_frames);
+    if (rc) return rc;
+    if (reinterpret_cast<uintptr_t>(d_soft) & 7u) return DABGPU_ERR_ARG;
+    if (n_frames == 0) return DABGPU_OK;
+    hipStream_t s = pick_stream(ctx, stream);
+    dabk::OfdmTables tab{ctx->d_twiddle, ctx->d_bin_of_n};
+    dabk::OfdmArgs a{};
+    a.iq = static_cast<const float2 *>(d_iq);
+    a.frame_stride = frame_stride;
+    a.freq_offset = d_freq_offset;
+    a.n_frames = n_frames;
+    a.soft = d_soft;
+    a.cyc = static_cast<float2 *>(d_cyc);
+    a.dqpsk = static_cast<float2 *>(d_dqpsk);
+    ScopedTimer tm(ctx, 0, s);
+    HIP_TRY(dabk::launch_ofdm_demod(tab, a, pick_group(ctx, n_frames, NB_DATA_SYMBOLS), s));
+    return DABGPU_OK;
+}
+
+int dabgpu_fft_symbols_dev(dabgpu_ctx *ctx, const void *d_iq, size_t frame_stride, int n_frames,
+                           const float *d_freq_offset, void *d_spectra, void *stream) {
+    if (!ctx || !d_spectra) return DABGPU_ERR_ARG;
+    int rc = check_iq(d_iq, frame_stride, n_frames);
+    if (rc) return rc;
+    if (n_frames == 0) return DABGPU_OK;
+    hipStream_t s = pick_stream(ctx, stream);
+    dabk::OfdmTables tab{ctx->d_twiddle, ctx->d_bin_of_n};
+    dabk::OfdmArgs a{};
+    a.iq = static_cast<const float2 *>(d_iq);
+    a.frame_stride = frame_stride;
+    a.freq_offset = d_freq_offset;
+    a.n_frames = n_frames;
+    a.spectra = static_cast<float2 *>(d_spectra);
+    ScopedTimer tm(ctx, 3, s);
+    HIP_TRY(dabk::launch_fft_symbols(tab, a, pick_group(ctx, n_frames, NB_FRAME_SYMBOLS), s));
+    return DABGPU_OK;
+}
+
+// host-pointer variants: stage through device buffers on the context stream
+static size_t iq_span(size_t frame_stride, int n_frames) {
+    return (size_t(n_frames - 1) * frame_stride + size_t(NB_FRAME_SYMBOLS) * NB_SYM_PERIOD) * sizeof(float2);
+}
+
+int dabgpu_ofdm_demod_frames(dabgpu_ctx *ctx, const float *iq, size_t frame_stride, int n_frames,
+                             const float *freq_offset, int8_t *soft, float *cyc, float *dqpsk) {
+    if (!ctx || !iq || !soft || n_frames < 0) return DABGPU_ERR_ARG;
+    if (n_frames == 0) return DABGPU_OK;
+    void *d_iq, *d_fo = nullptr, *d_soft, *d_cyc = nullptr, *d_dq = nullptr;
+    int rc;
+    const size_t nb_iq = iq_span(frame_stride, n_frames);
+    const size_t nb_soft = size_t(n_frames) * NB_FRAME_BITS;
+    const size_t nb_cyc = size_t(n_frames) * NB_FRAME_SYMBOLS * sizeof(float2);
+    const size_t nb_dq = size_t(n_frames) * NB_DATA_SYMBOLS * NB_CARRIERS * sizeof(float2);
+    if ((rc = stage(ctx, 0, nb_iq, &d_iq))) return rc;
+    if ((rc = stage(ctx, 1, nb_soft, &d_soft))) return rc;
+    if (freq_offset && (rc = stage(ctx, 2, sizeof(float) * n_frames, &d_fo))) return rc;
+    if (cyc && (rc = stage(ctx, 3, nb_cyc, &d_cyc))) return rc;
+    if (dqpsk && (rc = stage(ctx, 4, nb_dq, &d_dq))) return rc;
+    hipStream_t s = ctx->stream;
+    HIP_TRY(hipMemcpyAsync(d_iq, iq, nb_iq, hipMemcpyHostToDevice, s));
+    if (freq_offset) HIP_TRY(hipMemcpyAsync(d_fo, freq_offset, sizeof(float) * n_frames, hipMemcpyHostToDevice, s));
+    rc = dabgpu_ofdm_demod_frames_dev(ctx, d_iq, frame_stride, n_frames, static_cast<const float *>(d_fo),
+                                      static_cast<int8_t *>(d_soft), d_cyc, d_dq, s);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(soft, d_soft, nb_soft, hipMemcpyDeviceToHost, s));
+    if (cyc) HIP_TRY(hipMemcpyAsync(cyc, d_cyc, nb_cyc, hipMemcpyDeviceToHost, s));
+    if (dqpsk) HIP_TRY(hipMemcpyAsync(dqpsk, d_dq, nb_dq, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return DABGPU_OK;
+}
+
+int dabgpu_fft_symbols(dabgpu_ctx *ctx, const float *iq, size_t frame_stride, int n_frames,
+                       const float *freq_offset, float *spectra) {
+    if (!ctx || !iq || !spectra || n_frames < 0) return DABGPU_ERR_ARG;
+    if (n_frames == 0) return DABGPU_OK;
+    void *d_iq, *d_fo = nullptr, *d_sp;
+    int rc;
+    const size_t nb_iq = iq_span(frame_stride, n_frames);
+    const size_t nb_sp = size_t(n_frames) * NB_FRAME_SYMBOLS * NB_FFT * sizeof(float2);
+    if ((rc = stage(ctx, 0, nb_iq, &d_iq))) return rc;
+    if ((rc = stage(ctx, 4, nb_sp, &d_sp))) return rc;
+    if (freq_offset && (rc = stage(ctx, 2, sizeof(float) * n_frames, &d_fo))) return rc;
+    hipStream_t s = ctx->stream;
+    HIP_TRY(hipMemcpyAsync(d_iq, iq, nb_iq, hipMemcpyHostToDevice, s));
+    if (freq_offset) HIP_TRY(hipMemcpyAsync(d_fo, freq_offset, sizeof(float) * n_frames, hipMemcpyHostToDevice, s));
+    rc = dabgpu_fft_symbols_dev(ctx, d_iq, frame_stride, n_frames, static_cast<const float *>(d_fo), d_sp, s);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(spectra, d_sp, nb_sp, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return DABGPU_OK;
+}
+
+// ---------------------------------------------------------------------------- FIC
+int dabgpu_fic_decode_dev(dabgpu_ctx *ctx, const int8_t *d_soft, size_t soft_stride, int n_frames,
+                          uint8_t *d_fib, uint8_t *d_crc_ok, void *stream) {
+    if (!ctx || !d_soft || !d_fib || !d_crc_ok || n_frames < 0) return DABGPU_ERR_ARG;
+    if (n_frames > 1 && soft_stride < size_t(NB_FIC_BITS)) return DABGPU_ERR_ARG;
+    if (n_frames == 0) return DABGPU_OK;
+    hipStream_t s = pick_stream(ctx, stream);
+    ScopedTimer tm(ctx, 1, s);
+    HIP_TRY(dabk::launch_fic_decode(ctx->fic.tables(true), d_soft, soft_stride, n_frames, d_fib, d_crc_ok, s));
+    return DABGPU_OK;
+}
+
+int dabgpu_fic_decode(dabgpu_ctx *ctx, const int8_t *soft, size_t soft_stride, int n_frames, uint8_t *fib,
+                      uint8_t *crc_ok) {
+    if (!ctx || !soft || !fib || !crc_ok || n_frames < 0) return DABGPU_ERR_ARG;
+    if (n_frames == 0) return DABGPU_OK;
+    void *d_soft, *d_fib, *d_ok;
+    int rc;
+    const size_t nb_soft = size_t(n_frames - 1) * soft_stride + NB_FIC_BITS;
+    if ((rc = stage(ctx, 1, nb_soft, &d_soft))) return rc;
+    if ((rc = stage(ctx, 3, size_t(n_frames) * NB_FIBS * 32, &d_fib))) return rc;
+    if ((rc = stage(ctx, 2, size_t(n_frames) * NB_FIBS, &d_ok))) return rc;
+    hipStream_t s = ctx->stream;
+    HIP_TRY(hipMemcpyAsync(d_soft, soft, nb_soft, hipMemcpyHostToDevice, s));
+    rc = dabgpu_fic_decode_dev(ctx, static_cast<const int8_t *>(d_soft), soft_stride, n_frames,
+                               static_cast<uint8_t *>(d_fib), static_cast<uint8_t *>(d_ok), s);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(fib, d_fib, size_t(n_frames) * NB_FIBS * 32, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(crc_ok, d_ok, size_t(n_frames) * NB_FIBS, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return DABGPU_OK;
+}
+
+// ---------------------------------------------------------------------------- MSC
+static int subchannel_profile(const dabgpu_subchannel *sc, dab::PunctureProfile &prof) {
+    if (!sc) return DABGPU_ERR_ARG;
+    if (sc->is_uep) return DABGPU_ERR_PROFILE;
+    int size_cu = 0;
+    if (!make_eep_profile(sc->eep_type, sc->protection_level, sc->bitrate_kbps, prof, size_cu)) return DABGPU_ERR_PROFILE;
+    if (size_cu != sc->length) return DABGPU_ERR_PROFILE;
+    if (sc->start_address < 0 || sc->start_address + sc->length > 864) return DABGPU_ERR_ARG;
+    return DABGPU_OK;
+}
+
+int dabgpu_subchannel_bytes(const dabgpu_subchannel *sc) {
+    dab::PunctureProfile prof;
+    int rc = subchannel_profile(sc, prof);
+    if (rc) return rc;
+    return (prof.nsteps - 6) / 8;
+}
+
+int dabgpu_msc_decode_dev(dabgpu_ctx *ctx, const dabgpu_subchannel *sc, const int8_t *d_soft, size_t soft_stride,
+                          int n_streams, int frames_per_stream, const int8_t *d_history_in,
+                          int8_t *d_history_out, uint8_t *d_out, void *stream) {
+    if (!ctx || !d_soft || !d_out || n_streams < 0 || frames_per_stream < 0) return DABGPU_ERR_ARG;
+    if (d_history_in && d_history_in == d_history_out) return DABGPU_ERR_ARG;
+    if (soft_stride < size_t(NB_FRAME_BITS) && size_t(n_streams) * frames_per_stream > 1) return DABGPU_ERR_ARG;
+    dab::PunctureProfile prof;
+    int rc = subchannel_profile(sc, prof);
+    if (rc) return rc;
+    if (n_streams == 0 || frames_per_stream == 0) return DABGPU_OK;
+    if (dabk::viterbi_wave_lds_bytes(prof.nsteps) * 4 > 160 * 1024) return DABGPU_ERR_CAPACITY;
+    DeviceCode *dc = nullptr;
+    if ((rc = get_code(ctx, std::move(prof), &dc))) return rc;
+    hipStream_t s = pick_stream(ctx, stream);
+    dabk::MscArgs a{};
+    a.soft = d_soft;
+    a.soft_stride = soft_stride;
+    a.n_streams = n_streams;
+    a.frames_per_stream = frames_per_stream;
+    a.start_bit = sc->start_address * CU_BITS;
+    a.nbits = sc->length * CU_BITS;
+    a.hist_in = d_history_in;
+    a.hist_out = d_history_out;
+    a.out = d_out;
+    ScopedTimer tm(ctx, 2, s);
+    HIP_TRY(dabk::launch_msc_decode(dc->tables(true), a, s));
+    return DABGPU_OK;
+}
+
+int dabgpu_msc_decode(dabgpu_ctx *ctx, const dabgpu_subchannel *sc, const int8_t *soft, size_t soft_stride,
+                      int n_streams, int frames_per_stream, const int8_t *history_in, int8_t *history_out,
+                      uint8_t *out) {
+    if (!ctx || !soft || !out || n_streams < 0 || frames_per_stream < 0) return DABGPU_ERR_ARG;
+    const int nbytes = dabgpu_subchannel_bytes(sc);
+    if (nbytes < 0) return nbytes;
+    const size_t nframes = size_t(n_streams) * frames_per_stream;
+    if (nframes == 0) return DABGPU_OK;
+    const size_t nb_soft = (nframes - 1) * soft_stride + NB_FRAME_BITS;
+    const size_t nb_hist = size_t(n_streams) * 15 * sc->length * CU_BITS;
+    const size_t nb_out = nframes * NB_CIFS * nbytes;
+    void *d_soft, *d_hi = nullptr, *d_ho = nullptr, *d_out;
+    int rc;
+    if ((rc = stage(ctx, 1, nb_soft, &d_soft))) return rc;
+    if ((rc = stage(ctx, 3, nb_out, &d_out))) return rc;
+    if (history_in && (rc = stage(ctx, 4, nb_hist, &d_hi))) return rc;
+    if (history_out && (rc = stage(ctx, 5, nb_hist, &d_ho))) return rc;
+    hipStream_t s = ctx->stream;
+    HIP_TRY(hipMemcpyAsync(d_soft, soft, nb_soft, hipMemcpyHostToDevice, s));
+    if (history_in) HIP_TRY(hipMemcpyAsync(d_hi, history_in, nb_hist, hipMemcpyHostToDevice, s));
+    rc = dabgpu_msc_decode_dev(ctx, sc, static_cast<const int8_t *>(d_soft), soft_stride, n_streams,
+                               frames_per_stream, static_cast<const int8_t *>(d_hi), static_cast<int8_t *>(d_ho),
+                               static_cast<uint8_t *>(d_out), s);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, d_out, nb_out, hipMemcpyDeviceToHost, s));
+    if (history_out) HIP_TRY(hipMemcpyAsync(history_out, d_ho, nb_hist, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return DABGPU_OK;
+}
+
+// ---------------------------------------------------------------------------- plain Viterbi
+int dabgpu_viterbi_dev(dabgpu_ctx *ctx, const int8_t *d_punct, int n_codewords, const uint8_t *mask, int nsteps,
+                       uint8_t *d_out_bytes, void *stream) {
+    if (!ctx || !d_punct || !mask || !d_out_bytes || n_codewords < 0) return DABGPU_ERR_ARG;
+    if (nsteps < 14 || ((nsteps - 6) & 7)) return DABGPU_ERR_ARG;
+    if (dabk::viterbi_wave_lds_bytes(nsteps) * 4 > 160 * 1024) return DABGPU_ERR_CAPACITY;
+    dab::PunctureProfile prof;
+    prof.mask.assign(mask, mask + 4 * size_t(nsteps));
+    for (uint8_t &f : prof.mask) f = f ? 1 : 0;
+    finish_profile(prof);
+    if (n_codewords == 0) return DABGPU_OK;
+    DeviceCode *dc = nullptr;
+    int rc = get_code(ctx, std::move(prof), &dc);
+    if (rc) return rc;
+    hipStream_t s = pick_stream(ctx, stream);
+    HIP_TRY(dabk::launch_viterbi_plain(dc->tables(false), d_punct, n_codewords, d_out_bytes, s));
+    return DABGPU_OK;
+}
+
+int dabgpu_viterbi(dabgpu_ctx *ctx, const int8_t *punct, int n_codewords, const uint8_t *mask, int nsteps,
+                   uint8_t *out_bytes) {
+    if (!ctx || !punct || !mask || !out_bytes || n_codewords < 0) return DABGPU_ERR_ARG;
+    if (nsteps < 14 || ((nsteps - 6) & 7)) return DABGPU_ERR_ARG;
+    if (n_codewords == 0) return DABGPU_OK;
+    size_t n_punct = 0;
+    for (int i = 0; i < 4 * nsteps; i++) n_punct += mask[i] ? 1 : 0;
+    const size_t nb_in = size_t(n_codewords) * n_punct, nb_out = size_t(n_codewords) * ((nsteps - 6) / 8);
+    void *d_in, *d_out;
+    int rc;
+    if ((rc = stage(ctx, 1, nb_in ? nb_in : 1, &d_in))) return rc;
+    if ((rc = stage(ctx, 3, nb_out, &d_out))) return rc;
+    hipStream_t s = ctx->stream;
+    if (nb_in) HIP_TRY(hipMemcpyAsync(d_in, punct, nb_in, hipMemcpyHostToDevice, s));
+    rc = dabgpu_viterbi_dev(ctx, static_cast<const int8_t *>(d_in), n_codewords, mask, nsteps,
+                            static_cast<uint8_t *>(d_out), s);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out_bytes, d_out, nb_out, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return DABGPU_OK;
+}
+
+}  // extern "C"

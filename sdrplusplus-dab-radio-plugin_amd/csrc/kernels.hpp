@@ -1,0 +1,62 @@
+// kernels.hpp -- launch interfaces of the hand-written gfx950 kernels (internal to libdabgpu).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdint>
+
+namespace dabk {
+
+// ---- OFDM front end (ofdm_kernels.hip) -------------------------------------
+struct OfdmTables {
+    const float2 *twiddle;     // [2048] exp(-2*pi*i*m/2048)
+    const uint16_t *bin_of_n;  // [1536] FFT bin of data index n (mapper folded with carrier->bin)
+};
+
+struct OfdmArgs {
+    const float2 *iq;          // frame f at iq + f*frame_stride (first PRS sample)
+    size_t frame_stride;       // complex samples
+    const float *freq_offset;  // [n_frames] or nullptr
+    int n_frames;
+    int8_t *soft;              // [n_frames][230400]
+    float2 *cyc;               // [n_frames][76] or nullptr
+    float2 *dqpsk;             // [n_frames][75][1536] or nullptr
+    float2 *spectra;           // FFT-only mode: [n_frames][76][2048]
+};
+
+// fused A2..A6.  syms_per_group must divide 75.
+hipError_t launch_ofdm_demod(const OfdmTables &t, const OfdmArgs &a, int syms_per_group, hipStream_t s);
+// A2+A3 only. syms_per_group must divide 76.
+hipError_t launch_fft_symbols(const OfdmTables &t, const OfdmArgs &a, int syms_per_group, hipStream_t s);
+
+// ---- channel decoder (viterbi_kernels.hip) ---------------------------------
+struct CodeTables {
+    const uint16_t *mother_pos;  // [n_punct] mother-bit position of punctured bit i
+    int n_punct;
+    int nsteps;                  // trellis steps (info bits + 6)
+    const uint8_t *prbs_bytes;   // [(nsteps-6)/8] energy-dispersal bytes, or nullptr = no descramble
+};
+
+// A8..A11: FIC of n_frames frames.
+hipError_t launch_fic_decode(const CodeTables &c, const int8_t *soft, size_t soft_stride, int n_frames,
+                             uint8_t *fib, uint8_t *crc_ok, hipStream_t s);
+// A9 on contiguous punctured codewords.
+hipError_t launch_viterbi_plain(const CodeTables &c, const int8_t *punct, int n_codewords, uint8_t *out,
+                                hipStream_t s);
+// A12: one subchannel, time de-interleave fused into the fetch.
+struct MscArgs {
+    const int8_t *soft;
+    size_t soft_stride;
+    int n_streams;
+    int frames_per_stream;
+    int start_bit;             // start_address * 64
+    int nbits;                 // length * 64 (== n_punct)
+    const int8_t *hist_in;     // [n_streams][15][nbits] or nullptr
+    int8_t *hist_out;          // [n_streams][15][nbits] or nullptr
+    uint8_t *out;              // [n_streams][frames*4][(nsteps-6)/8]
+};
+hipError_t launch_msc_decode(const CodeTables &c, const MscArgs &a, hipStream_t s);
+
+// LDS bytes one codeword needs in the wave-per-codeword kernel
+inline size_t viterbi_wave_lds_bytes(int nsteps) { return size_t(nsteps) * 12 + 64; }
+
+}  // namespace dabk

@@ -1,0 +1,272 @@
+"""Thin ctypes binding of libdabgpu.so (the C ABI in include/dabgpu.h).
+
+Plumbing only: argument marshalling and error translation.  There is no Python or
+CPU implementation behind these calls -- if the HIP library is missing or no gfx950
+device is visible they raise.  Used by tests/, bench.py and __graft_entry__.py.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libdabgpu.so")
+
+NB_FFT = 2048
+NB_CP = 504
+NB_SYM = 2552
+NB_NULL = 2656
+NB_SYMBOLS = 76
+NB_CARRIERS = 1536
+NB_FRAME_BITS = 230400
+NB_FRAME_SAMPLES = 196608
+NB_FIC_BITS = 9216
+NB_CIF_BITS = 55296
+FRAME_USED_SAMPLES = NB_SYMBOLS * NB_SYM
+
+#: every symbol include/dabgpu.h declares (tests check the library exports all of them)
+EXPORTS = [
+    "dabgpu_abi_version", "dabgpu_strerror", "dabgpu_get_ofdm_params", "dabgpu_get_dab_params",
+    "dabgpu_get_prs_reference", "dabgpu_get_mapper_reference", "dabgpu_create", "dabgpu_destroy",
+    "dabgpu_sync", "dabgpu_stream", "dabgpu_ofdm_demod_frames_dev", "dabgpu_ofdm_demod_frames",
+    "dabgpu_fft_symbols_dev", "dabgpu_fft_symbols", "dabgpu_fic_decode_dev", "dabgpu_fic_decode",
+    "dabgpu_subchannel_bytes", "dabgpu_msc_decode_dev", "dabgpu_msc_decode", "dabgpu_viterbi_dev",
+    "dabgpu_viterbi", "dabgpu_set_timing", "dabgpu_last_kernel_ms",
+]
+
+
+class DabGpuError(RuntimeError):
+    def __init__(self, status, what):
+        self.status = status
+        super().__init__("%s failed: %s (%d)" % (what, strerror(status), status))
+
+
+class OfdmParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "nb_frame_symbols", "nb_symbol_period", "nb_null_period", "nb_fft", "nb_cyclic_prefix",
+        "nb_data_carriers", "freq_carrier_spacing", "nb_frame_samples")]
+
+
+class DabParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "nb_frame_bits", "nb_symbols", "nb_fic_symbols", "nb_msc_symbols", "nb_sym_bits", "nb_fic_bits",
+        "nb_msc_bits", "nb_fibs", "nb_cifs", "nb_fib_bits", "nb_fib_cif_bits", "nb_fibs_per_cif",
+        "nb_cif_bits")]
+
+
+class Cfg(C.Structure):
+    _fields_ = [("device", C.c_int32), ("max_frames", C.c_int32), ("transmission_mode", C.c_int32),
+                ("flags", C.c_int32)]
+
+
+class Subchannel(C.Structure):
+    _fields_ = [("start_address", C.c_int32), ("length", C.c_int32), ("is_uep", C.c_int32),
+                ("eep_type", C.c_int32), ("protection_level", C.c_int32), ("bitrate_kbps", C.c_int32)]
+
+
+_LIB = None
+
+
+def lib():
+    """Load libdabgpu.so (raises if it has not been built -- there is no fallback)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libdabgpu.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "or `make -C sdrplusplus-dab-radio-plugin_amd/csrc` (expected %s)" % LIB_PATH)
+        try:
+            # share the HIP runtime torch already loaded (same SONAME libamdhip64.so.7)
+            import torch  # noqa: F401
+        except Exception:
+            pass
+        L = C.CDLL(LIB_PATH)
+        L.dabgpu_strerror.restype = C.c_char_p
+        L.dabgpu_stream.restype = C.c_void_p
+        L.dabgpu_stream.argtypes = [C.c_void_p]
+        L.dabgpu_destroy.restype = None
+        L.dabgpu_destroy.argtypes = [C.c_void_p]
+        vp, sz, i = C.c_void_p, C.c_size_t, C.c_int
+        L.dabgpu_create.argtypes = [C.POINTER(Cfg), C.POINTER(vp)]
+        L.dabgpu_sync.argtypes = [vp]
+        L.dabgpu_ofdm_demod_frames_dev.argtypes = [vp, vp, sz, i, vp, vp, vp, vp, vp]
+        L.dabgpu_ofdm_demod_frames.argtypes = [vp, vp, sz, i, vp, vp, vp, vp]
+        L.dabgpu_fft_symbols_dev.argtypes = [vp, vp, sz, i, vp, vp, vp]
+        L.dabgpu_fft_symbols.argtypes = [vp, vp, sz, i, vp, vp]
+        L.dabgpu_fic_decode_dev.argtypes = [vp, vp, sz, i, vp, vp, vp]
+        L.dabgpu_fic_decode.argtypes = [vp, vp, sz, i, vp, vp]
+        L.dabgpu_subchannel_bytes.argtypes = [C.POINTER(Subchannel)]
+        L.dabgpu_msc_decode_dev.argtypes = [vp, C.POINTER(Subchannel), vp, sz, i, i, vp, vp, vp, vp]
+        L.dabgpu_msc_decode.argtypes = [vp, C.POINTER(Subchannel), vp, sz, i, i, vp, vp, vp]
+        L.dabgpu_viterbi_dev.argtypes = [vp, vp, i, vp, i, vp, vp]
+        L.dabgpu_viterbi.argtypes = [vp, vp, i, vp, i, vp]
+        L.dabgpu_set_timing.argtypes = [vp, i]
+        L.dabgpu_last_kernel_ms.argtypes = [vp, i, C.POINTER(C.c_float)]
+        L.dabgpu_get_prs_reference.argtypes = [i, vp, i]
+        L.dabgpu_get_mapper_reference.argtypes = [vp, i, i]
+        _LIB = L
+    return _LIB
+
+
+def strerror(status):
+    return lib().dabgpu_strerror(C.c_int(status)).decode()
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise DabGpuError(rc, what)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+# ------------------------------------------------------------------ tables (no GPU needed)
+def get_ofdm_params(mode=1):
+    p = OfdmParams()
+    _check(lib().dabgpu_get_ofdm_params(C.c_int(mode), C.byref(p)), "dabgpu_get_ofdm_params")
+    return p
+
+
+def get_dab_params(mode=1):
+    p = DabParams()
+    _check(lib().dabgpu_get_dab_params(C.c_int(mode), C.byref(p)), "dabgpu_get_dab_params")
+    return p
+
+
+def get_prs_reference(mode=1):
+    out = np.zeros(2 * NB_FFT, np.float32)
+    _check(lib().dabgpu_get_prs_reference(mode, _p(out), NB_FFT), "dabgpu_get_prs_reference")
+    return out.view(np.complex64)
+
+
+def get_mapper_reference():
+    out = np.zeros(NB_CARRIERS, np.int32)
+    _check(lib().dabgpu_get_mapper_reference(_p(out), NB_CARRIERS, NB_FFT), "dabgpu_get_mapper_reference")
+    return out
+
+
+def subchannel(start_address, bitrate_kbps, level=3, eep_type=0):
+    """EEP subchannel descriptor with the length implied by the profile."""
+    if eep_type == 0:
+        n = bitrate_kbps // 8
+        length = {1: 12 * n, 2: 8 * n, 3: 6 * n, 4: 4 * n}[level]
+    else:
+        n = bitrate_kbps // 32
+        length = {1: 27 * n, 2: 21 * n, 3: 18 * n, 4: 15 * n}[level]
+    return Subchannel(start_address, length, 0, eep_type, level, bitrate_kbps)
+
+
+# ------------------------------------------------------------------ context
+class Context:
+    """Owns a dabgpu_ctx.  Host-array methods copy in/out and synchronise; *_dev methods take
+    raw device addresses (e.g. torch.Tensor.data_ptr()) and a stream handle and only enqueue."""
+
+    def __init__(self, device=0, max_frames=64):
+        self._h = C.c_void_p()
+        cfg = Cfg(device, max_frames, 1, 0)
+        _check(lib().dabgpu_create(C.byref(cfg), C.byref(self._h)), "dabgpu_create")
+
+    def close(self):
+        if self._h:
+            lib().dabgpu_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def stream(self):
+        return lib().dabgpu_stream(self._h)
+
+    def sync(self):
+        _check(lib().dabgpu_sync(self._h), "dabgpu_sync")
+
+    def set_timing(self, on):
+        _check(lib().dabgpu_set_timing(self._h, 1 if on else 0), "dabgpu_set_timing")
+
+    def last_kernel_ms(self, which):
+        ms = C.c_float(0)
+        _check(lib().dabgpu_last_kernel_ms(self._h, which, C.byref(ms)), "dabgpu_last_kernel_ms")
+        return ms.value
+
+    # ---- host arrays
+    def ofdm_demod_frames(self, iq, freq_offset=None, want_cyc=False, want_dqpsk=False):
+        """iq: complex64 [n_frames][>=76*2552], row f starting at the first PRS sample."""
+        iq = np.ascontiguousarray(iq, np.complex64)
+        n_frames, stride = iq.shape
+        soft = np.zeros((n_frames, NB_FRAME_BITS), np.int8)
+        fo = None if freq_offset is None else np.ascontiguousarray(freq_offset, np.float32)
+        cyc = np.zeros((n_frames, NB_SYMBOLS), np.complex64) if want_cyc else None
+        dq = np.zeros((n_frames, NB_SYMBOLS - 1, NB_CARRIERS), np.complex64) if want_dqpsk else None
+        _check(lib().dabgpu_ofdm_demod_frames(self._h, _p(iq), stride, n_frames, _p(fo), _p(soft), _p(cyc), _p(dq)),
+               "dabgpu_ofdm_demod_frames")
+        return soft, cyc, dq
+
+    def fft_symbols(self, iq, freq_offset=None):
+        iq = np.ascontiguousarray(iq, np.complex64)
+        n_frames, stride = iq.shape
+        fo = None if freq_offset is None else np.ascontiguousarray(freq_offset, np.float32)
+        out = np.zeros((n_frames, NB_SYMBOLS, NB_FFT), np.complex64)
+        _check(lib().dabgpu_fft_symbols(self._h, _p(iq), stride, n_frames, _p(fo), _p(out)), "dabgpu_fft_symbols")
+        return out
+
+    def fic_decode(self, soft):
+        """soft: int8 [n_frames][>=9216]."""
+        soft = np.ascontiguousarray(soft, np.int8)
+        n_frames, stride = soft.shape
+        fib = np.zeros((n_frames, 12, 32), np.uint8)
+        ok = np.zeros((n_frames, 12), np.uint8)
+        _check(lib().dabgpu_fic_decode(self._h, _p(soft), stride, n_frames, _p(fib), _p(ok)), "dabgpu_fic_decode")
+        return fib, ok
+
+    def msc_decode(self, sc, soft, n_streams, history_in=None, want_history=False):
+        """soft: int8 [n_streams*frames_per_stream][230400]."""
+        soft = np.ascontiguousarray(soft, np.int8)
+        n_frames, stride = soft.shape
+        fps = n_frames // n_streams
+        nbytes = lib().dabgpu_subchannel_bytes(C.byref(sc))
+        _check(min(nbytes, 0), "dabgpu_subchannel_bytes")
+        out = np.zeros((n_streams, fps * 4, nbytes), np.uint8)
+        hi = None if history_in is None else np.ascontiguousarray(history_in, np.int8)
+        ho = np.zeros((n_streams, 15, sc.length * 64), np.int8) if want_history else None
+        _check(lib().dabgpu_msc_decode(self._h, C.byref(sc), _p(soft), stride, n_streams, fps, _p(hi), _p(ho), _p(out)),
+               "dabgpu_msc_decode")
+        return out, ho
+
+    def viterbi(self, punct, mask):
+        """punct: int8 [n_codewords][n_punct]; mask: uint8 [4*nsteps] -> bytes [n][(nsteps-6)/8]."""
+        punct = np.ascontiguousarray(punct, np.int8)
+        mask = np.ascontiguousarray(mask, np.uint8)
+        nsteps = mask.size // 4
+        n = punct.shape[0]
+        out = np.zeros((n, (nsteps - 6) // 8), np.uint8)
+        _check(lib().dabgpu_viterbi(self._h, _p(punct), n, _p(mask), nsteps, _p(out)), "dabgpu_viterbi")
+        return out
+
+    # ---- device pointers (ints), enqueue only
+    def ofdm_demod_frames_dev(self, d_iq, frame_stride, n_frames, d_freq_offset, d_soft, d_cyc=None, d_dqpsk=None,
+                              stream=None):
+        _check(lib().dabgpu_ofdm_demod_frames_dev(self._h, d_iq, frame_stride, n_frames, d_freq_offset, d_soft,
+                                                  d_cyc, d_dqpsk, stream), "dabgpu_ofdm_demod_frames_dev")
+
+    def fft_symbols_dev(self, d_iq, frame_stride, n_frames, d_freq_offset, d_spectra, stream=None):
+        _check(lib().dabgpu_fft_symbols_dev(self._h, d_iq, frame_stride, n_frames, d_freq_offset, d_spectra, stream),
+               "dabgpu_fft_symbols_dev")
+
+    def fic_decode_dev(self, d_soft, soft_stride, n_frames, d_fib, d_crc_ok, stream=None):
+        _check(lib().dabgpu_fic_decode_dev(self._h, d_soft, soft_stride, n_frames, d_fib, d_crc_ok, stream),
+               "dabgpu_fic_decode_dev")
+
+    def msc_decode_dev(self, sc, d_soft, soft_stride, n_streams, frames_per_stream, d_hist_in, d_hist_out, d_out,
+                       stream=None):
+        _check(lib().dabgpu_msc_decode_dev(self._h, C.byref(sc), d_soft, soft_stride, n_streams, frames_per_stream,
+                                           d_hist_in, d_hist_out, d_out, stream), "dabgpu_msc_decode_dev")
