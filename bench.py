@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""bench.py -- DAB Mode-I frames/s (OFDM front end + FIC Viterbi + one MSC subchannel).
+
+One step = one pass of the hot path over one batch of synthetic input that is already
+resident in HBM: `--ensembles` independent DAB ensembles per GPU x `--frames` consecutive
+transmission frames each (default 64 x 16 = 1024 frames, 1.6 GB of cf32 IQ).  Per step:
+  dabgpu_ofdm_demod_frames_dev -> dabgpu_fic_decode_dev -> dabgpu_msc_decode_dev
+all through the C ABI (include/dabgpu.h) on the current torch stream.  torch is plumbing:
+device buffers, stream, events, and torch.distributed (RCCL) for the barrier / max-reduce.
+
+Ensembles shard across GPUs with no data-path collective (weak scaling: 64 per rank).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "sdrplusplus-dab-radio-plugin_amd"))
+sys.path.insert(0, ROOT)
+
+# algorithmic HBM bytes per frame (DESIGN.md "Measurement"): the fused front end reads the
+# 76 symbols of 2552 cf32 samples once and writes 230400 int8 soft bits.
+A_OFDM = 76 * 2552 * 8 + 230400            # 1 782 016 B
+A_FFT = 76 * 2552 * 8 + 76 * 2048 * 8      # 2 796 800 B (unfused FFT stage)
+HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: 8 TB/s spec
+REALTIME_FPS = 1.0 / 0.096
+
+
+def make_streams(torch, dev, n_ens, n_frames, n_unique, rank, snr_db):
+    """[n_ens][n_frames][196608] cf32 on the device, plus ground truth for verification."""
+    from dabgpu import synth
+    ens = [synth.Ensemble(seed=0xDAB00000 + rank * 4096 + u, n_frames=4) for u in range(n_unique)]
+    base = torch.from_numpy(np.stack([e.iq() for e in ens])).to(dev)        # [U][4][196608]
+    g = torch.Generator(device=dev)
+    g.manual_seed(0xDAB0 + rank)
+    n = torch.arange(synth.NB_FRAME_SAMPLES * n_frames, device=dev, dtype=torch.float64)
+    iq = torch.empty((n_ens, n_frames, synth.NB_FRAME_SAMPLES), dtype=torch.complex64, device=dev)
+    cfo = (torch.rand(n_ens, generator=g, device=dev, dtype=torch.float64) * 0.8 - 0.4) / 2048.0
+    sigma = float(np.sqrt(0.5 * 10 ** (-snr_db / 10)))
+    for s in range(n_ens):
+        clean = base[s % n_unique][torch.arange(n_frames, device=dev) % 4].reshape(-1)
+        rot = torch.exp(2j * np.pi * cfo[s] * n).to(torch.complex64)
+        noise = torch.randn(clean.shape, generator=g, device=dev, dtype=torch.float32) + \
+            1j * torch.randn(clean.shape, generator=g, device=dev, dtype=torch.float32)
+        iq[s] = (clean * rot + sigma * noise).reshape(n_frames, -1)
+    fo = (-cfo).to(torch.float32).repeat_interleave(n_frames).contiguous()    # [n_ens*n_frames]
+    return iq, fo, ens
+
+
+def cpu_baseline(iq_host, fo_host, sc_len_bits, mask, nsteps, budget_s, threads):
+    """Time the CPU oracle ('port') on the same workload: OFDM demod + FIC + 4 MSC logical
+    frames per transmission frame.  Bounded sample, all host cores (one frame per task)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as O
+    O.lib()
+    n = iq_host.shape[0]
+
+    def one(i):
+        soft, _, _, _ = O.ofdm_demod_frame(iq_host[i], float(fo_host[i]))
+        O.fic_decode(soft)
+        cif = soft[O.NB_FIC_BITS:].reshape(4, O.NB_CIF_BITS)[:, :sc_len_bits]
+        ring = np.ascontiguousarray(np.tile(cif, (4, 1)))        # 16 CIFs of history-shaped input
+        for _ in range(4):
+            de = O.time_deinterleave(ring)
+            O.msc_decode_lf(de, mask, nsteps)
+        return 1
+
+    t0 = time.perf_counter()
+    one(0)
+    per = time.perf_counter() - t0
+    total = int(max(threads, min(n * 64, budget_s * threads / max(per, 1e-4))))
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(one, [i % n for i in range(total)]))
+    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    k1 = max(1, int(total / threads / 4))
+    for i in range(k1):
+        one(i % n)
+    dt1 = time.perf_counter() - t1
+    return {"value": total / dt, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": "%d frames (OFDM+FIC+64kbps EEP-3A MSC) of the bench input through oracle/dab_oracle.c, "
+                      "%d threads, %.1f s" % (total, threads, dt),
+            "single_core_value": k1 / dt1}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--ensembles", type=int, default=64, help="independent ensembles per GPU")
+    ap.add_argument("--frames", type=int, default=16, help="consecutive frames per ensemble per step")
+    ap.add_argument("--unique", type=int, default=8, help="distinct synthetic multiplexes generated on the host")
+    ap.add_argument("--snr", type=float, default=20.0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
+    ap.add_argument("--no-fft-stage", action="store_true", help="skip the unfused FFT-stage measurement")
+    args = ap.parse_args()
+
+    import torch
+    import dabgpu
+    from dabgpu import synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a gfx950 GPU (libdabgpu has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+
+    E, F = args.ensembles, args.frames
+    n_frames = E * F
+    iq, fo, ens = make_streams(torch, dev, E, F, min(args.unique, E), rank, args.snr)
+    soft = torch.empty((n_frames, dabgpu.NB_FRAME_BITS), dtype=torch.int8, device=dev)
+    fib = torch.zeros((n_frames, 12, 32), dtype=torch.uint8, device=dev)
+    crc = torch.zeros((n_frames, 12), dtype=torch.uint8, device=dev)
+    sc = dabgpu.subchannel(0, 64, level=3)
+    msc = torch.zeros((E, F * 4, 192), dtype=torch.uint8, device=dev)
+    hist = [torch.zeros((E, 15, sc.length * 64), dtype=torch.int8, device=dev) for _ in range(2)]
+    cyc = torch.zeros((n_frames, 76), dtype=torch.complex64, device=dev)
+
+    ctx = dabgpu.Context(device=local_rank, max_frames=n_frames)
+    torch.cuda.synchronize()
+    tstream = torch.cuda.Stream(device=dev)      # non-null handle: the C ABI treats NULL as "context stream"
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
+    d_iq = iq.data_ptr() + synth.NB_NULL * 8          # first PRS sample of frame 0
+    ofdm_ev = []
+
+    def step(k, timed):
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        ctx.ofdm_demod_frames_dev(d_iq, synth.NB_FRAME_SAMPLES, n_frames, fo.data_ptr(), soft.data_ptr(),
+                                  cyc.data_ptr(), None, stream)
+        if timed:
+            e1.record()
+            ofdm_ev.append((e0, e1))
+        ctx.fic_decode_dev(soft.data_ptr(), dabgpu.NB_FRAME_BITS, n_frames, fib.data_ptr(), crc.data_ptr(), stream)
+        ctx.msc_decode_dev(sc, soft.data_ptr(), dabgpu.NB_FRAME_BITS, E, F, hist[k & 1].data_ptr(),
+                           hist[(k & 1) ^ 1].data_ptr(), msc.data_ptr(), stream)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(k, False)
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(args.warmup + k, True)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    # ---- correctness of what was just timed (outside the timed region) ----
+    fib_h, crc_h, msc_h = fib.cpu().numpy(), crc.cpu().numpy(), msc.cpu().numpy()
+    fic_ok = bool(crc_h.all())
+    msc_ok = True
+    for s in range(E):
+        e = ens[s % len(ens)]
+        for f in range(F):
+            fic_ok &= bool((fib_h[s * F + f] == e.fibs[f % 4]).all())
+        # logical frame finished by CIF t was transmitted from CIF t-15 (cyclic 16-CIF multiplex);
+        # with warm history every entry is valid
+        for t in range(0 if args.warmup + args.steps >= 2 else 15, F * 4):
+            msc_ok &= bool((msc_h[s, t] == e.msc_bytes[(t - 15) % 16]).all())
+    from dabgpu.shard import reduce_report
+    elapsed, frames_total, (fic_ok, msc_ok) = reduce_report(dist, dev, elapsed, n_frames * args.steps,
+                                                            [fic_ok, msc_ok])
+
+    ofdm_ms = float(np.mean([a.elapsed_time(b) for a, b in ofdm_ev]))
+
+    if rank == 0:
+        value = frames_total / elapsed
+        achieved = A_OFDM * n_frames / (ofdm_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("frames_per_launch") == n_frames:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "DAB Mode-I frames/sec (OFDM+Viterbi)", "value": value, "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%d ensembles/GPU x %d frames/step, Mode-I OFDM + FIC Viterbi + one 64 kbps "
+                                   "EEP-3A MSC subchannel, IQ resident in HBM" % (E, F),
+                       "ensembles_per_gpu": E, "frames_per_step_per_gpu": n_frames, "snr_db": args.snr,
+                       "sharding": "independent ensembles per rank, no data-path collective"},
+            "x_realtime": value / REALTIME_FPS,
+            "fic_bit_exact": fic_ok, "msc_bit_exact": msc_ok,
+            "roofline": {"bound": "hbm", "kernel": "ofdm_kernel<fused>", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "avg_launch_ms": ofdm_ms, "frames_per_launch": n_frames,
+                         "algorithmic_bytes_per_frame": A_OFDM},
+        }
+        if not args.no_fft_stage:
+            spectra = torch.empty((n_frames, 76, 2048), dtype=torch.complex64, device=dev)
+            evs = []
+            for i in range(3 + 5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                ctx.fft_symbols_dev(d_iq, synth.NB_FRAME_SAMPLES, n_frames, fo.data_ptr(), spectra.data_ptr(), stream)
+                e1.record()
+                if i >= 3:
+                    evs.append((e0, e1))
+            torch.cuda.synchronize()
+            fft_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+            ach = A_FFT * n_frames / (fft_ms * 1e-3) / 1e9
+            out["roofline_fft_stage"] = {"bound": "hbm", "kernel": "ofdm_kernel<fft_only>", "achieved": ach,
+                                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                         "avg_launch_ms": fft_ms, "algorithmic_bytes_per_frame": A_FFT}
+            del spectra
+        if world == 1 and args.cpu_seconds > 0:
+            k = min(n_frames, 64)
+            iq_h = iq.reshape(n_frames, -1)[:k, synth.NB_NULL:].contiguous().cpu().numpy()
+            out["cpu_baseline"] = cpu_baseline(iq_h, fo[:k].cpu().numpy(), sc.length * 64, ens[0].mask,
+                                               64 * 24 + 6, args.cpu_seconds, os.cpu_count() or 1)
+        print(json.dumps(out))
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,7 +1,7 @@
 // dab_tables.hpp -- Mode-I constants and host-side table builders for libdabgpu.
 //
-// Product code (not the oracle): restated from ETSI EN 300 401 independently of
-// oracle/dab_oracle.c so that tests can cross-check the two.  Stands behind
+// Product code: restated from ETSI EN 300 401 independently of the CPU test oracle
+// so that tests can cross-check the two.  Stands behind
 // get_DAB_OFDM_params / get_dab_parameters / get_DAB_PRS_reference /
 // get_DAB_mapper_ref (/root/reference/src/radio_block.cpp:12-21).
 #pragma once

@@ -8,7 +8,7 @@
 // trellis state.  Path metrics live in a VGPR per lane, predecessor metrics arrive
 // by cross-lane permute, the 64 survivor decisions of a step are one __ballot word
 // kept in LDS together with the depunctured codeword; traceback runs from LDS.
-// Decisions are bit-identical to oracle_viterbi (exact integer correlation metric,
+// Decisions follow the exact integer correlation metric,
 // strict-greater tie-break, start state 0, end state 0).
 #include <algorithm>
 

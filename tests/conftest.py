@@ -1,0 +1,52 @@
+"""Shared fixtures.  `-m "not gpu"` covers the oracle, the synthetic transmitter, the
+host-side logic and that libdabgpu loads and exports the C ABI; `-m gpu` is parity proper
+(HIP kernels through the C ABI vs the oracle)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "sdrplusplus-dab-radio-plugin_amd"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950) device")
+
+
+@pytest.fixture(scope="session")
+def built():
+    """Make sure libdabgpu.so and the oracle exist (hipcc cross-compiles on CPU-only hosts)."""
+    import dabgpu
+    if not os.path.exists(dabgpu.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    from oracle import oracle as O
+    O.lib()
+    return True
+
+
+@pytest.fixture(scope="session")
+def ensemble():
+    from dabgpu import synth
+    return synth.Ensemble(seed=0xDAB0, n_frames=5)
+
+
+@pytest.fixture(scope="session")
+def ensemble_iq(ensemble):
+    return ensemble.iq()
+
+
+@pytest.fixture(scope="session")
+def ctx(built):
+    import dabgpu
+    c = dabgpu.Context(device=0, max_frames=64)
+    yield c
+    c.close()
+
+
+def golden_path(name):
+    return os.path.join(ROOT, "tests", "golden", name)

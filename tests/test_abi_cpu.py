@@ -1,0 +1,51 @@
+"""The C-ABI library loads on a GPU-less host, exports every symbol include/dabgpu.h
+declares, and refuses to compute without a gfx950 device (no CPU fallback)."""
+import os
+import re
+
+import pytest
+
+import dabgpu
+from conftest import ROOT
+
+
+def test_header_symbols_are_all_exported(built):
+    hdr = open(os.path.join(ROOT, "include", "dabgpu.h")).read()
+    declared = set(re.findall(r"\b(dabgpu_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(dabgpu.EXPORTS)
+    L = dabgpu.lib()
+    for sym in declared:
+        assert hasattr(L, sym), sym
+    assert L.dabgpu_abi_version() == 1
+
+
+def test_strerror_and_argument_errors(built):
+    assert dabgpu.strerror(0) == "ok"
+    assert "gfx950" in dabgpu.strerror(-4)
+    L = dabgpu.lib()
+    assert L.dabgpu_get_ofdm_params(1, None) == -1
+    assert L.dabgpu_create(None, None) == -1
+    sc = dabgpu.subchannel(0, 64, level=3)
+    assert L.dabgpu_subchannel_bytes(sc) == 192
+    bad = dabgpu.Subchannel(0, 47, 0, 0, 3, 64)           # length does not match the profile
+    assert L.dabgpu_subchannel_bytes(bad) == -5
+    assert L.dabgpu_subchannel_bytes(dabgpu.Subchannel(850, 48, 0, 0, 3, 64)) == -1   # beyond CU 863
+
+
+def test_no_cpu_fallback(built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(dabgpu.DabGpuError) as e:
+        dabgpu.Context(device=0)
+    assert e.value.status == -4
+
+
+def test_product_path_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "sdrplusplus-dab-radio-plugin_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp", "Makefile")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "dab_oracle" not in txt and "liboracle" not in txt, os.path.join(dirpath, f)
+                assert not re.search(r"^\s*(from|import)\s+oracle", txt, re.M), os.path.join(dirpath, f)

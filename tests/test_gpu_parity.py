@@ -1,0 +1,214 @@
+"""Parity proper: the HIP kernels through the C ABI (libdabgpu.so) against the CPU oracle
+on identical inputs.  Bars: bit-exact for FIC / MSC / Viterbi bytes and CRC flags; soft bits
+within 1 int8 LSB; cf32 intermediates within 1e-4 of the symbol's peak magnitude."""
+import numpy as np
+import pytest
+
+import dabgpu
+from conftest import golden_path
+from dabgpu import synth
+from oracle import oracle as O
+from golden.make_golden import PROFILES
+
+pytestmark = pytest.mark.gpu
+
+CF32_TOL = 1e-4          # relative to max |X| of the symbol
+SOFT_TOL = 1             # int8 LSB
+
+
+def _rx(ensemble_iq, snr, cfo, seed=11):
+    rng = np.random.default_rng(seed)
+    rx = synth.channel(ensemble_iq.ravel(), snr_db=snr, cfo=cfo, rng=rng).reshape(ensemble_iq.shape)
+    return np.ascontiguousarray(rx[:, synth.NB_NULL:])
+
+
+def test_context_and_device(ctx):
+    assert ctx.stream
+    ctx.sync()
+
+
+@pytest.mark.parametrize("cfo", [0.0, 0.37 / 2048, -5.2 / 2048])
+def test_fft_stage_matches_oracle_and_numpy(ctx, ensemble_iq, cfo):
+    frames = _rx(ensemble_iq, 25.0, cfo)[:2]
+    fo = np.full(2, -cfo, np.float32)
+    got = ctx.fft_symbols(frames, fo if cfo else None)
+    for f in range(2):
+        _, spec, _, _ = O.ofdm_demod_frame(frames[f], float(-cfo), want_spectra=True)
+        scale = np.abs(spec).max(axis=1, keepdims=True)
+        assert (np.abs(got[f] - spec) <= CF32_TOL * scale).all()
+    if cfo == 0.0:
+        sym = frames[0].reshape(76, 2552)[:, 504:].astype(np.complex128)
+        ref = np.fft.fft(sym, axis=1)
+        assert np.abs(got[0] - ref).max() <= CF32_TOL * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("snr,cfo", [(None, 0.0), (20.0, 0.41 / 2048), (8.0, -0.13 / 2048), (14.0, 7.3 / 2048)])
+def test_ofdm_soft_bits_within_one_lsb(ctx, ensemble, ensemble_iq, snr, cfo):
+    frames = _rx(ensemble_iq, snr, cfo)
+    fo = np.full(frames.shape[0], -cfo, np.float32)
+    soft, cyc, dq = ctx.ofdm_demod_frames(frames, fo, want_cyc=True, want_dqpsk=True)
+    for f in range(frames.shape[0]):
+        osoft, _, ocyc, odq = O.ofdm_demod_frame(frames[f], float(fo[f]), want_cyc=True, want_dqpsk=True)
+        delta = np.abs(soft[f].astype(np.int32) - osoft.astype(np.int32))
+        assert delta.max() <= SOFT_TOL
+        assert (delta != 0).mean() < 0.02
+        assert np.abs(cyc[f] - ocyc).max() <= 1e-3 * np.abs(ocyc).max()
+        scale = np.abs(odq).max(axis=1, keepdims=True)
+        assert (np.abs(dq[f] - odq) <= 2 * CF32_TOL * scale).all()
+        if snr is None:
+            assert ((soft[f] > 0).astype(np.uint8) == ensemble.frame_bits[f]).all()
+
+
+def test_ofdm_group_splits_agree(built, ensemble_iq, monkeypatch):
+    """The frame may be split over 1..75 workgroups; results must not depend on the split."""
+    frames = _rx(ensemble_iq, 12.0, 0.2 / 2048)[:2]
+    fo = np.full(2, -0.2 / 2048, np.float32)
+    outs = []
+    for g in ("75", "25", "15", "5", "3", "1"):
+        monkeypatch.setenv("DABGPU_OFDM_GROUP", g)
+        with dabgpu.Context(device=0) as c:
+            outs.append(c.ofdm_demod_frames(frames, fo, want_cyc=True))
+    for soft, cyc, _ in outs[1:]:
+        assert (soft == outs[0][0]).all()
+        assert np.array_equal(cyc, outs[0][1])
+
+
+def test_ofdm_empty_and_bad_arguments(ctx):
+    soft, _, _ = ctx.ofdm_demod_frames(np.zeros((0, 76 * 2552), np.complex64))
+    assert soft.shape == (0, 230400)
+    L = dabgpu.lib()
+    assert L.dabgpu_ofdm_demod_frames_dev(ctx._h, None, 196608, 1, None, None, None, None, None) == -1
+    assert L.dabgpu_fic_decode_dev(ctx._h, None, 230400, 1, None, None, None) == -1
+
+
+def test_ofdm_all_zero_input_gives_erasures(ctx):
+    soft, _, _ = ctx.ofdm_demod_frames(np.zeros((1, 76 * 2552), np.complex64))
+    assert not soft.any()                      # A == 0 -> erased soft bits, as the oracle defines
+    assert not O.ofdm_demod_frame(np.zeros(76 * 2552, np.complex64))[0].any()
+
+
+def test_fic_bit_exact_on_golden_and_noise(ctx):
+    d = np.load(golden_path("fic_cases.npz"))
+    fib, ok = ctx.fic_decode(d["soft"])
+    assert (fib == d["fib"]).all() and (ok == d["ok"]).all()
+    rng = np.random.default_rng(4)
+    noise = rng.integers(-127, 128, size=(9, 9216), dtype=np.int8)      # ragged count, pure noise
+    noise[7] = 0                                                          # all erasures: every ACS ties
+    noise[8] = rng.choice(np.array([-127, 127], np.int8), 9216)           # saturated
+    fib, ok = ctx.fic_decode(noise)
+    for f in range(9):
+        ofib, ook = O.fic_decode(noise[f])
+        assert (fib[f] == ofib).all() and (ok[f] == ook).all()
+
+
+def test_fic_strided_input_matches_contiguous(ctx, ensemble, ensemble_iq):
+    frames = _rx(ensemble_iq, 10.0, 0.0)
+    soft, _, _ = ctx.ofdm_demod_frames(frames)
+    fib, ok = ctx.fic_decode(soft)                        # stride 230400
+    fib2, ok2 = ctx.fic_decode(soft[:, :9216])            # stride 9216
+    assert (fib == fib2).all() and (ok == ok2).all()
+    assert ok.all() and (fib == ensemble.fibs).all()      # known answer: transmitted FIBs
+
+
+@pytest.mark.parametrize("opt,lvl,br", PROFILES)
+def test_viterbi_bit_exact_golden(ctx, opt, lvl, br):
+    d = np.load(golden_path("viterbi_cases.npz"))
+    mask = O.eep_puncture_mask(opt, lvl, br)[0]
+    key = "eep%d_%d_%d" % (opt, lvl, br)
+    got = ctx.viterbi(d[key + "_punct"], mask)
+    assert (got == d[key + "_bytes"]).all()
+
+
+def test_viterbi_bit_exact_random_batch(ctx):
+    rng = np.random.default_rng(8)
+    mask, kept, nsteps, _ = O.eep_puncture_mask(0, 3, 48)
+    cw = rng.integers(-127, 128, size=(37, kept), dtype=np.int8)          # 37: not a multiple of 4 waves
+    cw[::3] = (cw[::3] // 16) * 16                                        # coarse levels -> many exact ties
+    got = ctx.viterbi(cw, mask)
+    for i in range(cw.shape[0]):
+        assert (got[i] == np.packbits(O.viterbi(O.depuncture(cw[i], mask)))).all(), i
+
+
+def test_viterbi_unpunctured_mother_code(ctx):
+    rng = np.random.default_rng(6)
+    nsteps = 6 + 64
+    mask = np.ones(4 * nsteps, np.uint8)
+    bits = rng.integers(0, 2, size=(5, 64), dtype=np.uint8)
+    cw = np.stack([np.where(O.conv_encode(b) > 0, 127, -127) for b in bits]).astype(np.int8)
+    assert (ctx.viterbi(cw, mask) == np.packbits(bits, axis=1)).all()
+
+
+@pytest.mark.parametrize("opt,lvl,br,start", [(0, 3, 64, 0), (0, 2, 16, 5), (1, 4, 32, 849)])
+def test_msc_bit_exact_with_history(ctx, opt, lvl, br, start):
+    n_frames = 6
+    ens = [synth.Ensemble(seed=100 + s, n_frames=n_frames, option=opt, level=lvl, bitrate=br, start_cu=start)
+           for s in range(2)]
+    rng = np.random.default_rng(3)
+    soft = []
+    for e in ens:
+        rx = synth.channel(e.iq().ravel(), snr_db=9.0, rng=rng).reshape(n_frames, -1)
+        soft.append(ctx.ofdm_demod_frames(np.ascontiguousarray(rx[:, synth.NB_NULL:]))[0])
+    soft = np.concatenate(soft)                                          # [2*6][230400]
+    sc = dabgpu.subchannel(start, br, level=lvl, eep_type=opt)
+    nbits = sc.length * 64
+    # one call over all 6 frames per stream
+    out_all, hist_all = ctx.msc_decode(sc, soft, n_streams=2, want_history=True)
+    # the same as two calls of 3 frames with the history carried across
+    first = np.concatenate([soft[0:3], soft[6:9]])
+    second = np.concatenate([soft[3:6], soft[9:12]])
+    out_a, hist_a = ctx.msc_decode(sc, first, n_streams=2, want_history=True)
+    out_b, hist_b = ctx.msc_decode(sc, second, n_streams=2, history_in=hist_a, want_history=True)
+    assert (np.concatenate([out_a, out_b], axis=1) == out_all).all()
+    assert (hist_b == hist_all).all()
+    mask = O.eep_puncture_mask(opt, lvl, br)[0]
+    for s in range(2):
+        cifs = soft[6 * s:6 * s + 6, synth.NB_FIC_BITS:].reshape(24, synth.NB_CIF_BITS)[:, start * 64:start * 64 + nbits]
+        padded = np.concatenate([np.zeros((15, nbits), np.int8), cifs])
+        for t in range(24):
+            want = O.msc_decode_lf(O.time_deinterleave(padded[t:t + 16]), mask, br * 24 + 6)
+            assert (out_all[s, t] == want).all(), (s, t)
+            if t >= 15:
+                assert (want == ens[s].msc_bytes[t - 15]).all()          # known answer
+        assert (hist_all[s] == cifs[-15:]).all()
+
+
+def test_msc_rejects_bad_profiles(ctx):
+    soft = np.zeros((1, 230400), np.int8)
+    with pytest.raises(dabgpu.DabGpuError) as e:
+        ctx.msc_decode(dabgpu.Subchannel(0, 48, 1, 0, 3, 64), soft, 1)       # UEP not built yet
+    assert e.value.status == -5
+
+
+def test_full_size_batch_properties(ctx):
+    """64 ensembles x 4 frames (BASELINE config 4 shape): every FIB equals what was sent,
+    decode is idempotent, and permuting the frames permutes the outputs."""
+    E, F = 64, 4
+    ens = [synth.Ensemble(seed=500 + u, n_frames=F) for u in range(4)]
+    base = [e.iq() for e in ens]
+    rng = np.random.default_rng(1)
+    iq = np.empty((E * F, 76 * 2552), np.complex64)
+    fo = np.empty(E * F, np.float32)
+    for s in range(E):
+        cfo = (rng.random() * 0.8 - 0.4) / 2048
+        rx = synth.channel(base[s % 4].ravel(), snr_db=18.0, cfo=cfo, rng=rng).reshape(F, -1)
+        iq[s * F:(s + 1) * F] = rx[:, synth.NB_NULL:]
+        fo[s * F:(s + 1) * F] = -cfo
+    soft, _, _ = ctx.ofdm_demod_frames(iq, fo)
+    fib, ok = ctx.fic_decode(soft)
+    assert ok.all()
+    for s in range(E):
+        assert (fib[s * F:(s + 1) * F] == ens[s % 4].fibs).all()
+    soft2, _, _ = ctx.ofdm_demod_frames(iq, fo)
+    assert (soft2 == soft).all()                                           # idempotent / deterministic
+    perm = rng.permutation(E * F)
+    soft3, _, _ = ctx.ofdm_demod_frames(iq[perm], fo[perm])
+    assert (soft3 == soft[perm]).all()
+    sc = dabgpu.subchannel(0, 64, level=3)
+    msc, _ = ctx.msc_decode(sc, soft, n_streams=E)
+    for s in range(E):
+        assert (msc[s, 15] == ens[s % 4].msc_bytes[0]).all()
+
+
+def test_smoke_entry_point():
+    import __graft_entry__ as g
+    g.smoke()

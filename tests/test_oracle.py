@@ -1,0 +1,94 @@
+"""Known-answer tests of the CPU oracle against the independent numpy transmitter: the
+reference has no tests or vectors, so truth = transmitted bits."""
+import numpy as np
+import pytest
+
+from dabgpu import synth
+from oracle import oracle as O
+
+
+def test_fft_matches_numpy():
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal(2048) + 1j * rng.standard_normal(2048)).astype(np.complex64)
+    ref = np.fft.fft(x.astype(np.complex128))
+    got = O.fft2048(x)
+    assert np.abs(got - ref).max() <= 2e-6 * np.abs(ref).max() * 11     # ~log2(N) ulp growth
+    e = np.zeros(2048, np.complex64)
+    e[1] = 1
+    assert np.allclose(O.fft2048(e), np.exp(-2j * np.pi * np.arange(2048) / 2048), atol=1e-6)
+
+
+@pytest.mark.parametrize("snr,cfo", [(None, 0.0), (20.0, 0.37 / 2048), (9.0, -0.21 / 2048), (15.0, 3.25 / 2048)])
+def test_frame_roundtrip(ensemble, ensemble_iq, snr, cfo):
+    rng = np.random.default_rng(5)
+    rx = synth.channel(ensemble_iq.ravel(), snr_db=snr, cfo=cfo, rng=rng).reshape(ensemble_iq.shape)
+    for f in range(2):
+        soft, _, cyc, dq = O.ofdm_demod_frame(rx[f, synth.NB_NULL:], -cfo, want_cyc=True, want_dqpsk=True)
+        fib, ok = O.fic_decode(soft)
+        assert ok.all() and (fib == ensemble.fibs[f]).all()
+        if snr is None:
+            assert ((soft > 0).astype(np.uint8) == ensemble.frame_bits[f]).all()
+            assert np.abs(soft).max() == 127
+            # residual cyclic phase ~ 0 once the offset is corrected
+            assert np.abs(np.angle(cyc)).max() < 1e-3
+        assert np.abs(soft.astype(int)).max() <= 127
+
+
+def test_cyclic_prefix_correlation_measures_fine_offset(ensemble_iq):
+    cfo = 0.2 / 2048          # 0.2 carrier spacings, uncorrected
+    rx = synth.channel(ensemble_iq[0], cfo=cfo)
+    _, _, cyc, _ = O.ofdm_demod_frame(rx[synth.NB_NULL:], 0.0, want_cyc=True)
+    est = np.angle(cyc).mean() / (2 * np.pi * 2048)
+    assert abs(est - cfo) < 0.01 / 2048
+
+
+def test_uncorrected_integer_offset_breaks_and_correction_fixes(ensemble, ensemble_iq):
+    cfo = 2.0 / 2048
+    rx = synth.channel(ensemble_iq[0], cfo=cfo)
+    soft_bad, _, _, _ = O.ofdm_demod_frame(rx[synth.NB_NULL:], 0.0)
+    assert not O.fic_decode(soft_bad)[1].all()
+    soft, _, _, _ = O.ofdm_demod_frame(rx[synth.NB_NULL:], -cfo)
+    assert O.fic_decode(soft)[1].all()
+
+
+def test_msc_roundtrip_through_time_deinterleaver(ensemble, ensemble_iq):
+    rng = np.random.default_rng(9)
+    rx = synth.channel(ensemble_iq.ravel(), snr_db=12.0, rng=rng).reshape(ensemble_iq.shape)
+    softs = np.stack([O.ofdm_demod_frame(rx[f, synth.NB_NULL:])[0] for f in range(5)])
+    cifs = softs[:, synth.NB_FIC_BITS:].reshape(20, synth.NB_CIF_BITS)[:, :ensemble.size_cu * 64]
+    for t in range(15, 20):
+        de = O.time_deinterleave(cifs[t - 15:t + 1])
+        assert (O.msc_decode_lf(de, ensemble.mask, 64 * 24 + 6) == ensemble.msc_bytes[t - 15]).all()
+
+
+@pytest.mark.parametrize("option,level,bitrate", [(0, 1, 8), (0, 2, 8), (0, 2, 16), (0, 4, 8), (0, 3, 128), (1, 1, 32), (1, 4, 64)])
+def test_viterbi_decodes_every_profile_family(option, level, bitrate):
+    rng = np.random.default_rng(bitrate + level)
+    mask, kept, nsteps, _ = O.eep_puncture_mask(option, level, bitrate)
+    bits = rng.integers(0, 2, nsteps - 6, dtype=np.uint8)
+    tx = O.conv_encode(bits)[mask.astype(bool)]
+    soft = np.where(tx > 0, 127, -127).astype(np.int8)
+    assert (O.viterbi(O.depuncture(soft, mask)) == bits).all()
+    # a few well-separated erasures and flips must be corrected at these rates
+    soft2 = soft.copy()
+    idx = np.arange(20, kept - 20, max(kept // 8, 97))
+    soft2[idx] = -soft2[idx]
+    if level <= 3:
+        assert (O.viterbi(O.depuncture(soft2, mask)) == bits).all()
+
+
+def test_viterbi_degenerate_inputs_are_deterministic():
+    z = np.zeros(4 * 30, np.int8)
+    assert not O.viterbi(z).any()                         # all ties -> older-bit-0 survivor -> zeros
+    rng = np.random.default_rng(2)
+    g = rng.integers(-127, 128, 4 * 774, dtype=np.int8)
+    assert (O.viterbi(g) == O.viterbi(g.copy())).all()
+
+
+def test_time_interleaver_is_inverse_of_deinterleaver():
+    rng = np.random.default_rng(1)
+    coded = rng.integers(-127, 128, size=(32, 128)).astype(np.int8)
+    tx = synth.time_interleave(coded, cyclic=True)
+    for r in range(32):
+        rows = np.stack([tx[(r + k) % 32] for k in range(16)])
+        assert (O.time_deinterleave(rows) == coded[r]).all()
