@@ -11,6 +11,7 @@
 // Decisions follow the exact integer correlation metric,
 // strict-greater tie-break, start state 0, end state 0).
 #include <algorithm>
+#include <cstdlib>
 
 #include "kernels.hpp"
 #include "dab_tables.hpp"
@@ -25,6 +26,16 @@ constexpr int WAVES_PER_WG = 4;
 constexpr int WGV = 64 * WAVES_PER_WG;
 
 __device__ __forceinline__ int parity32(unsigned x) { return __popc(x) & 1; }
+
+// CRC-16/CCITT (x^16+x^12+x^5+1), one byte per call, table-free byte-wise form
+__device__ __forceinline__ unsigned crc16_byte(unsigned crc, unsigned byte) {
+    crc = ((crc >> 8) | (crc << 8)) & 0xFFFFu;
+    crc ^= byte;
+    crc ^= (crc & 0xFFu) >> 4;
+    crc ^= (crc << 12) & 0xFFFFu;
+    crc ^= ((crc & 0xFFu) << 5) & 0xFFFFu;
+    return crc;
+}
 
 // ---- where a codeword's punctured soft bits come from -----------------------
 struct FetchFic {
@@ -139,16 +150,209 @@ __global__ __launch_bounds__(WGV) void viterbi_wave_kernel(Fetch fetch, CodeTabl
         if (lane < 3) {
             const uint8_t *p = bytes + 32 * lane;
             unsigned crc = 0xFFFFu;
-            for (int i = 0; i < 30; i++) {
-                crc ^= unsigned(p[i]) << 8;
-#pragma unroll
-                for (int b = 0; b < 8; b++) crc = (crc & 0x8000u) ? ((crc << 1) ^ 0x1021u) : (crc << 1);
-                crc &= 0xFFFFu;
-            }
+            for (int i = 0; i < 30; i++) crc = crc16_byte(crc, p[i]);
             crc ^= 0xFFFFu;
             if (active) crc_ok[size_t(cw) * 3 + lane] = uint8_t(crc == ((unsigned(p[30]) << 8) | p[31]));
         }
     }
+}
+
+
+// ============================================================================
+// Kernel 2 ("rot" variant): same decoder, restructured around the dependency chain.
+//
+// Lane l holds trellis state rotl6(l, t mod 6) at step t.  With that layout the two
+// predecessors of the state a lane will hold next are the lane itself and the lane
+// differing in ONE bit position q = (5 - t) mod 6, so the ACS butterfly is a fixed
+// XOR exchange: DPP quad_perm / row_half_mirror / row_ror for 1,2,4,8 and
+// v_permlane16/32_swap for 16,32 -- all VALU latency, no LDS crossbar.  Branch
+// metrics are one v_dot4_i32_i8 of a per-lane sign vector with the (wave-uniform)
+// soft word fetched by v_readlane.  Each lane shifts its own survivor bit into a
+// register and spills one dword per 32 steps; traceback runs on the scalar unit in
+// the lane domain (the state update is "replace bit q of the lane index").
+// Requires nsteps = 96k + 6, which every DAB codeword satisfies (FIC 768+6,
+// EEP 192n+6); other lengths use kernel 1.
+// ============================================================================
+template <int XORMASK>
+__device__ __forceinline__ int lane_xchg(int m, int lane) {
+#ifdef DABGPU_VIT_SAFE_XCHG
+    return __shfl_xor(m, XORMASK);
+#else
+    if constexpr (XORMASK == 1) {
+        return __builtin_amdgcn_update_dpp(0, m, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+    } else if constexpr (XORMASK == 2) {
+        return __builtin_amdgcn_update_dpp(0, m, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    } else if constexpr (XORMASK == 4) {
+        const int h = __builtin_amdgcn_update_dpp(0, m, 0x141, 0xF, 0xF, false);   // row_half_mirror: i ^ 7
+        return __builtin_amdgcn_update_dpp(0, h, 0x1B, 0xF, 0xF, false);           // quad_perm [3,2,1,0]: i ^ 3
+    } else if constexpr (XORMASK == 8) {
+        return __builtin_amdgcn_update_dpp(0, m, 0x128, 0xF, 0xF, false);  // row_ror:8
+    } else if constexpr (XORMASK == 16) {
+        typedef unsigned u2 __attribute__((ext_vector_type(2)));
+        const u2 r = __builtin_amdgcn_permlane16_swap(unsigned(m), unsigned(m), false, false);
+        return (lane & 16) ? int(r.x) : int(r.y);
+    } else {
+        typedef unsigned u2 __attribute__((ext_vector_type(2)));
+        const u2 r = __builtin_amdgcn_permlane32_swap(unsigned(m), unsigned(m), false, false);
+        return (lane & 32) ? int(r.x) : int(r.y);
+    }
+#endif
+}
+
+struct RotTables {
+    int tab_cs[6];   // int8x4 signs giving  sigma * c   (sigma = -1 where the lane is the older-bit-1 predecessor)
+    int tab_c2[6];   // int8x4 signs giving  -2 * c
+    int sigma[6];
+};
+
+__device__ __forceinline__ int pack_i8x4(int a, int b, int c, int d) {
+    return (a & 0xFF) | ((b & 0xFF) << 8) | ((c & 0xFF) << 16) | ((d & 0xFF) << 24);
+}
+
+// one trellis step at phase PH (= t mod 6); w = the step's four soft bits (wave-uniform)
+template <int PH>
+__device__ __forceinline__ void rot_step(const RotTables &T, int lane, int w, int &metric, unsigned &dec) {
+    constexpr int Q = 5 - PH;
+    const int cs = __builtin_amdgcn_sdot4(T.tab_cs[PH], w, 0, false);
+    const int c2 = __builtin_amdgcn_sdot4(T.tab_c2[PH], w, 0, false);
+    const int other = lane_xchg<(1 << Q)>(metric, lane);
+    const int x = metric + cs;
+    const int y = other - cs;
+    const int g = __mul24(T.sigma[PH], other - metric) + c2;   // candidate(older bit 1) - candidate(older bit 0)
+    metric = max(x, y);
+    dec = (dec << 1) | (g > 0 ? 1u : 0u);
+}
+
+template <class Fetch, Tail TAIL>
+__global__ __launch_bounds__(WGV) void viterbi_rot_kernel(Fetch fetch, CodeTables code, int n_codewords,
+                                                          uint8_t *out, uint8_t *crc_ok, int lds_per_wave) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int cw_raw = blockIdx.x * WAVES_PER_WG + wave;
+    const bool active = cw_raw < n_codewords;
+    const int cw = active ? cw_raw : n_codewords - 1;
+    const int nsteps = code.nsteps;
+    const int nchunks = (nsteps - 6) / 96;
+
+    int8_t *mother = reinterpret_cast<int8_t *>(smem + size_t(wave) * lds_per_wave);
+    const int dec_off = (4 * nsteps + 255) & ~255;
+    unsigned *W = reinterpret_cast<unsigned *>(mother + dec_off);           // [ngroups][64]
+    int *m4 = reinterpret_cast<int *>(mother);
+
+    // ---- A8: depuncture into LDS ----
+    for (int i = lane; i < dec_off / 4; i += 64) m4[i] = 0;
+    __syncthreads();
+    for (int i = lane; i < code.n_punct; i += 64) mother[code.mother_pos[i]] = fetch(cw, i);
+    __syncthreads();
+
+    // ---- per-lane sign tables for the six layout phases ----
+    RotTables T;
+#pragma unroll
+    for (int ph = 0; ph < 6; ph++) {
+        const int rot = (ph + 1) % 6;                                       // state held AFTER the step
+        const int n = ((lane << rot) | (lane >> (6 - rot))) & 63;
+        const int s0 = parity32(n & 109) ? 1 : -1, s1 = parity32(n & 79) ? 1 : -1, s2 = parity32(n & 83) ? 1 : -1;
+        const int sg = ((lane >> (5 - ph)) & 1) ? -1 : 1;
+        T.sigma[ph] = sg;
+        T.tab_cs[ph] = pack_i8x4(sg * s0, sg * s1, sg * s2, sg * s0);
+        T.tab_c2[ph] = pack_i8x4(-2 * s0, -2 * s1, -2 * s2, -2 * s0);
+    }
+
+    // ---- A9 forward pass ----
+    int metric = (lane == 0) ? 0 : -VITERBI_INIT_PENALTY;
+    unsigned dec = 0;
+    int cw0 = m4[lane], cw1 = m4[64 + (lane & 31)];
+    for (int c = 0; c < nchunks; c++) {
+        const int a0 = cw0, a1 = cw1;
+        const int tn = (c + 1) * 96;
+        cw0 = m4[tn + lane];                 // prefetch (the last one reads into W: harmless, unused)
+        cw1 = m4[tn + 64 + (lane & 31)];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+#define DAB_ROT_STEP(PH)                                                                         \
+    {                                                                                            \
+        const int j = 6 * i + PH;                                                                \
+        const int w = __builtin_amdgcn_readlane(j < 64 ? a0 : a1, j & 63);                       \
+        rot_step<PH>(T, lane, w, metric, dec);                                                   \
+        if ((j & 31) == 31) W[(c * 3 + (j >> 5)) * 64 + lane] = dec;                             \
+    }
+            DAB_ROT_STEP(0) DAB_ROT_STEP(1) DAB_ROT_STEP(2) DAB_ROT_STEP(3) DAB_ROT_STEP(4) DAB_ROT_STEP(5)
+#undef DAB_ROT_STEP
+        }
+    }
+    {   // the six tail steps (zero tail bits): one more phase cycle
+        dec = 0;
+        const int a0 = cw0;
+        rot_step<0>(T, lane, __builtin_amdgcn_readlane(a0, 0), metric, dec);
+        rot_step<1>(T, lane, __builtin_amdgcn_readlane(a0, 1), metric, dec);
+        rot_step<2>(T, lane, __builtin_amdgcn_readlane(a0, 2), metric, dec);
+        rot_step<3>(T, lane, __builtin_amdgcn_readlane(a0, 3), metric, dec);
+        rot_step<4>(T, lane, __builtin_amdgcn_readlane(a0, 4), metric, dec);
+        rot_step<5>(T, lane, __builtin_amdgcn_readlane(a0, 5), metric, dec);
+        W[nchunks * 3 * 64 + lane] = dec;    // bit 5 = first tail step ... bit 0 = last
+    }
+    __syncthreads();
+
+    // ---- traceback in the lane domain, on the scalar unit ----
+    // end state 0 sits in lane 0 in every layout; going back over step t replaces bit q_t of the lane
+    // index by the survivor bit, and the bit it replaces is the decoded input bit of step t.
+    unsigned *outw = reinterpret_cast<unsigned *>(mother);                   // [nchunks*3] words, MSB = earliest bit
+    int l = 0;
+    {
+        const unsigned wv = W[nchunks * 3 * 64 + lane];
+#pragma unroll
+        for (int r = 5; r >= 0; r--) {
+            const int q = 5 - r;                                             // phase of tail step r is r
+            const unsigned sw = unsigned(__builtin_amdgcn_readlane(int(wv), l));
+            const unsigned h = (sw >> (5 - r)) & 1u;
+            l = (l & ~(1 << q)) | int(h << q);
+        }
+    }
+    for (int c = nchunks - 1; c >= 0; c--) {
+#pragma unroll
+        for (int gg = 2; gg >= 0; gg--) {
+            const unsigned wv = W[(c * 3 + gg) * 64 + lane];
+            unsigned word = 0;
+#pragma unroll
+            for (int r = 31; r >= 0; r--) {
+                const int q = 5 - ((32 * gg + r) % 6);
+                const unsigned sw = unsigned(__builtin_amdgcn_readlane(int(wv), l));
+                const unsigned h = (sw >> (31 - r)) & 1u;
+                word |= unsigned((l >> q) & 1) << (31 - r);
+                l = (l & ~(1 << q)) | int(h << q);
+            }
+            if (lane == 0) outw[c * 3 + gg] = word;
+        }
+    }
+    __syncthreads();
+
+    // ---- A10: bytes out (big-endian within each word) + energy dispersal ----
+    const int nbytes = (nsteps - 6) >> 3;
+    uint8_t *bytes = reinterpret_cast<uint8_t *>(W);
+    uint8_t *o = out + size_t(cw) * nbytes;
+    for (int k = lane; k < nbytes; k += 64) {
+        unsigned v = (outw[k >> 2] >> (24 - 8 * (k & 3))) & 0xFFu;
+        if (code.prbs_bytes) v ^= code.prbs_bytes[k];
+        bytes[k] = uint8_t(v);
+        if (active) o[k] = uint8_t(v);
+    }
+    if (TAIL == Tail::kFic) {
+        __syncthreads();
+        if (lane < 3) {
+            const uint8_t *p = bytes + 32 * lane;
+            unsigned crc = 0xFFFFu;
+            for (int i = 0; i < 30; i++) crc = crc16_byte(crc, p[i]);
+            crc ^= 0xFFFFu;
+            if (active) crc_ok[size_t(cw) * 3 + lane] = uint8_t(crc == ((unsigned(p[30]) << 8) | p[31]));
+        }
+    }
+}
+
+inline size_t viterbi_rot_lds_bytes(int nsteps) {
+    const size_t mother = (size_t(4) * nsteps + 255) & ~size_t(255);
+    const size_t groups = size_t((nsteps - 6) / 32 + 1);
+    return mother + groups * 256 + 512;     // +512: the prefetch past the last chunk stays inside the wave's slab
 }
 
 // history ring update: hist_out[s][h] = CIF (4F - 15 + h), h = 0..14
@@ -176,17 +380,26 @@ template <class Fetch, Tail TAIL>
 hipError_t launch_wave(Fetch f, const CodeTables &c, int n_codewords, uint8_t *out, uint8_t *crc_ok,
                        hipStream_t s) {
     if (n_codewords <= 0) return hipSuccess;
-    const int lds_per_wave = int((viterbi_wave_lds_bytes(c.nsteps) + 15) & ~size_t(15));
+    static const bool force_v0 = std::getenv("DABGPU_VITERBI_V0") != nullptr;
+    const bool rot = !force_v0 && c.nsteps >= 102 && (c.nsteps - 6) % 96 == 0 &&
+                     viterbi_rot_lds_bytes(c.nsteps) * WAVES_PER_WG <= 160 * 1024;
+    const size_t per_wave = rot ? viterbi_rot_lds_bytes(c.nsteps) : viterbi_wave_lds_bytes(c.nsteps);
+    const int lds_per_wave = int((per_wave + 255) & ~size_t(255));
     const size_t lds = size_t(lds_per_wave) * WAVES_PER_WG;
-    auto kern = viterbi_wave_kernel<Fetch, TAIL>;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
+    const void *kern = rot ? reinterpret_cast<const void *>(viterbi_rot_kernel<Fetch, TAIL>)
+                           : reinterpret_cast<const void *>(viterbi_wave_kernel<Fetch, TAIL>);
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
         if (e != hipSuccess) return e;
     }
     const unsigned grid = unsigned((n_codewords + WAVES_PER_WG - 1) / WAVES_PER_WG);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WGV), lds, s, f, c, n_codewords, out, crc_ok, lds_per_wave);
+    if (rot)
+        hipLaunchKernelGGL((viterbi_rot_kernel<Fetch, TAIL>), dim3(grid), dim3(WGV), lds, s, f, c, n_codewords, out,
+                           crc_ok, lds_per_wave);
+    else
+        hipLaunchKernelGGL((viterbi_wave_kernel<Fetch, TAIL>), dim3(grid), dim3(WGV), lds, s, f, c, n_codewords, out,
+                           crc_ok, lds_per_wave);
     return hipGetLastError();
 }
 
