@@ -11,7 +11,10 @@ import sys
 def short(name):
     name = name.replace("(anonymous namespace)::", "")
     name = re.sub(r"^void ", "", name)
-    name = re.sub(r"\((dabk::[A-Za-z]+, )*.*\)$", "", name)
+    m = re.match(r"(dabk::\w+)(<.*>)?\(", name)
+    if m:
+        targs = (m.group(2) or "").replace("dabk::", "").replace("(Tail)", "Tail=")
+        return m.group(1) + targs
     return name
 
 
