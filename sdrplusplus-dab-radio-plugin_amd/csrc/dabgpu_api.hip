@@ -43,6 +43,7 @@ struct dabgpu_ctx {
     hipStream_t stream = nullptr;
     float2 *d_twiddle = nullptr;
     uint16_t *d_bin_of_n = nullptr;
+    uint16_t *d_n_of_vj = nullptr;
     DeviceCode fic;
     std::map<std::vector<uint8_t>, std::unique_ptr<DeviceCode>> codes;   // keyed by puncture mask
     // staging for the host-pointer entry points
@@ -252,6 +253,21 @@ int dabgpu_create(const dabgpu_cfg *cfg, dabgpu_ctx **out) {
         std::vector<uint16_t> bins(NB_CARRIERS);
         for (int n = 0; n < NB_CARRIERS; n++) bins[n] = uint16_t(carrier_bin(mapper[n]));
         if ((rc = upload(&ctx->d_bin_of_n, bins))) break;
+        // wave kernel: lane v ends each symbol holding bins v + 64*m; carrier register j <-> m = j (j<12) or j+8;
+        // lane 0 register 0 holds bin 768 instead of DC
+        std::vector<int> n_of_bin(NB_FFT, -1);
+        for (int n = 0; n < NB_CARRIERS; n++) n_of_bin[bins[n]] = n;
+        std::vector<uint16_t> nvj(24 * 64);
+        bool ok = true;
+        for (int j = 0; j < 24; j++)
+            for (int v = 0; v < 64; v++) {
+                int bin = v + 64 * (j < 12 ? j : j + 8);
+                if (j == 0 && v == 0) bin = 768;
+                if (n_of_bin[bin] < 0) ok = false;
+                nvj[j * 64 + v] = uint16_t(n_of_bin[bin] < 0 ? 0 : n_of_bin[bin]);
+            }
+        if (!ok) { rc = DABGPU_ERR_PROFILE; break; }
+        if ((rc = upload(&ctx->d_n_of_vj, nvj))) break;
         ctx->fic.prof = make_fic_profile();
         if (ctx->fic.prof.nsteps != NB_FIC_STEPS || ctx->fic.prof.n_punct != NB_FIC_GROUP_BITS) { rc = DABGPU_ERR_PROFILE; break; }
         if ((rc = build_device_code(ctx->fic))) break;
@@ -267,6 +283,7 @@ void dabgpu_destroy(dabgpu_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->d_twiddle) (void)hipFree(ctx->d_twiddle);
     if (ctx->d_bin_of_n) (void)hipFree(ctx->d_bin_of_n);
+    if (ctx->d_n_of_vj) (void)hipFree(ctx->d_n_of_vj);
     free_device_code(ctx->fic);
     for (auto &kv : ctx->codes) free_device_code(*kv.second);
     for (void *p : ctx->d_stage) if (p) (void)hipFree(p);
@@ -315,10 +332,10 @@ int dabgpu_ofdm_demod_frames_dev(dabgpu_ctx *ctx, const void *d_iq, size_t frame
     if (!ctx || !d_soft) return DABGPU_ERR_ARG;
     int rc = check_iq(d_iq, frame_stride, n_frames);
     if (rc) return rc;
-    if (reinterpret_cast<uintptr_t>(d_soft) & 7u) return DABGPU_ERR_ARG;
+    if (reinterpret_cast<uintptr_t>(d_soft) & 15u) return DABGPU_ERR_ARG;
     if (n_frames == 0) return DABGPU_OK;
     hipStream_t s = pick_stream(ctx, stream);
-    dabk::OfdmTables tab{ctx->d_twiddle, ctx->d_bin_of_n};
+    dabk::OfdmTables tab{ctx->d_twiddle, ctx->d_bin_of_n, ctx->d_n_of_vj};
     dabk::OfdmArgs a{};
     a.iq = static_cast<const float2 *>(d_iq);
     a.frame_stride = frame_stride;
@@ -339,7 +356,7 @@ int dabgpu_fft_symbols_dev(dabgpu_ctx *ctx, const void *d_iq, size_t frame_strid
     if (rc) return rc;
     if (n_frames == 0) return DABGPU_OK;
     hipStream_t s = pick_stream(ctx, stream);
-    dabk::OfdmTables tab{ctx->d_twiddle, ctx->d_bin_of_n};
+    dabk::OfdmTables tab{ctx->d_twiddle, ctx->d_bin_of_n, ctx->d_n_of_vj};
     dabk::OfdmArgs a{};
     a.iq = static_cast<const float2 *>(d_iq);
     a.frame_stride = frame_stride;

@@ -15,6 +15,8 @@
 // spectrum in LDS so every IQ sample is read from HBM once.  The FFT is a Stockham
 // autosort radix-8/8/8/4 through LDS; the first radix-8 pass is fed straight from the
 // coalesced global loads with the NCO rotation applied in registers.
+#include <cstdlib>
+
 #include "kernels.hpp"
 #include "dab_tables.hpp"
 
@@ -223,14 +225,338 @@ __global__ __launch_bounds__(WG) void ofdm_kernel(OfdmTables tab, OfdmArgs a, in
     }
 }
 
+
+// ============================================================================
+// Kernel 2 ("wave" variant): one 64-lane wavefront owns a run of consecutive symbols of
+// one frame and keeps a whole 2048-point symbol in registers (32 complex per lane).
+//
+//   n = 128*n1 + 8*n2 + n3   (n1<16, n2<16, n3<8)      k = k1 + 16*k2 + 256*k3
+//   step 1  lane (n2, n3/2): two 16-point DFTs over n1   (inputs are the lane's own 16-byte loads)
+//           twiddle W256^(n2*k1), exchange through LDS
+//   step 2  lane (k1, n3/2): two 16-point DFTs over n2,  twiddle W2048^(n3*(k1+16*k2)), exchange
+//   step 3  lane v = (k1 | k2%4 << 4): four 8-point DFTs over n3 -> bins v + 64*m, m = 0..31
+//
+// Because every lane ends each symbol with the SAME bins, the previous spectrum stays in
+// registers and the differential demodulation needs no memory at all.  The two LDS
+// exchanges use XOR-swizzled layouts that are bank-conflict free for both the
+// ds_write_b64 and the ds_read_b64 side (tools: see DESIGN.md).  No workgroup barrier is
+// needed after the twiddle table is loaded: a wave only talks to itself.
+// Soft bits are scattered as bytes into the (then idle) exchange buffer and leave as
+// three coalesced 16-byte stores per lane.
+// ============================================================================
+constexpr int WAVES = 4;
+
+struct WaveLds {
+    float2 tw[NB_FFT];           // exp(-2*pi*i*m/2048)
+    float2 ex[WAVES][NB_FFT];    // per-wave exchange buffer, reused as soft-bit staging
+};
+
+__device__ __forceinline__ float2 cmul_k(float2 a, float c, float s) {   // a * (c + j*s)
+    return make_float2(a.x * c - a.y * s, a.x * s + a.y * c);
+}
+
+// in-place 16-point forward DFT, natural order in and out (radix 4 x 4)
+__device__ __forceinline__ void fft16(float2 *x) {
+    constexpr float C1 = 0.92387953251128675613f, S1 = 0.38268343236508977173f;
+#pragma unroll
+    for (int b = 0; b < 4; b++) fft4(x[b], x[4 + b], x[8 + b], x[12 + b]);   // x[4c+b] = Y[b][c]
+    // Y[b][c] *= W16^(b*c)
+    x[5] = cmul_k(x[5], C1, -S1);                 // W16^1
+    x[6] = cmul_k(x[6], SQRT1_2, -SQRT1_2);       // W16^2
+    x[7] = cmul_k(x[7], S1, -C1);                 // W16^3
+    x[9] = cmul_k(x[9], SQRT1_2, -SQRT1_2);       // W16^2
+    x[10] = mul_mj(x[10]);                        // W16^4
+    x[11] = cmul_k(x[11], -SQRT1_2, -SQRT1_2);    // W16^6
+    x[13] = cmul_k(x[13], S1, -C1);               // W16^3
+    x[14] = cmul_k(x[14], -SQRT1_2, -SQRT1_2);    // W16^6
+    x[15] = cmul_k(x[15], -C1, S1);               // W16^9
+    float2 o[16];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        float2 a = x[4 * c], b = x[4 * c + 1], d = x[4 * c + 2], e = x[4 * c + 3];
+        fft4(a, b, d, e);
+        o[c] = a; o[c + 4] = b; o[c + 8] = d; o[c + 12] = e;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) x[i] = o[i];
+}
+
+// wave-wide sum by XOR butterflies on the VALU (DPP / permlane swaps), result in every lane
+template <int XORMASK>
+__device__ __forceinline__ float lane_xor_f(float v, int lane) {
+    const int m = __float_as_int(v);
+    int r;
+    if constexpr (XORMASK == 1) {
+        r = __builtin_amdgcn_update_dpp(0, m, 0xB1, 0xF, 0xF, false);
+    } else if constexpr (XORMASK == 2) {
+        r = __builtin_amdgcn_update_dpp(0, m, 0x4E, 0xF, 0xF, false);
+    } else if constexpr (XORMASK == 4) {
+        r = __builtin_amdgcn_update_dpp(0, __builtin_amdgcn_update_dpp(0, m, 0x141, 0xF, 0xF, false), 0x1B, 0xF, 0xF, false);
+    } else if constexpr (XORMASK == 8) {
+        r = __builtin_amdgcn_update_dpp(0, m, 0x128, 0xF, 0xF, false);
+    } else if constexpr (XORMASK == 16) {
+        typedef unsigned u2 __attribute__((ext_vector_type(2)));
+        const u2 t = __builtin_amdgcn_permlane16_swap(unsigned(m), unsigned(m), false, false);
+        r = (lane & 16) ? int(t.x) : int(t.y);
+    } else {
+        typedef unsigned u2 __attribute__((ext_vector_type(2)));
+        const u2 t = __builtin_amdgcn_permlane32_swap(unsigned(m), unsigned(m), false, false);
+        r = (lane & 32) ? int(t.x) : int(t.y);
+    }
+    return __int_as_float(r);
+}
+__device__ __forceinline__ float wave_sum(float v, int lane) {
+    v += lane_xor_f<1>(v, lane);
+    v += lane_xor_f<2>(v, lane);
+    v += lane_xor_f<4>(v, lane);
+    v += lane_xor_f<8>(v, lane);
+    v += lane_xor_f<16>(v, lane);
+    v += lane_xor_f<32>(v, lane);
+    return v;
+}
+
+template <bool FFT_ONLY, bool WITH_DQPSK>
+__global__ __launch_bounds__(64 * WAVES, 2) void ofdm_wave_kernel(OfdmTables tab, OfdmArgs a, int syms_per_group,
+                                                                  int groups_per_frame, int n_items) {
+    __shared__ WaveLds sm;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    for (int i = tid; i < NB_FFT; i += 64 * WAVES) sm.tw[i] = tab.twiddle[i];
+    __syncthreads();
+    const int item = blockIdx.x * WAVES + wave;
+    if (item >= n_items) return;
+    const int frame = item / groups_per_frame;
+    const int group = item - frame * groups_per_frame;
+    const float2 *fiq = a.iq + size_t(frame) * a.frame_stride;
+#ifdef DAB_EXP_NOPLL
+    const uint32_t dphi = 0u;
+#else
+    const uint32_t dphi = dphi_of(a.freq_offset, frame);
+#endif
+#ifdef DAB_EXP_NOCYC
+    a.cyc = nullptr;
+#endif
+    float2 *ex = sm.ex[wave];
+    const float2 *tw = sm.tw;
+
+    // lane roles
+    const int n2 = lane >> 2, p = lane & 3;            // step 1 (and k1 = n2, p' = p in step 2)
+    const int k1v = lane & 15, kk = lane >> 4;         // step 3
+    // exchange-1 slots: n3*256 + k1*16 + (n2 ^ (n3/2)<<2 ^ (k1/2)&3)
+    const int w1_base = p * 512, w1_r = n2 ^ (p << 2);
+    // exchange-2 slots: n3*256 + k2*16 + (k1 ^ (n3/2)<<2)
+    const int w2_base = p * 512 + (n2 ^ (p << 2));
+    const int r2_base = kk * 16;
+
+    // step-1 twiddles W256^(n2*k1) are the same for every symbol: keep them in registers? (30 VGPRs) -- no,
+    // they are re-read from LDS per symbol; the table index is 8*n2*k1.
+    // frequency de-interleave: data index of each carrier register (24 per lane)
+    uint32_t nidx2[12];          // two 16-bit data indices per register
+    if (!FFT_ONLY) {
+#pragma unroll
+        for (int j = 0; j < 12; j++)
+            nidx2[j] = uint32_t(tab.n_of_vj[(2 * j) * 64 + lane]) | (uint32_t(tab.n_of_vj[(2 * j + 1) * 64 + lane]) << 16);
+    }
+    float2 prev[24];
+#pragma unroll
+    for (int j = 0; j < 24; j++) prev[j] = make_float2(0.f, 0.f);
+
+    const float2 r1 = nco(1u, dphi), r128 = nco(128u, dphi), rot2048 = nco(uint32_t(NB_FFT), dphi);
+
+    const int l_first = group * syms_per_group;
+    const int l_last = FFT_ONLY ? l_first + syms_per_group - 1 : l_first + syms_per_group;
+
+    for (int l = l_first; l <= l_last; l++) {
+        const float2 *sym = fiq + size_t(l) * NB_SYM_PERIOD;
+        const bool emit = FFT_ONLY || (l > l_first) || (l == 0);
+        // Opaque per-iteration copies of the lane roles: every LDS address below is one or two VALU ops
+        // from these, which is cheaper than letting LICM park ~60 loop-invariant addresses in VGPRs (spills).
+        int n2i = n2, pi = p;
+        asm volatile("" : "+v"(n2i), "+v"(pi));
+        // phasor of this lane's first sample, computed before the loads so sincospi's temporaries are dead
+        // by the time 64 data registers are live
+        float2 w = make_float2(1.f, 0.f);
+        if (dphi != 0u) w = nco(uint32_t(l * NB_SYM_PERIOD + NB_CP + 2 * lane), dphi);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- loads: 16 x 16 B per lane, row n1 = samples 128*n1 + 2*lane, +1 ----
+        float2 x0[16], x1[16];
+        {
+            const float4 *rows = reinterpret_cast<const float4 *>(sym + NB_CP) + lane;
+#pragma unroll
+            for (int n1 = 0; n1 < 16; n1++) {
+                const float4 v = rows[64 * n1];
+                x0[n1] = make_float2(v.x, v.y);
+                x1[n1] = make_float2(v.z, v.w);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- cyclic-prefix correlation on raw samples: CP pair c = lane-4+64*i <-> row 12+i of this lane ----
+        if (a.cyc && emit) {
+            float2 acc = make_float2(0.f, 0.f);
+            const float4 *cp = reinterpret_cast<const float4 *>(sym) + (lane - 4);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if (i > 0 || lane >= 4) {
+                    const float4 c = cp[64 * i];
+                    const float2 u0 = x0[12 + i], u1 = x1[12 + i];
+                    acc.x += c.x * u0.x + c.y * u0.y + c.z * u1.x + c.w * u1.y;      // conj(c) * u
+                    acc.y += c.x * u0.y - c.y * u0.x + c.z * u1.y - c.w * u1.x;
+                }
+            }
+            acc.x = wave_sum(acc.x, lane);
+            acc.y = wave_sum(acc.y, lane);
+            if (lane == 0) a.cyc[size_t(frame) * NB_FRAME_SYMBOLS + l] = cmul(acc, rot2048);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- A2: NCO ----
+        if (dphi != 0u) {
+#pragma unroll
+            for (int n1 = 0; n1 < 16; n1++) {
+                x0[n1] = cmul(x0[n1], w);
+                x1[n1] = cmul(x1[n1], cmul(w, r1));
+                // pin the order row by row: without this the whole phasor chain is computed up front and
+                // ~100 extra VGPRs are live next to the 64 data registers (spills)
+                asm volatile("" : "+v"(x0[n1].x), "+v"(x0[n1].y), "+v"(x1[n1].x), "+v"(x1[n1].y));
+                w = cmul(w, r128);
+                asm volatile("" : "+v"(w.x), "+v"(w.y));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- step 1 ----
+        fft16(x0);
+        __builtin_amdgcn_sched_barrier(0);
+        fft16(x1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k1 = 1; k1 < 16; k1++) {
+            const float2 t = tw[(8 * n2i) * k1];          // index <= 8*15*15 = 1800
+            x0[k1] = cmul(x0[k1], t);
+            x1[k1] = cmul(x1[k1], t);
+        }
+#pragma unroll
+        for (int k1 = 0; k1 < 16; k1++) {
+            const int s = w1_base + k1 * 16 + (w1_r ^ ((k1 >> 1) & 3));
+            ex[s] = x0[k1];
+            ex[s + 256] = x1[k1];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- step 2: lane (k1 = n2, n3 = 2p + e) gathers over n2' ----
+        const int r1b = pi * 512 + n2i * 16, r1x = (pi << 2) ^ ((n2i >> 1) & 3);
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            const int s = r1b + (m ^ r1x);
+            x0[m] = ex[s];
+            x1[m] = ex[s + 256];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        fft16(x0);
+        __builtin_amdgcn_sched_barrier(0);
+        fft16(x1);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            // W2048^(n3*(k1+16*k2)), k1 = n2 of this lane, n3 = 2p (+1)
+            const int i0 = 2 * pi * n2i, st0 = 32 * pi, i1 = i0 + n2i, st1 = st0 + 16;
+#pragma unroll
+            for (int k2 = 0; k2 < 16; k2++) {
+                x0[k2] = cmul(x0[k2], tw[i0 + st0 * k2]);
+                x1[k2] = cmul(x1[k2], tw[i1 + st1 * k2]);
+            }
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < 16; k2++) {
+            ex[w2_base + k2 * 16] = x0[k2];
+            ex[w2_base + k2 * 16 + 256] = x1[k2];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- step 3: lane v reads B[n3][k1v][4c+kk], four 8-point DFTs ----
+        float2 X[4][8];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+#pragma unroll
+            for (int n3 = 0; n3 < 8; n3++)
+                X[c][n3] = ex[n3 * 256 + c * 64 + r2_base + (k1v ^ ((n3 >> 1) << 2))];
+            fft8(X[c]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // bin of X[c][k3] is lane + 64*(c + 4*k3)
+        if (FFT_ONLY) {
+            float2 *o = a.spectra + (size_t(frame) * NB_FRAME_SYMBOLS + l) * NB_FFT + lane;
+#pragma unroll
+            for (int k3 = 0; k3 < 8; k3++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) o[64 * (c + 4 * k3)] = X[c][k3];
+            continue;
+        }
+        // ---- carrier registers: j<12 -> m=j ; j>=12 -> m=j+8 ; lane 0 holds bin 768 (m=12) instead of DC ----
+        float2 cur[24];
+#pragma unroll
+        for (int j = 0; j < 24; j++) {
+            const int m = j < 12 ? j : j + 8;
+            cur[j] = X[m & 3][m >> 2];
+        }
+        if (lane == 0) cur[0] = X[0][3];
+#ifdef DAB_EXP_NOEPI
+        if (l > l_first && cur[3].x == 12345.f) {
+#else
+        if (l > l_first) {
+#endif
+            uint8_t *stg = reinterpret_cast<uint8_t *>(ex);
+#pragma unroll
+            for (int j = 0; j < 24; j++) {
+                const float2 d = cmulc(cur[j], prev[j]);
+                // A6: trunc(-127 * c / max(|re|,|im|)).  One v_rcp (1 ulp) instead of two IEEE divisions; the
+                // 2^-22 head-room makes the larger component land on exactly +-127 after the clamp, as an exact
+                // division gives.  A == 0 (erased carrier) yields 0 because d == 0 and the floor keeps sc finite.
+                const float Amax = fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), 1.0e-30f);
+                const float sc = -127.00003f * __builtin_amdgcn_rcpf(Amax);
+                const int br = int(__builtin_amdgcn_fmed3f(d.x * sc, -127.0f, 127.0f));
+                const int bi = int(__builtin_amdgcn_fmed3f(d.y * sc, -127.0f, 127.0f));
+                const uint32_t ni = (j & 1) ? (nidx2[j >> 1] >> 16) : (nidx2[j >> 1] & 0xFFFFu);
+                stg[ni] = uint8_t(br);
+                stg[NB_CARRIERS + ni] = uint8_t(bi);
+                if constexpr (WITH_DQPSK) {
+                    // carrier-order index: bins 1..768 -> 767+bin ; bins 1280..2047 -> bin-1280
+                    float2 *dq = a.dqpsk + (size_t(frame) * NB_DATA_SYMBOLS + (l - 1)) * NB_CARRIERS;
+                    const int m = j < 12 ? j : j + 8;
+                    int bin = lane + 64 * m;
+                    if (j == 0 && lane == 0) bin = 768;
+                    dq[bin >= 1280 ? bin - 1280 : bin + 767] = d;
+                }
+            }
+            const uint4 *sv = reinterpret_cast<const uint4 *>(stg) + lane;
+            uint4 *o = reinterpret_cast<uint4 *>(a.soft + size_t(frame) * NB_FRAME_BITS + size_t(l - 1) * NB_SYM_BITS) + lane;
+            const uint4 s0 = sv[0], s1 = sv[64], s2 = sv[128];
+            o[0] = s0; o[64] = s1; o[128] = s2;
+        }
+#pragma unroll
+        for (int j = 0; j < 24; j++) prev[j] = cur[j];
+    }
+}
+
 }  // namespace
+
+static bool use_v0() {
+    static const bool v = std::getenv("DABGPU_OFDM_V0") != nullptr;
+    return v;
+}
 
 hipError_t launch_ofdm_demod(const OfdmTables &t, const OfdmArgs &a, int syms_per_group, hipStream_t s) {
     if (a.n_frames <= 0) return hipSuccess;
     if (syms_per_group <= 0 || NB_DATA_SYMBOLS % syms_per_group) return hipErrorInvalidValue;
     const int groups = NB_DATA_SYMBOLS / syms_per_group;
-    hipLaunchKernelGGL(ofdm_kernel<false>, dim3(unsigned(a.n_frames) * groups), dim3(WG), 0, s, t, a,
-                       syms_per_group, groups);
+    if (use_v0()) {
+        hipLaunchKernelGGL(ofdm_kernel<false>, dim3(unsigned(a.n_frames) * groups), dim3(WG), 0, s, t, a,
+                           syms_per_group, groups);
+    } else {
+        const int items = a.n_frames * groups;
+        if (a.dqpsk)
+            hipLaunchKernelGGL((ofdm_wave_kernel<false, true>), dim3(unsigned((items + WAVES - 1) / WAVES)),
+                               dim3(64 * WAVES), 0, s, t, a, syms_per_group, groups, items);
+        else
+            hipLaunchKernelGGL((ofdm_wave_kernel<false, false>), dim3(unsigned((items + WAVES - 1) / WAVES)),
+                               dim3(64 * WAVES), 0, s, t, a, syms_per_group, groups, items);
+    }
     return hipGetLastError();
 }
 
@@ -238,8 +564,14 @@ hipError_t launch_fft_symbols(const OfdmTables &t, const OfdmArgs &a, int syms_p
     if (a.n_frames <= 0) return hipSuccess;
     if (syms_per_group <= 0 || NB_FRAME_SYMBOLS % syms_per_group) return hipErrorInvalidValue;
     const int groups = NB_FRAME_SYMBOLS / syms_per_group;
-    hipLaunchKernelGGL(ofdm_kernel<true>, dim3(unsigned(a.n_frames) * groups), dim3(WG), 0, s, t, a,
-                       syms_per_group, groups);
+    if (use_v0()) {
+        hipLaunchKernelGGL(ofdm_kernel<true>, dim3(unsigned(a.n_frames) * groups), dim3(WG), 0, s, t, a,
+                           syms_per_group, groups);
+    } else {
+        const int items = a.n_frames * groups;
+        hipLaunchKernelGGL((ofdm_wave_kernel<true, false>), dim3(unsigned((items + WAVES - 1) / WAVES)),
+                           dim3(64 * WAVES), 0, s, t, a, syms_per_group, groups, items);
+    }
     return hipGetLastError();
 }
 

@@ -243,7 +243,9 @@ __global__ __launch_bounds__(WGV) void viterbi_rot_kernel(Fetch fetch, CodeTable
     // ---- A8: depuncture into LDS ----
     for (int i = lane; i < dec_off / 4; i += 64) m4[i] = 0;
     __syncthreads();
+#ifndef DAB_EXP_NO_DEPUNCT
     for (int i = lane; i < code.n_punct; i += 64) mother[code.mother_pos[i]] = fetch(cw, i);
+#endif
     __syncthreads();
 
     // ---- per-lane sign tables for the six layout phases ----
@@ -263,7 +265,11 @@ __global__ __launch_bounds__(WGV) void viterbi_rot_kernel(Fetch fetch, CodeTable
     int metric = (lane == 0) ? 0 : -VITERBI_INIT_PENALTY;
     unsigned dec = 0;
     int cw0 = m4[lane], cw1 = m4[64 + (lane & 31)];
+#ifdef DAB_EXP_NO_FORWARD
+    for (int c = 0; c < 0; c++) {
+#else
     for (int c = 0; c < nchunks; c++) {
+#endif
         const int a0 = cw0, a1 = cw1;
         const int tn = (c + 1) * 96;
         cw0 = m4[tn + lane];                 // prefetch (the last one reads into W: harmless, unused)
@@ -309,7 +315,11 @@ __global__ __launch_bounds__(WGV) void viterbi_rot_kernel(Fetch fetch, CodeTable
             l = (l & ~(1 << q)) | int(h << q);
         }
     }
+#ifdef DAB_EXP_NO_TRACEBACK
+    for (int c = -1; c >= 0; c--) {
+#else
     for (int c = nchunks - 1; c >= 0; c--) {
+#endif
 #pragma unroll
         for (int gg = 2; gg >= 0; gg--) {
             const unsigned wv = W[(c * 3 + gg) * 64 + lane];

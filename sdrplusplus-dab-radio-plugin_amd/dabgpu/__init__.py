@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libdabgpu.so")
+LIB_PATH = os.environ.get("DABGPU_LIB", os.path.join(os.path.dirname(_HERE), "libdabgpu.so"))
 
 NB_FFT = 2048
 NB_CP = 504
