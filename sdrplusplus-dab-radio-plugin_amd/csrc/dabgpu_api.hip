@@ -51,7 +51,8 @@ struct dabgpu_ctx {
     size_t stage_bytes[6] = {0, 0, 0, 0, 0, 0};
     bool timing = false;
     Timer timers[4];
-    int ofdm_group_override = 0;
+    int ofdm_parts_override = 0;
+    int wave_slots = 2048;       // resident OFDM wavefronts: 8 per CU
 };
 
 namespace {
@@ -132,19 +133,20 @@ struct ScopedTimer {
     }
 };
 
-// symbols per workgroup: whole frame per workgroup once there are enough frames to fill
-// 256 CUs several times over, otherwise split the frame (each split re-reads one symbol).
-int pick_group(const dabgpu_ctx *ctx, int n_frames, int total_syms) {
-    if (ctx->ofdm_group_override > 0 && total_syms % ctx->ofdm_group_override == 0)
-        return ctx->ofdm_group_override;
-    static const int DIV75[] = {75, 25, 15, 5, 3, 1};
-    static const int DIV76[] = {76, 38, 19, 4, 2, 1};
-    const int *divs = (total_syms == 75) ? DIV75 : DIV76;
-    for (int i = 0; i < 6; i++) {
-        const long wgs = long(n_frames) * (total_syms / divs[i]);
-        if (wgs >= 2048) return divs[i];
+// How many contiguous symbol runs to cut each frame into.  One run = one wavefront (8 resident per CU).
+// Cost model: rounds of resident waves x symbols per run (+1 for the re-read reference symbol); pick the
+// cheapest, preferring fewer cuts.
+int pick_parts(const dabgpu_ctx *ctx, int n_frames, int total_syms) {
+    if (ctx->ofdm_parts_override > 0 && ctx->ofdm_parts_override <= total_syms) return ctx->ofdm_parts_override;
+    const long slots = long(ctx->wave_slots);
+    long best_cost = -1;
+    int best = 1;
+    for (int p = 1; p <= total_syms; p++) {
+        const long rounds = (long(n_frames) * p + slots - 1) / slots;
+        const long cost = rounds * ((total_syms + p - 1) / p + 1);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = p; }
     }
-    return 1;
+    return best;
 }
 
 hipStream_t pick_stream(dabgpu_ctx *ctx, void *stream) {
@@ -239,7 +241,8 @@ int dabgpu_create(const dabgpu_cfg *cfg, dabgpu_ctx **out) {
     if (!ctx) return DABGPU_ERR_NOMEM;
     ctx->device = cfg->device;
     ctx->max_frames = cfg->max_frames;
-    if (const char *g = std::getenv("DABGPU_OFDM_GROUP")) ctx->ofdm_group_override = std::atoi(g);
+    if (const char *g = std::getenv("DABGPU_OFDM_PARTS")) ctx->ofdm_parts_override = std::atoi(g);
+    ctx->wave_slots = prop.multiProcessorCount > 0 ? prop.multiProcessorCount * 8 : 2048;
     int rc = DABGPU_OK;
     do {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { rc = DABGPU_ERR_HIP; break; }
@@ -345,7 +348,7 @@ int dabgpu_ofdm_demod_frames_dev(dabgpu_ctx *ctx, const void *d_iq, size_t frame
     a.cyc = static_cast<float2 *>(d_cyc);
     a.dqpsk = static_cast<float2 *>(d_dqpsk);
     ScopedTimer tm(ctx, 0, s);
-    HIP_TRY(dabk::launch_ofdm_demod(tab, a, pick_group(ctx, n_frames, NB_DATA_SYMBOLS), s));
+    HIP_TRY(dabk::launch_ofdm_demod(tab, a, pick_parts(ctx, n_frames, NB_DATA_SYMBOLS), s));
     return DABGPU_OK;
 }
 
@@ -364,7 +367,7 @@ int dabgpu_fft_symbols_dev(dabgpu_ctx *ctx, const void *d_iq, size_t frame_strid
     a.n_frames = n_frames;
     a.spectra = static_cast<float2 *>(d_spectra);
     ScopedTimer tm(ctx, 3, s);
-    HIP_TRY(dabk::launch_fft_symbols(tab, a, pick_group(ctx, n_frames, NB_FRAME_SYMBOLS), s));
+    HIP_TRY(dabk::launch_fft_symbols(tab, a, pick_parts(ctx, n_frames, NB_FRAME_SYMBOLS), s));
     return DABGPU_OK;
 }
 

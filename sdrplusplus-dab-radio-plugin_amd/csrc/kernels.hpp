@@ -24,10 +24,11 @@ struct OfdmArgs {
     float2 *spectra;           // FFT-only mode: [n_frames][76][2048]
 };
 
-// fused A2..A6.  syms_per_group must divide 75.
-hipError_t launch_ofdm_demod(const OfdmTables &t, const OfdmArgs &a, int syms_per_group, hipStream_t s);
-// A2+A3 only. syms_per_group must divide 76.
-hipError_t launch_fft_symbols(const OfdmTables &t, const OfdmArgs &a, int syms_per_group, hipStream_t s);
+// fused A2..A6.  Each frame is cut into `parts` contiguous runs of data symbols (1..75); a run re-reads
+// the symbol before it as differential reference.
+hipError_t launch_ofdm_demod(const OfdmTables &t, const OfdmArgs &a, int parts, hipStream_t s);
+// A2+A3 only; parts in 1..76.
+hipError_t launch_fft_symbols(const OfdmTables &t, const OfdmArgs &a, int parts, hipStream_t s);
 
 // ---- channel decoder (viterbi_kernels.hip) ---------------------------------
 struct CodeTables {

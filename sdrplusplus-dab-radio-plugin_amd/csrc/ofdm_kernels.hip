@@ -103,12 +103,11 @@ __device__ __forceinline__ void pass8(const float2 *src, float2 *dst, const floa
 }
 
 template <bool FFT_ONLY>
-__global__ __launch_bounds__(WG) void ofdm_kernel(OfdmTables tab, OfdmArgs a, int syms_per_group,
-                                                  int groups_per_frame) {
+__global__ __launch_bounds__(WG) void ofdm_kernel(OfdmTables tab, OfdmArgs a, int parts) {
     __shared__ Smem sm;
     const int tid = threadIdx.x;
-    const int frame = blockIdx.x / groups_per_frame;
-    const int group = blockIdx.x % groups_per_frame;
+    const int frame = blockIdx.x / parts;
+    const int part = blockIdx.x % parts;
     const float2 *fiq = a.iq + size_t(frame) * a.frame_stride;
     const uint32_t dphi = dphi_of(a.freq_offset, frame);
 
@@ -122,8 +121,9 @@ __global__ __launch_bounds__(WG) void ofdm_kernel(OfdmTables tab, OfdmArgs a, in
     }
 
     // symbols [l_first, l_last]; in fused mode l_first is only the differential reference
-    const int l_first = FFT_ONLY ? group * syms_per_group : group * syms_per_group;
-    const int l_last = FFT_ONLY ? l_first + syms_per_group - 1 : l_first + syms_per_group;
+    // fused: data symbols (l_first, l_last], l_first is only the differential reference
+    const int l_first = FFT_ONLY ? (NB_FRAME_SYMBOLS * part) / parts : (NB_DATA_SYMBOLS * part) / parts;
+    const int l_last = FFT_ONLY ? (NB_FRAME_SYMBOLS * (part + 1)) / parts - 1 : (NB_DATA_SYMBOLS * (part + 1)) / parts;
     __syncthreads();
 
     for (int l = l_first; l <= l_last; l++) {
@@ -316,8 +316,7 @@ __device__ __forceinline__ float wave_sum(float v, int lane) {
 }
 
 template <bool FFT_ONLY, bool WITH_DQPSK>
-__global__ __launch_bounds__(64 * WAVES, 2) void ofdm_wave_kernel(OfdmTables tab, OfdmArgs a, int syms_per_group,
-                                                                  int groups_per_frame, int n_items) {
+__global__ __launch_bounds__(64 * WAVES, 2) void ofdm_wave_kernel(OfdmTables tab, OfdmArgs a, int parts, int n_items) {
     __shared__ WaveLds sm;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -326,8 +325,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ofdm_wave_kernel(OfdmTables tab
     __syncthreads();
     const int item = blockIdx.x * WAVES + wave;
     if (item >= n_items) return;
-    const int frame = item / groups_per_frame;
-    const int group = item - frame * groups_per_frame;
+    const int frame = item / parts;
+    const int part = item - frame * parts;
     const float2 *fiq = a.iq + size_t(frame) * a.frame_stride;
 #ifdef DAB_EXP_NOPLL
     const uint32_t dphi = 0u;
@@ -364,8 +363,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ofdm_wave_kernel(OfdmTables tab
 
     const float2 r1 = nco(1u, dphi), r128 = nco(128u, dphi), rot2048 = nco(uint32_t(NB_FFT), dphi);
 
-    const int l_first = group * syms_per_group;
-    const int l_last = FFT_ONLY ? l_first + syms_per_group - 1 : l_first + syms_per_group;
+    // fused: data symbols (l_first, l_last]; l_first is only the differential reference
+    const int l_first = FFT_ONLY ? (NB_FRAME_SYMBOLS * part) / parts : (NB_DATA_SYMBOLS * part) / parts;
+    const int l_last = FFT_ONLY ? (NB_FRAME_SYMBOLS * (part + 1)) / parts - 1 : (NB_DATA_SYMBOLS * (part + 1)) / parts;
 
     for (int l = l_first; l <= l_last; l++) {
         const float2 *sym = fiq + size_t(l) * NB_SYM_PERIOD;
@@ -541,36 +541,31 @@ static bool use_v0() {
     return v;
 }
 
-hipError_t launch_ofdm_demod(const OfdmTables &t, const OfdmArgs &a, int syms_per_group, hipStream_t s) {
+hipError_t launch_ofdm_demod(const OfdmTables &t, const OfdmArgs &a, int parts, hipStream_t s) {
     if (a.n_frames <= 0) return hipSuccess;
-    if (syms_per_group <= 0 || NB_DATA_SYMBOLS % syms_per_group) return hipErrorInvalidValue;
-    const int groups = NB_DATA_SYMBOLS / syms_per_group;
+    if (parts <= 0 || parts > NB_DATA_SYMBOLS) return hipErrorInvalidValue;
+    const int items = a.n_frames * parts;
     if (use_v0()) {
-        hipLaunchKernelGGL(ofdm_kernel<false>, dim3(unsigned(a.n_frames) * groups), dim3(WG), 0, s, t, a,
-                           syms_per_group, groups);
+        hipLaunchKernelGGL(ofdm_kernel<false>, dim3(unsigned(items)), dim3(WG), 0, s, t, a, parts);
+    } else if (a.dqpsk) {
+        hipLaunchKernelGGL((ofdm_wave_kernel<false, true>), dim3(unsigned((items + WAVES - 1) / WAVES)),
+                           dim3(64 * WAVES), 0, s, t, a, parts, items);
     } else {
-        const int items = a.n_frames * groups;
-        if (a.dqpsk)
-            hipLaunchKernelGGL((ofdm_wave_kernel<false, true>), dim3(unsigned((items + WAVES - 1) / WAVES)),
-                               dim3(64 * WAVES), 0, s, t, a, syms_per_group, groups, items);
-        else
-            hipLaunchKernelGGL((ofdm_wave_kernel<false, false>), dim3(unsigned((items + WAVES - 1) / WAVES)),
-                               dim3(64 * WAVES), 0, s, t, a, syms_per_group, groups, items);
+        hipLaunchKernelGGL((ofdm_wave_kernel<false, false>), dim3(unsigned((items + WAVES - 1) / WAVES)),
+                           dim3(64 * WAVES), 0, s, t, a, parts, items);
     }
     return hipGetLastError();
 }
 
-hipError_t launch_fft_symbols(const OfdmTables &t, const OfdmArgs &a, int syms_per_group, hipStream_t s) {
+hipError_t launch_fft_symbols(const OfdmTables &t, const OfdmArgs &a, int parts, hipStream_t s) {
     if (a.n_frames <= 0) return hipSuccess;
-    if (syms_per_group <= 0 || NB_FRAME_SYMBOLS % syms_per_group) return hipErrorInvalidValue;
-    const int groups = NB_FRAME_SYMBOLS / syms_per_group;
+    if (parts <= 0 || parts > NB_FRAME_SYMBOLS) return hipErrorInvalidValue;
+    const int items = a.n_frames * parts;
     if (use_v0()) {
-        hipLaunchKernelGGL(ofdm_kernel<true>, dim3(unsigned(a.n_frames) * groups), dim3(WG), 0, s, t, a,
-                           syms_per_group, groups);
+        hipLaunchKernelGGL(ofdm_kernel<true>, dim3(unsigned(items)), dim3(WG), 0, s, t, a, parts);
     } else {
-        const int items = a.n_frames * groups;
         hipLaunchKernelGGL((ofdm_wave_kernel<true, false>), dim3(unsigned((items + WAVES - 1) / WAVES)),
-                           dim3(64 * WAVES), 0, s, t, a, syms_per_group, groups, items);
+                           dim3(64 * WAVES), 0, s, t, a, parts, items);
     }
     return hipGetLastError();
 }

@@ -61,12 +61,12 @@ def test_ofdm_soft_bits_within_one_lsb(ctx, ensemble, ensemble_iq, snr, cfo):
 
 
 def test_ofdm_group_splits_agree(built, ensemble_iq, monkeypatch):
-    """The frame may be split over 1..75 workgroups; results must not depend on the split."""
+    """A frame may be cut into 1..75 symbol runs; results must not depend on the cut."""
     frames = _rx(ensemble_iq, 12.0, 0.2 / 2048)[:2]
     fo = np.full(2, -0.2 / 2048, np.float32)
     outs = []
-    for g in ("75", "25", "15", "5", "3", "1"):
-        monkeypatch.setenv("DABGPU_OFDM_GROUP", g)
+    for g in ("1", "2", "3", "7", "31", "75"):
+        monkeypatch.setenv("DABGPU_OFDM_PARTS", g)
         with dabgpu.Context(device=0) as c:
             outs.append(c.ofdm_demod_frames(frames, fo, want_cyc=True))
     for soft, cyc, _ in outs[1:]:
