@@ -244,7 +244,10 @@ __global__ __launch_bounds__(WG) void ofdm_kernel(OfdmTables tab, OfdmArgs a, in
 // Soft bits are scattered as bytes into the (then idle) exchange buffer and leave as
 // three coalesced 16-byte stores per lane.
 // ============================================================================
-constexpr int WAVES = 4;
+#ifndef DAB_OFDM_WAVES
+#define DAB_OFDM_WAVES 4
+#endif
+constexpr int WAVES = DAB_OFDM_WAVES;
 
 struct WaveLds {
     float2 tw[NB_FFT];           // exp(-2*pi*i*m/2048)
