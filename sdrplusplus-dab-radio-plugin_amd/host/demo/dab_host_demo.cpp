@@ -1,0 +1,99 @@
+// dab_host_demo -- drives the host-side mirror the way Radio_Block does
+// (/root/reference/src/radio_block.cpp:11-49): OFDM_Demod -> ThreadedRingBuffer -> radio thread ->
+// BasicRadio::Process, fed from a cf32 file in arbitrary chunks like OFDM_Demodulator_Sink::run
+// (/root/reference/src/dab_module.cpp:20-28).  Writes the decoded FIBs / CRC flags / MSC bytes to files so a
+// test can compare them with what was transmitted.
+//
+//   dab_host_demo <iq.cf32> <out_prefix> [chunk_samples] [coarse_offset_cycles_per_sample] [bitrate start_cu level]
+#include <complex>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <memory>
+#include <thread>
+#include <vector>
+
+#include "app_helpers/app_io_buffers.h"
+#include "basic_radio/basic_radio.h"
+#include "dab/constants/dab_parameters.h"
+#include "ofdm/dab_mapper_ref.h"
+#include "ofdm/dab_ofdm_params_ref.h"
+#include "ofdm/dab_prs_ref.h"
+#include "ofdm/ofdm_demodulator.h"
+
+int main(int argc, char **argv) {
+    if (argc < 3) {
+        std::fprintf(stderr, "usage: %s iq.cf32 out_prefix [chunk] [coarse] [bitrate start_cu level]\n", argv[0]);
+        return 2;
+    }
+    const size_t chunk = argc > 3 ? size_t(std::atol(argv[3])) : 65536;
+    const float coarse = argc > 4 ? float(std::atof(argv[4])) : 0.0f;
+    constexpr int TRANSMISSION_MODE = 1;
+    const auto ofdm_params = get_DAB_OFDM_params(TRANSMISSION_MODE);
+    const auto dab_params = get_dab_parameters(TRANSMISSION_MODE);
+    auto prs = std::vector<std::complex<float>>(ofdm_params.nb_fft);
+    get_DAB_PRS_reference(TRANSMISSION_MODE, prs);
+    auto mapper = std::vector<int>(ofdm_params.nb_data_carriers);
+    get_DAB_mapper_ref(mapper, int(ofdm_params.nb_fft));
+
+    std::shared_ptr<OFDM_Demod> demod;
+    std::shared_ptr<BasicRadio> radio;
+    try {
+        demod = std::make_shared<OFDM_Demod>(ofdm_params, prs, mapper, 1);
+        radio = std::make_shared<BasicRadio>(dab_params, 1);
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "fatal: %s\n", e.what());
+        return 3;
+    }
+    demod->SetCoarseFrequencyOffset(coarse);
+    if (argc > 7) {
+        dabgpu_subchannel sc{};
+        sc.bitrate_kbps = std::atoi(argv[5]);
+        sc.start_address = std::atoi(argv[6]);
+        sc.protection_level = std::atoi(argv[7]);
+        sc.eep_type = 0;
+        const int n = sc.bitrate_kbps / 8;
+        const int lens[5] = {0, 12 * n, 8 * n, 6 * n, 4 * n};
+        sc.length = lens[sc.protection_level];
+        if (radio->AddSubchannel(sc) < 0) { std::fprintf(stderr, "bad subchannel\n"); return 4; }
+    }
+    const std::string prefix = argv[2];
+    std::ofstream f_fib(prefix + ".fib", std::ios::binary), f_crc(prefix + ".crc", std::ios::binary),
+        f_msc(prefix + ".msc", std::ios::binary);
+    radio->On_FIC().Attach([&](tcb::span<const uint8_t> fib, tcb::span<const uint8_t> ok) {
+        f_fib.write(reinterpret_cast<const char *>(fib.data()), std::streamsize(fib.size()));
+        f_crc.write(reinterpret_cast<const char *>(ok.data()), std::streamsize(ok.size()));
+    });
+    radio->On_MSC_Frame().Attach([&](int, tcb::span<const uint8_t> bytes) {
+        f_msc.write(reinterpret_cast<const char *>(bytes.data()), std::streamsize(bytes.size()));
+    });
+
+    auto ring = std::make_shared<ThreadedRingBuffer<viterbi_bit_t>>(size_t(dab_params.nb_frame_bits) * 2);
+    demod->On_OFDM_Frame().Attach([ring](tcb::span<const viterbi_bit_t> buf) { ring->write(buf); });
+    std::thread radio_thread([&]() {
+        auto data = std::vector<viterbi_bit_t>(size_t(dab_params.nb_frame_bits));
+        while (true) {
+            const size_t n = ring->read(data);
+            if (n != data.size()) break;
+            radio->Process(data);
+        }
+    });
+
+    std::ifstream in(argv[1], std::ios::binary);
+    if (!in) { std::fprintf(stderr, "cannot open %s\n", argv[1]); return 5; }
+    std::vector<std::complex<float>> buf(chunk);
+    while (in) {
+        in.read(reinterpret_cast<char *>(buf.data()), std::streamsize(chunk * sizeof(buf[0])));
+        const size_t got = size_t(in.gcount()) / sizeof(buf[0]);
+        if (!got) break;
+        demod->Process(tcb::span<std::complex<float>>(buf.data(), got));   // non-const span, as dab_module.cpp does
+    }
+    ring->close();
+    radio_thread.join();
+    std::printf("state=%d frames_read=%d frames_desync=%d fine=%.6g net=%.6g level=%.4f fibs=%d fib_errors=%d\n",
+                int(demod->GetState()), demod->GetTotalFramesRead(), demod->GetTotalFramesDesync(),
+                demod->GetFineFrequencyOffset() * OFDM_DEMOD_SAMPLING_RATE,
+                demod->GetNetFrequencyOffset() * OFDM_DEMOD_SAMPLING_RATE, demod->GetSignalAverage(),
+                radio->GetTotalFIBs(), radio->GetTotalFIBErrors());
+    return 0;
+}

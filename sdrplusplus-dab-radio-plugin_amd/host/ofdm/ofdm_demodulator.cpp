@@ -1,0 +1,163 @@
+// ofdm/ofdm_demodulator.cpp -- see the header.  Host work is O(samples) additions for the power detector and
+// memcpy into the frame buffer; every per-sample DSP operation of rows A2..A6 is inside libdabgpu.
+#include "ofdm/ofdm_demodulator.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <stdexcept>
+
+OFDM_Demod::OFDM_Demod(const OFDM_Params &params, tcb::span<const std::complex<float>> prs_fft_ref,
+                       tcb::span<const int> carrier_mapper, int /*nb_desired_threads*/)
+    : m_params(params), m_state(State::FINDING_NULL_POWER_DIP), m_ctx(nullptr) {
+    // the device tables are generated from the same constants; reject anything else loudly
+    dabgpu_ofdm_params ref;
+    if (dabgpu_get_ofdm_params(1, &ref) != DABGPU_OK || size_t(ref.nb_fft) != params.nb_fft ||
+        size_t(ref.nb_data_carriers) != params.nb_data_carriers || prs_fft_ref.size() != params.nb_fft ||
+        carrier_mapper.size() != params.nb_data_carriers)
+        throw std::runtime_error("OFDM_Demod: only DAB transmission mode I is supported");
+    std::vector<int32_t> mapper(params.nb_data_carriers);
+    dabgpu_get_mapper_reference(mapper.data(), int(mapper.size()), int(params.nb_fft));
+    for (size_t i = 0; i < mapper.size(); i++)
+        if (mapper[i] != carrier_mapper[i]) throw std::runtime_error("OFDM_Demod: carrier mapper differs from Mode I");
+    dabgpu_cfg cfg{0, 1, 1, 0};
+    const int rc = dabgpu_create(&cfg, &m_ctx);
+    if (rc != DABGPU_OK) throw std::runtime_error(std::string("OFDM_Demod: ") + dabgpu_strerror(rc));
+    m_frame.resize(params.nb_frame_symbols * params.nb_symbol_period);
+    m_soft.resize(size_t(params.nb_frame_symbols - 1) * params.nb_data_carriers * 2);
+    m_cyc.resize(params.nb_frame_symbols);
+    m_frame_data_vec.resize(size_t(params.nb_frame_symbols - 1) * params.nb_data_carriers);
+    Reset();
+}
+
+OFDM_Demod::~OFDM_Demod() { dabgpu_destroy(m_ctx); }
+
+void OFDM_Demod::Reset() {
+    m_state = State::FINDING_NULL_POWER_DIP;
+    m_signal_l1_average = 0.0f;
+    m_in_null = false;
+    m_null_blocks = 0;
+    m_history.clear();
+    m_frame_fill = 0;
+    m_skip = 0;
+    m_carry.clear();
+    m_freq_fine_offset = 0.0f;
+    m_freq_coarse_offset = 0.0f;
+    m_total_frames_read = 0;
+    m_total_frames_desync = 0;
+}
+
+void OFDM_Demod::Process(tcb::span<const std::complex<float>> block) {
+    const std::complex<float> *x = block.data();
+    size_t n = block.size();
+    // feed whole L1 blocks; keep the remainder for the next call (chunks are arbitrary, dab_module.cpp:23-25)
+    if (!m_carry.empty()) {
+        const size_t need = std::min(n, L1_BLOCK - m_carry.size());
+        m_carry.insert(m_carry.end(), x, x + need);
+        x += need;
+        n -= need;
+        if (m_carry.size() < L1_BLOCK) return;
+        push_sample_block(m_carry.data(), L1_BLOCK);
+        m_carry.clear();
+    }
+    const size_t whole = n - n % L1_BLOCK;
+    for (size_t i = 0; i < whole; i += L1_BLOCK) push_sample_block(x + i, L1_BLOCK);
+    m_carry.assign(x + whole, x + n);
+}
+
+void OFDM_Demod::push_sample_block(const std::complex<float> *x, size_t n) {
+    const size_t frame_len = m_frame.size();
+    if (m_state == State::READING_SYMBOLS) {
+        size_t i = 0;
+        if (m_skip) {
+            const size_t d = std::min(m_skip, n);
+            m_skip -= d;
+            i = d;
+        }
+        const size_t take = std::min(n - i, frame_len - m_frame_fill);
+        std::memcpy(m_frame.data() + m_frame_fill, x + i, take * sizeof(*x));
+        m_frame_fill += take;
+        if (m_frame_fill == frame_len) {
+            demodulate_frame();
+            // locked: the next PRS starts one null symbol after this frame's 76 symbols
+            m_frame_fill = 0;
+            m_skip = m_params.nb_null_period - (n - i - take);
+            if (m_skip > m_params.nb_null_period) m_skip = 0;   // (n-i-take) can never exceed a block
+        }
+        return;
+    }
+    // ---- acquisition: null-symbol power dip on the L1 norm ----
+    float l1 = 0.0f;
+    for (size_t i = 0; i < n; i++) l1 += std::fabs(x[i].real()) + std::fabs(x[i].imag());
+    l1 /= float(n);
+    // keep TIMING_MARGIN + one block of history so the frame can start before the detection point
+    m_history.insert(m_history.end(), x, x + n);
+    const size_t keep = TIMING_MARGIN + 2 * L1_BLOCK;
+    if (m_history.size() > keep) m_history.erase(m_history.begin(), m_history.end() - keep);
+
+    if (!m_in_null) {
+        if (m_signal_l1_average > 0.0f && l1 < m_cfg.null_l1_search.thresh_null_start * m_signal_l1_average) {
+            m_in_null = true;
+            m_null_blocks = 1;
+            m_state = State::READING_NULL_AND_PRS;
+        } else {
+            const float beta = m_cfg.signal_l1.update_beta;
+            m_signal_l1_average = (m_signal_l1_average == 0.0f) ? l1 : beta * m_signal_l1_average + (1.0f - beta) * l1;
+        }
+        return;
+    }
+    if (l1 > m_cfg.null_l1_search.thresh_null_end * m_signal_l1_average) {
+        // the PRS began somewhere inside this block (or the previous one): start TIMING_MARGIN samples
+        // before the START of this block
+        m_in_null = false;
+        const bool plausible = m_null_blocks * L1_BLOCK > m_params.nb_null_period / 2;
+        if (!plausible) {
+            m_state = State::FINDING_NULL_POWER_DIP;
+            return;
+        }
+        const size_t back = std::min(m_history.size(), TIMING_MARGIN + n);
+        std::memcpy(m_frame.data(), m_history.data() + (m_history.size() - back), back * sizeof(*x));
+        m_frame_fill = back;
+        m_skip = 0;
+        m_state = State::READING_SYMBOLS;
+    } else {
+        m_null_blocks++;
+        if (m_null_blocks * L1_BLOCK > 2 * m_params.nb_null_period) {   // not a null symbol: signal vanished
+            m_in_null = false;
+            m_signal_l1_average = 0.0f;
+            m_state = State::FINDING_NULL_POWER_DIP;
+        }
+    }
+}
+
+void OFDM_Demod::demodulate_frame() {
+    const float f = GetNetFrequencyOffset();
+    const int rc = dabgpu_ofdm_demod_frames(m_ctx, reinterpret_cast<const float *>(m_frame.data()), m_frame.size(), 1,
+                                            &f, m_soft.data(), reinterpret_cast<float *>(m_cyc.data()),
+                                            reinterpret_cast<float *>(m_frame_data_vec.data()));
+    if (rc != DABGPU_OK) {   // no exceptions on the streaming path: count it as a lost frame
+        m_total_frames_desync++;
+        m_state = State::FINDING_NULL_POWER_DIP;
+        return;
+    }
+    // fine frequency loop: mean cyclic-prefix phase -> residual offset in cycles/sample
+    double acc = 0.0;
+    for (const auto &c : m_cyc) acc += std::atan2(double(c.imag()), double(c.real()));
+    const float err = float(acc / double(m_cyc.size()) / (2.0 * M_PI * double(m_params.nb_fft)));
+    m_freq_fine_offset -= m_cfg.sync.fine_freq_update_beta * err;
+    const float half_carrier = 0.5f / float(m_params.nb_fft);
+    if (m_freq_fine_offset > half_carrier) m_freq_fine_offset -= 2 * half_carrier;
+    if (m_freq_fine_offset < -half_carrier) m_freq_fine_offset += 2 * half_carrier;
+    // desync check: the samples where the next null symbol should be are examined by the acquisition logic
+    // only after a loss; here the signal level of the frame is refreshed
+    float l1 = 0.0f;
+    for (size_t i = 0; i < 4096; i++) l1 += std::fabs(m_frame[i].real()) + std::fabs(m_frame[i].imag());
+    l1 /= 4096.0f;
+    if (l1 < m_cfg.null_l1_search.thresh_null_start * m_signal_l1_average) {
+        m_total_frames_desync++;
+        m_state = State::FINDING_NULL_POWER_DIP;
+        return;
+    }
+    m_total_frames_read++;
+    m_obs_on_ofdm_frame.Notify(tcb::span<const viterbi_bit_t>(m_soft.data(), m_soft.size()));
+}

@@ -1,0 +1,105 @@
+// ofdm/ofdm_demodulator.h -- host-side mirror of the reference's OFDM_Demod, backed by libdabgpu.
+//
+// Same names, argument meaning and error behaviour (void Process, no exceptions after construction) as the
+// class the plugin uses: ctor (/root/reference/src/radio_block.cpp:22), Process (src/dab_module.cpp:24-25),
+// On_OFDM_Frame (src/radio_block.cpp:25), and the getters the GUI reads
+// (src/render_radio_block.cpp:96, 109, 192-207, 213-235).
+//
+// Row A1 of SURVEY.md section 8a lives here on the host: chunk reassembly and frame synchronisation by the
+// null-symbol power dip.  Rows A2..A6 (everything per sample) run in dabgpu_ofdm_demod_frames on the GPU.
+// Differential demodulation is insensitive to a constant timing offset inside the cyclic prefix, so the
+// FFT windows are placed `TIMING_MARGIN` samples early and no fine-time search is needed for correctness;
+// coarse-frequency / fine-time search on the device is the "next" row.
+#pragma once
+#include <complex>
+#include <cstdint>
+#include <vector>
+#include "dabgpu.h"
+#include "ofdm/ofdm_params.h"
+#include "utility/observable.h"
+#include "utility/span.h"
+#include "viterbi_config.h"
+
+constexpr float OFDM_DEMOD_SAMPLING_RATE = 2.048e6f;   // src/render_radio_block.cpp:202
+
+struct OFDM_Demod_Config {
+    struct {
+        float update_beta = 0.95f;
+    } signal_l1;
+    struct {
+        float thresh_null_start = 0.35f;
+        float thresh_null_end = 0.75f;
+    } null_l1_search;
+    struct {
+        bool is_coarse_freq_correction = true;
+        float fine_freq_update_beta = 0.9f;
+        float max_coarse_freq_correction_norm = 0.1f;
+        float coarse_freq_slow_beta = 0.1f;
+        float impulse_peak_threshold_db = 20.0f;
+        float impulse_peak_distance_probability = 0.15f;
+    } sync;
+};
+
+class OFDM_Demod {
+public:
+    enum class State {
+        FINDING_NULL_POWER_DIP,
+        READING_NULL_AND_PRS,
+        RUNNING_COARSE_FREQ_SYNC,
+        RUNNING_FINE_TIME_SYNC,
+        READING_SYMBOLS
+    };
+
+    OFDM_Demod(const OFDM_Params &params, tcb::span<const std::complex<float>> prs_fft_ref,
+               tcb::span<const int> carrier_mapper, int nb_desired_threads = 0);
+    ~OFDM_Demod();
+    OFDM_Demod(const OFDM_Demod &) = delete;
+    OFDM_Demod &operator=(const OFDM_Demod &) = delete;
+
+    void Process(tcb::span<const std::complex<float>> block);
+    void Reset();
+
+    OFDM_Params GetOFDMParams() const { return m_params; }
+    State GetState() const { return m_state; }
+    float GetFineFrequencyOffset() const { return m_freq_fine_offset; }
+    float GetCoarseFrequencyOffset() const { return m_freq_coarse_offset; }
+    float GetNetFrequencyOffset() const { return m_freq_fine_offset + m_freq_coarse_offset; }
+    float GetSignalAverage() const { return m_signal_l1_average; }
+    int GetTotalFramesRead() const { return m_total_frames_read; }
+    int GetTotalFramesDesync() const { return m_total_frames_desync; }
+    OFDM_Demod_Config &GetConfig() { return m_cfg; }
+    tcb::span<const std::complex<float>> GetFrameDataVec() const { return m_frame_data_vec; }
+    Observable<tcb::span<const viterbi_bit_t>> &On_OFDM_Frame() { return m_obs_on_ofdm_frame; }
+
+    // extension: apply a known coarse offset (cycles/sample) until the device-side search exists
+    void SetCoarseFrequencyOffset(float f) { m_freq_coarse_offset = f; }
+
+private:
+    static constexpr size_t L1_BLOCK = 64;         // power measured in blocks of 64 samples
+    static constexpr size_t TIMING_MARGIN = 128;   // place FFT windows this many samples early (inside the CP)
+
+    void push_sample_block(const std::complex<float> *x, size_t n);
+    void demodulate_frame();
+
+    const OFDM_Params m_params;
+    OFDM_Demod_Config m_cfg;
+    State m_state;
+    dabgpu_ctx *m_ctx;
+    // sync state
+    float m_signal_l1_average;
+    bool m_in_null;
+    size_t m_null_blocks;
+    std::vector<std::complex<float>> m_history;     // last TIMING_MARGIN + block samples, to start a frame early
+    std::vector<std::complex<float>> m_frame;       // 76 * 2552 samples being assembled
+    size_t m_frame_fill;
+    size_t m_skip;                                  // samples to drop before the next frame starts
+    std::vector<std::complex<float>> m_carry;       // partial L1 block between Process calls
+    // tracking
+    float m_freq_fine_offset, m_freq_coarse_offset;
+    int m_total_frames_read, m_total_frames_desync;
+    // outputs
+    std::vector<viterbi_bit_t> m_soft;
+    std::vector<std::complex<float>> m_cyc;
+    std::vector<std::complex<float>> m_frame_data_vec;
+    Observable<tcb::span<const viterbi_bit_t>> m_obs_on_ofdm_frame;
+};
