@@ -53,40 +53,21 @@ def make_streams(torch, dev, n_ens, n_frames, n_unique, rank, snr_db):
 
 
 def cpu_baseline(iq_host, fo_host, sc_len_bits, mask, nsteps, budget_s, threads):
-    """Time the CPU oracle ('port') on the same workload: OFDM demod + FIC + 4 MSC logical
-    frames per transmission frame.  Bounded sample, all host cores (one frame per task)."""
-    from concurrent.futures import ThreadPoolExecutor
+    """Time the CPU oracle ('port', oracle/dab_oracle.c driven by oracle/oracle_bench.c) on the same workload:
+    OFDM demod + FIC + 4 MSC logical frames per transmission frame.  Bounded sample; one pthread per host core,
+    plus a single-thread figure (the reference plugin runs 1 OFDM + 1 decoder thread, dab_module.cpp:92)."""
     from oracle import oracle as O
-    O.lib()
     n = iq_host.shape[0]
-
-    def one(i):
-        soft, _, _, _ = O.ofdm_demod_frame(iq_host[i], float(fo_host[i]))
-        O.fic_decode(soft)
-        cif = soft[O.NB_FIC_BITS:].reshape(4, O.NB_CIF_BITS)[:, :sc_len_bits]
-        ring = np.ascontiguousarray(np.tile(cif, (4, 1)))        # 16 CIFs of history-shaped input
-        for _ in range(4):
-            de = O.time_deinterleave(ring)
-            O.msc_decode_lf(de, mask, nsteps)
-        return 1
-
-    t0 = time.perf_counter()
-    one(0)
-    per = time.perf_counter() - t0
-    total = int(max(threads, min(n * 64, budget_s * threads / max(per, 1e-4))))
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(threads) as ex:
-        list(ex.map(one, [i % n for i in range(total)]))
-    dt = time.perf_counter() - t0
-    t1 = time.perf_counter()
-    k1 = max(1, int(total / threads / 4))
-    for i in range(k1):
-        one(i % n)
-    dt1 = time.perf_counter() - t1
-    return {"value": total / dt, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": "%d frames (OFDM+FIC+64kbps EEP-3A MSC) of the bench input through oracle/dab_oracle.c, "
-                      "%d threads, %.1f s" % (total, threads, dt),
-            "single_core_value": k1 / dt1}
+    t1 = O.bench_frames(iq_host, fo_host, 8, 1, mask, nsteps, sc_len_bits)
+    per = t1 / 8
+    k1 = max(8, int(min(budget_s * 0.3, 4.0) / per))
+    t1 = O.bench_frames(iq_host, fo_host, k1, 1, mask, nsteps, sc_len_bits)
+    total = max(threads, int(budget_s * 0.7 / per) * threads)
+    tn = O.bench_frames(iq_host, fo_host, total, threads, mask, nsteps, sc_len_bits)
+    return {"value": total / tn, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": "%d frames (OFDM+FIC+64kbps EEP-3A MSC, %d distinct bench-input frames cycled) through "
+                      "oracle/dab_oracle.c on %d pthreads, %.1f s" % (total, n, threads, tn),
+            "single_core_value": k1 / t1}
 
 
 def main():

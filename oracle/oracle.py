@@ -28,7 +28,7 @@ NB_CIF_BITS = 55296
 
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
-    src = [os.path.join(_HERE, f) for f in ("dab_oracle.c", "dab_oracle.h")]
+    src = [os.path.join(_HERE, f) for f in ("dab_oracle.c", "dab_oracle.h", "oracle_bench.c")]
     stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src)
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
@@ -44,6 +44,7 @@ def lib():
         L.oracle_fic_puncture_mask.restype = C.c_int
         L.oracle_eep_puncture_mask.restype = C.c_int
         L.oracle_crc16.restype = C.c_uint16
+        L.oracle_bench_frames.restype = C.c_double
     return _LIB
 
 
@@ -170,3 +171,13 @@ def ofdm_demod_frame(iq, freq_offset=0.0, want_spectra=False, want_cyc=False, wa
                                   _p(cyc) if want_cyc else None,
                                   _p(dq) if want_dqpsk else None)
     return soft, spectra, cyc, dq
+
+
+def bench_frames(iq, freq_offset, total, threads, mask, nsteps, sc_bits):
+    """Wall seconds for `total` frames of the whole per-frame hot path over `threads` pthreads.
+    iq: complex64 [n_frames][76*2552]."""
+    a = np.ascontiguousarray(iq, np.complex64)
+    fo = np.ascontiguousarray(freq_offset, np.float32)
+    m = np.ascontiguousarray(mask, np.uint8)
+    return float(lib().oracle_bench_frames(_p(a), C.c_size_t(a.shape[1]), _p(fo), C.c_int(a.shape[0]), C.c_int(total),
+                                           C.c_int(threads), _p(m), C.c_int(nsteps), C.c_int(sc_bits)))
