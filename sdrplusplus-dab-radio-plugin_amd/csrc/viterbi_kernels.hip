@@ -200,27 +200,38 @@ __device__ __forceinline__ int lane_xchg(int m, int lane) {
 }
 
 struct RotTables {
-    int tab_cs[6];   // int8x4 signs giving  sigma * c   (sigma = -1 where the lane is the older-bit-1 predecessor)
-    int tab_c2[6];   // int8x4 signs giving  -2 * c
-    int sigma[6];
+    int tab_cs[6];    // int8x4 signs giving  +sigma * c  (sigma = -1 where the lane itself is the older-bit-1 predecessor)
+    int tab_ncs[6];   // int8x4 signs giving  -sigma * c
+    int thr[6];       // 0 where bit q of the lane is 0, -1 where it is 1 (strict-compare threshold, see rot_step)
 };
+
+// lanes whose bit q is set, q = 0..5
+__device__ __forceinline__ constexpr unsigned long long qmask(int q) {
+    return q == 0 ? 0xAAAAAAAAAAAAAAAAull : q == 1 ? 0xCCCCCCCCCCCCCCCCull : q == 2 ? 0xF0F0F0F0F0F0F0F0ull
+         : q == 3 ? 0xFF00FF00FF00FF00ull : q == 4 ? 0xFFFF0000FFFF0000ull : 0xFFFFFFFF00000000ull;
+}
 
 __device__ __forceinline__ int pack_i8x4(int a, int b, int c, int d) {
     return (a & 0xFF) | ((b & 0xFF) << 8) | ((c & 0xFF) << 16) | ((d & 0xFF) << 24);
 }
 
 // one trellis step at phase PH (= t mod 6); w = the step's four soft bits (wave-uniform)
+//   x = M_self + sigma*c, y = M_other - sigma*c are the two candidates of the state this lane holds next.
+//   Lanes with bit q clear are the older-bit-0 predecessor themselves: survivor bit = (y > x).
+//   Lanes with bit q set are the older-bit-1 predecessor:               survivor bit = (x > y) = !(y - x > -1).
+//   So one compare against a per-lane threshold (0 / -1) and an XOR with a constant lane mask gives the
+//   strict-greater rule for both; the bit is shifted into `dec` by an add-with-carry.
 template <int PH>
 __device__ __forceinline__ void rot_step(const RotTables &T, int lane, int w, int &metric, unsigned &dec) {
     constexpr int Q = 5 - PH;
-    const int cs = __builtin_amdgcn_sdot4(T.tab_cs[PH], w, 0, false);
-    const int c2 = __builtin_amdgcn_sdot4(T.tab_c2[PH], w, 0, false);
+    const int x = __builtin_amdgcn_sdot4(T.tab_cs[PH], w, metric, false);
     const int other = lane_xchg<(1 << Q)>(metric, lane);
-    const int x = metric + cs;
-    const int y = other - cs;
-    const int g = __mul24(T.sigma[PH], other - metric) + c2;   // candidate(older bit 1) - candidate(older bit 0)
+    const int y = __builtin_amdgcn_sdot4(T.tab_ncs[PH], w, other, false);
+    const int d = y - x;
     metric = max(x, y);
-    dec = (dec << 1) | (g > 0 ? 1u : 0u);
+    const unsigned long long m = __ballot(d > T.thr[PH]) ^ qmask(Q);
+    unsigned long long carry_out;
+    asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(dec), "=s"(carry_out) : "v"(dec), "s"(m));
 }
 
 template <class Fetch, Tail TAIL>
@@ -235,13 +246,20 @@ __global__ __launch_bounds__(WGV) void viterbi_rot_kernel(Fetch fetch, CodeTable
     const int nsteps = code.nsteps;
     const int nchunks = (nsteps - 6) / 96;
 
-    int8_t *mother = reinterpret_cast<int8_t *>(smem + size_t(wave) * lds_per_wave);
-    const int dec_off = (4 * nsteps + 255) & ~255;
-    unsigned *W = reinterpret_cast<unsigned *>(mother + dec_off);           // [ngroups][64]
+    // Per-wave LDS slab.  The survivor words W grow from the bottom (256 B per 32 steps) while the depunctured
+    // codeword is consumed from a region that starts half-way up W's final extent: a W row is only written after
+    // the codeword bytes it overlaps have been read (4 B/step consumed vs 8 B/step produced, offset = |W|/2).
+    unsigned char *slab = smem + size_t(wave) * lds_per_wave;
+    const int ngroups = (nsteps - 6) / 32 + 1;
+    const int mother_off = ngroups * 128;
+    const int mother_bytes = (4 * nsteps + 255) & ~255;
+    unsigned *W = reinterpret_cast<unsigned *>(slab);                        // [ngroups][64]
+    int8_t *mother = reinterpret_cast<int8_t *>(slab + mother_off);
     int *m4 = reinterpret_cast<int *>(mother);
+    uint8_t *out6 = slab + mother_off + mother_bytes;                        // [16*nchunks] six-bit groups
 
     // ---- A8: depuncture into LDS ----
-    for (int i = lane; i < dec_off / 4; i += 64) m4[i] = 0;
+    for (int i = lane; i < mother_bytes / 4; i += 64) m4[i] = 0;
     __syncthreads();
 #ifndef DAB_EXP_NO_DEPUNCT
     for (int i = lane; i < code.n_punct; i += 64) mother[code.mother_pos[i]] = fetch(cw, i);
@@ -255,10 +273,11 @@ __global__ __launch_bounds__(WGV) void viterbi_rot_kernel(Fetch fetch, CodeTable
         const int rot = (ph + 1) % 6;                                       // state held AFTER the step
         const int n = ((lane << rot) | (lane >> (6 - rot))) & 63;
         const int s0 = parity32(n & 109) ? 1 : -1, s1 = parity32(n & 79) ? 1 : -1, s2 = parity32(n & 83) ? 1 : -1;
-        const int sg = ((lane >> (5 - ph)) & 1) ? -1 : 1;
-        T.sigma[ph] = sg;
+        const int qb = (lane >> (5 - ph)) & 1;
+        const int sg = qb ? -1 : 1;
+        T.thr[ph] = -qb;
         T.tab_cs[ph] = pack_i8x4(sg * s0, sg * s1, sg * s2, sg * s0);
-        T.tab_c2[ph] = pack_i8x4(-2 * s0, -2 * s1, -2 * s2, -2 * s0);
+        T.tab_ncs[ph] = pack_i8x4(-sg * s0, -sg * s1, -sg * s2, -sg * s0);
     }
 
     // ---- A9 forward pass ----
@@ -272,8 +291,8 @@ __global__ __launch_bounds__(WGV) void viterbi_rot_kernel(Fetch fetch, CodeTable
 #endif
         const int a0 = cw0, a1 = cw1;
         const int tn = (c + 1) * 96;
-        cw0 = m4[tn + lane];                 // prefetch (the last one reads into W: harmless, unused)
-        cw1 = m4[tn + 64 + (lane & 31)];
+        cw0 = m4[min(tn + lane, nsteps - 1)];              // prefetch; clamped so it never leaves the codeword
+        cw1 = m4[min(tn + 64 + (lane & 31), nsteps - 1)];
 #pragma unroll
         for (int i = 0; i < 16; i++) {
 #define DAB_ROT_STEP(PH)                                                                         \
@@ -301,9 +320,10 @@ __global__ __launch_bounds__(WGV) void viterbi_rot_kernel(Fetch fetch, CodeTable
     __syncthreads();
 
     // ---- traceback in the lane domain, on the scalar unit ----
-    // end state 0 sits in lane 0 in every layout; going back over step t replaces bit q_t of the lane
-    // index by the survivor bit, and the bit it replaces is the decoded input bit of step t.
-    unsigned *outw = reinterpret_cast<unsigned *>(mother);                   // [nchunks*3] words, MSB = earliest bit
+    // End state 0 sits in lane 0 in every layout.  Going back over step t replaces bit q_t of the lane index by
+    // the survivor bit h_t, and h_t is the input bit of step t-6 (it becomes the oldest bit of the earlier
+    // state).  After the six steps of one phase cycle (q = 0,1,..,5 going backwards) the lane index therefore
+    // IS six consecutive decoded bits, earliest in bit 5: they are appended to the output six at a time.
     int l = 0;
     {
         const unsigned wv = W[nchunks * 3 * 64 + lane];
@@ -314,25 +334,23 @@ __global__ __launch_bounds__(WGV) void viterbi_rot_kernel(Fetch fetch, CodeTable
             const unsigned h = (sw >> (5 - r)) & 1u;
             l = (l & ~(1 << q)) | int(h << q);
         }
+        // l now holds the last six INFO bits (inputs of steps 96k-6 .. 96k-1), earliest in bit 5
     }
-#ifdef DAB_EXP_NO_TRACEBACK
-    for (int c = -1; c >= 0; c--) {
-#else
     for (int c = nchunks - 1; c >= 0; c--) {
-#endif
+        unsigned wv = 0;
 #pragma unroll
-        for (int gg = 2; gg >= 0; gg--) {
-            const unsigned wv = W[(c * 3 + gg) * 64 + lane];
-            unsigned word = 0;
+        for (int cyc = 15; cyc >= 0; cyc--) {
+            // entering: l = info bits [96c + 6*cyc, +6)
+            if (lane == 0) out6[c * 16 + cyc] = uint8_t(l);
 #pragma unroll
-            for (int r = 31; r >= 0; r--) {
-                const int q = 5 - ((32 * gg + r) % 6);
+            for (int ph = 5; ph >= 0; ph--) {
+                const int j = 6 * cyc + ph;                                    // step index inside the chunk
+                if ((j & 31) == 31 || j == 95) wv = W[(c * 3 + (j >> 5)) * 64 + lane];
+                const int q = 5 - ph;
                 const unsigned sw = unsigned(__builtin_amdgcn_readlane(int(wv), l));
-                const unsigned h = (sw >> (31 - r)) & 1u;
-                word |= unsigned((l >> q) & 1) << (31 - r);
+                const unsigned h = (sw >> (31 - (j & 31))) & 1u;
                 l = (l & ~(1 << q)) | int(h << q);
             }
-            if (lane == 0) outw[c * 3 + gg] = word;
         }
     }
     __syncthreads();
@@ -342,7 +360,10 @@ __global__ __launch_bounds__(WGV) void viterbi_rot_kernel(Fetch fetch, CodeTable
     uint8_t *bytes = reinterpret_cast<uint8_t *>(W);
     uint8_t *o = out + size_t(cw) * nbytes;
     for (int k = lane; k < nbytes; k += 64) {
-        unsigned v = (outw[k >> 2] >> (24 - 8 * (k & 3))) & 0xFFu;
+        // byte k = bits 8k..8k+7 = tail of six-bit group g and head of group g+1
+        const int g = (8 * k) / 6, off = 8 * k - 6 * g;                      // off in {0, 2, 4}
+        const unsigned two = (unsigned(out6[g]) << 6) | unsigned(out6[g + 1]);   // 12 bits (g+1 < 16*nchunks always)
+        unsigned v = (two >> (4 - off)) & 0xFFu;
         if (code.prbs_bytes) v ^= code.prbs_bytes[k];
         bytes[k] = uint8_t(v);
         if (active) o[k] = uint8_t(v);
@@ -362,7 +383,8 @@ __global__ __launch_bounds__(WGV) void viterbi_rot_kernel(Fetch fetch, CodeTable
 inline size_t viterbi_rot_lds_bytes(int nsteps) {
     const size_t mother = (size_t(4) * nsteps + 255) & ~size_t(255);
     const size_t groups = size_t((nsteps - 6) / 32 + 1);
-    return mother + groups * 256 + 512;     // +512: the prefetch past the last chunk stays inside the wave's slab
+    const size_t out6 = (size_t((nsteps - 6) / 6) + 255) & ~size_t(255);
+    return std::max(groups * 256, groups * 128 + mother + out6);
 }
 
 // history ring update: hist_out[s][h] = CIF (4F - 15 + h), h = 0..14
@@ -394,16 +416,36 @@ hipError_t launch_wave(Fetch f, const CodeTables &c, int n_codewords, uint8_t *o
     const bool rot = !force_v0 && c.nsteps >= 102 && (c.nsteps - 6) % 96 == 0 &&
                      viterbi_rot_lds_bytes(c.nsteps) * WAVES_PER_WG <= 160 * 1024;
     const size_t per_wave = rot ? viterbi_rot_lds_bytes(c.nsteps) : viterbi_wave_lds_bytes(c.nsteps);
-    const int lds_per_wave = int((per_wave + 255) & ~size_t(255));
-    const size_t lds = size_t(lds_per_wave) * WAVES_PER_WG;
+    int lds_per_wave = int((per_wave + 255) & ~size_t(255));
+    size_t lds = size_t(lds_per_wave) * WAVES_PER_WG;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
+    const unsigned grid = unsigned((n_codewords + WAVES_PER_WG - 1) / WAVES_PER_WG);
+    {
+        // Balance the grid over the CUs: with o_max workgroups resident per CU the dispatcher fills CUs greedily,
+        // so a grid that is not a multiple of o_max * CUs leaves some CUs with more co-resident (slower) waves
+        // than others.  Ask for just enough LDS that every CU holds the same number of workgroups per round.
+        static const int n_cu = [] {
+            int dev = 0, n = 256;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                n = prop.multiProcessorCount;
+            return n;
+        }();
+        const size_t cu_lds = 160 * 1024;
+        const unsigned o_max = unsigned(std::min<size_t>(cu_lds / lds, 8));
+        const unsigned rounds = (grid + o_max * n_cu - 1) / (o_max * n_cu);
+        const unsigned o_need = std::max(1u, (grid + rounds * n_cu - 1) / (rounds * n_cu));
+        if (o_need < o_max) {
+            const size_t padded = (cu_lds / o_need) & ~size_t(1023);
+            if (padded >= lds) { lds = padded; }
+        }
+    }
     const void *kern = rot ? reinterpret_cast<const void *>(viterbi_rot_kernel<Fetch, TAIL>)
                            : reinterpret_cast<const void *>(viterbi_wave_kernel<Fetch, TAIL>);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
         if (e != hipSuccess) return e;
     }
-    const unsigned grid = unsigned((n_codewords + WAVES_PER_WG - 1) / WAVES_PER_WG);
     if (rot)
         hipLaunchKernelGGL((viterbi_rot_kernel<Fetch, TAIL>), dim3(grid), dim3(WGV), lds, s, f, c, n_codewords, out,
                            crc_ok, lds_per_wave);
