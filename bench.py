@@ -3,7 +3,7 @@
 
 One step = one pass of the hot path over one batch of synthetic input that is already
 resident in HBM: `--ensembles` independent DAB ensembles per GPU x `--frames` consecutive
-transmission frames each (default 64 x 16 = 1024 frames, 1.6 GB of cf32 IQ).  Per step:
+transmission frames each (default 64 x 64 = 4096 frames, 6.4 GB of cf32 IQ).  Per step:
   dabgpu_ofdm_demod_frames_dev -> dabgpu_fic_decode_dev -> dabgpu_msc_decode_dev
 all through the C ABI (include/dabgpu.h) on the current torch stream.  torch is plumbing:
 device buffers, stream, events, and torch.distributed (RCCL) for the barrier / max-reduce.
@@ -58,25 +58,21 @@ def cpu_baseline(iq_host, fo_host, sc_len_bits, mask, nsteps, budget_s, threads)
     plus a single-thread figure (the reference plugin runs 1 OFDM + 1 decoder thread, dab_module.cpp:92)."""
     from oracle import oracle as O
     n = iq_host.shape[0]
-    t1 = O.bench_frames(iq_host, fo_host, 8, 1, mask, nsteps, sc_len_bits)
-    per = t1 / 8
-    k1 = max(8, int(min(budget_s * 0.3, 4.0) / per))
-    t1 = O.bench_frames(iq_host, fo_host, k1, 1, mask, nsteps, sc_len_bits)
-    total = max(threads, int(budget_s * 0.7 / per) * threads)
-    tn = O.bench_frames(iq_host, fo_host, total, threads, mask, nsteps, sc_len_bits)
+    k1, t1 = O.bench_frames_timed(iq_host, fo_host, min(4.0, budget_s * 0.3), 1, mask, nsteps, sc_len_bits)
+    total, tn = O.bench_frames_timed(iq_host, fo_host, budget_s * 0.7, threads, mask, nsteps, sc_len_bits)
     return {"value": total / tn, "unit": "frames/s", "cores": threads, "kind": "port",
             "sample": "%d frames (OFDM+FIC+64kbps EEP-3A MSC, %d distinct bench-input frames cycled) through "
-                      "oracle/dab_oracle.c on %d pthreads, %.1f s" % (total, n, threads, tn),
+                      "oracle/dab_oracle.c on %d pthreads in %.1f s" % (total, n, threads, tn),
             "single_core_value": k1 / t1}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--ensembles", type=int, default=64, help="independent ensembles per GPU")
-    ap.add_argument("--frames", type=int, default=16, help="consecutive frames per ensemble per step")
+    ap.add_argument("--frames", type=int, default=64, help="consecutive frames per ensemble per step (multiple of 4)")
     ap.add_argument("--unique", type=int, default=8, help="distinct synthetic multiplexes generated on the host")
     ap.add_argument("--snr", type=float, default=20.0)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
@@ -217,7 +213,7 @@ def main():
             k = min(n_frames, 64)
             iq_h = iq.reshape(n_frames, -1)[:k, synth.NB_NULL:].contiguous().cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(iq_h, fo[:k].cpu().numpy(), sc.length * 64, ens[0].mask,
-                                               64 * 24 + 6, args.cpu_seconds, os.cpu_count() or 1)
+                                               64 * 24 + 6, args.cpu_seconds, len(os.sched_getaffinity(0)) or 1)
         print(json.dumps(out))
     ctx.close()
     if dist is not None:

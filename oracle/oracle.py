@@ -45,6 +45,7 @@ def lib():
         L.oracle_eep_puncture_mask.restype = C.c_int
         L.oracle_crc16.restype = C.c_uint16
         L.oracle_bench_frames.restype = C.c_double
+        L.oracle_bench_frames_timed.restype = C.c_double
     return _LIB
 
 
@@ -181,3 +182,14 @@ def bench_frames(iq, freq_offset, total, threads, mask, nsteps, sc_bits):
     m = np.ascontiguousarray(mask, np.uint8)
     return float(lib().oracle_bench_frames(_p(a), C.c_size_t(a.shape[1]), _p(fo), C.c_int(a.shape[0]), C.c_int(total),
                                            C.c_int(threads), _p(m), C.c_int(nsteps), C.c_int(sc_bits)))
+
+
+def bench_frames_timed(iq, freq_offset, seconds, threads, mask, nsteps, sc_bits):
+    """Run the per-frame hot path on `threads` pthreads for about `seconds`; returns (frames_done, elapsed_s)."""
+    a = np.ascontiguousarray(iq, np.complex64)
+    fo = np.ascontiguousarray(freq_offset, np.float32)
+    m = np.ascontiguousarray(mask, np.uint8)
+    done = C.c_long(0)
+    el = lib().oracle_bench_frames_timed(_p(a), C.c_size_t(a.shape[1]), _p(fo), C.c_int(a.shape[0]), C.c_double(seconds),
+                                         C.c_int(threads), _p(m), C.c_int(nsteps), C.c_int(sc_bits), C.byref(done))
+    return int(done.value), float(el)
