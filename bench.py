@@ -187,7 +187,7 @@ def main():
                        "sharding": "independent ensembles per rank, no data-path collective"},
             "x_realtime": value / REALTIME_FPS,
             "fic_bit_exact": fic_ok, "msc_bit_exact": msc_ok,
-            "roofline": {"bound": "hbm", "kernel": "ofdm_kernel<fused>", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "dabk::ofdm_wave_kernel<false,false> (fused A2..A6)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "avg_launch_ms": ofdm_ms, "frames_per_launch": n_frames,
                          "algorithmic_bytes_per_frame": A_OFDM},
@@ -205,7 +205,7 @@ def main():
             torch.cuda.synchronize()
             fft_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
             ach = A_FFT * n_frames / (fft_ms * 1e-3) / 1e9
-            out["roofline_fft_stage"] = {"bound": "hbm", "kernel": "ofdm_kernel<fft_only>", "achieved": ach,
+            out["roofline_fft_stage"] = {"bound": "hbm", "kernel": "dabk::ofdm_wave_kernel<true,false> (FFT stage only)", "achieved": ach,
                                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                          "avg_launch_ms": fft_ms, "algorithmic_bytes_per_frame": A_FFT}
             del spectra
