@@ -88,12 +88,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a gfx950 GPU (libdabgpu has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    dev_index = local_rank % n_dev        # (== local_rank on a real multi-GPU node; lets a 1-GPU box run 2 test ranks)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
+    backend = os.environ.get("DABGPU_DIST_BACKEND", "nccl")      # "nccl" is RCCL on ROCm; "gloo" only for tests
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
 
     E, F = args.ensembles, args.frames
@@ -107,7 +114,7 @@ def main():
     hist = [torch.zeros((E, 15, sc.length * 64), dtype=torch.int8, device=dev) for _ in range(2)]
     cyc = torch.zeros((n_frames, 76), dtype=torch.complex64, device=dev)
 
-    ctx = dabgpu.Context(device=local_rank, max_frames=n_frames)
+    ctx = dabgpu.Context(device=dev_index, max_frames=n_frames)
     torch.cuda.synchronize()
     tstream = torch.cuda.Stream(device=dev)      # non-null handle: the C ABI treats NULL as "context stream"
     torch.cuda.set_stream(tstream)
@@ -159,7 +166,7 @@ def main():
         for t in range(0 if args.warmup + args.steps >= 2 else 15, F * 4):
             msc_ok &= bool((msc_h[s, t] == e.msc_bytes[(t - 15) % 16]).all())
     from dabgpu.shard import reduce_report
-    elapsed, frames_total, (fic_ok, msc_ok) = reduce_report(dist, dev, elapsed, n_frames * args.steps,
+    elapsed, frames_total, (fic_ok, msc_ok) = reduce_report(dist, red_dev, elapsed, n_frames * args.steps,
                                                             [fic_ok, msc_ok])
 
     ofdm_ms = float(np.mean([a.elapsed_time(b) for a, b in ofdm_ev]))
