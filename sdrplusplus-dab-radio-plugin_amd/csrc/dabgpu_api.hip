@@ -52,7 +52,7 @@ struct dabgpu_ctx {
     bool timing = false;
     Timer timers[4];
     int ofdm_parts_override = 0;
-    int wave_slots = 2048;       // resident OFDM wavefronts: 8 per CU
+    int wave_slots = 3072;       // resident OFDM wavefronts: 12 per CU
 };
 
 namespace {
@@ -242,7 +242,7 @@ int dabgpu_create(const dabgpu_cfg *cfg, dabgpu_ctx **out) {
     ctx->device = cfg->device;
     ctx->max_frames = cfg->max_frames;
     if (const char *g = std::getenv("DABGPU_OFDM_PARTS")) ctx->ofdm_parts_override = std::atoi(g);
-    ctx->wave_slots = prop.multiProcessorCount > 0 ? prop.multiProcessorCount * 8 : 2048;
+    ctx->wave_slots = prop.multiProcessorCount > 0 ? prop.multiProcessorCount * 12 : 3072;   // 3 workgroups x 4 waves per CU
     int rc = DABGPU_OK;
     do {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { rc = DABGPU_ERR_HIP; break; }
@@ -260,6 +260,7 @@ int dabgpu_create(const dabgpu_cfg *cfg, dabgpu_ctx **out) {
         // lane 0 register 0 holds bin 768 instead of DC
         std::vector<int> n_of_bin(NB_FFT, -1);
         for (int n = 0; n < NB_CARRIERS; n++) n_of_bin[bins[n]] = n;
+        // layout [12][64] dwords: dword (jj, v) = n(2jj, v) | n(2jj+1, v) << 16
         std::vector<uint16_t> nvj(24 * 64);
         bool ok = true;
         for (int j = 0; j < 24; j++)
@@ -267,7 +268,7 @@ int dabgpu_create(const dabgpu_cfg *cfg, dabgpu_ctx **out) {
                 int bin = v + 64 * (j < 12 ? j : j + 8);
                 if (j == 0 && v == 0) bin = 768;
                 if (n_of_bin[bin] < 0) ok = false;
-                nvj[j * 64 + v] = uint16_t(n_of_bin[bin] < 0 ? 0 : n_of_bin[bin]);
+                nvj[((j >> 1) * 64 + v) * 2 + (j & 1)] = uint16_t(n_of_bin[bin] < 0 ? 0 : n_of_bin[bin]);
             }
         if (!ok) { rc = DABGPU_ERR_PROFILE; break; }
         if ((rc = upload(&ctx->d_n_of_vj, nvj))) break;

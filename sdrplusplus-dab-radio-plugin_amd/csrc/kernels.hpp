@@ -10,7 +10,7 @@ namespace dabk {
 struct OfdmTables {
     const float2 *twiddle;     // [2048] exp(-2*pi*i*m/2048)
     const uint16_t *bin_of_n;  // [1536] FFT bin of data index n (mapper folded with carrier->bin)
-    const uint16_t *n_of_vj;   // [24][64] data index of carrier register j of lane v (wave kernel)
+    const uint16_t *n_of_vj;   // [12][64][2] data index of carrier registers 2jj, 2jj+1 of lane v (wave kernel)
 };
 
 struct OfdmArgs {

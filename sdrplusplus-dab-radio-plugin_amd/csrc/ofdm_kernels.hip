@@ -250,9 +250,11 @@ __global__ __launch_bounds__(WG) void ofdm_kernel(OfdmTables tab, OfdmArgs a, in
 constexpr int WAVES = DAB_OFDM_WAVES;
 
 struct WaveLds {
-    float2 tw[NB_FFT];           // exp(-2*pi*i*m/2048)
-    float2 ex[WAVES][NB_FFT];    // per-wave exchange buffer, reused as soft-bit staging
-};
+    float2 tw[NB_FFT];               // exp(-2*pi*i*m/2048)                                   16 KB
+    uint32_t nidx[12 * 64];          // frequency de-interleave table, two data indices per dword  3 KB
+    float2 ex[WAVES][NB_FFT / 2];    // per-wave exchange buffer (half a symbol per pass), reused
+                                     // as soft-bit staging                                    8 KB each
+};   // 51 KB per 4-wave workgroup -> 3 workgroups = 12 waves per CU
 
 __device__ __forceinline__ float2 cmul_k(float2 a, float c, float s) {   // a * (c + j*s)
     return make_float2(a.x * c - a.y * s, a.x * s + a.y * c);
@@ -319,18 +321,23 @@ __device__ __forceinline__ float wave_sum(float v, int lane) {
 }
 
 template <bool FFT_ONLY, bool WITH_DQPSK>
-__global__ __launch_bounds__(64 * WAVES, 2) void ofdm_wave_kernel(OfdmTables tab, OfdmArgs a, int parts, int n_items) {
+__global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab, OfdmArgs a, int parts, int n_items) {
     __shared__ WaveLds sm;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     for (int i = tid; i < NB_FFT; i += 64 * WAVES) sm.tw[i] = tab.twiddle[i];
+    for (int i = tid; i < 12 * 64; i += 64 * WAVES) sm.nidx[i] = reinterpret_cast<const uint32_t *>(tab.n_of_vj)[i];
     __syncthreads();
     const int item = blockIdx.x * WAVES + wave;
     if (item >= n_items) return;
     const int frame = item / parts;
     const int part = item - frame * parts;
     const float2 *fiq = a.iq + size_t(frame) * a.frame_stride;
+#ifdef DAB_OFDM_STAGGER
+    // de-phase the co-resident waves so that their load / FFT / LDS phases do not line up
+    for (int i = 0; i < (item % 12) * DAB_OFDM_STAGGER; i++) __builtin_amdgcn_s_sleep(32);
+#endif
 #ifdef DAB_EXP_NOPLL
     const uint32_t dphi = 0u;
 #else
@@ -345,21 +352,15 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ofdm_wave_kernel(OfdmTables tab
     // lane roles
     const int n2 = lane >> 2, p = lane & 3;            // step 1 (and k1 = n2, p' = p in step 2)
     const int k1v = lane & 15, kk = lane >> 4;         // step 3
-    // exchange-1 slots: n3*256 + k1*16 + (n2 ^ (n3/2)<<2 ^ (k1/2)&3)
-    const int w1_base = p * 512, w1_r = n2 ^ (p << 2);
-    // exchange-2 slots: n3*256 + k2*16 + (k1 ^ (n3/2)<<2)
-    const int w2_base = p * 512 + (n2 ^ (p << 2));
+    // exchange-1 slots (one pass per e = n3 & 1): (n3/2)*256 + k1*16 + (n2 ^ (n3/2)<<2 ^ (k1/2)&3)
+    const int w1_base = p * 256, w1_r = n2 ^ (p << 2);
+    // exchange-2 slots (one pass per half of k2): n3*128 + (k2 % 8)*16 + (k1 ^ (n3/2)<<2)
+    const int w2_base = p * 256 + (n2 ^ (p << 2));
     const int r2_base = kk * 16;
 
     // step-1 twiddles W256^(n2*k1) are the same for every symbol: keep them in registers? (30 VGPRs) -- no,
     // they are re-read from LDS per symbol; the table index is 8*n2*k1.
     // frequency de-interleave: data index of each carrier register (24 per lane)
-    uint32_t nidx2[12];          // two 16-bit data indices per register
-    if (!FFT_ONLY) {
-#pragma unroll
-        for (int j = 0; j < 12; j++)
-            nidx2[j] = uint32_t(tab.n_of_vj[(2 * j) * 64 + lane]) | (uint32_t(tab.n_of_vj[(2 * j + 1) * 64 + lane]) << 16);
-    }
     float2 prev[24];
 #pragma unroll
     for (int j = 0; j < 24; j++) prev[j] = make_float2(0.f, 0.f);
@@ -437,21 +438,16 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ofdm_wave_kernel(OfdmTables tab
             x0[k1] = cmul(x0[k1], t);
             x1[k1] = cmul(x1[k1], t);
         }
+        // ---- exchange 1 + step 2, one pass per column parity e (the buffer holds half a symbol) ----
+        const int r1b = pi * 256 + n2i * 16, r1x = (pi << 2) ^ ((n2i >> 1) & 3);
 #pragma unroll
-        for (int k1 = 0; k1 < 16; k1++) {
-            const int s = w1_base + k1 * 16 + (w1_r ^ ((k1 >> 1) & 3));
-            ex[s] = x0[k1];
-            ex[s + 256] = x1[k1];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- step 2: lane (k1 = n2, n3 = 2p + e) gathers over n2' ----
-        const int r1b = pi * 512 + n2i * 16, r1x = (pi << 2) ^ ((n2i >> 1) & 3);
+        for (int k1 = 0; k1 < 16; k1++) ex[w1_base + k1 * 16 + (w1_r ^ ((k1 >> 1) & 3))] = x0[k1];
 #pragma unroll
-        for (int m = 0; m < 16; m++) {
-            const int s = r1b + (m ^ r1x);
-            x0[m] = ex[s];
-            x1[m] = ex[s + 256];
-        }
+        for (int m = 0; m < 16; m++) x0[m] = ex[r1b + (m ^ r1x)];
+#pragma unroll
+        for (int k1 = 0; k1 < 16; k1++) ex[w1_base + k1 * 16 + (w1_r ^ ((k1 >> 1) & 3))] = x1[k1];
+#pragma unroll
+        for (int m = 0; m < 16; m++) x1[m] = ex[r1b + (m ^ r1x)];
         __builtin_amdgcn_sched_barrier(0);
         fft16(x0);
         __builtin_amdgcn_sched_barrier(0);
@@ -466,21 +462,26 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ofdm_wave_kernel(OfdmTables tab
                 x1[k2] = cmul(x1[k2], tw[i1 + st1 * k2]);
             }
         }
-#pragma unroll
-        for (int k2 = 0; k2 < 16; k2++) {
-            ex[w2_base + k2 * 16] = x0[k2];
-            ex[w2_base + k2 * 16 + 256] = x1[k2];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- step 3: lane v reads B[n3][k1v][4c+kk], four 8-point DFTs ----
+        // ---- exchange 2 + step 3 in two passes over k2 (k2 < 8, then k2 >= 8) ----
         float2 X[4][8];
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
+        for (int h = 0; h < 2; h++) {
 #pragma unroll
-            for (int n3 = 0; n3 < 8; n3++)
-                X[c][n3] = ex[n3 * 256 + c * 64 + r2_base + (k1v ^ ((n3 >> 1) << 2))];
-            fft8(X[c]);
+            for (int k2 = 0; k2 < 8; k2++) {
+                ex[w2_base + k2 * 16] = x0[8 * h + k2];
+                ex[w2_base + k2 * 16 + 128] = x1[8 * h + k2];
+            }
+            // lane v reads B[n3][k1v][k2 = 8h + 4c' + kk], c' = 0,1
+#pragma unroll
+            for (int cc = 0; cc < 2; cc++) {
+#pragma unroll
+                for (int n3 = 0; n3 < 8; n3++)
+                    X[2 * h + cc][n3] = ex[n3 * 128 + cc * 64 + r2_base + (k1v ^ ((n3 >> 1) << 2))];
+            }
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < 4; c++) fft8(X[c]);
         __builtin_amdgcn_sched_barrier(0);
         // bin of X[c][k3] is lane + 64*(c + 4*k3)
         if (FFT_ONLY) {
@@ -515,7 +516,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ofdm_wave_kernel(OfdmTables tab
                 const float sc = -127.00003f * __builtin_amdgcn_rcpf(Amax);
                 const int br = int(__builtin_amdgcn_fmed3f(d.x * sc, -127.0f, 127.0f));
                 const int bi = int(__builtin_amdgcn_fmed3f(d.y * sc, -127.0f, 127.0f));
-                const uint32_t ni = (j & 1) ? (nidx2[j >> 1] >> 16) : (nidx2[j >> 1] & 0xFFFFu);
+                const uint32_t nd = sm.nidx[(j >> 1) * 64 + lane];
+                const uint32_t ni = (j & 1) ? (nd >> 16) : (nd & 0xFFFFu);
                 stg[ni] = uint8_t(br);
                 stg[NB_CARRIERS + ni] = uint8_t(bi);
                 if constexpr (WITH_DQPSK) {
