@@ -150,6 +150,38 @@ int dabgpu_fft_symbols(dabgpu_ctx *ctx, const float *iq, size_t frame_stride, in
                        const float *freq_offset, float *spectra);
 
 /* ------------------------------------------------------------------------ */
+/* Frame synchronisation on the phase reference symbol.      */
+/* Replaces the RUNNING_COARSE_FREQ_SYNC and RUNNING_FINE_TIME_SYNC work of    */
+/* OFDM_Demod (/root/reference/src/render_radio_block.cpp:195-196) and its     */
+/* knobs is_coarse_freq_correction / max_coarse_freq_correction_norm /         */
+/* impulse_peak_threshold_db (:213-231).                                       */
+/*                                                                            */
+/* iq            candidate f starts at iq + f*frame_stride: the caller's guess */
+/*               of the FIRST sample of the PRS cyclic prefix; 2552 samples    */
+/*               are read.  16-byte aligned, frame_stride even.                */
+/* freq_offset   [n] correction applied before the search (NULL = none)        */
+/* max_coarse    search range in carriers, 0..1023                             */
+/* out[f].coarse_carriers  integer carrier offset k of the signal: apply       */
+/*               -k/2048 cycles/sample as coarse correction                    */
+/* out[f].time_offset      the PRS useful part starts at candidate + 504 +     */
+/*               time_offset samples (signed, -1024..1023)                     */
+/* out[f].peak_to_mean     impulse-response peak / mean power (threshold it    */
+/*               like impulse_peak_threshold_db)                               */
+/* out[f].coarse_peak_to_mean  same for the coarse correlation                 */
+/* ------------------------------------------------------------------------ */
+typedef struct dabgpu_sync_result {
+    int32_t coarse_carriers;
+    int32_t time_offset;
+    float peak_to_mean;
+    float coarse_peak_to_mean;
+} dabgpu_sync_result;
+
+int dabgpu_sync_prs_dev(dabgpu_ctx *ctx, const void *d_iq, size_t frame_stride, int n_frames,
+                        const float *d_freq_offset, int max_coarse, dabgpu_sync_result *d_out, void *stream);
+int dabgpu_sync_prs(dabgpu_ctx *ctx, const float *iq, size_t frame_stride, int n_frames, const float *freq_offset,
+                    int max_coarse, dabgpu_sync_result *out);
+
+/* ------------------------------------------------------------------------ */
 /* A7..A11: FIC.  Replaces the FIC branch of BasicRadio::Process              */
 /*   /root/reference/src/radio_block.cpp:42 (call), :60 (ctor).               */
 /* soft      frame f's bits start at soft + f*soft_stride; the first 9216 are  */

@@ -424,3 +424,87 @@ void oracle_ofdm_demod_frame(const float *iq, float freq_offset, int8_t *soft,
     }
     free(y); free(X[0]); free(X[1]); free(d);
 }
+
+/* ------------------------------------------------------------------------- */
+/* f-1: coarse frequency + fine time synchronisation on the PRS (see header).   */
+/* ------------------------------------------------------------------------- */
+void oracle_sync_prs(const float *sym, float freq_offset, int max_coarse, int32_t *k_out, int32_t *toff,
+                     float *peak_to_mean, float *coarse_peak_to_mean)
+{
+    const int32_t dphi = (int32_t)lrint((double)freq_offset * 4294967296.0);
+    float *y = (float *)malloc(sizeof(float) * 2 * DAB_NB_FFT);
+    float *X = (float *)malloc(sizeof(float) * 2 * DAB_NB_FFT);
+    float *Q = (float *)malloc(sizeof(float) * 2 * DAB_NB_FFT);
+    float *Z = (float *)malloc(sizeof(float) * 2 * DAB_NB_FFT);
+    float *H = (float *)malloc(sizeof(float) * 2 * DAB_NB_FFT);
+    float R[2 * DAB_NB_FFT];
+    int8_t qt[DAB_NB_FFT];              /* quarter turns of R per bin, -1 = not a carrier */
+    oracle_get_prs(R);
+    for (int b = 0; b < DAB_NB_FFT; b++) {
+        const float re = R[2 * b], im = R[2 * b + 1];
+        qt[b] = (re == 0.f && im == 0.f) ? -1 : (re > 0.5f ? 0 : (im > 0.5f ? 1 : (re < -0.5f ? 2 : 3)));
+    }
+    for (int n = 0; n < DAB_NB_FFT; n++) {
+        const uint32_t ph = (uint32_t)n * (uint32_t)dphi;
+        const double ang = 2.0 * M_PI * ((double)ph / 4294967296.0);
+        const float wr = (float)cos(ang), wi = (float)sin(ang);
+        const float xr = sym[2 * (DAB_NB_CP + n)], xi = sym[2 * (DAB_NB_CP + n) + 1];
+        y[2 * n] = xr * wr - xi * wi;
+        y[2 * n + 1] = xr * wi + xi * wr;
+    }
+    oracle_fft2048(y, X);
+    for (int b = 0; b < DAB_NB_FFT; b++) {
+        const int b1 = (b + 1) & (DAB_NB_FFT - 1);
+        const float ar = X[2 * b1], ai = X[2 * b1 + 1], br = X[2 * b], bi = X[2 * b + 1];
+        Q[2 * b] = ar * br + ai * bi;
+        Q[2 * b + 1] = ai * br - ar * bi;
+    }
+    /* coarse: scan k = -max..+max */
+    float best = -1.0f, sum = 0.0f;
+    int best_k = 0;
+    for (int k = -max_coarse; k <= max_coarse; k++) {
+        float dr = 0.f, di = 0.f;
+        for (int b = 0; b < DAB_NB_FFT - 1; b++) {
+            if (qt[b] < 0 || qt[b + 1] < 0) continue;
+            const int s = (qt[b + 1] - qt[b]) & 3;                 /* S[b] = j^s ; multiply Q by (-j)^s */
+            const int i = (b + k) & (DAB_NB_FFT - 1);
+            const float qr = Q[2 * i], qi = Q[2 * i + 1];
+            switch (s) {
+            case 0: dr += qr; di += qi; break;
+            case 1: dr += qi; di -= qr; break;
+            case 2: dr -= qr; di -= qi; break;
+            default: dr -= qi; di += qr; break;
+            }
+        }
+        const float m = dr * dr + di * di;
+        sum += m;
+        if (m > best) { best = m; best_k = k; }
+    }
+    *k_out = best_k;
+    *coarse_peak_to_mean = best / (sum / (float)(2 * max_coarse + 1));
+    /* fine time: |IFFT(Z)| == |FFT(conj Z)| index for index */
+    for (int b = 0; b < DAB_NB_FFT; b++) {
+        if (qt[b] < 0) { Z[2 * b] = 0.f; Z[2 * b + 1] = 0.f; continue; }
+        const int i = (b + best_k) & (DAB_NB_FFT - 1);
+        const float xr = X[2 * i], xi = X[2 * i + 1];
+        float zr, zi;                                              /* X * conj(R) = X * (-j)^qt */
+        switch (qt[b]) {
+        case 0: zr = xr; zi = xi; break;
+        case 1: zr = xi; zi = -xr; break;
+        case 2: zr = -xr; zi = -xi; break;
+        default: zr = -xi; zi = xr; break;
+        }
+        Z[2 * b] = zr; Z[2 * b + 1] = -zi;                          /* conj */
+    }
+    oracle_fft2048(Z, H);
+    float pk = -1.0f, tot = 0.0f;
+    int pi = 0;
+    for (int n = 0; n < DAB_NB_FFT; n++) {
+        const float m = H[2 * n] * H[2 * n] + H[2 * n + 1] * H[2 * n + 1];
+        tot += m;
+        if (m > pk) { pk = m; pi = n; }
+    }
+    *toff = (pi < DAB_NB_FFT / 2) ? pi : pi - DAB_NB_FFT;
+    *peak_to_mean = pk / (tot / (float)DAB_NB_FFT);
+    free(y); free(X); free(Q); free(Z); free(H);
+}

@@ -111,6 +111,20 @@ void oracle_fft2048(const float *in_cf32, float *out_cf32);  /* forward, unnorma
 void oracle_ofdm_demod_frame(const float *iq, float freq_offset, int8_t *soft,
                              float *spectra, float *cyc, float *dqpsk);
 
+/* ---- synchronisation on the phase reference symbol ----
+ * Stands behind the RUNNING_COARSE_FREQ_SYNC and RUNNING_FINE_TIME_SYNC states of OFDM_Demod
+ * (/root/reference/src/render_radio_block.cpp:195-196; knobs :213-231).
+ * sym: 2552 cf32 starting at the CANDIDATE first sample of the PRS cyclic prefix; the FFT window is taken at
+ * [504, 2552).  freq_offset is applied first (same NCO as the demodulator, n = 0 at the window start).
+ *   coarse: D_k = sum over adjacent carrier pairs b of Q[b+k] * conj(S[b]),  Q[b] = X[b+1] conj X[b],
+ *           S[b] = R[b+1] conj R[b];  *k = argmax |D_k|^2 over |k| <= max_coarse (first maximum scanning
+ *           k = -max..+max)
+ *   fine time: h = IFFT(X[b+k] conj R[b]);  *toff = argmax |h[n]|^2 as a signed offset (n >= 1024 -> n-2048):
+ *           the PRS useful part really starts at window start + *toff
+ *   *peak_to_mean = |h|^2 peak / mean,  *coarse_peak_to_mean = |D_k|^2 peak / mean over the scanned k */
+void oracle_sync_prs(const float *sym, float freq_offset, int max_coarse, int32_t *k, int32_t *toff,
+                     float *peak_to_mean, float *coarse_peak_to_mean);
+
 #ifdef __cplusplus
 }
 #endif

@@ -193,3 +193,13 @@ def bench_frames_timed(iq, freq_offset, seconds, threads, mask, nsteps, sc_bits)
     el = lib().oracle_bench_frames_timed(_p(a), C.c_size_t(a.shape[1]), _p(fo), C.c_int(a.shape[0]), C.c_double(seconds),
                                          C.c_int(threads), _p(m), C.c_int(nsteps), C.c_int(sc_bits), C.byref(done))
     return int(done.value), float(el)
+
+
+def sync_prs(sym, freq_offset=0.0, max_coarse=200):
+    """sym: complex64[2552] from the candidate PRS start -> (coarse_carriers, time_offset, peak_to_mean, coarse_ptm)."""
+    a = np.ascontiguousarray(sym, np.complex64)
+    assert a.size >= NB_SYM
+    k, t = C.c_int32(0), C.c_int32(0)
+    p, cp = C.c_float(0), C.c_float(0)
+    lib().oracle_sync_prs(_p(a), C.c_float(freq_offset), C.c_int(max_coarse), C.byref(k), C.byref(t), C.byref(p), C.byref(cp))
+    return k.value, t.value, p.value, cp.value

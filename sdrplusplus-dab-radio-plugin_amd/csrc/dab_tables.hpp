@@ -59,7 +59,10 @@ inline int carrier_bin(int i) {
 
 // ETSI clause 14.3.2: phase reference symbol; returns quarter-turn counts per bin
 // (-1 = unused bin) so callers can build cf32 or phases.
-inline std::vector<int8_t> make_prs_quarter_turns() {
+// (noinline + a volatile-free plain loop: hipcc's host pass was observed to mis-vectorise the inlined copy of
+// this function inside dabgpu_create -- rows indexed as H[i][j] instead of H[i][j % 16] -- while the copy in
+// dabgpu_get_prs_reference was correct; tests/test_sync.py now pins the device table against the oracle.)
+__attribute__((noinline)) inline std::vector<int8_t> make_prs_quarter_turns() {
     static const uint8_t H[4][16] = {
         {0, 2, 0, 0, 0, 0, 1, 1, 2, 0, 0, 0, 2, 2, 1, 1},
         {0, 3, 2, 3, 0, 1, 3, 0, 2, 1, 2, 3, 2, 3, 3, 0},
@@ -74,10 +77,12 @@ inline std::vector<int8_t> make_prs_quarter_turns() {
     std::vector<int8_t> q(NB_FFT, -1);
     for (int b = 0; b < 48; b++) {
         const int k0 = (b < 24) ? (-768 + 32 * b) : (1 + 32 * (b - 24));
-        for (int j = 0; j < 32; j++) {
-            const int k = k0 + j;
-            q[(k + NB_FFT) % NB_FFT] = int8_t((H[I_[b]][j & 15] + N_[b]) & 3);
-        }
+        const uint8_t *row = H[I_[b]];
+        for (int half = 0; half < 2; half++)          // the 32-entry row of the standard is the 16-entry row twice
+            for (int j = 0; j < 16; j++) {
+                const int k = k0 + 16 * half + j;
+                q[size_t((k + NB_FFT) % NB_FFT)] = int8_t((row[j] + N_[b]) & 3);
+            }
     }
     return q;
 }

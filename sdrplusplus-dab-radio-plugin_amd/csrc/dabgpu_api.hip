@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -44,6 +45,9 @@ struct dabgpu_ctx {
     float2 *d_twiddle = nullptr;
     uint16_t *d_bin_of_n = nullptr;
     uint16_t *d_n_of_vj = nullptr;
+    int8_t *d_prs_qt = nullptr;
+    uint16_t *d_sync_pairs = nullptr;
+    int n_sync_pairs = 0;
     DeviceCode fic;
     std::map<std::vector<uint8_t>, std::unique_ptr<DeviceCode>> codes;   // keyed by puncture mask
     // staging for the host-pointer entry points
@@ -272,6 +276,15 @@ int dabgpu_create(const dabgpu_cfg *cfg, dabgpu_ctx **out) {
             }
         if (!ok) { rc = DABGPU_ERR_PROFILE; break; }
         if ((rc = upload(&ctx->d_n_of_vj, nvj))) break;
+        {   // synchronisation tables: PRS quarter turns and the adjacent-carrier pair list
+            const std::vector<int8_t> qt = make_prs_quarter_turns();
+            std::vector<uint16_t> pairs;
+            for (int b = 0; b + 1 < NB_FFT; b++)
+                if (qt[b] >= 0 && qt[b + 1] >= 0) pairs.push_back(uint16_t(b | (((qt[b + 1] - qt[b]) & 3) << 11)));
+            ctx->n_sync_pairs = int(pairs.size());
+            if ((rc = upload(&ctx->d_prs_qt, qt))) break;
+            if ((rc = upload(&ctx->d_sync_pairs, pairs))) break;
+        }
         ctx->fic.prof = make_fic_profile();
         if (ctx->fic.prof.nsteps != NB_FIC_STEPS || ctx->fic.prof.n_punct != NB_FIC_GROUP_BITS) { rc = DABGPU_ERR_PROFILE; break; }
         if ((rc = build_device_code(ctx->fic))) break;
@@ -288,6 +301,8 @@ void dabgpu_destroy(dabgpu_ctx *ctx) {
     if (ctx->d_twiddle) (void)hipFree(ctx->d_twiddle);
     if (ctx->d_bin_of_n) (void)hipFree(ctx->d_bin_of_n);
     if (ctx->d_n_of_vj) (void)hipFree(ctx->d_n_of_vj);
+    if (ctx->d_prs_qt) (void)hipFree(ctx->d_prs_qt);
+    if (ctx->d_sync_pairs) (void)hipFree(ctx->d_sync_pairs);
     free_device_code(ctx->fic);
     for (auto &kv : ctx->codes) free_device_code(*kv.second);
     for (void *p : ctx->d_stage) if (p) (void)hipFree(p);
@@ -422,6 +437,43 @@ int dabgpu_fft_symbols(dabgpu_ctx *ctx, const float *iq, size_t frame_stride, in
     rc = dabgpu_fft_symbols_dev(ctx, d_iq, frame_stride, n_frames, static_cast<const float *>(d_fo), d_sp, s);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(spectra, d_sp, nb_sp, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return DABGPU_OK;
+}
+
+// ---------------------------------------------------------------------------- PRS sync
+static_assert(sizeof(dabgpu_sync_result) == sizeof(dabk::SyncResult), "ABI struct mirrors the kernel's");
+
+int dabgpu_sync_prs_dev(dabgpu_ctx *ctx, const void *d_iq, size_t frame_stride, int n_frames,
+                        const float *d_freq_offset, int max_coarse, dabgpu_sync_result *d_out, void *stream) {
+    if (!ctx || !d_iq || !d_out || n_frames < 0 || max_coarse < 0 || max_coarse > 1023) return DABGPU_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(d_iq) & 15u) || (frame_stride & 1u)) return DABGPU_ERR_ARG;
+    if (n_frames > 1 && frame_stride < size_t(NB_SYM_PERIOD)) return DABGPU_ERR_ARG;
+    if (n_frames == 0) return DABGPU_OK;
+    hipStream_t s = pick_stream(ctx, stream);
+    dabk::SyncTables tab{ctx->d_twiddle, ctx->d_prs_qt, ctx->d_sync_pairs, ctx->n_sync_pairs};
+    HIP_TRY(dabk::launch_prs_sync(tab, static_cast<const float2 *>(d_iq), frame_stride, n_frames, d_freq_offset,
+                                  max_coarse, reinterpret_cast<dabk::SyncResult *>(d_out), s));
+    return DABGPU_OK;
+}
+
+int dabgpu_sync_prs(dabgpu_ctx *ctx, const float *iq, size_t frame_stride, int n_frames, const float *freq_offset,
+                    int max_coarse, dabgpu_sync_result *out) {
+    if (!ctx || !iq || !out || n_frames < 0) return DABGPU_ERR_ARG;
+    if (n_frames == 0) return DABGPU_OK;
+    void *d_iq, *d_fo = nullptr, *d_out;
+    int rc;
+    const size_t nb_iq = (size_t(n_frames - 1) * frame_stride + NB_SYM_PERIOD) * sizeof(float2);
+    if ((rc = stage(ctx, 0, nb_iq, &d_iq))) return rc;
+    if ((rc = stage(ctx, 3, sizeof(dabgpu_sync_result) * n_frames, &d_out))) return rc;
+    if (freq_offset && (rc = stage(ctx, 2, sizeof(float) * n_frames, &d_fo))) return rc;
+    hipStream_t s = ctx->stream;
+    HIP_TRY(hipMemcpyAsync(d_iq, iq, nb_iq, hipMemcpyHostToDevice, s));
+    if (freq_offset) HIP_TRY(hipMemcpyAsync(d_fo, freq_offset, sizeof(float) * n_frames, hipMemcpyHostToDevice, s));
+    rc = dabgpu_sync_prs_dev(ctx, d_iq, frame_stride, n_frames, static_cast<const float *>(d_fo), max_coarse,
+                             static_cast<dabgpu_sync_result *>(d_out), s);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, d_out, sizeof(dabgpu_sync_result) * n_frames, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return DABGPU_OK;
 }

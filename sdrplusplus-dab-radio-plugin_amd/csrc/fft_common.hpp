@@ -1,0 +1,110 @@
+// fft_common.hpp -- device helpers shared by the OFDM and synchronisation kernels: complex arithmetic on
+// float2, radix-4/8 butterflies, the NCO phasor, and a 256-thread 2048-point Stockham FFT through LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+#include "dab_tables.hpp"
+
+namespace dabk {
+namespace {
+
+using namespace dab;
+
+constexpr int WG = 256;
+constexpr float SQRT1_2 = 0.70710678118654752440f;
+
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+// a * conj(b)
+__device__ __forceinline__ float2 cmulc(float2 a, float2 b) {
+    return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+// multiply by -j
+__device__ __forceinline__ float2 mul_mj(float2 a) { return make_float2(a.y, -a.x); }
+
+__device__ __forceinline__ void fft4(float2 &a, float2 &b, float2 &c, float2 &d) {
+    const float2 t0 = cadd(a, c), t1 = csub(a, c), t2 = cadd(b, d), t3 = mul_mj(csub(b, d));
+    a = cadd(t0, t2);
+    b = cadd(t1, t3);
+    c = csub(t0, t2);
+    d = csub(t1, t3);
+}
+
+// in-place 8-point forward DFT, natural order in and out
+__device__ __forceinline__ void fft8(float2 *v) {
+    float2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
+    float2 o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+    fft4(e0, e1, e2, e3);
+    fft4(o0, o1, o2, o3);
+    // W8^k * O[k]
+    o1 = make_float2((o1.x + o1.y) * SQRT1_2, (o1.y - o1.x) * SQRT1_2);   // (1-j)/sqrt2
+    o2 = mul_mj(o2);
+    o3 = make_float2((o3.y - o3.x) * SQRT1_2, -(o3.x + o3.y) * SQRT1_2);  // (-1-j)/sqrt2
+    v[0] = cadd(e0, o0); v[4] = csub(e0, o0);
+    v[1] = cadd(e1, o1); v[5] = csub(e1, o1);
+    v[2] = cadd(e2, o2); v[6] = csub(e2, o2);
+    v[3] = cadd(e3, o3); v[7] = csub(e3, o3);
+}
+
+// NCO: unit phasor for sample index n (relative to the first PRS sample).
+__device__ __forceinline__ float2 nco(uint32_t n, uint32_t dphi) {
+    const int32_t ph = int32_t(n * dphi);
+    const float rev2 = float(ph) * (1.0f / 2147483648.0f);   // 2 * revolutions in [-1,1)
+    float s, c;
+    sincospif(rev2, &s, &c);
+    return make_float2(c, s);
+}
+
+__device__ __forceinline__ uint32_t dphi_of(const float *freq_offset, int frame) {
+    if (!freq_offset) return 0u;
+    const long long q = __double2ll_rn(double(freq_offset[frame]) * 4294967296.0);
+    return uint32_t(q);
+}
+
+// One Stockham pass with radix 8 from LDS to LDS.
+template <int NS>
+__device__ __forceinline__ void pass8(const float2 *src, float2 *dst, const float2 *tw, int j) {
+    float2 v[8];
+    const int k = j & (NS - 1);
+#pragma unroll
+    for (int r = 0; r < 8; r++) v[r] = src[j + r * (NB_FFT / 8)];
+#pragma unroll
+    for (int r = 1; r < 8; r++) v[r] = cmul(v[r], tw[r * k * (NB_FFT / (NS * 8))]);
+    fft8(v);
+    const int j0 = (j - k) * 8 + k;
+#pragma unroll
+    for (int r = 0; r < 8; r++) dst[j0 + r * NS] = v[r];
+}
+
+
+// 2048-point forward FFT by one 256-thread workgroup.  Each thread passes its eight inputs x[tid + 256*r]
+// in v[]; the result lands in `out` (natural order).  t1 and out are 2048-entry LDS buffers (distinct), tw the
+// exp(-2*pi*i*m/2048) table in LDS.  Ends with a barrier.
+__device__ __forceinline__ void block_fft2048(float2 (&v)[8], float2 *t1, float2 *out, const float2 *tw, int tid) {
+    fft8(v);
+#pragma unroll
+    for (int r = 0; r < 8; r++) t1[tid * 8 + r] = v[r];
+    __syncthreads();
+    pass8<8>(t1, out, tw, tid);
+    __syncthreads();
+    pass8<64>(out, t1, tw, tid);
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int j = tid + h * WG;
+        float2 v0 = t1[j], v1 = t1[j + 512], v2 = t1[j + 1024], v3 = t1[j + 1536];
+        v1 = cmul(v1, tw[j]);
+        v2 = cmul(v2, tw[2 * j]);
+        v3 = cmul(v3, tw[3 * j]);
+        fft4(v0, v1, v2, v3);
+        out[j] = v0; out[j + 512] = v1; out[j + 1024] = v2; out[j + 1536] = v3;
+    }
+    __syncthreads();
+}
+
+}  // namespace
+}  // namespace dabk

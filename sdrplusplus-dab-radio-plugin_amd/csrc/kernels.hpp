@@ -30,6 +30,22 @@ hipError_t launch_ofdm_demod(const OfdmTables &t, const OfdmArgs &a, int parts, 
 // A2+A3 only; parts in 1..76.
 hipError_t launch_fft_symbols(const OfdmTables &t, const OfdmArgs &a, int parts, hipStream_t s);
 
+// ---- synchronisation on the PRS (sync_kernels.hip) -----------------------------
+struct SyncTables {
+    const float2 *twiddle;     // [2048]
+    const int8_t *prs_qt;      // [2048] quarter turns of the PRS per bin, -1 = not a carrier
+    const uint16_t *pairs;     // [n_pairs] adjacent carrier pairs: bin | ((qt[bin+1]-qt[bin])&3) << 11
+    int n_pairs;
+};
+struct SyncResult {            // == dabgpu_sync_result
+    int32_t coarse_carriers;
+    int32_t time_offset;
+    float peak_to_mean;
+    float coarse_peak_to_mean;
+};
+hipError_t launch_prs_sync(const SyncTables &t, const float2 *iq, size_t frame_stride, int n_frames,
+                           const float *freq_offset, int max_coarse, SyncResult *out, hipStream_t s);
+
 // ---- channel decoder (viterbi_kernels.hip) ---------------------------------
 struct CodeTables {
     const uint16_t *mother_pos;  // [n_punct] mother-bit position of punctured bit i

@@ -19,6 +19,7 @@
 
 #include "kernels.hpp"
 #include "dab_tables.hpp"
+#include "fft_common.hpp"
 
 namespace dabk {
 
@@ -26,81 +27,12 @@ using namespace dab;
 
 namespace {
 
-constexpr int WG = 256;
-constexpr float SQRT1_2 = 0.70710678118654752440f;
-
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
-}
-// a * conj(b)
-__device__ __forceinline__ float2 cmulc(float2 a, float2 b) {
-    return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
-}
-// multiply by -j
-__device__ __forceinline__ float2 mul_mj(float2 a) { return make_float2(a.y, -a.x); }
-
-__device__ __forceinline__ void fft4(float2 &a, float2 &b, float2 &c, float2 &d) {
-    const float2 t0 = cadd(a, c), t1 = csub(a, c), t2 = cadd(b, d), t3 = mul_mj(csub(b, d));
-    a = cadd(t0, t2);
-    b = cadd(t1, t3);
-    c = csub(t0, t2);
-    d = csub(t1, t3);
-}
-
-// in-place 8-point forward DFT, natural order in and out
-__device__ __forceinline__ void fft8(float2 *v) {
-    float2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
-    float2 o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
-    fft4(e0, e1, e2, e3);
-    fft4(o0, o1, o2, o3);
-    // W8^k * O[k]
-    o1 = make_float2((o1.x + o1.y) * SQRT1_2, (o1.y - o1.x) * SQRT1_2);   // (1-j)/sqrt2
-    o2 = mul_mj(o2);
-    o3 = make_float2((o3.y - o3.x) * SQRT1_2, -(o3.x + o3.y) * SQRT1_2);  // (-1-j)/sqrt2
-    v[0] = cadd(e0, o0); v[4] = csub(e0, o0);
-    v[1] = cadd(e1, o1); v[5] = csub(e1, o1);
-    v[2] = cadd(e2, o2); v[6] = csub(e2, o2);
-    v[3] = cadd(e3, o3); v[7] = csub(e3, o3);
-}
-
-// NCO: unit phasor for sample index n (relative to the first PRS sample).
-__device__ __forceinline__ float2 nco(uint32_t n, uint32_t dphi) {
-    const int32_t ph = int32_t(n * dphi);
-    const float rev2 = float(ph) * (1.0f / 2147483648.0f);   // 2 * revolutions in [-1,1)
-    float s, c;
-    sincospif(rev2, &s, &c);
-    return make_float2(c, s);
-}
-
-__device__ __forceinline__ uint32_t dphi_of(const float *freq_offset, int frame) {
-    if (!freq_offset) return 0u;
-    const long long q = __double2ll_rn(double(freq_offset[frame]) * 4294967296.0);
-    return uint32_t(q);
-}
-
 struct Smem {
     float2 tw[NB_FFT];
     float2 t1[NB_FFT];
     float2 x[2][NB_FFT];
     float2 red[4];
 };
-
-// One Stockham pass with radix 8 from LDS to LDS.
-template <int NS>
-__device__ __forceinline__ void pass8(const float2 *src, float2 *dst, const float2 *tw, int j) {
-    float2 v[8];
-    const int k = j & (NS - 1);
-#pragma unroll
-    for (int r = 0; r < 8; r++) v[r] = src[j + r * (NB_FFT / 8)];
-#pragma unroll
-    for (int r = 1; r < 8; r++) v[r] = cmul(v[r], tw[r * k * (NB_FFT / (NS * 8))]);
-    fft8(v);
-    const int j0 = (j - k) * 8 + k;
-#pragma unroll
-    for (int r = 0; r < 8; r++) dst[j0 + r * NS] = v[r];
-}
 
 template <bool FFT_ONLY>
 __global__ __launch_bounds__(WG) void ofdm_kernel(OfdmTables tab, OfdmArgs a, int parts) {

@@ -31,7 +31,7 @@ EXPORTS = [
     "dabgpu_sync", "dabgpu_stream", "dabgpu_ofdm_demod_frames_dev", "dabgpu_ofdm_demod_frames",
     "dabgpu_fft_symbols_dev", "dabgpu_fft_symbols", "dabgpu_fic_decode_dev", "dabgpu_fic_decode",
     "dabgpu_subchannel_bytes", "dabgpu_msc_decode_dev", "dabgpu_msc_decode", "dabgpu_viterbi_dev",
-    "dabgpu_viterbi", "dabgpu_set_timing", "dabgpu_last_kernel_ms",
+    "dabgpu_viterbi", "dabgpu_set_timing", "dabgpu_last_kernel_ms", "dabgpu_sync_prs_dev", "dabgpu_sync_prs",
 ]
 
 
@@ -57,6 +57,11 @@ class DabParams(C.Structure):
 class Cfg(C.Structure):
     _fields_ = [("device", C.c_int32), ("max_frames", C.c_int32), ("transmission_mode", C.c_int32),
                 ("flags", C.c_int32)]
+
+
+class SyncResult(C.Structure):
+    _fields_ = [("coarse_carriers", C.c_int32), ("time_offset", C.c_int32), ("peak_to_mean", C.c_float),
+                ("coarse_peak_to_mean", C.c_float)]
 
 
 class Subchannel(C.Structure):
@@ -100,6 +105,8 @@ def lib():
         L.dabgpu_viterbi_dev.argtypes = [vp, vp, i, vp, i, vp, vp]
         L.dabgpu_viterbi.argtypes = [vp, vp, i, vp, i, vp]
         L.dabgpu_set_timing.argtypes = [vp, i]
+        L.dabgpu_sync_prs_dev.argtypes = [vp, vp, sz, i, vp, i, vp, vp]
+        L.dabgpu_sync_prs.argtypes = [vp, vp, sz, i, vp, i, vp]
         L.dabgpu_last_kernel_ms.argtypes = [vp, i, C.POINTER(C.c_float)]
         L.dabgpu_get_prs_reference.argtypes = [i, vp, i]
         L.dabgpu_get_mapper_reference.argtypes = [vp, i, i]
@@ -217,6 +224,17 @@ class Context:
         fo = None if freq_offset is None else np.ascontiguousarray(freq_offset, np.float32)
         out = np.zeros((n_frames, NB_SYMBOLS, NB_FFT), np.complex64)
         _check(lib().dabgpu_fft_symbols(self._h, _p(iq), stride, n_frames, _p(fo), _p(out)), "dabgpu_fft_symbols")
+        return out
+
+    def sync_prs(self, iq, freq_offset=None, max_coarse=200):
+        """iq: complex64 [n][>=2552], row f starting at the candidate first sample of the PRS cyclic prefix.
+        -> structured array with coarse_carriers, time_offset, peak_to_mean, coarse_peak_to_mean."""
+        iq = np.ascontiguousarray(iq, np.complex64)
+        n, stride = iq.shape
+        fo = None if freq_offset is None else np.ascontiguousarray(freq_offset, np.float32)
+        out = np.zeros(n, dtype=[("coarse_carriers", np.int32), ("time_offset", np.int32),
+                                 ("peak_to_mean", np.float32), ("coarse_peak_to_mean", np.float32)])
+        _check(lib().dabgpu_sync_prs(self._h, _p(iq), stride, n, _p(fo), max_coarse, _p(out)), "dabgpu_sync_prs")
         return out
 
     def fic_decode(self, soft):
