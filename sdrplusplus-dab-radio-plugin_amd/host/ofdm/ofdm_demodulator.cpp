@@ -40,6 +40,9 @@ void OFDM_Demod::Reset() {
     m_history.clear();
     m_frame_fill = 0;
     m_skip = 0;
+    m_is_acquiring = true;
+    m_last_time_offset = 0;
+    m_last_peak_db = 0.0f;
     m_carry.clear();
     m_freq_fine_offset = 0.0f;
     m_freq_coarse_offset = 0.0f;
@@ -79,10 +82,10 @@ void OFDM_Demod::push_sample_block(const std::complex<float> *x, size_t n) {
         m_frame_fill += take;
         if (m_frame_fill == frame_len) {
             demodulate_frame();
-            // locked: the next PRS starts one null symbol after this frame's 76 symbols
+            // locked: the next PRS starts one null symbol (+/- the timing correction) after this frame's symbols
             m_frame_fill = 0;
-            m_skip = m_params.nb_null_period - (n - i - take);
-            if (m_skip > m_params.nb_null_period) m_skip = 0;   // (n-i-take) can never exceed a block
+            const size_t used = n - i - take;                  // rest of this block already belongs to the gap
+            m_skip = m_next_skip > used ? m_next_skip - used : 0;
         }
         return;
     }
@@ -119,6 +122,7 @@ void OFDM_Demod::push_sample_block(const std::complex<float> *x, size_t n) {
         std::memcpy(m_frame.data(), m_history.data() + (m_history.size() - back), back * sizeof(*x));
         m_frame_fill = back;
         m_skip = 0;
+        m_is_acquiring = true;
         m_state = State::READING_SYMBOLS;
     } else {
         m_null_blocks++;
@@ -130,7 +134,46 @@ void OFDM_Demod::push_sample_block(const std::complex<float> *x, size_t n) {
     }
 }
 
+// Coarse frequency + fine time on the frame's PRS (GPU).  Returns false when the frame must be dropped.
+bool OFDM_Demod::synchronise_frame() {
+    const float fine = m_freq_fine_offset + (m_is_acquiring ? 0.0f : m_freq_coarse_offset);
+    int max_coarse = 0;
+    if (m_is_acquiring && m_cfg.sync.is_coarse_freq_correction)
+        max_coarse = std::min(1023, int(m_cfg.sync.max_coarse_freq_correction_norm * float(m_params.nb_fft)));
+    dabgpu_sync_result res;
+    m_state = m_is_acquiring ? State::RUNNING_COARSE_FREQ_SYNC : State::RUNNING_FINE_TIME_SYNC;
+    if (dabgpu_sync_prs(m_ctx, reinterpret_cast<const float *>(m_frame.data()), m_frame.size(), 1, &fine, max_coarse,
+                        &res) != DABGPU_OK)
+        return false;
+    m_last_time_offset = res.time_offset;
+    m_last_peak_db = 10.0f * std::log10(std::max(res.peak_to_mean, 1e-9f));
+    if (m_last_peak_db < m_cfg.sync.impulse_peak_threshold_db) return false;      // not a PRS: false lock / lost
+    if (m_is_acquiring) {
+        m_freq_coarse_offset = -float(res.coarse_carriers) / float(m_params.nb_fft);
+        m_is_acquiring = false;
+    }
+    // keep the FFT windows TIMING_MARGIN samples inside the cyclic prefix: time_offset is how early this frame's
+    // windows are; steer the start of the next frame (never by more than a few samples once locked)
+    const int err = res.time_offset - int(TIMING_MARGIN);
+    const long skip = long(m_params.nb_null_period) + err;
+    m_next_skip = size_t(std::max(0L, skip));
+    // windows outside the cyclic prefix (late, or more than a CP early) cannot be demodulated
+    return res.time_offset >= 0 && res.time_offset <= int(m_params.nb_cyclic_prefix) - 16;
+}
+
 void OFDM_Demod::demodulate_frame() {
+    m_next_skip = m_params.nb_null_period;
+    if (!synchronise_frame()) {
+        m_total_frames_desync++;
+        if (m_last_peak_db < m_cfg.sync.impulse_peak_threshold_db) {
+            m_state = State::FINDING_NULL_POWER_DIP;
+            m_in_null = false;
+            return;
+        }
+        m_state = State::READING_SYMBOLS;      // timing was off: the next frame starts at the corrected position
+        return;
+    }
+    m_state = State::READING_SYMBOLS;
     const float f = GetNetFrequencyOffset();
     const int rc = dabgpu_ofdm_demod_frames(m_ctx, reinterpret_cast<const float *>(m_frame.data()), m_frame.size(), 1,
                                             &f, m_soft.data(), reinterpret_cast<float *>(m_cyc.data()),

@@ -5,11 +5,12 @@
 // On_OFDM_Frame (src/radio_block.cpp:25), and the getters the GUI reads
 // (src/render_radio_block.cpp:96, 109, 192-207, 213-235).
 //
-// Row A1 of SURVEY.md section 8a lives here on the host: chunk reassembly and frame synchronisation by the
-// null-symbol power dip.  Rows A2..A6 (everything per sample) run in dabgpu_ofdm_demod_frames on the GPU.
-// Differential demodulation is insensitive to a constant timing offset inside the cyclic prefix, so the
-// FFT windows are placed `TIMING_MARGIN` samples early and no fine-time search is needed for correctness;
-// coarse-frequency / fine-time search on the device is the "next" row.
+// Row A1 of SURVEY.md section 8a lives here on the host: chunk reassembly and the null-symbol power-dip search.
+// Everything per sample runs on the GPU: rows A2..A6 in dabgpu_ofdm_demod_frames, and the coarse-frequency /
+// fine-time search on the phase reference symbol (section 8f-1) in dabgpu_sync_prs, which is run on every
+// frame's PRS: at acquisition it sets the coarse offset and rejects false locks (impulse_peak_threshold_db),
+// afterwards it tracks timing drift.  Differential demodulation is insensitive to a constant timing offset
+// inside the cyclic prefix, so the FFT windows are kept `TIMING_MARGIN` samples early.
 #pragma once
 #include <complex>
 #include <cstdint>
@@ -73,6 +74,8 @@ public:
 
     // extension: apply a known coarse offset (cycles/sample) until the device-side search exists
     void SetCoarseFrequencyOffset(float f) { m_freq_coarse_offset = f; }
+    int GetFineTimeOffset() const { return m_last_time_offset; }
+    float GetImpulsePeakDb() const { return m_last_peak_db; }
 
 private:
     static constexpr size_t L1_BLOCK = 64;         // power measured in blocks of 64 samples
@@ -80,6 +83,7 @@ private:
 
     void push_sample_block(const std::complex<float> *x, size_t n);
     void demodulate_frame();
+    bool synchronise_frame();
 
     const OFDM_Params m_params;
     OFDM_Demod_Config m_cfg;
@@ -93,6 +97,10 @@ private:
     std::vector<std::complex<float>> m_frame;       // 76 * 2552 samples being assembled
     size_t m_frame_fill;
     size_t m_skip;                                  // samples to drop before the next frame starts
+    size_t m_next_skip;                             // null-symbol gap to the next frame incl. timing correction
+    bool m_is_acquiring;                            // first frame after a null detection: coarse sync + lock check
+    int m_last_time_offset;
+    float m_last_peak_db;
     std::vector<std::complex<float>> m_carry;       // partial L1 block between Process calls
     // tracking
     float m_freq_fine_offset, m_freq_coarse_offset;

@@ -34,7 +34,8 @@ def test_reference_radio_block_compiles_unchanged(host_built):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("chunk,cfo", [(65536, 0.0), (10007, 0.23 / 2048), (196608 * 2 + 13, -0.31 / 2048)])
+@pytest.mark.parametrize("chunk,cfo", [(65536, 0.0), (10007, 0.23 / 2048), (196608 * 2 + 13, -0.31 / 2048),
+                                       (32768, 7.3 / 2048), (50001, -41.8 / 2048)])
 def test_demo_recovers_transmitted_data(host_built, tmp_path, chunk, cfo):
     n_frames = 8
     ens = synth.Ensemble(seed=77, n_frames=n_frames)
@@ -52,6 +53,9 @@ def test_demo_recovers_transmitted_data(host_built, tmp_path, chunk, cfo):
     crc = np.fromfile(prefix + ".crc", np.uint8).reshape(-1, 12)
     msc = np.fromfile(prefix + ".msc", np.uint8).reshape(-1, 192)
     assert "frames_desync=0" in r.stdout, r.stdout
+    # coarse offset found on the PRS by dabgpu_sync_prs (integer carriers), fine loop takes the rest
+    net_hz = float(r.stdout.split("net=")[1].split()[0])
+    assert abs(net_hz + cfo * 2.048e6) < 30.0, r.stdout
     assert fib.shape[0] == n_frames, r.stdout            # every frame after the leading fragment
     # the fine-frequency loop starts at 0 and converges within a frame or two; once CRCs pass, data is exact
     good = crc.all(axis=1)
