@@ -227,6 +227,16 @@ int dabgpu_msc_decode(dabgpu_ctx *ctx, const dabgpu_subchannel *sc, const int8_t
                       size_t soft_stride, int n_streams, int frames_per_stream,
                       const int8_t *history_in, int8_t *history_out, uint8_t *out);
 
+/* Whole-ensemble variant: decode `n_subchannels` subchannels of the same frames in one
+ * call (all on one stream; EEP-A and EEP-B profiles, UEP not built).  Per subchannel i:
+ *   history_in[i] / history_out[i]   as above, may be NULL pointers inside the arrays
+ *   out[i]                           [n_streams][frames_per_stream*4][bitrate_i*3]
+ * The three pointer arrays are HOST arrays of DEVICE pointers.  Subchannels must not overlap in the CIF. */
+int dabgpu_msc_decode_multi_dev(dabgpu_ctx *ctx, const dabgpu_subchannel *sc, int n_subchannels,
+                                const int8_t *d_soft, size_t soft_stride, int n_streams, int frames_per_stream,
+                                const int8_t *const *d_history_in, int8_t *const *d_history_out,
+                                uint8_t *const *d_out, void *stream);
+
 /* ------------------------------------------------------------------------ */
 /* A9 on its own: batched punctured soft Viterbi (K=7, rate 1/4).             */
 /* Replaces the `viterbi` package (/root/reference/CMakeLists.txt:53-54).     */

@@ -539,7 +539,7 @@ int dabgpu_msc_decode_dev(dabgpu_ctx *ctx, const dabgpu_subchannel *sc, const in
     int rc = subchannel_profile(sc, prof);
     if (rc) return rc;
     if (n_streams == 0 || frames_per_stream == 0) return DABGPU_OK;
-    if (dabk::viterbi_wave_lds_bytes(prof.nsteps) * 4 > 160 * 1024) return DABGPU_ERR_CAPACITY;
+    if (!dabk::viterbi_fits(prof.nsteps)) return DABGPU_ERR_CAPACITY;
     DeviceCode *dc = nullptr;
     if ((rc = get_code(ctx, std::move(prof), &dc))) return rc;
     hipStream_t s = pick_stream(ctx, stream);
@@ -588,12 +588,38 @@ int dabgpu_msc_decode(dabgpu_ctx *ctx, const dabgpu_subchannel *sc, const int8_t
     return DABGPU_OK;
 }
 
+int dabgpu_msc_decode_multi_dev(dabgpu_ctx *ctx, const dabgpu_subchannel *sc, int n_subchannels,
+                                const int8_t *d_soft, size_t soft_stride, int n_streams, int frames_per_stream,
+                                const int8_t *const *d_history_in, int8_t *const *d_history_out,
+                                uint8_t *const *d_out, void *stream) {
+    if (!ctx || !sc || !d_out || n_subchannels < 0) return DABGPU_ERR_ARG;
+    // validate everything before enqueueing anything: profiles, bounds, no overlap inside the CIF
+    std::vector<char> used(864, 0);
+    for (int i = 0; i < n_subchannels; i++) {
+        dab::PunctureProfile prof;
+        const int rc = subchannel_profile(&sc[i], prof);
+        if (rc) return rc;
+        if (!d_out[i]) return DABGPU_ERR_ARG;
+        for (int cu = sc[i].start_address; cu < sc[i].start_address + sc[i].length; cu++) {
+            if (used[cu]) return DABGPU_ERR_ARG;
+            used[cu] = 1;
+        }
+    }
+    for (int i = 0; i < n_subchannels; i++) {
+        const int rc = dabgpu_msc_decode_dev(ctx, &sc[i], d_soft, soft_stride, n_streams, frames_per_stream,
+                                             d_history_in ? d_history_in[i] : nullptr,
+                                             d_history_out ? d_history_out[i] : nullptr, d_out[i], stream);
+        if (rc) return rc;
+    }
+    return DABGPU_OK;
+}
+
 // ---------------------------------------------------------------------------- plain Viterbi
 int dabgpu_viterbi_dev(dabgpu_ctx *ctx, const int8_t *d_punct, int n_codewords, const uint8_t *mask, int nsteps,
                        uint8_t *d_out_bytes, void *stream) {
     if (!ctx || !d_punct || !mask || !d_out_bytes || n_codewords < 0) return DABGPU_ERR_ARG;
     if (nsteps < 14 || ((nsteps - 6) & 7)) return DABGPU_ERR_ARG;
-    if (dabk::viterbi_wave_lds_bytes(nsteps) * 4 > 160 * 1024) return DABGPU_ERR_CAPACITY;
+    if (!dabk::viterbi_fits(nsteps)) return DABGPU_ERR_CAPACITY;
     dab::PunctureProfile prof;
     prof.mask.assign(mask, mask + 4 * size_t(nsteps));
     for (uint8_t &f : prof.mask) f = f ? 1 : 0;

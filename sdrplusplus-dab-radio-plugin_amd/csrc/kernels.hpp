@@ -74,7 +74,12 @@ struct MscArgs {
 };
 hipError_t launch_msc_decode(const CodeTables &c, const MscArgs &a, hipStream_t s);
 
-// LDS bytes one codeword needs in the wave-per-codeword kernel
+// LDS bytes one codeword needs in the first (fallback) wave-per-codeword kernel
 inline size_t viterbi_wave_lds_bytes(int nsteps) { return size_t(nsteps) * 12 + 64; }
+// largest trellis either kernel can hold in one CU's 160 KB of LDS (8 B/step for DAB codeword lengths)
+inline bool viterbi_fits(int nsteps) {
+    const bool rot = nsteps >= 102 && (nsteps - 6) % 96 == 0;
+    return (rot ? size_t(nsteps) * 8 + 4096 : viterbi_wave_lds_bytes(nsteps)) <= 160 * 1024;
+}
 
 }  // namespace dabk

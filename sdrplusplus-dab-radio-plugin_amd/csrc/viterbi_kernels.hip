@@ -83,7 +83,7 @@ __global__ __launch_bounds__(WGV) void viterbi_wave_kernel(Fetch fetch, CodeTabl
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int cw_raw = blockIdx.x * WAVES_PER_WG + wave;
+    const int cw_raw = blockIdx.x * int(blockDim.x >> 6) + wave;
     const bool active = cw_raw < n_codewords;
     const int cw = active ? cw_raw : n_codewords - 1;
     const int nsteps = code.nsteps;
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(WGV) void viterbi_rot_kernel(Fetch fetch, CodeTable
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int cw_raw = blockIdx.x * WAVES_PER_WG + wave;
+    const int cw_raw = blockIdx.x * int(blockDim.x >> 6) + wave;
     const bool active = cw_raw < n_codewords;
     const int cw = active ? cw_raw : n_codewords - 1;
     const int nsteps = code.nsteps;
@@ -414,12 +414,15 @@ hipError_t launch_wave(Fetch f, const CodeTables &c, int n_codewords, uint8_t *o
     if (n_codewords <= 0) return hipSuccess;
     static const bool force_v0 = std::getenv("DABGPU_VITERBI_V0") != nullptr;
     const bool rot = !force_v0 && c.nsteps >= 102 && (c.nsteps - 6) % 96 == 0 &&
-                     viterbi_rot_lds_bytes(c.nsteps) * WAVES_PER_WG <= 160 * 1024;
+                     viterbi_rot_lds_bytes(c.nsteps) <= 160 * 1024;
     const size_t per_wave = rot ? viterbi_rot_lds_bytes(c.nsteps) : viterbi_wave_lds_bytes(c.nsteps);
     int lds_per_wave = int((per_wave + 255) & ~size_t(255));
-    size_t lds = size_t(lds_per_wave) * WAVES_PER_WG;
+    // 4 waves per workgroup normally; long codewords (high bit rates) need more LDS per wave -> fewer waves
+    int waves = WAVES_PER_WG;
+    while (waves > 1 && size_t(lds_per_wave) * waves > 160 * 1024) waves >>= 1;
+    size_t lds = size_t(lds_per_wave) * waves;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    const unsigned grid = unsigned((n_codewords + WAVES_PER_WG - 1) / WAVES_PER_WG);
+    const unsigned grid = unsigned((n_codewords + waves - 1) / waves);
     {
         // Balance the grid over the CUs: with o_max workgroups resident per CU the dispatcher fills CUs greedily,
         // so a grid that is not a multiple of o_max * CUs leaves some CUs with more co-resident (slower) waves
@@ -447,10 +450,10 @@ hipError_t launch_wave(Fetch f, const CodeTables &c, int n_codewords, uint8_t *o
         if (e != hipSuccess) return e;
     }
     if (rot)
-        hipLaunchKernelGGL((viterbi_rot_kernel<Fetch, TAIL>), dim3(grid), dim3(WGV), lds, s, f, c, n_codewords, out,
+        hipLaunchKernelGGL((viterbi_rot_kernel<Fetch, TAIL>), dim3(grid), dim3(64 * waves), lds, s, f, c, n_codewords, out,
                            crc_ok, lds_per_wave);
     else
-        hipLaunchKernelGGL((viterbi_wave_kernel<Fetch, TAIL>), dim3(grid), dim3(WGV), lds, s, f, c, n_codewords, out,
+        hipLaunchKernelGGL((viterbi_wave_kernel<Fetch, TAIL>), dim3(grid), dim3(64 * waves), lds, s, f, c, n_codewords, out,
                            crc_ok, lds_per_wave);
     return hipGetLastError();
 }

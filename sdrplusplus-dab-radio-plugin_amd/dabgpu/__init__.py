@@ -32,6 +32,7 @@ EXPORTS = [
     "dabgpu_fft_symbols_dev", "dabgpu_fft_symbols", "dabgpu_fic_decode_dev", "dabgpu_fic_decode",
     "dabgpu_subchannel_bytes", "dabgpu_msc_decode_dev", "dabgpu_msc_decode", "dabgpu_viterbi_dev",
     "dabgpu_viterbi", "dabgpu_set_timing", "dabgpu_last_kernel_ms", "dabgpu_sync_prs_dev", "dabgpu_sync_prs",
+    "dabgpu_msc_decode_multi_dev",
 ]
 
 
@@ -105,6 +106,7 @@ def lib():
         L.dabgpu_viterbi_dev.argtypes = [vp, vp, i, vp, i, vp, vp]
         L.dabgpu_viterbi.argtypes = [vp, vp, i, vp, i, vp]
         L.dabgpu_set_timing.argtypes = [vp, i]
+        L.dabgpu_msc_decode_multi_dev.argtypes = [vp, vp, i, vp, sz, i, i, vp, vp, vp, vp]
         L.dabgpu_sync_prs_dev.argtypes = [vp, vp, sz, i, vp, i, vp, vp]
         L.dabgpu_sync_prs.argtypes = [vp, vp, sz, i, vp, i, vp]
         L.dabgpu_last_kernel_ms.argtypes = [vp, i, C.POINTER(C.c_float)]
@@ -283,6 +285,19 @@ class Context:
     def fic_decode_dev(self, d_soft, soft_stride, n_frames, d_fib, d_crc_ok, stream=None):
         _check(lib().dabgpu_fic_decode_dev(self._h, d_soft, soft_stride, n_frames, d_fib, d_crc_ok, stream),
                "dabgpu_fic_decode_dev")
+
+    def msc_decode_multi_dev(self, scs, d_soft, soft_stride, n_streams, frames_per_stream, d_hist_in, d_hist_out, d_out,
+                             stream=None):
+        """scs: list of Subchannel; d_hist_in/out, d_out: lists of device addresses (or None)."""
+        n = len(scs)
+        arr = (Subchannel * n)(*scs)
+        def ptrs(lst):
+            if lst is None:
+                return None
+            return (C.c_void_p * n)(*[C.c_void_p(x) if x else None for x in lst])
+        hi, ho, out = ptrs(d_hist_in), ptrs(d_hist_out), ptrs(d_out)
+        _check(lib().dabgpu_msc_decode_multi_dev(self._h, arr, n, d_soft, soft_stride, n_streams, frames_per_stream,
+                                                 hi, ho, out, stream), "dabgpu_msc_decode_multi_dev")
 
     def msc_decode_dev(self, sc, d_soft, soft_stride, n_streams, frames_per_stream, d_hist_in, d_hist_out, d_out,
                        stream=None):

@@ -268,3 +268,29 @@ class Ensemble:
     def iq(self):
         """[n_frames][196608] complex64."""
         return np.stack([modulate_frame(self.frame_bits[f]) for f in range(self.n_frames)])
+
+
+class MultiEnsemble:
+    """Cyclic multiplex with several EEP subchannels: specs = [(option, level, bitrate, start_cu), ...]."""
+
+    def __init__(self, seed, specs, n_frames=4):
+        rng = np.random.default_rng(seed)
+        self.n_frames = n_frames
+        self.specs = specs
+        R = 4 * n_frames
+        self.fibs = make_fibs(rng, 12 * n_frames).reshape(n_frames, 12, 32)
+        cifs = rng.integers(0, 2, size=(R, NB_CIF_BITS), dtype=np.uint8)
+        self.masks, self.sizes, self.msc_bytes = [], [], []
+        for (option, level, bitrate, start_cu) in specs:
+            mask, size_cu = eep_mask(option, level, bitrate)
+            data = rng.integers(0, 256, size=(R, bitrate * 3), dtype=np.uint8)
+            coded = np.stack([msc_encode_lf(data[r], mask) for r in range(R)])
+            cifs[:, start_cu * 64:(start_cu + size_cu) * 64] = time_interleave(coded, cyclic=True)
+            self.masks.append(mask); self.sizes.append(size_cu); self.msc_bytes.append(data)
+        self.frame_bits = np.zeros((n_frames, NB_FRAME_BITS), np.uint8)
+        for f in range(n_frames):
+            self.frame_bits[f, :NB_FIC_BITS] = fic_encode(self.fibs[f])
+            self.frame_bits[f, NB_FIC_BITS:] = cifs[4 * f:4 * f + 4].ravel()
+
+    def iq(self):
+        return np.stack([modulate_frame(self.frame_bits[f]) for f in range(self.n_frames)])

@@ -173,6 +173,36 @@ def test_msc_bit_exact_with_history(ctx, opt, lvl, br, start):
         assert (hist_all[s] == cifs[-15:]).all()
 
 
+def test_whole_ensemble_multi_subchannel(ctx):
+    """SURVEY 8f-2 shape: a multiplex filled with EEP-A and EEP-B subchannels of different rates, decoded in one
+    call from device-resident soft bits; every logical frame equals what was transmitted."""
+    import torch
+    specs = [(0, 3, 64, 0), (0, 2, 48, 48), (1, 2, 32, 96), (0, 4, 128, 117), (0, 1, 8, 181), (0, 3, 96, 193),
+             (1, 4, 64, 265), (0, 3, 32, 295), (0, 3, 192, 319), (0, 2, 16, 463)]
+    ens = synth.MultiEnsemble(seed=321, specs=specs, n_frames=8)
+    assert all(a[3] + s <= 864 for a, s in zip(specs, ens.sizes))
+    rng = np.random.default_rng(2)
+    rx = synth.channel(ens.iq().ravel(), snr_db=14.0, rng=rng).reshape(8, -1)
+    soft, _, _ = ctx.ofdm_demod_frames(np.ascontiguousarray(rx[:, synth.NB_NULL:]))
+    dev = torch.device("cuda", 0)
+    d_soft = torch.from_numpy(soft).to(dev)
+    scs = [dabgpu.subchannel(st, br, level=lv, eep_type=op) for (op, lv, br, st) in specs]
+    outs = [torch.zeros((1, 32, br * 3), dtype=torch.uint8, device=dev) for (_, _, br, _) in specs]
+    st = torch.cuda.Stream()
+    ctx.msc_decode_multi_dev(scs, d_soft.data_ptr(), 230400, 1, 8, None, None, [o.data_ptr() for o in outs],
+                             st.cuda_stream)
+    st.synchronize()
+    for i, o in enumerate(outs):
+        got = o.cpu().numpy()[0]
+        for t in range(15, 32):
+            assert (got[t] == ens.msc_bytes[i][t - 15]).all(), (i, t)
+    # overlapping subchannels are refused before anything is enqueued
+    bad = [scs[0], dabgpu.subchannel(40, 64, level=3)]
+    with pytest.raises(dabgpu.DabGpuError):
+        ctx.msc_decode_multi_dev(bad, d_soft.data_ptr(), 230400, 1, 8, None, None, [outs[0].data_ptr()] * 2,
+                                 st.cuda_stream)
+
+
 def test_msc_rejects_bad_profiles(ctx):
     soft = np.zeros((1, 230400), np.int8)
     with pytest.raises(dabgpu.DabGpuError) as e:
