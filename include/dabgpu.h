@@ -238,6 +238,38 @@ int dabgpu_msc_decode_multi_dev(dabgpu_ctx *ctx, const dabgpu_subchannel *sc, in
                                 uint8_t *const *d_out, void *stream);
 
 /* ------------------------------------------------------------------------ */
+/* DAB+ audio super-frame: Fire code, RS(120,110), AU CRC.    */
+/* Replaces the checks the reference reports as the "Firecode / RS / AU"       */
+/* flags and GetSuperFrameHeader()                                             */
+/*   (/root/reference/src/render_radio_block.cpp:414-437).                     */
+/*                                                                            */
+/* in        super-frame f = 5 consecutive logical frames of a DAB+ subchannel */
+/*           (the bytes dabgpu_msc_decode produces) = 15*bitrate bytes,        */
+/*           starting at in + f*in_stride.  The caller finds the alignment by   */
+/*           trying the 5 possible logical-frame offsets until firecode_ok.     */
+/* out       [n][110*s] corrected data part (s = bitrate/8)                    */
+/* status[f] firecode_ok (after RS), rs_corrected bytes, rs_uncorrectable       */
+/*           codewords (of s), num_aus (0 when the Fire code fails),            */
+/*           au_crc_mask (bit a = access unit a passes its CRC16),              */
+/*           au_start[0..num_aus] byte offsets into `out`                       */
+/* ------------------------------------------------------------------------ */
+typedef struct dabgpu_superframe_status {
+    int32_t firecode_ok;
+    int32_t rs_corrected;
+    int32_t rs_uncorrectable;
+    int32_t num_aus;
+    int32_t au_crc_mask;
+    int32_t au_start[8];
+    int32_t reserved[3];
+} dabgpu_superframe_status;
+
+int dabgpu_dabplus_superframes_dev(dabgpu_ctx *ctx, const uint8_t *d_in, size_t in_stride, int n_superframes,
+                                   int bitrate_kbps, uint8_t *d_out, dabgpu_superframe_status *d_status,
+                                   void *stream);
+int dabgpu_dabplus_superframes(dabgpu_ctx *ctx, const uint8_t *in, size_t in_stride, int n_superframes,
+                               int bitrate_kbps, uint8_t *out, dabgpu_superframe_status *status);
+
+/* ------------------------------------------------------------------------ */
 /* A9 on its own: batched punctured soft Viterbi (K=7, rate 1/4).             */
 /* Replaces the `viterbi` package (/root/reference/CMakeLists.txt:53-54).     */
 /* punct     [n_codewords][n_punct] int8 punctured soft bits                   */

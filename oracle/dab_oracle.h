@@ -125,6 +125,12 @@ void oracle_ofdm_demod_frame(const float *iq, float freq_offset, int8_t *soft,
 void oracle_sync_prs(const float *sym, float freq_offset, int max_coarse, int32_t *k, int32_t *toff,
                      float *peak_to_mean, float *coarse_peak_to_mean);
 
+/* ---- DAB+ audio super-frame (dabplus_oracle.c) ---- */
+uint16_t oracle_firecode(const uint8_t *bytes, int n);
+void oracle_rs_encode(const uint8_t *data110, uint8_t *parity10);
+int  oracle_rs_decode(uint8_t *cw120);           /* in place; corrected count or -1 */
+void oracle_dabplus_superframe(uint8_t *sf, int s, int32_t status[5], int32_t au_start[8]);
+
 #ifdef __cplusplus
 }
 #endif

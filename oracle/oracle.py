@@ -28,7 +28,7 @@ NB_CIF_BITS = 55296
 
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
-    src = [os.path.join(_HERE, f) for f in ("dab_oracle.c", "dab_oracle.h", "oracle_bench.c")]
+    src = [os.path.join(_HERE, f) for f in ("dab_oracle.c", "dab_oracle.h", "oracle_bench.c", "dabplus_oracle.c")]
     stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src)
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
@@ -38,13 +38,16 @@ def build(force=False):
 def lib():
     global _LIB
     if _LIB is None:
-        _LIB = C.CDLL(build())
+        # ORACLE_LIB lets the CPU suite run against the ASan/UBSan build (make -C oracle liboracle_asan.so)
+        _LIB = C.CDLL(os.environ.get("ORACLE_LIB") or build())
         L = _LIB
         L.oracle_carrier_bin.restype = C.c_int
         L.oracle_fic_puncture_mask.restype = C.c_int
         L.oracle_eep_puncture_mask.restype = C.c_int
         L.oracle_crc16.restype = C.c_uint16
         L.oracle_bench_frames.restype = C.c_double
+        L.oracle_firecode.restype = C.c_uint16
+        L.oracle_rs_decode.restype = C.c_int
         L.oracle_bench_frames_timed.restype = C.c_double
     return _LIB
 
@@ -203,3 +206,34 @@ def sync_prs(sym, freq_offset=0.0, max_coarse=200):
     p, cp = C.c_float(0), C.c_float(0)
     lib().oracle_sync_prs(_p(a), C.c_float(freq_offset), C.c_int(max_coarse), C.byref(k), C.byref(t), C.byref(p), C.byref(cp))
     return k.value, t.value, p.value, cp.value
+
+
+def firecode(data):
+    a = np.ascontiguousarray(data, np.uint8)
+    return int(lib().oracle_firecode(_p(a), C.c_int(a.size)))
+
+
+def rs_encode(data110):
+    d = np.ascontiguousarray(data110, np.uint8)
+    assert d.size == 110
+    out = np.zeros(10, np.uint8)
+    lib().oracle_rs_encode(_p(d), _p(out))
+    return out
+
+
+def rs_decode(cw120):
+    """-> (corrected codeword, n_corrected or -1)."""
+    c = np.array(cw120, np.uint8, copy=True)
+    assert c.size == 120
+    r = lib().oracle_rs_decode(_p(c))
+    return c, int(r)
+
+
+def dabplus_superframe(sf, s):
+    """sf: uint8[120*s] -> (corrected sf, status[5], au_start[8])."""
+    a = np.array(sf, np.uint8, copy=True)
+    assert a.size == 120 * s
+    st = np.zeros(5, np.int32)
+    au = np.zeros(8, np.int32)
+    lib().oracle_dabplus_superframe(_p(a), C.c_int(s), _p(st), _p(au))
+    return a, st, au

@@ -614,6 +614,48 @@ int dabgpu_msc_decode_multi_dev(dabgpu_ctx *ctx, const dabgpu_subchannel *sc, in
     return DABGPU_OK;
 }
 
+// ---------------------------------------------------------------------------- DAB+ super-frame
+static_assert(sizeof(dabgpu_superframe_status) == sizeof(dabk::SuperframeStatus), "ABI struct mirrors the kernel's");
+
+int dabgpu_dabplus_superframes_dev(dabgpu_ctx *ctx, const uint8_t *d_in, size_t in_stride, int n_superframes,
+                                   int bitrate_kbps, uint8_t *d_out, dabgpu_superframe_status *d_status,
+                                   void *stream) {
+    if (!ctx || !d_in || !d_out || !d_status || n_superframes < 0) return DABGPU_ERR_ARG;
+    if (bitrate_kbps < 8 || bitrate_kbps % 8 || bitrate_kbps > 512) return DABGPU_ERR_PROFILE;
+    const int s = bitrate_kbps / 8;
+    if (n_superframes > 1 && in_stride < size_t(120) * s) return DABGPU_ERR_ARG;
+    if (n_superframes == 0) return DABGPU_OK;
+    HIP_TRY(dabk::launch_dabplus_superframes(d_in, in_stride, n_superframes, s, d_out,
+                                             reinterpret_cast<dabk::SuperframeStatus *>(d_status),
+                                             pick_stream(ctx, stream)));
+    return DABGPU_OK;
+}
+
+int dabgpu_dabplus_superframes(dabgpu_ctx *ctx, const uint8_t *in, size_t in_stride, int n_superframes,
+                               int bitrate_kbps, uint8_t *out, dabgpu_superframe_status *status) {
+    if (!ctx || !in || !out || !status || n_superframes < 0) return DABGPU_ERR_ARG;
+    if (bitrate_kbps < 8 || bitrate_kbps % 8 || bitrate_kbps > 512) return DABGPU_ERR_PROFILE;
+    if (n_superframes == 0) return DABGPU_OK;
+    const int s = bitrate_kbps / 8;
+    const size_t nb_in = size_t(n_superframes - 1) * in_stride + size_t(120) * s;
+    const size_t nb_out = size_t(n_superframes) * 110 * s;
+    void *d_in, *d_out, *d_st;
+    int rc;
+    if ((rc = stage(ctx, 1, nb_in, &d_in))) return rc;
+    if ((rc = stage(ctx, 3, nb_out, &d_out))) return rc;
+    if ((rc = stage(ctx, 2, sizeof(dabgpu_superframe_status) * n_superframes, &d_st))) return rc;
+    hipStream_t st = ctx->stream;
+    HIP_TRY(hipMemcpyAsync(d_in, in, nb_in, hipMemcpyHostToDevice, st));
+    rc = dabgpu_dabplus_superframes_dev(ctx, static_cast<const uint8_t *>(d_in), in_stride, n_superframes,
+                                        bitrate_kbps, static_cast<uint8_t *>(d_out),
+                                        static_cast<dabgpu_superframe_status *>(d_st), st);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, d_out, nb_out, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(status, d_st, sizeof(dabgpu_superframe_status) * n_superframes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return DABGPU_OK;
+}
+
 // ---------------------------------------------------------------------------- plain Viterbi
 int dabgpu_viterbi_dev(dabgpu_ctx *ctx, const int8_t *d_punct, int n_codewords, const uint8_t *mask, int nsteps,
                        uint8_t *d_out_bytes, void *stream) {

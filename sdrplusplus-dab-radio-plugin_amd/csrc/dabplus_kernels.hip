@@ -1,0 +1,220 @@
+// dabplus_kernels.hip -- DAB+ audio super-frame checks on the GPU: the step after the
+// MSC Viterbi for DAB+ subchannels.  The reference shows the results as the "Firecode / RS / AU" error flags and
+// GetSuperFrameHeader() (/root/reference/src/render_radio_block.cpp:414-437); the code is in the absent
+// DAB-Radio submodule, so this restates ETSI TS 102 563 (see oracle/dabplus_oracle.c for the conventions).
+//
+// One 64-thread workgroup per super-frame (120*s bytes, s = bitrate/8 <= 64):
+//   thread j < s     RS(120,110) decode of byte-interleaved column j: syndromes by Horner, and only if one is
+//                    non-zero Berlekamp-Massey + Chien + Forney (<= 5 byte errors), GF(2^8)/0x11D via log tables
+//   thread 0         Fire code over header bytes 2..10, AU table (2/3/4/6 access units, 12-bit starts)
+//   thread a < n_au  CRC16-CCITT of access unit a
+// Byte-serial integer work at kB/s rates: one LDS-resident super-frame, no attempt at a roofline.
+#include "kernels.hpp"
+
+namespace dabk {
+
+namespace {
+
+struct GfLds {
+    uint8_t exp[512];
+    uint8_t log[256];
+};
+
+__device__ __forceinline__ unsigned gmul(const GfLds &g, unsigned a, unsigned b) {
+    return (a && b) ? g.exp[g.log[a] + g.log[b]] : 0u;
+}
+__device__ __forceinline__ unsigned gdiv(const GfLds &g, unsigned a, unsigned b) {   // b != 0
+    return a ? g.exp[g.log[a] + 255 - g.log[b]] : 0u;
+}
+// coefficient c (non-zero handled by caller) times X^-j, with xinv = log(X^-1)
+__device__ __forceinline__ unsigned gpow_term(const GfLds &g, unsigned c, int xinv, int j) {
+    return c ? g.exp[(g.log[c] + xinv * j) % 255] : 0u;
+}
+
+__device__ __forceinline__ unsigned crc_ccitt_byte(unsigned crc, unsigned byte) {
+    crc = ((crc >> 8) | (crc << 8)) & 0xFFFFu;
+    crc ^= byte;
+    crc ^= (crc & 0xFFu) >> 4;
+    crc ^= (crc << 12) & 0xFFFFu;
+    crc ^= ((crc & 0xFFu) << 5) & 0xFFFFu;
+    return crc;
+}
+
+// in-place RS(120,110) decode of the column {sf[j + s*i]}; returns corrected bytes or -1
+__device__ int rs_decode_column(const GfLds &g, uint8_t *sf, int j, int s) {
+    constexpr int N = 120, T2 = 10;
+    unsigned S[T2];
+    unsigned any = 0;
+#pragma unroll
+    for (int k = 0; k < T2; k++) S[k] = 0;
+    for (int i = 0; i < N; i++) {
+        const unsigned r = sf[j + s * i];
+#pragma unroll
+        for (int k = 0; k < T2; k++) S[k] = gmul(g, S[k], g.exp[k]) ^ r;
+    }
+#pragma unroll
+    for (int k = 0; k < T2; k++) any |= S[k];
+    if (!any) return 0;
+    // Berlekamp-Massey (fixed-bound loops so everything stays in registers)
+    unsigned L[T2 + 1], B[T2 + 1], Tm[T2 + 1];
+#pragma unroll
+    for (int i = 0; i <= T2; i++) { L[i] = 0; B[i] = 0; }
+    L[0] = 1; B[0] = 1;
+    int ll = 0, m = 1;
+    unsigned bb = 1;
+#pragma unroll
+    for (int n = 0; n < T2; n++) {
+        unsigned d = S[n];
+#pragma unroll
+        for (int i = 1; i <= T2; i++)
+            if (i <= ll && i <= n) d ^= gmul(g, L[i], S[n - i]);
+        if (d == 0) { m++; continue; }
+#pragma unroll
+        for (int i = 0; i <= T2; i++) Tm[i] = L[i];
+        const unsigned coef = gdiv(g, d, bb);
+#pragma unroll
+        for (int i = 0; i <= T2; i++)
+            if (i >= m) L[i] ^= gmul(g, coef, B[(i - m) < 0 ? 0 : (i - m)]);
+        if (2 * ll <= n) {
+            ll = n + 1 - ll;
+#pragma unroll
+            for (int i = 0; i <= T2; i++) B[i] = Tm[i];
+            bb = d;
+            m = 1;
+        } else {
+            m++;
+        }
+    }
+    if (ll > 5) return -1;
+    unsigned Om[T2];
+#pragma unroll
+    for (int i = 0; i < T2; i++) {
+        unsigned v = 0;
+#pragma unroll
+        for (int jj = 0; jj <= 5; jj++)
+            if (jj <= i && jj <= ll) v ^= gmul(g, L[jj], S[i - jj]);
+        Om[i] = v;
+    }
+    int nerr = 0;
+    int pos[5];
+    unsigned val[5];
+    for (int i = 0; i < N; i++) {
+        const int p = N - 1 - i;
+        const int xinv = (255 - p) % 255;
+        unsigned ev = 0;
+#pragma unroll
+        for (int jj = 0; jj <= 5; jj++) ev ^= gpow_term(g, L[jj], xinv, jj);
+        if (ev) continue;
+        if (nerr == 5) return -1;
+        unsigned om = 0, dl = 0;
+#pragma unroll
+        for (int jj = 0; jj < T2; jj++) om ^= gpow_term(g, Om[jj], xinv, jj);
+        dl = gpow_term(g, L[1], xinv, 0) ^ gpow_term(g, L[3], xinv, 2) ^ gpow_term(g, L[5], xinv, 4);
+        if (dl == 0) return -1;
+        const unsigned e = gmul(g, g.exp[p % 255], gdiv(g, om, dl));
+#pragma unroll
+        for (int q = 0; q < 5; q++)
+            if (q == nerr) { pos[q] = i; val[q] = e; }
+        nerr++;
+    }
+    if (nerr != ll) return -1;
+#pragma unroll
+    for (int q = 0; q < 5; q++)
+        if (q < nerr) sf[j + s * pos[q]] ^= uint8_t(val[q]);
+    return nerr;
+}
+
+__global__ __launch_bounds__(64) void dabplus_superframe_kernel(const uint8_t *in, size_t in_stride, int s,
+                                                                uint8_t *out, SuperframeStatus *status) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    GfLds &g = *reinterpret_cast<GfLds *>(smem);
+    uint8_t *sf = smem + sizeof(GfLds);
+    __shared__ int sh_corrected, sh_bad, sh_mask, sh_naus;
+    __shared__ int sh_start[8];
+    const int tid = threadIdx.x;
+    const int nbytes = 120 * s;
+    const uint8_t *src = in + size_t(blockIdx.x) * in_stride;
+    // GF(2^8) tables: x^8 + x^4 + x^3 + x^2 + 1, alpha = 2
+    if (tid == 0) {
+        unsigned x = 1;
+        for (int i = 0; i < 255; i++) {
+            g.exp[i] = uint8_t(x);
+            g.log[x] = uint8_t(i);
+            x <<= 1;
+            if (x & 0x100u) x ^= 0x11Du;
+        }
+        for (int i = 255; i < 512; i++) g.exp[i] = g.exp[i - 255];
+        g.log[0] = 0;
+        sh_corrected = 0; sh_bad = 0; sh_mask = 0; sh_naus = 0;
+    }
+    for (int i = tid; i < nbytes; i += 64) sf[i] = src[i];
+    if (tid < 8) sh_start[tid] = 0;
+    __syncthreads();
+    if (tid < s) {
+        const int r = rs_decode_column(g, sf, tid, s);
+        if (r < 0) atomicAdd(&sh_bad, 1);
+        else if (r > 0) atomicAdd(&sh_corrected, r);
+    }
+    __syncthreads();
+    int fire_ok = 0;
+    if (tid == 0) {
+        unsigned crc = 0;
+        for (int i = 2; i < 11; i++) {
+            crc ^= unsigned(sf[i]) << 8;
+            for (int b = 0; b < 8; b++) crc = (crc & 0x8000u) ? ((crc << 1) ^ 0x782Fu) : (crc << 1);
+            crc &= 0xFFFFu;
+        }
+        fire_ok = crc == ((unsigned(sf[0]) << 8) | sf[1]);
+        if (fire_ok) {
+            const int dac_rate = (sf[2] >> 6) & 1, sbr = (sf[2] >> 5) & 1;
+            const int naus = dac_rate ? (sbr ? 3 : 6) : (sbr ? 2 : 4);
+            sh_start[0] = naus == 2 ? 5 : naus == 3 ? 6 : naus == 4 ? 8 : 11;
+            int bitpos = 24;
+            for (int a = 1; a < naus; a++) {
+                int v = 0;
+                for (int b = 0; b < 12; b++, bitpos++) v = (v << 1) | ((sf[bitpos >> 3] >> (7 - (bitpos & 7))) & 1);
+                sh_start[a] = v;
+            }
+            sh_start[naus] = 110 * s;
+            sh_naus = naus;
+        }
+    }
+    __syncthreads();
+    if (tid < sh_naus) {
+        const int b0 = sh_start[tid], b1 = sh_start[tid + 1];
+        if (b0 >= 3 && b1 <= 110 * s && b1 - b0 >= 3) {
+            unsigned crc = 0xFFFFu;
+            for (int i = b0; i < b1 - 2; i++) crc = crc_ccitt_byte(crc, sf[i]);
+            crc ^= 0xFFFFu;
+            if (crc == ((unsigned(sf[b1 - 2]) << 8) | sf[b1 - 1])) atomicOr(&sh_mask, 1 << tid);
+        }
+    }
+    __syncthreads();
+    uint8_t *dst = out + size_t(blockIdx.x) * size_t(110 * s);
+    for (int i = tid; i < 110 * s; i += 64) dst[i] = sf[i];
+    if (tid == 0) {
+        SuperframeStatus st;
+        st.firecode_ok = fire_ok;
+        st.rs_corrected = sh_corrected;
+        st.rs_uncorrectable = sh_bad;
+        st.num_aus = sh_naus;
+        st.au_crc_mask = sh_mask;
+        for (int a = 0; a < 8; a++) st.au_start[a] = sh_start[a];
+        st.reserved[0] = st.reserved[1] = st.reserved[2] = 0;
+        status[blockIdx.x] = st;
+    }
+}
+
+}  // namespace
+
+hipError_t launch_dabplus_superframes(const uint8_t *in, size_t in_stride, int n_superframes, int s, uint8_t *out,
+                                      SuperframeStatus *status, hipStream_t stream) {
+    if (n_superframes <= 0) return hipSuccess;
+    if (s < 1 || s > 64) return hipErrorInvalidValue;
+    const size_t lds = sizeof(GfLds) + size_t(120) * s;
+    hipLaunchKernelGGL(dabplus_superframe_kernel, dim3(unsigned(n_superframes)), dim3(64), lds, stream, in, in_stride,
+                       s, out, status);
+    return hipGetLastError();
+}
+
+}  // namespace dabk

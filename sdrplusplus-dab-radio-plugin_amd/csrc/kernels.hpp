@@ -46,6 +46,19 @@ struct SyncResult {            // == dabgpu_sync_result
 hipError_t launch_prs_sync(const SyncTables &t, const float2 *iq, size_t frame_stride, int n_frames,
                            const float *freq_offset, int max_coarse, SyncResult *out, hipStream_t s);
 
+// ---- DAB+ audio super-frame (dabplus_kernels.hip) ------------------------------
+struct SuperframeStatus {      // == dabgpu_superframe_status
+    int32_t firecode_ok;
+    int32_t rs_corrected;
+    int32_t rs_uncorrectable;
+    int32_t num_aus;
+    int32_t au_crc_mask;
+    int32_t au_start[8];
+    int32_t reserved[3];
+};
+hipError_t launch_dabplus_superframes(const uint8_t *in, size_t in_stride, int n_superframes, int s, uint8_t *out,
+                                      SuperframeStatus *status, hipStream_t stream);
+
 // ---- channel decoder (viterbi_kernels.hip) ---------------------------------
 struct CodeTables {
     const uint16_t *mother_pos;  // [n_punct] mother-bit position of punctured bit i

@@ -32,7 +32,7 @@ EXPORTS = [
     "dabgpu_fft_symbols_dev", "dabgpu_fft_symbols", "dabgpu_fic_decode_dev", "dabgpu_fic_decode",
     "dabgpu_subchannel_bytes", "dabgpu_msc_decode_dev", "dabgpu_msc_decode", "dabgpu_viterbi_dev",
     "dabgpu_viterbi", "dabgpu_set_timing", "dabgpu_last_kernel_ms", "dabgpu_sync_prs_dev", "dabgpu_sync_prs",
-    "dabgpu_msc_decode_multi_dev",
+    "dabgpu_msc_decode_multi_dev", "dabgpu_dabplus_superframes_dev", "dabgpu_dabplus_superframes",
 ]
 
 
@@ -106,6 +106,8 @@ def lib():
         L.dabgpu_viterbi_dev.argtypes = [vp, vp, i, vp, i, vp, vp]
         L.dabgpu_viterbi.argtypes = [vp, vp, i, vp, i, vp]
         L.dabgpu_set_timing.argtypes = [vp, i]
+        L.dabgpu_dabplus_superframes_dev.argtypes = [vp, vp, sz, i, i, vp, vp, vp]
+        L.dabgpu_dabplus_superframes.argtypes = [vp, vp, sz, i, i, vp, vp]
         L.dabgpu_msc_decode_multi_dev.argtypes = [vp, vp, i, vp, sz, i, i, vp, vp, vp, vp]
         L.dabgpu_sync_prs_dev.argtypes = [vp, vp, sz, i, vp, i, vp, vp]
         L.dabgpu_sync_prs.argtypes = [vp, vp, sz, i, vp, i, vp]
@@ -238,6 +240,19 @@ class Context:
                                  ("peak_to_mean", np.float32), ("coarse_peak_to_mean", np.float32)])
         _check(lib().dabgpu_sync_prs(self._h, _p(iq), stride, n, _p(fo), max_coarse, _p(out)), "dabgpu_sync_prs")
         return out
+
+    def dabplus_superframes(self, sfs, bitrate_kbps):
+        """sfs: uint8 [n][>=15*bitrate] aligned super-frames -> (data [n][110*s], status structured array)."""
+        sfs = np.ascontiguousarray(sfs, np.uint8)
+        n, stride = sfs.shape
+        s = bitrate_kbps // 8
+        out = np.zeros((n, 110 * s), np.uint8)
+        st = np.zeros(n, dtype=[("firecode_ok", np.int32), ("rs_corrected", np.int32), ("rs_uncorrectable", np.int32),
+                                ("num_aus", np.int32), ("au_crc_mask", np.int32), ("au_start", np.int32, (8,)),
+                                ("reserved", np.int32, (3,))])
+        _check(lib().dabgpu_dabplus_superframes(self._h, _p(sfs), stride, n, bitrate_kbps, _p(out), _p(st)),
+               "dabgpu_dabplus_superframes")
+        return out, st
 
     def fic_decode(self, soft):
         """soft: int8 [n_frames][>=9216]."""

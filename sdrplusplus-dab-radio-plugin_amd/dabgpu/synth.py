@@ -294,3 +294,88 @@ class MultiEnsemble:
 
     def iq(self):
         return np.stack([modulate_frame(self.frame_bits[f]) for f in range(self.n_frames)])
+
+
+# ----------------------------------------------------------------------------- DAB+ audio super-frame (TS 102 563)
+def _gf256():
+    exp = np.zeros(512, np.int64)
+    log = np.zeros(256, np.int64)
+    x = 1
+    for i in range(255):
+        exp[i] = x
+        log[x] = i
+        x <<= 1
+        if x & 0x100:
+            x ^= 0x11D
+    exp[255:510] = exp[:255]
+    return exp, log
+
+
+_GF_EXP, _GF_LOG = _gf256()
+
+
+def _gf_mul(a, b):
+    return 0 if a == 0 or b == 0 else int(_GF_EXP[_GF_LOG[a] + _GF_LOG[b]])
+
+
+def _rs_generator():
+    g = [1]                                   # g[i] = coefficient of x^i
+    for k in range(10):
+        nx = [0] * (len(g) + 1)
+        for i, c in enumerate(g):
+            nx[i + 1] ^= c
+            nx[i] ^= _gf_mul(c, int(_GF_EXP[k]))
+        g = nx
+    return g
+
+
+_RS_G = _rs_generator()
+
+
+def rs_parity(data110):
+    """RS(120,110) parity: remainder of d(x) x^10 by prod_{k=0..9}(x - alpha^k), GF(2^8) / 0x11D."""
+    rem = [0] * 10                            # rem[0] = highest degree
+    for d in data110:
+        fb = int(d) ^ rem[0]
+        rem = [rem[j + 1] ^ _gf_mul(fb, _RS_G[9 - j]) for j in range(9)] + [_gf_mul(fb, _RS_G[0])]
+    return np.array(rem, np.uint8)
+
+
+def firecode16(data):
+    crc = 0
+    for byte in bytes(data):
+        crc ^= byte << 8
+        for _ in range(8):
+            crc = ((crc << 1) ^ 0x782F) if (crc & 0x8000) else (crc << 1)
+            crc &= 0xFFFF
+    return crc
+
+
+def build_superframe(rng, bitrate, dac_rate=1, sbr=0, channel_mode=1, ps=0):
+    """-> (sf uint8[120*s], au_start list with the end appended, list of AU payloads incl. CRC)."""
+    s = bitrate // 8
+    size = 110 * s
+    num_aus = {(0, 1): 2, (1, 1): 3, (0, 0): 4, (1, 0): 6}[(dac_rate, sbr)]
+    first = {2: 5, 3: 6, 4: 8, 6: 11}[num_aus]
+    cuts = np.sort(rng.choice(np.arange(first + 8, size - 8, 4), num_aus - 1, replace=False))
+    starts = [first] + [int(c) for c in cuts] + [size]
+    sf = np.zeros(120 * s, np.uint8)
+    sf[2] = (dac_rate << 6) | (sbr << 5) | (channel_mode << 4) | (ps << 3)
+    bits = []
+    for a in range(1, num_aus):
+        bits += [(starts[a] >> (11 - b)) & 1 for b in range(12)]
+    bits += [0] * ((-len(bits)) % 8)
+    hdr = np.packbits(np.array(bits, np.uint8)) if bits else np.zeros(0, np.uint8)
+    sf[3:3 + hdr.size] = hdr
+    aus = []
+    for a in range(num_aus):
+        body = rng.integers(0, 256, starts[a + 1] - starts[a] - 2, dtype=np.uint8)
+        c = crc16(body)
+        au = np.concatenate([body, np.array([c >> 8, c & 0xFF], np.uint8)])
+        sf[starts[a]:starts[a + 1]] = au
+        aus.append(au)
+    fc = firecode16(sf[2:11])
+    sf[0], sf[1] = fc >> 8, fc & 0xFF
+    for j in range(s):
+        sf[size + j::s] = rs_parity(sf[j:size:s])
+    return sf, starts, aus

@@ -1,0 +1,134 @@
+"""DAB+ audio super-frame checks: Fire code, RS(120,110), AU table and CRC.
+CPU: oracle vs the independent numpy builder.  GPU: dabgpu_dabplus_superframes bit-exact vs the oracle, clean and
+with byte errors, and end to end from IQ through the MSC Viterbi."""
+import numpy as np
+import pytest
+
+from dabgpu import synth
+from oracle import oracle as O
+
+CASES = [(64, 1, 0), (32, 0, 1), (96, 1, 1), (128, 0, 0), (8, 0, 1), (192, 1, 0)]
+
+
+def test_rs_and_firecode_agree_with_builder():
+    rng = np.random.default_rng(1)
+    for _ in range(5):
+        d = rng.integers(0, 256, 110, dtype=np.uint8)
+        assert (synth.rs_parity(d) == O.rs_encode(d)).all()
+        assert synth.firecode16(d[:9]) == O.firecode(d[:9])
+    d = rng.integers(0, 256, 110, dtype=np.uint8)
+    cw = np.concatenate([d, O.rs_encode(d)])
+    assert O.rs_decode(cw)[1] == 0
+    for ne in range(1, 6):
+        e = cw.copy()
+        idx = rng.choice(120, ne, replace=False)
+        e[idx] ^= rng.integers(1, 256, ne, dtype=np.uint8)
+        c, r = O.rs_decode(e)
+        assert r == ne and (c == cw).all()
+    e = cw.copy()
+    e[rng.choice(120, 7, replace=False)] ^= 0x33
+    assert O.rs_decode(e)[1] == -1 or not (O.rs_decode(e)[0] == cw).all()     # beyond t=5: flagged or miscorrected
+
+
+@pytest.mark.parametrize("bitrate,dac_rate,sbr", CASES)
+def test_oracle_superframe(bitrate, dac_rate, sbr):
+    rng = np.random.default_rng(bitrate)
+    sf, starts, aus = synth.build_superframe(rng, bitrate, dac_rate, sbr)
+    s = bitrate // 8
+    c, st, au = O.dabplus_superframe(sf, s)
+    n = len(aus)
+    assert st.tolist() == [1, 0, 0, n, (1 << n) - 1] and au[:n + 1].tolist() == starts
+    # two byte errors in every column are repaired
+    e = sf.copy()
+    for j in range(s):
+        e[j + s * rng.choice(120, 2, replace=False)] ^= 0xA5
+    c, st, au = O.dabplus_superframe(e, s)
+    assert (c == sf).all() and st.tolist() == [1, 2 * s, 0, n, (1 << n) - 1]
+    # a corrupted header byte beyond repair of the Fire code (no RS help: damage 6 bytes of column 2's codeword)
+    bad = sf.copy()
+    bad[2::s][:6] ^= 0xFF
+    _, st, _ = O.dabplus_superframe(bad, s)
+    assert st[2] >= 1 or st[0] == 0
+
+
+def _noisy_batch(rng):
+    sfs, truth = [], []
+    for (br, dr, sb) in [(64, 1, 0)] * 6:
+        sf, starts, aus = synth.build_superframe(rng, br, dr, sb)
+        truth.append(sf.copy())
+        sfs.append(sf)
+    sfs = np.stack(sfs)
+    s = 8
+    sfs[1, rng.choice(960, 10, replace=False)] ^= 0x11          # few scattered errors
+    for j in range(s):
+        sfs[2, j + s * rng.choice(120, 5, replace=False)] ^= 0xC3   # 5 per column: the limit
+    sfs[3, 0:960:8][:7] ^= 0x5A                                 # 7 errors in column 0: uncorrectable
+    sfs[4, 20] ^= 0x01                                          # one bit inside an AU
+    sfs[5] = rng.integers(0, 256, 960, dtype=np.uint8)          # garbage
+    return sfs, truth
+
+
+@pytest.mark.gpu
+def test_gpu_superframes_match_oracle(ctx):
+    rng = np.random.default_rng(7)
+    sfs, truth = _noisy_batch(rng)
+    out, st = ctx.dabplus_superframes(sfs, 64)
+    for i in range(sfs.shape[0]):
+        c, ost, oau = O.dabplus_superframe(sfs[i], 8)
+        assert (out[i] == c[:880]).all(), i
+        got = [int(st["firecode_ok"][i]), int(st["rs_corrected"][i]), int(st["rs_uncorrectable"][i]),
+               int(st["num_aus"][i]), int(st["au_crc_mask"][i])]
+        assert got == ost.tolist(), (i, got, ost)
+        assert st["au_start"][i].tolist() == oau.tolist()
+    assert (out[2] == truth[2][:880]).all() and st["rs_corrected"][2] == 40
+    assert st["rs_uncorrectable"][3] >= 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bitrate,dac_rate,sbr", CASES)
+def test_gpu_superframe_profiles(ctx, bitrate, dac_rate, sbr):
+    rng = np.random.default_rng(bitrate + 1)
+    sf, starts, aus = synth.build_superframe(rng, bitrate, dac_rate, sbr)
+    s = bitrate // 8
+    e = sf.copy()
+    for j in range(s):
+        e[j + s * rng.choice(120, 3, replace=False)] ^= 0x77
+    out, st = ctx.dabplus_superframes(e[None, :], bitrate)
+    n = len(aus)
+    assert (out[0] == sf[:110 * s]).all()
+    assert (st["firecode_ok"][0], st["rs_corrected"][0], st["rs_uncorrectable"][0], st["num_aus"][0],
+            st["au_crc_mask"][0]) == (1, 3 * s, 0, n, (1 << n) - 1)
+    assert st["au_start"][0][:n + 1].tolist() == starts
+
+
+@pytest.mark.gpu
+def test_end_to_end_iq_to_access_units(ctx):
+    """IQ -> OFDM -> MSC Viterbi -> super-frame: the subchannel carries real DAB+ super-frames."""
+    import dabgpu
+    rng = np.random.default_rng(11)
+    n_frames = 10                                   # 40 logical frames = 8 super-frames
+    ens = synth.Ensemble(seed=5, n_frames=n_frames)
+    sfs = [synth.build_superframe(rng, 64, 1, 0)[0] for _ in range(8)]
+    payload = np.concatenate(sfs).reshape(40, 192)
+    # re-encode the subchannel with this payload (cyclic interleaving as in Ensemble)
+    coded = np.stack([synth.msc_encode_lf(payload[r], ens.mask) for r in range(40)])
+    tx = synth.time_interleave(coded, cyclic=True)
+    bits = ens.frame_bits.copy()
+    for f in range(n_frames):
+        for c in range(4):
+            a = synth.NB_FIC_BITS + c * synth.NB_CIF_BITS
+            bits[f, a:a + ens.size_cu * 64] = tx[4 * f + c]
+    iq = np.stack([synth.modulate_frame(bits[f]) for f in range(n_frames)])
+    rx = synth.channel(iq.ravel(), snr_db=11.0, rng=rng).reshape(n_frames, -1)
+    soft, _, _ = ctx.ofdm_demod_frames(np.ascontiguousarray(rx[:, synth.NB_NULL:]))
+    sc = dabgpu.subchannel(0, 64, level=3)
+    lf, _ = ctx.msc_decode(sc, soft, n_streams=1)          # [1][40][192]; entry t = logical frame t-15
+    got = lf[0, 15:40]                                      # logical frames 0..24 = super-frames 0..4
+    out, st = ctx.dabplus_superframes(got.reshape(5, 960), 64)
+    assert st["firecode_ok"].all() and (st["rs_uncorrectable"] == 0).all()
+    assert (st["au_crc_mask"] == 63).all() and (st["num_aus"] == 6).all()
+    for i in range(5):
+        assert (out[i] == sfs[i][:880]).all()
+    # a mis-aligned start (one logical frame late) is detected by the Fire code
+    _, st_bad = ctx.dabplus_superframes(lf[0, 16:36].reshape(4, 960), 64)
+    assert not st_bad["firecode_ok"].any()
