@@ -26,6 +26,7 @@ struct DeviceCode {
     dab::PunctureProfile prof;
     uint16_t *d_mother_pos = nullptr;
     uint8_t *d_prbs = nullptr;
+    int32_t *d_punct_idx = nullptr;      // [4*nsteps] punctured index of each mother bit, -1 = erased (lane kernels)
     dabk::CodeTables tables(bool descramble) const {
         return dabk::CodeTables{d_mother_pos, prof.n_punct, prof.nsteps, descramble ? d_prbs : nullptr};
     }
@@ -56,6 +57,9 @@ struct dabgpu_ctx {
     bool timing = false;
     Timer timers[4];
     int ofdm_parts_override = 0;
+    void *d_lane_scratch = nullptr;      // work buffers of the codeword-per-lane Viterbi
+    size_t lane_scratch_bytes = 0;
+    int lane_mode = -1;                  // DABGPU_VITERBI_LANE: 1 force, 0 never, -1 by batch size
     int wave_slots = 3072;       // resident OFDM wavefronts: 12 per CU
 };
 
@@ -82,12 +86,18 @@ int build_device_code(DeviceCode &dc) {
     if (dc.prof.mask.size() > 65535 || int(pos.size()) != dc.prof.n_punct) return DABGPU_ERR_PROFILE;
     int rc = upload(&dc.d_mother_pos, pos);
     if (rc) return rc;
+    std::vector<int32_t> pidx(dc.prof.mask.size(), -1);
+    for (size_t i = 0, j = 0; i < dc.prof.mask.size(); i++)
+        if (dc.prof.mask[i]) pidx[i] = int32_t(j++);
+    if ((rc = upload(&dc.d_punct_idx, pidx))) return rc;
     return upload(&dc.d_prbs, dab::make_prbs_bytes((dc.prof.nsteps - 6 + 7) / 8));
 }
 
 void free_device_code(DeviceCode &dc) {
     if (dc.d_mother_pos) (void)hipFree(dc.d_mother_pos);
     if (dc.d_prbs) (void)hipFree(dc.d_prbs);
+    if (dc.d_punct_idx) (void)hipFree(dc.d_punct_idx);
+    dc.d_punct_idx = nullptr;
     dc.d_mother_pos = nullptr;
     dc.d_prbs = nullptr;
 }
@@ -151,6 +161,33 @@ int pick_parts(const dabgpu_ctx *ctx, int n_frames, int total_syms) {
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = p; }
     }
     return best;
+}
+
+// The codeword-per-lane Viterbi pays once a launch has enough codewords to give every SIMD a wave (one wave =
+// 64 codewords; its single-wave latency equals the wave-per-codeword kernels' time at ~24k codewords).
+constexpr int LANE_MIN_CODEWORDS = 24576;
+
+// returns true and a scratch descriptor when the lane kernels should take this launch
+bool use_lane(dabgpu_ctx *ctx, int nsteps, int n_codewords, hipStream_t s, dabk::LaneScratch *sc, int *rc) {
+    *rc = DABGPU_OK;
+    if (ctx->lane_mode == 0 || !dabk::lane_supported(nsteps)) return false;
+    if (ctx->lane_mode < 0 && n_codewords < LANE_MIN_CODEWORDS) return false;
+    const size_t need = dabk::lane_scratch_bytes(nsteps, n_codewords);
+    if (ctx->lane_scratch_bytes < need) {
+        // growing the buffer must not race with work still using the old one
+        if (hipStreamSynchronize(s) != hipSuccess) { *rc = DABGPU_ERR_HIP; return false; }
+        if (ctx->d_lane_scratch) (void)hipFree(ctx->d_lane_scratch);
+        ctx->d_lane_scratch = nullptr;
+        ctx->lane_scratch_bytes = 0;
+        if (hipMalloc(&ctx->d_lane_scratch, need) != hipSuccess) {
+            if (ctx->lane_mode > 0) *rc = DABGPU_ERR_NOMEM;
+            return false;                                     // fall back to the wave kernels
+        }
+        ctx->lane_scratch_bytes = need;
+    }
+    sc->base = ctx->d_lane_scratch;
+    sc->bytes = ctx->lane_scratch_bytes;
+    return true;
 }
 
 hipStream_t pick_stream(dabgpu_ctx *ctx, void *stream) {
@@ -246,6 +283,7 @@ int dabgpu_create(const dabgpu_cfg *cfg, dabgpu_ctx **out) {
     ctx->device = cfg->device;
     ctx->max_frames = cfg->max_frames;
     if (const char *g = std::getenv("DABGPU_OFDM_PARTS")) ctx->ofdm_parts_override = std::atoi(g);
+    if (const char *g = std::getenv("DABGPU_VITERBI_LANE")) ctx->lane_mode = std::atoi(g);
     ctx->wave_slots = prop.multiProcessorCount > 0 ? prop.multiProcessorCount * 12 : 3072;   // 3 workgroups x 4 waves per CU
     int rc = DABGPU_OK;
     do {
@@ -306,6 +344,7 @@ void dabgpu_destroy(dabgpu_ctx *ctx) {
     free_device_code(ctx->fic);
     for (auto &kv : ctx->codes) free_device_code(*kv.second);
     for (void *p : ctx->d_stage) if (p) (void)hipFree(p);
+    if (ctx->d_lane_scratch) (void)hipFree(ctx->d_lane_scratch);
     for (Timer &t : ctx->timers) {
         if (t.start) (void)hipEventDestroy(t.start);
         if (t.stop) (void)hipEventDestroy(t.stop);
@@ -486,6 +525,14 @@ int dabgpu_fic_decode_dev(dabgpu_ctx *ctx, const int8_t *d_soft, size_t soft_str
     if (n_frames == 0) return DABGPU_OK;
     hipStream_t s = pick_stream(ctx, stream);
     ScopedTimer tm(ctx, 1, s);
+    dabk::LaneScratch lsc{};
+    int lrc;
+    if (use_lane(ctx, ctx->fic.prof.nsteps, n_frames * NB_FIC_GROUPS, s, &lsc, &lrc)) {
+        HIP_TRY(dabk::launch_fic_decode_lane(ctx->fic.tables(true), ctx->fic.d_punct_idx, d_soft, soft_stride, n_frames,
+                                             lsc, d_fib, d_crc_ok, s));
+        return DABGPU_OK;
+    }
+    if (lrc) return lrc;
     HIP_TRY(dabk::launch_fic_decode(ctx->fic.tables(true), d_soft, soft_stride, n_frames, d_fib, d_crc_ok, s));
     return DABGPU_OK;
 }
@@ -554,6 +601,14 @@ int dabgpu_msc_decode_dev(dabgpu_ctx *ctx, const dabgpu_subchannel *sc, const in
     a.hist_out = d_history_out;
     a.out = d_out;
     ScopedTimer tm(ctx, 2, s);
+    dabk::LaneScratch lsc{};
+    int lrc;
+    if (use_lane(ctx, dc->prof.nsteps, n_streams * frames_per_stream * NB_CIFS, s, &lsc, &lrc)) {
+        HIP_TRY(dabk::launch_msc_decode_lane(dc->tables(true), dc->d_punct_idx, a, lsc, s));
+        HIP_TRY(dabk::launch_msc_history(a, s));
+        return DABGPU_OK;
+    }
+    if (lrc) return lrc;
     HIP_TRY(dabk::launch_msc_decode(dc->tables(true), a, s));
     return DABGPU_OK;
 }
@@ -671,6 +726,14 @@ int dabgpu_viterbi_dev(dabgpu_ctx *ctx, const int8_t *d_punct, int n_codewords, 
     int rc = get_code(ctx, std::move(prof), &dc);
     if (rc) return rc;
     hipStream_t s = pick_stream(ctx, stream);
+    dabk::LaneScratch lsc{};
+    int lrc;
+    if (use_lane(ctx, dc->prof.nsteps, n_codewords, s, &lsc, &lrc)) {
+        HIP_TRY(dabk::launch_viterbi_plain_lane(dc->tables(false), dc->d_punct_idx, d_punct, n_codewords, lsc,
+                                                d_out_bytes, s));
+        return DABGPU_OK;
+    }
+    if (lrc) return lrc;
     HIP_TRY(dabk::launch_viterbi_plain(dc->tables(false), d_punct, n_codewords, d_out_bytes, s));
     return DABGPU_OK;
 }

@@ -87,6 +87,25 @@ struct MscArgs {
 };
 hipError_t launch_msc_decode(const CodeTables &c, const MscArgs &a, hipStream_t s);
 
+// ---- large-batch variant: one codeword per lane (viterbi_lane_kernels.hip) ----
+struct LaneScratch {
+    void *base;
+    size_t bytes;
+};
+size_t lane_scratch_bytes(int nsteps, int n_codewords);
+bool lane_supported(int nsteps);
+hipError_t launch_fic_decode_lane(const CodeTables &c, const int32_t *punct_idx, const int8_t *soft, size_t soft_stride,
+                                  int n_frames, const LaneScratch &sc, uint8_t *fib, uint8_t *crc_ok, hipStream_t s);
+hipError_t launch_viterbi_plain_lane(const CodeTables &c, const int32_t *punct_idx, const int8_t *punct,
+                                     int n_codewords, const LaneScratch &sc, uint8_t *out, hipStream_t s);
+hipError_t launch_msc_decode_lane(const CodeTables &c, const int32_t *punct_idx, const MscArgs &a, const LaneScratch &sc,
+                                  hipStream_t s);
+// Dynamic-LDS request (>= lds) that makes every CU hold the same number of workgroups of a `grid`-workgroup
+// launch when at most `o_cap` fit per CU otherwise (the dispatcher fills CUs greedily).
+size_t balanced_lds_bytes(unsigned grid, size_t lds, unsigned o_cap);
+// history ring update alone (used by both MSC variants)
+hipError_t launch_msc_history(const MscArgs &a, hipStream_t s);
+
 // LDS bytes one codeword needs in the first (fallback) wave-per-codeword kernel
 inline size_t viterbi_wave_lds_bytes(int nsteps) { return size_t(nsteps) * 12 + 64; }
 // largest trellis either kernel can hold in one CU's 160 KB of LDS (8 B/step for DAB codeword lengths)

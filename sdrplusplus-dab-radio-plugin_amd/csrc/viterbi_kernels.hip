@@ -423,26 +423,7 @@ hipError_t launch_wave(Fetch f, const CodeTables &c, int n_codewords, uint8_t *o
     size_t lds = size_t(lds_per_wave) * waves;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const unsigned grid = unsigned((n_codewords + waves - 1) / waves);
-    {
-        // Balance the grid over the CUs: with o_max workgroups resident per CU the dispatcher fills CUs greedily,
-        // so a grid that is not a multiple of o_max * CUs leaves some CUs with more co-resident (slower) waves
-        // than others.  Ask for just enough LDS that every CU holds the same number of workgroups per round.
-        static const int n_cu = [] {
-            int dev = 0, n = 256;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                n = prop.multiProcessorCount;
-            return n;
-        }();
-        const size_t cu_lds = 160 * 1024;
-        const unsigned o_max = unsigned(std::min<size_t>(cu_lds / lds, 8));
-        const unsigned rounds = (grid + o_max * n_cu - 1) / (o_max * n_cu);
-        const unsigned o_need = std::max(1u, (grid + rounds * n_cu - 1) / (rounds * n_cu));
-        if (o_need < o_max) {
-            const size_t padded = (cu_lds / o_need) & ~size_t(1023);
-            if (padded >= lds) { lds = padded; }
-        }
-    }
+    lds = balanced_lds_bytes(grid, lds, 8);
     const void *kern = rot ? reinterpret_cast<const void *>(viterbi_rot_kernel<Fetch, TAIL>)
                            : reinterpret_cast<const void *>(viterbi_wave_kernel<Fetch, TAIL>);
     if (lds > 64 * 1024) {
@@ -476,13 +457,39 @@ hipError_t launch_msc_decode(const CodeTables &c, const MscArgs &a, hipStream_t 
     hipError_t e = launch_wave<FetchMsc, Tail::kBytes>(f, c, a.n_streams * a.frames_per_stream * NB_CIFS, a.out,
                                                        nullptr, s);
     if (e != hipSuccess) return e;
-    if (a.hist_out) {
-        const size_t total = size_t(a.n_streams) * 15 * a.nbits;
-        const unsigned grid = unsigned(std::min<size_t>((total + 255) / 256, 2048));
-        hipLaunchKernelGGL(msc_history_kernel, dim3(grid), dim3(256), 0, s, a);
-        e = hipGetLastError();
+    return launch_msc_history(a, s);
+}
+
+// Balance a grid over the CUs: with o_max workgroups resident per CU the dispatcher fills CUs greedily, so a grid
+// that is not a multiple of o_max * CUs leaves some CUs with more co-resident (slower) waves than others.  Ask for
+// just enough LDS that every CU holds the same number of workgroups per round.
+size_t balanced_lds_bytes(unsigned grid, size_t lds, unsigned o_cap) {
+    static const unsigned n_cu = [] {
+        int dev = 0;
+        unsigned n = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            n = unsigned(prop.multiProcessorCount);
+        return n;
+    }();
+    const size_t cu_lds = 160 * 1024;
+    const unsigned o_max = unsigned(std::min<size_t>(lds ? cu_lds / lds : o_cap, o_cap));
+    if (o_max == 0 || grid == 0) return lds;
+    const unsigned rounds = (grid + o_max * n_cu - 1) / (o_max * n_cu);
+    const unsigned o_need = std::max(1u, (grid + rounds * n_cu - 1) / (rounds * n_cu));
+    if (o_need < o_max) {
+        const size_t padded = (cu_lds / o_need) & ~size_t(1023);
+        if (padded >= lds) lds = padded;
     }
-    return e;
+    return lds;
+}
+
+hipError_t launch_msc_history(const MscArgs &a, hipStream_t s) {
+    if (!a.hist_out) return hipSuccess;
+    const size_t total = size_t(a.n_streams) * 15 * a.nbits;
+    const unsigned grid = unsigned(std::min<size_t>((total + 255) / 256, 2048));
+    hipLaunchKernelGGL(msc_history_kernel, dim3(grid), dim3(256), 0, s, a);
+    return hipGetLastError();
 }
 
 }  // namespace dabk

@@ -1,0 +1,464 @@
+// viterbi_lane_kernels.hip -- the K=7 rate-1/4 soft Viterbi for LARGE batches: one codeword per LANE.
+//
+// viterbi_kernels.hip spends a whole wavefront on one codeword (lane = state); per trellis step that costs
+// ~10 VALU + ~6 SALU instructions for 64 add-compare-selects because branch metrics, the lane exchange and the
+// survivor bookkeeping are paid per state.  Here a lane owns a codeword and keeps all 64 path metrics in 32
+// VGPRs as packed int16 pairs, so per step a wave does 64 codewords x 64 ACS in ~250 instructions (~4 per
+// codeword-step) with no cross-lane traffic at all.  It needs >= ~25k codewords per launch to fill the chip
+// (one wave = 64 codewords), so the launcher picks it by batch size (rows A8..A12 of SURVEY.md section 8a,
+// same results bit for bit).
+//
+// Exactness.  Metrics are stored doubled (2m, LSB clear).  The candidate through the older-bit-1 predecessor
+// is even, the one through the older-bit-0 predecessor is made odd by adding 1, so one packed max yields both
+// the survivor metric (after clearing the LSB, exactly 2m again) and, in its LSB, the survivor tag with the
+// reference tie rule (older-bit-1 wins only when strictly larger: 2*m0 + 1 > 2*m1  <=>  m0 >= m1).  Every 12 steps the metric of one slot is subtracted
+// from all (a common offset never changes a decision); with start penalty 6144 (> 6*2*508, the largest lead a
+// wrong start state can gain before its path merges, so equivalent to the reference's "known start state") the
+// doubled values stay within +-24480 < 2^15.
+//
+// Layout.  Slot p (0..63) = register p/2, half p%2 holds state rotl6(p, t mod 6) at step t.  Going from t to t+1
+// only bit q = (5 - t) mod 6 of the slot index changes meaning (oldest bit out, newest bit in), so the two
+// predecessors of slot p are the slots p with bit q cleared / set: for q >= 1 that is a PAIR OF REGISTERS updated
+// in place by packed add/sub/max on both halves at once; for q = 0 it is the two halves of one register (one
+// half-swap).  Nothing ever moves.
+#include <algorithm>
+
+#include "kernels.hpp"
+#include "dab_tables.hpp"
+
+namespace dabk {
+
+using namespace dab;
+
+namespace {
+
+constexpr int LANE_INIT2 = 2 * 6144;      // doubled start penalty of states != 0
+
+typedef short s2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned as_u(s2 v) { return __builtin_bit_cast(unsigned, v); }
+__device__ __forceinline__ s2 as_s2(unsigned v) { return __builtin_bit_cast(s2, v); }
+__device__ __forceinline__ unsigned pk_add(unsigned a, unsigned b) { return as_u(as_s2(a) + as_s2(b)); }
+__device__ __forceinline__ unsigned pk_sub(unsigned a, unsigned b) { return as_u(as_s2(a) - as_s2(b)); }
+__device__ __forceinline__ unsigned pk_max(unsigned a, unsigned b) {
+    return as_u(__builtin_elementwise_max(as_s2(a), as_s2(b)));
+}
+// (lo16(lo), lo16(hi))
+__device__ __forceinline__ unsigned pack16(int lo, int hi) { return __builtin_amdgcn_perm(unsigned(hi), unsigned(lo), 0x05040100u); }
+__device__ __forceinline__ unsigned swap16(unsigned a) { return __builtin_amdgcn_perm(a, a, 0x01000302u); }
+
+__host__ __device__ constexpr int par7(int x) { x ^= x >> 4; x ^= x >> 2; x ^= x >> 1; return x & 1; }
+__host__ __device__ constexpr int rotl6c(int v, int r) { return r == 0 ? v : (((v << r) | (v >> (6 - r))) & 63); }
+// sign pattern of the branch (state n reached from its older-bit-0 predecessor): bit0 <-> (s0+s3), bit1 <-> s1, bit2 <-> s2
+__host__ __device__ constexpr int sig_of(int n) { return par7(n & 109) | (par7(n & 79) << 1) | (par7(n & 83) << 2); }
+
+// ---- where a codeword's punctured soft bits come from ----
+// row(g): first punctured byte of codeword g.  PRE = how many earlier codewords a codeword draws from (the time
+// de-interleaver reads CIFs t-15..t of its own stream; consecutive codeword indices are consecutive CIFs).
+struct LSrcFic {
+    static constexpr int PRE = 0;
+    const int8_t *soft;
+    size_t stride;
+    __device__ __forceinline__ const int8_t *row(int g) const {
+        return soft + size_t(g >> 2) * stride + size_t(g & 3) * NB_FIC_GROUP_BITS;
+    }
+};
+struct LSrcPlain {
+    static constexpr int PRE = 0;
+    const int8_t *punct;
+    int n_punct;
+    __device__ __forceinline__ const int8_t *row(int g) const { return punct + size_t(g) * n_punct; }
+};
+struct LSrcMsc {
+    static constexpr int PRE = 15;
+    const int8_t *soft;
+    size_t stride;
+    const int8_t *hist;
+    int cifs_per_stream;
+    int start_bit;
+    int nbits;
+    __device__ __forceinline__ const int8_t *row(int g) const {
+        return soft + size_t(g >> 2) * stride + NB_FIC_BITS + size_t(g & 3) * NB_CIF_BITS + start_bit;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// K1: depuncture (+ time de-interleave) + transpose.  Block = (group of 64 codewords, tile of 64 steps).
+// The punctured bytes the tile needs -- one contiguous span of <= 256 bytes per source codeword -- are staged
+// in LDS with 16-byte loads along the codewords; then every thread assembles the 4 soft bytes of (step, lane)
+// from LDS and the stores run along the lanes: M[group][step][lane].
+// ---------------------------------------------------------------------------------------------------------
+constexpr int PREP_STEPS = 64;
+constexpr int PREP_PITCH = 276;                               // bytes per staged row: 17 chunks + pad, 69 dwords (odd)
+
+template <class Src>
+__global__ __launch_bounds__(256) void lane_prep_kernel(Src src, const int32_t *punct_idx, int nsteps, int n_codewords,
+                                                        int vec16, uint32_t *M) {
+    constexpr int ROWS = 64 + Src::PRE;
+    __shared__ __attribute__((aligned(16))) uint8_t win[ROWS * PREP_PITCH];
+    __shared__ int s_idx[4 * PREP_STEPS];
+    __shared__ int s_lo, s_hi;
+    const int tid = threadIdx.x;
+    const int group = blockIdx.y;
+    const int t0 = blockIdx.x * PREP_STEPS;
+    const int cw0 = group * 64;
+    if (tid == 0) { s_lo = 0x7fffffff; s_hi = 0; }
+    __syncthreads();
+    {
+        const int p = 4 * t0 + tid;
+        const int idx = (p < 4 * nsteps) ? punct_idx[p] : -1;
+        s_idx[tid] = idx;
+        if (idx >= 0) { atomicMin(&s_lo, idx); atomicMax(&s_hi, idx + 1); }
+    }
+    __syncthreads();
+    const int lo = s_lo, hi = s_hi;
+    const int lo_al = lo & ~15;
+    if (hi > lo) {
+        // stage rows cw0-PRE .. cw0+63 (those that exist)
+        if (vec16) {
+            const int nchunks = (hi - lo_al + 15) >> 4;       // <= 17
+            for (int i = tid; i < ROWS * nchunks; i += 256) {
+                const int row = i / nchunks, c = i - row * nchunks;
+                const int g = cw0 - Src::PRE + row;
+                if (g < 0 || g >= n_codewords) continue;
+                const uint4 v = *reinterpret_cast<const uint4 *>(src.row(g) + lo_al + 16 * c);
+                uint32_t *d = reinterpret_cast<uint32_t *>(win + row * PREP_PITCH + 16 * c);
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+        } else {
+            const int span = hi - lo_al;
+            for (int i = tid; i < ROWS * span; i += 256) {
+                const int row = i / span, c = i - row * span;
+                const int g = cw0 - Src::PRE + row;
+                if (g < 0 || g >= n_codewords) continue;
+                win[row * PREP_PITCH + c] = uint8_t(src.row(g)[lo_al + c]);
+            }
+        }
+    }
+    __syncthreads();
+    const int lane = tid & 63;
+    const int r_eff = min(lane, n_codewords - 1 - cw0);       // lanes past the end repeat the last codeword
+    int t_in_stream = 0, stream = 0;
+    if constexpr (Src::PRE > 0) {
+        const int cw = cw0 + r_eff;
+        stream = cw / src.cifs_per_stream;
+        t_in_stream = cw - stream * src.cifs_per_stream;
+    }
+    for (int sstep = tid >> 6; sstep < PREP_STEPS; sstep += 4) {
+        const int t = t0 + sstep;
+        if (t >= nsteps) break;
+        uint32_t w = 0;
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const int idx = s_idx[4 * sstep + m];
+            if (idx < 0) continue;
+            unsigned v;
+            if constexpr (Src::PRE > 0) {
+                const int d = int(__brev(unsigned(idx) & 15u) >> 28);
+                if (t_in_stream + d >= 15) {
+                    v = win[(r_eff + d) * PREP_PITCH + (idx - lo_al)];
+                } else {                                      // before the stream's first CIF: carried history
+                    v = src.hist ? uint8_t(src.hist[(size_t(stream) * 15 + t_in_stream + d) * src.nbits + idx]) : 0u;
+                }
+            } else {
+                v = win[r_eff * PREP_PITCH + (idx - lo_al)];
+            }
+            w |= v << (8 * m);
+        }
+        M[(size_t(group) * nsteps + t) * 64 + lane] = w;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K2: forward pass.  One wave = 64 codewords.
+// ---------------------------------------------------------------------------------------------------------
+// doubled branch correlations for the 8 sign patterns, low 16 bits valid
+struct Bm {
+    int c2[8];
+};
+__device__ __forceinline__ Bm branch_metrics(uint32_t w) {
+    const int s0 = int(int8_t(w)), s1 = int(int8_t(w >> 8)), s2 = int(int8_t(w >> 16)), s3 = int(w) >> 24;
+    const int a = 2 * (s0 + s3), b = 2 * s1, c = 2 * s2;
+    const int e1 = a + b, e2 = a - b;
+    Bm m;
+    m.c2[7] = e1 + c;          // (+,+,+)
+    m.c2[3] = e1 - c;          // (+,+,-)
+    m.c2[5] = e2 + c;          // (+,-,+)
+    m.c2[1] = e2 - c;          // (+,-,-)
+    m.c2[0] = -m.c2[7];
+    m.c2[4] = -m.c2[3];
+    m.c2[2] = -m.c2[5];
+    m.c2[6] = -m.c2[1];
+    return m;
+}
+
+// Record the survivor tags (bits 0 and 16 of the max results) of a pair of registers: one byte gather, one mask,
+// one shift-or.  Pair I puts its 4 tags into bits I%8 + {0, 8, 16, 24} of word I/8, in the order (first register
+// low half, high half, second register low half, high half).  The tags also stay in the registers: the next step
+// forces them to 1 or 0 anyway when it makes the operand odd or even.
+template <int I>
+__device__ __forceinline__ void take_tags(unsigned first, unsigned second, unsigned &acc0, unsigned &acc1) {
+    const unsigned g = __builtin_amdgcn_perm(second, first, 0x06040200u) & 0x01010101u;
+    if constexpr (I < 8) asm("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(acc0) : "v"(g), "n"(I & 7));
+    else asm("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(acc1) : "v"(g), "n"(I & 7));
+}
+
+template <int PH, int I>
+__device__ __forceinline__ void lane_pair(unsigned (&M)[32], const Bm &bm, unsigned &acc0, unsigned &acc1) {
+    constexpr int Q = 5 - PH;                 // slot bit replaced in this step, 1..5 here
+    constexpr int RB = Q - 1;                 // the same bit in register-index space
+    constexpr int RA = ((I >> RB) << (RB + 1)) | (I & ((1 << RB) - 1));
+    constexpr int RBI = RA | (1 << RB);
+    constexpr int ROT = (PH + 1) % 6;         // layout after the step
+    constexpr int SLO = sig_of(rotl6c(2 * RA, ROT)), SHI = sig_of(rotl6c(2 * RA + 1, ROT));
+    const unsigned k2 = pack16(bm.c2[SLO], bm.c2[SHI]);        // 2c of the two new states of register RA
+    const unsigned a1 = M[RA] | 0x00010001u;                   // older-bit-0 candidates are odd (metric + 1)
+    const unsigned b = M[RBI] & 0xFFFEFFFEu;                   // older-bit-1 candidates even (metric)
+    const unsigned x = pk_add(a1, k2), y = pk_sub(b, k2);      // new states with newest bit 0 (register RA)
+    const unsigned u = pk_sub(a1, k2), v = pk_add(b, k2);      // newest bit 1 (register RB): c flips sign
+    M[RA] = pk_max(x, y);
+    M[RBI] = pk_max(u, v);
+    take_tags<I>(M[RA], M[RBI], acc0, acc1);
+}
+
+template <int R>
+__device__ __forceinline__ unsigned lane_self1(unsigned m, const unsigned (&kk)[8]) {
+    // phase 5: the replaced bit is the half bit; both predecessors live in this register.  After the step the
+    // layout rotation is 0, so the new state of slot 2R is 2R itself.
+    constexpr int S = sig_of(2 * R);
+    const unsigned a = (m & 0xFFFEFFFFu) | 1u;           // (lo + 1, hi): odd older-bit-0, even older-bit-1 operand
+    const unsigned p = pk_add(a, kk[S]);                 // (lo + 1 + 2c, hi + 2c)
+    const unsigned q = pk_sub(swap16(a), kk[S]);         // (hi - 2c, lo + 1 - 2c)
+    return pk_max(p, q);
+}
+template <int I>
+__device__ __forceinline__ void lane_self(unsigned (&M)[32], const unsigned (&kk)[8], unsigned &acc0, unsigned &acc1) {
+    M[2 * I] = lane_self1<2 * I>(M[2 * I], kk);
+    M[2 * I + 1] = lane_self1<2 * I + 1>(M[2 * I + 1], kk);
+    take_tags<I>(M[2 * I], M[2 * I + 1], acc0, acc1);
+}
+
+template <int PH>
+__device__ __forceinline__ void lane_step(unsigned (&M)[32], uint32_t w, uint2 *dec_out) {
+    const Bm bm = branch_metrics(w);
+    unsigned acc0 = 0, acc1 = 0;
+    if constexpr (PH < 5) {
+        lane_pair<PH, 0>(M, bm, acc0, acc1);  lane_pair<PH, 1>(M, bm, acc0, acc1);
+        lane_pair<PH, 2>(M, bm, acc0, acc1);  lane_pair<PH, 3>(M, bm, acc0, acc1);
+        lane_pair<PH, 4>(M, bm, acc0, acc1);  lane_pair<PH, 5>(M, bm, acc0, acc1);
+        lane_pair<PH, 6>(M, bm, acc0, acc1);  lane_pair<PH, 7>(M, bm, acc0, acc1);
+        lane_pair<PH, 8>(M, bm, acc0, acc1);  lane_pair<PH, 9>(M, bm, acc0, acc1);
+        lane_pair<PH, 10>(M, bm, acc0, acc1); lane_pair<PH, 11>(M, bm, acc0, acc1);
+        lane_pair<PH, 12>(M, bm, acc0, acc1); lane_pair<PH, 13>(M, bm, acc0, acc1);
+        lane_pair<PH, 14>(M, bm, acc0, acc1); lane_pair<PH, 15>(M, bm, acc0, acc1);
+    } else {
+        unsigned kk[8];
+#pragma unroll
+        for (int s = 0; s < 8; s++) kk[s] = pack16(bm.c2[s], bm.c2[s]);
+        lane_self<0>(M, kk, acc0, acc1);          lane_self<1>(M, kk, acc0, acc1);
+        lane_self<2>(M, kk, acc0, acc1);          lane_self<3>(M, kk, acc0, acc1);
+        lane_self<4>(M, kk, acc0, acc1);          lane_self<5>(M, kk, acc0, acc1);
+        lane_self<6>(M, kk, acc0, acc1);          lane_self<7>(M, kk, acc0, acc1);
+        lane_self<8>(M, kk, acc0, acc1);          lane_self<9>(M, kk, acc0, acc1);
+        lane_self<10>(M, kk, acc0, acc1);          lane_self<11>(M, kk, acc0, acc1);
+        lane_self<12>(M, kk, acc0, acc1);          lane_self<13>(M, kk, acc0, acc1);
+        lane_self<14>(M, kk, acc0, acc1);          lane_self<15>(M, kk, acc0, acc1);
+    }
+    *dec_out = make_uint2(acc0, acc1);
+}
+
+// Four groups per workgroup (one per SIMD); the launcher pads the LDS request so that every CU gets the same
+// number of workgroups -- the dispatcher otherwise packs some SIMDs with 3 waves while others hold 1.
+__global__ __launch_bounds__(256) void lane_forward_kernel(const uint32_t *Msoft, int nsteps, int groups, uint2 *dec) {
+    const int lane = threadIdx.x & 63;
+    const int group = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (group >= groups) return;
+    const size_t base = size_t(group) * nsteps * 64 + lane;
+    const uint32_t *src = Msoft + base;
+    uint2 *dst = dec + base;
+    unsigned M[32];
+#pragma unroll
+    for (int r = 0; r < 32; r++) M[r] = pack16(-LANE_INIT2, -LANE_INIT2);
+    M[0] = pack16(0, -LANE_INIT2);                         // state 0 sits in slot 0 at t = 0
+    uint32_t w[6], wn[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) w[i] = src[size_t(i) * 64];
+    for (int t = 0; t < nsteps; t += 6) {
+        const int tn = (t + 6 < nsteps) ? t + 6 : t;       // prefetch the next phase cycle (last one re-reads)
+#pragma unroll
+        for (int i = 0; i < 6; i++) wn[i] = src[size_t(tn + i) * 64];
+        lane_step<0>(M, w[0], dst + size_t(t + 0) * 64);
+        lane_step<1>(M, w[1], dst + size_t(t + 1) * 64);
+        lane_step<2>(M, w[2], dst + size_t(t + 2) * 64);
+        lane_step<3>(M, w[3], dst + size_t(t + 3) * 64);
+        lane_step<4>(M, w[4], dst + size_t(t + 4) * 64);
+        lane_step<5>(M, w[5], dst + size_t(t + 5) * 64);
+        if (((t / 6) & 1) == 1) {                          // every 12 steps (two phase cycles)
+            const unsigned ref = pack16(int(M[0]), int(M[0])) & 0xFFFEFFFEu;
+#pragma unroll
+            for (int r = 0; r < 32; r++) M[r] = pk_sub(M[r], ref);
+        }
+#pragma unroll
+        for (int i = 0; i < 6; i++) w[i] = wn[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K3: traceback + output.  One wave per group, one lane per codeword, from slot 0 (end state 0 sits in slot 0
+// in every layout).  The survivor tag of slot p sits where take_tags() put it, set when the older-bit-0
+// predecessor survived; the bit the step replaces in the slot index is the decoded input bit.
+// Decoded words go to an LDS tile [codeword][word]; the group's output bytes are one contiguous block, written
+// with dword stores after energy dispersal; FIB CRCs are checked from the tile.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lane_tb_step(const uint2 d, int t, int nsteps, unsigned &p, int &q, unsigned &word,
+                                             uint32_t *row) {
+    // where the forward pass put the tag of slot p: registers were paired across register-index bit rb
+    const unsigned rb = unsigned(q > 0 ? q - 1 : 0);
+    const unsigned R = p >> 1;
+    const unsigned I = ((R >> (rb + 1)) << rb) | (R & ((1u << rb) - 1u));
+    const unsigned sel = (I & 8u) ? d.y : d.x;
+    const unsigned h = (~sel >> (((((R >> rb) & 1u) << 1 | (p & 1u)) << 3) + (I & 7u))) & 1u;
+    const unsigned b = (p >> q) & 1u;
+    if (t < nsteps - 6) {
+        word |= b << (31 - (t & 31));
+        if ((t & 31) == 0) {
+            row[t >> 5] = word;
+            word = 0;
+        }
+    }
+    p = (p & ~(1u << q)) | (h << q);
+    q = (q == 5) ? 0 : q + 1;                                // q(t-1) = (5 - (t-1)) mod 6
+}
+
+__device__ __forceinline__ unsigned crc16_byte_l(unsigned crc, unsigned byte) {
+    crc = ((crc >> 8) | (crc << 8)) & 0xFFFFu;
+    crc ^= byte;
+    crc ^= (crc & 0xFFu) >> 4;
+    crc ^= (crc << 12) & 0xFFFFu;
+    crc ^= ((crc & 0xFFu) << 5) & 0xFFFFu;
+    return crc;
+}
+
+__global__ __launch_bounds__(64) void lane_traceback_kernel(const uint2 *dec, int nsteps, int n_codewords,
+                                                            const uint8_t *prbs_bytes, uint8_t *out, uint8_t *crc_ok) {
+    extern __shared__ uint32_t tile[];                        // [64][nwords + 1]
+    const int lane = threadIdx.x;
+    const int group = blockIdx.x;
+    const uint2 *src = dec + size_t(group) * nsteps * 64 + lane;
+    const int nwords = (nsteps - 6) >> 5;
+    const int pitch = nwords | 1;                             // odd -> rows start in different banks
+    uint32_t *row = tile + lane * pitch;
+    unsigned p = 0, word = 0;
+    int q = 5 - ((nsteps - 1) % 6);
+    // The survivor words do not depend on the path: they are fetched a block of 32 steps ahead, only the slot
+    // update is serial.
+    uint2 d[32], dn[32];
+#pragma unroll
+    for (int i = 0; i < 6; i++) d[i] = src[size_t(nsteps - 1 - i) * 64];
+#pragma unroll
+    for (int i = 0; i < 32; i++) dn[i] = src[size_t(nsteps - 7 - i) * 64];
+#pragma unroll
+    for (int i = 0; i < 6; i++) lane_tb_step(d[i], nsteps - 1 - i, nsteps, p, q, word, row);
+    for (int t1 = nsteps - 7; t1 >= 0; t1 -= 32) {            // nsteps - 6 is a multiple of 32
+#pragma unroll
+        for (int i = 0; i < 32; i++) d[i] = dn[i];
+        if (t1 >= 32) {
+#pragma unroll
+            for (int i = 0; i < 32; i++) dn[i] = src[size_t(t1 - 32 - i) * 64];
+        }
+#pragma unroll
+        for (int i = 0; i < 32; i++) lane_tb_step(d[i], t1 - i, nsteps, p, q, word, row);
+    }
+    __syncthreads();
+    // output: codewords of a group are adjacent in the output, so the tile is one contiguous run of dwords
+    const int nvalid = min(64, n_codewords - group * 64);
+    const uint32_t *prbs32 = reinterpret_cast<const uint32_t *>(prbs_bytes);
+    uint32_t *out32 = reinterpret_cast<uint32_t *>(out + size_t(group) * 64 * nwords * 4);
+    for (int i = lane; i < nvalid * nwords; i += 64) {
+        const int r = i / nwords, w = i - r * nwords;
+        uint32_t v = __builtin_bswap32(tile[r * pitch + w]);  // MSB-first bytes in memory order
+        if (prbs32) v ^= prbs32[w];
+        out32[i] = v;
+        if (crc_ok) tile[r * pitch + w] = v;                  // descrambled, memory byte order, for the CRC
+    }
+    if (crc_ok) {                                             // FIC: three 32-byte FIBs per codeword
+        __syncthreads();
+        const int nfib = nwords >> 3;
+        for (int j = lane; j < nvalid * nfib; j += 64) {
+            const int r = j / nfib, fi = j - r * nfib;
+            const uint32_t *wp = tile + r * pitch + 8 * fi;
+            unsigned crc = 0xFFFFu;
+#pragma unroll
+            for (int k = 0; k < 30; k++) crc = crc16_byte_l(crc, (wp[k >> 2] >> (8 * (k & 3))) & 0xFFu);
+            const unsigned rx = ((wp[7] >> 16) & 0xFFu) << 8 | (wp[7] >> 24);
+            crc_ok[(size_t(group) * 64) * nfib + j] = uint8_t((crc ^ 0xFFFFu) == rx);
+        }
+    }
+}
+
+template <class Src>
+hipError_t run_lane(Src f, bool vec16, const CodeTables &c, const int32_t *punct_idx, int n_codewords,
+                    const LaneScratch &sc, uint8_t *out, uint8_t *crc_ok, hipStream_t s) {
+    const int groups = (n_codewords + 63) / 64;
+    const int nwords = (c.nsteps - 6) >> 5;
+    const size_t need = lane_scratch_bytes(c.nsteps, n_codewords);
+    if (!sc.base || sc.bytes < need || (reinterpret_cast<uintptr_t>(out) & 3)) return hipErrorInvalidValue;
+    uint32_t *M = reinterpret_cast<uint32_t *>(sc.base);
+    uint2 *dec = reinterpret_cast<uint2 *>(M + size_t(groups) * c.nsteps * 64);
+    hipLaunchKernelGGL((lane_prep_kernel<Src>), dim3(unsigned((c.nsteps + PREP_STEPS - 1) / PREP_STEPS), unsigned(groups)),
+                       dim3(256), 0, s, f, punct_idx, c.nsteps, n_codewords, int(vec16), M);
+    const unsigned fgrid = unsigned((groups + 3) / 4);
+    const size_t fwd_lds = balanced_lds_bytes(fgrid, 0, 8);
+    if (fwd_lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lane_forward_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, int(fwd_lds));
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(lane_forward_kernel, dim3(fgrid), dim3(256), fwd_lds, s, M, c.nsteps, groups, dec);
+    const size_t tb_lds = size_t(64) * (nwords | 1) * 4;
+    if (tb_lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lane_traceback_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, int(tb_lds));
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(lane_traceback_kernel, dim3(unsigned(groups)), dim3(64), tb_lds, s, dec, c.nsteps, n_codewords,
+                       c.prbs_bytes, out, crc_ok);
+    return hipGetLastError();
+}
+
+inline bool aligned16(const void *p, size_t stride) { return ((reinterpret_cast<uintptr_t>(p) | stride) & 15) == 0; }
+
+}  // namespace
+
+size_t lane_scratch_bytes(int nsteps, int n_codewords) {
+    const size_t groups = size_t((n_codewords + 63) / 64);
+    const size_t nwords = size_t((nsteps - 6) >> 5);
+    (void)nwords;
+    return groups * 64 * size_t(nsteps) * 12 + 256;           // soft dwords + survivor words
+}
+
+bool lane_supported(int nsteps) {
+    // whole phase cycles, whole 32-bit output words, and the traceback tile (64 x words) must fit in LDS
+    return nsteps >= 38 && nsteps % 6 == 0 && ((nsteps - 6) & 31) == 0 && size_t(64) * (((nsteps - 6) >> 5) | 1) * 4 <= 150 * 1024;
+}
+
+hipError_t launch_fic_decode_lane(const CodeTables &c, const int32_t *punct_idx, const int8_t *soft, size_t soft_stride,
+                                  int n_frames, const LaneScratch &sc, uint8_t *fib, uint8_t *crc_ok, hipStream_t s) {
+    return run_lane(LSrcFic{soft, soft_stride}, aligned16(soft, soft_stride), c, punct_idx, n_frames * NB_FIC_GROUPS, sc,
+                    fib, crc_ok, s);
+}
+
+hipError_t launch_viterbi_plain_lane(const CodeTables &c, const int32_t *punct_idx, const int8_t *punct,
+                                     int n_codewords, const LaneScratch &sc, uint8_t *out, hipStream_t s) {
+    return run_lane(LSrcPlain{punct, c.n_punct}, aligned16(punct, size_t(c.n_punct)), c, punct_idx, n_codewords, sc, out,
+                    nullptr, s);
+}
+
+hipError_t launch_msc_decode_lane(const CodeTables &c, const int32_t *punct_idx, const MscArgs &a, const LaneScratch &sc,
+                                  hipStream_t s) {
+    LSrcMsc f{a.soft, a.soft_stride, a.hist_in, a.frames_per_stream * NB_CIFS, a.start_bit, a.nbits};
+    return run_lane(f, aligned16(a.soft, a.soft_stride) && (a.start_bit & 15) == 0, c, punct_idx,
+                    a.n_streams * a.frames_per_stream * NB_CIFS, sc, a.out, nullptr, s);
+}
+
+}  // namespace dabk
