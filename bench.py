@@ -3,7 +3,8 @@
 
 One step = one pass of the hot path over one batch of synthetic input that is already
 resident in HBM: `--ensembles` independent DAB ensembles per GPU x `--frames` consecutive
-transmission frames each (default 64 x 64 = 4096 frames, 6.4 GB of cf32 IQ).  Per step:
+transmission frames each (default 64 x 256 = 16384 frames, 25.8 GB of cf32 IQ: BASELINE config 4,
+64 ensembles per GPU, >= 256 frames per stream).  Per step:
   dabgpu_ofdm_demod_frames_dev -> dabgpu_fic_decode_dev -> dabgpu_msc_decode_dev
 all through the C ABI (include/dabgpu.h) on the current torch stream.  torch is plumbing:
 device buffers, stream, events, and torch.distributed (RCCL) for the barrier / max-reduce.
@@ -29,6 +30,8 @@ A_OFDM = 76 * 2552 * 8 + 230400            # 1 782 016 B
 A_FFT = 76 * 2552 * 8 + 76 * 2048 * 8      # 2 796 800 B (unfused FFT stage)
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: 8 TB/s spec
 REALTIME_FPS = 1.0 / 0.096
+ACS_FIC = 4 * 774 * 64                    # add-compare-selects per frame, FIC
+ACS_MSC64 = 4 * 1542 * 64                 # one 64 kbit/s EEP 3-A subchannel (A12)
 
 
 def make_streams(torch, dev, n_ens, n_frames, n_unique, rank, snr_db):
@@ -52,6 +55,23 @@ def make_streams(torch, dev, n_ens, n_frames, n_unique, rank, snr_db):
     return iq, fo, ens
 
 
+def copy_ceiling(torch, dev):
+    """Measured device-to-device copy rate (read + write bytes), GB/s: the practical HBM ceiling next to the 8 TB/s
+    spec figure."""
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.uint8, device=dev)
+    b = torch.empty(n, dtype=torch.uint8, device=dev)
+    for _ in range(2):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * n * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def cpu_baseline(iq_host, fo_host, sc_len_bits, mask, nsteps, budget_s, threads):
     """Time the CPU oracle ('port', oracle/dab_oracle.c driven by oracle/oracle_bench.c) on the same workload:
     OFDM demod + FIC + 4 MSC logical frames per transmission frame.  Bounded sample; one pthread per host core,
@@ -72,7 +92,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--ensembles", type=int, default=64, help="independent ensembles per GPU")
-    ap.add_argument("--frames", type=int, default=64, help="consecutive frames per ensemble per step (multiple of 4)")
+    ap.add_argument("--frames", type=int, default=256, help="consecutive frames per ensemble per step (multiple of 4)")
     ap.add_argument("--unique", type=int, default=8, help="distinct synthetic multiplexes generated on the host")
     ap.add_argument("--snr", type=float, default=20.0)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
@@ -120,20 +140,24 @@ def main():
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream
     d_iq = iq.data_ptr() + synth.NB_NULL * 8          # first PRS sample of frame 0
-    ofdm_ev = []
+    ofdm_ev, fic_ev, msc_ev = [], [], []
 
     def step(k, timed):
         if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            ev[0].record()
         ctx.ofdm_demod_frames_dev(d_iq, synth.NB_FRAME_SAMPLES, n_frames, fo.data_ptr(), soft.data_ptr(),
                                   cyc.data_ptr(), None, stream)
         if timed:
-            e1.record()
-            ofdm_ev.append((e0, e1))
+            ev[1].record()
         ctx.fic_decode_dev(soft.data_ptr(), dabgpu.NB_FRAME_BITS, n_frames, fib.data_ptr(), crc.data_ptr(), stream)
+        if timed:
+            ev[2].record()
         ctx.msc_decode_dev(sc, soft.data_ptr(), dabgpu.NB_FRAME_BITS, E, F, hist[k & 1].data_ptr(),
                            hist[(k & 1) ^ 1].data_ptr(), msc.data_ptr(), stream)
+        if timed:
+            ev[3].record()
+            ofdm_ev.append((ev[0], ev[1])); fic_ev.append((ev[1], ev[2])); msc_ev.append((ev[2], ev[3]))
 
     def barrier():
         torch.cuda.synchronize()
@@ -170,6 +194,8 @@ def main():
                                                             [fic_ok, msc_ok])
 
     ofdm_ms = float(np.mean([a.elapsed_time(b) for a, b in ofdm_ev]))
+    fic_ms = float(np.mean([a.elapsed_time(b) for a, b in fic_ev]))
+    msc_ms = float(np.mean([a.elapsed_time(b) for a, b in msc_ev]))
 
     if rank == 0:
         value = frames_total / elapsed
@@ -197,7 +223,11 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "dabk::ofdm_wave_kernel<false,false> (fused A2..A6)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "avg_launch_ms": ofdm_ms, "frames_per_launch": n_frames,
-                         "algorithmic_bytes_per_frame": A_OFDM},
+                         "algorithmic_bytes_per_frame": A_OFDM,
+                         "copy_ceiling": copy_ceiling(torch, dev)},
+            # the channel decoder is integer add-compare-select work, not bandwidth: report ACS/s
+            "decoder": {"fic_ms": fic_ms, "msc_ms": msc_ms,
+                        "acs_per_s": (ACS_FIC + ACS_MSC64) * n_frames / ((fic_ms + msc_ms) * 1e-3)},
         }
         if not args.no_fft_stage:
             spectra = torch.empty((n_frames, 76, 2048), dtype=torch.complex64, device=dev)

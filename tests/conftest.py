@@ -40,10 +40,26 @@ def ensemble_iq(ensemble):
     return ensemble.iq()
 
 
-@pytest.fixture(scope="session")
-def ctx(built):
+def make_ctx(lane_mode=None, max_frames=64):
+    """Context with the Viterbi variant pinned: None = chosen by batch size (the default), 1 = the
+    codeword-per-lane kernels even for small batches, 0 = the wave-per-codeword kernels only."""
     import dabgpu
-    c = dabgpu.Context(device=0, max_frames=64)
+    old = os.environ.pop("DABGPU_VITERBI_LANE", None)
+    if lane_mode is not None:
+        os.environ["DABGPU_VITERBI_LANE"] = str(lane_mode)
+    try:
+        return dabgpu.Context(device=0, max_frames=max_frames)
+    finally:
+        os.environ.pop("DABGPU_VITERBI_LANE", None)
+        if old is not None:
+            os.environ["DABGPU_VITERBI_LANE"] = old
+
+
+@pytest.fixture(scope="session", params=["auto", "lane"])
+def ctx(built, request):
+    """Every parity test runs twice: with the default kernel selection (small test batches -> one wavefront per
+    codeword) and with the large-batch codeword-per-lane Viterbi forced, so both are held to the oracle."""
+    c = make_ctx(1 if request.param == "lane" else None)
     yield c
     c.close()
 

@@ -1,0 +1,74 @@
+"""The large-batch (codeword-per-lane) Viterbi against the small-batch kernels and the oracle at the batch sizes
+where the library switches over by itself (>= 24576 codewords per launch)."""
+import numpy as np
+import pytest
+import torch
+
+import dabgpu
+from conftest import make_ctx
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def test_switch_over_is_bit_exact():
+    n_streams, fps = 14, 448                                 # 6272 frames -> 25088 FIC and MSC codewords
+    n = n_streams * fps
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    stride = 16384                                           # compact frames: only the FIC part is present
+    soft = torch.zeros((n, stride), dtype=torch.int8, device=dev)
+    soft[:, :dabgpu.NB_FIC_BITS] = torch.randint(-127, 128, (n, dabgpu.NB_FIC_BITS), dtype=torch.int8, device=dev,
+                                                 generator=g)
+    outs = []
+    for mode in (0, None):
+        c = make_ctx(mode, max_frames=64)
+        fib = torch.zeros((n, 12, 32), dtype=torch.uint8, device=dev)
+        ok = torch.zeros((n, 12), dtype=torch.uint8, device=dev)
+        c.fic_decode_dev(soft.data_ptr(), stride, n, fib.data_ptr(), ok.data_ptr(), None)
+        c.sync()
+        outs.append((fib.cpu().numpy(), ok.cpu().numpy()))
+        c.close()
+    assert (outs[0][0] == outs[1][0]).all() and (outs[0][1] == outs[1][1]).all()
+    # spot-check the oracle on a few codewords from both ends of the batch
+    s = soft.cpu().numpy()
+    for f in (0, 1, n // 2, n - 1):
+        ofib, ook = O.fic_decode(s[f, :dabgpu.NB_FIC_BITS])
+        assert (outs[1][0][f] == np.asarray(ofib).reshape(12, 32)).all() and (outs[1][1][f] == ook).all()
+
+
+def test_switch_over_msc_with_history_and_ragged_streams():
+    # 25 streams x 247 frames: 24700 codewords, stream length not a multiple of the 64-codeword groups, so groups
+    # straddle streams and the de-interleaver history of each stream is picked up inside a group
+    n_streams, fps = 25, 247
+    sc = dabgpu.subchannel(3, 32, level=2)                   # 32 kbit/s EEP 2-A
+    nbits = sc.length * 64
+    n = n_streams * fps
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev); g.manual_seed(9)
+    stride = 4 * 55296 + dabgpu.NB_FIC_BITS
+    soft = torch.zeros((n, stride), dtype=torch.int8, device=dev)
+    view = soft[:, dabgpu.NB_FIC_BITS:].view(n, 4, 55296)[:, :, 3 * 64:3 * 64 + nbits]
+    view.copy_(torch.randint(-127, 128, (n, 4, nbits), dtype=torch.int8, device=dev, generator=g))
+    hist = torch.randint(-127, 128, (n_streams, 15, nbits), dtype=torch.int8, device=dev, generator=g)
+    nbytes = 32 * 3
+    res = []
+    for mode in (0, None):
+        c = make_ctx(mode, max_frames=64)
+        out = torch.zeros((n_streams, fps * 4, nbytes), dtype=torch.uint8, device=dev)
+        hout = torch.zeros_like(hist)
+        c.msc_decode_dev(sc, soft.data_ptr(), stride, n_streams, fps, hist.data_ptr(), hout.data_ptr(), out.data_ptr(), None)
+        c.sync()
+        res.append((out.cpu().numpy(), hout.cpu().numpy()))
+        c.close()
+    assert (res[0][0] == res[1][0]).all() and (res[0][1] == res[1][1]).all()
+    # oracle on the first CIFs of one stream (history in play) and the last CIF of the last stream
+    mask = O.eep_puncture_mask(0, 2, 32)[0]
+    s_np = view[:fps * 1].cpu().numpy().reshape(fps * 4, nbits)
+    padded = np.concatenate([hist[0].cpu().numpy(), s_np])
+    for t in (0, 1, 14, 15, 16):
+        want = O.msc_decode_lf(O.time_deinterleave(padded[t:t + 16]), mask, 32 * 24 + 6)
+        assert (res[1][0][0, t] == want).all(), t
+    last = view[(n_streams - 1) * fps:].cpu().numpy().reshape(fps * 4, nbits)
+    want = O.msc_decode_lf(O.time_deinterleave(last[-16:]), mask, 32 * 24 + 6)
+    assert (res[1][0][-1, -1] == want).all()
