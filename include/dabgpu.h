@@ -182,6 +182,59 @@ int dabgpu_sync_prs(dabgpu_ctx *ctx, const float *iq, size_t frame_stride, int n
                     int max_coarse, dabgpu_sync_result *out);
 
 /* ------------------------------------------------------------------------ */
+/* Acquisition on unaligned captures: everything OFDM_Demod   */
+/* does before READING_SYMBOLS -- FINDING_NULL_POWER_DIP, READING_NULL_AND_PRS, */
+/* RUNNING_COARSE_FREQ_SYNC, RUNNING_FINE_TIME_SYNC                            */
+/* (/root/reference/src/render_radio_block.cpp:193-196; knobs                  */
+/* thresh_null_start/end, max_coarse_freq_correction_norm,                     */
+/* impulse_peak_threshold_db at :213-235) -- for whole captures at once.        */
+/*                                                                            */
+/* iq       stream s = iq + s*stream_stride complex samples, n_samples each;    */
+/*          any 8-byte aligned position (no frame alignment assumed)            */
+/* out      [n_streams][max_frames]: one entry per null symbol found whose      */
+/*          frame lies inside the capture, in time order; entries past          */
+/*          counts[s] have flags 0 and start -1                                 */
+/*   start            first sample of the PRS cyclic prefix minus               */
+/*                    cfg.timing_margin, relative to the stream                 */
+/*   freq_offset      correction to hand to the demodulator, cycles/sample      */
+/*                    (= fine_offset - coarse_carriers/2048)                    */
+/*   fine_offset      from the cyclic prefix of the PRS, (-0.5..0.5]/2048       */
+/*   flags            bit 0: impulse peak_to_mean >= cfg.min_peak_to_mean       */
+/*                    bit 1: all 76 symbols lie inside the capture              */
+/* dabgpu_ofdm_demod_acquired_dev demodulates exactly those frames (A2..A6 as   */
+/* dabgpu_ofdm_demod_frames): soft [n_streams*max_frames][230400]; entries      */
+/* whose flags are not 3 give all-zero (erased) soft bits.                      */
+/* ------------------------------------------------------------------------ */
+typedef struct dabgpu_acquire_cfg {
+    float thr_null_start;        /* dip begins below this fraction of the mean block L1 norm (0.35) */
+    float thr_null_end;          /* and ends above this one (0.75)                                   */
+    int32_t min_null_blocks;     /* shortest dip, in 64-sample blocks, taken for a null symbol (30)  */
+    int32_t max_coarse_carriers; /* coarse search range (200)                                        */
+    float min_peak_to_mean;      /* lock threshold on the impulse response (30 = 14.8 dB)            */
+    int32_t timing_margin;       /* samples the FFT windows are kept inside the cyclic prefix (64)   */
+} dabgpu_acquire_cfg;
+
+typedef struct dabgpu_acquired_frame {
+    int64_t start;
+    float freq_offset;
+    int32_t coarse_carriers;
+    float fine_offset;
+    float peak_to_mean;
+    float coarse_peak_to_mean;
+    int32_t flags;
+} dabgpu_acquired_frame;
+
+void dabgpu_acquire_default_cfg(dabgpu_acquire_cfg *cfg);
+int dabgpu_acquire_dev(dabgpu_ctx *ctx, const void *d_iq, size_t stream_stride, int n_streams, int64_t n_samples,
+                       const dabgpu_acquire_cfg *cfg, int max_frames, dabgpu_acquired_frame *d_out, int32_t *d_counts,
+                       void *stream);
+int dabgpu_acquire(dabgpu_ctx *ctx, const float *iq, size_t stream_stride, int n_streams, int64_t n_samples,
+                   const dabgpu_acquire_cfg *cfg, int max_frames, dabgpu_acquired_frame *out, int32_t *counts);
+int dabgpu_ofdm_demod_acquired_dev(dabgpu_ctx *ctx, const void *d_iq, size_t stream_stride, int n_streams,
+                                   int max_frames, const dabgpu_acquired_frame *d_frames, int8_t *d_soft, void *d_cyc,
+                                   void *d_dqpsk, void *stream);
+
+/* ------------------------------------------------------------------------ */
 /* A7..A11: FIC.  Replaces the FIC branch of BasicRadio::Process              */
 /*   /root/reference/src/radio_block.cpp:42 (call), :60 (ctor).               */
 /* soft      frame f's bits start at soft + f*soft_stride; the first 9216 are  */

@@ -426,6 +426,93 @@ void oracle_ofdm_demod_frame(const float *iq, float freq_offset, int8_t *soft,
 }
 
 /* ------------------------------------------------------------------------- */
+/* f-1: null-symbol search on a whole capture (see header).                       */
+/* Summation trees are fixed so the result does not depend on who computes it:    */
+/* a block is 32 pairs of samples; pair j contributes ((|x0|+|y0|)+|x1|)+|y1|,    */
+/* the 32 pair sums are combined by the butterfly p[j] += p[j ^ off],             */
+/* off = 1,2,4,8,16.                                                              */
+/* ------------------------------------------------------------------------- */
+void oracle_null_block_l1(const float *iq, int64_t n_samples, float *l1)
+{
+    const int64_t nb = n_samples / 64;
+    for (int64_t b = 0; b < nb; b++) {
+        const float *x = iq + (size_t)b * 128;
+        float p[32], q[32];
+        for (int j = 0; j < 32; j++)
+            p[j] = ((fabsf(x[4 * j]) + fabsf(x[4 * j + 1])) + fabsf(x[4 * j + 2])) + fabsf(x[4 * j + 3]);
+        for (int off = 1; off < 32; off <<= 1) {
+            for (int j = 0; j < 32; j++) q[j] = p[j] + p[j ^ off];
+            memcpy(p, q, sizeof(p));
+        }
+        l1[b] = p[0];
+    }
+}
+
+int oracle_null_search(const float *iq, int64_t n_samples, float thr_start, float thr_end, int min_blocks,
+                       int max_out, int64_t *cands)
+{
+    const int64_t nb = n_samples / 64;
+    if (nb <= 0 || max_out <= 0) return 0;
+    float *l1 = (float *)malloc(sizeof(float) * (size_t)nb);
+    oracle_null_block_l1(iq, n_samples, l1);
+    /* mean: 64 strided partial sums in double, then the butterfly over 64 */
+    double p[64], q[64];
+    for (int j = 0; j < 64; j++) {
+        double a = 0.0;
+        for (int64_t b = j; b < nb; b += 64) a += (double)l1[b];
+        p[j] = a;
+    }
+    for (int off = 1; off < 64; off <<= 1) {
+        for (int j = 0; j < 64; j++) q[j] = p[j] + p[j ^ off];
+        memcpy(p, q, sizeof(p));
+    }
+    const float avg = (float)(p[0] / (double)nb);
+    const float ts = thr_start * avg, te = thr_end * avg;
+    const int max_blocks = 2 * DAB_NB_NULL_PERIOD / 64;                       /* 83 */
+    int count = 0, state = 0;
+    int64_t dip_begin = 0;
+    for (int64_t b = 0; b < nb && count < max_out; b++) {
+        if (state == 0) {
+            if (l1[b] < ts) { state = 1; dip_begin = b; }
+        } else if (l1[b] > te) {
+            const int64_t len = b - dip_begin;
+            const int64_t c = b * 64 - 48;
+            if (len >= min_blocks && len <= max_blocks && c >= 0 &&
+                c + (int64_t)DAB_NB_FRAME_SYMBOLS * DAB_NB_SYM_PERIOD + 512 <= n_samples)
+                cands[count++] = c;
+            state = 0;
+        }
+    }
+    free(l1);
+    return count;
+}
+
+void oracle_acquire_candidate(const float *iq, int64_t n_samples, int64_t cand, int max_coarse,
+                              float min_peak_to_mean, int margin, oracle_acquired_frame *out)
+{
+    const float *x = iq + 2 * (size_t)cand;
+    double cr = 0.0, ci = 0.0;
+    for (int i = 64; i < 440; i++) {
+        const float ar = x[2 * i], ai = x[2 * i + 1];
+        const float br = x[2 * (i + DAB_NB_FFT)], bi = x[2 * (i + DAB_NB_FFT) + 1];
+        cr += (double)(ar * br + ai * bi);                              /* conj(a) * b */
+        ci += (double)(ar * bi - ai * br);
+    }
+    const float fine = (float)(-atan2(ci, cr) / (2.0 * M_PI * (double)DAB_NB_FFT));
+    int32_t k, toff;
+    float ptm, cptm;
+    oracle_sync_prs(x, fine, max_coarse, &k, &toff, &ptm, &cptm);
+    out->start = cand + toff - margin;
+    out->coarse_carriers = k;
+    out->fine_offset = fine;
+    out->freq_offset = fine - (float)k / (float)DAB_NB_FFT;
+    out->peak_to_mean = ptm;
+    out->coarse_peak_to_mean = cptm;
+    out->flags = (ptm >= min_peak_to_mean ? 1 : 0) |
+                 ((out->start >= 0 && out->start + (int64_t)DAB_NB_FRAME_SYMBOLS * DAB_NB_SYM_PERIOD <= n_samples) ? 2 : 0);
+}
+
+/* ------------------------------------------------------------------------- */
 /* f-1: coarse frequency + fine time synchronisation on the PRS (see header).   */
 /* ------------------------------------------------------------------------- */
 void oracle_sync_prs(const float *sym, float freq_offset, int max_coarse, int32_t *k_out, int32_t *toff,

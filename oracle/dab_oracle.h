@@ -125,6 +125,37 @@ void oracle_ofdm_demod_frame(const float *iq, float freq_offset, int8_t *soft,
 void oracle_sync_prs(const float *sym, float freq_offset, int max_coarse, int32_t *k, int32_t *toff,
                      float *peak_to_mean, float *coarse_peak_to_mean);
 
+/* ---- acquisition on an unaligned capture (first half) ----
+ * Stands behind the FINDING_NULL_POWER_DIP / READING_NULL_AND_PRS states of OFDM_Demod
+ * (/root/reference/src/render_radio_block.cpp:193-194; knobs thresh_null_start / thresh_null_end,
+ * :215-235) restated for a whole capture at once:
+ *   l1[b]   = sum over the 64 samples of block b of |re| + |im|   (fixed summation tree, see the .c file)
+ *   avg     = mean of l1[] (double accumulation, fixed order)
+ *   a dip begins at the first block with l1 < thr_start*avg and ends at the first later block with
+ *   l1 > thr_end*avg; it is a null symbol when it lasted min_blocks..83 blocks.  The candidate first sample of the
+ *   PRS cyclic prefix is (end block)*64 - 48 (the boundary block is more often the one before); only candidates with a whole frame (+512 samples of slack) inside the
+ *   capture are kept.  Returns the number of candidates written (<= max_out). */
+void oracle_null_block_l1(const float *iq, int64_t n_samples, float *l1);
+int  oracle_null_search(const float *iq, int64_t n_samples, float thr_start, float thr_end, int min_blocks,
+                        int max_out, int64_t *cands);
+/* One candidate -> frame: fractional frequency error from the cyclic prefix of the PRS (samples 64..439 of the
+ * candidate's prefix against the samples 2048 later), then oracle_sync_prs with that correction.
+ *   fine_offset     = -angle(sum conj(x[i]) x[i+2048]) / (2 pi 2048)   cycles/sample
+ *   start           = cand + time_offset - margin   (first sample the demodulator should treat as PRS prefix)
+ *   freq_offset     = fine_offset - coarse_carriers/2048  (what the demodulator should apply)
+ *   flags bit 0     = peak_to_mean >= min_peak_to_mean (locked), bit 1 = the whole frame lies inside the capture */
+typedef struct oracle_acquired_frame {
+    int64_t start;
+    float freq_offset;
+    int32_t coarse_carriers;
+    float fine_offset;
+    float peak_to_mean;
+    float coarse_peak_to_mean;
+    int32_t flags;
+} oracle_acquired_frame;
+void oracle_acquire_candidate(const float *iq, int64_t n_samples, int64_t cand, int max_coarse,
+                              float min_peak_to_mean, int margin, oracle_acquired_frame *out);
+
 /* ---- DAB+ audio super-frame (dabplus_oracle.c) ---- */
 uint16_t oracle_firecode(const uint8_t *bytes, int n);
 void oracle_rs_encode(const uint8_t *data110, uint8_t *parity10);

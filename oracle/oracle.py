@@ -208,6 +208,38 @@ def sync_prs(sym, freq_offset=0.0, max_coarse=200):
     return k.value, t.value, p.value, cp.value
 
 
+class AcquiredFrame(C.Structure):
+    """== oracle_acquired_frame == dabgpu_acquired_frame (32 bytes)."""
+    _fields_ = [("start", C.c_int64), ("freq_offset", C.c_float), ("coarse_carriers", C.c_int32),
+                ("fine_offset", C.c_float), ("peak_to_mean", C.c_float), ("coarse_peak_to_mean", C.c_float),
+                ("flags", C.c_int32)]
+
+
+def null_block_l1(iq):
+    a = np.ascontiguousarray(iq, np.complex64).ravel()
+    out = np.zeros(a.size // 64, np.float32)
+    lib().oracle_null_block_l1(_p(a), C.c_int64(a.size), _p(out))
+    return out
+
+
+def null_search(iq, thr_start=0.35, thr_end=0.75, min_blocks=30, max_out=64):
+    """Candidate PRS starts (sample indices) of every whole frame in an unaligned capture."""
+    a = np.ascontiguousarray(iq, np.complex64).ravel()
+    out = np.zeros(max_out, np.int64)
+    lib().oracle_null_search.restype = C.c_int
+    n = lib().oracle_null_search(_p(a), C.c_int64(a.size), C.c_float(thr_start), C.c_float(thr_end), C.c_int(min_blocks),
+                                 C.c_int(max_out), _p(out))
+    return out[:n]
+
+
+def acquire_candidate(iq, cand, max_coarse=200, min_peak_to_mean=30.0, margin=0):
+    a = np.ascontiguousarray(iq, np.complex64).ravel()
+    r = AcquiredFrame()
+    lib().oracle_acquire_candidate(_p(a), C.c_int64(a.size), C.c_int64(int(cand)), C.c_int(max_coarse),
+                                   C.c_float(min_peak_to_mean), C.c_int(margin), C.byref(r))
+    return r
+
+
 def firecode(data):
     a = np.ascontiguousarray(data, np.uint8)
     return int(lib().oracle_firecode(_p(a), C.c_int(a.size)))

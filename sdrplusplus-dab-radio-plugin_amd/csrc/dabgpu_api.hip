@@ -57,6 +57,8 @@ struct dabgpu_ctx {
     bool timing = false;
     Timer timers[4];
     int ofdm_parts_override = 0;
+    void *d_acq_scratch = nullptr;       // block norms + candidates of dabgpu_acquire
+    size_t acq_scratch_bytes = 0;
     void *d_lane_scratch = nullptr;      // work buffers of the codeword-per-lane Viterbi
     size_t lane_scratch_bytes = 0;
     int lane_mode = -1;                  // DABGPU_VITERBI_LANE: 1 force, 0 never, -1 by batch size
@@ -177,6 +179,7 @@ bool use_lane(dabgpu_ctx *ctx, int nsteps, int n_codewords, hipStream_t s, dabk:
         // growing the buffer must not race with work still using the old one
         if (hipStreamSynchronize(s) != hipSuccess) { *rc = DABGPU_ERR_HIP; return false; }
         if (ctx->d_lane_scratch) (void)hipFree(ctx->d_lane_scratch);
+    if (ctx->d_acq_scratch) (void)hipFree(ctx->d_acq_scratch);
         ctx->d_lane_scratch = nullptr;
         ctx->lane_scratch_bytes = 0;
         if (hipMalloc(&ctx->d_lane_scratch, need) != hipSuccess) {
@@ -345,6 +348,7 @@ void dabgpu_destroy(dabgpu_ctx *ctx) {
     for (auto &kv : ctx->codes) free_device_code(*kv.second);
     for (void *p : ctx->d_stage) if (p) (void)hipFree(p);
     if (ctx->d_lane_scratch) (void)hipFree(ctx->d_lane_scratch);
+    if (ctx->d_acq_scratch) (void)hipFree(ctx->d_acq_scratch);
     for (Timer &t : ctx->timers) {
         if (t.start) (void)hipEventDestroy(t.start);
         if (t.stop) (void)hipEventDestroy(t.stop);
@@ -514,6 +518,118 @@ int dabgpu_sync_prs(dabgpu_ctx *ctx, const float *iq, size_t frame_stride, int n
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(out, d_out, sizeof(dabgpu_sync_result) * n_frames, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    return DABGPU_OK;
+}
+
+// ---------------------------------------------------------------------------- acquisition
+void dabgpu_acquire_default_cfg(dabgpu_acquire_cfg *cfg) {
+    if (!cfg) return;
+    cfg->thr_null_start = 0.35f;
+    cfg->thr_null_end = 0.75f;
+    cfg->min_null_blocks = 30;
+    cfg->max_coarse_carriers = 200;
+    cfg->min_peak_to_mean = 30.0f;
+    cfg->timing_margin = 64;
+}
+
+int dabgpu_acquire_dev(dabgpu_ctx *ctx, const void *d_iq, size_t stream_stride, int n_streams, int64_t n_samples,
+                       const dabgpu_acquire_cfg *cfg, int max_frames, dabgpu_acquired_frame *d_out, int32_t *d_counts,
+                       void *stream) {
+    static_assert(sizeof(dabgpu_acquired_frame) == 32 && sizeof(dabk::AcquiredFrame) == 32, "acquired-frame layout");
+    if (!ctx || !d_iq || !d_out || !d_counts || n_streams < 0 || max_frames <= 0 || n_samples < 0) return DABGPU_ERR_ARG;
+    if (reinterpret_cast<uintptr_t>(d_iq) & 7u) return DABGPU_ERR_ARG;
+    if (n_streams > 1 && stream_stride < size_t(n_samples)) return DABGPU_ERR_ARG;
+    dabgpu_acquire_cfg c;
+    if (cfg) c = *cfg; else dabgpu_acquire_default_cfg(&c);
+    if (c.max_coarse_carriers < 0 || c.max_coarse_carriers > 1023 || c.min_null_blocks < 1 || c.timing_margin < 0 ||
+        c.timing_margin > NB_CP || !(c.thr_null_start > 0.f) || !(c.thr_null_end >= c.thr_null_start))
+        return DABGPU_ERR_ARG;
+    if (n_streams == 0) return DABGPU_OK;
+    hipStream_t s = pick_stream(ctx, stream);
+    if (n_samples < 64) {                                      // nothing to search: no frames anywhere
+        HIP_TRY(hipMemsetAsync(d_counts, 0, sizeof(int32_t) * n_streams, s));
+        HIP_TRY(hipMemsetAsync(d_out, 0, sizeof(dabgpu_acquired_frame) * size_t(n_streams) * max_frames, s));
+        return DABGPU_OK;
+    }
+    const size_t need = dabk::acquire_scratch_bytes(n_streams, n_samples, max_frames);
+    if (ctx->acq_scratch_bytes < need) {
+        HIP_TRY(hipStreamSynchronize(s));
+        if (ctx->d_acq_scratch) (void)hipFree(ctx->d_acq_scratch);
+        ctx->d_acq_scratch = nullptr;
+        ctx->acq_scratch_bytes = 0;
+        if (hipMalloc(&ctx->d_acq_scratch, need) != hipSuccess) return DABGPU_ERR_NOMEM;
+        ctx->acq_scratch_bytes = need;
+    }
+    dabk::AcquireArgs a{};
+    a.iq = static_cast<const float2 *>(d_iq);
+    a.stream_stride = stream_stride;
+    a.n_streams = n_streams;
+    a.n_samples = n_samples;
+    a.thr_start = c.thr_null_start;
+    a.thr_end = c.thr_null_end;
+    a.min_blocks = c.min_null_blocks;
+    a.max_coarse = c.max_coarse_carriers;
+    a.min_peak_to_mean = c.min_peak_to_mean;
+    a.margin = c.timing_margin;
+    a.max_out = max_frames;
+    a.l1 = static_cast<float *>(ctx->d_acq_scratch);
+    const size_t l1_bytes = (size_t(n_streams) * size_t(n_samples / 64) * sizeof(float) + 255) & ~size_t(255);
+    a.cands = reinterpret_cast<int64_t *>(static_cast<char *>(ctx->d_acq_scratch) + l1_bytes);
+    a.out = reinterpret_cast<dabk::AcquiredFrame *>(d_out);
+    a.counts = d_counts;
+    dabk::SyncTables tab{ctx->d_twiddle, ctx->d_prs_qt, ctx->d_sync_pairs, ctx->n_sync_pairs};
+    HIP_TRY(dabk::launch_acquire(tab, a, s));
+    return DABGPU_OK;
+}
+
+int dabgpu_acquire(dabgpu_ctx *ctx, const float *iq, size_t stream_stride, int n_streams, int64_t n_samples,
+                   const dabgpu_acquire_cfg *cfg, int max_frames, dabgpu_acquired_frame *out, int32_t *counts) {
+    if (!ctx || !iq || !out || !counts || n_streams < 0 || max_frames <= 0 || n_samples < 0) return DABGPU_ERR_ARG;
+    if (n_streams == 0) return DABGPU_OK;
+    if (n_streams > 1 && stream_stride < size_t(n_samples)) return DABGPU_ERR_ARG;
+    // a capture is as large as the caller makes it: its device copy is allocated for the call, not kept
+    const size_t nb_iq = (size_t(n_streams - 1) * stream_stride + size_t(n_samples)) * sizeof(float2);
+    const size_t nb_out = sizeof(dabgpu_acquired_frame) * size_t(n_streams) * max_frames;
+    void *d_iq = nullptr, *d_out = nullptr, *d_cnt = nullptr;
+    hipStream_t s = ctx->stream;
+    int rc = DABGPU_OK;
+    if (hipMalloc(&d_iq, std::max<size_t>(nb_iq, 16)) != hipSuccess || hipMalloc(&d_out, nb_out) != hipSuccess ||
+        hipMalloc(&d_cnt, sizeof(int32_t) * n_streams) != hipSuccess)
+        rc = DABGPU_ERR_NOMEM;
+    if (!rc && hipMemcpyAsync(d_iq, iq, nb_iq, hipMemcpyHostToDevice, s) != hipSuccess) rc = DABGPU_ERR_HIP;
+    if (!rc)
+        rc = dabgpu_acquire_dev(ctx, d_iq, stream_stride, n_streams, n_samples, cfg, max_frames,
+                                static_cast<dabgpu_acquired_frame *>(d_out), static_cast<int32_t *>(d_cnt), s);
+    if (!rc && (hipMemcpyAsync(out, d_out, nb_out, hipMemcpyDeviceToHost, s) != hipSuccess ||
+                hipMemcpyAsync(counts, d_cnt, sizeof(int32_t) * n_streams, hipMemcpyDeviceToHost, s) != hipSuccess))
+        rc = DABGPU_ERR_HIP;
+    if (hipStreamSynchronize(s) != hipSuccess && !rc) rc = DABGPU_ERR_HIP;
+    if (d_iq) (void)hipFree(d_iq);
+    if (d_out) (void)hipFree(d_out);
+    if (d_cnt) (void)hipFree(d_cnt);
+    return rc;
+}
+
+int dabgpu_ofdm_demod_acquired_dev(dabgpu_ctx *ctx, const void *d_iq, size_t stream_stride, int n_streams,
+                                   int max_frames, const dabgpu_acquired_frame *d_frames, int8_t *d_soft, void *d_cyc,
+                                   void *d_dqpsk, void *stream) {
+    if (!ctx || !d_iq || !d_frames || !d_soft || n_streams < 0 || max_frames <= 0) return DABGPU_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(d_iq) & 7u) || (reinterpret_cast<uintptr_t>(d_soft) & 15u)) return DABGPU_ERR_ARG;
+    if (n_streams == 0) return DABGPU_OK;
+    if (size_t(n_streams) * size_t(max_frames) > size_t(0x7fffffff) / NB_DATA_SYMBOLS) return DABGPU_ERR_ARG;
+    hipStream_t s = pick_stream(ctx, stream);
+    dabk::OfdmTables tab{ctx->d_twiddle, ctx->d_bin_of_n, ctx->d_n_of_vj};
+    dabk::OfdmArgs a{};
+    a.iq = static_cast<const float2 *>(d_iq);
+    a.frame_stride = stream_stride;
+    a.n_frames = n_streams * max_frames;
+    a.soft = d_soft;
+    a.cyc = static_cast<float2 *>(d_cyc);
+    a.dqpsk = static_cast<float2 *>(d_dqpsk);
+    a.acq = reinterpret_cast<const dabk::AcquiredFrame *>(d_frames);
+    a.acq_per_stream = max_frames;
+    ScopedTimer tm(ctx, 0, s);
+    HIP_TRY(dabk::launch_ofdm_demod(tab, a, pick_parts(ctx, a.n_frames, NB_DATA_SYMBOLS), s));
     return DABGPU_OK;
 }
 

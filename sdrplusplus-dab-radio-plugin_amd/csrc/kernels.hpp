@@ -22,6 +22,11 @@ struct OfdmArgs {
     float2 *cyc;               // [n_frames][76] or nullptr
     float2 *dqpsk;             // [n_frames][75][1536] or nullptr
     float2 *spectra;           // FFT-only mode: [n_frames][76][2048]
+    // acquired mode (acq != nullptr): frame f belongs to stream f / acq_per_stream, which starts at
+    // iq + stream*frame_stride; its first sample and frequency correction come from acq[f]; frames whose
+    // flags are not 3 produce all-zero (erased) soft bits
+    const struct AcquiredFrame *acq = nullptr;
+    int acq_per_stream = 1;
 };
 
 // fused A2..A6.  Each frame is cut into `parts` contiguous runs of data symbols (1..75); a run re-reads
@@ -45,6 +50,35 @@ struct SyncResult {            // == dabgpu_sync_result
 };
 hipError_t launch_prs_sync(const SyncTables &t, const float2 *iq, size_t frame_stride, int n_frames,
                            const float *freq_offset, int max_coarse, SyncResult *out, hipStream_t s);
+
+// ---- acquisition on unaligned captures (sync_kernels.hip) ----------------------
+struct AcquiredFrame {         // == dabgpu_acquired_frame (32 bytes)
+    int64_t start;             // first sample the demodulator treats as PRS cyclic prefix, relative to the stream
+    float freq_offset;         // fine_offset - coarse_carriers/2048: what the demodulator applies
+    int32_t coarse_carriers;
+    float fine_offset;
+    float peak_to_mean;
+    float coarse_peak_to_mean;
+    int32_t flags;             // bit 0 locked, bit 1 whole frame inside the capture
+};
+struct AcquireArgs {
+    const float2 *iq;          // stream s at iq + s*stream_stride
+    size_t stream_stride;      // complex samples
+    int n_streams;
+    int64_t n_samples;         // per stream
+    float thr_start, thr_end;  // null-symbol dip thresholds relative to the mean block L1
+    int min_blocks;            // shortest dip (64-sample blocks) accepted as a null symbol
+    int max_coarse;            // carriers
+    float min_peak_to_mean;
+    int margin;                // samples the FFT windows are kept inside the cyclic prefix
+    int max_out;               // frames per stream
+    float *l1;                 // scratch [n_streams][n_samples/64]
+    int64_t *cands;            // scratch [n_streams][max_out]
+    AcquiredFrame *out;        // [n_streams][max_out]; entries >= counts[s] get flags 0, start -1
+    int32_t *counts;           // [n_streams]
+};
+size_t acquire_scratch_bytes(int n_streams, int64_t n_samples, int max_out);
+hipError_t launch_acquire(const SyncTables &t, const AcquireArgs &a, hipStream_t s);
 
 // ---- DAB+ audio super-frame (dabplus_kernels.hip) ------------------------------
 struct SuperframeStatus {      // == dabgpu_superframe_status

@@ -266,6 +266,25 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
     const int frame = item / parts;
     const int part = item - frame * parts;
     const float2 *fiq = a.iq + size_t(frame) * a.frame_stride;
+    // fused: data symbols (l_first, l_last]; l_first is only the differential reference
+    const int l_first = FFT_ONLY ? (NB_FRAME_SYMBOLS * part) / parts : (NB_DATA_SYMBOLS * part) / parts;
+    const int l_last = FFT_ONLY ? (NB_FRAME_SYMBOLS * (part + 1)) / parts - 1 : (NB_DATA_SYMBOLS * (part + 1)) / parts;
+    uint32_t dphi_acq = 0u;
+    if (a.acq) {
+        // frames found by the acquisition kernels: arbitrary (8-byte aligned) start inside their stream
+        const AcquiredFrame m = a.acq[frame];
+        if ((m.flags & 3) != 3) {
+            if constexpr (!FFT_ONLY) {                        // not a demodulable frame: erased soft bits
+                uint4 *o = reinterpret_cast<uint4 *>(a.soft + size_t(frame) * NB_FRAME_BITS + size_t(l_first) * NB_SYM_BITS);
+                const int n16 = (l_last - l_first) * NB_SYM_BITS / 16;
+                for (int i = lane; i < n16; i += 64) o[i] = make_uint4(0u, 0u, 0u, 0u);
+            }
+            return;
+        }
+        fiq = a.iq + size_t(frame / a.acq_per_stream) * a.frame_stride + m.start;
+        dphi_acq = uint32_t(__double2ll_rn(double(m.freq_offset) * 4294967296.0));
+    }
+    const bool aligned16 = (reinterpret_cast<uintptr_t>(fiq) & 15u) == 0;
 #ifdef DAB_OFDM_STAGGER
     // de-phase the co-resident waves so that their load / FFT / LDS phases do not line up
     for (int i = 0; i < (item % 12) * DAB_OFDM_STAGGER; i++) __builtin_amdgcn_s_sleep(32);
@@ -273,7 +292,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
 #ifdef DAB_EXP_NOPLL
     const uint32_t dphi = 0u;
 #else
-    const uint32_t dphi = dphi_of(a.freq_offset, frame);
+    const uint32_t dphi = a.acq ? dphi_acq : dphi_of(a.freq_offset, frame);
 #endif
 #ifdef DAB_EXP_NOCYC
     a.cyc = nullptr;
@@ -299,10 +318,6 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
 
     const float2 r1 = nco(1u, dphi), r128 = nco(128u, dphi), rot2048 = nco(uint32_t(NB_FFT), dphi);
 
-    // fused: data symbols (l_first, l_last]; l_first is only the differential reference
-    const int l_first = FFT_ONLY ? (NB_FRAME_SYMBOLS * part) / parts : (NB_DATA_SYMBOLS * part) / parts;
-    const int l_last = FFT_ONLY ? (NB_FRAME_SYMBOLS * (part + 1)) / parts - 1 : (NB_DATA_SYMBOLS * (part + 1)) / parts;
-
     for (int l = l_first; l <= l_last; l++) {
         const float2 *sym = fiq + size_t(l) * NB_SYM_PERIOD;
         const bool emit = FFT_ONLY || (l > l_first) || (l == 0);
@@ -317,24 +332,43 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
         __builtin_amdgcn_sched_barrier(0);
         // ---- loads: 16 x 16 B per lane, row n1 = samples 128*n1 + 2*lane, +1 ----
         float2 x0[16], x1[16];
-        {
+        if (aligned16) {
             const float4 *rows = reinterpret_cast<const float4 *>(sym + NB_CP) + lane;
 #pragma unroll
             for (int n1 = 0; n1 < 16; n1++) {
+#ifdef DAB_EXP_NT_LD
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(rows + 64 * n1));
+                const float4 v = make_float4(t.x, t.y, t.z, t.w);
+#else
                 const float4 v = rows[64 * n1];
+#endif
                 x0[n1] = make_float2(v.x, v.y);
                 x1[n1] = make_float2(v.z, v.w);
+            }
+        } else {                                              // odd sample offset: 8-byte loads
+            const float2 *rows = sym + NB_CP + 2 * lane;
+#pragma unroll
+            for (int n1 = 0; n1 < 16; n1++) {
+                x0[n1] = rows[128 * n1];
+                x1[n1] = rows[128 * n1 + 1];
             }
         }
         __builtin_amdgcn_sched_barrier(0);
         // ---- cyclic-prefix correlation on raw samples: CP pair c = lane-4+64*i <-> row 12+i of this lane ----
         if (a.cyc && emit) {
             float2 acc = make_float2(0.f, 0.f);
-            const float4 *cp = reinterpret_cast<const float4 *>(sym) + (lane - 4);
+            const float2 *cp = sym + 2 * (lane - 4);
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 if (i > 0 || lane >= 4) {
-                    const float4 c = cp[64 * i];
+                    float4 c;
+                    if (aligned16) {
+                        c = *reinterpret_cast<const float4 *>(cp + 128 * i);
+                    } else {
+                        const float2 c0 = cp[128 * i], c1 = cp[128 * i + 1];
+                        c = make_float4(c0.x, c0.y, c1.x, c1.y);
+                    }
                     const float2 u0 = x0[12 + i], u1 = x1[12 + i];
                     acc.x += c.x * u0.x + c.y * u0.y + c.z * u1.x + c.w * u1.y;      // conj(c) * u
                     acc.y += c.x * u0.y - c.y * u0.x + c.z * u1.y - c.w * u1.x;
@@ -464,7 +498,14 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
             const uint4 *sv = reinterpret_cast<const uint4 *>(stg) + lane;
             uint4 *o = reinterpret_cast<uint4 *>(a.soft + size_t(frame) * NB_FRAME_BITS + size_t(l - 1) * NB_SYM_BITS) + lane;
             const uint4 s0 = sv[0], s1 = sv[64], s2 = sv[128];
+#ifdef DAB_EXP_NT_ST
+            typedef unsigned v4u __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(v4u{s0.x, s0.y, s0.z, s0.w}, reinterpret_cast<v4u *>(o));
+            __builtin_nontemporal_store(v4u{s1.x, s1.y, s1.z, s1.w}, reinterpret_cast<v4u *>(o + 64));
+            __builtin_nontemporal_store(v4u{s2.x, s2.y, s2.z, s2.w}, reinterpret_cast<v4u *>(o + 128));
+#else
             o[0] = s0; o[64] = s1; o[128] = s2;
+#endif
         }
 #pragma unroll
         for (int j = 0; j < 24; j++) prev[j] = cur[j];
@@ -482,6 +523,7 @@ hipError_t launch_ofdm_demod(const OfdmTables &t, const OfdmArgs &a, int parts, 
     if (a.n_frames <= 0) return hipSuccess;
     if (parts <= 0 || parts > NB_DATA_SYMBOLS) return hipErrorInvalidValue;
     const int items = a.n_frames * parts;
+    if (use_v0() && a.acq) return hipErrorInvalidValue;       // the first-generation kernel only takes aligned frames
     if (use_v0()) {
         hipLaunchKernelGGL(ofdm_kernel<false>, dim3(unsigned(items)), dim3(WG), 0, s, t, a, parts);
     } else if (a.dqpsk) {

@@ -11,6 +11,8 @@
 //   h   = IFFT(X[b+k^] conj R[b])  channel impulse response;  time offset = argmax |h|^2 (signed)
 // Both FFTs are the 256-thread LDS Stockham of fft_common.hpp; the correlation is adds only because R is a
 // fourth root of unity.  Results are integers plus two peak-to-mean ratios for thresholding.
+#include <algorithm>
+
 #include "kernels.hpp"
 #include "dab_tables.hpp"
 #include "fft_common.hpp"
@@ -22,6 +24,7 @@ using namespace dab;
 namespace {
 
 struct SyncLds {
+    double red_d[2][WG];        // acquisition: cyclic-prefix correlation
     float2 tw[NB_FFT];
     float2 t1[NB_FFT];
     float2 x[NB_FFT];
@@ -66,13 +69,52 @@ __device__ __forceinline__ void block_argmax_sum(SyncLds &sm, int tid, float m, 
     __syncthreads();
 }
 
+// ACQ = false: candidates at a fixed stride, correction given, SyncResult out.
+// ACQ = true : candidates from the null search; the fractional frequency error is first measured on the cyclic
+//              prefix of the PRS (products 64..439 of the prefix against the samples 2048 later: inside the prefix
+//              for any candidate within +-64 samples), then the same search; AcquiredFrame out.
+template <bool ACQ>
 __global__ __launch_bounds__(WG) void prs_sync_kernel(SyncTables tab, const float2 *iq, size_t frame_stride,
-                                                      const float *freq_offset, int max_coarse, SyncResult *out) {
+                                                      const float *freq_offset, int max_coarse, SyncResult *out,
+                                                      AcquireArgs acq) {
     __shared__ SyncLds sm;
     const int tid = threadIdx.x;
     const int frame = blockIdx.x;
-    const float2 *sym = iq + size_t(frame) * frame_stride;
-    const uint32_t dphi = dphi_of(freq_offset, frame);
+    const float2 *sym;
+    uint32_t dphi;
+    int64_t cand = 0;
+    float fine = 0.0f;
+    if constexpr (ACQ) {
+        const int st = frame / acq.max_out, j = frame - st * acq.max_out;
+        if (j >= acq.counts[st]) {
+            if (tid == 0) acq.out[frame] = AcquiredFrame{-1, 0.f, 0, 0.f, 0.f, 0.f, 0};
+            return;
+        }
+        cand = acq.cands[frame];
+        sym = acq.iq + size_t(st) * acq.stream_stride + cand;
+        double cr = 0.0, ci = 0.0;
+        for (int i = 64 + tid; i < 440; i += WG) {
+            const float2 a = sym[i], b = sym[i + NB_FFT];
+            cr += double(__fadd_rn(__fmul_rn(a.x, b.x), __fmul_rn(a.y, b.y)));      // conj(a) * b
+            ci += double(__fsub_rn(__fmul_rn(a.x, b.y), __fmul_rn(a.y, b.x)));
+        }
+        sm.red_d[0][tid] = cr;
+        sm.red_d[1][tid] = ci;
+        __syncthreads();
+        for (int off = WG / 2; off > 0; off >>= 1) {
+            if (tid < off) {
+                sm.red_d[0][tid] += sm.red_d[0][tid + off];
+                sm.red_d[1][tid] += sm.red_d[1][tid + off];
+            }
+            __syncthreads();
+        }
+        fine = float(-atan2(sm.red_d[1][0], sm.red_d[0][0]) / (2.0 * 3.14159265358979323846 * double(NB_FFT)));
+        dphi = uint32_t(__double2ll_rn(double(fine) * 4294967296.0));
+        max_coarse = acq.max_coarse;
+    } else {
+        sym = iq + size_t(frame) * frame_stride;
+        dphi = dphi_of(freq_offset, frame);
+    }
     for (int i = tid; i < NB_FFT; i += WG) {
         sm.tw[i] = tab.twiddle[i];
         sm.qt[i] = tab.prs_qt[i];
@@ -153,13 +195,99 @@ __global__ __launch_bounds__(WG) void prs_sync_kernel(SyncTables tab, const floa
     int best_n;
     block_argmax_sum(sm, tid, my_m, my_n, my_s, best_m, best_n, total);
     if (tid == 0) {
-        SyncResult r;
-        r.coarse_carriers = khat;
-        r.time_offset = best_n < NB_FFT / 2 ? best_n : best_n - NB_FFT;
-        r.peak_to_mean = best_m / (total / float(NB_FFT));
-        r.coarse_peak_to_mean = coarse_ptm;
-        out[frame] = r;
+        const int toff = best_n < NB_FFT / 2 ? best_n : best_n - NB_FFT;
+        const float ptm = best_m / (total / float(NB_FFT));
+        if constexpr (ACQ) {
+            AcquiredFrame r;
+            r.start = cand + toff - acq.margin;
+            r.coarse_carriers = khat;
+            r.fine_offset = fine;
+            r.freq_offset = __fsub_rn(fine, float(khat) / float(NB_FFT));
+            r.peak_to_mean = ptm;
+            r.coarse_peak_to_mean = coarse_ptm;
+            r.flags = (ptm >= acq.min_peak_to_mean ? 1 : 0) |
+                      ((r.start >= 0 && r.start + int64_t(NB_FRAME_SYMBOLS) * NB_SYM_PERIOD <= acq.n_samples) ? 2 : 0);
+            acq.out[frame] = r;
+        } else {
+            SyncResult r;
+            r.coarse_carriers = khat;
+            r.time_offset = toff;
+            r.peak_to_mean = ptm;
+            r.coarse_peak_to_mean = coarse_ptm;
+            out[frame] = r;
+        }
     }
+}
+
+// ---- null-symbol search (FINDING_NULL_POWER_DIP, /root/reference/src/render_radio_block.cpp:193) ----
+// L1 norm of every 64-sample block.  A wave takes two blocks per trip: lane j of a half holds samples 2j, 2j+1,
+// the 32 pair sums are combined by the XOR butterfly 1, 2, 4, 8, 16 (the fixed tree the oracle restates).
+__global__ __launch_bounds__(256) void null_l1_kernel(const float2 *iq, size_t stream_stride, int64_t nb, float *l1) {
+    const int st = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    const int64_t n_waves = int64_t(gridDim.x) * 4;
+    const float2 *x = iq + size_t(st) * stream_stride;
+    float *o = l1 + size_t(st) * nb;
+    for (int64_t b2 = wave; 2 * b2 < nb; b2 += n_waves) {
+        const int64_t b = 2 * b2 + (lane >> 5);
+        float v = 0.0f;
+        if (b < nb) {
+            const float2 *p = x + b * 64 + 2 * (lane & 31);
+            const float2 s0 = p[0], s1 = p[1];
+            v = __fadd_rn(__fadd_rn(__fadd_rn(fabsf(s0.x), fabsf(s0.y)), fabsf(s1.x)), fabsf(s1.y));
+        }
+#pragma unroll
+        for (int off = 1; off < 32; off <<= 1) v = __fadd_rn(v, __shfl_xor(v, off));
+        if ((lane & 31) == 0 && b < nb) o[b] = v;
+    }
+}
+
+// Dip search: one wave per stream.  Mean of the block norms (64 strided partial sums in double, XOR butterfly),
+// then the two-threshold state machine; 64 blocks are classified per trip with two ballots and the scalar
+// unit walks the events.
+__global__ __launch_bounds__(64) void null_dip_kernel(AcquireArgs a, int64_t nb) {
+    const int st = blockIdx.x;
+    const int lane = threadIdx.x;
+    const float *l1 = a.l1 + size_t(st) * nb;
+    double acc = 0.0;
+    for (int64_t b = lane; b < nb; b += 64) acc += double(l1[b]);
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) acc += __shfl_xor(acc, off);
+    const float avg = float(acc / double(nb));
+    const float ts = __fmul_rn(a.thr_start, avg), te = __fmul_rn(a.thr_end, avg);
+    const int max_blocks = 2 * NB_NULL_PERIOD / 64;
+    int count = 0, state = 0;
+    int64_t dip_begin = 0;
+    int64_t *cands = a.cands + size_t(st) * a.max_out;
+    for (int64_t base = 0; base < nb && count < a.max_out; base += 64) {
+        const int64_t b = base + lane;
+        const float v = b < nb ? l1[b] : 0.0f;
+        const unsigned long long low = __ballot(b < nb && v < ts);
+        const unsigned long long high = __ballot(b < nb && v > te);
+        int pos = 0;                                            // wave-uniform walk over this trip's events
+        while (pos < 64 && count < a.max_out) {
+            const unsigned long long m = (state == 0 ? low : high) >> pos;
+            if (m == 0ull) break;
+            const int bit = pos + __builtin_ctzll(m);
+            const int64_t bb = base + bit;
+            if (state == 0) {
+                state = 1;
+                dip_begin = bb;
+            } else {
+                const int64_t len = bb - dip_begin;
+                const int64_t c = bb * 64 - 48;
+                if (len >= a.min_blocks && len <= max_blocks && c >= 0 &&
+                    c + int64_t(NB_FRAME_SYMBOLS) * NB_SYM_PERIOD + 512 <= a.n_samples) {
+                    if (lane == 0) cands[count] = c;
+                    count++;
+                }
+                state = 0;
+            }
+            pos = bit + 1;
+        }
+    }
+    if (lane == 0) a.counts[st] = count;
 }
 
 }  // namespace
@@ -168,8 +296,26 @@ hipError_t launch_prs_sync(const SyncTables &t, const float2 *iq, size_t frame_s
                            const float *freq_offset, int max_coarse, SyncResult *out, hipStream_t s) {
     if (n_frames <= 0) return hipSuccess;
     if (max_coarse < 0 || max_coarse > 1023) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(prs_sync_kernel, dim3(unsigned(n_frames)), dim3(WG), 0, s, t, iq, frame_stride, freq_offset,
-                       max_coarse, out);
+    hipLaunchKernelGGL(prs_sync_kernel<false>, dim3(unsigned(n_frames)), dim3(WG), 0, s, t, iq, frame_stride,
+                       freq_offset, max_coarse, out, AcquireArgs{});
+    return hipGetLastError();
+}
+
+size_t acquire_scratch_bytes(int n_streams, int64_t n_samples, int max_out) {
+    const size_t nb = size_t(n_samples / 64);
+    return ((size_t(n_streams) * nb * sizeof(float) + 255) & ~size_t(255)) + size_t(n_streams) * max_out * sizeof(int64_t);
+}
+
+hipError_t launch_acquire(const SyncTables &t, const AcquireArgs &a, hipStream_t s) {
+    if (a.n_streams <= 0 || a.max_out <= 0) return hipSuccess;
+    const int64_t nb = a.n_samples / 64;
+    if (nb <= 0 || a.max_coarse < 0 || a.max_coarse > 1023) return hipErrorInvalidValue;
+    const unsigned gx = unsigned(std::min<int64_t>((nb / 2 + 3) / 4 + 1, 4096));
+    hipLaunchKernelGGL(null_l1_kernel, dim3(gx, unsigned(a.n_streams)), dim3(256), 0, s, a.iq, a.stream_stride, nb, a.l1);
+    hipLaunchKernelGGL(null_dip_kernel, dim3(unsigned(a.n_streams)), dim3(64), 0, s, a, nb);
+    hipLaunchKernelGGL(prs_sync_kernel<true>, dim3(unsigned(a.n_streams) * unsigned(a.max_out)), dim3(WG), 0, s, t,
+                       static_cast<const float2 *>(nullptr), size_t(0), static_cast<const float *>(nullptr), 0,
+                       static_cast<SyncResult *>(nullptr), a);
     return hipGetLastError();
 }
 

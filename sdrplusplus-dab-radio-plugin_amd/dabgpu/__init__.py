@@ -33,6 +33,7 @@ EXPORTS = [
     "dabgpu_subchannel_bytes", "dabgpu_msc_decode_dev", "dabgpu_msc_decode", "dabgpu_viterbi_dev",
     "dabgpu_viterbi", "dabgpu_set_timing", "dabgpu_last_kernel_ms", "dabgpu_sync_prs_dev", "dabgpu_sync_prs",
     "dabgpu_msc_decode_multi_dev", "dabgpu_dabplus_superframes_dev", "dabgpu_dabplus_superframes",
+    "dabgpu_acquire_default_cfg", "dabgpu_acquire_dev", "dabgpu_acquire", "dabgpu_ofdm_demod_acquired_dev",
 ]
 
 
@@ -63,6 +64,27 @@ class Cfg(C.Structure):
 class SyncResult(C.Structure):
     _fields_ = [("coarse_carriers", C.c_int32), ("time_offset", C.c_int32), ("peak_to_mean", C.c_float),
                 ("coarse_peak_to_mean", C.c_float)]
+
+
+class AcquireCfg(C.Structure):
+    _fields_ = [("thr_null_start", C.c_float), ("thr_null_end", C.c_float), ("min_null_blocks", C.c_int32),
+                ("max_coarse_carriers", C.c_int32), ("min_peak_to_mean", C.c_float), ("timing_margin", C.c_int32)]
+
+
+ACQUIRED_FRAME_DTYPE = np.dtype([("start", np.int64), ("freq_offset", np.float32), ("coarse_carriers", np.int32),
+                                 ("fine_offset", np.float32), ("peak_to_mean", np.float32),
+                                 ("coarse_peak_to_mean", np.float32), ("flags", np.int32)])     # 32 bytes
+
+
+def acquire_cfg(**kw):
+    """dabgpu_acquire_default_cfg(), then the given fields overridden."""
+    c = AcquireCfg()
+    lib().dabgpu_acquire_default_cfg(C.byref(c))
+    for k, v in kw.items():
+        if not hasattr(c, k):
+            raise AttributeError(k)
+        setattr(c, k, v)
+    return c
 
 
 class Subchannel(C.Structure):
@@ -111,6 +133,11 @@ def lib():
         L.dabgpu_msc_decode_multi_dev.argtypes = [vp, vp, i, vp, sz, i, i, vp, vp, vp, vp]
         L.dabgpu_sync_prs_dev.argtypes = [vp, vp, sz, i, vp, i, vp, vp]
         L.dabgpu_sync_prs.argtypes = [vp, vp, sz, i, vp, i, vp]
+        L.dabgpu_acquire_default_cfg.restype = None
+        L.dabgpu_acquire_default_cfg.argtypes = [C.POINTER(AcquireCfg)]
+        L.dabgpu_acquire_dev.argtypes = [vp, vp, sz, i, C.c_int64, C.POINTER(AcquireCfg), i, vp, vp, vp]
+        L.dabgpu_acquire.argtypes = [vp, vp, sz, i, C.c_int64, C.POINTER(AcquireCfg), i, vp, vp]
+        L.dabgpu_ofdm_demod_acquired_dev.argtypes = [vp, vp, sz, i, i, vp, vp, vp, vp, vp]
         L.dabgpu_last_kernel_ms.argtypes = [vp, i, C.POINTER(C.c_float)]
         L.dabgpu_get_prs_reference.argtypes = [i, vp, i]
         L.dabgpu_get_mapper_reference.argtypes = [vp, i, i]
@@ -240,6 +267,27 @@ class Context:
                                  ("peak_to_mean", np.float32), ("coarse_peak_to_mean", np.float32)])
         _check(lib().dabgpu_sync_prs(self._h, _p(iq), stride, n, _p(fo), max_coarse, _p(out)), "dabgpu_sync_prs")
         return out
+
+    def acquire(self, iq, max_frames, cfg=None):
+        """iq: complex64 [n_streams][n_samples] unaligned captures -> (frames [n_streams][max_frames] structured
+        array (ACQUIRED_FRAME_DTYPE), counts [n_streams])."""
+        iq = np.ascontiguousarray(iq, np.complex64)
+        n_streams, n_samples = iq.shape
+        out = np.zeros((n_streams, max_frames), ACQUIRED_FRAME_DTYPE)
+        counts = np.zeros(n_streams, np.int32)
+        _check(lib().dabgpu_acquire(self._h, _p(iq), n_samples, n_streams, n_samples,
+                                    None if cfg is None else C.byref(cfg), max_frames, _p(out), _p(counts)), "dabgpu_acquire")
+        return out, counts
+
+    def acquire_dev(self, d_iq, stream_stride, n_streams, n_samples, max_frames, d_out, d_counts, cfg=None, stream=None):
+        _check(lib().dabgpu_acquire_dev(self._h, d_iq, stream_stride, n_streams, n_samples,
+                                        None if cfg is None else C.byref(cfg), max_frames, d_out, d_counts, stream),
+               "dabgpu_acquire_dev")
+
+    def ofdm_demod_acquired_dev(self, d_iq, stream_stride, n_streams, max_frames, d_frames, d_soft, d_cyc=None,
+                                d_dqpsk=None, stream=None):
+        _check(lib().dabgpu_ofdm_demod_acquired_dev(self._h, d_iq, stream_stride, n_streams, max_frames, d_frames, d_soft,
+                                                    d_cyc, d_dqpsk, stream), "dabgpu_ofdm_demod_acquired_dev")
 
     def dabplus_superframes(self, sfs, bitrate_kbps):
         """sfs: uint8 [n][>=15*bitrate] aligned super-frames -> (data [n][110*s], status structured array)."""

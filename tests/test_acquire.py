@@ -1,0 +1,153 @@
+"""Acquisition on unaligned captures: null-symbol power-dip search, fractional frequency from the
+cyclic prefix, coarse frequency + fine time on the PRS, then demodulation of the frames found where they lie.
+CPU part: the oracle against known answers.  GPU part: the kernels against the oracle and against the
+transmitted FIBs."""
+import numpy as np
+import pytest
+
+from dabgpu import synth
+from oracle import oracle as O
+
+NULL = synth.NB_NULL
+FRAME = synth.NB_FRAME_SAMPLES
+SYMS = 76 * 2552
+
+
+def capture(seed, n_frames, cut, tail, snr, cfo_carriers, gain=1.0):
+    """A capture that starts `cut` samples into a frame and ends `tail` samples into another one.
+    -> (iq, true first-PRS-sample positions of the whole frames, ensemble, index of the first whole frame)."""
+    e = synth.Ensemble(seed=seed, n_frames=n_frames)
+    iq = e.iq().ravel()
+    x = np.concatenate([iq[cut:], iq[:tail]]) if tail else iq[cut:]
+    rng = np.random.default_rng(seed)
+    x = synth.channel(x, snr_db=snr, cfo=cfo_carriers / 2048.0, rng=rng) * np.float32(gain)
+    first = 0 if cut <= 0 else 1
+    starts = [k * FRAME + NULL - cut for k in range(first, n_frames) if k * FRAME + NULL - cut + SYMS + 512 <= x.size]
+    if tail >= NULL + SYMS + 512:
+        starts.append(n_frames * FRAME + NULL - cut)
+    return x.astype(np.complex64), np.array(starts, np.int64), e, first
+
+
+def test_oracle_block_norms_match_numpy():
+    x, _, _, _ = capture(3, 1, 5000, 0, 20.0, 0.0)
+    l1 = O.null_block_l1(x)
+    ref = (np.abs(x.real.astype(np.float64)) + np.abs(x.imag.astype(np.float64)))[:l1.size * 64].reshape(-1, 64).sum(1)
+    assert np.allclose(l1, ref, rtol=1e-5)
+
+
+@pytest.mark.parametrize("snr,cfo,gain", [(25.0, 0.0, 1.0), (12.0, 3.3, 0.02), (8.0, -17.45, 40.0)])
+def test_oracle_finds_every_whole_frame(snr, cfo, gain):
+    x, starts, _, _ = capture(11, 4, 123457, 60001, snr, cfo, gain)
+    cands = O.null_search(x)
+    assert len(cands) == len(starts)
+    assert (np.abs(cands - starts) <= 96).all()               # block resolution + noise
+    for c, s in zip(cands, starts):
+        r = O.acquire_candidate(x, c, margin=0)
+        assert r.flags == 3
+        assert abs(r.start - s) <= 1                          # sample-accurate timing
+        assert r.coarse_carriers == int(np.round(cfo))        # signal sits cfo carriers high
+        frac = cfo - np.round(cfo)
+        assert abs(r.fine_offset * 2048 + frac) < 0.02        # correction = -fractional part
+        assert abs(r.freq_offset * 2048 + cfo) < 0.02
+
+
+def test_oracle_ignores_short_dips_and_silence():
+    x, starts, _, _ = capture(5, 2, 0, 0, 20.0, 0.0)
+    y = x.copy()
+    y[50000:50000 + 640] = 0                                  # a 10-block dropout is not a null symbol
+    assert len(O.null_search(y)) == len(O.null_search(x))
+    y = x.copy()
+    y[300000:] *= 1e-3                                        # the signal vanishes: no frame may be invented
+    got = O.null_search(y)
+    assert (got < 300000).all()
+    assert len(O.null_search(np.zeros(4096, np.complex64))) == 0
+
+
+# ------------------------------------------------------------------ GPU
+@pytest.fixture(scope="module")
+def gctx(built):
+    from conftest import make_ctx
+    c = make_ctx(None, 16)
+    yield c
+    c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("snr,cfo,cut", [(25.0, 0.0, 100000), (12.0, 3.3, 77777), (9.0, -17.45, 150001)])
+def test_gpu_acquire_matches_oracle(gctx, snr, cfo, cut):
+    import dabgpu
+    caps = [capture(21 + i, 3, cut + 999 * i, 50000, snr, cfo + 0.11 * i) for i in range(3)]
+    n = min(c[0].size for c in caps)
+    iq = np.stack([c[0][:n] for c in caps])
+    cfg = dabgpu.acquire_cfg(timing_margin=0)
+    frames, counts = gctx.acquire(iq, 6, cfg)
+    for s in range(3):
+        cands = O.null_search(iq[s], max_out=6)
+        assert counts[s] == len(cands) >= 2
+        for j, c in enumerate(cands):
+            r = O.acquire_candidate(iq[s], c, margin=0)
+            g = frames[s, j]
+            assert (g["start"], g["coarse_carriers"], g["flags"]) == (r.start, r.coarse_carriers, r.flags)
+            assert abs(g["fine_offset"] - r.fine_offset) <= 1e-9 + 1e-5 * abs(r.fine_offset)
+            assert abs(g["peak_to_mean"] - r.peak_to_mean) <= 2e-3 * r.peak_to_mean
+            assert abs(g["coarse_peak_to_mean"] - r.coarse_peak_to_mean) <= 2e-3 * r.coarse_peak_to_mean
+        assert (frames[s, counts[s]:]["flags"] == 0).all() and (frames[s, counts[s]:]["start"] == -1).all()
+
+
+@pytest.mark.gpu
+def test_gpu_unaligned_capture_to_fibs(gctx):
+    """Whole chain with nothing known in advance: capture -> acquire -> demodulate in place -> FIC."""
+    import torch
+    import dabgpu
+    n_streams, max_frames = 4, 5
+    caps = [capture(40 + i, 4, 30001 + 17001 * i, 60000, 14.0, (-1) ** i * (2.0 + 0.37 * i), gain=0.5 + i)
+            for i in range(n_streams)]
+    n = min(c[0].size for c in caps)
+    dev = torch.device("cuda", 0)
+    iq = torch.from_numpy(np.stack([c[0][:n] for c in caps])).to(dev)
+    frames = torch.zeros((n_streams, max_frames, 32), dtype=torch.uint8, device=dev)
+    counts = torch.zeros(n_streams, dtype=torch.int32, device=dev)
+    soft = torch.full((n_streams * max_frames, dabgpu.NB_FRAME_BITS), 7, dtype=torch.int8, device=dev)
+    fib = torch.zeros((n_streams * max_frames, 12, 32), dtype=torch.uint8, device=dev)
+    ok = torch.zeros((n_streams * max_frames, 12), dtype=torch.uint8, device=dev)
+    gctx.acquire_dev(iq.data_ptr(), n, n_streams, n, max_frames, frames.data_ptr(), counts.data_ptr())
+    gctx.ofdm_demod_acquired_dev(iq.data_ptr(), n, n_streams, max_frames, frames.data_ptr(), soft.data_ptr())
+    gctx.fic_decode_dev(soft.data_ptr(), dabgpu.NB_FRAME_BITS, n_streams * max_frames, fib.data_ptr(), ok.data_ptr())
+    gctx.sync()
+    fr = frames.cpu().numpy().view(dabgpu.ACQUIRED_FRAME_DTYPE).reshape(n_streams, max_frames)
+    cnt, soft_h = counts.cpu().numpy(), soft.cpu().numpy().reshape(n_streams, max_frames, -1)
+    fib_h, ok_h = fib.cpu().numpy().reshape(n_streams, max_frames, 12, 32), ok.cpu().numpy().reshape(n_streams, max_frames, 12)
+    odd = 0
+    for s, (x, starts, e, first) in enumerate(caps):
+        starts = starts[starts + SYMS + 512 <= n]
+        assert cnt[s] == len(starts) == 3, (cnt[s], starts)
+        for j in range(cnt[s]):
+            assert fr[s, j]["flags"] == 3
+            assert abs(fr[s, j]["start"] + 64 - starts[j]) <= 1          # default timing margin: 64 samples early
+            odd += int(fr[s, j]["start"] & 1)
+            assert ok_h[s, j].all()
+            assert (fib_h[s, j] == e.fibs[first + j]).all()              # known answer: the transmitted FIBs
+            # parity with the oracle demodulating the same samples with the same correction
+            st = int(fr[s, j]["start"])
+            osoft, _, _, _ = O.ofdm_demod_frame(x[st:st + SYMS], float(fr[s, j]["freq_offset"]))
+            assert np.abs(soft_h[s, j].astype(np.int32) - osoft.astype(np.int32)).max() <= 1
+        assert not soft_h[s, cnt[s]:].any()                              # unused entries: erased, not stale
+    assert odd > 0                                                       # the 8-byte-aligned load path was exercised
+
+
+@pytest.mark.gpu
+def test_gpu_acquire_rejects_noise_and_bad_arguments(gctx):
+    import dabgpu
+    rng = np.random.default_rng(2)
+    noise = (rng.standard_normal((2, 400000)) + 1j * rng.standard_normal((2, 400000))).astype(np.complex64)
+    noise[1, 100000:102656] = 0                                          # a gap as long as a null symbol, no PRS after it
+    frames, counts = gctx.acquire(noise, 4)
+    assert counts[0] == 0 and counts[1] == 1
+    assert frames[1, 0]["flags"] & 1 == 0                                # found a dip, but it does not lock
+    L = dabgpu.lib()
+    assert L.dabgpu_acquire(gctx._h, None, 0, 1, 100, None, 4, None, None) == -1
+    bad = dabgpu.acquire_cfg(max_coarse_carriers=5000)
+    with pytest.raises(dabgpu.DabGpuError):
+        gctx.acquire(noise, 4, bad)
+    frames, counts = gctx.acquire(noise[:, :32], 4)                      # shorter than one block
+    assert (counts == 0).all()

@@ -4,7 +4,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "sdrplusplus-dab-radio-plugin_amd")); sys.path.insert(0, ROOT)
 import numpy as np, torch, dabgpu
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+n = int(sys.argv[1]) if len(sys.argv) > 1 else int(os.environ.get("OFDM_TIME_N", "1024"))
 dev = torch.device("cuda", 0)
 iq = torch.randn((n, 196608, 2), dtype=torch.float32, device=dev)
 fo = ((torch.rand(n, device=dev) - 0.5) * 0.8 / 2048).float()
