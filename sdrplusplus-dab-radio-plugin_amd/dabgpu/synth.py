@@ -379,3 +379,130 @@ def build_superframe(rng, bitrate, dac_rate=1, sbr=0, channel_mode=1, ps=0):
     for j in range(s):
         sf[size + j::s] = rs_parity(sf[j:size:s])
     return sf, starts, aus
+
+
+# ----------------------------------------------------------------------------- FIGs (EN 300 401 clauses 5.2, 6, 8)
+# What a multiplex says about itself in the FIC: enough for a receiver to find and decode its audio services
+# without being told anything (FIG 0/0 ensemble, 0/1 sub-channel organisation, 0/2 service organisation,
+# 1/0 ensemble label, 1/1 service labels).
+ASCTY_DAB = 0          # MPEG-1/2 layer II
+ASCTY_DABPLUS = 63     # HE-AAC v2 super-frames (TS 102 563)
+
+
+def _bits(*fields):
+    """fields: (value, width) ... MSB first -> bytes (total width must be a multiple of 8)."""
+    v, n = 0, 0
+    for val, w in fields:
+        assert 0 <= val < (1 << w), (val, w)
+        v = (v << w) | val
+        n += w
+    assert n % 8 == 0
+    return bytes((v >> (8 * (n // 8 - 1 - i))) & 0xFF for i in range(n // 8))
+
+
+def fig0(ext, body, cn=0, oe=0, pd=0):
+    data = _bits((cn, 1), (oe, 1), (pd, 1), (ext, 5)) + body
+    assert len(data) <= 29
+    return _bits((0, 3), (len(data), 5)) + data
+
+
+def fig0_0(eid, cif_count, change=0, alarm=0):
+    return fig0(0, _bits((eid, 16), (change, 2), (alarm, 1), ((cif_count // 250) % 20, 5), (cif_count % 250, 8)))
+
+
+def fig0_1(subchannels):
+    """subchannels: dicts {id, start, option, level, size} (long form, EEP) or {id, start, uep_index} (short form)."""
+    body = b""
+    for sc in subchannels:
+        if "uep_index" in sc:
+            body += _bits((sc["id"], 6), (sc["start"], 10), (0, 1), (0, 1), (sc["uep_index"], 6))
+        else:
+            body += _bits((sc["id"], 6), (sc["start"], 10), (1, 1), (sc["option"], 3), (sc["level"] - 1, 2), (sc["size"], 10))
+    return fig0(1, body)
+
+
+def fig0_2(services):
+    """services: dicts {sid (16 bit), components: [{subchannel, ascty, primary}]} (programme services, MSC stream audio)."""
+    body = b""
+    for sv in services:
+        comps = sv["components"]
+        body += _bits((sv["sid"], 16), (0, 1), (0, 3), (len(comps), 4))
+        for c in comps:
+            body += _bits((0, 2), (c["ascty"], 6), (c["subchannel"], 6), (1 if c.get("primary", True) else 0, 1), (0, 1))
+    return fig0(2, body)
+
+
+def fig1(ext, ident, label, charset=0):
+    text = label.encode("latin-1")[:16].ljust(16, b" ")
+    data = _bits((charset, 4), (0, 1), (ext, 3), (ident, 16)) + text + _bits((0xFF00, 16))
+    return _bits((1, 3), (len(data), 5)) + data
+
+
+def pack_fibs(figs):
+    """Greedy packing of FIGs (bytes) into 30-byte FIB data fields (end marker 0xFF, zero padding) + CRC."""
+    fibs, cur = [], b""
+    for f in figs:
+        assert len(f) <= 30
+        if len(cur) + len(f) > 30:
+            fibs.append(cur)
+            cur = b""
+        cur += f
+    if cur:
+        fibs.append(cur)
+    out = np.zeros((len(fibs), 32), np.uint8)
+    for i, d in enumerate(fibs):
+        d = d + (b"\xff" if len(d) < 30 else b"")
+        d = d.ljust(30, b"\x00")
+        c = crc16(d)
+        out[i] = np.frombuffer(d + bytes([c >> 8, c & 0xFF]), np.uint8)
+    return out
+
+
+class ServiceEnsemble:
+    """A cyclic multiplex that describes itself: DAB+ services on EEP sub-channels carrying real super-frames,
+    FIC made of FIG 0/0, 0/1, 0/2, 1/0, 1/1.  services = [(label, sid, subchannel_id, option, level, bitrate,
+    start_cu), ...].  n_frames must be a multiple of 5 so that whole super-frames (5 logical frames) tile."""
+
+    def __init__(self, seed, services, n_frames=5, eid=0xC181, label="Synth Ensemble"):
+        assert n_frames % 5 == 0
+        rng = np.random.default_rng(seed)
+        self.n_frames, self.eid, self.label, self.services = n_frames, eid, label, services
+        R = 4 * n_frames
+        cifs = rng.integers(0, 2, size=(R, NB_CIF_BITS), dtype=np.uint8)
+        self.masks, self.sizes, self.msc_bytes, self.superframes, self.aus = [], [], [], [], []
+        self.subchannels = []
+        for (lab, sid, scid, option, level, bitrate, start_cu) in services:
+            mask, size_cu = eep_mask(option, level, bitrate)
+            sfs, aus = [], []
+            for _ in range(R // 5):
+                sf, starts, au = build_superframe(rng, bitrate, dac_rate=1, sbr=1, channel_mode=1, ps=0)
+                sfs.append(sf); aus.append(au)
+            data = np.concatenate(sfs).reshape(R, bitrate * 3)
+            coded = np.stack([msc_encode_lf(data[r], mask) for r in range(R)])
+            cifs[:, start_cu * 64:(start_cu + size_cu) * 64] = time_interleave(coded, cyclic=True)
+            self.masks.append(mask); self.sizes.append(size_cu); self.msc_bytes.append(data)
+            self.superframes.append(sfs); self.aus.append(aus)
+            self.subchannels.append({"id": scid, "start": start_cu, "option": option, "level": level, "size": size_cu})
+        sv = [{"sid": sid, "components": [{"subchannel": scid, "ascty": ASCTY_DABPLUS}]}
+              for (lab, sid, scid, *_rest) in services]
+        labels = [fig1(0, eid, label)] + [fig1(1, sid, lab) for (lab, sid, *_rest) in services]
+        self.fibs = np.zeros((n_frames, 12, 32), np.uint8)
+        k = 0
+        for f in range(n_frames):
+            for c in range(4):
+                figs = [fig0_0(eid, 4 * f + c)]
+                figs += [fig0_1(self.subchannels[i:i + 6]) for i in range(0, len(self.subchannels), 6)]
+                figs += [fig0_2(sv[i:i + 5]) for i in range(0, len(sv), 5)]
+                figs.append(labels[k % len(labels)]); k += 1
+                fibs = pack_fibs(figs)
+                assert len(fibs) <= 3, "too many FIGs for one CIF's three FIBs"
+                pad = pack_fibs([fig0_0(eid, 4 * f + c)])
+                block = np.concatenate([fibs] + [pad] * (3 - len(fibs)))
+                self.fibs[f, 3 * c:3 * c + 3] = block
+        self.frame_bits = np.zeros((n_frames, NB_FRAME_BITS), np.uint8)
+        for f in range(n_frames):
+            self.frame_bits[f, :NB_FIC_BITS] = fic_encode(self.fibs[f])
+            self.frame_bits[f, NB_FIC_BITS:] = cifs[4 * f:4 * f + 4].ravel()
+
+    def iq(self):
+        return np.stack([modulate_frame(self.frame_bits[f]) for f in range(self.n_frames)])

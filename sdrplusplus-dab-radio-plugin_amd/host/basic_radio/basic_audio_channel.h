@@ -1,11 +1,12 @@
-// Minimal stand-in so that radio_block.cpp's audio hook compiles (/root/reference/src/radio_block.cpp:62-79).
-// Audio decoding (AAC/MP2) is outside the hot path: BasicRadio never creates one of these.
+// basic_radio/basic_audio_channel.h -- the audio-channel interface radio_block.cpp hooks its audio pipeline to
+// (/root/reference/src/radio_block.cpp:62-79: GetControls(), OnAudioData()).  Audio decoding (AAC/MP2) is outside
+// the hot path, so OnAudioData() never fires here; what the channel does produce is listed
+// in basic_dab_plus_channel.h.
 #pragma once
 #include <cstdint>
+#include "dab/database/dab_database_entities.h"
 #include "utility/observable.h"
 #include "utility/span.h"
-
-typedef uint8_t subchannel_id_t;
 
 struct BasicAudioParams {
     uint32_t frequency = 48000;
@@ -16,6 +17,8 @@ struct BasicAudioParams {
 class Basic_Audio_Controls {
 public:
     bool GetIsPlayAudio() const { return m_play; }
+    bool GetIsDecodeAudio() const { return m_decode; }
+    bool GetIsDecodeData() const { return m_data; }
     void SetIsPlayAudio(bool v) { m_play = v; }
     void SetIsDecodeAudio(bool v) { m_decode = v; }
     void SetIsDecodeData(bool v) { m_data = v; }
@@ -26,10 +29,11 @@ private:
 
 class Basic_Audio_Channel {
 public:
+    virtual ~Basic_Audio_Channel() = default;
     Basic_Audio_Controls &GetControls() { return m_controls; }
-    Observable<BasicAudioParams, tcb::span<const uint8_t>> &OnAudioData() { return m_obs; }
+    Observable<BasicAudioParams, tcb::span<const uint8_t>> &OnAudioData() { return m_obs_audio; }
 
-private:
+protected:
     Basic_Audio_Controls m_controls;
-    Observable<BasicAudioParams, tcb::span<const uint8_t>> m_obs;
+    Observable<BasicAudioParams, tcb::span<const uint8_t>> m_obs_audio;
 };

@@ -3,15 +3,22 @@
 // (src/render_radio_block.cpp:124), On_Audio_Channel() (src/radio_block.cpp:62).
 //
 // Process splits a frame into FIC and MSC (row A7) and runs rows A8..A12 on the GPU through libdabgpu:
-// the FIC every frame, plus every subchannel registered with AddSubchannel().  What the reference does after
-// that (FIG parsing -> database, DAB+ superframe, audio) is outside the hot path, so the
-// decoded bytes are handed out through two observers instead.
+// the FIC every frame, plus every subchannel registered with AddSubchannel().  The FIBs go through the FIG
+// parser into the database; every DAB+ audio component found there on an EEP sub-channel gets
+// its sub-channel decoded and a Basic_DAB_Plus_Channel (8f-3) without being asked (On_Audio_Channel fires once per
+// channel, as in the reference).  Audio decoding is outside the path: channels hand out access units.
 #pragma once
 #include <cstdint>
 #include <mutex>
 #include <vector>
+#include <map>
+#include <memory>
 #include "basic_radio/basic_audio_channel.h"
+#include "basic_radio/basic_dab_plus_channel.h"
 #include "dab/constants/dab_parameters.h"
+#include "dab/database/dab_database.h"
+#include "dab/database/dab_database_updater.h"
+#include "dab/fic/fic_parser.h"
 #include "dabgpu.h"
 #include "utility/observable.h"
 #include "utility/span.h"
@@ -27,6 +34,16 @@ public:
     void Process(tcb::span<const viterbi_bit_t> buf);
     std::mutex &GetMutex() { return m_mutex; }
     Observable<subchannel_id_t, Basic_Audio_Channel &> &On_Audio_Channel() { return m_obs_audio_channel; }
+    // read under GetMutex(), as the GUI does (/root/reference/src/render_radio_block.cpp:124, 158-160, 239, 755)
+    DAB_Database &GetDatabase() { return m_database; }
+    const DAB_Database_Statistics &GetDatabaseStatistics() const { return m_updater.GetStatistics(); }
+    Basic_DAB_Plus_Channel *Get_Audio_Channel(subchannel_id_t id) {
+        auto it = m_channels.find(id);
+        return it == m_channels.end() ? nullptr : it->second.get();
+    }
+    // sub-channels listed in the FIC that cannot be decoded here (UEP: the protection table is not restated)
+    int GetTotalUnsupportedSubchannels() const { return m_total_unsupported; }
+    void SetAutoChannels(bool v) { m_auto_channels = v; }
 
     // ---- hot-path outputs (extensions) ----
     // 12 FIBs x 32 bytes and their CRC flags, once per frame
@@ -46,7 +63,10 @@ private:
         int cur = 0;
         int cifs_seen = 0;
         std::vector<uint8_t> out;
+        Basic_DAB_Plus_Channel *channel = nullptr;    // set for sub-channels opened from the database
     };
+    void update_channels_from_database();
+    int add_subchannel_locked(const dabgpu_subchannel &sc);
     const DAB_Parameters m_params;
     dabgpu_ctx *m_ctx;
     std::mutex m_mutex;
@@ -56,4 +76,13 @@ private:
     Observable<subchannel_id_t, Basic_Audio_Channel &> m_obs_audio_channel;
     Observable<tcb::span<const uint8_t>, tcb::span<const uint8_t>> m_obs_fic;
     Observable<int, tcb::span<const uint8_t>> m_obs_msc;
+    DAB_Database m_database;
+    DAB_Database_Updater m_updater{m_database};
+    FIC_Parser m_fic_parser{m_updater};
+    std::map<subchannel_id_t, std::unique_ptr<Basic_DAB_Plus_Channel>> m_channels;
+    std::vector<subchannel_id_t> m_rejected;             // sub-channels we looked at and cannot open
+    size_t m_seen_components = 0;
+    bool m_pending_components = false;                   // a component whose sub-channel is not described yet
+    bool m_auto_channels = true;
+    int m_total_unsupported = 0;
 };

@@ -1,0 +1,18 @@
+// dab/database/dab_database.h -- what BasicRadio::GetDatabase() returns
+// (/root/reference/src/render_radio_block.cpp:158, 239, 491, 781).
+#pragma once
+#include <vector>
+#include "dab/database/dab_database_entities.h"
+
+struct DAB_Database {
+    Ensemble ensemble;
+    std::vector<Service> services;
+    std::vector<ServiceComponent> service_components;
+    std::vector<Subchannel> subchannels;
+};
+
+struct DAB_Database_Statistics {           // GetDatabaseStatistics(), render_radio_block.cpp:755
+    size_t nb_total = 0;                   // entity fields written
+    size_t nb_updates = 0;                 // of which changed something
+    size_t nb_conflicts = 0;               // a field that was already set arrived with a different value
+};

@@ -1,0 +1,61 @@
+// dab/database/dab_database_updater.h -- find-or-create access to the database for the FIG parser.
+// A field is written once; a later FIG carrying a different value for it counts as a conflict and is ignored
+// (a corrupted FIB that slipped through the CRC must not rewrite the multiplex).
+#pragma once
+#include <string>
+#include "dab/database/dab_database.h"
+
+class DAB_Database_Updater {
+public:
+    explicit DAB_Database_Updater(DAB_Database &db) : m_db(db) {}
+    const DAB_Database_Statistics &GetStatistics() const { return m_stats; }
+
+    void SetEnsembleId(uint16_t eid) {
+        if (!m_have_eid) { m_db.ensemble.id.value = eid; m_have_eid = true; changed(); }
+        else same(m_db.ensemble.id.value == eid);
+    }
+    void SetEnsembleCIFCounter(int v) { m_db.ensemble.cif_counter = v; }
+    void SetEnsembleLabel(const std::string &label) { set_string(m_db.ensemble.label, label); }
+
+    Subchannel &GetSubchannel(subchannel_id_t id, bool *is_new) {
+        for (auto &s : m_db.subchannels)
+            if (s.id == id) { *is_new = false; return s; }
+        m_db.subchannels.emplace_back();
+        m_db.subchannels.back().id = id;
+        *is_new = true;
+        changed();
+        return m_db.subchannels.back();
+    }
+    Service &GetService(uint32_t sid) {
+        for (auto &s : m_db.services)
+            if (s.id.value == sid) return s;
+        m_db.services.emplace_back();
+        m_db.services.back().id.value = sid;
+        m_db.ensemble.nb_services = uint8_t(m_db.services.size());
+        changed();
+        return m_db.services.back();
+    }
+    void SetServiceLabel(uint32_t sid, const std::string &label) { set_string(GetService(sid).label, label); }
+    ServiceComponent &GetServiceComponent(uint32_t sid, subchannel_id_t subchannel_id, bool *is_new) {
+        for (auto &c : m_db.service_components)
+            if (c.service_id.value == sid && c.subchannel_id == subchannel_id) { *is_new = false; return c; }
+        m_db.service_components.emplace_back();
+        auto &c = m_db.service_components.back();
+        c.service_id.value = sid;
+        c.subchannel_id = subchannel_id;
+        *is_new = true;
+        changed();
+        return c;
+    }
+    void same(bool ok) { m_stats.nb_total++; if (!ok) m_stats.nb_conflicts++; }
+    void changed() { m_stats.nb_total++; m_stats.nb_updates++; }
+
+private:
+    void set_string(std::string &dst, const std::string &v) {
+        if (dst.empty() && !v.empty()) { dst = v; changed(); }
+        else same(dst == v);
+    }
+    DAB_Database &m_db;
+    DAB_Database_Statistics m_stats;
+    bool m_have_eid = false;
+};

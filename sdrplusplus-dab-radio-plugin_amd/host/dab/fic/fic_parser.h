@@ -1,0 +1,28 @@
+// dab/fic/fic_parser.h -- FIB -> FIGs -> database: the step the reference's BasicRadio runs on
+// the decoded FIC (absent vendor/DAB-Radio sub-module) so that the GUI can list the multiplex through
+// radio.GetDatabase() (/root/reference/src/render_radio_block.cpp:239-306).  Handles the FIGs a receiver needs to
+// find and decode audio services: 0/0 ensemble, 0/1 sub-channel organisation, 0/2 service organisation,
+// 1/0 and 1/1 labels (ETSI EN 300 401 clauses 5.2, 6.2.1, 6.3.1, 6.4, 8.1.13-14).  Everything else is skipped by
+// its length field.
+#pragma once
+#include <cstdint>
+#include "dab/database/dab_database_updater.h"
+#include "utility/span.h"
+
+class FIC_Parser {
+public:
+    explicit FIC_Parser(DAB_Database_Updater &updater) : m_updater(updater) {}
+    // fib: 32 bytes (30 data + CRC16).  Returns false, touching nothing, when the CRC fails.
+    bool ProcessFIB(tcb::span<const uint8_t> fib);
+    static uint16_t CRC16(const uint8_t *data, size_t n);
+    int GetTotalFIGs() const { return m_total_figs; }
+
+private:
+    void fig0(const uint8_t *d, int n);
+    void fig0_0(const uint8_t *d, int n);
+    void fig0_1(const uint8_t *d, int n);
+    void fig0_2(const uint8_t *d, int n, bool pd);
+    void fig1(const uint8_t *d, int n);
+    DAB_Database_Updater &m_updater;
+    int m_total_figs = 0;
+};

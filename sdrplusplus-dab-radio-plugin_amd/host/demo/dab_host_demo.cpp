@@ -2,14 +2,18 @@
 // (/root/reference/src/radio_block.cpp:11-49): OFDM_Demod -> ThreadedRingBuffer -> radio thread ->
 // BasicRadio::Process, fed from a cf32 file in arbitrary chunks like OFDM_Demodulator_Sink::run
 // (/root/reference/src/dab_module.cpp:20-28).  Writes the decoded FIBs / CRC flags / MSC bytes to files so a
-// test can compare them with what was transmitted.
+// test can compare them with what was transmitted.  The multiplex is discovered from the FIC: <prefix>.db lists the
+// database, <prefix>.aus holds every CRC-clean DAB+ access unit as records
+// {u8 sub-channel id, u8 index, u8 units in super-frame, u16le length, bytes}.
 //
 //   dab_host_demo <iq.cf32> <out_prefix> [chunk_samples] [coarse_offset_cycles_per_sample] [bitrate start_cu level]
+#include <algorithm>
 #include <complex>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -59,7 +63,17 @@ int main(int argc, char **argv) {
     }
     const std::string prefix = argv[2];
     std::ofstream f_fib(prefix + ".fib", std::ios::binary), f_crc(prefix + ".crc", std::ios::binary),
-        f_msc(prefix + ".msc", std::ios::binary);
+        f_msc(prefix + ".msc", std::ios::binary), f_aus(prefix + ".aus", std::ios::binary);
+    // as Radio_Block::reset_radio does (/root/reference/src/radio_block.cpp:62): one hook per audio channel
+    radio->On_Audio_Channel().Attach([&](subchannel_id_t id, Basic_Audio_Channel &channel) {
+        auto *dabplus = dynamic_cast<Basic_DAB_Plus_Channel *>(&channel);
+        if (!dabplus) return;
+        dabplus->OnAccessUnit().Attach([&f_aus, id](int index, int total, tcb::span<const uint8_t> au) {
+            const uint8_t hdr[5] = {id, uint8_t(index), uint8_t(total), uint8_t(au.size() & 0xFF), uint8_t(au.size() >> 8)};
+            f_aus.write(reinterpret_cast<const char *>(hdr), 5);
+            f_aus.write(reinterpret_cast<const char *>(au.data()), std::streamsize(au.size()));
+        });
+    });
     radio->On_FIC().Attach([&](tcb::span<const uint8_t> fib, tcb::span<const uint8_t> ok) {
         f_fib.write(reinterpret_cast<const char *>(fib.data()), std::streamsize(fib.size()));
         f_crc.write(reinterpret_cast<const char *>(ok.data()), std::streamsize(ok.size()));
@@ -90,6 +104,39 @@ int main(int argc, char **argv) {
     }
     ring->close();
     radio_thread.join();
+    {
+        auto lock = std::scoped_lock(radio->GetMutex());
+        const auto &db = radio->GetDatabase();
+        std::FILE *f = std::fopen((prefix + ".db").c_str(), "w");
+        if (f) {
+            if (db.ensemble.cif_counter >= 0 || !db.ensemble.label.empty())
+                std::fprintf(f, "ensemble id=%04X label=[%s]\n", unsigned(db.ensemble.id.value), escape_label(db.ensemble.label).c_str());
+            auto subs = db.subchannels;
+            std::sort(subs.begin(), subs.end(), [](const Subchannel &a, const Subchannel &b) { return a.id < b.id; });
+            for (const auto &sc : subs)
+                std::fprintf(f, "subchannel id=%d start=%d length=%d uep=%d uep_index=%d eep_type=%d eep_level=%d\n", sc.id,
+                             sc.start_address, sc.length, int(sc.is_uep), sc.uep_prot_index, int(sc.eep_type), sc.eep_prot_level);
+            auto svs = db.services;
+            std::sort(svs.begin(), svs.end(), [](const Service &a, const Service &b) { return a.id.value < b.id.value; });
+            for (const auto &sv : svs) {
+                std::fprintf(f, "service id=%04X label=[%s]\n", unsigned(sv.id.value), escape_label(sv.label).c_str());
+                for (const auto &c : db.service_components)
+                    if (c.service_id.value == sv.id.value)
+                        std::fprintf(f, "component service=%04X subchannel=%d tmid=%d ascty=%d primary=%d\n", unsigned(sv.id.value),
+                                     c.subchannel_id, int(c.transport_mode), int(c.audio_service_type), int(c.is_primary));
+            }
+            for (const auto &sc : subs) {
+                auto *ch = radio->Get_Audio_Channel(sc.id);
+                if (!ch) continue;
+                const auto &h = ch->GetSuperFrameHeader();
+                std::fprintf(f, "channel subchannel=%d superframes=%d aus=%d au_errors=%d rate=%u sbr=%d stereo=%d firecode_error=%d rs_error=%d\n",
+                             sc.id, ch->GetTotalSuperFrames(), ch->GetTotalAccessUnits(), ch->GetTotalAccessUnitErrors(),
+                             h.sampling_rate, int(h.is_spectral_band_replication), int(h.is_stereo), int(ch->IsFirecodeError()),
+                             int(ch->IsRSError()));
+            }
+            std::fclose(f);
+        }
+    }
     std::printf("state=%d frames_read=%d frames_desync=%d fine=%.6g net=%.6g level=%.4f fibs=%d fib_errors=%d\n",
                 int(demod->GetState()), demod->GetTotalFramesRead(), demod->GetTotalFramesDesync(),
                 demod->GetFineFrequencyOffset() * OFDM_DEMOD_SAMPLING_RATE,

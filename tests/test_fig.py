@@ -1,0 +1,139 @@
+"""FIC -> FIG -> database -> DAB+ channels (SURVEY.md 8f-4 with 8f-3 behind it).
+CPU: the host FIG parser (C++, no GPU needed) against the Python restatement and against what the synthetic
+multiplex says about itself; fuzzing with random CRC-valid FIBs.  GPU: the demo wired like Radio_Block discovers the
+services of an unknown multiplex from IQ and hands out their access units."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from dabgpu import synth
+from oracle import fig_oracle as FO
+
+HOST = os.path.join(ROOT, "sdrplusplus-dab-radio-plugin_amd", "host")
+SERVICES = [("Radio One", 0xC221, 3, 0, 3, 64, 0), ("Jazz 24", 0xC222, 7, 0, 2, 48, 48), ("News", 0xC223, 9, 1, 2, 32, 200)]
+
+
+@pytest.fixture(scope="module")
+def parser_exe():
+    exe = os.path.join(HOST, "test_fig_parser")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", HOST, "test_fig_parser"], stdout=subprocess.DEVNULL)
+    return exe
+
+
+@pytest.fixture(scope="module")
+def ensemble():
+    return synth.ServiceEnsemble(1, SERVICES, n_frames=5)
+
+
+def run_parser(exe, fibs, tmp_path):
+    path = tmp_path / "fibs.bin"
+    np.ascontiguousarray(fibs, np.uint8).tofile(path)
+    out = subprocess.run([exe, str(path)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0
+    lines = out.stdout.splitlines()
+    return [l for l in lines if not l.startswith("#")], [l for l in lines if l.startswith("#")][0]
+
+
+def test_oracle_reads_back_what_the_multiplex_says(ensemble):
+    db = FO.parse_fibs(ensemble.fibs.reshape(-1, 32))
+    assert db.ensemble["id"] == 0xC181 and db.ensemble["label"] == "Synth Ensemble"
+    assert sorted(db.subchannels) == [3, 7, 9]
+    for (label, sid, scid, option, level, bitrate, start), size in zip(SERVICES, ensemble.sizes):
+        s = db.subchannels[scid]
+        assert (s["start_address"], s["length"], s["is_uep"], s["eep_type"], s["eep_prot_level"]) == (start, size, False, option, level)
+        sv = db.services[sid]
+        assert sv["label"] == label
+        assert sv["components"] == [{"subchannel_id": scid, "transport_mode": 0, "audio_service_type": 63, "is_primary": True}]
+
+
+def test_host_parser_equals_oracle(parser_exe, ensemble, tmp_path):
+    fibs = ensemble.fibs.reshape(-1, 32).copy()
+    got, stats = run_parser(parser_exe, fibs, tmp_path)
+    assert got == FO.parse_fibs(fibs).lines()
+    assert "fibs_bad_crc=0" in stats and "conflicts=0" in stats
+    # FIBs damaged in transit must be ignored, not half-parsed
+    bad = fibs.copy()
+    bad[::7, 5] ^= 0x40                            # every FIG is repeated in later CIFs, so nothing is lost
+    got, stats = run_parser(parser_exe, bad, tmp_path)
+    assert got == FO.parse_fibs(bad).lines() == FO.parse_fibs(fibs).lines()
+    assert "fibs_bad_crc=%d" % len(bad[::7]) in stats
+
+
+def test_host_parser_other_forms(parser_exe, tmp_path):
+    figs = [synth.fig0_0(0xE1C5, 4999),
+            synth.fig0_1([{"id": 1, "start": 0, "uep_index": 37}, {"id": 62, "start": 700, "option": 1, "level": 4, "size": 90},
+                          {"id": 5, "start": 100, "option": 3, "level": 1, "size": 12}]),       # reserved option: skipped
+            synth.fig0(2, synth._bits((0xE0D12345, 32), (0, 1), (0, 3), (2, 4), (0, 2), (0, 6), (1, 6), (1, 1), (0, 1),
+                                      (1, 2), (5, 6), (62, 6), (0, 1), (0, 1)), pd=1),           # 32-bit SId; one data component
+            synth.fig0(9, bytes([0x12, 0x34, 0x56])),                                            # unknown extension: skipped
+            synth.fig1(1, 0x1234, "Short"), synth.fig1(5, 0x1234, "Other kind")]
+    fibs = synth.pack_fibs(figs)
+    got, _ = run_parser(parser_exe, fibs, tmp_path)
+    want = FO.parse_fibs(fibs).lines()
+    assert got == want
+    assert "subchannel id=1 start=0 length=0 uep=1 uep_index=37 eep_type=0 eep_level=0" in got
+    assert "subchannel id=62 start=700 length=90 uep=0 uep_index=0 eep_type=1 eep_level=4" in got
+    assert not any(l.startswith("subchannel id=5 ") for l in got)
+    assert "component service=E0D12345 subchannel=1 tmid=0 ascty=0 primary=1" in got
+    assert sum(l.startswith("component") for l in got) == 1
+    assert "service id=1234 label=[Short]" in got
+
+
+def test_host_parser_fuzz(parser_exe, tmp_path):
+    """Random bytes with a valid CRC: whatever they mean, both parsers must read the same thing and neither may
+    crash (lengths that overrun the FIB, truncated entries, reserved fields ...)."""
+    rng = np.random.default_rng(99)
+    fibs = synth.make_fibs(rng, 3000)
+    # make FIG headers plausible more often: type 0/1 with assorted lengths at the start of the FIB
+    fibs[:1500, 0] = rng.choice(np.array([0x05, 0x0D, 0x1D, 0x35, 0x15, 0x3F, 0x03], np.uint8), 1500)
+    fibs[:1500, 1] &= 0x27
+    for f in fibs:
+        c = synth.crc16(f[:30])
+        f[30], f[31] = c >> 8, c & 0xFF
+    got, _ = run_parser(parser_exe, fibs, tmp_path)
+    assert got == FO.parse_fibs(fibs).lines()
+
+
+@pytest.mark.gpu
+def test_unknown_multiplex_from_iq_to_access_units(built, ensemble, tmp_path):
+    if not os.path.exists(os.path.join(HOST, "dab_host_demo")):
+        subprocess.check_call(["make", "-C", HOST, "-j4"], stdout=subprocess.DEVNULL)
+    rng = np.random.default_rng(8)
+    cycles = 3
+    iq = np.tile(ensemble.iq().ravel(), cycles)
+    iq = synth.channel(iq, snr_db=20.0, cfo=1.2 / 2048, rng=rng)
+    path = tmp_path / "iq.cf32"
+    np.concatenate([iq[-30000:], iq, iq[:synth.NB_NULL + 5000]]).astype(np.complex64).tofile(path)
+    prefix = str(tmp_path / "out")
+    r = subprocess.run([os.path.join(HOST, "dab_host_demo"), str(path), prefix, "40000"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert "frames_desync=0" in r.stdout, r.stdout
+    db = open(prefix + ".db").read().splitlines()
+    want = FO.parse_fibs(ensemble.fibs.reshape(-1, 32)).lines()
+    assert [l for l in db if not l.startswith("channel")] == want
+    chans = [l for l in db if l.startswith("channel")]
+    assert len(chans) == 3 and all("firecode_error=0" in l and "rs_error=0" in l and "rate=48000 sbr=1 stereo=1" in l for l in chans)
+    # access units, per sub-channel, in transmission order
+    raw = np.fromfile(prefix + ".aus", np.uint8)
+    got = {3: [], 7: [], 9: []}
+    i = 0
+    while i < raw.size:
+        scid, idx, total, n = int(raw[i]), int(raw[i + 1]), int(raw[i + 2]), int(raw[i + 3]) | (int(raw[i + 4]) << 8)
+        got[scid].append((idx, total, raw[i + 5:i + 5 + n]))
+        i += 5 + n
+    n_lf = 4 * 5 * cycles - 15                       # logical frames the de-interleaver completes
+    for k, (label, sid, scid, *_r) in enumerate(SERVICES):
+        sent = []
+        for sf in range(n_lf // 5):
+            aus = ensemble.aus[k][sf % len(ensemble.aus[k])]
+            sent += [(a, len(aus), au) for a, au in enumerate(aus)]
+        # the first frames may be lost while the fine-frequency loop settles: compare the tail
+        assert len(got[scid]) >= len(sent) - 2 * 3
+        tail = got[scid][-(len(sent) - 6):]
+        for (gi, gt, gb), (si, st, sb) in zip(tail, sent[-len(tail):]):
+            assert (gi, gt) == (si, st) and gb.size == sb.size and (gb == sb).all()
