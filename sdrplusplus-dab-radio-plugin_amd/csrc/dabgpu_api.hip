@@ -179,7 +179,6 @@ bool use_lane(dabgpu_ctx *ctx, int nsteps, int n_codewords, hipStream_t s, dabk:
         // growing the buffer must not race with work still using the old one
         if (hipStreamSynchronize(s) != hipSuccess) { *rc = DABGPU_ERR_HIP; return false; }
         if (ctx->d_lane_scratch) (void)hipFree(ctx->d_lane_scratch);
-    if (ctx->d_acq_scratch) (void)hipFree(ctx->d_acq_scratch);
         ctx->d_lane_scratch = nullptr;
         ctx->lane_scratch_bytes = 0;
         if (hipMalloc(&ctx->d_lane_scratch, need) != hipSuccess) {
