@@ -5,7 +5,10 @@
 #include <cstdio>
 #include <numeric>
 #include <thread>
+#include <memory>
 #include <vector>
+#include "dab/database/dab_database_updater.h"
+#include "utility/lru_cache.h"
 
 #include "app_helpers/app_io_buffers.h"
 #include "dab/constants/dab_parameters.h"
@@ -68,6 +71,28 @@ int main() {
     bool threw = false;
     try { get_DAB_OFDM_params(2); } catch (const std::exception &) { threw = true; }
     assert(threw);
+    // LRU cache as the GUI's texture cache uses it
+    {
+        LRU_Cache<uint32_t, std::unique_ptr<int>> cache;
+        cache.set_max_size(2);
+        cache.emplace(1u, std::make_unique<int>(10));
+        cache.emplace(2u, std::make_unique<int>(20));
+        assert(cache.find(1u) && **cache.find(1u) == 10);       // 1 is now the most recent
+        cache.emplace(3u, std::make_unique<int>(30));           // evicts 2
+        assert(cache.find(2u) == nullptr && cache.find(1u) && cache.find(3u) && cache.size() == 2);
+        cache.set_max_size(1);
+        assert(cache.size() == 1 && cache.find(3u));
+    }
+    // the database updater keeps the first value of a field and counts later disagreements
+    {
+        DAB_Database db;
+        DAB_Database_Updater up(db);
+        up.SetEnsembleLabel("One");
+        up.SetEnsembleLabel("Two");
+        up.SetEnsembleLabel("One");
+        assert(db.ensemble.label == "One" && up.GetStatistics().nb_conflicts == 1);
+        assert(escape_label("a[b]\\\x01") == "a\\x5Bb\\x5D\\x5C\\x01");
+    }
     std::puts("host types ok");
     return 0;
 }

@@ -1,0 +1,2 @@
+#pragma once   // TEST-ONLY stub (see README.md)
+namespace ImGui { class ConstellationDiagram {}; }

@@ -1,0 +1,1 @@
+#pragma once   // TEST-ONLY stub (see README.md)

@@ -33,6 +33,14 @@ def test_reference_radio_block_compiles_unchanged(host_built):
     assert r.returncode == 0, r.stderr[-2000:]
 
 
+@pytest.mark.skipif(not os.path.exists("/root/reference/src/dab_module.cpp"), reason="reference not mounted")
+def test_reference_dab_module_compiles_unchanged(host_built):
+    """The plugin's own module file against the mirror headers; SDR++'s headers are TEST-ONLY declarations under
+    tests/stubs/sdrpp (see its README)."""
+    r = subprocess.run(["make", "-C", HOST, "check_reference_dab_module"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("chunk,cfo", [(65536, 0.0), (10007, 0.23 / 2048), (196608 * 2 + 13, -0.31 / 2048),
                                        (32768, 7.3 / 2048), (50001, -41.8 / 2048)])
