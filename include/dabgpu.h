@@ -140,6 +140,27 @@ int dabgpu_ofdm_demod_frames_dev(dabgpu_ctx *ctx, const void *d_iq, size_t frame
 int dabgpu_ofdm_demod_frames(dabgpu_ctx *ctx, const float *iq, size_t frame_stride, int n_frames,
                              const float *freq_offset, int8_t *soft, float *cyc, float *dqpsk);
 
+/* Soft-bit selection (batch receivers that decode the FIC and a few sub-channels and never look at the rest of the
+ * frame): from the next call on, dabgpu_ofdm_demod_frames[_dev] and dabgpu_ofdm_demod_acquired_dev of this context
+ * write only the listed parts of each frame's 230400 soft bits and leave the other bytes of `soft` untouched
+ * (every symbol is still transformed and used as the next one's differential reference).  The reference's
+ * OFDM_Demod always emits whole frames (/root/reference/src/radio_block.cpp:25); its BasicRadio then reads the
+ * FIC and the selected sub-channels only (:42) -- this moves that choice in front of the 230 kB store.
+ *   ranges    frame-bit coordinates [first, first+count), both multiples of 16, inside 0..230400
+ *   n_ranges  0 = write everything again (the default)
+ * Calls with a constellation output (dqpsk != NULL) ignore the selection.  Not to be changed while a demodulation
+ * call of this context is still running on some stream.
+ * dabgpu_soft_selection writes the ranges of the FIC (with_fic != 0) and of the given sub-channels (4 CIFs each)
+ * to `out` and returns how many there are (more than max_out = nothing written beyond max_out), or a negative
+ * status for a bad sub-channel. */
+typedef struct dabgpu_bit_range {
+    int32_t first;
+    int32_t count;
+} dabgpu_bit_range;
+int dabgpu_ofdm_set_soft_selection(dabgpu_ctx *ctx, const dabgpu_bit_range *ranges, int n_ranges);
+int dabgpu_soft_selection(const struct dabgpu_subchannel *subchannels, int n_subchannels, int with_fic,
+                          dabgpu_bit_range *out, int max_out);
+
 /* A2+A3 alone (the unfused "FFT stage"): frequency-corrected 2048-point forward
  * FFT of the useful part of each of the 76 symbols.  Replaces the FFTW3f plan the
  * reference links (/root/reference/CMakeLists.txt:55-64).

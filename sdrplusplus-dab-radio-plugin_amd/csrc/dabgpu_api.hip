@@ -57,6 +57,8 @@ struct dabgpu_ctx {
     bool timing = false;
     Timer timers[4];
     int ofdm_parts_override = 0;
+    const unsigned long long *d_keep = nullptr;          // current soft-bit selection table ([75][3] words) or nullptr
+    std::vector<void *> keep_tables;                     // every table handed to a kernel so far (freed on destroy)
     void *d_acq_scratch = nullptr;       // block norms + candidates of dabgpu_acquire
     size_t acq_scratch_bytes = 0;
     void *d_lane_scratch = nullptr;      // work buffers of the codeword-per-lane Viterbi
@@ -348,6 +350,7 @@ void dabgpu_destroy(dabgpu_ctx *ctx) {
     for (void *p : ctx->d_stage) if (p) (void)hipFree(p);
     if (ctx->d_lane_scratch) (void)hipFree(ctx->d_lane_scratch);
     if (ctx->d_acq_scratch) (void)hipFree(ctx->d_acq_scratch);
+    for (void *p : ctx->keep_tables) (void)hipFree(p);
     for (Timer &t : ctx->timers) {
         if (t.start) (void)hipEventDestroy(t.start);
         if (t.stop) (void)hipEventDestroy(t.stop);
@@ -405,8 +408,40 @@ int dabgpu_ofdm_demod_frames_dev(dabgpu_ctx *ctx, const void *d_iq, size_t frame
     a.soft = d_soft;
     a.cyc = static_cast<float2 *>(d_cyc);
     a.dqpsk = static_cast<float2 *>(d_dqpsk);
+    a.keep = ctx->d_keep;
     ScopedTimer tm(ctx, 0, s);
     HIP_TRY(dabk::launch_ofdm_demod(tab, a, pick_parts(ctx, n_frames, NB_DATA_SYMBOLS), s));
+    return DABGPU_OK;
+}
+
+int dabgpu_ofdm_set_soft_selection(dabgpu_ctx *ctx, const dabgpu_bit_range *ranges, int n_ranges) {
+    if (!ctx || n_ranges < 0 || (n_ranges > 0 && !ranges)) return DABGPU_ERR_ARG;
+    if (n_ranges == 0) { ctx->d_keep = nullptr; return DABGPU_OK; }
+    constexpr int CHUNKS_PER_SYMBOL = NB_SYM_BITS / 16;          // 192 = 3 words
+    std::vector<unsigned long long> words(size_t(NB_DATA_SYMBOLS) * 3, 0ull);
+    for (int r = 0; r < n_ranges; r++) {
+        const int first = ranges[r].first, count = ranges[r].count;
+        if (first < 0 || count < 0 || (first & 15) || (count & 15) || first > NB_FRAME_BITS - count) return DABGPU_ERR_ARG;
+        for (int c = first / 16; c < (first + count) / 16; c++) {
+            const int sym = c / CHUNKS_PER_SYMBOL, k = c % CHUNKS_PER_SYMBOL;
+            words[size_t(sym) * 3 + (k >> 6)] |= 1ull << (k & 63);
+        }
+    }
+    // kernels already launched keep reading the table they were given: a new selection gets a new table
+    if (ctx->keep_tables.size() >= 256) {
+        HIP_TRY(hipDeviceSynchronize());
+        for (void *p : ctx->keep_tables) (void)hipFree(p);
+        ctx->keep_tables.clear();
+        ctx->d_keep = nullptr;
+    }
+    void *d = nullptr;
+    if (hipMalloc(&d, words.size() * sizeof(words[0])) != hipSuccess) return DABGPU_ERR_NOMEM;
+    if (hipMemcpy(d, words.data(), words.size() * sizeof(words[0]), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(d);
+        return DABGPU_ERR_HIP;
+    }
+    ctx->keep_tables.push_back(d);
+    ctx->d_keep = static_cast<const unsigned long long *>(d);
     return DABGPU_OK;
 }
 
@@ -627,6 +662,7 @@ int dabgpu_ofdm_demod_acquired_dev(dabgpu_ctx *ctx, const void *d_iq, size_t str
     a.dqpsk = static_cast<float2 *>(d_dqpsk);
     a.acq = reinterpret_cast<const dabk::AcquiredFrame *>(d_frames);
     a.acq_per_stream = max_frames;
+    a.keep = ctx->d_keep;
     ScopedTimer tm(ctx, 0, s);
     HIP_TRY(dabk::launch_ofdm_demod(tab, a, pick_parts(ctx, a.n_frames, NB_DATA_SYMBOLS), s));
     return DABGPU_OK;
@@ -682,6 +718,25 @@ static int subchannel_profile(const dabgpu_subchannel *sc, dab::PunctureProfile 
     if (size_cu != sc->length) return DABGPU_ERR_PROFILE;
     if (sc->start_address < 0 || sc->start_address + sc->length > 864) return DABGPU_ERR_ARG;
     return DABGPU_OK;
+}
+
+int dabgpu_soft_selection(const dabgpu_subchannel *subchannels, int n_subchannels, int with_fic,
+                          dabgpu_bit_range *out, int max_out) {
+    if (n_subchannels < 0 || (n_subchannels > 0 && !subchannels) || max_out < 0 || (max_out > 0 && !out)) return DABGPU_ERR_ARG;
+    int n = 0;
+    auto put = [&](int first, int count) {
+        if (n < max_out) { out[n].first = first; out[n].count = count; }
+        n++;
+    };
+    if (with_fic) put(0, NB_FIC_BITS);
+    for (int i = 0; i < n_subchannels; i++) {
+        dab::PunctureProfile prof;
+        const int rc = subchannel_profile(&subchannels[i], prof);
+        if (rc) return rc;
+        for (int c = 0; c < NB_CIFS; c++)
+            put(NB_FIC_BITS + c * NB_CIF_BITS + subchannels[i].start_address * 64, subchannels[i].length * 64);
+    }
+    return n;
 }
 
 int dabgpu_subchannel_bytes(const dabgpu_subchannel *sc) {

@@ -27,6 +27,8 @@ struct OfdmArgs {
     // flags are not 3 produce all-zero (erased) soft bits
     const struct AcquiredFrame *acq = nullptr;
     int acq_per_stream = 1;
+    // soft-bit selection: [75][3] words, bit k of symbol s = write its 16-byte chunk k; nullptr = write everything
+    const unsigned long long *keep = nullptr;
 };
 
 // fused A2..A6.  Each frame is cut into `parts` contiguous runs of data symbols (1..75); a run re-reads

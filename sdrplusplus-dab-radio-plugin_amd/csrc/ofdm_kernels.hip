@@ -252,7 +252,8 @@ __device__ __forceinline__ float wave_sum(float v, int lane) {
     return v;
 }
 
-template <bool FFT_ONLY, bool WITH_DQPSK>
+// SELECT: soft-bit selection table in use (a separate instantiation so that the plain kernel keeps its registers)
+template <bool FFT_ONLY, bool WITH_DQPSK, bool SELECT = false>
 __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab, OfdmArgs a, int parts, int n_items) {
     __shared__ WaveLds sm;
     const int tid = threadIdx.x;
@@ -466,10 +467,19 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
             cur[j] = X[m & 3][m >> 2];
         }
         if (lane == 0) cur[0] = X[0][3];
+        // soft-bit selection: bit k of the symbol's 192-bit word = its 16-byte chunk k is wanted.  A symbol nobody
+        // wants skips the whole epilogue (its spectrum is still the next symbol's reference).
+        bool wanted = true;
+        if constexpr (SELECT) {
+            if (l > l_first) {
+                const unsigned long long *kw = a.keep + 3 * __builtin_amdgcn_readfirstlane(l - 1);
+                wanted = (kw[0] | kw[1] | kw[2]) != 0ull;
+            }
+        }
 #ifdef DAB_EXP_NOEPI
         if (l > l_first && cur[3].x == 12345.f) {
 #else
-        if (l > l_first) {
+        if (l > l_first && wanted) {
 #endif
             uint8_t *stg = reinterpret_cast<uint8_t *>(ex);
 #pragma unroll
@@ -504,7 +514,16 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
             __builtin_nontemporal_store(v4u{s1.x, s1.y, s1.z, s1.w}, reinterpret_cast<v4u *>(o + 64));
             __builtin_nontemporal_store(v4u{s2.x, s2.y, s2.z, s2.w}, reinterpret_cast<v4u *>(o + 128));
 #else
-            o[0] = s0; o[64] = s1; o[128] = s2;
+            if constexpr (SELECT) {
+                // wave-uniform selection words; one predicated 16-byte store per chunk
+                const unsigned long long *kw = a.keep + 3 * __builtin_amdgcn_readfirstlane(l - 1);
+                const unsigned long long me = 1ull << lane;
+                if (kw[0] & me) o[0] = s0;
+                if (kw[1] & me) o[64] = s1;
+                if (kw[2] & me) o[128] = s2;
+            } else {
+                o[0] = s0; o[64] = s1; o[128] = s2;
+            }
 #endif
         }
 #pragma unroll
@@ -523,11 +542,17 @@ hipError_t launch_ofdm_demod(const OfdmTables &t, const OfdmArgs &a, int parts, 
     if (a.n_frames <= 0) return hipSuccess;
     if (parts <= 0 || parts > NB_DATA_SYMBOLS) return hipErrorInvalidValue;
     const int items = a.n_frames * parts;
-    if (use_v0() && a.acq) return hipErrorInvalidValue;       // the first-generation kernel only takes aligned frames
+    if (use_v0() && (a.acq || a.keep)) return hipErrorInvalidValue;   // the first-generation kernel: aligned frames, all bits
     if (use_v0()) {
         hipLaunchKernelGGL(ofdm_kernel<false>, dim3(unsigned(items)), dim3(WG), 0, s, t, a, parts);
     } else if (a.dqpsk) {
+        // the constellation output covers every symbol, so a selection only applies to the plain variant
+        OfdmArgs b = a;
+        b.keep = nullptr;
         hipLaunchKernelGGL((ofdm_wave_kernel<false, true>), dim3(unsigned((items + WAVES - 1) / WAVES)),
+                           dim3(64 * WAVES), 0, s, t, b, parts, items);
+    } else if (a.keep) {
+        hipLaunchKernelGGL((ofdm_wave_kernel<false, false, true>), dim3(unsigned((items + WAVES - 1) / WAVES)),
                            dim3(64 * WAVES), 0, s, t, a, parts, items);
     } else {
         hipLaunchKernelGGL((ofdm_wave_kernel<false, false>), dim3(unsigned((items + WAVES - 1) / WAVES)),

@@ -88,8 +88,13 @@ struct LSrcMsc {
 // in LDS with 16-byte loads along the codewords; then every thread assembles the 4 soft bytes of (step, lane)
 // from LDS and the stores run along the lanes: M[group][step][lane].
 // ---------------------------------------------------------------------------------------------------------
-constexpr int PREP_STEPS = 64;
-constexpr int PREP_PITCH = 276;                               // bytes per staged row: 17 chunks + pad, 69 dwords (odd)
+#ifndef DAB_PREP_STEPS
+#define DAB_PREP_STEPS 64
+#endif
+constexpr int PREP_STEPS = DAB_PREP_STEPS;
+// bytes per staged row: the span (<= 4 bytes per step) rounded up to 16-byte chunks + one chunk of alignment slack,
+// padded to an odd number of dwords (64 steps: 17 chunks + 4 = 276 B = 69 dwords)
+constexpr int PREP_PITCH = ((4 * PREP_STEPS + 15) / 16 + 1) * 16 + 4;
 
 template <class Src>
 __global__ __launch_bounds__(256) void lane_prep_kernel(Src src, const int32_t *punct_idx, int nsteps, int n_codewords,
@@ -104,10 +109,10 @@ __global__ __launch_bounds__(256) void lane_prep_kernel(Src src, const int32_t *
     const int cw0 = group * 64;
     if (tid == 0) { s_lo = 0x7fffffff; s_hi = 0; }
     __syncthreads();
-    {
-        const int p = 4 * t0 + tid;
+    for (int i = tid; i < 4 * PREP_STEPS; i += 256) {
+        const int p = 4 * t0 + i;
         const int idx = (p < 4 * nsteps) ? punct_idx[p] : -1;
-        s_idx[tid] = idx;
+        s_idx[i] = idx;
         if (idx >= 0) { atomicMin(&s_lo, idx); atomicMax(&s_hi, idx + 1); }
     }
     __syncthreads();

@@ -34,6 +34,7 @@ EXPORTS = [
     "dabgpu_viterbi", "dabgpu_set_timing", "dabgpu_last_kernel_ms", "dabgpu_sync_prs_dev", "dabgpu_sync_prs",
     "dabgpu_msc_decode_multi_dev", "dabgpu_dabplus_superframes_dev", "dabgpu_dabplus_superframes",
     "dabgpu_acquire_default_cfg", "dabgpu_acquire_dev", "dabgpu_acquire", "dabgpu_ofdm_demod_acquired_dev",
+    "dabgpu_ofdm_set_soft_selection", "dabgpu_soft_selection",
 ]
 
 
@@ -74,6 +75,16 @@ class AcquireCfg(C.Structure):
 ACQUIRED_FRAME_DTYPE = np.dtype([("start", np.int64), ("freq_offset", np.float32), ("coarse_carriers", np.int32),
                                  ("fine_offset", np.float32), ("peak_to_mean", np.float32),
                                  ("coarse_peak_to_mean", np.float32), ("flags", np.int32)])     # 32 bytes
+
+
+def soft_selection(subchannels, with_fic=True):
+    """[(first_bit, count), ...] covering the FIC and the given sub-channels (dabgpu_soft_selection)."""
+    n = len(subchannels)
+    arr = (Subchannel * max(n, 1))(*subchannels)
+    out = np.zeros((1 + 4 * n, 2), np.int32)
+    k = lib().dabgpu_soft_selection(arr, n, int(bool(with_fic)), _p(out), len(out))
+    _check(min(k, 0), "dabgpu_soft_selection")
+    return [tuple(int(v) for v in r) for r in out[:k]]
 
 
 def acquire_cfg(**kw):
@@ -133,6 +144,8 @@ def lib():
         L.dabgpu_msc_decode_multi_dev.argtypes = [vp, vp, i, vp, sz, i, i, vp, vp, vp, vp]
         L.dabgpu_sync_prs_dev.argtypes = [vp, vp, sz, i, vp, i, vp, vp]
         L.dabgpu_sync_prs.argtypes = [vp, vp, sz, i, vp, i, vp]
+        L.dabgpu_ofdm_set_soft_selection.argtypes = [vp, vp, i]
+        L.dabgpu_soft_selection.argtypes = [vp, i, i, vp, i]
         L.dabgpu_acquire_default_cfg.restype = None
         L.dabgpu_acquire_default_cfg.argtypes = [C.POINTER(AcquireCfg)]
         L.dabgpu_acquire_dev.argtypes = [vp, vp, sz, i, C.c_int64, C.POINTER(AcquireCfg), i, vp, vp, vp]
@@ -267,6 +280,12 @@ class Context:
                                  ("peak_to_mean", np.float32), ("coarse_peak_to_mean", np.float32)])
         _check(lib().dabgpu_sync_prs(self._h, _p(iq), stride, n, _p(fo), max_coarse, _p(out)), "dabgpu_sync_prs")
         return out
+
+    def set_soft_selection(self, ranges):
+        """ranges: iterable of (first_bit, count) in frame-bit coordinates, or None / empty for whole frames."""
+        arr = np.array(list(ranges) if ranges is not None else [], np.int32).reshape(-1, 2)
+        _check(lib().dabgpu_ofdm_set_soft_selection(self._h, _p(arr) if len(arr) else None, len(arr)),
+               "dabgpu_ofdm_set_soft_selection")
 
     def acquire(self, iq, max_frames, cfg=None):
         """iq: complex64 [n_streams][n_samples] unaligned captures -> (frames [n_streams][max_frames] structured

@@ -1,0 +1,72 @@
+"""Soft-bit selection: the front end writes only the parts of the frame a batch receiver will decode.  What is
+written must be byte-identical to the whole-frame run, what is not selected must stay untouched, and the channel
+decoder must not notice the difference."""
+import numpy as np
+import pytest
+import torch
+
+import dabgpu
+from conftest import make_ctx
+from dabgpu import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_selection_helper_and_argument_checks(built):
+    sc = dabgpu.subchannel(10, 64, level=3)                 # 48 CUs from CU 10
+    sel = dabgpu.soft_selection([sc])
+    assert sel[0] == (0, 9216)
+    assert sel[1:] == [(9216 + c * 55296 + 640, 3072) for c in range(4)]
+    assert dabgpu.soft_selection([], with_fic=False) == []
+    c = make_ctx(None, 4)
+    L = dabgpu.lib()
+    for bad in ([(8, 16)], [(0, 24)], [(-16, 16)], [(230400 - 16, 32)], [(0, 230416)]):
+        with pytest.raises(dabgpu.DabGpuError):
+            c.set_soft_selection(bad)
+    assert L.dabgpu_ofdm_set_soft_selection(c._h, None, 3) == -1
+    c.set_soft_selection([(0, 230400)])
+    c.set_soft_selection(None)
+    c.close()
+
+
+@pytest.mark.parametrize("parts", [None, "1", "7"])
+def test_selected_output_equals_whole_frame_run(built, ensemble, ensemble_iq, monkeypatch, parts):
+    if parts:
+        monkeypatch.setenv("DABGPU_OFDM_PARTS", parts)
+    c = make_ctx(None, 8)
+    rng = np.random.default_rng(3)
+    rx = synth.channel(ensemble_iq.ravel(), snr_db=15.0, cfo=0.21 / 2048, rng=rng).reshape(ensemble_iq.shape)
+    frames = np.ascontiguousarray(rx[:, synth.NB_NULL:])
+    n = frames.shape[0]
+    fo = np.full(n, -0.21 / 2048, np.float32)
+    full, _, _ = c.ofdm_demod_frames(frames, fo)
+    sc = dabgpu.subchannel(ensemble.start_cu, 64, level=3)
+    # FIC + the sub-channel + an odd little piece in the middle of a symbol
+    sel = dabgpu.soft_selection([sc]) + [(100000 - 100000 % 16, 48)]
+    c.set_soft_selection(sel)
+    dev = torch.device("cuda", 0)
+    d_iq = torch.from_numpy(frames).to(dev)
+    d_fo = torch.from_numpy(fo).to(dev)
+    d_soft = torch.full((n, dabgpu.NB_FRAME_BITS), 99, dtype=torch.int8, device=dev)
+    c.ofdm_demod_frames_dev(d_iq.data_ptr(), frames.shape[1], n, d_fo.data_ptr(), d_soft.data_ptr(), None, None, None)
+    c.sync()
+    got = d_soft.cpu().numpy()
+    want = np.full_like(full, 99)
+    for first, count in sel:
+        want[:, first:first + count] = full[:, first:first + count]
+    assert (got == want).all()
+    # the decoder sees no difference
+    fib_a, ok_a = c.fic_decode(full)
+    fib_b, ok_b = c.fic_decode(got)
+    assert (fib_a == fib_b).all() and (ok_a == ok_b).all() and ok_a.all()
+    out_a, _ = c.msc_decode(sc, full, n_streams=1, want_history=True)
+    out_b, _ = c.msc_decode(sc, got, n_streams=1, want_history=True)
+    assert (out_a == out_b).all()
+    # the constellation output needs every symbol: the selection is ignored there
+    soft2, _, dq = c.ofdm_demod_frames(frames[:1], fo[:1], want_dqpsk=True)
+    assert (soft2 == full[:1]).all() and np.isfinite(dq).all()
+    # and switching it off restores whole frames
+    c.set_soft_selection(None)
+    again, _, _ = c.ofdm_demod_frames(frames, fo)
+    assert (again == full).all()
+    c.close()
