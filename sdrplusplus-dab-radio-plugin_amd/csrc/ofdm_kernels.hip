@@ -328,6 +328,35 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
         asm volatile("" : "+v"(n2i), "+v"(pi));
         // phasor of this lane's first sample, computed before the loads so sincospi's temporaries are dead
         // by the time 64 data registers are live
+        if constexpr (SELECT) {
+            // A symbol is transformed only if some of its own soft bits are wanted or it is the differential
+            // reference of a wanted one.  The others give at most their cyclic-prefix correlation, which needs the
+            // prefix and the last 512 samples only (8 of the 20 loads).
+            const int ls = __builtin_amdgcn_readfirstlane(l);
+            bool need = false;
+            if (ls > l_first) { const unsigned long long *kw = a.keep + 3 * (ls - 1); need |= (kw[0] | kw[1] | kw[2]) != 0ull; }
+            if (ls < l_last) { const unsigned long long *kw = a.keep + 3 * ls; need |= (kw[0] | kw[1] | kw[2]) != 0ull; }
+            if (!need) {
+                if (a.cyc && emit) {
+                    float2 acc = make_float2(0.f, 0.f);
+                    const float2 *cp = sym + 2 * (lane - 4);
+                    const float2 *tail = sym + NB_CP + 128 * 12 + 2 * lane;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        if (i > 0 || lane >= 4) {
+                            const float2 c0 = cp[128 * i], c1 = cp[128 * i + 1];
+                            const float2 u0 = tail[128 * i], u1 = tail[128 * i + 1];
+                            acc.x += c0.x * u0.x + c0.y * u0.y + c1.x * u1.x + c1.y * u1.y;      // conj(c) * u
+                            acc.y += c0.x * u0.y - c0.y * u0.x + c1.x * u1.y - c1.y * u1.x;
+                        }
+                    }
+                    acc.x = wave_sum(acc.x, lane);
+                    acc.y = wave_sum(acc.y, lane);
+                    if (lane == 0) a.cyc[size_t(frame) * NB_FRAME_SYMBOLS + l] = cmul(acc, rot2048);
+                }
+                continue;
+            }
+        }
         float2 w = make_float2(1.f, 0.f);
         if (dphi != 0u) w = nco(uint32_t(l * NB_SYM_PERIOD + NB_CP + 2 * lane), dphi);
         __builtin_amdgcn_sched_barrier(0);
