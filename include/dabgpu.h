@@ -278,11 +278,17 @@ int dabgpu_fic_decode(dabgpu_ctx *ctx, const int8_t *soft, size_t soft_stride, i
 typedef struct dabgpu_subchannel {
     int32_t start_address;   /* first capacity unit (0..863)                  */
     int32_t length;          /* size in capacity units                        */
-    int32_t is_uep;          /* must be 0 in this version                     */
-    int32_t eep_type;        /* 0 = A, 1 = B                                  */
-    int32_t protection_level;/* 1..4                                          */
-    int32_t bitrate_kbps;    /* multiple of 8 (A) / 32 (B)                    */
+    int32_t is_uep;          /* 0 = EEP (long form), 1 = UEP (short form)     */
+    int32_t eep_type;        /* EEP: 0 = A, 1 = B                             */
+    int32_t protection_level;/* EEP 1..4; UEP 1..5                            */
+    int32_t bitrate_kbps;    /* EEP: multiple of 8 (A) / 32 (B); UEP: one of  */
+                             /* the 14 rates of the protection profile table  */
 } dabgpu_subchannel;
+
+/* UEP sub-channels are announced by an index into the standard's table of 64 protection profiles
+ * (FIG 0/1 short form, `uep_prot_index` in the reference's Subchannel entity,
+ * /root/reference/src/render_formatters.cpp:9-25): fills bit rate, level and size from it. */
+int dabgpu_uep_subchannel(int table_index, int start_address, dabgpu_subchannel *out);
 
 /* bytes one CIF of this subchannel decodes to (bitrate*3), or <0 */
 int dabgpu_subchannel_bytes(const dabgpu_subchannel *sc);
@@ -302,7 +308,7 @@ int dabgpu_msc_decode(dabgpu_ctx *ctx, const dabgpu_subchannel *sc, const int8_t
                       const int8_t *history_in, int8_t *history_out, uint8_t *out);
 
 /* Whole-ensemble variant: decode `n_subchannels` subchannels of the same frames in one
- * call (all on one stream; EEP-A and EEP-B profiles, UEP not built).  Per subchannel i:
+ * call (all on one stream; EEP-A, EEP-B and UEP profiles).  Per subchannel i:
  *   history_in[i] / history_out[i]   as above, may be NULL pointers inside the arrays
  *   out[i]                           [n_streams][frames_per_stream*4][bitrate_i*3]
  * The three pointer arrays are HOST arrays of DEVICE pointers.  Subchannels must not overlap in the CIF. */

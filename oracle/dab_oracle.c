@@ -426,6 +426,110 @@ void oracle_ofdm_demod_frame(const float *iq, float freq_offset, int8_t *soft,
 }
 
 /* ------------------------------------------------------------------------- */
+/* UEP protection profiles (EN 300 401 clause 11.3.1, Table 8), table-index      */
+/* order: bitrate, level, size (CU), L1..L4, PI1..PI4, padding.  Restated from   */
+/* memory; oracle_uep_puncture_mask refuses a row that fails the two identities   */
+/* sum L = 24*bitrate/32 and sum L*(32+4*PI) + 12 + padding = 64*size.            */
+/* ------------------------------------------------------------------------- */
+static const int16_t UEP_ROWS[64][12] = {
+    { 32,   5,  16,   3,   4,  17,   0,   5,   3,   2,   0,   0},
+    { 32,   4,  21,   3,   3,  18,   0,  11,   6,   5,   0,   0},
+    { 32,   3,  24,   3,   4,  14,   3,  15,   9,   6,   8,   0},
+    { 32,   2,  29,   3,   4,  14,   3,  22,  13,   8,  13,   0},
+    { 32,   1,  35,   3,   5,  13,   3,  24,  17,  12,  17,   4},
+    { 48,   5,  24,   4,   3,  26,   3,   5,   4,   2,   3,   0},
+    { 48,   4,  29,   3,   4,  26,   3,   9,   6,   4,   6,   0},
+    { 48,   3,  35,   3,   4,  26,   3,  15,  10,   6,   9,   4},
+    { 48,   2,  42,   3,   4,  26,   3,  24,  14,   8,  15,   0},
+    { 48,   1,  52,   3,   5,  25,   3,  24,  18,  13,  18,   0},
+    { 56,   5,  29,   6,  10,  23,   3,   5,   4,   2,   3,   0},
+    { 56,   4,  35,   6,  10,  23,   3,   9,   6,   4,   5,   0},
+    { 56,   3,  42,   6,  12,  21,   3,  16,   7,   6,   9,   0},
+    { 56,   2,  52,   6,  10,  23,   3,  23,  13,   8,  13,   8},
+    { 64,   5,  32,   6,   9,  31,   2,   5,   3,   2,   3,   0},
+    { 64,   4,  42,   6,   9,  33,   0,  11,   6,   5,   0,   0},
+    { 64,   3,  48,   6,  12,  27,   3,  16,   8,   6,   9,   0},
+    { 64,   2,  58,   6,  10,  29,   3,  23,  13,   8,  13,   8},
+    { 64,   1,  70,   6,  11,  28,   3,  24,  18,  12,  18,   4},
+    { 80,   5,  40,   6,  10,  41,   3,   6,   3,   2,   3,   0},
+    { 80,   4,  52,   6,  10,  41,   3,  11,   6,   5,   6,   0},
+    { 80,   3,  58,   6,  11,  40,   3,  16,   8,   6,   7,   0},
+    { 80,   2,  70,   6,  10,  41,   3,  23,  13,   8,  13,   8},
+    { 80,   1,  84,   6,  10,  41,   3,  24,  17,  12,  18,   4},
+    { 96,   5,  48,   7,   9,  53,   3,   5,   4,   2,   4,   0},
+    { 96,   4,  58,   7,  10,  52,   3,   9,   6,   4,   6,   0},
+    { 96,   3,  70,   6,  12,  51,   3,  16,   9,   6,  10,   4},
+    { 96,   2,  84,   6,  10,  53,   3,  22,  12,   9,  12,   0},
+    { 96,   1, 104,   6,  13,  50,   3,  24,  18,  13,  19,   0},
+    {112,   5,  58,  14,  17,  50,   3,   5,   4,   2,   5,   0},
+    {112,   4,  70,  11,  21,  49,   3,   9,   6,   4,   8,   0},
+    {112,   3,  84,  11,  23,  47,   3,  16,   8,   6,   9,   0},
+    {112,   2, 104,  11,  21,  49,   3,  23,  12,   9,  14,   4},
+    {128,   5,  64,  12,  19,  62,   3,   5,   3,   2,   4,   0},
+    {128,   4,  84,  11,  21,  61,   3,  11,   6,   5,   7,   0},
+    {128,   3,  96,  11,  22,  60,   3,  16,   9,   6,  10,   4},
+    {128,   2, 116,  11,  21,  61,   3,  22,  12,   9,  14,   0},
+    {128,   1, 140,  11,  20,  62,   3,  24,  17,  13,  19,   8},
+    {160,   5,  80,  11,  19,  87,   3,   5,   4,   2,   4,   0},
+    {160,   4, 104,  11,  23,  83,   3,  11,   6,   5,   9,   0},
+    {160,   3, 116,  11,  24,  82,   3,  16,   8,   6,  11,   0},
+    {160,   2, 140,  11,  21,  85,   3,  22,  11,   9,  13,   0},
+    {160,   1, 168,  11,  22,  84,   3,  24,  18,  12,  19,   0},
+    {192,   5,  96,  11,  20, 110,   3,   6,   4,   2,   5,   0},
+    {192,   4, 116,  11,  22, 108,   3,  10,   6,   4,   9,   0},
+    {192,   3, 140,  11,  24, 106,   3,  16,  10,   6,  11,   0},
+    {192,   2, 168,  11,  20, 110,   3,  22,  13,   9,  13,   8},
+    {192,   1, 208,  11,  21, 109,   3,  24,  20,  13,  24,   0},
+    {224,   5, 116,  12,  22, 131,   3,   8,   6,   2,   6,   4},
+    {224,   4, 140,  12,  26, 127,   3,  12,   8,   4,  11,   0},
+    {224,   3, 168,  11,  20, 134,   3,  16,  10,   7,   9,   0},
+    {224,   2, 208,  11,  22, 132,   3,  24,  16,  10,  15,   0},
+    {224,   1, 232,  11,  24, 130,   3,  24,  20,  12,  20,   4},
+    {256,   5, 128,  11,  24, 154,   3,   6,   5,   2,   5,   0},
+    {256,   4, 168,  11,  24, 154,   3,  12,   9,   5,  10,   4},
+    {256,   3, 192,  11,  27, 151,   3,  16,  10,   7,  10,   0},
+    {256,   2, 232,  11,  22, 156,   3,  24,  14,  10,  13,   8},
+    {256,   1, 280,  11,  26, 152,   3,  24,  19,  14,  18,   4},
+    {320,   5, 160,  11,  26, 200,   3,   8,   5,   2,   6,   4},
+    {320,   4, 208,  11,  25, 201,   3,  13,   9,   5,  10,   8},
+    {320,   2, 280,  11,  26, 200,   3,  24,  17,   9,  17,   0},
+    {384,   5, 192,  11,  27, 247,   3,   8,   6,   2,   7,   0},
+    {384,   3, 280,  11,  24, 250,   3,  16,   9,   7,  10,   4},
+    {384,   1, 416,  12,  28, 245,   3,  24,  20,  14,  23,   8},
+};
+
+int oracle_uep_profile(int index, int *bitrate, int *level, int *size_cu)
+{
+    if (index < 0 || index >= 64) return -1;
+    *bitrate = UEP_ROWS[index][0];
+    *level = UEP_ROWS[index][1];
+    *size_cu = UEP_ROWS[index][2];
+    return 0;
+}
+
+int oracle_uep_puncture_mask(int index, uint8_t *mask, int *nsteps, int *n_kept, int *size_cu)
+{
+    if (index < 0 || index >= 64) return -1;
+    const int16_t *r = UEP_ROWS[index];
+    int blocks = 0, bits = 12 + r[11];
+    for (int i = 0; i < 4; i++) { blocks += r[3 + i]; bits += r[3 + i] * (32 + 4 * r[7 + i]); }
+    if (blocks * 32 != r[0] * 24 || bits != r[2] * 64) return -1;
+    int pos = 0, kept = 0;
+    uint8_t v[32];
+    for (int i = 0; i < 4; i++) {
+        if (r[3 + i] == 0) continue;
+        oracle_puncture_vector(r[7 + i], v);
+        for (int b = 0; b < 4 * r[3 + i]; b++)
+            for (int k = 0; k < 32; k++) { mask[pos++] = v[k]; kept += v[k]; }
+    }
+    for (int i = 0; i < 6; i++) { mask[pos++] = 1; mask[pos++] = 1; mask[pos++] = 0; mask[pos++] = 0; kept += 2; }
+    *nsteps = pos / 4;
+    *n_kept = kept;
+    *size_cu = r[2];
+    return (kept + r[11] == r[2] * 64 && pos / 4 == r[0] * 24 + 6) ? 0 : -1;
+}
+
+/* ------------------------------------------------------------------------- */
 /* f-1: null-symbol search on a whole capture (see header).                       */
 /* Summation trees are fixed so the result does not depend on who computes it:    */
 /* a block is 32 pairs of samples; pair j contributes ((|x0|+|y0|)+|x1|)+|y1|,    */

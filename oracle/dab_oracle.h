@@ -102,6 +102,11 @@ void oracle_time_deinterleave(const int8_t *const cifs[16], int nbits, int8_t *o
 /* one logical frame of a subchannel: deinterleaved punctured soft bits -> bytes */
 void oracle_msc_decode_lf(const int8_t *deint, const uint8_t *mask, int nsteps, uint8_t *out_bytes);
 
+/* UEP (clause 11.3.1, Table 8): table index 0..63 -> puncture mask (4*(24*bitrate+6) flags), trellis steps,
+   transmitted bits WITHOUT the padding, size in CUs.  Returns 0, or -1 for a bad index. */
+int oracle_uep_profile(int index, int *bitrate, int *level, int *size_cu);
+int oracle_uep_puncture_mask(int index, uint8_t *mask, int *nsteps, int *n_kept, int *size_cu);
+
 /* ---- OFDM front end (A2..A6) ---- */
 void oracle_fft2048(const float *in_cf32, float *out_cf32);  /* forward, unnormalised, fp32 */
 /* one aligned frame: iq = 76*2552 cf32 starting at the first PRS sample.

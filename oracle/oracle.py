@@ -95,6 +95,23 @@ def eep_puncture_mask(option, level, bitrate):
     return m, kept, nsteps.value, cu.value
 
 
+def uep_profile(index):
+    br, lv, cu = C.c_int(0), C.c_int(0), C.c_int(0)
+    if lib().oracle_uep_profile(C.c_int(index), C.byref(br), C.byref(lv), C.byref(cu)) != 0:
+        raise ValueError("invalid UEP table index")
+    return br.value, lv.value, cu.value
+
+
+def uep_puncture_mask(index):
+    """-> (mask, transmitted bits without padding, nsteps, size_cu)."""
+    br, _, _ = uep_profile(index)
+    m = np.zeros(4 * (br * 24 + 6), np.uint8)
+    nsteps, kept, cu = C.c_int(0), C.c_int(0), C.c_int(0)
+    if lib().oracle_uep_puncture_mask(C.c_int(index), _p(m), C.byref(nsteps), C.byref(kept), C.byref(cu)) != 0:
+        raise ValueError("invalid UEP profile")
+    return m, kept.value, nsteps.value, cu.value
+
+
 def prbs(n):
     out = np.zeros(n, np.uint8)
     lib().oracle_prbs(_p(out), C.c_int(n))

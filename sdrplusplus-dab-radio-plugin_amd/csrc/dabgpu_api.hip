@@ -712,9 +712,12 @@ int dabgpu_fic_decode(dabgpu_ctx *ctx, const int8_t *soft, size_t soft_stride, i
 // ---------------------------------------------------------------------------- MSC
 static int subchannel_profile(const dabgpu_subchannel *sc, dab::PunctureProfile &prof) {
     if (!sc) return DABGPU_ERR_ARG;
-    if (sc->is_uep) return DABGPU_ERR_PROFILE;
     int size_cu = 0;
-    if (!make_eep_profile(sc->eep_type, sc->protection_level, sc->bitrate_kbps, prof, size_cu)) return DABGPU_ERR_PROFILE;
+    if (sc->is_uep) {
+        if (!make_uep_profile(uep_table_index(sc->bitrate_kbps, sc->protection_level), prof, size_cu)) return DABGPU_ERR_PROFILE;
+    } else if (!make_eep_profile(sc->eep_type, sc->protection_level, sc->bitrate_kbps, prof, size_cu)) {
+        return DABGPU_ERR_PROFILE;
+    }
     if (size_cu != sc->length) return DABGPU_ERR_PROFILE;
     if (sc->start_address < 0 || sc->start_address + sc->length > 864) return DABGPU_ERR_ARG;
     return DABGPU_OK;
@@ -737,6 +740,20 @@ int dabgpu_soft_selection(const dabgpu_subchannel *subchannels, int n_subchannel
             put(NB_FIC_BITS + c * NB_CIF_BITS + subchannels[i].start_address * 64, subchannels[i].length * 64);
     }
     return n;
+}
+
+int dabgpu_uep_subchannel(int table_index, int start_address, dabgpu_subchannel *out) {
+    if (!out) return DABGPU_ERR_ARG;
+    if (table_index < 0 || table_index >= 64) return DABGPU_ERR_PROFILE;
+    const UepProfileRow &r = UEP_TABLE[table_index];
+    if (start_address < 0 || start_address + r.size > 864) return DABGPU_ERR_ARG;
+    out->start_address = start_address;
+    out->length = r.size;
+    out->is_uep = 1;
+    out->eep_type = 0;
+    out->protection_level = r.level;
+    out->bitrate_kbps = r.bitrate;
+    return DABGPU_OK;
 }
 
 int dabgpu_subchannel_bytes(const dabgpu_subchannel *sc) {

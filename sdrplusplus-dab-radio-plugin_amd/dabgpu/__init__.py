@@ -34,7 +34,7 @@ EXPORTS = [
     "dabgpu_viterbi", "dabgpu_set_timing", "dabgpu_last_kernel_ms", "dabgpu_sync_prs_dev", "dabgpu_sync_prs",
     "dabgpu_msc_decode_multi_dev", "dabgpu_dabplus_superframes_dev", "dabgpu_dabplus_superframes",
     "dabgpu_acquire_default_cfg", "dabgpu_acquire_dev", "dabgpu_acquire", "dabgpu_ofdm_demod_acquired_dev",
-    "dabgpu_ofdm_set_soft_selection", "dabgpu_soft_selection",
+    "dabgpu_ofdm_set_soft_selection", "dabgpu_soft_selection", "dabgpu_uep_subchannel",
 ]
 
 
@@ -146,6 +146,7 @@ def lib():
         L.dabgpu_sync_prs.argtypes = [vp, vp, sz, i, vp, i, vp]
         L.dabgpu_ofdm_set_soft_selection.argtypes = [vp, vp, i]
         L.dabgpu_soft_selection.argtypes = [vp, i, i, vp, i]
+        L.dabgpu_uep_subchannel.argtypes = [i, i, C.POINTER(Subchannel)]
         L.dabgpu_acquire_default_cfg.restype = None
         L.dabgpu_acquire_default_cfg.argtypes = [C.POINTER(AcquireCfg)]
         L.dabgpu_acquire_dev.argtypes = [vp, vp, sz, i, C.c_int64, C.POINTER(AcquireCfg), i, vp, vp, vp]
@@ -205,6 +206,13 @@ def subchannel(start_address, bitrate_kbps, level=3, eep_type=0):
         n = bitrate_kbps // 32
         length = {1: 27 * n, 2: 21 * n, 3: 18 * n, 4: 15 * n}[level]
     return Subchannel(start_address, length, 0, eep_type, level, bitrate_kbps)
+
+
+def uep_subchannel(table_index, start_address):
+    """UEP subchannel descriptor from the protection-profile table index (FIG 0/1 short form)."""
+    sc = Subchannel()
+    _check(lib().dabgpu_uep_subchannel(table_index, start_address, C.byref(sc)), "dabgpu_uep_subchannel")
+    return sc
 
 
 # ------------------------------------------------------------------ context

@@ -111,6 +111,99 @@ def eep_mask(option, level, bitrate):
     return m, cu
 
 
+# UEP protection profiles (clause 11.3.1, Table 8) in table-index order: bitrate level size L1 L2 L3 L4 PI1 PI2 PI3 PI4
+# padding.  Restated from memory; uep_profile() asserts the two identities every row must satisfy.
+_UEP_TABLE = [tuple(int(v) for v in line.split()) for line in """
+    32 5 16 3 4 17 0 5 3 2 0 0
+    32 4 21 3 3 18 0 11 6 5 0 0
+    32 3 24 3 4 14 3 15 9 6 8 0
+    32 2 29 3 4 14 3 22 13 8 13 0
+    32 1 35 3 5 13 3 24 17 12 17 4
+    48 5 24 4 3 26 3 5 4 2 3 0
+    48 4 29 3 4 26 3 9 6 4 6 0
+    48 3 35 3 4 26 3 15 10 6 9 4
+    48 2 42 3 4 26 3 24 14 8 15 0
+    48 1 52 3 5 25 3 24 18 13 18 0
+    56 5 29 6 10 23 3 5 4 2 3 0
+    56 4 35 6 10 23 3 9 6 4 5 0
+    56 3 42 6 12 21 3 16 7 6 9 0
+    56 2 52 6 10 23 3 23 13 8 13 8
+    64 5 32 6 9 31 2 5 3 2 3 0
+    64 4 42 6 9 33 0 11 6 5 0 0
+    64 3 48 6 12 27 3 16 8 6 9 0
+    64 2 58 6 10 29 3 23 13 8 13 8
+    64 1 70 6 11 28 3 24 18 12 18 4
+    80 5 40 6 10 41 3 6 3 2 3 0
+    80 4 52 6 10 41 3 11 6 5 6 0
+    80 3 58 6 11 40 3 16 8 6 7 0
+    80 2 70 6 10 41 3 23 13 8 13 8
+    80 1 84 6 10 41 3 24 17 12 18 4
+    96 5 48 7 9 53 3 5 4 2 4 0
+    96 4 58 7 10 52 3 9 6 4 6 0
+    96 3 70 6 12 51 3 16 9 6 10 4
+    96 2 84 6 10 53 3 22 12 9 12 0
+    96 1 104 6 13 50 3 24 18 13 19 0
+    112 5 58 14 17 50 3 5 4 2 5 0
+    112 4 70 11 21 49 3 9 6 4 8 0
+    112 3 84 11 23 47 3 16 8 6 9 0
+    112 2 104 11 21 49 3 23 12 9 14 4
+    128 5 64 12 19 62 3 5 3 2 4 0
+    128 4 84 11 21 61 3 11 6 5 7 0
+    128 3 96 11 22 60 3 16 9 6 10 4
+    128 2 116 11 21 61 3 22 12 9 14 0
+    128 1 140 11 20 62 3 24 17 13 19 8
+    160 5 80 11 19 87 3 5 4 2 4 0
+    160 4 104 11 23 83 3 11 6 5 9 0
+    160 3 116 11 24 82 3 16 8 6 11 0
+    160 2 140 11 21 85 3 22 11 9 13 0
+    160 1 168 11 22 84 3 24 18 12 19 0
+    192 5 96 11 20 110 3 6 4 2 5 0
+    192 4 116 11 22 108 3 10 6 4 9 0
+    192 3 140 11 24 106 3 16 10 6 11 0
+    192 2 168 11 20 110 3 22 13 9 13 8
+    192 1 208 11 21 109 3 24 20 13 24 0
+    224 5 116 12 22 131 3 8 6 2 6 4
+    224 4 140 12 26 127 3 12 8 4 11 0
+    224 3 168 11 20 134 3 16 10 7 9 0
+    224 2 208 11 22 132 3 24 16 10 15 0
+    224 1 232 11 24 130 3 24 20 12 20 4
+    256 5 128 11 24 154 3 6 5 2 5 0
+    256 4 168 11 24 154 3 12 9 5 10 4
+    256 3 192 11 27 151 3 16 10 7 10 0
+    256 2 232 11 22 156 3 24 14 10 13 8
+    256 1 280 11 26 152 3 24 19 14 18 4
+    320 5 160 11 26 200 3 8 5 2 6 4
+    320 4 208 11 25 201 3 13 9 5 10 8
+    320 2 280 11 26 200 3 24 17 9 17 0
+    384 5 192 11 27 247 3 8 6 2 7 0
+    384 3 280 11 24 250 3 16 9 7 10 4
+    384 1 416 12 28 245 3 24 20 14 23 8
+""".strip().splitlines()]
+
+
+def uep_index(bitrate, level):
+    for i, r in enumerate(_UEP_TABLE):
+        if r[0] == bitrate and r[1] == level:
+            return i
+    raise ValueError("no UEP profile for %d kbit/s level %d" % (bitrate, level))
+
+
+def uep_profile(index):
+    """-> (blocks [(L,PI) x4], size_cu, padding_bits, bitrate)."""
+    br, level, size, L1, L2, L3, L4, P1, P2, P3, P4, pad = _UEP_TABLE[index]
+    blocks = [(L1, P1), (L2, P2), (L3, P3), (L4, P4)]
+    assert sum(L for L, _ in blocks) * 32 == br * 24
+    assert sum(L * (32 + 4 * P) for L, P in blocks) + 12 + pad == size * 64
+    return blocks, size, pad, br
+
+
+def uep_mask(index):
+    blocks, cu, pad, br = uep_profile(index)
+    m = _mask_from_profile(blocks)
+    assert m.size == 4 * (br * 24 + 6) and int(m.sum()) + pad == cu * 64
+    return m, cu
+
+
 # ----------------------------------------------------------------------------- bit level
 def prbs(n):
     reg = [1] * 9  # reg[0] newest
@@ -246,16 +339,22 @@ class Ensemble:
     `n_frames` frames form a cyclically time-interleaved stream (4*n_frames CIFs) so that
     tiling the frames back to back is a valid continuous transmission."""
 
-    def __init__(self, seed, n_frames=4, option=0, level=3, bitrate=64, start_cu=0):
+    def __init__(self, seed, n_frames=4, option=0, level=3, bitrate=64, start_cu=0, uep_index=None):
         rng = np.random.default_rng(seed)
         self.n_frames = n_frames
-        self.mask, self.size_cu = eep_mask(option, level, bitrate)
+        if uep_index is None:
+            self.mask, self.size_cu = eep_mask(option, level, bitrate)
+        else:                                    # UEP: the table row fixes bit rate, level and size
+            self.mask, self.size_cu = uep_mask(uep_index)
+            bitrate = _UEP_TABLE[uep_index][0]
         self.start_cu = start_cu
         self.lf_bytes = bitrate * 3
         R = 4 * n_frames
         self.fibs = make_fibs(rng, 12 * n_frames).reshape(n_frames, 12, 32)
         self.msc_bytes = rng.integers(0, 256, size=(R, self.lf_bytes), dtype=np.uint8)
         coded = np.stack([msc_encode_lf(self.msc_bytes[r], self.mask) for r in range(R)])
+        if coded.shape[1] < self.size_cu * 64:   # UEP padding bits (zeros) fill the sub-channel
+            coded = np.concatenate([coded, np.zeros((R, self.size_cu * 64 - coded.shape[1]), np.uint8)], axis=1)
         tx = time_interleave(coded, cyclic=True)
         cifs = rng.integers(0, 2, size=(R, NB_CIF_BITS), dtype=np.uint8)
         a = start_cu * 64
@@ -463,7 +562,9 @@ class ServiceEnsemble:
     FIC made of FIG 0/0, 0/1, 0/2, 1/0, 1/1.  services = [(label, sid, subchannel_id, option, level, bitrate,
     start_cu), ...].  n_frames must be a multiple of 5 so that whole super-frames (5 logical frames) tile."""
 
-    def __init__(self, seed, services, n_frames=5, eid=0xC181, label="Synth Ensemble"):
+    def __init__(self, seed, services, n_frames=5, eid=0xC181, label="Synth Ensemble", dab_services=()):
+        """dab_services: DAB (MPEG layer II) services on UEP sub-channels, [(label, sid, subchannel_id, uep_index,
+        start_cu), ...]; every logical frame of such a sub-channel is one layer-II frame (header + random body)."""
         assert n_frames % 5 == 0
         rng = np.random.default_rng(seed)
         self.n_frames, self.eid, self.label, self.services = n_frames, eid, label, services
@@ -483,9 +584,25 @@ class ServiceEnsemble:
             self.masks.append(mask); self.sizes.append(size_cu); self.msc_bytes.append(data)
             self.superframes.append(sfs); self.aus.append(aus)
             self.subchannels.append({"id": scid, "start": start_cu, "option": option, "level": level, "size": size_cu})
+        self.dab_services, self.mp2_frames = list(dab_services), []
+        for (lab, sid, scid, uidx, start_cu) in self.dab_services:
+            mask, size_cu = uep_mask(uidx)
+            bitrate = _UEP_TABLE[uidx][0]
+            data = rng.integers(0, 256, size=(R, bitrate * 3), dtype=np.uint8)
+            data[:, 0], data[:, 1] = 0xFF, 0xFD                     # sync, MPEG-1, layer II, no CRC
+            data[:, 2] = (data[:, 2] & 0xF0) | 0x04                 # 48 kHz
+            data[:, 3] &= 0x3F                                      # stereo
+            coded = np.stack([msc_encode_lf(data[r], mask) for r in range(R)])
+            coded = np.concatenate([coded, np.zeros((R, size_cu * 64 - coded.shape[1]), np.uint8)], axis=1)
+            cifs[:, start_cu * 64:(start_cu + size_cu) * 64] = time_interleave(coded, cyclic=True)
+            self.mp2_frames.append(data)
+            self.subchannels.append({"id": scid, "start": start_cu, "uep_index": uidx})
         sv = [{"sid": sid, "components": [{"subchannel": scid, "ascty": ASCTY_DABPLUS}]}
               for (lab, sid, scid, *_rest) in services]
+        sv += [{"sid": sid, "components": [{"subchannel": scid, "ascty": ASCTY_DAB}]}
+               for (lab, sid, scid, *_rest) in self.dab_services]
         labels = [fig1(0, eid, label)] + [fig1(1, sid, lab) for (lab, sid, *_rest) in services]
+        labels += [fig1(1, sid, lab) for (lab, sid, *_rest) in self.dab_services]
         self.fibs = np.zeros((n_frames, 12, 32), np.uint8)
         k = 0
         for f in range(n_frames):

@@ -56,56 +56,69 @@ void BasicRadio::Process(tcb::span<const viterbi_bit_t> buf) {
             if (++s.cifs_seen < 16) continue;
             const tcb::span<const uint8_t> lf(s.out.data() + size_t(c) * s.nbytes, size_t(s.nbytes));
             m_obs_msc.Notify(int(i), lf);
-            if (s.channel) s.channel->Process(lf);
+            if (s.dab_plus) s.dab_plus->Process(lf);
+            if (s.dab) s.dab->Process(lf);
         }
     }
 }
 
-// Open every DAB+ audio component whose sub-channel the FIC has described (called with the mutex held).
+// Open every audio component whose sub-channel the FIC has described (called with the mutex held).
 void BasicRadio::update_channels_from_database() {
     if (m_database.service_components.size() == m_seen_components && !m_pending_components) return;
     m_pending_components = false;
     for (const auto &comp : m_database.service_components) {
         if (comp.transport_mode != TransportMode::STREAM_MODE_AUDIO) continue;
-        if (comp.audio_service_type != AudioServiceType::DAB_PLUS) continue;
+        const bool is_dab_plus = comp.audio_service_type == AudioServiceType::DAB_PLUS;
+        const bool is_dab = comp.audio_service_type == AudioServiceType::DAB;
+        if (!is_dab_plus && !is_dab) continue;
         if (m_channels.count(comp.subchannel_id)) continue;
         bool rejected = false;
         for (auto id : m_rejected) rejected |= (id == comp.subchannel_id);
         if (rejected) continue;
-        const ::Subchannel *sub = nullptr;
-        for (const auto &s : m_database.subchannels)
+        ::Subchannel *sub = nullptr;
+        for (auto &s : m_database.subchannels)
             if (s.id == comp.subchannel_id) sub = &s;
         if (!sub) {                                          // FIG 0/1 for it has not arrived yet
             m_pending_components = true;
             continue;
         }
-        if (sub->is_uep || sub->eep_prot_level < 1 || sub->eep_prot_level > 4 || sub->length == 0) {
-            m_rejected.push_back(sub->id);
-            m_total_unsupported++;
-            continue;
-        }
-        // EEP: size = k * n capacity units with n = bitrate/8 (option A) or bitrate/32 (option B)
-        static const int per_unit_a[5] = {0, 12, 8, 6, 4}, per_unit_b[5] = {0, 27, 21, 18, 15};
-        const bool type_b = sub->eep_type == EEP_Type::TYPE_B;
-        const int k = (type_b ? per_unit_b : per_unit_a)[sub->eep_prot_level];
         dabgpu_subchannel sc{};
-        sc.start_address = sub->start_address;
-        sc.length = sub->length;
-        sc.protection_level = sub->eep_prot_level;
-        sc.eep_type = type_b ? 1 : 0;
-        sc.bitrate_kbps = (sub->length / k) * (type_b ? 32 : 8);
-        int idx = -1;
-        if (sub->length % k == 0 && sc.bitrate_kbps % 8 == 0) idx = add_subchannel_locked(sc);
+        bool ok = false;
+        if (sub->is_uep) {
+            // short form: bit rate, level and size come from the protection profile table
+            ok = dabgpu_uep_subchannel(sub->uep_prot_index, sub->start_address, &sc) == DABGPU_OK;
+            if (ok) sub->length = uint16_t(sc.length);
+        } else if (sub->eep_prot_level >= 1 && sub->eep_prot_level <= 4 && sub->length > 0) {
+            // EEP: size = k * n capacity units with n = bitrate/8 (option A) or bitrate/32 (option B)
+            static const int per_unit_a[5] = {0, 12, 8, 6, 4}, per_unit_b[5] = {0, 27, 21, 18, 15};
+            const bool type_b = sub->eep_type == EEP_Type::TYPE_B;
+            const int k = (type_b ? per_unit_b : per_unit_a)[sub->eep_prot_level];
+            sc.start_address = sub->start_address;
+            sc.length = sub->length;
+            sc.protection_level = sub->eep_prot_level;
+            sc.eep_type = type_b ? 1 : 0;
+            sc.bitrate_kbps = (sub->length / k) * (type_b ? 32 : 8);
+            ok = sub->length % k == 0;
+        }
+        const int idx = ok ? add_subchannel_locked(sc) : -1;
         if (idx < 0) {
             m_rejected.push_back(sub->id);
             m_total_unsupported++;
             continue;
         }
-        auto ch = std::make_unique<Basic_DAB_Plus_Channel>(m_ctx, *sub, sc.bitrate_kbps);
-        m_subchannels[size_t(idx)].channel = ch.get();
-        Basic_DAB_Plus_Channel &ref = *ch;
-        m_channels.emplace(sub->id, std::move(ch));
-        m_obs_audio_channel.Notify(sub->id, ref);
+        Basic_Audio_Channel *ref = nullptr;
+        if (is_dab_plus) {
+            auto ch = std::make_unique<Basic_DAB_Plus_Channel>(m_ctx, *sub, sc.bitrate_kbps);
+            m_subchannels[size_t(idx)].dab_plus = ch.get();
+            ref = ch.get();
+            m_channels.emplace(sub->id, std::move(ch));
+        } else {
+            auto ch = std::make_unique<Basic_DAB_Channel>(*sub, sc.bitrate_kbps);
+            m_subchannels[size_t(idx)].dab = ch.get();
+            ref = ch.get();
+            m_channels.emplace(sub->id, std::move(ch));
+        }
+        m_obs_audio_channel.Notify(sub->id, *ref);
     }
     m_seen_components = m_database.service_components.size();
 }

@@ -4,8 +4,8 @@
 //
 // Process splits a frame into FIC and MSC (row A7) and runs rows A8..A12 on the GPU through libdabgpu:
 // the FIC every frame, plus every subchannel registered with AddSubchannel().  The FIBs go through the FIG
-// parser into the database; every DAB+ audio component found there on an EEP sub-channel gets
-// its sub-channel decoded and a Basic_DAB_Plus_Channel (8f-3) without being asked (On_Audio_Channel fires once per
+// parser into the database; every audio component found there (DAB+ or DAB, EEP or UEP sub-channel)
+// gets its sub-channel decoded and a Basic_DAB_Plus_Channel (8f-3) / Basic_DAB_Channel without being asked (On_Audio_Channel fires once per
 // channel, as in the reference).  Audio decoding is outside the path: channels hand out access units.
 #pragma once
 #include <cstdint>
@@ -14,6 +14,7 @@
 #include <map>
 #include <memory>
 #include "basic_radio/basic_audio_channel.h"
+#include "basic_radio/basic_dab_channel.h"
 #include "basic_radio/basic_dab_plus_channel.h"
 #include "dab/constants/dab_parameters.h"
 #include "dab/database/dab_database.h"
@@ -37,11 +38,11 @@ public:
     // read under GetMutex(), as the GUI does (/root/reference/src/render_radio_block.cpp:124, 158-160, 239, 755)
     DAB_Database &GetDatabase() { return m_database; }
     const DAB_Database_Statistics &GetDatabaseStatistics() const { return m_updater.GetStatistics(); }
-    Basic_DAB_Plus_Channel *Get_Audio_Channel(subchannel_id_t id) {
+    Basic_Audio_Channel *Get_Audio_Channel(subchannel_id_t id) {
         auto it = m_channels.find(id);
         return it == m_channels.end() ? nullptr : it->second.get();
     }
-    // sub-channels listed in the FIC that cannot be decoded here (UEP: the protection table is not restated)
+    // sub-channels listed in the FIC that cannot be decoded here (invalid profile, does not fit the CIF)
     int GetTotalUnsupportedSubchannels() const { return m_total_unsupported; }
     void SetAutoChannels(bool v) { m_auto_channels = v; }
 
@@ -63,7 +64,8 @@ private:
         int cur = 0;
         int cifs_seen = 0;
         std::vector<uint8_t> out;
-        Basic_DAB_Plus_Channel *channel = nullptr;    // set for sub-channels opened from the database
+        Basic_DAB_Plus_Channel *dab_plus = nullptr;   // set for sub-channels opened from the database
+        Basic_DAB_Channel *dab = nullptr;
     };
     void update_channels_from_database();
     int add_subchannel_locked(const dabgpu_subchannel &sc);
@@ -79,7 +81,7 @@ private:
     DAB_Database m_database;
     DAB_Database_Updater m_updater{m_database};
     FIC_Parser m_fic_parser{m_updater};
-    std::map<subchannel_id_t, std::unique_ptr<Basic_DAB_Plus_Channel>> m_channels;
+    std::map<subchannel_id_t, std::unique_ptr<Basic_Audio_Channel>> m_channels;
     std::vector<subchannel_id_t> m_rejected;             // sub-channels we looked at and cannot open
     size_t m_seen_components = 0;
     bool m_pending_components = false;                   // a component whose sub-channel is not described yet

@@ -66,6 +66,15 @@ int main(int argc, char **argv) {
         f_msc(prefix + ".msc", std::ios::binary), f_aus(prefix + ".aus", std::ios::binary);
     // as Radio_Block::reset_radio does (/root/reference/src/radio_block.cpp:62): one hook per audio channel
     radio->On_Audio_Channel().Attach([&](subchannel_id_t id, Basic_Audio_Channel &channel) {
+        if (auto *mp2 = dynamic_cast<Basic_DAB_Channel *>(&channel)) {
+            // DAB (layer II) services: one record per MPEG frame, index/total = 0/1
+            mp2->OnMP2Frame().Attach([&f_aus, id](tcb::span<const uint8_t> fr) {
+                const uint8_t hdr[5] = {id, 0, 1, uint8_t(fr.size() & 0xFF), uint8_t(fr.size() >> 8)};
+                f_aus.write(reinterpret_cast<const char *>(hdr), 5);
+                f_aus.write(reinterpret_cast<const char *>(fr.data()), std::streamsize(fr.size()));
+            });
+            return;
+        }
         auto *dabplus = dynamic_cast<Basic_DAB_Plus_Channel *>(&channel);
         if (!dabplus) return;
         dabplus->OnAccessUnit().Attach([&f_aus, id](int index, int total, tcb::span<const uint8_t> au) {
@@ -126,7 +135,14 @@ int main(int argc, char **argv) {
                                      c.subchannel_id, int(c.transport_mode), int(c.audio_service_type), int(c.is_primary));
             }
             for (const auto &sc : subs) {
-                auto *ch = radio->Get_Audio_Channel(sc.id);
+                if (auto *mp2 = dynamic_cast<Basic_DAB_Channel *>(radio->Get_Audio_Channel(sc.id))) {
+                    const auto &ap = mp2->GetAudioParams();
+                    std::fprintf(f, "channel subchannel=%d mp2_frames=%d header_errors=%d rate=%u stereo=%d\n", sc.id,
+                                 mp2->GetTotalFrames(), mp2->GetTotalHeaderErrors(), ap ? ap->frequency : 0u,
+                                 ap ? int(ap->is_stereo) : 0);
+                    continue;
+                }
+                auto *ch = dynamic_cast<Basic_DAB_Plus_Channel *>(radio->Get_Audio_Channel(sc.id));
                 if (!ch) continue;
                 const auto &h = ch->GetSuperFrameHeader();
                 std::fprintf(f, "channel subchannel=%d superframes=%d aus=%d au_errors=%d rate=%u sbr=%d stereo=%d firecode_error=%d rs_error=%d\n",

@@ -3,7 +3,8 @@
 synthetic transmitter.  The reference holds no fixtures for this path and its DSP cannot
 be built here, so nothing in these files comes from /root/reference.
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py          # everything
+    python tests/golden/make_golden.py uep      # only uep_cases.npz (added later; leaves the other files alone)
 """
 import hashlib
 import json
@@ -20,6 +21,28 @@ from dabgpu import synth          # noqa: E402
 from oracle import oracle as O    # noqa: E402
 
 PROFILES = [(0, 3, 64), (0, 1, 8), (0, 2, 16), (0, 4, 24), (1, 2, 32), (1, 4, 64)]
+UEP_INDICES = [0, 4, 13, 15, 29]      # 32k/5, 32k/1 (4 padding bits), 56k/2 (8), 64k/4 (three runs), 112k/5
+
+
+def make_uep():
+    """Viterbi cases for UEP profiles: clean, noisy, pure noise, saturated/erased -- punctured soft bits in,
+    bytes out (no energy dispersal), as the EEP cases in viterbi_cases.npz."""
+    rng = np.random.default_rng(0x0E9)
+    out = {}
+    for idx in UEP_INDICES:
+        mask, kept, nsteps, _ = O.uep_puncture_mask(idx)
+        bits = rng.integers(0, 2, nsteps - 6, dtype=np.uint8)
+        tx = np.where(O.conv_encode(bits)[mask.astype(bool)] > 0, 100.0, -100.0)
+        cw = np.stack([
+            np.clip(tx, -127, 127),
+            np.clip(tx + rng.normal(0, 90, kept), -127, 127),
+            rng.integers(-127, 128, kept).astype(np.float64),
+            rng.choice([-127.0, 127.0, 0.0], kept),
+        ]).astype(np.int8)
+        out["uep%d_punct" % idx] = cw
+        out["uep%d_bytes" % idx] = np.stack([np.packbits(O.viterbi(O.depuncture(c, mask))) for c in cw])
+        out["uep%d_truth" % idx] = np.packbits(bits)
+    np.savez_compressed(os.path.join(HERE, "uep_cases.npz"), **out)
 
 
 def main():
@@ -67,4 +90,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["uep"]:
+        make_uep()
+    else:
+        main()
+        make_uep()

@@ -137,3 +137,40 @@ def test_unknown_multiplex_from_iq_to_access_units(built, ensemble, tmp_path):
         tail = got[scid][-(len(sent) - 6):]
         for (gi, gt, gb), (si, st, sb) in zip(tail, sent[-len(tail):]):
             assert (gi, gt) == (si, st) and gb.size == sb.size and (gb == sb).all()
+
+
+@pytest.mark.gpu
+def test_dab_layer2_service_on_uep_subchannel(built, tmp_path):
+    """A DAB (MPEG layer II) service announced with the FIG 0/1 short form: the receiver has to take bit rate,
+    protection and size from the UEP table index, open the sub-channel and hand out the layer-II frames."""
+    if not os.path.exists(os.path.join(HOST, "dab_host_demo")):
+        subprocess.check_call(["make", "-C", HOST, "-j4"], stdout=subprocess.DEVNULL)
+    ens = synth.ServiceEnsemble(3, [("Plus One", 0xC331, 2, 0, 3, 48, 0)], n_frames=5,
+                                dab_services=[("Classic", 0xC332, 11, 17, 100)])      # 64 kbit/s UEP level 2: 58 CUs
+    rng = np.random.default_rng(4)
+    cycles = 3
+    iq = synth.channel(np.tile(ens.iq().ravel(), cycles), snr_db=18.0, cfo=-0.4 / 2048, rng=rng)
+    path = tmp_path / "iq.cf32"
+    np.concatenate([iq[-30000:], iq, iq[:synth.NB_NULL + 5000]]).astype(np.complex64).tofile(path)
+    prefix = str(tmp_path / "out")
+    r = subprocess.run([os.path.join(HOST, "dab_host_demo"), str(path), prefix, "65536"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "frames_desync=0" in r.stdout, r.stdout + r.stderr
+    db = open(prefix + ".db").read().splitlines()
+    assert "subchannel id=11 start=100 length=58 uep=1 uep_index=17 eep_type=0 eep_level=0" in db   # size from the table
+    assert "service id=C332 label=[Classic]" in db
+    assert "component service=C332 subchannel=11 tmid=0 ascty=0 primary=1" in db
+    mp2 = [l for l in db if l.startswith("channel subchannel=11")]
+    assert len(mp2) == 1 and "header_errors=0" in mp2[0] and "rate=48000 stereo=1" in mp2[0]
+    raw = np.fromfile(prefix + ".aus", np.uint8)
+    frames, i = [], 0
+    while i < raw.size:
+        scid, n = int(raw[i]), int(raw[i + 3]) | (int(raw[i + 4]) << 8)
+        if scid == 11:
+            frames.append(raw[i + 5:i + 5 + n])
+        i += 5 + n
+    n_lf = 4 * 5 * cycles - 15
+    assert n_lf - 8 <= len(frames) <= n_lf
+    sent = [ens.mp2_frames[0][k % 20] for k in range(n_lf)]
+    for got, want in zip(frames[::-1], sent[::-1]):                 # compare from the end: the start may be lost to lock-in
+        assert got.size == 192 and (got == want).all()

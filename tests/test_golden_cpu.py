@@ -7,7 +7,7 @@ import numpy as np
 from conftest import golden_path
 from dabgpu import synth
 from oracle import oracle as O
-from golden.make_golden import PROFILES
+from golden.make_golden import PROFILES, UEP_INDICES
 
 
 def test_fic_cases():
@@ -27,6 +27,15 @@ def test_viterbi_cases():
         key = "eep%d_%d_%d" % (opt, lvl, br)
         for c, want in zip(d[key + "_punct"], d[key + "_bytes"]):
             assert (np.packbits(O.viterbi(O.depuncture(c, mask))) == want).all()
+
+
+def test_uep_cases():
+    d = np.load(golden_path("uep_cases.npz"))
+    for idx in UEP_INDICES:
+        mask = O.uep_puncture_mask(idx)[0]
+        for c, want in zip(d["uep%d_punct" % idx], d["uep%d_bytes" % idx]):
+            assert (np.packbits(O.viterbi(O.depuncture(c, mask))) == want).all()
+        assert (d["uep%d_bytes" % idx][0] == d["uep%d_truth" % idx]).all()      # the clean codeword decodes to what was sent
 
 
 def test_frame_hashes():

@@ -205,9 +205,13 @@ def test_whole_ensemble_multi_subchannel(ctx):
 
 def test_msc_rejects_bad_profiles(ctx):
     soft = np.zeros((1, 230400), np.int8)
-    with pytest.raises(dabgpu.DabGpuError) as e:
-        ctx.msc_decode(dabgpu.Subchannel(0, 48, 1, 0, 3, 64), soft, 1)       # UEP not built yet
-    assert e.value.status == -5
+    for bad in (dabgpu.Subchannel(0, 48, 1, 0, 3, 40),        # UEP: 40 kbit/s is not in the protection profile table
+                dabgpu.Subchannel(0, 47, 1, 0, 3, 64),        # UEP: wrong size for 64 kbit/s level 3
+                dabgpu.Subchannel(0, 48, 0, 0, 5, 64),        # EEP has no level 5
+                dabgpu.Subchannel(0, 48, 0, 2, 3, 64)):       # EEP option 2 is reserved
+        with pytest.raises(dabgpu.DabGpuError) as e:
+            ctx.msc_decode(bad, soft, 1)
+        assert e.value.status == -5
 
 
 def test_full_size_batch_properties(ctx):
