@@ -98,6 +98,26 @@ def test_host_parser_fuzz(parser_exe, tmp_path):
     assert got == FO.parse_fibs(fibs).lines()
 
 
+def test_host_parser_under_sanitizers(tmp_path):
+    """The same fuzz input through an AddressSanitizer + UBSan build of the parser (CPU build only: the pool has no
+    GPU sanitizers)."""
+    exe = str(tmp_path / "test_fig_parser_asan")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-I" + HOST, "-I" + os.path.join(ROOT, "include"), os.path.join(HOST, "tests", "test_fig_parser.cpp"),
+                           os.path.join(HOST, "dab", "fic", "fic_parser.cpp"), "-o", exe])
+    rng = np.random.default_rng(7)
+    fibs = synth.make_fibs(rng, 6000)
+    fibs[:4500, 0] = rng.choice(np.array([0x05, 0x0D, 0x1D, 0x35, 0x15, 0x3F, 0x03, 0x1F, 0x3E, 0x01, 0x21, 0x02], np.uint8), 4500)
+    fibs[:4500, 1] &= 0x27
+    for f in fibs:
+        c = synth.crc16(f[:30])
+        f[30], f[31] = c >> 8, c & 0xFF
+    path = tmp_path / "fuzz.bin"
+    fibs.tofile(path)
+    r = subprocess.run([exe, str(path)], capture_output=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:].decode("latin-1")
+
+
 @pytest.mark.gpu
 def test_unknown_multiplex_from_iq_to_access_units(built, ensemble, tmp_path):
     if not os.path.exists(os.path.join(HOST, "dab_host_demo")):
