@@ -27,6 +27,8 @@ struct DeviceCode {
     uint16_t *d_mother_pos = nullptr;
     uint8_t *d_prbs = nullptr;
     int32_t *d_punct_idx = nullptr;      // [4*nsteps] punctured index of each mother bit, -1 = erased (lane kernels)
+    int32_t *d_fused_desc = nullptr, *d_fused_tiles = nullptr;   // fused lane forward pass (build_lane_fused_tables)
+    dabk::LaneTables lane_tables() const { return dabk::LaneTables{d_punct_idx, d_fused_desc, d_fused_tiles}; }
     dabk::CodeTables tables(bool descramble) const {
         return dabk::CodeTables{d_mother_pos, prof.n_punct, prof.nsteps, descramble ? d_prbs : nullptr};
     }
@@ -94,6 +96,12 @@ int build_device_code(DeviceCode &dc) {
     for (size_t i = 0, j = 0; i < dc.prof.mask.size(); i++)
         if (dc.prof.mask[i]) pidx[i] = int32_t(j++);
     if ((rc = upload(&dc.d_punct_idx, pidx))) return rc;
+    {
+        std::vector<int32_t> desc, tiles;
+        dabk::build_lane_fused_tables(dc.prof.mask.data(), dc.prof.nsteps, desc, tiles);
+        if ((rc = upload(&dc.d_fused_desc, desc))) return rc;
+        if ((rc = upload(&dc.d_fused_tiles, tiles))) return rc;
+    }
     return upload(&dc.d_prbs, dab::make_prbs_bytes((dc.prof.nsteps - 6 + 7) / 8));
 }
 
@@ -101,6 +109,9 @@ void free_device_code(DeviceCode &dc) {
     if (dc.d_mother_pos) (void)hipFree(dc.d_mother_pos);
     if (dc.d_prbs) (void)hipFree(dc.d_prbs);
     if (dc.d_punct_idx) (void)hipFree(dc.d_punct_idx);
+    if (dc.d_fused_desc) (void)hipFree(dc.d_fused_desc);
+    if (dc.d_fused_tiles) (void)hipFree(dc.d_fused_tiles);
+    dc.d_fused_desc = dc.d_fused_tiles = nullptr;
     dc.d_punct_idx = nullptr;
     dc.d_mother_pos = nullptr;
     dc.d_prbs = nullptr;
@@ -679,7 +690,7 @@ int dabgpu_fic_decode_dev(dabgpu_ctx *ctx, const int8_t *d_soft, size_t soft_str
     dabk::LaneScratch lsc{};
     int lrc;
     if (use_lane(ctx, ctx->fic.prof.nsteps, n_frames * NB_FIC_GROUPS, s, &lsc, &lrc)) {
-        HIP_TRY(dabk::launch_fic_decode_lane(ctx->fic.tables(true), ctx->fic.d_punct_idx, d_soft, soft_stride, n_frames,
+        HIP_TRY(dabk::launch_fic_decode_lane(ctx->fic.tables(true), ctx->fic.lane_tables(), d_soft, soft_stride, n_frames,
                                              lsc, d_fib, d_crc_ok, s));
         return DABGPU_OK;
     }
@@ -791,7 +802,7 @@ int dabgpu_msc_decode_dev(dabgpu_ctx *ctx, const dabgpu_subchannel *sc, const in
     dabk::LaneScratch lsc{};
     int lrc;
     if (use_lane(ctx, dc->prof.nsteps, n_streams * frames_per_stream * NB_CIFS, s, &lsc, &lrc)) {
-        HIP_TRY(dabk::launch_msc_decode_lane(dc->tables(true), dc->d_punct_idx, a, lsc, s));
+        HIP_TRY(dabk::launch_msc_decode_lane(dc->tables(true), dc->lane_tables(), a, lsc, s));
         HIP_TRY(dabk::launch_msc_history(a, s));
         return DABGPU_OK;
     }
@@ -916,7 +927,7 @@ int dabgpu_viterbi_dev(dabgpu_ctx *ctx, const int8_t *d_punct, int n_codewords, 
     dabk::LaneScratch lsc{};
     int lrc;
     if (use_lane(ctx, dc->prof.nsteps, n_codewords, s, &lsc, &lrc)) {
-        HIP_TRY(dabk::launch_viterbi_plain_lane(dc->tables(false), dc->d_punct_idx, d_punct, n_codewords, lsc,
+        HIP_TRY(dabk::launch_viterbi_plain_lane(dc->tables(false), dc->lane_tables(), d_punct, n_codewords, lsc,
                                                 d_out_bytes, s));
         return DABGPU_OK;
     }

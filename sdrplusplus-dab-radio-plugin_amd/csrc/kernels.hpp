@@ -1,6 +1,8 @@
 // kernels.hpp -- launch interfaces of the hand-written gfx950 kernels (internal to libdabgpu).
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <vector>
 #include <cstddef>
 #include <cstdint>
 
@@ -130,11 +132,19 @@ struct LaneScratch {
 };
 size_t lane_scratch_bytes(int nsteps, int n_codewords);
 bool lane_supported(int nsteps);
-hipError_t launch_fic_decode_lane(const CodeTables &c, const int32_t *punct_idx, const int8_t *soft, size_t soft_stride,
+// per-profile tables of the lane kernels: punct_idx [4*nsteps] (punctured index of each mother bit, -1 = erased);
+// fused_desc [4*nsteps] and fused_tiles [2*ceil(nsteps/24)] from build_lane_fused_tables (may be null: prep path)
+struct LaneTables {
+    const int32_t *punct_idx;
+    const int32_t *fused_desc;
+    const int32_t *fused_tiles;
+};
+void build_lane_fused_tables(const uint8_t *mask, int nsteps, std::vector<int32_t> &desc, std::vector<int32_t> &tiles);
+hipError_t launch_fic_decode_lane(const CodeTables &c, const LaneTables &lt, const int8_t *soft, size_t soft_stride,
                                   int n_frames, const LaneScratch &sc, uint8_t *fib, uint8_t *crc_ok, hipStream_t s);
-hipError_t launch_viterbi_plain_lane(const CodeTables &c, const int32_t *punct_idx, const int8_t *punct,
+hipError_t launch_viterbi_plain_lane(const CodeTables &c, const LaneTables &lt, const int8_t *punct,
                                      int n_codewords, const LaneScratch &sc, uint8_t *out, hipStream_t s);
-hipError_t launch_msc_decode_lane(const CodeTables &c, const int32_t *punct_idx, const MscArgs &a, const LaneScratch &sc,
+hipError_t launch_msc_decode_lane(const CodeTables &c, const LaneTables &lt, const MscArgs &a, const LaneScratch &sc,
                                   hipStream_t s);
 // Dynamic-LDS request (>= lds) that makes every CU hold the same number of workgroups of a `grid`-workgroup
 // launch when at most `o_cap` fit per CU otherwise (the dispatcher fills CUs greedily).

@@ -22,6 +22,8 @@
 // in place by packed add/sub/max on both halves at once; for q = 0 it is the two halves of one register (one
 // half-swap).  Nothing ever moves.
 #include <algorithm>
+#include <cstdlib>
+#include <vector>
 
 #include "kernels.hpp"
 #include "dab_tables.hpp"
@@ -309,6 +311,133 @@ __global__ __launch_bounds__(256) void lane_forward_kernel(const uint32_t *Msoft
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// K2': forward pass that depunctures for itself ("fused" variant: no lane_prep_kernel, no M[] round trip).
+// Each wave stages the punctured bytes its 64 codewords need for the next FT steps -- rows = the codewords
+// themselves plus, for the time de-interleaver, the 15 CIFs before the first one (history rows at a stream start)
+// -- in a wave-private LDS window with 16-byte loads issued one tile ahead, and every lane picks its 4 soft bytes
+// per step from the window: row = lane + delay, column = punctured index - tile start, both from a per-profile
+// descriptor table that the scalar unit walks.  Requires that a group of 64 codewords never straddles two streams
+// (CIFs per stream a multiple of 64); other shapes take the prep kernel.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int FT = 24;                          // steps per tile (four phase cycles)
+constexpr int FCOLS = 8;                        // 16-byte chunks per staged row (span <= 15 + 4*FT = 111 bytes)
+constexpr int FPITCH = FCOLS * 16 + 4;          // 132 B = 33 dwords (odd); bytes 128..131 stay zero (erased bits)
+constexpr int FERASED = FCOLS * 16;             // column of the always-zero byte
+
+// row r (0 .. 63+PRE) of the window of the group whose first codeword is cw0 -> first punctured byte, or nullptr
+// for a row that does not exist (reads as erasures)
+__device__ __forceinline__ const int8_t *fused_row(const LSrcFic &s, int cw0, int r, int n_codewords) {
+    const int g = cw0 + r;
+    return g < n_codewords ? s.row(g) : nullptr;
+}
+__device__ __forceinline__ const int8_t *fused_row(const LSrcPlain &s, int cw0, int r, int n_codewords) {
+    const int g = cw0 + r;
+    return g < n_codewords ? s.row(g) : nullptr;
+}
+__device__ __forceinline__ const int8_t *fused_row(const LSrcMsc &s, int cw0, int r, int n_codewords) {
+    const int stream = cw0 / s.cifs_per_stream;
+    const int v = cw0 - stream * s.cifs_per_stream - 15 + r;          // CIF of this stream, < 0 = carried history
+    if (v < 0) return s.hist ? s.hist + (size_t(stream) * 15 + (15 + v)) * s.nbits : nullptr;
+    const int g = stream * s.cifs_per_stream + v;
+    return g < n_codewords ? s.row(g) : nullptr;
+}
+
+template <class Src>
+__global__ __launch_bounds__(256) void lane_forward_fused_kernel(Src src, const int32_t *desc, const int32_t *tiles,
+                                                                 int nsteps, int groups, int n_codewords, uint2 *dec) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t fused_lds[];
+    constexpr int ROWS = 64 + Src::PRE;
+    constexpr int NK = (ROWS * FCOLS + 63) / 64;
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int group = blockIdx.x * 4 + wv;
+    if (group >= groups) return;
+    uint8_t *win = fused_lds + wv * (ROWS * FPITCH);
+    const int cw0 = group * 64;
+    uint2 *dst = dec + size_t(group) * nsteps * 64 + lane;
+    // this lane's staging duties: chunk (row, col) = (i >> 3, i & 7), i = lane + 64 k
+    const int8_t *rowp[NK];
+#pragma unroll
+    for (int k = 0; k < NK; k++) {
+        const int row = (lane + 64 * k) >> 3;
+        rowp[k] = row < ROWS ? fused_row(src, cw0, row, n_codewords) : nullptr;
+    }
+    // rows that do not exist read as erasures for the whole codeword: zero them once, never stage them
+    for (int i = lane; i < ROWS * (FPITCH / 4); i += 64) reinterpret_cast<uint32_t *>(win)[i] = 0u;
+    const int r_eff = min(lane, n_codewords - 1 - cw0);       // lanes past the end repeat the last codeword
+    const uint8_t *my = win + r_eff * FPITCH;
+
+    uint4 R[NK];
+    auto fetch = [&](int tile) {
+        const int lo_al = tiles[2 * tile], nch = tiles[2 * tile + 1];
+#pragma unroll
+        for (int k = 0; k < NK; k++) {
+            const int c = (lane + 64 * k) & 7;
+            if (rowp[k] && c < nch) R[k] = *reinterpret_cast<const uint4 *>(rowp[k] + lo_al + 16 * c);
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int k = 0; k < NK; k++) {
+            const int i = lane + 64 * k;
+            if (rowp[k]) {                                     // (columns past the tile's span hold stale bytes nobody reads)
+                uint32_t *d = reinterpret_cast<uint32_t *>(win + (i >> 3) * FPITCH + 16 * (i & 7));
+                d[0] = R[k].x; d[1] = R[k].y; d[2] = R[k].z; d[3] = R[k].w;
+            }
+        }
+    };
+    unsigned M[32];
+#pragma unroll
+    for (int r = 0; r < 32; r++) M[r] = pack16(-LANE_INIT2, -LANE_INIT2);
+    M[0] = pack16(0, -LANE_INIT2);
+    fetch(0);
+    stash();
+    // Descriptors of the next six steps are fetched while the current six are worked on: with one wave per SIMD
+    // nothing else would hide their latency.  They are deliberately NOT restrict-qualified: as scalar loads they
+    // share the LDS counter (lgkmcnt) and every wait for them also drains the window reads (measured slower).
+    int32_t dcur[24], dnxt[24];
+#pragma unroll
+    for (int j = 0; j < 24; j++) dcur[j] = desc[j];
+    int tile = 0;
+    for (int t0 = 0; t0 < nsteps; t0 += FT, tile++) {
+        const bool more = t0 + FT < nsteps;
+        if (more) fetch(tile + 1);
+        const int t_end = min(t0 + FT, nsteps);
+        for (int t = t0; t < t_end; t += 6) {
+            const int32_t *dp = desc + 4 * min(t + 6, nsteps - 6);
+#pragma unroll
+            for (int j = 0; j < 24; j++) dnxt[j] = dp[j];
+            uint32_t w[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                uint32_t v = 0;
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    const int dsc = dcur[4 * i + m];                            // wave-uniform: column | delay << 8
+                    const int off = (Src::PRE ? (dsc >> 8) * FPITCH : 0) + (dsc & 0xFF);
+                    v |= uint32_t(my[off]) << (8 * m);
+                }
+                w[i] = v;
+            }
+#pragma unroll
+            for (int j = 0; j < 24; j++) dcur[j] = dnxt[j];
+            lane_step<0>(M, w[0], dst + size_t(t + 0) * 64);
+            lane_step<1>(M, w[1], dst + size_t(t + 1) * 64);
+            lane_step<2>(M, w[2], dst + size_t(t + 2) * 64);
+            lane_step<3>(M, w[3], dst + size_t(t + 3) * 64);
+            lane_step<4>(M, w[4], dst + size_t(t + 4) * 64);
+            lane_step<5>(M, w[5], dst + size_t(t + 5) * 64);
+            if (((t / 6) & 1) == 1) {                          // every 12 steps (two phase cycles)
+                const unsigned ref = pack16(int(M[0]), int(M[0])) & 0xFFFEFFFEu;
+#pragma unroll
+                for (int r = 0; r < 32; r++) M[r] = pk_sub(M[r], ref);
+            }
+        }
+        if (more) stash();                                     // the wave's own LDS reads above are already issued
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // K3: traceback + output.  One wave per group, one lane per codeword, from slot 0 (end state 0 sits in slot 0
 // in every layout).  The survivor tag of slot p sits where take_tags() put it, set when the older-bit-0
 // predecessor survived; the bit the step replaces in the slot index is the decoded input bit.
@@ -402,7 +531,7 @@ __global__ __launch_bounds__(64) void lane_traceback_kernel(const uint2 *dec, in
 }
 
 template <class Src>
-hipError_t run_lane(Src f, bool vec16, const CodeTables &c, const int32_t *punct_idx, int n_codewords,
+hipError_t run_lane(Src f, bool vec16, bool fusable, const CodeTables &c, const LaneTables &lt, int n_codewords,
                     const LaneScratch &sc, uint8_t *out, uint8_t *crc_ok, hipStream_t s) {
     const int groups = (n_codewords + 63) / 64;
     const int nwords = (c.nsteps - 6) >> 5;
@@ -410,16 +539,28 @@ hipError_t run_lane(Src f, bool vec16, const CodeTables &c, const int32_t *punct
     if (!sc.base || sc.bytes < need || (reinterpret_cast<uintptr_t>(out) & 3)) return hipErrorInvalidValue;
     uint32_t *M = reinterpret_cast<uint32_t *>(sc.base);
     uint2 *dec = reinterpret_cast<uint2 *>(M + size_t(groups) * c.nsteps * 64);
-    hipLaunchKernelGGL((lane_prep_kernel<Src>), dim3(unsigned((c.nsteps + PREP_STEPS - 1) / PREP_STEPS), unsigned(groups)),
-                       dim3(256), 0, s, f, punct_idx, c.nsteps, n_codewords, int(vec16), M);
     const unsigned fgrid = unsigned((groups + 3) / 4);
-    const size_t fwd_lds = balanced_lds_bytes(fgrid, 0, 8);
-    if (fwd_lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lane_forward_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, int(fwd_lds));
-        if (e != hipSuccess) return e;
+    static const bool no_fuse = std::getenv("DABGPU_LANE_NOFUSE") != nullptr;
+    if (fusable && vec16 && lt.fused_desc && lt.fused_tiles && !no_fuse) {
+        const size_t lds = balanced_lds_bytes(fgrid, size_t(4) * (64 + Src::PRE) * FPITCH, 3);
+        const void *kern = reinterpret_cast<const void *>(lane_forward_fused_kernel<Src>);
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL((lane_forward_fused_kernel<Src>), dim3(fgrid), dim3(256), lds, s, f, lt.fused_desc, lt.fused_tiles,
+                           c.nsteps, groups, n_codewords, dec);
+    } else {
+        hipLaunchKernelGGL((lane_prep_kernel<Src>), dim3(unsigned((c.nsteps + PREP_STEPS - 1) / PREP_STEPS), unsigned(groups)),
+                           dim3(256), 0, s, f, lt.punct_idx, c.nsteps, n_codewords, int(vec16), M);
+        const size_t fwd_lds = balanced_lds_bytes(fgrid, 0, 8);
+        if (fwd_lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lane_forward_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, int(fwd_lds));
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(lane_forward_kernel, dim3(fgrid), dim3(256), fwd_lds, s, M, c.nsteps, groups, dec);
     }
-    hipLaunchKernelGGL(lane_forward_kernel, dim3(fgrid), dim3(256), fwd_lds, s, M, c.nsteps, groups, dec);
     const size_t tb_lds = size_t(64) * (nwords | 1) * 4;
     if (tb_lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lane_traceback_kernel),
@@ -447,23 +588,50 @@ bool lane_supported(int nsteps) {
     return nsteps >= 38 && nsteps % 6 == 0 && ((nsteps - 6) & 31) == 0 && size_t(64) * (((nsteps - 6) >> 5) | 1) * 4 <= 150 * 1024;
 }
 
-hipError_t launch_fic_decode_lane(const CodeTables &c, const int32_t *punct_idx, const int8_t *soft, size_t soft_stride,
+hipError_t launch_fic_decode_lane(const CodeTables &c, const LaneTables &lt, const int8_t *soft, size_t soft_stride,
                                   int n_frames, const LaneScratch &sc, uint8_t *fib, uint8_t *crc_ok, hipStream_t s) {
-    return run_lane(LSrcFic{soft, soft_stride}, aligned16(soft, soft_stride), c, punct_idx, n_frames * NB_FIC_GROUPS, sc,
+    return run_lane(LSrcFic{soft, soft_stride}, aligned16(soft, soft_stride), true, c, lt, n_frames * NB_FIC_GROUPS, sc,
                     fib, crc_ok, s);
 }
 
-hipError_t launch_viterbi_plain_lane(const CodeTables &c, const int32_t *punct_idx, const int8_t *punct,
+hipError_t launch_viterbi_plain_lane(const CodeTables &c, const LaneTables &lt, const int8_t *punct,
                                      int n_codewords, const LaneScratch &sc, uint8_t *out, hipStream_t s) {
-    return run_lane(LSrcPlain{punct, c.n_punct}, aligned16(punct, size_t(c.n_punct)), c, punct_idx, n_codewords, sc, out,
+    return run_lane(LSrcPlain{punct, c.n_punct}, aligned16(punct, size_t(c.n_punct)), true, c, lt, n_codewords, sc, out,
                     nullptr, s);
 }
 
-hipError_t launch_msc_decode_lane(const CodeTables &c, const int32_t *punct_idx, const MscArgs &a, const LaneScratch &sc,
+hipError_t launch_msc_decode_lane(const CodeTables &c, const LaneTables &lt, const MscArgs &a, const LaneScratch &sc,
                                   hipStream_t s) {
     LSrcMsc f{a.soft, a.soft_stride, a.hist_in, a.frames_per_stream * NB_CIFS, a.start_bit, a.nbits};
-    return run_lane(f, aligned16(a.soft, a.soft_stride) && (a.start_bit & 15) == 0, c, punct_idx,
+    // the fused forward pass wants whole groups inside one stream and 16-byte aligned history rows
+    const bool fusable = (a.frames_per_stream * NB_CIFS) % 64 == 0 &&
+                         (!a.hist_in || ((reinterpret_cast<uintptr_t>(a.hist_in) | size_t(a.nbits)) & 15) == 0);
+    return run_lane(f, aligned16(a.soft, a.soft_stride) && (a.start_bit & 15) == 0, fusable, c, lt,
                     a.n_streams * a.frames_per_stream * NB_CIFS, sc, a.out, nullptr, s);
+}
+
+void build_lane_fused_tables(const uint8_t *mask, int nsteps, std::vector<int32_t> &desc, std::vector<int32_t> &tiles) {
+    std::vector<int> idx(size_t(4) * nsteps, -1);
+    for (int p = 0, j = 0; p < 4 * nsteps; p++)
+        if (mask[p]) idx[p] = j++;
+    const int ntiles = (nsteps + FT - 1) / FT;
+    desc.assign(size_t(4) * nsteps, FERASED);
+    tiles.assign(size_t(2) * ntiles, 0);
+    for (int tile = 0; tile < ntiles; tile++) {
+        const int p0 = 4 * FT * tile, p1 = std::min(4 * nsteps, p0 + 4 * FT);
+        int lo = -1, hi = 0;
+        for (int p = p0; p < p1; p++)
+            if (idx[p] >= 0) { if (lo < 0) lo = idx[p]; hi = idx[p] + 1; }
+        if (lo < 0) continue;                                   // a tile of erasures only
+        const int lo_al = lo & ~15;
+        tiles[2 * tile] = lo_al;
+        tiles[2 * tile + 1] = (hi - lo_al + 15) / 16;           // <= FCOLS by construction
+        for (int p = p0; p < p1; p++) {
+            if (idx[p] < 0) continue;
+            unsigned i = unsigned(idx[p]) & 15u, d = ((i & 1) << 3) | ((i & 2) << 1) | ((i & 4) >> 1) | ((i & 8) >> 3);
+            desc[p] = (idx[p] - lo_al) | int(d << 8);
+        }
+    }
 }
 
 }  // namespace dabk

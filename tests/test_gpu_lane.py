@@ -72,3 +72,39 @@ def test_switch_over_msc_with_history_and_ragged_streams():
     last = view[(n_streams - 1) * fps:].cpu().numpy().reshape(fps * 4, nbits)
     want = O.msc_decode_lf(O.time_deinterleave(last[-16:]), mask, 32 * 24 + 6)
     assert (res[1][0][-1, -1] == want).all()
+
+
+@pytest.mark.parametrize("fps,with_hist", [(16, True), (32, False), (48, True)])
+def test_fused_forward_msc_whole_groups(fps, with_hist):
+    """Streams whose CIF count is a multiple of 64 take the forward pass that depunctures for itself (history rows
+    staged like any other row); same bytes as the wave-per-codeword kernels and as the oracle."""
+    n_streams = 3
+    sc = dabgpu.subchannel(20, 48, level=2)                  # 48 kbit/s EEP 2-A
+    nbits = sc.length * 64
+    n = n_streams * fps
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev); g.manual_seed(fps)
+    stride = dabgpu.NB_FRAME_BITS
+    soft = torch.zeros((n, stride), dtype=torch.int8, device=dev)
+    view = soft[:, dabgpu.NB_FIC_BITS:].view(n, 4, 55296)[:, :, 20 * 64:20 * 64 + nbits]
+    view.copy_(torch.randint(-127, 128, (n, 4, nbits), dtype=torch.int8, device=dev, generator=g))
+    hist = torch.randint(-127, 128, (n_streams, 15, nbits), dtype=torch.int8, device=dev, generator=g)
+    res = []
+    for mode in (0, 1):
+        c = make_ctx(mode, max_frames=8)
+        out = torch.zeros((n_streams, fps * 4, 48 * 3), dtype=torch.uint8, device=dev)
+        hout = torch.zeros_like(hist)
+        c.msc_decode_dev(sc, soft.data_ptr(), stride, n_streams, fps, hist.data_ptr() if with_hist else None,
+                         hout.data_ptr(), out.data_ptr(), None)
+        c.sync()
+        res.append((out.cpu().numpy(), hout.cpu().numpy()))
+        c.close()
+    assert (res[0][0] == res[1][0]).all() and (res[0][1] == res[1][1]).all()
+    mask = O.eep_puncture_mask(0, 2, 48)[0]
+    for s in (0, n_streams - 1):
+        cifs = view[s * fps:(s + 1) * fps].cpu().numpy().reshape(fps * 4, nbits)
+        h = hist[s].cpu().numpy() if with_hist else np.zeros((15, nbits), np.int8)
+        padded = np.concatenate([h, cifs])
+        for t in (0, 7, 15, 63, fps * 4 - 1):
+            want = O.msc_decode_lf(O.time_deinterleave(padded[t:t + 16]), mask, 48 * 24 + 6)
+            assert (res[1][0][s, t] == want).all(), (s, t)
