@@ -72,6 +72,40 @@ def copy_ceiling(torch, dev):
     return 2.0 * n * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
+def fftw_fft_stage(iq_host, seconds=3.0):
+    """if the box happens to have FFTW3f (the reference's FFT library,
+    /root/reference/CMakeLists.txt:55-64), time its 2048-point c2c transform on the FFT stage's work (76 per frame,
+    one thread, FFTW_MEASURE).  Returns frames/s or None when the library is not installed."""
+    import ctypes as C
+    try:
+        fw = C.CDLL("libfftw3f.so.3")
+    except OSError:
+        return None
+    fw.fftwf_malloc.restype = C.c_void_p
+    fw.fftwf_malloc.argtypes = [C.c_size_t]
+    fw.fftwf_plan_many_dft.restype = C.c_void_p
+    fw.fftwf_plan_many_dft.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int,
+                                       C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_uint]
+    fw.fftwf_execute.argtypes = [C.c_void_p]
+    fw.fftwf_destroy_plan.argtypes = [C.c_void_p]
+    fw.fftwf_free.argtypes = [C.c_void_p]
+    n, howmany = C.c_int(2048), 76
+    nbytes = howmany * 2552 * 8
+    a, b = fw.fftwf_malloc(nbytes), fw.fftwf_malloc(howmany * 2048 * 8)
+    C.memmove(a, iq_host[0].ctypes.data, nbytes)
+    # symbol l: input at l*2552 + 504, output at l*2048
+    plan = fw.fftwf_plan_many_dft(1, C.byref(n), howmany, C.c_void_p(a + 504 * 8), None, 1, 2552, C.c_void_p(b), None, 1, 2048,
+                                  -1, 0)      # FFTW_FORWARD, FFTW_MEASURE
+    C.memmove(a, iq_host[0].ctypes.data, nbytes)
+    t0, k = time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds:
+        fw.fftwf_execute(plan)
+        k += 1
+    el = time.perf_counter() - t0
+    fw.fftwf_destroy_plan(plan); fw.fftwf_free(a); fw.fftwf_free(b)
+    return k / el
+
+
 def cpu_baseline(iq_host, fo_host, sc_len_bits, mask, nsteps, budget_s, threads):
     """Time the CPU oracle ('port', oracle/dab_oracle.c driven by oracle/oracle_bench.c) on the same workload:
     OFDM demod + FIC + 4 MSC logical frames per transmission frame.  Bounded sample; one pthread per host core,
@@ -80,7 +114,9 @@ def cpu_baseline(iq_host, fo_host, sc_len_bits, mask, nsteps, budget_s, threads)
     n = iq_host.shape[0]
     k1, t1 = O.bench_frames_timed(iq_host, fo_host, min(4.0, budget_s * 0.3), 1, mask, nsteps, sc_len_bits)
     total, tn = O.bench_frames_timed(iq_host, fo_host, budget_s * 0.7, threads, mask, nsteps, sc_len_bits)
-    return {"value": total / tn, "unit": "frames/s", "cores": threads, "kind": "port",
+    fftw = fftw_fft_stage(iq_host)
+    return {"fftw3f_fft_stage_frames_per_s_1_thread": fftw if fftw is not None else "FFTW3f: not available on this box",
+            "value": total / tn, "unit": "frames/s", "cores": threads, "kind": "port",
             "sample": "%d frames (OFDM+FIC+64kbps EEP-3A MSC, %d distinct bench-input frames cycled) through "
                       "oracle/dab_oracle.c on %d pthreads in %.1f s" % (total, n, threads, tn),
             "single_core_value": k1 / t1}
