@@ -111,6 +111,13 @@ int  dabgpu_sync(dabgpu_ctx *ctx);
 /* the context's own hipStream_t (as void*) */
 void *dabgpu_stream(dabgpu_ctx *ctx);
 
+/* Page-locked host memory for the host-pointer entry points: buffers obtained here are copied to and from the
+ * device by DMA at the full link rate, pageable ones go through the runtime's bounce buffers (measured on the
+ * pool's PCIe Gen5 link: see DESIGN.md section 5).  Any host pointer is accepted everywhere; this is an
+ * optimisation for callers that own their buffers, e.g. the host mirror's frame and soft-bit buffers. */
+void *dabgpu_host_alloc(size_t bytes);
+void dabgpu_host_free(void *p);
+
 /* ------------------------------------------------------------------------ */
 /* A2..A6: OFDM front end on time-aligned frames.                             */
 /* Replaces the READING_SYMBOLS work of OFDM_Demod::Process                    */

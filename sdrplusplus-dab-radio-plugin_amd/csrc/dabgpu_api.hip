@@ -370,6 +370,16 @@ void dabgpu_destroy(dabgpu_ctx *ctx) {
     delete ctx;
 }
 
+void *dabgpu_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+void dabgpu_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+
 int dabgpu_sync(dabgpu_ctx *ctx) {
     if (!ctx) return DABGPU_ERR_ARG;
     HIP_TRY(hipStreamSynchronize(ctx->stream));

@@ -35,6 +35,7 @@ EXPORTS = [
     "dabgpu_msc_decode_multi_dev", "dabgpu_dabplus_superframes_dev", "dabgpu_dabplus_superframes",
     "dabgpu_acquire_default_cfg", "dabgpu_acquire_dev", "dabgpu_acquire", "dabgpu_ofdm_demod_acquired_dev",
     "dabgpu_ofdm_set_soft_selection", "dabgpu_soft_selection", "dabgpu_uep_subchannel",
+    "dabgpu_host_alloc", "dabgpu_host_free",
 ]
 
 
@@ -147,6 +148,10 @@ def lib():
         L.dabgpu_ofdm_set_soft_selection.argtypes = [vp, vp, i]
         L.dabgpu_soft_selection.argtypes = [vp, i, i, vp, i]
         L.dabgpu_uep_subchannel.argtypes = [i, i, C.POINTER(Subchannel)]
+        L.dabgpu_host_alloc.restype = C.c_void_p
+        L.dabgpu_host_alloc.argtypes = [sz]
+        L.dabgpu_host_free.restype = None
+        L.dabgpu_host_free.argtypes = [C.c_void_p]
         L.dabgpu_acquire_default_cfg.restype = None
         L.dabgpu_acquire_default_cfg.argtypes = [C.POINTER(AcquireCfg)]
         L.dabgpu_acquire_dev.argtypes = [vp, vp, sz, i, C.c_int64, C.POINTER(AcquireCfg), i, vp, vp, vp]
@@ -206,6 +211,30 @@ def subchannel(start_address, bitrate_kbps, level=3, eep_type=0):
         n = bitrate_kbps // 32
         length = {1: 27 * n, 2: 21 * n, 3: 18 * n, 4: 15 * n}[level]
     return Subchannel(start_address, length, 0, eep_type, level, bitrate_kbps)
+
+
+class PinnedArray:
+    """numpy view of page-locked host memory from dabgpu_host_alloc (freed by close() / garbage collection)."""
+
+    def __init__(self, shape, dtype):
+        self._n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self._p = lib().dabgpu_host_alloc(self._n)
+        if not self._p:
+            raise MemoryError("dabgpu_host_alloc(%d)" % self._n)
+        buf = (C.c_char * self._n).from_address(self._p)
+        self.array = np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    def close(self):
+        if self._p:
+            self.array = None
+            lib().dabgpu_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def uep_subchannel(table_index, start_address):
