@@ -16,6 +16,10 @@
  *     without `_dev` take HOST pointers, copy, run and synchronise.
  *   - the caller owns every buffer; a context is thread-compatible (one caller
  *     at a time per context), contexts are independent.
+ *   - work enqueued through ONE context must be stream-ordered: the decoder entry
+ *     points share per-context work buffers, so two calls on different streams
+ *     need an event between them (or two contexts, as the host mirror uses: one
+ *     for OFDM_Demod, one for BasicRadio).
  *   - soft bits are int8: +127 = logical 1, -127 = logical 0, 0 = erased
  *     (`viterbi_bit_t`, /root/reference/src/radio_block.h:19).
  *   - the library REQUIRES a gfx950 device for everything except the table
