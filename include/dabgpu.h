@@ -328,6 +328,16 @@ int dabgpu_msc_decode_multi_dev(dabgpu_ctx *ctx, const dabgpu_subchannel *sc, in
                                 const int8_t *const *d_history_in, int8_t *const *d_history_out,
                                 uint8_t *const *d_out, void *stream);
 
+/* A7..A12 in one call: what BasicRadio::Process does with a frame (/root/reference/src/radio_block.cpp:42) --
+ * the FIC and every listed sub-channel -- for a whole batch of frames.  Arguments as dabgpu_fic_decode_dev and
+ * dabgpu_msc_decode_multi_dev.  Large batches whose streams are a multiple of 16 frames long put the FIC and all
+ * sub-channels through one pair of launches (their codewords then share the machine instead of queueing up behind
+ * each other); any other shape is decoded part by part with the same results. */
+int dabgpu_decode_frames_dev(dabgpu_ctx *ctx, const int8_t *d_soft, size_t soft_stride, int n_streams,
+                             int frames_per_stream, uint8_t *d_fib, uint8_t *d_crc_ok, const dabgpu_subchannel *sc,
+                             int n_subchannels, const int8_t *const *d_history_in, int8_t *const *d_history_out,
+                             uint8_t *const *d_out, void *stream);
+
 /* ------------------------------------------------------------------------ */
 /* DAB+ audio super-frame: Fire code, RS(120,110), AU CRC.    */
 /* Replaces the checks the reference reports as the "Firecode / RS / AU"       */

@@ -851,6 +851,73 @@ int dabgpu_msc_decode(dabgpu_ctx *ctx, const dabgpu_subchannel *sc, const int8_t
     return DABGPU_OK;
 }
 
+// The FIC (d_fib != nullptr) and/or several sub-channels in one grouped lane launch.  Returns 0 when everything was
+// enqueued, 1 when the grouped path does not apply (caller falls back to one call per part), < 0 on errors.
+static int decode_grouped(dabgpu_ctx *ctx, uint8_t *d_fib, uint8_t *d_crc_ok, const dabgpu_subchannel *sc, int n_subchannels,
+                          const int8_t *d_soft, size_t soft_stride, int n_streams, int frames_per_stream,
+                          const int8_t *const *d_history_in, int8_t *const *d_history_out, uint8_t *const *d_out,
+                          void *stream) {
+    const int n_items = n_subchannels + (d_fib ? 1 : 0);
+    if (n_items < 2 || ctx->lane_mode == 0 || !d_soft || n_streams <= 0 || frames_per_stream <= 0 ||
+        soft_stride < size_t(NB_FRAME_BITS))
+        return 1;
+    const long total_cw = long(n_items) * n_streams * frames_per_stream * NB_CIFS;
+    if (ctx->lane_mode < 0 && total_cw < LANE_MIN_CODEWORDS) return 1;
+    std::vector<dabk::LaneGroupItem> items;
+    if (d_fib) {
+        dabk::LaneGroupItem it{};
+        it.code = ctx->fic.tables(true);
+        it.tables = ctx->fic.lane_tables();
+        it.args.soft = d_soft;
+        it.args.soft_stride = soft_stride;
+        it.args.n_streams = n_streams;
+        it.args.frames_per_stream = frames_per_stream;
+        it.args.out = d_fib;
+        it.is_fic = true;
+        it.crc_ok = d_crc_ok;
+        if (((reinterpret_cast<uintptr_t>(d_soft) | soft_stride) & 15) || (reinterpret_cast<uintptr_t>(d_fib) & 3)) return 1;
+        items.push_back(it);
+    }
+    for (int i = 0; i < n_subchannels; i++) {
+        dab::PunctureProfile prof;
+        int rc = subchannel_profile(&sc[i], prof);
+        if (rc) return rc;
+        DeviceCode *dc = nullptr;
+        if ((rc = get_code(ctx, std::move(prof), &dc))) return rc;
+        dabk::LaneGroupItem it{};
+        it.code = dc->tables(true);
+        it.tables = dc->lane_tables();
+        it.args.soft = d_soft;
+        it.args.soft_stride = soft_stride;
+        it.args.n_streams = n_streams;
+        it.args.frames_per_stream = frames_per_stream;
+        it.args.start_bit = sc[i].start_address * CU_BITS;
+        it.args.nbits = sc[i].length * CU_BITS;
+        it.args.hist_in = d_history_in ? d_history_in[i] : nullptr;
+        it.args.hist_out = d_history_out ? d_history_out[i] : nullptr;
+        it.args.out = d_out[i];
+        if (it.args.hist_in && it.args.hist_in == it.args.hist_out) return DABGPU_ERR_ARG;
+        if (!dabk::lane_supported(dc->prof.nsteps) || !dabk::lane_group_fusable(it.args)) return 1;
+        items.push_back(it);
+    }
+    hipStream_t s = pick_stream(ctx, stream);
+    const size_t need = dabk::lane_group_scratch_bytes(items.data(), n_items);
+    if (ctx->lane_scratch_bytes < need) {
+        HIP_TRY(hipStreamSynchronize(s));
+        if (ctx->d_lane_scratch) (void)hipFree(ctx->d_lane_scratch);
+        ctx->d_lane_scratch = nullptr;
+        ctx->lane_scratch_bytes = 0;
+        if (hipMalloc(&ctx->d_lane_scratch, need) != hipSuccess) return 1;
+        ctx->lane_scratch_bytes = need;
+    }
+    ScopedTimer tm(ctx, 2, s);
+    dabk::LaneScratch lsc{ctx->d_lane_scratch, ctx->lane_scratch_bytes};
+    HIP_TRY(dabk::launch_lane_group(items.data(), n_items, lsc, s));
+    for (const dabk::LaneGroupItem &it : items)
+        if (!it.is_fic) HIP_TRY(dabk::launch_msc_history(it.args, s));
+    return 0;
+}
+
 int dabgpu_msc_decode_multi_dev(dabgpu_ctx *ctx, const dabgpu_subchannel *sc, int n_subchannels,
                                 const int8_t *d_soft, size_t soft_stride, int n_streams, int frames_per_stream,
                                 const int8_t *const *d_history_in, int8_t *const *d_history_out,
@@ -868,10 +935,48 @@ int dabgpu_msc_decode_multi_dev(dabgpu_ctx *ctx, const dabgpu_subchannel *sc, in
             used[cu] = 1;
         }
     }
+    {
+        const int g = decode_grouped(ctx, nullptr, nullptr, sc, n_subchannels, d_soft, soft_stride, n_streams,
+                                     frames_per_stream, d_history_in, d_history_out, d_out, stream);
+        if (g <= 0) return g;                                  // done (0) or a real error (< 0); 1 = not applicable
+    }
     for (int i = 0; i < n_subchannels; i++) {
         const int rc = dabgpu_msc_decode_dev(ctx, &sc[i], d_soft, soft_stride, n_streams, frames_per_stream,
                                              d_history_in ? d_history_in[i] : nullptr,
                                              d_history_out ? d_history_out[i] : nullptr, d_out[i], stream);
+        if (rc) return rc;
+    }
+    return DABGPU_OK;
+}
+
+int dabgpu_decode_frames_dev(dabgpu_ctx *ctx, const int8_t *d_soft, size_t soft_stride, int n_streams,
+                             int frames_per_stream, uint8_t *d_fib, uint8_t *d_crc_ok, const dabgpu_subchannel *sc,
+                             int n_subchannels, const int8_t *const *d_history_in, int8_t *const *d_history_out,
+                             uint8_t *const *d_out, void *stream) {
+    if (!ctx || !d_soft || !d_fib || !d_crc_ok || n_streams < 0 || frames_per_stream < 0 || n_subchannels < 0) return DABGPU_ERR_ARG;
+    if (n_subchannels > 0 && (!sc || !d_out)) return DABGPU_ERR_ARG;
+    if (soft_stride < size_t(NB_FRAME_BITS) && size_t(n_streams) * frames_per_stream > 1) return DABGPU_ERR_ARG;
+    std::vector<char> used(864, 0);
+    for (int i = 0; i < n_subchannels; i++) {
+        dab::PunctureProfile prof;
+        const int rc = subchannel_profile(&sc[i], prof);
+        if (rc) return rc;
+        if (!d_out[i]) return DABGPU_ERR_ARG;
+        for (int cu = sc[i].start_address; cu < sc[i].start_address + sc[i].length; cu++) {
+            if (used[cu]) return DABGPU_ERR_ARG;
+            used[cu] = 1;
+        }
+    }
+    if (n_streams == 0 || frames_per_stream == 0) return DABGPU_OK;
+    const int g = decode_grouped(ctx, d_fib, d_crc_ok, sc, n_subchannels, d_soft, soft_stride, n_streams, frames_per_stream,
+                                 d_history_in, d_history_out, d_out, stream);
+    if (g <= 0) return g;
+    int rc = dabgpu_fic_decode_dev(ctx, d_soft, soft_stride, n_streams * frames_per_stream, d_fib, d_crc_ok, stream);
+    if (rc) return rc;
+    for (int i = 0; i < n_subchannels; i++) {
+        rc = dabgpu_msc_decode_dev(ctx, &sc[i], d_soft, soft_stride, n_streams, frames_per_stream,
+                                   d_history_in ? d_history_in[i] : nullptr, d_history_out ? d_history_out[i] : nullptr,
+                                   d_out[i], stream);
         if (rc) return rc;
     }
     return DABGPU_OK;

@@ -146,6 +146,20 @@ hipError_t launch_viterbi_plain_lane(const CodeTables &c, const LaneTables &lt, 
                                      int n_codewords, const LaneScratch &sc, uint8_t *out, hipStream_t s);
 hipError_t launch_msc_decode_lane(const CodeTables &c, const LaneTables &lt, const MscArgs &a, const LaneScratch &sc,
                                   hipStream_t s);
+// Grouped launch: the FIC and/or several sub-channels of the same frames, each with its own profile, in ONE forward
+// and ONE traceback launch.  Sub-channel items must pass lane_group_fusable(); all items lane_supported(nsteps).
+// For the FIC item only args.soft / soft_stride / n_streams / frames_per_stream / out (= FIBs) and crc_ok are used.
+// The history rings are updated by the caller (launch_msc_history per sub-channel).
+struct LaneGroupItem {
+    CodeTables code;
+    LaneTables tables;
+    MscArgs args;
+    bool is_fic;
+    uint8_t *crc_ok;
+};
+bool lane_group_fusable(const MscArgs &a);
+size_t lane_group_scratch_bytes(const LaneGroupItem *items, int n);
+hipError_t launch_lane_group(const LaneGroupItem *items, int n, const LaneScratch &sc, hipStream_t s);
 // Dynamic-LDS request (>= lds) that makes every CU hold the same number of workgroups of a `grid`-workgroup
 // launch when at most `o_cap` fit per CU otherwise (the dispatcher fills CUs greedily).
 size_t balanced_lds_bytes(unsigned grid, size_t lds, unsigned o_cap);

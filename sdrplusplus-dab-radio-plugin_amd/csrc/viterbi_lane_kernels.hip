@@ -77,12 +77,22 @@ struct LSrcMsc {
     size_t stride;
     const int8_t *hist;
     int cifs_per_stream;
-    int start_bit;
+    int base_off;             // first byte of the codeword's part in CIF 0 of a frame (FIC: 0; MSC: 9216 + 64*start CU)
+    int per_cif;              // distance between the four codewords of a frame (FIC group: 2304; CIF: 55296)
     int nbits;
+    int d_force;              // -1: time de-interleaver delays from the descriptor table; 15: no interleaving (FIC)
     __device__ __forceinline__ const int8_t *row(int g) const {
-        return soft + size_t(g >> 2) * stride + NB_FIC_BITS + size_t(g & 3) * NB_CIF_BITS + start_bit;
+        return soft + size_t(g >> 2) * stride + base_off + size_t(g & 3) * per_cif;
     }
 };
+__host__ __device__ inline LSrcMsc make_msc_src(const MscArgs &a) {
+    return LSrcMsc{a.soft, a.soft_stride, a.hist_in, a.frames_per_stream * NB_CIFS, NB_FIC_BITS + a.start_bit, NB_CIF_BITS,
+                   a.nbits, -1};
+}
+// delay (in rows of the window) of a punctured bit with descriptor dsc
+template <class Src>
+__device__ __forceinline__ int delay_rows(const Src &, int) { return 0; }
+__device__ __forceinline__ int delay_rows(const LSrcMsc &s, int dsc) { return s.d_force >= 0 ? s.d_force : (dsc >> 8); }
 
 // ---------------------------------------------------------------------------------------------------------
 // K1: depuncture (+ time de-interleave) + transpose.  Block = (group of 64 codewords, tile of 64 steps).
@@ -342,17 +352,13 @@ __device__ __forceinline__ const int8_t *fused_row(const LSrcMsc &s, int cw0, in
     return g < n_codewords ? s.row(g) : nullptr;
 }
 
+// one wave = one group of 64 codewords; `win` is the wave's private window
 template <class Src>
-__global__ __launch_bounds__(256) void lane_forward_fused_kernel(Src src, const int32_t *desc, const int32_t *tiles,
-                                                                 int nsteps, int groups, int n_codewords, uint2 *dec) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t fused_lds[];
+__device__ __forceinline__ void lane_forward_fused_body(const Src &src, const int32_t *desc, const int32_t *tiles,
+                                                        int nsteps, int group, int n_codewords, uint2 *dec, uint8_t *win,
+                                                        int lane) {
     constexpr int ROWS = 64 + Src::PRE;
     constexpr int NK = (ROWS * FCOLS + 63) / 64;
-    const int lane = threadIdx.x & 63;
-    const int wv = threadIdx.x >> 6;
-    const int group = blockIdx.x * 4 + wv;
-    if (group >= groups) return;
-    uint8_t *win = fused_lds + wv * (ROWS * FPITCH);
     const int cw0 = group * 64;
     uint2 *dst = dec + size_t(group) * nsteps * 64 + lane;
     // this lane's staging duties: chunk (row, col) = (i >> 3, i & 7), i = lane + 64 k
@@ -414,7 +420,7 @@ __global__ __launch_bounds__(256) void lane_forward_fused_kernel(Src src, const 
 #pragma unroll
                 for (int m = 0; m < 4; m++) {
                     const int dsc = dcur[4 * i + m];                            // wave-uniform: column | delay << 8
-                    const int off = (Src::PRE ? (dsc >> 8) * FPITCH : 0) + (dsc & 0xFF);
+                    const int off = delay_rows(src, dsc) * FPITCH + (dsc & 0xFF);
                     v |= uint32_t(my[off]) << (8 * m);
                 }
                 w[i] = v;
@@ -435,6 +441,49 @@ __global__ __launch_bounds__(256) void lane_forward_fused_kernel(Src src, const 
         }
         if (more) stash();                                     // the wave's own LDS reads above are already issued
     }
+}
+
+template <class Src>
+__global__ __launch_bounds__(256) void lane_forward_fused_kernel(Src src, const int32_t *desc, const int32_t *tiles,
+                                                                 int nsteps, int groups, int n_codewords, uint2 *dec) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t fused_lds[];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int group = blockIdx.x * 4 + wv;
+    if (group >= groups) return;
+    lane_forward_fused_body(src, desc, tiles, nsteps, group, n_codewords, dec, fused_lds + wv * ((64 + Src::PRE) * FPITCH),
+                            lane);
+}
+
+// Grouped launch (every sub-channel of a multiplex in one launch): the entries sit in device
+// memory, a wave looks up which sub-channel its group belongs to and runs the same body with that entry's
+// parameters.  Codeword lengths differ between entries; nothing else does.
+struct LaneEntry {
+    LSrcMsc src;
+    const int32_t *desc, *tiles;
+    const uint8_t *prbs;
+    uint8_t *out;
+    uint8_t *crc_ok;          // FIC entry: CRC flag per FIB; nullptr for sub-channels
+    uint2 *dec;
+    int nsteps, n_codewords, first_group, groups;
+};
+
+__device__ __forceinline__ int find_entry(const LaneEntry *entries, int n_entries, int group) {
+    int e = 0;
+    while (e + 1 < n_entries && group >= entries[e + 1].first_group) e++;
+    return e;
+}
+
+__global__ __launch_bounds__(256) void lane_forward_grouped_kernel(const LaneEntry *entries, int n_entries, int total_groups) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t fused_lds[];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int group = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv);
+    if (group >= total_groups) return;
+    const LaneEntry &en = entries[find_entry(entries, n_entries, group)];
+    const LSrcMsc src = en.src;
+    lane_forward_fused_body(src, en.desc, en.tiles, en.nsteps, group - en.first_group, en.n_codewords, en.dec,
+                            fused_lds + wv * ((64 + LSrcMsc::PRE) * FPITCH), lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -473,11 +522,9 @@ __device__ __forceinline__ unsigned crc16_byte_l(unsigned crc, unsigned byte) {
     return crc;
 }
 
-__global__ __launch_bounds__(64) void lane_traceback_kernel(const uint2 *dec, int nsteps, int n_codewords,
-                                                            const uint8_t *prbs_bytes, uint8_t *out, uint8_t *crc_ok) {
-    extern __shared__ uint32_t tile[];                        // [64][nwords + 1]
-    const int lane = threadIdx.x;
-    const int group = blockIdx.x;
+__device__ __forceinline__ void lane_traceback_body(const uint2 *dec, int nsteps, int n_codewords, int group,
+                                                    const uint8_t *prbs_bytes, uint8_t *out, uint8_t *crc_ok, uint32_t *tile,
+                                                    int lane) {
     const uint2 *src = dec + size_t(group) * nsteps * 64 + lane;
     const int nwords = (nsteps - 6) >> 5;
     const int pitch = nwords | 1;                             // odd -> rows start in different banks
@@ -528,6 +575,20 @@ __global__ __launch_bounds__(64) void lane_traceback_kernel(const uint2 *dec, in
             crc_ok[(size_t(group) * 64) * nfib + j] = uint8_t((crc ^ 0xFFFFu) == rx);
         }
     }
+}
+
+__global__ __launch_bounds__(64) void lane_traceback_kernel(const uint2 *dec, int nsteps, int n_codewords,
+                                                            const uint8_t *prbs_bytes, uint8_t *out, uint8_t *crc_ok) {
+    extern __shared__ uint32_t tile[];                        // [64][nwords + 1]
+    lane_traceback_body(dec, nsteps, n_codewords, blockIdx.x, prbs_bytes, out, crc_ok, tile, threadIdx.x);
+}
+
+__global__ __launch_bounds__(64) void lane_traceback_grouped_kernel(const LaneEntry *entries, int n_entries) {
+    extern __shared__ uint32_t tile[];                        // sized for the longest entry
+    const int group = blockIdx.x;
+    const LaneEntry &en = entries[find_entry(entries, n_entries, group)];
+    lane_traceback_body(en.dec, en.nsteps, en.n_codewords, group - en.first_group, en.prbs, en.out, en.crc_ok, tile,
+                        threadIdx.x);
 }
 
 template <class Src>
@@ -602,12 +663,85 @@ hipError_t launch_viterbi_plain_lane(const CodeTables &c, const LaneTables &lt, 
 
 hipError_t launch_msc_decode_lane(const CodeTables &c, const LaneTables &lt, const MscArgs &a, const LaneScratch &sc,
                                   hipStream_t s) {
-    LSrcMsc f{a.soft, a.soft_stride, a.hist_in, a.frames_per_stream * NB_CIFS, a.start_bit, a.nbits};
+    const LSrcMsc f = make_msc_src(a);
     // the fused forward pass wants whole groups inside one stream and 16-byte aligned history rows
     const bool fusable = (a.frames_per_stream * NB_CIFS) % 64 == 0 &&
                          (!a.hist_in || ((reinterpret_cast<uintptr_t>(a.hist_in) | size_t(a.nbits)) & 15) == 0);
     return run_lane(f, aligned16(a.soft, a.soft_stride) && (a.start_bit & 15) == 0, fusable, c, lt,
                     a.n_streams * a.frames_per_stream * NB_CIFS, sc, a.out, nullptr, s);
+}
+
+bool lane_group_fusable(const MscArgs &a) {
+    return (a.frames_per_stream * NB_CIFS) % 64 == 0 && aligned16(a.soft, a.soft_stride) && (a.start_bit & 15) == 0 &&
+           (!a.hist_in || ((reinterpret_cast<uintptr_t>(a.hist_in) | size_t(a.nbits)) & 15) == 0) &&
+           (reinterpret_cast<uintptr_t>(a.out) & 3) == 0;
+}
+
+static size_t item_codewords(const LaneGroupItem &it) {
+    return size_t(it.args.n_streams) * it.args.frames_per_stream * NB_CIFS;      // FIC: 4 groups per frame as well
+}
+
+size_t lane_group_scratch_bytes(const LaneGroupItem *items, int n) {
+    size_t total = 0;
+    for (int i = 0; i < n; i++) total += ((item_codewords(items[i]) + 63) / 64) * 64 * size_t(items[i].code.nsteps) * sizeof(uint2);
+    return total + size_t(n) * sizeof(LaneEntry) + 512;
+}
+
+hipError_t launch_lane_group(const LaneGroupItem *items, int n, const LaneScratch &sc, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    if (!sc.base || sc.bytes < lane_group_scratch_bytes(items, n)) return hipErrorInvalidValue;
+    std::vector<LaneEntry> entries(static_cast<size_t>(n));
+    // scratch: entry table first (256-byte aligned block), then every entry's survivor store
+    char *p = static_cast<char *>(sc.base);
+    LaneEntry *d_entries = reinterpret_cast<LaneEntry *>(p);
+    p += (size_t(n) * sizeof(LaneEntry) + 255) & ~size_t(255);
+    int total_groups = 0, max_nwords = 0;
+    for (int i = 0; i < n; i++) {
+        const LaneGroupItem &it = items[i];
+        const MscArgs &a = it.args;
+        if (!it.tables.fused_desc || !it.tables.fused_tiles || !lane_supported(it.code.nsteps)) return hipErrorInvalidValue;
+        LaneEntry &e = entries[size_t(i)];
+        e.n_codewords = int(item_codewords(it));
+        if (it.is_fic) {
+            // the FIC as one more entry: four 2304-bit groups per frame, no interleaving (every bit "delay 15" = the
+            // codeword's own row), never a history row
+            if (!aligned16(a.soft, a.soft_stride) || (reinterpret_cast<uintptr_t>(a.out) & 3)) return hipErrorInvalidValue;
+            e.src = LSrcMsc{a.soft, a.soft_stride, nullptr, e.n_codewords + 128, 0, NB_FIC_GROUP_BITS, NB_FIC_GROUP_BITS, 15};
+        } else {
+            if (!lane_group_fusable(a)) return hipErrorInvalidValue;
+            e.src = make_msc_src(a);
+        }
+        e.desc = it.tables.fused_desc;
+        e.tiles = it.tables.fused_tiles;
+        e.prbs = it.code.prbs_bytes;
+        e.out = a.out;
+        e.crc_ok = it.is_fic ? it.crc_ok : nullptr;
+        e.dec = reinterpret_cast<uint2 *>(p);
+        e.nsteps = it.code.nsteps;
+        e.first_group = total_groups;
+        e.groups = (e.n_codewords + 63) / 64;
+        total_groups += e.groups;
+        p += size_t(e.groups) * 64 * size_t(e.nsteps) * sizeof(uint2);
+        max_nwords = std::max(max_nwords, (e.nsteps - 6) >> 5);
+    }
+    hipError_t err = hipMemcpyAsync(d_entries, entries.data(), size_t(n) * sizeof(LaneEntry), hipMemcpyHostToDevice, s);
+    if (err != hipSuccess) return err;
+    const unsigned fgrid = unsigned((total_groups + 3) / 4);
+    const size_t lds = balanced_lds_bytes(fgrid, size_t(4) * (64 + LSrcMsc::PRE) * FPITCH, 3);
+    if (lds > 64 * 1024) {
+        err = hipFuncSetAttribute(reinterpret_cast<const void *>(lane_forward_grouped_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        if (err != hipSuccess) return err;
+    }
+    hipLaunchKernelGGL(lane_forward_grouped_kernel, dim3(fgrid), dim3(256), lds, s, d_entries, n, total_groups);
+    const size_t tb_lds = size_t(64) * (max_nwords | 1) * 4;
+    if (tb_lds > 64 * 1024) {
+        err = hipFuncSetAttribute(reinterpret_cast<const void *>(lane_traceback_grouped_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, int(tb_lds));
+        if (err != hipSuccess) return err;
+    }
+    hipLaunchKernelGGL(lane_traceback_grouped_kernel, dim3(unsigned(total_groups)), dim3(64), tb_lds, s, d_entries, n);
+    return hipGetLastError();
 }
 
 void build_lane_fused_tables(const uint8_t *mask, int nsteps, std::vector<int32_t> &desc, std::vector<int32_t> &tiles) {

@@ -35,7 +35,7 @@ EXPORTS = [
     "dabgpu_msc_decode_multi_dev", "dabgpu_dabplus_superframes_dev", "dabgpu_dabplus_superframes",
     "dabgpu_acquire_default_cfg", "dabgpu_acquire_dev", "dabgpu_acquire", "dabgpu_ofdm_demod_acquired_dev",
     "dabgpu_ofdm_set_soft_selection", "dabgpu_soft_selection", "dabgpu_uep_subchannel",
-    "dabgpu_host_alloc", "dabgpu_host_free",
+    "dabgpu_host_alloc", "dabgpu_host_free", "dabgpu_decode_frames_dev",
 ]
 
 
@@ -143,6 +143,7 @@ def lib():
         L.dabgpu_dabplus_superframes_dev.argtypes = [vp, vp, sz, i, i, vp, vp, vp]
         L.dabgpu_dabplus_superframes.argtypes = [vp, vp, sz, i, i, vp, vp]
         L.dabgpu_msc_decode_multi_dev.argtypes = [vp, vp, i, vp, sz, i, i, vp, vp, vp, vp]
+        L.dabgpu_decode_frames_dev.argtypes = [vp, vp, sz, i, i, vp, vp, vp, i, vp, vp, vp, vp]
         L.dabgpu_sync_prs_dev.argtypes = [vp, vp, sz, i, vp, i, vp, vp]
         L.dabgpu_sync_prs.argtypes = [vp, vp, sz, i, vp, i, vp]
         L.dabgpu_ofdm_set_soft_selection.argtypes = [vp, vp, i]
@@ -417,6 +418,19 @@ class Context:
         hi, ho, out = ptrs(d_hist_in), ptrs(d_hist_out), ptrs(d_out)
         _check(lib().dabgpu_msc_decode_multi_dev(self._h, arr, n, d_soft, soft_stride, n_streams, frames_per_stream,
                                                  hi, ho, out, stream), "dabgpu_msc_decode_multi_dev")
+
+    def decode_frames_dev(self, d_soft, soft_stride, n_streams, frames_per_stream, d_fib, d_crc_ok, scs, d_hist_in, d_hist_out,
+                          d_out, stream=None):
+        """FIC + the sub-channels `scs` of every frame in one call (lists of device addresses as msc_decode_multi_dev)."""
+        n = len(scs)
+        arr = (Subchannel * max(n, 1))(*scs)
+        def ptrs(lst):
+            if lst is None or n == 0:
+                return None
+            return (C.c_void_p * n)(*[C.c_void_p(x) if x else None for x in lst])
+        _check(lib().dabgpu_decode_frames_dev(self._h, d_soft, soft_stride, n_streams, frames_per_stream, d_fib, d_crc_ok,
+                                              arr, n, ptrs(d_hist_in), ptrs(d_hist_out), ptrs(d_out), stream),
+               "dabgpu_decode_frames_dev")
 
     def msc_decode_dev(self, sc, d_soft, soft_stride, n_streams, frames_per_stream, d_hist_in, d_hist_out, d_out,
                        stream=None):

@@ -108,3 +108,82 @@ def test_fused_forward_msc_whole_groups(fps, with_hist):
         for t in (0, 7, 15, 63, fps * 4 - 1):
             want = O.msc_decode_lf(O.time_deinterleave(padded[t:t + 16]), mask, 48 * 24 + 6)
             assert (res[1][0][s, t] == want).all(), (s, t)
+
+
+def test_grouped_multi_subchannel_launch():
+    """dabgpu_msc_decode_multi_dev with whole-group streams: every sub-channel's codewords go through ONE forward and
+    ONE traceback launch (entries of different length, EEP-A / EEP-B / UEP); same bytes and history rings as decoding
+    them one by one with the wave-per-codeword kernels."""
+    n_streams, fps = 2, 16
+    scs = [dabgpu.subchannel(0, 64, level=3), dabgpu.subchannel(48, 48, level=2), dabgpu.subchannel(96, 32, level=2, eep_type=1),
+           dabgpu.uep_subchannel(17, 117), dabgpu.subchannel(175, 8, level=1), dabgpu.subchannel(187, 128, level=4),
+           dabgpu.uep_subchannel(4, 251)]
+    n = n_streams * fps
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev); g.manual_seed(77)
+    soft = torch.randint(-127, 128, (n, dabgpu.NB_FRAME_BITS), dtype=torch.int8, device=dev, generator=g)
+    hin = [torch.randint(-127, 128, (n_streams, 15, sc.length * 64), dtype=torch.int8, device=dev, generator=g) for sc in scs]
+    res = []
+    for mode in (0, 1):
+        c = make_ctx(mode, max_frames=8)
+        outs = [torch.zeros((n_streams, fps * 4, sc.bitrate_kbps * 3), dtype=torch.uint8, device=dev) for sc in scs]
+        hout = [torch.zeros_like(h) for h in hin]
+        c.msc_decode_multi_dev(scs, soft.data_ptr(), dabgpu.NB_FRAME_BITS, n_streams, fps, [h.data_ptr() for h in hin],
+                               [h.data_ptr() for h in hout], [o.data_ptr() for o in outs], None)
+        c.sync()
+        res.append(([o.cpu().numpy() for o in outs], [h.cpu().numpy() for h in hout]))
+        c.close()
+    for i in range(len(scs)):
+        assert (res[0][0][i] == res[1][0][i]).all(), i
+        assert (res[0][1][i] == res[1][1][i]).all(), i
+    # oracle spot check on the UEP entry (index 3) across the stream start
+    mask, kept, nsteps, _ = O.uep_puncture_mask(17)
+    sc = scs[3]
+    nbits = sc.length * 64
+    cifs = soft[:fps, dabgpu.NB_FIC_BITS:].reshape(fps * 4, 55296)[:, sc.start_address * 64:sc.start_address * 64 + nbits].cpu().numpy()
+    padded = np.concatenate([hin[3][0].cpu().numpy(), cifs])
+    for t in (0, 14, 15, 40, 63):
+        want = O.msc_decode_lf(O.time_deinterleave(padded[t:t + 16])[:kept], mask, nsteps)
+        assert (res[1][0][3][0, t] == want).all(), t
+
+
+@pytest.mark.parametrize("mode,fps", [(1, 16), (1, 6), (0, 16), (None, 16)])
+def test_decode_frames_equals_separate_calls(mode, fps):
+    """dabgpu_decode_frames_dev (FIC + sub-channels, BasicRadio::Process for a batch): grouped launch with the FIC as
+    one more entry (mode 1, 16 frames per stream), the part-by-part path for other shapes; always the same bytes as
+    dabgpu_fic_decode_dev + dabgpu_msc_decode_dev."""
+    n_streams = 3
+    scs = [dabgpu.subchannel(0, 64, level=3), dabgpu.uep_subchannel(5, 60), dabgpu.subchannel(100, 32, level=4, eep_type=1)]
+    n = n_streams * fps
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev); g.manual_seed(fps)
+    soft = torch.randint(-127, 128, (n, dabgpu.NB_FRAME_BITS), dtype=torch.int8, device=dev, generator=g)
+    hin = [torch.randint(-127, 128, (n_streams, 15, sc.length * 64), dtype=torch.int8, device=dev, generator=g) for sc in scs]
+    def buffers():
+        return (torch.zeros((n, 12, 32), dtype=torch.uint8, device=dev), torch.zeros((n, 12), dtype=torch.uint8, device=dev),
+                [torch.zeros((n_streams, fps * 4, sc.bitrate_kbps * 3), dtype=torch.uint8, device=dev) for sc in scs],
+                [torch.zeros_like(h) for h in hin])
+    ref = make_ctx(0, max_frames=8)
+    fib0, ok0, out0, hout0 = buffers()
+    ref.fic_decode_dev(soft.data_ptr(), dabgpu.NB_FRAME_BITS, n, fib0.data_ptr(), ok0.data_ptr(), None)
+    for i, sc in enumerate(scs):
+        ref.msc_decode_dev(sc, soft.data_ptr(), dabgpu.NB_FRAME_BITS, n_streams, fps, hin[i].data_ptr(), hout0[i].data_ptr(),
+                           out0[i].data_ptr(), None)
+    ref.sync()
+    c = make_ctx(mode, max_frames=8)
+    fib1, ok1, out1, hout1 = buffers()
+    c.decode_frames_dev(soft.data_ptr(), dabgpu.NB_FRAME_BITS, n_streams, fps, fib1.data_ptr(), ok1.data_ptr(), scs,
+                        [h.data_ptr() for h in hin], [h.data_ptr() for h in hout1], [o.data_ptr() for o in out1], None)
+    c.sync()
+    assert (fib0 == fib1).all() and (ok0 == ok1).all()
+    for i in range(len(scs)):
+        assert (out0[i] == out1[i]).all() and (hout0[i] == hout1[i]).all(), i
+    # FIC only (no sub-channels) and bad arguments
+    fib2, ok2, _, _ = buffers()
+    c.decode_frames_dev(soft.data_ptr(), dabgpu.NB_FRAME_BITS, n_streams, fps, fib2.data_ptr(), ok2.data_ptr(), [], None, None, None, None)
+    c.sync()
+    assert (fib2 == fib0).all()
+    with pytest.raises(dabgpu.DabGpuError):
+        c.decode_frames_dev(soft.data_ptr(), dabgpu.NB_FRAME_BITS, n_streams, fps, fib2.data_ptr(), ok2.data_ptr(),
+                            [scs[0], dabgpu.subchannel(10, 64, level=3)], None, None, [out1[0].data_ptr()] * 2, None)
+    ref.close(); c.close()
