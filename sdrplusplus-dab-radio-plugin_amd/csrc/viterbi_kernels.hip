@@ -83,7 +83,7 @@ __global__ __launch_bounds__(WGV) void viterbi_wave_kernel(Fetch fetch, CodeTabl
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int cw_raw = blockIdx.x * int(blockDim.x >> 6) + wave;
+    const int cw_raw = __builtin_amdgcn_readfirstlane(blockIdx.x * int(blockDim.x >> 6) + wave);   // wave-uniform
     const bool active = cw_raw < n_codewords;
     const int cw = active ? cw_raw : n_codewords - 1;
     const int nsteps = code.nsteps;
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(WGV) void viterbi_rot_kernel(Fetch fetch, CodeTable
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int cw_raw = blockIdx.x * int(blockDim.x >> 6) + wave;
+    const int cw_raw = __builtin_amdgcn_readfirstlane(blockIdx.x * int(blockDim.x >> 6) + wave);   // wave-uniform
     const bool active = cw_raw < n_codewords;
     const int cw = active ? cw_raw : n_codewords - 1;
     const int nsteps = code.nsteps;

@@ -288,7 +288,7 @@ __device__ __forceinline__ void lane_step(unsigned (&M)[32], uint32_t w, uint2 *
 // number of workgroups -- the dispatcher otherwise packs some SIMDs with 3 waves while others hold 1.
 __global__ __launch_bounds__(256) void lane_forward_kernel(const uint32_t *Msoft, int nsteps, int groups, uint2 *dec) {
     const int lane = threadIdx.x & 63;
-    const int group = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int group = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (group >= groups) return;
     const size_t base = size_t(group) * nsteps * 64 + lane;
     const uint32_t *src = Msoft + base;
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(256) void lane_forward_fused_kernel(Src src, const 
     extern __shared__ __attribute__((aligned(16))) uint8_t fused_lds[];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
-    const int group = blockIdx.x * 4 + wv;
+    const int group = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv);     // wave-uniform: pointers stay in SGPRs
     if (group >= groups) return;
     lane_forward_fused_body(src, desc, tiles, nsteps, group, n_codewords, dec, fused_lds + wv * ((64 + Src::PRE) * FPITCH),
                             lane);
