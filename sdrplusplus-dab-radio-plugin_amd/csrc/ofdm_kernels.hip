@@ -253,7 +253,9 @@ __device__ __forceinline__ float wave_sum(float v, int lane) {
 }
 
 // SELECT: soft-bit selection table in use (a separate instantiation so that the plain kernel keeps its registers)
-template <bool FFT_ONLY, bool WITH_DQPSK, bool SELECT = false>
+// NCO: a frequency correction is applied (the launch has a freq_offset array or acquired frames).  A compile-time
+// switch, not a per-frame branch: the branch cost 31 register moves per symbol where its two paths re-joined.
+template <bool FFT_ONLY, bool WITH_DQPSK, bool SELECT = false, bool NCO = true>
 __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab, OfdmArgs a, int parts, int n_items) {
     __shared__ WaveLds sm;
     const int tid = threadIdx.x;
@@ -360,7 +362,11 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
             }
         }
         float2 w = make_float2(1.f, 0.f);
+#ifdef DAB_EXP_NCO_BRANCH
         if (dphi != 0u) w = nco(uint32_t(l * NB_SYM_PERIOD + NB_CP + 2 * lane), dphi);
+#else
+        if constexpr (NCO) w = nco(uint32_t(l * NB_SYM_PERIOD + NB_CP + 2 * lane), dphi);
+#endif
         __builtin_amdgcn_sched_barrier(0);
         // ---- loads: 16 x 16 B per lane, row n1 = samples 128*n1 + 2*lane, +1 ----
         float2 x0[16], x1[16];
@@ -412,7 +418,11 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
         }
         __builtin_amdgcn_sched_barrier(0);
         // ---- A2: NCO ----
+#ifdef DAB_EXP_NCO_BRANCH
         if (dphi != 0u) {
+#else
+        if constexpr (NCO) {
+#endif
 #pragma unroll
             for (int n1 = 0; n1 < 16; n1++) {
                 x0[n1] = cmul(x0[n1], w);
@@ -576,18 +586,21 @@ hipError_t launch_ofdm_demod(const OfdmTables &t, const OfdmArgs &a, int parts, 
     if (use_v0() && (a.acq || a.keep)) return hipErrorInvalidValue;   // the first-generation kernel: aligned frames, all bits
     if (use_v0()) {
         hipLaunchKernelGGL(ofdm_kernel<false>, dim3(unsigned(items)), dim3(WG), 0, s, t, a, parts);
-    } else if (a.dqpsk) {
-        // the constellation output covers every symbol, so a selection only applies to the plain variant
-        OfdmArgs b = a;
-        b.keep = nullptr;
-        hipLaunchKernelGGL((ofdm_wave_kernel<false, true>), dim3(unsigned((items + WAVES - 1) / WAVES)),
-                           dim3(64 * WAVES), 0, s, t, b, parts, items);
-    } else if (a.keep) {
-        hipLaunchKernelGGL((ofdm_wave_kernel<false, false, true>), dim3(unsigned((items + WAVES - 1) / WAVES)),
-                           dim3(64 * WAVES), 0, s, t, a, parts, items);
     } else {
-        hipLaunchKernelGGL((ofdm_wave_kernel<false, false>), dim3(unsigned((items + WAVES - 1) / WAVES)),
-                           dim3(64 * WAVES), 0, s, t, a, parts, items);
+        const bool nco = a.freq_offset != nullptr || a.acq != nullptr;
+        const dim3 grid(unsigned((items + WAVES - 1) / WAVES)), block(64 * WAVES);
+        OfdmArgs b = a;
+        if (a.dqpsk) b.keep = nullptr;      // the constellation output covers every symbol: a selection is ignored there
+        if (b.dqpsk) {
+            if (nco) hipLaunchKernelGGL((ofdm_wave_kernel<false, true, false, true>), grid, block, 0, s, t, b, parts, items);
+            else hipLaunchKernelGGL((ofdm_wave_kernel<false, true, false, false>), grid, block, 0, s, t, b, parts, items);
+        } else if (b.keep) {
+            if (nco) hipLaunchKernelGGL((ofdm_wave_kernel<false, false, true, true>), grid, block, 0, s, t, b, parts, items);
+            else hipLaunchKernelGGL((ofdm_wave_kernel<false, false, true, false>), grid, block, 0, s, t, b, parts, items);
+        } else {
+            if (nco) hipLaunchKernelGGL((ofdm_wave_kernel<false, false, false, true>), grid, block, 0, s, t, b, parts, items);
+            else hipLaunchKernelGGL((ofdm_wave_kernel<false, false, false, false>), grid, block, 0, s, t, b, parts, items);
+        }
     }
     return hipGetLastError();
 }
@@ -599,8 +612,9 @@ hipError_t launch_fft_symbols(const OfdmTables &t, const OfdmArgs &a, int parts,
     if (use_v0()) {
         hipLaunchKernelGGL(ofdm_kernel<true>, dim3(unsigned(items)), dim3(WG), 0, s, t, a, parts);
     } else {
-        hipLaunchKernelGGL((ofdm_wave_kernel<true, false>), dim3(unsigned((items + WAVES - 1) / WAVES)),
-                           dim3(64 * WAVES), 0, s, t, a, parts, items);
+        const dim3 grid(unsigned((items + WAVES - 1) / WAVES)), block(64 * WAVES);
+        if (a.freq_offset) hipLaunchKernelGGL((ofdm_wave_kernel<true, false, false, true>), grid, block, 0, s, t, a, parts, items);
+        else hipLaunchKernelGGL((ofdm_wave_kernel<true, false, false, false>), grid, block, 0, s, t, a, parts, items);
     }
     return hipGetLastError();
 }
