@@ -183,9 +183,6 @@ constexpr int WAVES = DAB_OFDM_WAVES;
 
 struct WaveLds {
     float2 tw[NB_FFT];               // exp(-2*pi*i*m/2048)                                   16 KB
-#ifdef DAB_EXP_T1
-    float2 t1[15 * 16];              // step-1 twiddles W256^(n2*k1) as [k1-1][n2]: conflict-free, 4-lane broadcast
-#endif
     uint32_t nidx[12 * 64];          // frequency de-interleave table, two data indices per dword  3 KB
     float2 ex[WAVES][NB_FFT / 2];    // per-wave exchange buffer (half a symbol per pass), reused
                                      // as soft-bit staging                                    8 KB each
@@ -266,9 +263,6 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
     const int wave = tid >> 6;
     for (int i = tid; i < NB_FFT; i += 64 * WAVES) sm.tw[i] = tab.twiddle[i];
     for (int i = tid; i < 12 * 64; i += 64 * WAVES) sm.nidx[i] = reinterpret_cast<const uint32_t *>(tab.n_of_vj)[i];
-#ifdef DAB_EXP_T1
-    if (tid < 15 * 16) sm.t1[tid] = tab.twiddle[8 * (tid & 15) * ((tid >> 4) + 1)];
-#endif
     __syncthreads();
     // The item is the same for all lanes of a wave; saying so keeps everything derived from it (frame pointers, the
     // symbol counter, the NCO increment) in SGPRs: -5 % VALU instructions, -8 % time.
@@ -448,11 +442,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k1 = 1; k1 < 16; k1++) {
-#ifdef DAB_EXP_T1
-            const float2 t = sm.t1[(k1 - 1) * 16 + n2i];
-#else
             const float2 t = tw[(8 * n2i) * k1];          // index <= 8*15*15 = 1800
-#endif
             x0[k1] = cmul(x0[k1], t);
             x1[k1] = cmul(x1[k1], t);
         }
