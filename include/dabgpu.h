@@ -164,6 +164,7 @@ int dabgpu_ofdm_demod_frames(dabgpu_ctx *ctx, const float *iq, size_t frame_stri
  * dabgpu_soft_selection writes the ranges of the FIC (with_fic != 0) and of the given sub-channels (4 CIFs each)
  * to `out` and returns how many there are (more than max_out = nothing written beyond max_out), or a negative
  * status for a bad sub-channel. */
+struct dabgpu_subchannel;             /* defined with the MSC entry points below */
 typedef struct dabgpu_bit_range {
     int32_t first;
     int32_t count;

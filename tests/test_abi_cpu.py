@@ -19,6 +19,19 @@ def test_header_symbols_are_all_exported(built):
     assert L.dabgpu_abi_version() == 1
 
 
+def test_header_is_plain_c(tmp_path):
+    """include/dabgpu.h is what a C (cgo / JNI / ctypes-generator) binding compiles against: it must be valid C99 and
+    C++11 on its own, warning-free."""
+    import subprocess
+    src = tmp_path / "abi.c"
+    src.write_text('#include "dabgpu.h"\n'
+                   'int main(void) { dabgpu_cfg c = {0, 1, 1, 0}; dabgpu_subchannel s = {0, 48, 0, 0, 3, 64};\n'
+                   '  dabgpu_bit_range r[9]; (void)c; return dabgpu_soft_selection(&s, 1, 1, r, 9) == 5 ? 0 : 1; }\n')
+    inc = "-I" + os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", inc, str(src)])
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c++", inc, str(src)])
+
+
 def test_strerror_and_argument_errors(built):
     assert dabgpu.strerror(0) == "ok"
     assert "gfx950" in dabgpu.strerror(-4)
