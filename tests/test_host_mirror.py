@@ -42,6 +42,15 @@ def test_reference_dab_module_compiles_unchanged(host_built):
 
 
 @pytest.mark.gpu
+def test_c_abi_from_plain_c(host_built):
+    exe = os.path.join(HOST, "c_abi_smoke")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", HOST, "c_abi_smoke"], stdout=subprocess.DEVNULL)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "c abi ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("chunk,cfo", [(65536, 0.0), (10007, 0.23 / 2048), (196608 * 2 + 13, -0.31 / 2048),
                                        (32768, 7.3 / 2048), (50001, -41.8 / 2048)])
 def test_demo_recovers_transmitted_data(host_built, tmp_path, chunk, cfo):
