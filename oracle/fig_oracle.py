@@ -70,7 +70,7 @@ def _fig0_1(d, db):
             if option > 1:                        # reserved option: not an entry a receiver can use
                 i += 4
                 continue
-            level = ((d[i + 2] >> 2) & 3) + 1
+            level = (d[i + 2] >> 2) & 3          # 0..3 as transmitted (the GUI prints level + 1)
             size = ((d[i + 2] & 3) << 8) | d[i + 3]
             db.subchannels.setdefault(scid, {"start_address": start, "length": size, "is_uep": False,
                                              "uep_prot_index": 0, "eep_type": option, "eep_prot_level": level})

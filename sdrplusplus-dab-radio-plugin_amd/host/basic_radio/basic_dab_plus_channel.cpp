@@ -35,7 +35,7 @@ void Basic_DAB_Plus_Channel::Process(tcb::span<const uint8_t> lf) {
     m_header.is_spectral_band_replication = sbr;
     m_header.is_stereo = stereo;
     m_header.is_parametric_stereo = ps;
-    m_header.mpeg_surround = h & 7;
+    m_header.mpeg_surround = mpeg_surround_from_config(h & 7);
     m_header.nb_access_units = uint8_t(st.num_aus);
     bool au_error = false;
     for (int a = 0; a < st.num_aus; a++) {

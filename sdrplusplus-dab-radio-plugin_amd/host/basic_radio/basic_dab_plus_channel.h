@@ -10,6 +10,7 @@
 #include <string_view>
 #include <vector>
 #include "basic_radio/basic_audio_channel.h"
+#include "dab/audio/aac_frame_processor.h"
 #include "dabgpu.h"
 
 struct SuperFrameHeader {                  // TS 102 563 clause 5.2; fields as the GUI prints them
@@ -17,7 +18,7 @@ struct SuperFrameHeader {                  // TS 102 563 clause 5.2; fields as t
     bool is_stereo = false;
     bool is_spectral_band_replication = false;
     bool is_parametric_stereo = false;
-    uint8_t mpeg_surround = 0;
+    MPEG_Surround mpeg_surround = MPEG_Surround::NOT_USED;
     uint8_t nb_access_units = 0;
 };
 

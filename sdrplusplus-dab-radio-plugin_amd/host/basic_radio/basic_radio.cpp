@@ -1,5 +1,7 @@
 #include "basic_radio/basic_radio.h"
 
+#include "dab/constants/subchannel_protection_tables.h"
+
 #include <stdexcept>
 #include <string>
 
@@ -88,17 +90,14 @@ void BasicRadio::update_channels_from_database() {
             // short form: bit rate, level and size come from the protection profile table
             ok = dabgpu_uep_subchannel(sub->uep_prot_index, sub->start_address, &sc) == DABGPU_OK;
             if (ok) sub->length = uint16_t(sc.length);
-        } else if (sub->eep_prot_level >= 1 && sub->eep_prot_level <= 4 && sub->length > 0) {
-            // EEP: size = k * n capacity units with n = bitrate/8 (option A) or bitrate/32 (option B)
-            static const int per_unit_a[5] = {0, 12, 8, 6, 4}, per_unit_b[5] = {0, 27, 21, 18, 15};
+        } else if (sub->eep_prot_level <= 3 && sub->length > 0) {
             const bool type_b = sub->eep_type == EEP_Type::TYPE_B;
-            const int k = (type_b ? per_unit_b : per_unit_a)[sub->eep_prot_level];
             sc.start_address = sub->start_address;
             sc.length = sub->length;
-            sc.protection_level = sub->eep_prot_level;
+            sc.protection_level = sub->eep_prot_level + 1;       // the ABI counts levels 1..4
             sc.eep_type = type_b ? 1 : 0;
-            sc.bitrate_kbps = (sub->length / k) * (type_b ? 32 : 8);
-            ok = sub->length % k == 0;
+            sc.bitrate_kbps = int(CalculateEEPBitrate(*sub));
+            ok = sc.bitrate_kbps > 0;
         }
         const int idx = ok ? add_subchannel_locked(sc) : -1;
         if (idx < 0) {

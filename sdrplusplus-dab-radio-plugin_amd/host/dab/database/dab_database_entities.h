@@ -9,9 +9,14 @@
 
 typedef uint8_t subchannel_id_t;
 typedef uint8_t service_component_id_t;
+typedef uint8_t programme_id_t;
+typedef uint8_t language_id_t;
+typedef uint8_t country_id_t;
+typedef uint8_t extended_country_id_t;
 
 enum class TransportMode : uint8_t { STREAM_MODE_AUDIO = 0, STREAM_MODE_DATA = 1, FIDC = 2, PACKET_MODE_DATA = 3 };
 enum class AudioServiceType : uint8_t { DAB = 0, DAB_PLUS = 63, UNDEFINED = 255 };   // other ASCTy values are kept as sent
+enum class DataServiceType : uint8_t { UNDEFINED = 0, TRANSPARENT_CHANNEL = 5, MPEG2 = 24, MOT = 60, PROPRIETARY = 63 };
 enum class EEP_Type : uint8_t { TYPE_A = 0, TYPE_B = 1 };
 
 struct EnsembleId {
@@ -69,5 +74,5 @@ struct Subchannel {
     bool is_uep = false;
     uint8_t uep_prot_index = 0;
     EEP_Type eep_type = EEP_Type::TYPE_A;
-    uint8_t eep_prot_level = 0;    // 1..4
+    uint8_t eep_prot_level = 0;    // 0..3 as transmitted (the GUI prints eep_prot_level + 1, render_formatters.cpp:14)
 };

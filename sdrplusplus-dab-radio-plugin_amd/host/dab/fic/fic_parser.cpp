@@ -60,7 +60,7 @@ void FIC_Parser::fig0_1(const uint8_t *d, int n) {
             v.is_uep = false;
             v.eep_type = ((d[i + 2] >> 4) & 7) == 0 ? EEP_Type::TYPE_A : EEP_Type::TYPE_B;
             if (((d[i + 2] >> 4) & 7) > 1) { i += 4; continue; }      // reserved option: not an entry we can use
-            v.eep_prot_level = uint8_t(((d[i + 2] >> 2) & 3) + 1);
+            v.eep_prot_level = uint8_t((d[i + 2] >> 2) & 3);        // 0..3 as transmitted
             v.length = uint16_t(((d[i + 2] & 3) << 8) | d[i + 3]);
             i += 4;
         } else {                                            // short form: UEP table index

@@ -8,6 +8,8 @@
 #include <memory>
 #include <vector>
 #include "dab/database/dab_database_updater.h"
+#include "dab/audio/aac_frame_processor.h"
+#include "dab/constants/subchannel_protection_tables.h"
 #include "utility/lru_cache.h"
 
 #include "app_helpers/app_io_buffers.h"
@@ -92,6 +94,21 @@ int main() {
         up.SetEnsembleLabel("One");
         assert(db.ensemble.label == "One" && up.GetStatistics().nb_conflicts == 1);
         assert(escape_label("a[b]\\\x01") == "a\\x5Bb\\x5D\\x5C\\x01");
+    }
+    // the helpers the reference's formatters call (render_formatters.cpp:18-25); the UEP row comes through the C ABI
+    {
+        Subchannel eep;
+        eep.length = 48; eep.eep_type = EEP_Type::TYPE_A; eep.eep_prot_level = 2;        // "EEP 3-A", 64 kbit/s
+        assert(CalculateEEPBitrate(eep) == 64);
+        eep.length = 42; eep.eep_type = EEP_Type::TYPE_B; eep.eep_prot_level = 1;        // "EEP 2-B", 64 kbit/s
+        assert(CalculateEEPBitrate(eep) == 64);
+        eep.length = 47;
+        assert(CalculateEEPBitrate(eep) == 0);
+        Subchannel uep;
+        uep.is_uep = true; uep.uep_prot_index = 17;                                      // 64 kbit/s level 2: 58 CUs
+        const auto d = GetUEPDescriptor(uep);
+        assert(d.bitrate == 64 && d.protection_level == 2 && d.subchannel_size == 58);
+        assert(mpeg_surround_from_config(1) == MPEG_Surround::SURROUND_51);
     }
     std::puts("host types ok");
     return 0;

@@ -44,7 +44,7 @@ def test_oracle_reads_back_what_the_multiplex_says(ensemble):
     assert sorted(db.subchannels) == [3, 7, 9]
     for (label, sid, scid, option, level, bitrate, start), size in zip(SERVICES, ensemble.sizes):
         s = db.subchannels[scid]
-        assert (s["start_address"], s["length"], s["is_uep"], s["eep_type"], s["eep_prot_level"]) == (start, size, False, option, level)
+        assert (s["start_address"], s["length"], s["is_uep"], s["eep_type"], s["eep_prot_level"]) == (start, size, False, option, level - 1)
         sv = db.services[sid]
         assert sv["label"] == label
         assert sv["components"] == [{"subchannel_id": scid, "transport_mode": 0, "audio_service_type": 63, "is_primary": True}]
@@ -76,7 +76,7 @@ def test_host_parser_other_forms(parser_exe, tmp_path):
     want = FO.parse_fibs(fibs).lines()
     assert got == want
     assert "subchannel id=1 start=0 length=0 uep=1 uep_index=37 eep_type=0 eep_level=0" in got
-    assert "subchannel id=62 start=700 length=90 uep=0 uep_index=0 eep_type=1 eep_level=4" in got
+    assert "subchannel id=62 start=700 length=90 uep=0 uep_index=0 eep_type=1 eep_level=3" in got
     assert not any(l.startswith("subchannel id=5 ") for l in got)
     assert "component service=E0D12345 subchannel=1 tmid=0 ascty=0 primary=1" in got
     assert sum(l.startswith("component") for l in got) == 1

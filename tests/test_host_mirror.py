@@ -41,6 +41,14 @@ def test_reference_dab_module_compiles_unchanged(host_built):
     assert r.returncode == 0, r.stderr[-2000:]
 
 
+@pytest.mark.skipif(not os.path.exists("/root/reference/src/render_formatters.cpp"), reason="reference not mounted")
+def test_reference_render_formatters_compile_unchanged(host_built):
+    """The GUI's entity formatters (Subchannel / TransportMode / AudioServiceType / MPEG_Surround ..., UEP and EEP
+    bit-rate helpers) against the mirror's entities; {fmt} and three name tables are TEST-ONLY declarations."""
+    r = subprocess.run(["make", "-C", HOST, "check_reference_render_formatters"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+
+
 @pytest.mark.gpu
 def test_c_abi_from_plain_c(host_built):
     exe = os.path.join(HOST, "c_abi_smoke")
