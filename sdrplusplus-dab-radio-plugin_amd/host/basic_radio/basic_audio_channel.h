@@ -4,6 +4,7 @@
 // in basic_dab_plus_channel.h.
 #pragma once
 #include <cstdint>
+#include <string_view>
 #include "dab/database/dab_database_entities.h"
 #include "utility/observable.h"
 #include "utility/span.h"
@@ -22,6 +23,8 @@ public:
     void SetIsPlayAudio(bool v) { m_play = v; }
     void SetIsDecodeAudio(bool v) { m_decode = v; }
     void SetIsDecodeData(bool v) { m_data = v; }
+    void StopAll() { m_play = m_decode = m_data = false; }            // render_radio_block.cpp:392-394
+    void RunAll() { m_play = m_decode = m_data = true; }
 
 private:
     bool m_play = false, m_decode = true, m_data = true;
@@ -30,6 +33,10 @@ private:
 class Basic_Audio_Channel {
 public:
     virtual ~Basic_Audio_Channel() = default;
+    // which concrete channel this is (the GUI dispatches on it, /root/reference/src/render_radio_block.cpp:480-487)
+    virtual AudioServiceType GetType() const = 0;
+    // programme-associated text needs the audio decoder's PAD extraction: never set here
+    std::string_view GetDynamicLabel() const { return {}; }
     Basic_Audio_Controls &GetControls() { return m_controls; }
     Observable<BasicAudioParams, tcb::span<const uint8_t>> &OnAudioData() { return m_obs_audio; }
 

@@ -32,7 +32,7 @@ public:
     bool IsRSError() const { return m_rs_error; }
     bool IsAUError() const { return m_au_error; }
     bool IsCodecError() const { return false; }
-    std::string_view GetDynamicLabel() const { return {}; }
+    AudioServiceType GetType() const override { return AudioServiceType::DAB_PLUS; }
     // (index of the unit in its super-frame, units in the super-frame, bytes incl. CRC16); only CRC-clean units
     Observable<int, int, tcb::span<const uint8_t>> &OnAccessUnit() { return m_obs_au; }
     int GetTotalSuperFrames() const { return m_total_superframes; }

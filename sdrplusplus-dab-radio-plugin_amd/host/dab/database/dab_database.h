@@ -13,6 +13,8 @@ struct DAB_Database {
 
 struct DAB_Database_Statistics {           // GetDatabaseStatistics(), render_radio_block.cpp:755
     size_t nb_total = 0;                   // entity fields written
-    size_t nb_updates = 0;                 // of which changed something
+    size_t nb_pending = 0;                 // entities still missing something the FIC has yet to say (label, sub-channel)
+    size_t nb_completed = 0;               // entities that are complete
     size_t nb_conflicts = 0;               // a field that was already set arrived with a different value
+    size_t nb_updates = 0;                 // writes that changed something
 };

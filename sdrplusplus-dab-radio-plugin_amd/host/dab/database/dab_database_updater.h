@@ -8,7 +8,21 @@
 class DAB_Database_Updater {
 public:
     explicit DAB_Database_Updater(DAB_Database &db) : m_db(db) {}
-    const DAB_Database_Statistics &GetStatistics() const { return m_stats; }
+    // pending / completed are recounted from the database on every call
+    const DAB_Database_Statistics &GetStatistics() const {
+        size_t done = (m_have_eid && !m_db.ensemble.label.empty()) ? 1 : 0, all = 1;
+        for (const auto &s : m_db.services) { all++; done += s.label.empty() ? 0 : 1; }
+        for (const auto &c : m_db.service_components) {
+            all++;
+            for (const auto &sc : m_db.subchannels)
+                if (sc.id == c.subchannel_id) { done++; break; }
+        }
+        all += m_db.subchannels.size();
+        done += m_db.subchannels.size();
+        m_stats.nb_completed = done;
+        m_stats.nb_pending = all - done;
+        return m_stats;
+    }
 
     void SetEnsembleId(uint16_t eid) {
         if (!m_have_eid) { m_db.ensemble.id.value = eid; m_have_eid = true; changed(); }
@@ -56,6 +70,6 @@ private:
         else same(dst == v);
     }
     DAB_Database &m_db;
-    DAB_Database_Statistics m_stats;
+    mutable DAB_Database_Statistics m_stats;
     bool m_have_eid = false;
 };

@@ -138,7 +138,7 @@ int main(int argc, char **argv) {
                 if (auto *mp2 = dynamic_cast<Basic_DAB_Channel *>(radio->Get_Audio_Channel(sc.id))) {
                     const auto &ap = mp2->GetAudioParams();
                     std::fprintf(f, "channel subchannel=%d mp2_frames=%d header_errors=%d rate=%u stereo=%d\n", sc.id,
-                                 mp2->GetTotalFrames(), mp2->GetTotalHeaderErrors(), ap ? ap->frequency : 0u,
+                                 mp2->GetTotalFrames(), mp2->GetTotalHeaderErrors(), ap ? ap->sample_rate : 0u,
                                  ap ? int(ap->is_stereo) : 0);
                     continue;
                 }
