@@ -3,7 +3,8 @@
 Stands behind what the reference's BasicRadio does with decoded FIBs (FIG parser + database updater in the absent
 vendor/DAB-Radio sub-module; the GUI reads the result through radio.GetDatabase(),
 /root/reference/src/render_radio_block.cpp:239-306, 490-752).  PARITY UNPINNED: restated from ETSI EN 300 401
-clauses 5.2 (FIB / FIG structure), 6.2.1 (FIG 0/1), 6.3.1 (FIG 0/2), 6.4 (FIG 0/0), 8.1.13-14 (FIG 1/0, 1/1) from
+clauses 5.2 (FIB / FIG structure), 6.2.1 (FIG 0/1), 6.3.1 (FIG 0/2), 6.4 (FIG 0/0), 8.1.3.1 (FIG 0/10),
+8.1.13-14 (FIG 1/0, 1/1) from
 memory; pinned only against this repo's own transmitter.  A field is written once (first value wins), as the
 host-side updater does.
 
@@ -30,6 +31,7 @@ class Database:
         self.ensemble = {"id": None, "label": "", "cif_count": None}
         self.subchannels = {}     # id -> {start_address, length, is_uep, uep_prot_index, eep_type, eep_prot_level}
         self.services = {}        # sid -> {label, components: [{subchannel_id, transport_mode, audio_service_type, is_primary}]}
+        self.datetime = None      # (year, month, day, hours, minutes, seconds, milliseconds) of the last FIG 0/10
 
     def lines(self):
         """Canonical text form, the same the host-side test program prints."""
@@ -47,7 +49,29 @@ class Database:
             for c in sv["components"]:
                 out.append("component service=%04X subchannel=%d tmid=%d ascty=%d primary=%d" % (
                     k, c["subchannel_id"], c["transport_mode"], c["audio_service_type"], int(c["is_primary"])))
+        if self.datetime and self.datetime[0]:
+            out.append("datetime %04d-%02d-%02d %02d:%02d:%02d.%03d cif=%d" % (self.datetime + (self.ensemble["cif_count"] or 0,)))
         return out
+
+
+def mjd_to_ymd(mjd):
+    yp = int((mjd - 15078.2) / 365.25)
+    mp = int((mjd - 14956.1 - int(yp * 365.25)) / 30.6001)
+    day = mjd - 14956 - int(yp * 365.25) - int(mp * 30.6001)
+    k = 1 if mp in (14, 15) else 0
+    return 1900 + yp + k, mp - 1 - 12 * k, day
+
+
+def _fig0_10(d, db):
+    if len(d) < 4:
+        return
+    w = int.from_bytes(bytes(d[:4]), "big")
+    y, m, dd = mjd_to_ymd((w >> 14) & 0x1FFFF)
+    hours, minutes, sec, ms = (w >> 6) & 0x1F, w & 0x3F, 0, 0
+    if (w >> 11) & 1 and len(d) >= 6:
+        sec, ms = d[4] >> 2, ((d[4] & 3) << 8) | d[5]
+    if hours < 24 and minutes < 60 and sec < 61:
+        db.datetime = (y, m, dd, hours, minutes, sec, ms)
 
 
 def _fig0_0(d, db):
@@ -131,6 +155,8 @@ def parse_fib(fib, db):
                 _fig0_1(body[1:], db)
             elif ext == 2:
                 _fig0_2(body[1:], pd, db)
+            elif ext == 10:
+                _fig0_10(body[1:], db)
         elif ftype == 1 and flen >= 21:
             ext = body[0] & 7
             ident = (body[1] << 8) | body[2]

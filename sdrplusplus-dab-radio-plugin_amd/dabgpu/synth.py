@@ -531,6 +531,23 @@ def fig0_2(services):
     return fig0(2, body)
 
 
+def mjd(year, month, day):
+    """Modified Julian date of a calendar date (inverse of the standard's annex formula)."""
+    a = (14 - month) // 12
+    y, m = year + 4800 - a, month + 12 * a - 3
+    jdn = day + (153 * m + 2) // 5 + 365 * y + y // 4 - y // 100 + y // 400 - 32045
+    return jdn - 2400001
+
+
+def fig0_10(year, month, day, hours, minutes, seconds=None, milliseconds=0):
+    """Date and time (clause 8.1.3.1): short form without seconds, long form with seconds and milliseconds."""
+    long_form = seconds is not None
+    body = _bits((0, 1), (mjd(year, month, day), 17), (0, 1), (0, 1), (1 if long_form else 0, 1), (hours, 5), (minutes, 6))
+    if long_form:
+        body += _bits((seconds, 6), (milliseconds, 10))
+    return fig0(10, body)
+
+
 def fig1(ext, ident, label, charset=0):
     text = label.encode("latin-1")[:16].ljust(16, b" ")
     data = _bits((charset, 4), (0, 1), (ext, 3), (ident, 16)) + text + _bits((0xFF00, 16))
@@ -611,6 +628,9 @@ class ServiceEnsemble:
                 figs += [fig0_1(self.subchannels[i:i + 6]) for i in range(0, len(self.subchannels), 6)]
                 figs += [fig0_2(sv[i:i + 5]) for i in range(0, len(sv), 5)]
                 figs.append(labels[k % len(labels)]); k += 1
+                if c == 3:                                    # once per frame: date and time, advancing 96 ms
+                    ms = 96 * f
+                    figs.append(fig0_10(2024, 2, 29, 23, 59, 58 + ms // 1000 if ms < 2000 else 59, ms % 1000))
                 fibs = pack_fibs(figs)
                 assert len(fibs) <= 3, "too many FIGs for one CIF's three FIBs"
                 pad = pack_fibs([fig0_0(eid, 4 * f + c)])

@@ -39,10 +39,12 @@ public:
         m_sources.push_back(std::move(s));
     }
     AudioPipelineSink *get_sink() { return m_sink.get(); }
+    float &get_global_gain() { return m_global_gain; }                 // render_radio_block.cpp:839
     void set_sink(std::unique_ptr<AudioPipelineSink> sink) { m_sink = std::move(sink); }
 
 private:
     std::mutex m_mutex;
     std::vector<std::shared_ptr<AudioPipelineSource>> m_sources;
     std::unique_ptr<AudioPipelineSink> m_sink;
+    float m_global_gain = 1.0f;
 };

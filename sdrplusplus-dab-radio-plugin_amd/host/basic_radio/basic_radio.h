@@ -38,6 +38,7 @@ public:
     // read under GetMutex(), as the GUI does (/root/reference/src/render_radio_block.cpp:124, 158-160, 239, 755)
     DAB_Database &GetDatabase() { return m_database; }
     const DAB_Database_Statistics &GetDatabaseStatistics() const { return m_updater.GetStatistics(); }
+    const DAB_Misc_Info &GetMiscInfo() const { return m_updater.GetMiscInfo(); }     // render_radio_block.cpp:814
     Basic_Audio_Channel *Get_Audio_Channel(subchannel_id_t id) {
         auto it = m_channels.find(id);
         return it == m_channels.end() ? nullptr : it->second.get();

@@ -3,6 +3,7 @@
 // (a corrupted FIB that slipped through the CRC must not rewrite the multiplex).
 #pragma once
 #include <string>
+#include "dab/dab_misc_info.h"
 #include "dab/database/dab_database.h"
 
 class DAB_Database_Updater {
@@ -28,7 +29,13 @@ public:
         if (!m_have_eid) { m_db.ensemble.id.value = eid; m_have_eid = true; changed(); }
         else same(m_db.ensemble.id.value == eid);
     }
-    void SetEnsembleCIFCounter(int v) { m_db.ensemble.cif_counter = v; }
+    void SetEnsembleCIFCounter(uint8_t upper, uint8_t lower) {
+        m_db.ensemble.cif_counter = int(upper) * 250 + int(lower);
+        m_misc.cif_counter.upper_count = upper;
+        m_misc.cif_counter.lower_count = lower;
+    }
+    void SetDateTime(const DAB_Date_Time &dt) { m_misc.datetime = dt; }
+    const DAB_Misc_Info &GetMiscInfo() const { return m_misc; }
     void SetEnsembleLabel(const std::string &label) { set_string(m_db.ensemble.label, label); }
 
     Subchannel &GetSubchannel(subchannel_id_t id, bool *is_new) {
@@ -71,5 +78,6 @@ private:
     }
     DAB_Database &m_db;
     mutable DAB_Database_Statistics m_stats;
+    DAB_Misc_Info m_misc;
     bool m_have_eid = false;
 };

@@ -37,6 +37,7 @@ void FIC_Parser::fig0(const uint8_t *d, int n) {
     case 0: fig0_0(d + 1, n - 1); break;
     case 1: fig0_1(d + 1, n - 1); break;
     case 2: fig0_2(d + 1, n - 1, pd); break;
+    case 10: fig0_10(d + 1, n - 1); break;
     default: break;
     }
 }
@@ -44,7 +45,7 @@ void FIC_Parser::fig0(const uint8_t *d, int n) {
 void FIC_Parser::fig0_0(const uint8_t *d, int n) {
     if (n < 4) return;
     m_updater.SetEnsembleId(uint16_t((d[0] << 8) | d[1]));
-    m_updater.SetEnsembleCIFCounter(int(d[2] & 0x1F) * 250 + int(d[3]));
+    m_updater.SetEnsembleCIFCounter(uint8_t(d[2] & 0x1F), d[3]);
 }
 
 void FIC_Parser::fig0_1(const uint8_t *d, int n) {
@@ -104,6 +105,24 @@ void FIC_Parser::fig0_2(const uint8_t *d, int n, bool pd) {
             }
         }
     }
+}
+
+// FIG 0/10 date and time: Rfu(1) MJD(17) LSI(1) Rfu(1) UTC flag(1), then hours(5) minutes(6) and, in the long
+// form, seconds(6) milliseconds(10)
+void FIC_Parser::fig0_10(const uint8_t *d, int n) {
+    if (n < 4) return;
+    const uint32_t w = (uint32_t(d[0]) << 24) | (uint32_t(d[1]) << 16) | (uint32_t(d[2]) << 8) | d[3];
+    const int mjd = int((w >> 14) & 0x1FFFF);
+    const bool long_form = (w >> 11) & 1;
+    DAB_Date_Time dt;
+    mjd_to_ymd(mjd, dt.year, dt.month, dt.day);
+    dt.hours = uint8_t((w >> 6) & 0x1F);
+    dt.minutes = uint8_t(w & 0x3F);
+    if (long_form && n >= 6) {
+        dt.seconds = uint8_t(d[4] >> 2);
+        dt.milliseconds = uint16_t(((d[4] & 3) << 8) | d[5]);
+    }
+    if (dt.hours < 24 && dt.minutes < 60 && dt.seconds < 61) m_updater.SetDateTime(dt);
 }
 
 void FIC_Parser::fig1(const uint8_t *d, int n) {

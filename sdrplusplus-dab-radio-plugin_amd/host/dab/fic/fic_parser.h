@@ -2,7 +2,8 @@
 // the decoded FIC (absent vendor/DAB-Radio sub-module) so that the GUI can list the multiplex through
 // radio.GetDatabase() (/root/reference/src/render_radio_block.cpp:239-306).  Handles the FIGs a receiver needs to
 // find and decode audio services: 0/0 ensemble, 0/1 sub-channel organisation, 0/2 service organisation,
-// 1/0 and 1/1 labels (ETSI EN 300 401 clauses 5.2, 6.2.1, 6.3.1, 6.4, 8.1.13-14).  Everything else is skipped by
+// 0/10 date and time,
+// 1/0 and 1/1 labels (ETSI EN 300 401 clauses 5.2, 6.2.1, 6.3.1, 6.4, 8.1.3.1, 8.1.13-14).  Everything else is skipped by
 // its length field.
 #pragma once
 #include <cstdint>
@@ -22,6 +23,7 @@ private:
     void fig0_0(const uint8_t *d, int n);
     void fig0_1(const uint8_t *d, int n);
     void fig0_2(const uint8_t *d, int n, bool pd);
+    void fig0_10(const uint8_t *d, int n);
     void fig1(const uint8_t *d, int n);
     DAB_Database_Updater &m_updater;
     int m_total_figs = 0;

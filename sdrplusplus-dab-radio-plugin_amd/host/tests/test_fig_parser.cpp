@@ -32,6 +32,11 @@ int main(int argc, char **argv) {
                 std::printf("component service=%04X subchannel=%d tmid=%d ascty=%d primary=%d\n", unsigned(sv.id.value),
                             c.subchannel_id, int(c.transport_mode), int(c.audio_service_type), int(c.is_primary));
     }
+    const auto &mi = updater.GetMiscInfo();
+    if (mi.datetime.year)
+        std::printf("datetime %04d-%02d-%02d %02u:%02u:%02u.%03u cif=%u\n", mi.datetime.year, mi.datetime.month, mi.datetime.day,
+                    mi.datetime.hours, mi.datetime.minutes, mi.datetime.seconds, mi.datetime.milliseconds,
+                    mi.cif_counter.GetTotalCount());
     std::printf("# fibs_bad_crc=%d figs=%d conflicts=%zu\n", bad, parser.GetTotalFIGs(), updater.GetStatistics().nb_conflicts);
     return 0;
 }

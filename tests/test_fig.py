@@ -50,10 +50,21 @@ def test_oracle_reads_back_what_the_multiplex_says(ensemble):
         assert sv["components"] == [{"subchannel_id": scid, "transport_mode": 0, "audio_service_type": 63, "is_primary": True}]
 
 
+def test_date_time_round_trip():
+    for (y, m, d) in ((2024, 2, 29), (1999, 12, 31), (2000, 1, 1), (2026, 10, 1), (2100, 2, 28)):
+        assert FO.mjd_to_ymd(synth.mjd(y, m, d)) == (y, m, d)
+    assert synth.mjd(1858, 11, 17) == 0 and synth.mjd(2000, 1, 1) == 51544      # known answers
+    db = FO.parse_fibs(synth.pack_fibs([synth.fig0_0(0xC181, 4999), synth.fig0_10(2026, 10, 1, 13, 37, 42, 123)]))
+    assert db.datetime == (2026, 10, 1, 13, 37, 42, 123) and db.lines()[-1] == "datetime 2026-10-01 13:37:42.123 cif=4999"
+    db = FO.parse_fibs(synth.pack_fibs([synth.fig0_10(2026, 10, 1, 13, 37)]))         # short form: no seconds
+    assert db.datetime == (2026, 10, 1, 13, 37, 0, 0)
+
+
 def test_host_parser_equals_oracle(parser_exe, ensemble, tmp_path):
     fibs = ensemble.fibs.reshape(-1, 32).copy()
     got, stats = run_parser(parser_exe, fibs, tmp_path)
     assert got == FO.parse_fibs(fibs).lines()
+    assert got[-1].startswith("datetime 2024-02-29 23:59:5")
     assert "fibs_bad_crc=0" in stats and "conflicts=0" in stats
     # FIBs damaged in transit must be ignored, not half-parsed
     bad = fibs.copy()
@@ -135,7 +146,7 @@ def test_unknown_multiplex_from_iq_to_access_units(built, ensemble, tmp_path):
     assert "frames_desync=0" in r.stdout, r.stdout
     db = open(prefix + ".db").read().splitlines()
     want = FO.parse_fibs(ensemble.fibs.reshape(-1, 32)).lines()
-    assert [l for l in db if not l.startswith("channel")] == want
+    assert [l for l in db if not l.startswith(("channel", "datetime"))] == [l for l in want if not l.startswith("datetime")]
     chans = [l for l in db if l.startswith("channel")]
     assert len(chans) == 3 and all("firecode_error=0" in l and "rs_error=0" in l and "rate=48000 sbr=1 stereo=1" in l for l in chans)
     # access units, per sub-channel, in transmission order
