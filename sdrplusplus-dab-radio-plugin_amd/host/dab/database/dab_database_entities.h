@@ -1,7 +1,7 @@
 // dab/database/dab_database_entities.h -- the part of the reference's database the hot path's callers read:
 // field names as the GUI uses them (/root/reference/src/render_radio_block.cpp:239-306, 490-752;
 // src/render_formatters.cpp:9-25 for Subchannel{is_uep, uep_prot_index, eep_type, eep_prot_level,
-// start_address, length}).  Filled from FIG 0/0, 0/1, 0/2, 1/0, 1/1.
+// start_address, length}).  Filled from FIG 0/0, 0/1, 0/2, 0/10, 1/0, 1/1.
 #pragma once
 #include <cstdint>
 #include <string>
