@@ -35,6 +35,11 @@ using namespace dab;
 namespace {
 
 constexpr int LANE_INIT2 = 2 * 6144;      // doubled start penalty of states != 0
+// staging window of the fused forward pass (K2')
+constexpr int FT = 24;                          // steps per tile (four phase cycles)
+constexpr int FCOLS = 8;                        // 16-byte chunks per staged row (span <= 15 + 4*FT = 111 bytes)
+constexpr int FPITCH = FCOLS * 16 + 4;          // 132 B = 33 dwords (odd); bytes 128..131 stay zero (erased bits)
+constexpr int FERASED = FCOLS * 16;             // column of the always-zero byte
 
 typedef short s2 __attribute__((ext_vector_type(2)));
 
@@ -89,10 +94,16 @@ __host__ __device__ inline LSrcMsc make_msc_src(const MscArgs &a) {
     return LSrcMsc{a.soft, a.soft_stride, a.hist_in, a.frames_per_stream * NB_CIFS, NB_FIC_BITS + a.start_bit, NB_CIF_BITS,
                    a.nbits, -1};
 }
-// delay (in rows of the window) of a punctured bit with descriptor dsc
+// A descriptor is (delay * FPITCH + column) | column << 16: the low half is the window offset of a time-interleaved
+// bit, the high half the column alone for sources without interleaving (delay 0: FIC / plain codewords) or with a
+// forced delay (the FIC riding in a grouped launch: d_force = 15, its own row).  desc_shift / desc_extra pick the
+// half and the constant to add -- wave-uniform, so the per-byte work is one bit-field extract and one add.
 template <class Src>
-__device__ __forceinline__ int delay_rows(const Src &, int) { return 0; }
-__device__ __forceinline__ int delay_rows(const LSrcMsc &s, int dsc) { return s.d_force >= 0 ? s.d_force : (dsc >> 8); }
+__device__ __forceinline__ int desc_shift(const Src &) { return 16; }
+template <class Src>
+__device__ __forceinline__ int desc_extra(const Src &) { return 0; }
+__device__ __forceinline__ int desc_shift(const LSrcMsc &s) { return s.d_force >= 0 ? 16 : 0; }
+__device__ __forceinline__ int desc_extra(const LSrcMsc &s) { return s.d_force >= 0 ? s.d_force * FPITCH : 0; }
 
 // ---------------------------------------------------------------------------------------------------------
 // K1: depuncture (+ time de-interleave) + transpose.  Block = (group of 64 codewords, tile of 64 steps).
@@ -329,10 +340,6 @@ __global__ __launch_bounds__(256) void lane_forward_kernel(const uint32_t *Msoft
 // descriptor table that the scalar unit walks.  Requires that a group of 64 codewords never straddles two streams
 // (CIFs per stream a multiple of 64); other shapes take the prep kernel.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int FT = 24;                          // steps per tile (four phase cycles)
-constexpr int FCOLS = 8;                        // 16-byte chunks per staged row (span <= 15 + 4*FT = 111 bytes)
-constexpr int FPITCH = FCOLS * 16 + 4;          // 132 B = 33 dwords (odd); bytes 128..131 stay zero (erased bits)
-constexpr int FERASED = FCOLS * 16;             // column of the always-zero byte
 
 // row r (0 .. 63+PRE) of the window of the group whose first codeword is cw0 -> first punctured byte, or nullptr
 // for a row that does not exist (reads as erasures)
@@ -401,6 +408,7 @@ __device__ __forceinline__ void lane_forward_fused_body(const Src &src, const in
     // Descriptors of the next six steps are fetched while the current six are worked on: with one wave per SIMD
     // nothing else would hide their latency.  They are deliberately NOT restrict-qualified: as scalar loads they
     // share the LDS counter (lgkmcnt) and every wait for them also drains the window reads (measured slower).
+    const int dsh = desc_shift(src), dex = desc_extra(src);
     int32_t dcur[24], dnxt[24];
 #pragma unroll
     for (int j = 0; j < 24; j++) dcur[j] = desc[j];
@@ -420,7 +428,7 @@ __device__ __forceinline__ void lane_forward_fused_body(const Src &src, const in
 #pragma unroll
                 for (int m = 0; m < 4; m++) {
                     const int dsc = dcur[4 * i + m];                            // wave-uniform: column | delay << 8
-                    const int off = delay_rows(src, dsc) * FPITCH + (dsc & 0xFF);
+                    const int off = int((unsigned(dsc) >> dsh) & 0xFFFFu) + dex;
                     v |= uint32_t(my[off]) << (8 * m);
                 }
                 w[i] = v;
@@ -455,9 +463,13 @@ __global__ __launch_bounds__(256) void lane_forward_fused_kernel(Src src, const 
                             lane);
 }
 
-// Grouped launch (every sub-channel of a multiplex in one launch): the entries sit in device
-// memory, a wave looks up which sub-channel its group belongs to and runs the same body with that entry's
-// parameters.  Codeword lengths differ between entries; nothing else does.
+// Grouped launch (every sub-channel of a multiplex in one launch): a wave looks up which
+// sub-channel its group belongs to and runs the same body with that entry's parameters.  Codeword lengths differ
+// between entries; nothing else does.  The entry table travels BY VALUE in the kernel arguments: the lookup then
+// compiles to scalar loads, every field stays in SGPRs and the pointers are known to be global memory (as a table
+// in device memory they were generic pointers in VGPRs: flat loads/stores that also tick the LDS counter, and a
+// quarter-rate v_mul_lo_u32 per soft byte for the window address).
+constexpr int LANE_GROUP_MAX = 16;        // entries per launch (16 x 112 B of kernel arguments); longer lists are chunked
 struct LaneEntry {
     LSrcMsc src;
     const int32_t *desc, *tiles;
@@ -467,20 +479,25 @@ struct LaneEntry {
     uint2 *dec;
     int nsteps, n_codewords, first_group, groups;
 };
+struct LaneEntryPack {
+    int n;
+    int total_groups;
+    LaneEntry e[LANE_GROUP_MAX];
+};
 
-__device__ __forceinline__ int find_entry(const LaneEntry *entries, int n_entries, int group) {
+__device__ __forceinline__ int find_entry(const LaneEntryPack &pack, int group) {
     int e = 0;
-    while (e + 1 < n_entries && group >= entries[e + 1].first_group) e++;
+    while (e + 1 < pack.n && group >= pack.e[e + 1].first_group) e++;
     return e;
 }
 
-__global__ __launch_bounds__(256) void lane_forward_grouped_kernel(const LaneEntry *entries, int n_entries, int total_groups) {
+__global__ __launch_bounds__(256) void lane_forward_grouped_kernel(const LaneEntryPack pack) {
     extern __shared__ __attribute__((aligned(16))) uint8_t fused_lds[];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     const int group = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv);
-    if (group >= total_groups) return;
-    const LaneEntry &en = entries[find_entry(entries, n_entries, group)];
+    if (group >= pack.total_groups) return;
+    const LaneEntry &en = pack.e[find_entry(pack, group)];
     const LSrcMsc src = en.src;
     lane_forward_fused_body(src, en.desc, en.tiles, en.nsteps, group - en.first_group, en.n_codewords, en.dec,
                             fused_lds + wv * ((64 + LSrcMsc::PRE) * FPITCH), lane);
@@ -583,10 +600,10 @@ __global__ __launch_bounds__(64) void lane_traceback_kernel(const uint2 *dec, in
     lane_traceback_body(dec, nsteps, n_codewords, blockIdx.x, prbs_bytes, out, crc_ok, tile, threadIdx.x);
 }
 
-__global__ __launch_bounds__(64) void lane_traceback_grouped_kernel(const LaneEntry *entries, int n_entries) {
+__global__ __launch_bounds__(64) void lane_traceback_grouped_kernel(const LaneEntryPack pack) {
     extern __shared__ uint32_t tile[];                        // sized for the longest entry
     const int group = blockIdx.x;
-    const LaneEntry &en = entries[find_entry(entries, n_entries, group)];
+    const LaneEntry &en = pack.e[find_entry(pack, group)];
     lane_traceback_body(en.dec, en.nsteps, en.n_codewords, group - en.first_group, en.prbs, en.out, en.crc_ok, tile,
                         threadIdx.x);
 }
@@ -684,63 +701,62 @@ static size_t item_codewords(const LaneGroupItem &it) {
 size_t lane_group_scratch_bytes(const LaneGroupItem *items, int n) {
     size_t total = 0;
     for (int i = 0; i < n; i++) total += ((item_codewords(items[i]) + 63) / 64) * 64 * size_t(items[i].code.nsteps) * sizeof(uint2);
-    return total + size_t(n) * sizeof(LaneEntry) + 512;
+    return total + 512;
 }
 
 hipError_t launch_lane_group(const LaneGroupItem *items, int n, const LaneScratch &sc, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     if (!sc.base || sc.bytes < lane_group_scratch_bytes(items, n)) return hipErrorInvalidValue;
-    std::vector<LaneEntry> entries(static_cast<size_t>(n));
-    // scratch: entry table first (256-byte aligned block), then every entry's survivor store
     char *p = static_cast<char *>(sc.base);
-    LaneEntry *d_entries = reinterpret_cast<LaneEntry *>(p);
-    p += (size_t(n) * sizeof(LaneEntry) + 255) & ~size_t(255);
-    int total_groups = 0, max_nwords = 0;
-    for (int i = 0; i < n; i++) {
-        const LaneGroupItem &it = items[i];
-        const MscArgs &a = it.args;
-        if (!it.tables.fused_desc || !it.tables.fused_tiles || !lane_supported(it.code.nsteps)) return hipErrorInvalidValue;
-        LaneEntry &e = entries[size_t(i)];
-        e.n_codewords = int(item_codewords(it));
-        if (it.is_fic) {
-            // the FIC as one more entry: four 2304-bit groups per frame, no interleaving (every bit "delay 15" = the
-            // codeword's own row), never a history row
-            if (!aligned16(a.soft, a.soft_stride) || (reinterpret_cast<uintptr_t>(a.out) & 3)) return hipErrorInvalidValue;
-            e.src = LSrcMsc{a.soft, a.soft_stride, nullptr, e.n_codewords + 128, 0, NB_FIC_GROUP_BITS, NB_FIC_GROUP_BITS, 15};
-        } else {
-            if (!lane_group_fusable(a)) return hipErrorInvalidValue;
-            e.src = make_msc_src(a);
+    for (int i0 = 0; i0 < n; i0 += LANE_GROUP_MAX) {
+        LaneEntryPack pack{};
+        pack.n = std::min(LANE_GROUP_MAX, n - i0);
+        int max_nwords = 0;
+        for (int i = 0; i < pack.n; i++) {
+            const LaneGroupItem &it = items[i0 + i];
+            const MscArgs &a = it.args;
+            if (!it.tables.fused_desc || !it.tables.fused_tiles || !lane_supported(it.code.nsteps)) return hipErrorInvalidValue;
+            LaneEntry &e = pack.e[i];
+            e.n_codewords = int(item_codewords(it));
+            if (it.is_fic) {
+                // the FIC as one more entry: four 2304-bit groups per frame, no interleaving (every bit "delay 15" =
+                // the codeword's own row), never a history row
+                if (!aligned16(a.soft, a.soft_stride) || (reinterpret_cast<uintptr_t>(a.out) & 3)) return hipErrorInvalidValue;
+                e.src = LSrcMsc{a.soft, a.soft_stride, nullptr, e.n_codewords + 128, 0, NB_FIC_GROUP_BITS, NB_FIC_GROUP_BITS, 15};
+            } else {
+                if (!lane_group_fusable(a)) return hipErrorInvalidValue;
+                e.src = make_msc_src(a);
+            }
+            e.desc = it.tables.fused_desc;
+            e.tiles = it.tables.fused_tiles;
+            e.prbs = it.code.prbs_bytes;
+            e.out = a.out;
+            e.crc_ok = it.is_fic ? it.crc_ok : nullptr;
+            e.dec = reinterpret_cast<uint2 *>(p);
+            e.nsteps = it.code.nsteps;
+            e.first_group = pack.total_groups;
+            e.groups = (e.n_codewords + 63) / 64;
+            pack.total_groups += e.groups;
+            p += size_t(e.groups) * 64 * size_t(e.nsteps) * sizeof(uint2);
+            max_nwords = std::max(max_nwords, (e.nsteps - 6) >> 5);
         }
-        e.desc = it.tables.fused_desc;
-        e.tiles = it.tables.fused_tiles;
-        e.prbs = it.code.prbs_bytes;
-        e.out = a.out;
-        e.crc_ok = it.is_fic ? it.crc_ok : nullptr;
-        e.dec = reinterpret_cast<uint2 *>(p);
-        e.nsteps = it.code.nsteps;
-        e.first_group = total_groups;
-        e.groups = (e.n_codewords + 63) / 64;
-        total_groups += e.groups;
-        p += size_t(e.groups) * 64 * size_t(e.nsteps) * sizeof(uint2);
-        max_nwords = std::max(max_nwords, (e.nsteps - 6) >> 5);
+        const unsigned fgrid = unsigned((pack.total_groups + 3) / 4);
+        const size_t lds = balanced_lds_bytes(fgrid, size_t(4) * (64 + LSrcMsc::PRE) * FPITCH, 3);
+        hipError_t err;
+        if (lds > 64 * 1024) {
+            err = hipFuncSetAttribute(reinterpret_cast<const void *>(lane_forward_grouped_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+            if (err != hipSuccess) return err;
+        }
+        hipLaunchKernelGGL(lane_forward_grouped_kernel, dim3(fgrid), dim3(256), lds, s, pack);
+        const size_t tb_lds = size_t(64) * (max_nwords | 1) * 4;
+        if (tb_lds > 64 * 1024) {
+            err = hipFuncSetAttribute(reinterpret_cast<const void *>(lane_traceback_grouped_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, int(tb_lds));
+            if (err != hipSuccess) return err;
+        }
+        hipLaunchKernelGGL(lane_traceback_grouped_kernel, dim3(unsigned(pack.total_groups)), dim3(64), tb_lds, s, pack);
     }
-    hipError_t err = hipMemcpyAsync(d_entries, entries.data(), size_t(n) * sizeof(LaneEntry), hipMemcpyHostToDevice, s);
-    if (err != hipSuccess) return err;
-    const unsigned fgrid = unsigned((total_groups + 3) / 4);
-    const size_t lds = balanced_lds_bytes(fgrid, size_t(4) * (64 + LSrcMsc::PRE) * FPITCH, 3);
-    if (lds > 64 * 1024) {
-        err = hipFuncSetAttribute(reinterpret_cast<const void *>(lane_forward_grouped_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-        if (err != hipSuccess) return err;
-    }
-    hipLaunchKernelGGL(lane_forward_grouped_kernel, dim3(fgrid), dim3(256), lds, s, d_entries, n, total_groups);
-    const size_t tb_lds = size_t(64) * (max_nwords | 1) * 4;
-    if (tb_lds > 64 * 1024) {
-        err = hipFuncSetAttribute(reinterpret_cast<const void *>(lane_traceback_grouped_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, int(tb_lds));
-        if (err != hipSuccess) return err;
-    }
-    hipLaunchKernelGGL(lane_traceback_grouped_kernel, dim3(unsigned(total_groups)), dim3(64), tb_lds, s, d_entries, n);
     return hipGetLastError();
 }
 
@@ -749,7 +765,7 @@ void build_lane_fused_tables(const uint8_t *mask, int nsteps, std::vector<int32_
     for (int p = 0, j = 0; p < 4 * nsteps; p++)
         if (mask[p]) idx[p] = j++;
     const int ntiles = (nsteps + FT - 1) / FT;
-    desc.assign(size_t(4) * nsteps, FERASED);
+    desc.assign(size_t(4) * nsteps, FERASED | (FERASED << 16));
     tiles.assign(size_t(2) * ntiles, 0);
     for (int tile = 0; tile < ntiles; tile++) {
         const int p0 = 4 * FT * tile, p1 = std::min(4 * nsteps, p0 + 4 * FT);
@@ -763,7 +779,8 @@ void build_lane_fused_tables(const uint8_t *mask, int nsteps, std::vector<int32_
         for (int p = p0; p < p1; p++) {
             if (idx[p] < 0) continue;
             unsigned i = unsigned(idx[p]) & 15u, d = ((i & 1) << 3) | ((i & 2) << 1) | ((i & 4) >> 1) | ((i & 8) >> 3);
-            desc[p] = (idx[p] - lo_al) | int(d << 8);
+            const int col = idx[p] - lo_al;
+            desc[p] = (int(d) * FPITCH + col) | (col << 16);
         }
     }
 }
