@@ -51,6 +51,7 @@ struct dabgpu_ctx {
     int8_t *d_prs_qt = nullptr;
     uint16_t *d_sync_pairs = nullptr;
     int n_sync_pairs = 0;
+    float2 *d_sync_fs = nullptr;         // FFT of the PRS's adjacent-carrier differential (coarse search by FFT)
     DeviceCode fic;
     std::map<std::vector<uint8_t>, std::unique_ptr<DeviceCode>> codes;   // keyed by puncture mask
     // staging for the host-pointer entry points
@@ -337,6 +338,31 @@ int dabgpu_create(const dabgpu_cfg *cfg, dabgpu_ctx **out) {
             ctx->n_sync_pairs = int(pairs.size());
             if ((rc = upload(&ctx->d_prs_qt, qt))) break;
             if ((rc = upload(&ctx->d_sync_pairs, pairs))) break;
+            // spectrum of S[b] = j^s on the pair bins: a 2048-point radix-2 FFT in double on the host (once per context)
+            std::vector<double> fr(NB_FFT, 0.0), fi(NB_FFT, 0.0);
+            {
+                static const double SR[4] = {1, 0, -1, 0}, SI[4] = {0, 1, 0, -1};
+                for (uint16_t pr : pairs) {
+                    int b = pr & 2047, rev = 0;
+                    for (int bit = 0; bit < 11; bit++) rev |= ((b >> bit) & 1) << (10 - bit);      // bit-reversed input order
+                    fr[rev] = SR[pr >> 11];
+                    fi[rev] = SI[pr >> 11];
+                }
+                for (int len = 2; len <= NB_FFT; len <<= 1) {
+                    const double ang = -2.0 * M_PI / double(len);
+                    for (int i = 0; i < NB_FFT; i += len)
+                        for (int j = 0; j < len / 2; j++) {
+                            const double wr = std::cos(ang * j), wi = std::sin(ang * j);
+                            const int p0 = i + j, p1 = i + j + len / 2;
+                            const double tr = fr[p1] * wr - fi[p1] * wi, ti = fr[p1] * wi + fi[p1] * wr;
+                            fr[p1] = fr[p0] - tr; fi[p1] = fi[p0] - ti;
+                            fr[p0] += tr; fi[p0] += ti;
+                        }
+                }
+            }
+            std::vector<float2> fs(NB_FFT);
+            for (int m = 0; m < NB_FFT; m++) fs[m] = make_float2(float(fr[m]), float(fi[m]));
+            if ((rc = upload(&ctx->d_sync_fs, fs))) break;
         }
         ctx->fic.prof = make_fic_profile();
         if (ctx->fic.prof.nsteps != NB_FIC_STEPS || ctx->fic.prof.n_punct != NB_FIC_GROUP_BITS) { rc = DABGPU_ERR_PROFILE; break; }
@@ -356,6 +382,7 @@ void dabgpu_destroy(dabgpu_ctx *ctx) {
     if (ctx->d_n_of_vj) (void)hipFree(ctx->d_n_of_vj);
     if (ctx->d_prs_qt) (void)hipFree(ctx->d_prs_qt);
     if (ctx->d_sync_pairs) (void)hipFree(ctx->d_sync_pairs);
+    if (ctx->d_sync_fs) (void)hipFree(ctx->d_sync_fs);
     free_device_code(ctx->fic);
     for (auto &kv : ctx->codes) free_device_code(*kv.second);
     for (void *p : ctx->d_stage) if (p) (void)hipFree(p);
@@ -549,7 +576,7 @@ int dabgpu_sync_prs_dev(dabgpu_ctx *ctx, const void *d_iq, size_t frame_stride, 
     if (n_frames > 1 && frame_stride < size_t(NB_SYM_PERIOD)) return DABGPU_ERR_ARG;
     if (n_frames == 0) return DABGPU_OK;
     hipStream_t s = pick_stream(ctx, stream);
-    dabk::SyncTables tab{ctx->d_twiddle, ctx->d_prs_qt, ctx->d_sync_pairs, ctx->n_sync_pairs};
+    dabk::SyncTables tab{ctx->d_twiddle, ctx->d_prs_qt, ctx->d_sync_pairs, ctx->n_sync_pairs, ctx->d_sync_fs};
     HIP_TRY(dabk::launch_prs_sync(tab, static_cast<const float2 *>(d_iq), frame_stride, n_frames, d_freq_offset,
                                   max_coarse, reinterpret_cast<dabk::SyncResult *>(d_out), s));
     return DABGPU_OK;
@@ -632,7 +659,7 @@ int dabgpu_acquire_dev(dabgpu_ctx *ctx, const void *d_iq, size_t stream_stride, 
     a.cands = reinterpret_cast<int64_t *>(static_cast<char *>(ctx->d_acq_scratch) + l1_bytes);
     a.out = reinterpret_cast<dabk::AcquiredFrame *>(d_out);
     a.counts = d_counts;
-    dabk::SyncTables tab{ctx->d_twiddle, ctx->d_prs_qt, ctx->d_sync_pairs, ctx->n_sync_pairs};
+    dabk::SyncTables tab{ctx->d_twiddle, ctx->d_prs_qt, ctx->d_sync_pairs, ctx->n_sync_pairs, ctx->d_sync_fs};
     HIP_TRY(dabk::launch_acquire(tab, a, s));
     return DABGPU_OK;
 }

@@ -45,6 +45,7 @@ struct SyncTables {
     const int8_t *prs_qt;      // [2048] quarter turns of the PRS per bin, -1 = not a carrier
     const uint16_t *pairs;     // [n_pairs] adjacent carrier pairs: bin | ((qt[bin+1]-qt[bin])&3) << 11
     int n_pairs;
+    const float2 *pair_spectrum;   // [2048] FFT of S[b] = R[b+1] conj R[b] on carrier pairs (0 elsewhere): coarse search by FFT
 };
 struct SyncResult {            // == dabgpu_sync_result
     int32_t coarse_carriers;

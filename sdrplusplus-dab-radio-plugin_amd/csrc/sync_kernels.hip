@@ -28,6 +28,7 @@ struct SyncLds {
     float2 tw[NB_FFT];
     float2 t1[NB_FFT];
     float2 x[NB_FFT];
+    float2 y[NB_FFT];           // coarse search: spectrum of Q, then the correlation over all 2048 shifts
     int8_t qt[NB_FFT];          // quarter turns of the PRS per bin, -1 = not a carrier
     float red_m[WG];
     int red_i[WG];
@@ -138,23 +139,29 @@ __global__ __launch_bounds__(WG) void prs_sync_kernel(SyncTables tab, const floa
         sm.t1[b] = cmulc(sm.x[(b + 1) & (NB_FFT - 1)], sm.x[b]);
     }
     __syncthreads();
-    // ---- coarse frequency: scan k = -max..+max, this thread takes every 256th candidate ----
+    // ---- coarse frequency: D_k = sum_b Q[b+k] conj S[b] for ALL shifts at once as a circular correlation,
+    //      D = IFFT(FFT(Q) conj FFT(S)); FFT(S) is a table, |IFFT(Z)| = |FFT(conj Z)| (the common 1/N does not
+    //      change a peak-to-mean ratio).  Two more transforms instead of (2 max + 1) x 1535 complex adds. ----
+    {
+        float2 v[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) v[r] = sm.t1[tid + r * WG];
+        __syncthreads();                                       // t1 is the transform's scratch from here on
+        block_fft2048(v, sm.t1, sm.y, sm.tw, tid);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int b = tid + r * WG;
+            const float2 z = cmulc(sm.y[b], tab.pair_spectrum[b]);
+            v[r] = make_float2(z.x, -z.y);
+        }
+        __syncthreads();
+        block_fft2048(v, sm.t1, sm.y, sm.tw, tid);
+    }
     float my_m = -1.0f, my_s = 0.0f;
     int my_k = 0x7fffffff;
     for (int idx = tid; idx <= 2 * max_coarse; idx += WG) {
-        const int k = idx - max_coarse;
-        float dr = 0.f, di = 0.f;
-        for (int e = 0; e < tab.n_pairs; e++) {
-            const unsigned pr = tab.pairs[e];                      // bin | s << 11 (wave-uniform load)
-            const float2 q = sm.t1[(int(pr & 2047u) + k) & (NB_FFT - 1)];
-            switch (pr >> 11) {
-            case 0: dr += q.x; di += q.y; break;
-            case 1: dr += q.y; di -= q.x; break;
-            case 2: dr -= q.x; di -= q.y; break;
-            default: dr -= q.y; di += q.x; break;
-            }
-        }
-        const float m = dr * dr + di * di;
+        const float2 d = sm.y[(idx - max_coarse) & (NB_FFT - 1)];
+        const float m = d.x * d.x + d.y * d.y;
         my_s += m;
         if (m > my_m) { my_m = m; my_k = idx; }
     }
@@ -251,7 +258,17 @@ __global__ __launch_bounds__(64) void null_dip_kernel(AcquireArgs a, int64_t nb)
     const int lane = threadIdx.x;
     const float *l1 = a.l1 + size_t(st) * nb;
     double acc = 0.0;
-    for (int64_t b = lane; b < nb; b += 64) acc += double(l1[b]);
+    {   // same order of additions as the plain loop; eight loads in flight (one wave per stream: latency is all there is)
+        int64_t b = lane;
+        for (; b + 7 * 64 < nb; b += 8 * 64) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = l1[b + 64 * j];
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc += double(v[j]);
+        }
+        for (; b < nb; b += 64) acc += double(l1[b]);
+    }
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) acc += __shfl_xor(acc, off);
     const float avg = float(acc / double(nb));
@@ -260,9 +277,21 @@ __global__ __launch_bounds__(64) void null_dip_kernel(AcquireArgs a, int64_t nb)
     int count = 0, state = 0;
     int64_t dip_begin = 0;
     int64_t *cands = a.cands + size_t(st) * a.max_out;
+    constexpr int AHEAD = 8;                                   // trips fetched together
+    float vbuf[AHEAD];
     for (int64_t base = 0; base < nb && count < a.max_out; base += 64) {
+        const int slot = int((base >> 6) % AHEAD);
+        if (slot == 0) {
+#pragma unroll
+            for (int j = 0; j < AHEAD; j++) {
+                const int64_t bj = base + 64 * j + lane;
+                vbuf[j] = bj < nb ? l1[bj] : 0.0f;
+            }
+        }
         const int64_t b = base + lane;
-        const float v = b < nb ? l1[b] : 0.0f;
+        float v = vbuf[0];
+#pragma unroll
+        for (int j = 1; j < AHEAD; j++) v = (slot == j) ? vbuf[j] : v;
         const unsigned long long low = __ballot(b < nb && v < ts);
         const unsigned long long high = __ballot(b < nb && v > te);
         int pos = 0;                                            // wave-uniform walk over this trip's events
