@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DABGPU_ABI_VERSION 1
+#define DABGPU_ABI_VERSION 2
 
 typedef enum dabgpu_status {
     DABGPU_OK = 0,
@@ -100,9 +100,17 @@ typedef struct dabgpu_cfg {
     int32_t max_frames;      /* largest n_frames any call will pass (scratch sizing)  */
     int32_t transmission_mode; /* must be 1                                           */
     int32_t flags;           /* DABGPU_FLAG_*                                         */
+    int32_t ofdm_symbol_runs;  /* front end: cut every frame into this many runs of    */
+                             /* consecutive symbols (one wavefront each), 1..75;      */
+                             /* 0 = chosen from the batch size                        */
+    int32_t reserved[3];     /* must be 0                                             */
 } dabgpu_cfg;
 
+/* Which kernels decode (results are identical; the default picks by batch size).  Meant for tests and timing. */
 #define DABGPU_FLAG_NONE 0
+#define DABGPU_FLAG_VITERBI_WAVE  (1 << 0) /* channel decoder: one wavefront per codeword, always              */
+#define DABGPU_FLAG_VITERBI_LANE  (1 << 1) /* one codeword per lane wherever the length allows, any batch size */
+#define DABGPU_FLAG_LANE_UNFUSED  (1 << 2) /* lane decoder: separate depuncture pass before the forward pass   */
 
 /* Replaces the construction in Radio_Block::Radio_Block
  * (/root/reference/src/radio_block.cpp:11-22: params + PRS + mapper + OFDM_Demod). */
@@ -110,6 +118,8 @@ int  dabgpu_create(const dabgpu_cfg *cfg, dabgpu_ctx **out);
 void dabgpu_destroy(dabgpu_ctx *ctx);
 const char *dabgpu_strerror(int status);
 int  dabgpu_abi_version(void);
+/* Entry points make cfg.device current for the duration of the call and restore the caller's device afterwards: a
+ * process may hold contexts on several GPUs. */
 /* block until everything enqueued on the context's own stream has finished */
 int  dabgpu_sync(dabgpu_ctx *ctx);
 /* the context's own hipStream_t (as void*) */
@@ -151,10 +161,66 @@ int dabgpu_ofdm_demod_frames_dev(dabgpu_ctx *ctx, const void *d_iq, size_t frame
 int dabgpu_ofdm_demod_frames(dabgpu_ctx *ctx, const float *iq, size_t frame_stride, int n_frames,
                              const float *freq_offset, int8_t *soft, float *cyc, float *dqpsk);
 
+/* ------------------------------------------------------------------------ */
+/* Closed-loop front end: per-stream tracking state kept in device memory.    */
+/* Replaces the fine-frequency loop of OFDM_Demod and the scalars the GUI      */
+/* reads from it: GetFineFrequencyOffset / GetCoarseFrequencyOffset /          */
+/* GetNetFrequencyOffset / GetSignalAverage / GetTotalFramesRead /             */
+/* GetTotalFramesDesync and fine_freq_update_beta                              */
+/*   (/root/reference/src/render_radio_block.cpp:202-207, :216).               */
+/*                                                                            */
+/* A context owns `n_streams` states (dabgpu_streams_reset).  The stream call  */
+/* demodulates frames_per_stream consecutive frames of every stream with the   */
+/* stream's current fine + coarse offset -- no host-supplied frequency -- and  */
+/* then, on the device and in stream order, moves the fine offset by           */
+/* -beta * (mean angle of the frames' cyclic-prefix correlations)/(2*pi*2048), */
+/* kept within +-half a carrier; the next call uses the new value.  Frame      */
+/* (s, f) starts at iq + (s*frames_per_stream + f)*frame_stride.               */
+/* cyc may be NULL (the library keeps the correlations in its own scratch).    */
+/* ------------------------------------------------------------------------ */
+typedef struct dabgpu_stream_state {      /* DEVICE memory, 32 bytes */
+    float fine_freq_offset;               /* cycles/sample, within +-0.5/2048                     */
+    float coarse_freq_offset;             /* cycles/sample (whole carriers: -k/2048)              */
+    float signal_average;                 /* running mean of |re|+|im| per sample                 */
+    float last_fine_error;                /* residual the most recent call measured, cycles/sample */
+    int32_t total_frames_read;
+    int32_t total_frames_desync;          /* frames whose level fell below thresh_null_start x average */
+    int32_t reserved[2];
+} dabgpu_stream_state;
+
+typedef struct dabgpu_stats {             /* HOST copy with the derived fields the GUI prints */
+    int32_t state;                        /* OFDM_Demod::State value: 0 before the first frame, 4 = READING_SYMBOLS */
+    float fine_freq_offset;
+    float coarse_freq_offset;
+    float net_freq_offset;
+    float signal_average;
+    int32_t total_frames_read;
+    int32_t total_frames_desync;
+    float last_fine_error;
+} dabgpu_stats;
+
+/* (re)create the context's stream states, all zero */
+int dabgpu_streams_reset(dabgpu_ctx *ctx, int n_streams);
+/* the states in device memory ([n_streams]), e.g. to seed them from a kernel of the caller's; NULL before a reset */
+dabgpu_stream_state *dabgpu_stream_states(dabgpu_ctx *ctx);
+/* host-side setter (synchronises the context stream): NULL = leave that offset as it is.  The host mirror stores the
+ * coarse offset found at acquisition here (is_coarse_freq_correction, src/render_radio_block.cpp:215). */
+int dabgpu_set_stream_offsets(dabgpu_ctx *ctx, int stream_index, const float *fine, const float *coarse);
+int dabgpu_ofdm_demod_streams_dev(dabgpu_ctx *ctx, const void *d_iq, size_t frame_stride, int n_streams,
+                                  int frames_per_stream, float fine_freq_update_beta, int8_t *d_soft, void *d_cyc,
+                                  void *d_dqpsk, void *stream);
+int dabgpu_ofdm_demod_streams(dabgpu_ctx *ctx, const float *iq, size_t frame_stride, int n_streams,
+                              int frames_per_stream, float fine_freq_update_beta, int8_t *soft, float *cyc,
+                              float *dqpsk);
+/* the seven scalars of src/render_radio_block.cpp:192-207 for one stream (synchronises the context stream) */
+int dabgpu_get_stats(dabgpu_ctx *ctx, int stream_index, dabgpu_stats *out);
+
 /* Soft-bit selection (batch receivers that decode the FIC and a few sub-channels and never look at the rest of the
  * frame): from the next call on, dabgpu_ofdm_demod_frames[_dev] and dabgpu_ofdm_demod_acquired_dev of this context
- * write only the listed parts of each frame's 230400 soft bits and leave the other bytes of `soft` untouched
- * (every symbol is still transformed and used as the next one's differential reference).  The reference's
+ * write only the listed parts of each frame's 230400 soft bits and leave the other bytes of `soft` untouched -- in
+ * device memory and, for the host-pointer call, in the caller's host buffer (only the selected ranges are copied
+ * back).  Symbols that carry no selected bit and are not the differential reference of one that does are not
+ * transformed at all (their cyclic-prefix correlation is still produced when `cyc` is asked for).  The reference's
  * OFDM_Demod always emits whole frames (/root/reference/src/radio_block.cpp:25); its BasicRadio then reads the
  * FIC and the selected sub-channels only (:42) -- this moves that choice in front of the 230 kB store.
  *   ranges    frame-bit coordinates [first, first+count), both multiples of 16, inside 0..230400
@@ -338,6 +404,13 @@ int dabgpu_decode_frames_dev(dabgpu_ctx *ctx, const int8_t *d_soft, size_t soft_
                              int frames_per_stream, uint8_t *d_fib, uint8_t *d_crc_ok, const dabgpu_subchannel *sc,
                              int n_subchannels, const int8_t *const *d_history_in, int8_t *const *d_history_out,
                              uint8_t *const *d_out, void *stream);
+
+/* Host-pointer form for the plugin's one-frame-at-a-time use (BasicRadio::Process, src/radio_block.cpp:42): the
+ * frames are uploaded ONCE, the FIC and every sub-channel are decoded from that copy, the results come back in one
+ * batch of copies, one synchronisation.  history_in / history_out / out are HOST arrays of HOST pointers. */
+int dabgpu_decode_frames(dabgpu_ctx *ctx, const int8_t *soft, size_t soft_stride, int n_streams, int frames_per_stream,
+                         uint8_t *fib, uint8_t *crc_ok, const dabgpu_subchannel *sc, int n_subchannels,
+                         const int8_t *const *history_in, int8_t *const *history_out, uint8_t *const *out);
 
 /* ------------------------------------------------------------------------ */
 /* DAB+ audio super-frame: Fire code, RS(120,110), AU CRC.    */

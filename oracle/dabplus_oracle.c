@@ -163,7 +163,11 @@ void oracle_dabplus_superframe(uint8_t *sf, int s, int32_t status[5], int32_t au
     }
     status[1] = corrected;
     status[2] = bad;
-    status[0] = oracle_firecode(sf + 2, 9) == (((unsigned)sf[0] << 8) | sf[1]);
+    {   /* an all-zero header matches its own (zero) check word: not a super-frame */
+        unsigned any = 0;
+        for (int i = 0; i < 11; i++) any |= sf[i];
+        status[0] = any != 0 && oracle_firecode(sf + 2, 9) == (((unsigned)sf[0] << 8) | sf[1]);
+    }
     status[3] = 0;
     status[4] = 0;
     memset(au_start, 0, sizeof(int32_t) * 8);

@@ -194,6 +194,35 @@ def ofdm_demod_frame(iq, freq_offset=0.0, want_spectra=False, want_cyc=False, wa
     return soft, spectra, cyc, dq
 
 
+def stream_update(state, cyc, iq_last_frame, beta, thr_null_start=0.35):
+    """Restatement of the fine-frequency loop and counters of the stream call (TEST INFRASTRUCTURE; parity unpinned:
+    the loop runs inside the absent DAB-Radio OFDM_Demod, its existence and knobs are visible at
+    /root/reference/src/render_radio_block.cpp:202-207, :216).  state: dict with fine_freq_offset,
+    coarse_freq_offset, signal_average, total_frames_read, total_frames_desync; cyc: complex [frames][76];
+    iq_last_frame: the stream's most recent frame from its first PRS sample.  Returns the new dict."""
+    n = cyc.size
+    frames = cyc.shape[0]
+    err = np.float32(np.angle(cyc.astype(np.complex128)).sum() / n / (2.0 * np.pi * 2048.0))
+    half = np.float32(0.5 / 2048.0)
+    f = np.float32(state["fine_freq_offset"]) - np.float32(beta) * err
+    if f > half:
+        f -= 2 * half
+    if f < -half:
+        f += 2 * half
+    x = np.asarray(iq_last_frame[:4096])
+    l1 = np.float32((np.abs(x.real).astype(np.float64) + np.abs(x.imag).astype(np.float64)).sum() / 4096.0)
+    new = dict(state)
+    new["fine_freq_offset"] = np.float32(f)
+    new["last_fine_error"] = err
+    if state["signal_average"] > 0 and l1 < thr_null_start * state["signal_average"]:
+        new["total_frames_desync"] = state["total_frames_desync"] + 1
+        new["total_frames_read"] = state["total_frames_read"] + frames - 1
+    else:
+        new["total_frames_read"] = state["total_frames_read"] + frames
+        new["signal_average"] = np.float32(0.95 * state["signal_average"] + 0.05 * l1) if state["signal_average"] > 0 else l1
+    return new
+
+
 def bench_frames(iq, freq_offset, total, threads, mask, nsteps, sc_bits):
     """Wall seconds for `total` frames of the whole per-frame hot path over `threads` pthreads.
     iq: complex64 [n_frames][76*2552]."""

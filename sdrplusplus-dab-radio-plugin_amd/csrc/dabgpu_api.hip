@@ -66,11 +66,31 @@ struct dabgpu_ctx {
     size_t acq_scratch_bytes = 0;
     void *d_lane_scratch = nullptr;      // work buffers of the codeword-per-lane Viterbi
     size_t lane_scratch_bytes = 0;
-    int lane_mode = -1;                  // DABGPU_VITERBI_LANE: 1 force, 0 never, -1 by batch size
+    int lane_mode = -1;                  // 1 = DABGPU_FLAG_VITERBI_LANE, 0 = DABGPU_FLAG_VITERBI_WAVE, -1 by batch size
+    bool lane_unfused = false;           // DABGPU_FLAG_LANE_UNFUSED
     int wave_slots = 3072;       // resident OFDM wavefronts: 12 per CU
+    std::vector<dabgpu_bit_range> keep_ranges;           // the current selection, merged, for the host-pointer copy-back
+    dabk::StreamState *d_states = nullptr;               // per-stream tracking state (dabgpu_streams_reset)
+    int n_states = 0;
+    float thr_null_start = 0.35f;        // desync threshold of the stream call (null_l1_search.thresh_null_start)
 };
 
 namespace {
+
+// Makes the context's device current for the duration of an entry point and restores the caller's afterwards:
+// allocations, copies and launches of a context must never land on whatever device the calling thread last used.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(const dabgpu_ctx *ctx) {
+        if (ctx && hipGetDevice(&prev) == hipSuccess && prev != ctx->device) switched = hipSetDevice(ctx->device) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
 
 #define HIP_TRY(expr)                               \
     do {                                            \
@@ -203,6 +223,7 @@ bool use_lane(dabgpu_ctx *ctx, int nsteps, int n_codewords, hipStream_t s, dabk:
     }
     sc->base = ctx->d_lane_scratch;
     sc->bytes = ctx->lane_scratch_bytes;
+    sc->unfused = ctx->lane_unfused;
     return true;
 }
 
@@ -286,24 +307,33 @@ int dabgpu_create(const dabgpu_cfg *cfg, dabgpu_ctx **out) {
     if (!cfg || !out) return DABGPU_ERR_ARG;
     *out = nullptr;
     if (cfg->transmission_mode != 1) return DABGPU_ERR_PROFILE;
+    constexpr int KNOWN_FLAGS = DABGPU_FLAG_VITERBI_WAVE | DABGPU_FLAG_VITERBI_LANE | DABGPU_FLAG_LANE_UNFUSED;
+    if ((cfg->flags & ~KNOWN_FLAGS) || ((cfg->flags & DABGPU_FLAG_VITERBI_WAVE) && (cfg->flags & DABGPU_FLAG_VITERBI_LANE)))
+        return DABGPU_ERR_ARG;
+    if (cfg->ofdm_symbol_runs < 0 || cfg->ofdm_symbol_runs > NB_DATA_SYMBOLS) return DABGPU_ERR_ARG;
+    if (cfg->reserved[0] || cfg->reserved[1] || cfg->reserved[2]) return DABGPU_ERR_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return DABGPU_ERR_NODEVICE;
     if (cfg->device < 0 || cfg->device >= ndev) return DABGPU_ERR_ARG;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return DABGPU_ERR_HIP;
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return DABGPU_ERR_NODEVICE;
-    HIP_TRY(hipSetDevice(cfg->device));
-
     dabgpu_ctx *ctx = new (std::nothrow) dabgpu_ctx();
     if (!ctx) return DABGPU_ERR_NOMEM;
     ctx->device = cfg->device;
+    DeviceGuard guard(ctx);
     ctx->max_frames = cfg->max_frames;
-    if (const char *g = std::getenv("DABGPU_OFDM_PARTS")) ctx->ofdm_parts_override = std::atoi(g);
-    if (const char *g = std::getenv("DABGPU_VITERBI_LANE")) ctx->lane_mode = std::atoi(g);
+    ctx->ofdm_parts_override = cfg->ofdm_symbol_runs;
+    ctx->lane_mode = (cfg->flags & DABGPU_FLAG_VITERBI_LANE) ? 1 : (cfg->flags & DABGPU_FLAG_VITERBI_WAVE) ? 0 : -1;
+    ctx->lane_unfused = (cfg->flags & DABGPU_FLAG_LANE_UNFUSED) != 0;
     ctx->wave_slots = prop.multiProcessorCount > 0 ? prop.multiProcessorCount * 12 : 3072;   // 3 workgroups x 4 waves per CU
     int rc = DABGPU_OK;
     do {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { rc = DABGPU_ERR_HIP; break; }
+        if (dabk::init_viterbi_kernel_attributes() != hipSuccess || dabk::init_lane_kernel_attributes() != hipSuccess) {
+            rc = DABGPU_ERR_HIP;
+            break;
+        }
         std::vector<float2> tw(NB_FFT);
         for (int m = 0; m < NB_FFT; m++) {
             const double a = -2.0 * M_PI * double(m) / double(NB_FFT);
@@ -375,8 +405,10 @@ int dabgpu_create(const dabgpu_cfg *cfg, dabgpu_ctx **out) {
 
 void dabgpu_destroy(dabgpu_ctx *ctx) {
     if (!ctx) return;
-    (void)hipSetDevice(ctx->device);
+    {
+    DeviceGuard guard(ctx);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->d_states) (void)hipFree(ctx->d_states);
     if (ctx->d_twiddle) (void)hipFree(ctx->d_twiddle);
     if (ctx->d_bin_of_n) (void)hipFree(ctx->d_bin_of_n);
     if (ctx->d_n_of_vj) (void)hipFree(ctx->d_n_of_vj);
@@ -394,6 +426,7 @@ void dabgpu_destroy(dabgpu_ctx *ctx) {
         if (t.stop) (void)hipEventDestroy(t.stop);
     }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    }
     delete ctx;
 }
 
@@ -409,6 +442,7 @@ void dabgpu_host_free(void *p) {
 
 int dabgpu_sync(dabgpu_ctx *ctx) {
     if (!ctx) return DABGPU_ERR_ARG;
+    DeviceGuard guard(ctx);
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return DABGPU_OK;
 }
@@ -423,6 +457,7 @@ int dabgpu_set_timing(dabgpu_ctx *ctx, int enable) {
 
 int dabgpu_last_kernel_ms(dabgpu_ctx *ctx, int which, float *ms) {
     if (!ctx || !ms || which < 0 || which > 3) return DABGPU_ERR_ARG;
+    DeviceGuard guard(ctx);
     Timer &t = ctx->timers[which];
     if (!t.valid) return DABGPU_ERR_ARG;
     HIP_TRY(hipEventSynchronize(t.stop));
@@ -442,6 +477,7 @@ int dabgpu_ofdm_demod_frames_dev(dabgpu_ctx *ctx, const void *d_iq, size_t frame
                                  const float *d_freq_offset, int8_t *d_soft, void *d_cyc, void *d_dqpsk,
                                  void *stream) {
     if (!ctx || !d_soft) return DABGPU_ERR_ARG;
+    DeviceGuard guard(ctx);
     int rc = check_iq(d_iq, frame_stride, n_frames);
     if (rc) return rc;
     if (reinterpret_cast<uintptr_t>(d_soft) & 15u) return DABGPU_ERR_ARG;
@@ -464,7 +500,8 @@ int dabgpu_ofdm_demod_frames_dev(dabgpu_ctx *ctx, const void *d_iq, size_t frame
 
 int dabgpu_ofdm_set_soft_selection(dabgpu_ctx *ctx, const dabgpu_bit_range *ranges, int n_ranges) {
     if (!ctx || n_ranges < 0 || (n_ranges > 0 && !ranges)) return DABGPU_ERR_ARG;
-    if (n_ranges == 0) { ctx->d_keep = nullptr; return DABGPU_OK; }
+    DeviceGuard guard(ctx);
+    if (n_ranges == 0) { ctx->d_keep = nullptr; ctx->keep_ranges.clear(); return DABGPU_OK; }
     constexpr int CHUNKS_PER_SYMBOL = NB_SYM_BITS / 16;          // 192 = 3 words
     std::vector<unsigned long long> words(size_t(NB_DATA_SYMBOLS) * 3, 0ull);
     for (int r = 0; r < n_ranges; r++) {
@@ -490,12 +527,22 @@ int dabgpu_ofdm_set_soft_selection(dabgpu_ctx *ctx, const dabgpu_bit_range *rang
     }
     ctx->keep_tables.push_back(d);
     ctx->d_keep = static_cast<const unsigned long long *>(d);
+    // the same selection as merged byte runs, for the host-pointer call's copy-back
+    ctx->keep_ranges.clear();
+    for (int c = 0; c < NB_FRAME_BITS / 16; c++) {
+        if (!(words[size_t(c / CHUNKS_PER_SYMBOL) * 3 + ((c % CHUNKS_PER_SYMBOL) >> 6)] >> ((c % CHUNKS_PER_SYMBOL) & 63) & 1ull)) continue;
+        if (!ctx->keep_ranges.empty() && ctx->keep_ranges.back().first + ctx->keep_ranges.back().count == 16 * c)
+            ctx->keep_ranges.back().count += 16;
+        else
+            ctx->keep_ranges.push_back(dabgpu_bit_range{16 * c, 16});
+    }
     return DABGPU_OK;
 }
 
 int dabgpu_fft_symbols_dev(dabgpu_ctx *ctx, const void *d_iq, size_t frame_stride, int n_frames,
                            const float *d_freq_offset, void *d_spectra, void *stream) {
     if (!ctx || !d_spectra) return DABGPU_ERR_ARG;
+    DeviceGuard guard(ctx);
     int rc = check_iq(d_iq, frame_stride, n_frames);
     if (rc) return rc;
     if (n_frames == 0) return DABGPU_OK;
@@ -520,6 +567,7 @@ static size_t iq_span(size_t frame_stride, int n_frames) {
 int dabgpu_ofdm_demod_frames(dabgpu_ctx *ctx, const float *iq, size_t frame_stride, int n_frames,
                              const float *freq_offset, int8_t *soft, float *cyc, float *dqpsk) {
     if (!ctx || !iq || !soft || n_frames < 0) return DABGPU_ERR_ARG;
+    DeviceGuard guard(ctx);
     if (n_frames == 0) return DABGPU_OK;
     void *d_iq, *d_fo = nullptr, *d_soft, *d_cyc = nullptr, *d_dq = nullptr;
     int rc;
@@ -538,7 +586,137 @@ int dabgpu_ofdm_demod_frames(dabgpu_ctx *ctx, const float *iq, size_t frame_stri
     rc = dabgpu_ofdm_demod_frames_dev(ctx, d_iq, frame_stride, n_frames, static_cast<const float *>(d_fo),
                                       static_cast<int8_t *>(d_soft), d_cyc, d_dq, s);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(soft, d_soft, nb_soft, hipMemcpyDeviceToHost, s));
+    if (ctx->d_keep && !dqpsk) {
+        // a selection is active: the kernel wrote only the selected runs of the staging buffer, and only those go
+        // back -- the rest of the caller's `soft` stays as it was (one strided copy per run, over all frames)
+        for (const dabgpu_bit_range &r : ctx->keep_ranges)
+            HIP_TRY(hipMemcpy2DAsync(soft + r.first, NB_FRAME_BITS, static_cast<const int8_t *>(d_soft) + r.first, NB_FRAME_BITS,
+                                     size_t(r.count), size_t(n_frames), hipMemcpyDeviceToHost, s));
+    } else {
+        HIP_TRY(hipMemcpyAsync(soft, d_soft, nb_soft, hipMemcpyDeviceToHost, s));
+    }
+    if (cyc) HIP_TRY(hipMemcpyAsync(cyc, d_cyc, nb_cyc, hipMemcpyDeviceToHost, s));
+    if (dqpsk) HIP_TRY(hipMemcpyAsync(dqpsk, d_dq, nb_dq, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return DABGPU_OK;
+}
+
+// ---------------------------------------------------------------------------- closed-loop stream call
+static_assert(sizeof(dabgpu_stream_state) == 32 && sizeof(dabk::StreamState) == 32, "stream state layout");
+
+int dabgpu_streams_reset(dabgpu_ctx *ctx, int n_streams) {
+    if (!ctx || n_streams < 0) return DABGPU_ERR_ARG;
+    DeviceGuard guard(ctx);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (n_streams > ctx->n_states) {
+        if (ctx->d_states) (void)hipFree(ctx->d_states);
+        ctx->d_states = nullptr;
+        ctx->n_states = 0;
+        if (hipMalloc(reinterpret_cast<void **>(&ctx->d_states), sizeof(dabk::StreamState) * size_t(n_streams)) != hipSuccess)
+            return DABGPU_ERR_NOMEM;
+    }
+    ctx->n_states = n_streams;
+    if (n_streams > 0) HIP_TRY(hipMemset(ctx->d_states, 0, sizeof(dabk::StreamState) * size_t(n_streams)));
+    return DABGPU_OK;
+}
+
+dabgpu_stream_state *dabgpu_stream_states(dabgpu_ctx *ctx) {
+    return ctx ? reinterpret_cast<dabgpu_stream_state *>(ctx->d_states) : nullptr;
+}
+
+int dabgpu_set_stream_offsets(dabgpu_ctx *ctx, int stream_index, const float *fine, const float *coarse) {
+    if (!ctx || stream_index < 0 || stream_index >= ctx->n_states) return DABGPU_ERR_ARG;
+    DeviceGuard guard(ctx);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    dabk::StreamState *st = ctx->d_states + stream_index;
+    if (fine) HIP_TRY(hipMemcpy(&st->fine_freq_offset, fine, sizeof(float), hipMemcpyHostToDevice));
+    if (coarse) HIP_TRY(hipMemcpy(&st->coarse_freq_offset, coarse, sizeof(float), hipMemcpyHostToDevice));
+    return DABGPU_OK;
+}
+
+int dabgpu_get_stats(dabgpu_ctx *ctx, int stream_index, dabgpu_stats *out) {
+    if (!ctx || !out || stream_index < 0 || stream_index >= ctx->n_states) return DABGPU_ERR_ARG;
+    DeviceGuard guard(ctx);
+    dabk::StreamState st;
+    HIP_TRY(hipMemcpyAsync(&st, ctx->d_states + stream_index, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    out->state = (st.total_frames_read > 0) ? 4 : 0;           // READING_SYMBOLS / FINDING_NULL_POWER_DIP
+    out->fine_freq_offset = st.fine_freq_offset;
+    out->coarse_freq_offset = st.coarse_freq_offset;
+    out->net_freq_offset = st.fine_freq_offset + st.coarse_freq_offset;
+    out->signal_average = st.signal_average;
+    out->total_frames_read = st.total_frames_read;
+    out->total_frames_desync = st.total_frames_desync;
+    out->last_fine_error = st.last_fine_error;
+    return DABGPU_OK;
+}
+
+int dabgpu_ofdm_demod_streams_dev(dabgpu_ctx *ctx, const void *d_iq, size_t frame_stride, int n_streams,
+                                  int frames_per_stream, float fine_freq_update_beta, int8_t *d_soft, void *d_cyc,
+                                  void *d_dqpsk, void *stream) {
+    if (!ctx || !d_soft || n_streams < 0 || frames_per_stream < 0) return DABGPU_ERR_ARG;
+    DeviceGuard guard(ctx);
+    if (n_streams > ctx->n_states) return DABGPU_ERR_CAPACITY;   // dabgpu_streams_reset first
+    if (!(fine_freq_update_beta >= 0.f && fine_freq_update_beta <= 1.f)) return DABGPU_ERR_ARG;
+    if (size_t(n_streams) * size_t(frames_per_stream) > size_t(0x7fffffff) / NB_DATA_SYMBOLS) return DABGPU_ERR_ARG;
+    const int n_frames = n_streams * frames_per_stream;
+    int rc = check_iq(d_iq, frame_stride, n_frames);
+    if (rc) return rc;
+    if (reinterpret_cast<uintptr_t>(d_soft) & 15u) return DABGPU_ERR_ARG;
+    if (n_frames == 0) return DABGPU_OK;
+    hipStream_t s = pick_stream(ctx, stream);
+    if (!d_cyc) {                                               // the loop needs the correlations: keep them here
+        if ((rc = stage(ctx, 3, size_t(n_frames) * NB_FRAME_SYMBOLS * sizeof(float2), &d_cyc))) return rc;
+    }
+    dabk::OfdmTables tab{ctx->d_twiddle, ctx->d_bin_of_n, ctx->d_n_of_vj};
+    dabk::OfdmArgs a{};
+    a.iq = static_cast<const float2 *>(d_iq);
+    a.frame_stride = frame_stride;
+    a.n_frames = n_frames;
+    a.soft = d_soft;
+    a.cyc = static_cast<float2 *>(d_cyc);
+    a.dqpsk = static_cast<float2 *>(d_dqpsk);
+    a.keep = ctx->d_keep;
+    a.state = ctx->d_states;
+    a.frames_per_stream = frames_per_stream;
+    {
+        ScopedTimer tm(ctx, 0, s);
+        HIP_TRY(dabk::launch_ofdm_demod(tab, a, pick_parts(ctx, n_frames, NB_DATA_SYMBOLS), s));
+    }
+    HIP_TRY(dabk::launch_stream_update(ctx->d_states, a.cyc, a.iq, frame_stride, n_streams, frames_per_stream,
+                                       fine_freq_update_beta, ctx->thr_null_start, s));
+    return DABGPU_OK;
+}
+
+int dabgpu_ofdm_demod_streams(dabgpu_ctx *ctx, const float *iq, size_t frame_stride, int n_streams,
+                              int frames_per_stream, float fine_freq_update_beta, int8_t *soft, float *cyc,
+                              float *dqpsk) {
+    if (!ctx || !iq || !soft || n_streams < 0 || frames_per_stream < 0) return DABGPU_ERR_ARG;
+    DeviceGuard guard(ctx);
+    const int n_frames = n_streams * frames_per_stream;
+    if (n_frames == 0) return DABGPU_OK;
+    void *d_iq, *d_soft, *d_cyc = nullptr, *d_dq = nullptr;
+    int rc;
+    const size_t nb_iq = iq_span(frame_stride, n_frames);
+    const size_t nb_soft = size_t(n_frames) * NB_FRAME_BITS;
+    const size_t nb_cyc = size_t(n_frames) * NB_FRAME_SYMBOLS * sizeof(float2);
+    const size_t nb_dq = size_t(n_frames) * NB_DATA_SYMBOLS * NB_CARRIERS * sizeof(float2);
+    if ((rc = stage(ctx, 0, nb_iq, &d_iq))) return rc;
+    if ((rc = stage(ctx, 1, nb_soft, &d_soft))) return rc;
+    if ((rc = stage(ctx, 3, nb_cyc, &d_cyc))) return rc;
+    if (dqpsk && (rc = stage(ctx, 4, nb_dq, &d_dq))) return rc;
+    hipStream_t s = ctx->stream;
+    HIP_TRY(hipMemcpyAsync(d_iq, iq, nb_iq, hipMemcpyHostToDevice, s));
+    rc = dabgpu_ofdm_demod_streams_dev(ctx, d_iq, frame_stride, n_streams, frames_per_stream, fine_freq_update_beta,
+                                       static_cast<int8_t *>(d_soft), d_cyc, d_dq, s);
+    if (rc) return rc;
+    if (ctx->d_keep && !dqpsk) {
+        for (const dabgpu_bit_range &r : ctx->keep_ranges)
+            HIP_TRY(hipMemcpy2DAsync(soft + r.first, NB_FRAME_BITS, static_cast<const int8_t *>(d_soft) + r.first, NB_FRAME_BITS,
+                                     size_t(r.count), size_t(n_frames), hipMemcpyDeviceToHost, s));
+    } else {
+        HIP_TRY(hipMemcpyAsync(soft, d_soft, nb_soft, hipMemcpyDeviceToHost, s));
+    }
     if (cyc) HIP_TRY(hipMemcpyAsync(cyc, d_cyc, nb_cyc, hipMemcpyDeviceToHost, s));
     if (dqpsk) HIP_TRY(hipMemcpyAsync(dqpsk, d_dq, nb_dq, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -548,6 +726,7 @@ int dabgpu_ofdm_demod_frames(dabgpu_ctx *ctx, const float *iq, size_t frame_stri
 int dabgpu_fft_symbols(dabgpu_ctx *ctx, const float *iq, size_t frame_stride, int n_frames,
                        const float *freq_offset, float *spectra) {
     if (!ctx || !iq || !spectra || n_frames < 0) return DABGPU_ERR_ARG;
+    DeviceGuard guard(ctx);
     if (n_frames == 0) return DABGPU_OK;
     void *d_iq, *d_fo = nullptr, *d_sp;
     int rc;
@@ -572,6 +751,7 @@ static_assert(sizeof(dabgpu_sync_result) == sizeof(dabk::SyncResult), "ABI struc
 int dabgpu_sync_prs_dev(dabgpu_ctx *ctx, const void *d_iq, size_t frame_stride, int n_frames,
                         const float *d_freq_offset, int max_coarse, dabgpu_sync_result *d_out, void *stream) {
     if (!ctx || !d_iq || !d_out || n_frames < 0 || max_coarse < 0 || max_coarse > 1023) return DABGPU_ERR_ARG;
+    DeviceGuard guard(ctx);
     if ((reinterpret_cast<uintptr_t>(d_iq) & 15u) || (frame_stride & 1u)) return DABGPU_ERR_ARG;
     if (n_frames > 1 && frame_stride < size_t(NB_SYM_PERIOD)) return DABGPU_ERR_ARG;
     if (n_frames == 0) return DABGPU_OK;
@@ -585,6 +765,7 @@ int dabgpu_sync_prs_dev(dabgpu_ctx *ctx, const void *d_iq, size_t frame_stride, 
 int dabgpu_sync_prs(dabgpu_ctx *ctx, const float *iq, size_t frame_stride, int n_frames, const float *freq_offset,
                     int max_coarse, dabgpu_sync_result *out) {
     if (!ctx || !iq || !out || n_frames < 0) return DABGPU_ERR_ARG;
+    DeviceGuard guard(ctx);
     if (n_frames == 0) return DABGPU_OK;
     void *d_iq, *d_fo = nullptr, *d_out;
     int rc;
@@ -619,6 +800,7 @@ int dabgpu_acquire_dev(dabgpu_ctx *ctx, const void *d_iq, size_t stream_stride, 
                        void *stream) {
     static_assert(sizeof(dabgpu_acquired_frame) == 32 && sizeof(dabk::AcquiredFrame) == 32, "acquired-frame layout");
     if (!ctx || !d_iq || !d_out || !d_counts || n_streams < 0 || max_frames <= 0 || n_samples < 0) return DABGPU_ERR_ARG;
+    DeviceGuard guard(ctx);
     if (reinterpret_cast<uintptr_t>(d_iq) & 7u) return DABGPU_ERR_ARG;
     if (n_streams > 1 && stream_stride < size_t(n_samples)) return DABGPU_ERR_ARG;
     dabgpu_acquire_cfg c;
@@ -667,6 +849,7 @@ int dabgpu_acquire_dev(dabgpu_ctx *ctx, const void *d_iq, size_t stream_stride, 
 int dabgpu_acquire(dabgpu_ctx *ctx, const float *iq, size_t stream_stride, int n_streams, int64_t n_samples,
                    const dabgpu_acquire_cfg *cfg, int max_frames, dabgpu_acquired_frame *out, int32_t *counts) {
     if (!ctx || !iq || !out || !counts || n_streams < 0 || max_frames <= 0 || n_samples < 0) return DABGPU_ERR_ARG;
+    DeviceGuard guard(ctx);
     if (n_streams == 0) return DABGPU_OK;
     if (n_streams > 1 && stream_stride < size_t(n_samples)) return DABGPU_ERR_ARG;
     // a capture is as large as the caller makes it: its device copy is allocated for the call, not kept
@@ -696,6 +879,7 @@ int dabgpu_ofdm_demod_acquired_dev(dabgpu_ctx *ctx, const void *d_iq, size_t str
                                    int max_frames, const dabgpu_acquired_frame *d_frames, int8_t *d_soft, void *d_cyc,
                                    void *d_dqpsk, void *stream) {
     if (!ctx || !d_iq || !d_frames || !d_soft || n_streams < 0 || max_frames <= 0) return DABGPU_ERR_ARG;
+    DeviceGuard guard(ctx);
     if ((reinterpret_cast<uintptr_t>(d_iq) & 7u) || (reinterpret_cast<uintptr_t>(d_soft) & 15u)) return DABGPU_ERR_ARG;
     if (n_streams == 0) return DABGPU_OK;
     if (size_t(n_streams) * size_t(max_frames) > size_t(0x7fffffff) / NB_DATA_SYMBOLS) return DABGPU_ERR_ARG;
@@ -720,6 +904,7 @@ int dabgpu_ofdm_demod_acquired_dev(dabgpu_ctx *ctx, const void *d_iq, size_t str
 int dabgpu_fic_decode_dev(dabgpu_ctx *ctx, const int8_t *d_soft, size_t soft_stride, int n_frames,
                           uint8_t *d_fib, uint8_t *d_crc_ok, void *stream) {
     if (!ctx || !d_soft || !d_fib || !d_crc_ok || n_frames < 0) return DABGPU_ERR_ARG;
+    DeviceGuard guard(ctx);
     if (n_frames > 1 && soft_stride < size_t(NB_FIC_BITS)) return DABGPU_ERR_ARG;
     if (n_frames == 0) return DABGPU_OK;
     hipStream_t s = pick_stream(ctx, stream);
@@ -739,6 +924,7 @@ int dabgpu_fic_decode_dev(dabgpu_ctx *ctx, const int8_t *d_soft, size_t soft_str
 int dabgpu_fic_decode(dabgpu_ctx *ctx, const int8_t *soft, size_t soft_stride, int n_frames, uint8_t *fib,
                       uint8_t *crc_ok) {
     if (!ctx || !soft || !fib || !crc_ok || n_frames < 0) return DABGPU_ERR_ARG;
+    DeviceGuard guard(ctx);
     if (n_frames == 0) return DABGPU_OK;
     void *d_soft, *d_fib, *d_ok;
     int rc;
@@ -815,6 +1001,7 @@ int dabgpu_msc_decode_dev(dabgpu_ctx *ctx, const dabgpu_subchannel *sc, const in
                           int n_streams, int frames_per_stream, const int8_t *d_history_in,
                           int8_t *d_history_out, uint8_t *d_out, void *stream) {
     if (!ctx || !d_soft || !d_out || n_streams < 0 || frames_per_stream < 0) return DABGPU_ERR_ARG;
+    DeviceGuard guard(ctx);
     if (d_history_in && d_history_in == d_history_out) return DABGPU_ERR_ARG;
     if (soft_stride < size_t(NB_FRAME_BITS) && size_t(n_streams) * frames_per_stream > 1) return DABGPU_ERR_ARG;
     dab::PunctureProfile prof;
@@ -852,6 +1039,7 @@ int dabgpu_msc_decode(dabgpu_ctx *ctx, const dabgpu_subchannel *sc, const int8_t
                       int n_streams, int frames_per_stream, const int8_t *history_in, int8_t *history_out,
                       uint8_t *out) {
     if (!ctx || !soft || !out || n_streams < 0 || frames_per_stream < 0) return DABGPU_ERR_ARG;
+    DeviceGuard guard(ctx);
     const int nbytes = dabgpu_subchannel_bytes(sc);
     if (nbytes < 0) return nbytes;
     const size_t nframes = size_t(n_streams) * frames_per_stream;
@@ -885,7 +1073,7 @@ static int decode_grouped(dabgpu_ctx *ctx, uint8_t *d_fib, uint8_t *d_crc_ok, co
                           const int8_t *const *d_history_in, int8_t *const *d_history_out, uint8_t *const *d_out,
                           void *stream) {
     const int n_items = n_subchannels + (d_fib ? 1 : 0);
-    if (n_items < 2 || ctx->lane_mode == 0 || !d_soft || n_streams <= 0 || frames_per_stream <= 0 ||
+    if (n_items < 2 || ctx->lane_mode == 0 || ctx->lane_unfused || !d_soft || n_streams <= 0 || frames_per_stream <= 0 ||
         soft_stride < size_t(NB_FRAME_BITS))
         return 1;
     const long total_cw = long(n_items) * n_streams * frames_per_stream * NB_CIFS;
@@ -950,6 +1138,7 @@ int dabgpu_msc_decode_multi_dev(dabgpu_ctx *ctx, const dabgpu_subchannel *sc, in
                                 const int8_t *const *d_history_in, int8_t *const *d_history_out,
                                 uint8_t *const *d_out, void *stream) {
     if (!ctx || !sc || !d_out || n_subchannels < 0) return DABGPU_ERR_ARG;
+    DeviceGuard guard(ctx);
     // validate everything before enqueueing anything: profiles, bounds, no overlap inside the CIF
     std::vector<char> used(864, 0);
     for (int i = 0; i < n_subchannels; i++) {
@@ -981,6 +1170,7 @@ int dabgpu_decode_frames_dev(dabgpu_ctx *ctx, const int8_t *d_soft, size_t soft_
                              int n_subchannels, const int8_t *const *d_history_in, int8_t *const *d_history_out,
                              uint8_t *const *d_out, void *stream) {
     if (!ctx || !d_soft || !d_fib || !d_crc_ok || n_streams < 0 || frames_per_stream < 0 || n_subchannels < 0) return DABGPU_ERR_ARG;
+    DeviceGuard guard(ctx);
     if (n_subchannels > 0 && (!sc || !d_out)) return DABGPU_ERR_ARG;
     if (soft_stride < size_t(NB_FRAME_BITS) && size_t(n_streams) * frames_per_stream > 1) return DABGPU_ERR_ARG;
     std::vector<char> used(864, 0);
@@ -1009,6 +1199,67 @@ int dabgpu_decode_frames_dev(dabgpu_ctx *ctx, const int8_t *d_soft, size_t soft_
     return DABGPU_OK;
 }
 
+int dabgpu_decode_frames(dabgpu_ctx *ctx, const int8_t *soft, size_t soft_stride, int n_streams, int frames_per_stream,
+                         uint8_t *fib, uint8_t *crc_ok, const dabgpu_subchannel *sc, int n_subchannels,
+                         const int8_t *const *history_in, int8_t *const *history_out, uint8_t *const *out) {
+    if (!ctx || !soft || !fib || !crc_ok || n_streams < 0 || frames_per_stream < 0 || n_subchannels < 0) return DABGPU_ERR_ARG;
+    DeviceGuard guard(ctx);
+    if (n_subchannels > 0 && (!sc || !out)) return DABGPU_ERR_ARG;
+    const size_t nframes = size_t(n_streams) * frames_per_stream;
+    if (nframes == 0) return DABGPU_OK;
+    if (soft_stride < size_t(NB_FRAME_BITS) && nframes > 1) return DABGPU_ERR_ARG;
+    // layout of the result and history staging buffers: [fib | crc | out_0 | out_1 ...], [hist_0 | hist_1 ...]
+    auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
+    std::vector<size_t> out_off(n_subchannels), out_bytes(n_subchannels), hist_off(n_subchannels), hist_bytes(n_subchannels);
+    const size_t nb_fib = nframes * NB_FIBS * 32, nb_crc = nframes * NB_FIBS;
+    size_t res_total = al(nb_fib) + al(nb_crc), hist_total = 0;
+    for (int i = 0; i < n_subchannels; i++) {
+        const int nbytes = dabgpu_subchannel_bytes(&sc[i]);
+        if (nbytes < 0) return nbytes;
+        if (!out[i]) return DABGPU_ERR_ARG;
+        out_off[i] = res_total;
+        out_bytes[i] = nframes * NB_CIFS * size_t(nbytes);
+        res_total += al(out_bytes[i]);
+        hist_off[i] = hist_total;
+        hist_bytes[i] = size_t(n_streams) * 15 * sc[i].length * CU_BITS;
+        hist_total += al(hist_bytes[i]);
+    }
+    const size_t nb_soft = (nframes - 1) * soft_stride + NB_FRAME_BITS;
+    void *d_soft, *d_res, *d_hi = nullptr, *d_ho = nullptr;
+    int rc;
+    if ((rc = stage(ctx, 1, nb_soft, &d_soft))) return rc;
+    if ((rc = stage(ctx, 3, res_total, &d_res))) return rc;
+    if (hist_total && history_in && (rc = stage(ctx, 4, hist_total, &d_hi))) return rc;
+    if (hist_total && history_out && (rc = stage(ctx, 5, hist_total, &d_ho))) return rc;
+    hipStream_t s = ctx->stream;
+    HIP_TRY(hipMemcpyAsync(d_soft, soft, nb_soft, hipMemcpyHostToDevice, s));            // the frames go up once
+    std::vector<const int8_t *> p_hi(n_subchannels, nullptr);
+    std::vector<int8_t *> p_ho(n_subchannels, nullptr);
+    std::vector<uint8_t *> p_out(n_subchannels, nullptr);
+    char *res = static_cast<char *>(d_res);
+    for (int i = 0; i < n_subchannels; i++) {
+        p_out[i] = reinterpret_cast<uint8_t *>(res + out_off[i]);
+        if (history_in && history_in[i]) {
+            p_hi[i] = reinterpret_cast<const int8_t *>(static_cast<char *>(d_hi) + hist_off[i]);
+            HIP_TRY(hipMemcpyAsync(const_cast<int8_t *>(p_hi[i]), history_in[i], hist_bytes[i], hipMemcpyHostToDevice, s));
+        }
+        if (history_out && history_out[i]) p_ho[i] = reinterpret_cast<int8_t *>(static_cast<char *>(d_ho) + hist_off[i]);
+    }
+    uint8_t *d_fib = reinterpret_cast<uint8_t *>(res), *d_crc = reinterpret_cast<uint8_t *>(res + al(nb_fib));
+    rc = dabgpu_decode_frames_dev(ctx, static_cast<const int8_t *>(d_soft), soft_stride, n_streams, frames_per_stream, d_fib,
+                                  d_crc, sc, n_subchannels, n_subchannels ? p_hi.data() : nullptr,
+                                  n_subchannels ? p_ho.data() : nullptr, n_subchannels ? p_out.data() : nullptr, s);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(fib, d_fib, nb_fib, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(crc_ok, d_crc, nb_crc, hipMemcpyDeviceToHost, s));
+    for (int i = 0; i < n_subchannels; i++) {
+        HIP_TRY(hipMemcpyAsync(out[i], p_out[i], out_bytes[i], hipMemcpyDeviceToHost, s));
+        if (p_ho[i]) HIP_TRY(hipMemcpyAsync(history_out[i], p_ho[i], hist_bytes[i], hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));                                                  // one synchronisation
+    return DABGPU_OK;
+}
+
 // ---------------------------------------------------------------------------- DAB+ super-frame
 static_assert(sizeof(dabgpu_superframe_status) == sizeof(dabk::SuperframeStatus), "ABI struct mirrors the kernel's");
 
@@ -1016,6 +1267,7 @@ int dabgpu_dabplus_superframes_dev(dabgpu_ctx *ctx, const uint8_t *d_in, size_t 
                                    int bitrate_kbps, uint8_t *d_out, dabgpu_superframe_status *d_status,
                                    void *stream) {
     if (!ctx || !d_in || !d_out || !d_status || n_superframes < 0) return DABGPU_ERR_ARG;
+    DeviceGuard guard(ctx);
     if (bitrate_kbps < 8 || bitrate_kbps % 8 || bitrate_kbps > 512) return DABGPU_ERR_PROFILE;
     const int s = bitrate_kbps / 8;
     if (n_superframes > 1 && in_stride < size_t(120) * s) return DABGPU_ERR_ARG;
@@ -1029,6 +1281,7 @@ int dabgpu_dabplus_superframes_dev(dabgpu_ctx *ctx, const uint8_t *d_in, size_t 
 int dabgpu_dabplus_superframes(dabgpu_ctx *ctx, const uint8_t *in, size_t in_stride, int n_superframes,
                                int bitrate_kbps, uint8_t *out, dabgpu_superframe_status *status) {
     if (!ctx || !in || !out || !status || n_superframes < 0) return DABGPU_ERR_ARG;
+    DeviceGuard guard(ctx);
     if (bitrate_kbps < 8 || bitrate_kbps % 8 || bitrate_kbps > 512) return DABGPU_ERR_PROFILE;
     if (n_superframes == 0) return DABGPU_OK;
     const int s = bitrate_kbps / 8;
@@ -1055,6 +1308,7 @@ int dabgpu_dabplus_superframes(dabgpu_ctx *ctx, const uint8_t *in, size_t in_str
 int dabgpu_viterbi_dev(dabgpu_ctx *ctx, const int8_t *d_punct, int n_codewords, const uint8_t *mask, int nsteps,
                        uint8_t *d_out_bytes, void *stream) {
     if (!ctx || !d_punct || !mask || !d_out_bytes || n_codewords < 0) return DABGPU_ERR_ARG;
+    DeviceGuard guard(ctx);
     if (nsteps < 14 || ((nsteps - 6) & 7)) return DABGPU_ERR_ARG;
     if (!dabk::viterbi_fits(nsteps)) return DABGPU_ERR_CAPACITY;
     dab::PunctureProfile prof;
@@ -1081,6 +1335,7 @@ int dabgpu_viterbi_dev(dabgpu_ctx *ctx, const int8_t *d_punct, int n_codewords, 
 int dabgpu_viterbi(dabgpu_ctx *ctx, const int8_t *punct, int n_codewords, const uint8_t *mask, int nsteps,
                    uint8_t *out_bytes) {
     if (!ctx || !punct || !mask || !out_bytes || n_codewords < 0) return DABGPU_ERR_ARG;
+    DeviceGuard guard(ctx);
     if (nsteps < 14 || ((nsteps - 6) & 7)) return DABGPU_ERR_ARG;
     if (n_codewords == 0) return DABGPU_OK;
     size_t n_punct = 0;

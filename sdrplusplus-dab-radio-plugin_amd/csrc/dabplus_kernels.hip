@@ -158,13 +158,15 @@ __global__ __launch_bounds__(64) void dabplus_superframe_kernel(const uint8_t *i
     __syncthreads();
     int fire_ok = 0;
     if (tid == 0) {
-        unsigned crc = 0;
+        unsigned crc = 0, any = unsigned(sf[0]) | sf[1];
         for (int i = 2; i < 11; i++) {
+            any |= sf[i];
             crc ^= unsigned(sf[i]) << 8;
             for (int b = 0; b < 8; b++) crc = (crc & 0x8000u) ? ((crc << 1) ^ 0x782Fu) : (crc << 1);
             crc &= 0xFFFFu;
         }
-        fire_ok = crc == ((unsigned(sf[0]) << 8) | sf[1]);
+        // an all-zero header is its own (zero) check word: that is silence or erasures, not a super-frame
+        fire_ok = any != 0 && crc == ((unsigned(sf[0]) << 8) | sf[1]);
         if (fire_ok) {
             const int dac_rate = (sf[2] >> 6) & 1, sbr = (sf[2] >> 5) & 1;
             const int naus = dac_rate ? (sbr ? 3 : 6) : (sbr ? 2 : 4);

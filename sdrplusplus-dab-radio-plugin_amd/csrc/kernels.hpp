@@ -15,6 +15,19 @@ struct OfdmTables {
     const uint16_t *n_of_vj;   // [12][64][2] data index of carrier registers 2jj, 2jj+1 of lane v (wave kernel)
 };
 
+// Per-stream tracking state kept in device memory between launches (== dabgpu_stream_state, 32 bytes): the
+// frequency offsets OFDM_Demod shows through GetFineFrequencyOffset / GetCoarseFrequencyOffset
+// (/root/reference/src/render_radio_block.cpp:202-207) and its frame counters.
+struct StreamState {
+    float fine_freq_offset;    // cycles/sample, within +-0.5 carrier
+    float coarse_freq_offset;  // cycles/sample, whole carriers
+    float signal_average;      // mean |re|+|im| of the stream's most recent frame
+    float last_fine_error;     // residual the most recent update measured, cycles/sample
+    int32_t total_frames_read;
+    int32_t total_frames_desync;
+    int32_t reserved[2];
+};
+
 struct OfdmArgs {
     const float2 *iq;          // frame f at iq + f*frame_stride (first PRS sample)
     size_t frame_stride;       // complex samples
@@ -31,6 +44,10 @@ struct OfdmArgs {
     int acq_per_stream = 1;
     // soft-bit selection: [75][3] words, bit k of symbol s = write its 16-byte chunk k; nullptr = write everything
     const unsigned long long *keep = nullptr;
+    // stream mode (state != nullptr): frame f belongs to stream f / frames_per_stream and is corrected by that
+    // stream's fine + coarse offset; freq_offset is ignored
+    const StreamState *state = nullptr;
+    int frames_per_stream = 0;
 };
 
 // fused A2..A6.  Each frame is cut into `parts` contiguous runs of data symbols (1..75); a run re-reads
@@ -38,6 +55,12 @@ struct OfdmArgs {
 hipError_t launch_ofdm_demod(const OfdmTables &t, const OfdmArgs &a, int parts, hipStream_t s);
 // A2+A3 only; parts in 1..76.
 hipError_t launch_fft_symbols(const OfdmTables &t, const OfdmArgs &a, int parts, hipStream_t s);
+// Fine-frequency loop and counters of the stream call, after the demodulation launch on the same stream:
+// per stream, fine -= beta * mean(arg cyc[frame][symbol]) / (2*pi*2048), wrapped to +-half a carrier; frame count;
+// L1 level of the stream's last frame (first 4096 samples) into the running average, counted as a desync when it
+// is below thr_null_start times the average so far.
+hipError_t launch_stream_update(StreamState *state, const float2 *cyc, const float2 *iq, size_t frame_stride,
+                                int n_streams, int frames_per_stream, float beta, float thr_null_start, hipStream_t s);
 
 // ---- synchronisation on the PRS (sync_kernels.hip) -----------------------------
 struct SyncTables {
@@ -130,6 +153,7 @@ hipError_t launch_msc_decode(const CodeTables &c, const MscArgs &a, hipStream_t 
 struct LaneScratch {
     void *base;
     size_t bytes;
+    bool unfused = false;      // DABGPU_FLAG_LANE_UNFUSED: depuncture in a pass of its own (lane_prep_kernel)
 };
 size_t lane_scratch_bytes(int nsteps, int n_codewords);
 bool lane_supported(int nsteps);
@@ -166,6 +190,11 @@ hipError_t launch_lane_group(const LaneGroupItem *items, int n, const LaneScratc
 size_t balanced_lds_bytes(unsigned grid, size_t lds, unsigned o_cap);
 // history ring update alone (used by both MSC variants)
 hipError_t launch_msc_history(const MscArgs &a, hipStream_t s);
+
+// Let every kernel that takes dynamic LDS use the whole 160 KB of a CU: set once per context creation (on the
+// context's device) instead of per launch.
+hipError_t init_viterbi_kernel_attributes();
+hipError_t init_lane_kernel_attributes();
 
 // LDS bytes one codeword needs in the first (fallback) wave-per-codeword kernel
 inline size_t viterbi_wave_lds_bytes(int nsteps) { return size_t(nsteps) * 12 + 64; }

@@ -10,13 +10,21 @@
 //   A6  L-infinity normalise + int8 soft-bit quantise
 // plus the cyclic-prefix correlation that drives the fine-frequency loop.
 //
-// One 256-thread workgroup walks `syms_per_group` consecutive data symbols of one
-// frame (plus the symbol before them as differential reference), keeping the previous
-// spectrum in LDS so every IQ sample is read from HBM once.  The FFT is a Stockham
-// autosort radix-8/8/8/4 through LDS; the first radix-8 pass is fed straight from the
-// coalesced global loads with the NCO rotation applied in registers.
-#include <cstdlib>
-
+// One 64-lane wavefront owns a run of consecutive symbols of one frame and keeps a whole 2048-point symbol in
+// registers (32 complex per lane).
+//
+//   n = 128*n1 + 8*n2 + n3   (n1<16, n2<16, n3<8)      k = k1 + 16*k2 + 256*k3
+//   step 1  lane (n2, n3/2): two 16-point DFTs over n1   (inputs are the lane's own 16-byte loads)
+//           twiddle W256^(n2*k1), exchange through LDS
+//   step 2  lane (k1, n3/2): two 16-point DFTs over n2,  twiddle W2048^(n3*(k1+16*k2)), exchange
+//   step 3  lane v = (k1 | k2%4 << 4): four 8-point DFTs over n3 -> bins v + 64*m, m = 0..31
+//
+// Because every lane ends each symbol with the SAME bins, the previous spectrum stays in registers and the
+// differential demodulation needs no memory at all.  The two LDS exchanges use XOR-swizzled layouts and the
+// twiddle tables a lane-permuted layout; all of them are bank-conflict free on the hardware (measured:
+// tools/ubench/lds_conflict.hip, profiles/r02_ofdm_bound.md).  No workgroup barrier is needed after the tables are
+// loaded: a wave only talks to itself.  Soft bits are scattered as bytes into the (then idle) exchange buffer and
+// leave as three coalesced 16-byte stores per lane.
 #include "kernels.hpp"
 #include "dab_tables.hpp"
 #include "fft_common.hpp"
@@ -27,170 +35,36 @@ using namespace dab;
 
 namespace {
 
-struct Smem {
-    float2 tw[NB_FFT];
-    float2 t1[NB_FFT];
-    float2 x[2][NB_FFT];
-    float2 red[4];
-};
+constexpr int WAVES = 4;
 
-template <bool FFT_ONLY>
-__global__ __launch_bounds__(WG) void ofdm_kernel(OfdmTables tab, OfdmArgs a, int parts) {
-    __shared__ Smem sm;
-    const int tid = threadIdx.x;
-    const int frame = blockIdx.x / parts;
-    const int part = blockIdx.x % parts;
-    const float2 *fiq = a.iq + size_t(frame) * a.frame_stride;
-    const uint32_t dphi = dphi_of(a.freq_offset, frame);
-
-    for (int i = tid; i < NB_FFT; i += WG) sm.tw[i] = tab.twiddle[i];
-
-    // data indices this thread quantises: n0..n0+7 (threads 0..191)
-    uint16_t bins[8];
-    if (!FFT_ONLY && tid < NB_CARRIERS / 8) {
-#pragma unroll
-        for (int q = 0; q < 8; q++) bins[q] = tab.bin_of_n[tid * 8 + q];
-    }
-
-    // symbols [l_first, l_last]; in fused mode l_first is only the differential reference
-    // fused: data symbols (l_first, l_last], l_first is only the differential reference
-    const int l_first = FFT_ONLY ? (NB_FRAME_SYMBOLS * part) / parts : (NB_DATA_SYMBOLS * part) / parts;
-    const int l_last = FFT_ONLY ? (NB_FRAME_SYMBOLS * (part + 1)) / parts - 1 : (NB_DATA_SYMBOLS * (part + 1)) / parts;
-    __syncthreads();
-
-    for (int l = l_first; l <= l_last; l++) {
-        const float2 *sym = fiq + size_t(l) * NB_SYM_PERIOD;
-        float2 *xc = sm.x[l & 1];
-        const float2 *xp = sm.x[(l & 1) ^ 1];
-        const bool emit = FFT_ONLY || (l > l_first) || (l == 0);   // who owns the cyc of symbol l
-
-        // ---- A2 + first radix-8 pass straight from global memory ----
-        {
-            float2 v[8];
-            const uint32_t nbase = uint32_t(l * NB_SYM_PERIOD + NB_CP + tid);
-#pragma unroll
-            for (int r = 0; r < 8; r++) v[r] = sym[NB_CP + tid + r * WG];
-            if (dphi != 0u) {
-#pragma unroll
-                for (int r = 0; r < 8; r++) v[r] = cmul(v[r], nco(nbase + uint32_t(r * WG), dphi));
-            }
-            fft8(v);
-#pragma unroll
-            for (int r = 0; r < 8; r++) sm.t1[tid * 8 + r] = v[r];
-        }
-        // ---- cyclic-prefix correlation (on raw samples, rotated once at the end) ----
-        float2 acc = make_float2(0.f, 0.f);
-        if (a.cyc && emit && tid < NB_CP / 2) {
-            const float4 p = *reinterpret_cast<const float4 *>(sym + 2 * tid);
-            const float4 q = *reinterpret_cast<const float4 *>(sym + NB_FFT + 2 * tid);
-            // conj(p) * q
-            acc.x = p.x * q.x + p.y * q.y + p.z * q.z + p.w * q.w;
-            acc.y = p.x * q.y - p.y * q.x + p.z * q.w - p.w * q.z;
-        }
-        __syncthreads();
-        pass8<8>(sm.t1, xc, sm.tw, tid);
-        __syncthreads();
-        pass8<64>(xc, sm.t1, sm.tw, tid);
-        __syncthreads();
-        // ---- last pass: radix 4, NS = 512, two work items per thread ----
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int j = tid + h * WG;   // k == j since j < 512
-            float2 v0 = sm.t1[j], v1 = sm.t1[j + 512], v2 = sm.t1[j + 1024], v3 = sm.t1[j + 1536];
-            v1 = cmul(v1, sm.tw[j]);
-            v2 = cmul(v2, sm.tw[2 * j]);
-            v3 = cmul(v3, sm.tw[3 * j]);
-            fft4(v0, v1, v2, v3);
-            if (FFT_ONLY) {
-                float2 *o = a.spectra + (size_t(frame) * NB_FRAME_SYMBOLS + l) * NB_FFT;
-                o[j] = v0; o[j + 512] = v1; o[j + 1024] = v2; o[j + 1536] = v3;
-            } else {
-                xc[j] = v0; xc[j + 512] = v1; xc[j + 1024] = v2; xc[j + 1536] = v3;
-            }
-        }
-        // ---- reduce the cyclic-prefix correlation ----
-        if (a.cyc && emit) {
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                acc.x += __shfl_down(acc.x, off);
-                acc.y += __shfl_down(acc.y, off);
-            }
-            if ((tid & 63) == 0) sm.red[tid >> 6] = acc;
-        }
-        __syncthreads();
-        if (a.cyc && emit && tid == 0) {
-            float2 c = cadd(cadd(sm.red[0], sm.red[1]), cadd(sm.red[2], sm.red[3]));
-            c = cmul(c, nco(uint32_t(NB_FFT), dphi));   // conj(w_i) * w_{i+2048}
-            a.cyc[size_t(frame) * NB_FRAME_SYMBOLS + l] = c;
-        }
-        if (FFT_ONLY || l == l_first) continue;
-
-        // ---- A4..A6: differential demod, frequency de-interleave, quantise ----
-        if (tid < NB_CARRIERS / 8) {
-            uint32_t re_lo = 0, re_hi = 0, im_lo = 0, im_hi = 0;
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const float2 d = cmulc(xc[bins[q]], xp[bins[q]]);
-                const float A = fmaxf(fabsf(d.x), fabsf(d.y));
-                int br = 0, bi = 0;
-                if (A != 0.0f) {
-                    br = __float2int_rz(-127.0f * (d.x / A));
-                    bi = __float2int_rz(-127.0f * (d.y / A));
-                }
-                const uint32_t ur = uint32_t(br) & 0xFFu, ui = uint32_t(bi) & 0xFFu;
-                if (q < 4) { re_lo |= ur << (8 * q); im_lo |= ui << (8 * q); }
-                else       { re_hi |= ur << (8 * (q - 4)); im_hi |= ui << (8 * (q - 4)); }
-            }
-            int8_t *o = a.soft + size_t(frame) * NB_FRAME_BITS + size_t(l - 1) * NB_SYM_BITS + tid * 8;
-            *reinterpret_cast<uint2 *>(o) = make_uint2(re_lo, re_hi);
-            *reinterpret_cast<uint2 *>(o + NB_CARRIERS) = make_uint2(im_lo, im_hi);
-        }
-        if (a.dqpsk) {
-            float2 *o = a.dqpsk + (size_t(frame) * NB_DATA_SYMBOLS + (l - 1)) * NB_CARRIERS;
-            for (int i = tid; i < NB_CARRIERS; i += WG) {
-                const int bin = (i < NB_CARRIERS / 2) ? (NB_FFT - NB_CARRIERS / 2 + i) : (i - NB_CARRIERS / 2 + 1);
-                o[i] = cmulc(xc[bin], xp[bin]);
-            }
-        }
-        // the barrier after the next symbol's first pass orders these LDS reads before
-        // the next overwrite of x[]
-    }
-}
-
-
-// ============================================================================
-// Kernel 2 ("wave" variant): one 64-lane wavefront owns a run of consecutive symbols of
-// one frame and keeps a whole 2048-point symbol in registers (32 complex per lane).
-//
-//   n = 128*n1 + 8*n2 + n3   (n1<16, n2<16, n3<8)      k = k1 + 16*k2 + 256*k3
-//   step 1  lane (n2, n3/2): two 16-point DFTs over n1   (inputs are the lane's own 16-byte loads)
-//           twiddle W256^(n2*k1), exchange through LDS
-//   step 2  lane (k1, n3/2): two 16-point DFTs over n2,  twiddle W2048^(n3*(k1+16*k2)), exchange
-//   step 3  lane v = (k1 | k2%4 << 4): four 8-point DFTs over n3 -> bins v + 64*m, m = 0..31
-//
-// Because every lane ends each symbol with the SAME bins, the previous spectrum stays in
-// registers and the differential demodulation needs no memory at all.  The two LDS
-// exchanges use XOR-swizzled layouts that are bank-conflict free for both the
-// ds_write_b64 and the ds_read_b64 side (tools: see DESIGN.md).  No workgroup barrier is
-// needed after the twiddle table is loaded: a wave only talks to itself.
-// Soft bits are scattered as bytes into the (then idle) exchange buffer and leave as
-// three coalesced 16-byte stores per lane.
-// ============================================================================
-#ifndef DAB_OFDM_WAVES
-#define DAB_OFDM_WAVES 4
-#endif
-constexpr int WAVES = DAB_OFDM_WAVES;
+// Twiddle table layout (float2 entries), 16 KB:
+//   [0, TW_E1)       even samples (n3 = 2p, p = 1..3): block k2 has 49 entries -- rows k1>>3 of 24 entries at
+//                    (k1&3) + 4(p-1) + 12((k1>>2)&1), then one entry 1.0 that the p = 0 lanes (n3 = 0) read
+//   [TW_E1, TW_T1)   odd samples (n3 = 2p+1): block k2 has 64 entries -- rows k1>>3 of 32 entries at
+//                    (k1&3) + 4p + 16((k1>>2)&1)
+//   [TW_T1, 2048)    step-1 twiddles W256^(n2*k1) as [k1-1][n2]
+// With lane = 4*k1 + p each 16-lane group of a ds_read2_b64 touches 16 distinct bank pairs and each 32-lane group
+// of a ds_read_b64 32 distinct ones; k2 (step 2) and k1 (step 1) are immediate offsets, so a symbol needs three
+// address registers instead of 47 computed addresses.
+constexpr int TW_E1 = 16 * 49;             // 784
+constexpr int TW_T1 = TW_E1 + 16 * 64;     // 1808
+static_assert(TW_T1 + 15 * 16 == NB_FFT, "twiddle table fills 16 KB exactly");
 
 struct WaveLds {
-    float2 tw[NB_FFT];               // exp(-2*pi*i*m/2048)                                   16 KB
+    float2 tw[NB_FFT];               // twiddles, layout above                                  16 KB
     uint32_t nidx[12 * 64];          // frequency de-interleave table, two data indices per dword  3 KB
     float2 ex[WAVES][NB_FFT / 2];    // per-wave exchange buffer (half a symbol per pass), reused
                                      // as soft-bit staging                                    8 KB each
-};   // 51 KB per 4-wave workgroup -> 3 workgroups = 12 waves per CU
+    float2 cyc[WAVES][32];           // cyclic-prefix correlations waiting to leave as one wide store  1 KB
+};   // 52 KB per 4-wave workgroup -> 3 workgroups = 12 waves per CU
 
 __device__ __forceinline__ float2 cmul_k(float2 a, float c, float s) {   // a * (c + j*s)
     return make_float2(a.x * c - a.y * s, a.x * s + a.y * c);
 }
+
+// a wave-uniform value, kept in a scalar register
+__device__ __forceinline__ float uniform(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ float2 uniform(float2 v) { return make_float2(uniform(v.x), uniform(v.y)); }
 
 // in-place 16-point forward DFT, natural order in and out (radix 4 x 4)
 __device__ __forceinline__ void fft16(float2 *x) {
@@ -216,6 +90,21 @@ __device__ __forceinline__ void fft16(float2 *x) {
     }
 #pragma unroll
     for (int i = 0; i < 16; i++) x[i] = o[i];
+}
+
+// 8-point forward DFT whose odd-indexed inputs still lack a common factor r: c[k] = r * W8^k (wave-uniform).
+// The frequency correction of the odd samples (one more sample period than their even neighbours) rides on the
+// last butterfly stage this way instead of costing a phasor product per row of the load.
+__device__ __forceinline__ void fft8_odd_scaled(float2 *v, const float2 (&c)[4]) {
+    float2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
+    float2 o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+    fft4(e0, e1, e2, e3);
+    fft4(o0, o1, o2, o3);
+    o0 = cmul(o0, c[0]); o1 = cmul(o1, c[1]); o2 = cmul(o2, c[2]); o3 = cmul(o3, c[3]);
+    v[0] = cadd(e0, o0); v[4] = csub(e0, o0);
+    v[1] = cadd(e1, o1); v[5] = csub(e1, o1);
+    v[2] = cadd(e2, o2); v[6] = csub(e2, o2);
+    v[3] = cadd(e3, o3); v[7] = csub(e3, o3);
 }
 
 // wave-wide sum by XOR butterflies on the VALU (DPP / permlane swaps), result in every lane
@@ -252,16 +141,45 @@ __device__ __forceinline__ float wave_sum(float v, int lane) {
     return v;
 }
 
+// The wave's private LDS exchanges are ordered by the hardware (one wave's DS operations execute in order); these
+// keep the compiler from moving the loads of a phase above the stores of the one before.  No instruction is emitted.
+__device__ __forceinline__ void lds_stores_done() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); }
+__device__ __forceinline__ void lds_loads_may_start() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+
+// frequency correction of frame `frame`, as the NCO's 32-bit phase increment per sample
+__device__ __forceinline__ uint32_t frame_dphi(const OfdmArgs &a, int frame) {
+    if (a.state) {
+        const StreamState st = a.state[frame / a.frames_per_stream];
+        return uint32_t(__double2ll_rn(double(st.fine_freq_offset + st.coarse_freq_offset) * 4294967296.0));
+    }
+    return dphi_of(a.freq_offset, frame);
+}
+
 // SELECT: soft-bit selection table in use (a separate instantiation so that the plain kernel keeps its registers)
-// NCO: a frequency correction is applied (the launch has a freq_offset array or acquired frames).  A compile-time
-// switch, not a per-frame branch: the branch cost 31 register moves per symbol where its two paths re-joined.
+// NCO: a frequency correction is applied (the launch has a freq_offset array, stream states or acquired frames).  A
+// compile-time switch, not a per-frame branch: the branch cost 31 register moves per symbol where its two paths
+// re-joined.
 template <bool FFT_ONLY, bool WITH_DQPSK, bool SELECT = false, bool NCO = true>
 __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab, OfdmArgs a, int parts, int n_items) {
     __shared__ WaveLds sm;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    for (int i = tid; i < NB_FFT; i += 64 * WAVES) sm.tw[i] = tab.twiddle[i];
+    for (int i = tid; i < NB_FFT; i += 64 * WAVES) {
+        int m;                                                  // exponent of exp(-2*pi*i/2048)
+        if (i < TW_E1) {
+            const int k2 = i / 49, r = i - 49 * k2;
+            const int hi = r / 24, s = r - 24 * hi, kq = s / 12, s2 = s - 12 * kq;
+            m = r == 48 ? 0 : 2 * ((s2 >> 2) + 1) * (hi * 8 + kq * 4 + (s2 & 3) + 16 * k2);
+        } else if (i < TW_T1) {
+            const int j = i - TW_E1, k2 = j >> 6, r = j & 63;
+            m = (2 * ((r >> 2) & 3) + 1) * ((r >> 5) * 8 + ((r >> 4) & 1) * 4 + (r & 3) + 16 * k2);
+        } else {
+            const int j = i - TW_T1;
+            m = 8 * (j & 15) * ((j >> 4) + 1);
+        }
+        sm.tw[i] = tab.twiddle[m];                              // m <= 1800
+    }
     for (int i = tid; i < 12 * 64; i += 64 * WAVES) sm.nidx[i] = reinterpret_cast<const uint32_t *>(tab.n_of_vj)[i];
     __syncthreads();
     // The item is the same for all lanes of a wave; saying so keeps everything derived from it (frame pointers, the
@@ -290,48 +208,56 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
         dphi_acq = uint32_t(__double2ll_rn(double(m.freq_offset) * 4294967296.0));
     }
     const bool aligned16 = (reinterpret_cast<uintptr_t>(fiq) & 15u) == 0;
-#ifdef DAB_OFDM_STAGGER
-    // de-phase the co-resident waves so that their load / FFT / LDS phases do not line up
-    for (int i = 0; i < (item % 12) * DAB_OFDM_STAGGER; i++) __builtin_amdgcn_s_sleep(32);
-#endif
-#ifdef DAB_EXP_NOPLL
-    const uint32_t dphi = 0u;
-#else
-    const uint32_t dphi = a.acq ? dphi_acq : dphi_of(a.freq_offset, frame);
-#endif
-#ifdef DAB_EXP_NOCYC
-    a.cyc = nullptr;
-#endif
+    const uint32_t dphi = a.acq ? dphi_acq : frame_dphi(a, frame);
     float2 *ex = sm.ex[wave];
     const float2 *tw = sm.tw;
 
-    // lane roles
-    const int n2 = lane >> 2, p = lane & 3;            // step 1 (and k1 = n2, p' = p in step 2)
-    const int k1v = lane & 15, kk = lane >> 4;         // step 3
-    // exchange-1 slots (one pass per e = n3 & 1): (n3/2)*256 + k1*16 + (n2 ^ (n3/2)<<2 ^ (k1/2)&3)
-    const int w1_base = p * 256, w1_r = n2 ^ (p << 2);
-    // exchange-2 slots (one pass per half of k2): n3*128 + (k2 % 8)*16 + (k1 ^ (n3/2)<<2)
-    const int w2_base = p * 256 + (n2 ^ (p << 2));
-    const int r2_base = kk * 16;
-
-    // step-1 twiddles W256^(n2*k1) are the same for every symbol: keep them in registers? (30 VGPRs) -- no,
-    // they are re-read from LDS per symbol; the table index is 8*n2*k1.
-    // frequency de-interleave: data index of each carrier register (24 per lane)
+    // the previous symbol's carriers (unrolling the symbol loop by two to alternate between two register sets and
+    // save the 48 moves per symbol was tried: the allocator then spills ~40 registers)
     float2 prev[24];
 #pragma unroll
     for (int j = 0; j < 24; j++) prev[j] = make_float2(0.f, 0.f);
 
-    const float2 r1 = nco(1u, dphi), r128 = nco(128u, dphi), rot2048 = nco(uint32_t(NB_FFT), dphi);
+    // NCO phasors.  Wave-uniform ones live in SGPRs: rotation per row of 128 samples and per 2048 samples (cyclic-prefix
+    // correlation); the odd samples' extra sample period times W8^k for the last stage.
+    const float2 r128 = uniform(nco(128u, dphi)), rot2048 = uniform(nco(uint32_t(NB_FFT), dphi));
+    float2 codd[4];
+    {
+        const float2 r1 = nco(1u, dphi);
+        codd[0] = uniform(r1);
+        codd[1] = uniform(cmul_k(r1, SQRT1_2, -SQRT1_2));
+        codd[2] = uniform(mul_mj(r1));
+        codd[3] = uniform(cmul_k(r1, -SQRT1_2, -SQRT1_2));
+    }
+    // The correlation of symbol l is one 8-byte value: written on its own it is a partial cache line that the
+    // memory side has to read-modify-write.  They are collected in LDS and leave 32 at a time (or at the end of the
+    // run; the last symbol of a run always has a value: only a run's reference symbol l_first > 0 has none).
+    auto put_cyc = [&](const int l, const float2 c) {
+        const int slot = (l - l_first) & 31;                    // wave-uniform
+        if (lane == 0) sm.cyc[wave][slot] = c;
+        if (slot == 31 || l == l_last) {
+            lds_stores_done();
+            lds_loads_may_start();
+            const int li = l - slot + lane;                     // symbol whose value lane `lane` carries out
+            if (lane <= slot && (FFT_ONLY || li > l_first || li == 0))
+                a.cyc[size_t(frame) * NB_FRAME_SYMBOLS + li] = sm.cyc[wave][lane];
+        }
+    };
 
     for (int l = l_first; l <= l_last; l++) {
         const float2 *sym = fiq + size_t(l) * NB_SYM_PERIOD;
         const bool emit = FFT_ONLY || (l > l_first) || (l == 0);
-        // Opaque per-iteration copies of the lane roles: every LDS address below is one or two VALU ops
-        // from these, which is cheaper than letting LICM park ~60 loop-invariant addresses in VGPRs (spills).
-        int n2i = n2, pi = p;
-        asm volatile("" : "+v"(n2i), "+v"(pi));
-        // phasor of this lane's first sample, computed before the loads so sincospi's temporaries are dead
-        // by the time 64 data registers are live
+        // Lane roles, derived per iteration from an opaque copy of the lane number: every LDS address below is one or
+        // two VALU ops from these, which is cheaper than letting LICM park ~60 loop-invariant addresses in VGPRs (spills).
+        int li = lane;
+        asm volatile("" : "+v"(li));
+        const int n2i = li >> 2, pi = li & 3;              // step 1 (and k1 = n2, p' = p in step 2)
+        const int k1v = li & 15, kk = li >> 4;             // step 3
+        // exchange-1 slots (one pass per e = n3 & 1): (n3/2)*256 + k1*16 + (n2 ^ (n3/2)<<2 ^ (k1/2)&3)
+        const int w1_base = pi * 256, w1_r = n2i ^ (pi << 2);
+        // exchange-2 slots (one pass per half of k2): n3*128 + (k2 % 8)*16 + (k1 ^ (n3/2)<<2)
+        const int w2_base = pi * 256 + (n2i ^ (pi << 2));
+        const int r2_base = kk * 16;
         if constexpr (SELECT) {
             // A symbol is transformed only if some of its own soft bits are wanted or it is the differential
             // reference of a wanted one.  The others give at most their cyclic-prefix correlation, which needs the
@@ -356,17 +282,16 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
                     }
                     acc.x = wave_sum(acc.x, lane);
                     acc.y = wave_sum(acc.y, lane);
-                    if (lane == 0) a.cyc[size_t(frame) * NB_FRAME_SYMBOLS + l] = cmul(acc, rot2048);
+                    put_cyc(l, cmul(acc, rot2048));
                 }
                 continue;
             }
         }
+        // phasor of this lane's first sample, from the exact 32-bit phase (a recurrence from the previous symbol would
+        // save ~45 instructions but make a frame's soft bits depend on how the batch was cut into runs); computed
+        // before the loads so sincospi's temporaries are dead by the time 64 data registers are live
         float2 w = make_float2(1.f, 0.f);
-#ifdef DAB_EXP_NCO_BRANCH
-        if (dphi != 0u) w = nco(uint32_t(l * NB_SYM_PERIOD + NB_CP + 2 * lane), dphi);
-#else
         if constexpr (NCO) w = nco(uint32_t(l * NB_SYM_PERIOD + NB_CP + 2 * lane), dphi);
-#endif
         __builtin_amdgcn_sched_barrier(0);
         // ---- loads: 16 x 16 B per lane, row n1 = samples 128*n1 + 2*lane, +1 ----
         float2 x0[16], x1[16];
@@ -374,13 +299,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
             const float4 *rows = reinterpret_cast<const float4 *>(sym + NB_CP) + lane;
 #pragma unroll
             for (int n1 = 0; n1 < 16; n1++) {
-#ifdef DAB_EXP_NT_LD
-                typedef float v4f __attribute__((ext_vector_type(4)));
-                const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(rows + 64 * n1));
-                const float4 v = make_float4(t.x, t.y, t.z, t.w);
-#else
                 const float4 v = rows[64 * n1];
-#endif
                 x0[n1] = make_float2(v.x, v.y);
                 x1[n1] = make_float2(v.z, v.w);
             }
@@ -414,19 +333,16 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
             }
             acc.x = wave_sum(acc.x, lane);
             acc.y = wave_sum(acc.y, lane);
-            if (lane == 0) a.cyc[size_t(frame) * NB_FRAME_SYMBOLS + l] = cmul(acc, rot2048);
+            put_cyc(l, cmul(acc, rot2048));
         }
         __builtin_amdgcn_sched_barrier(0);
-        // ---- A2: NCO ----
-#ifdef DAB_EXP_NCO_BRANCH
-        if (dphi != 0u) {
-#else
+        // ---- A2: NCO.  Even and odd sample of a load get the same phasor here; the odd one's missing sample
+        // period is applied in step 3 (fft8_odd_scaled) ----
         if constexpr (NCO) {
-#endif
 #pragma unroll
             for (int n1 = 0; n1 < 16; n1++) {
                 x0[n1] = cmul(x0[n1], w);
-                x1[n1] = cmul(x1[n1], cmul(w, r1));
+                x1[n1] = cmul(x1[n1], w);
                 // pin the order row by row: without this the whole phasor chain is computed up front and
                 // ~100 extra VGPRs are live next to the 64 data registers (spills)
                 asm volatile("" : "+v"(x0[n1].x), "+v"(x0[n1].y), "+v"(x1[n1].x), "+v"(x1[n1].y));
@@ -440,20 +356,28 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
         __builtin_amdgcn_sched_barrier(0);
         fft16(x1);
         __builtin_amdgcn_sched_barrier(0);
+        {
+            const float2 *t1 = tw + TW_T1 + n2i;
 #pragma unroll
-        for (int k1 = 1; k1 < 16; k1++) {
-            const float2 t = tw[(8 * n2i) * k1];          // index <= 8*15*15 = 1800
-            x0[k1] = cmul(x0[k1], t);
-            x1[k1] = cmul(x1[k1], t);
+            for (int k1 = 1; k1 < 16; k1++) {
+                const float2 t = t1[(k1 - 1) * 16];
+                x0[k1] = cmul(x0[k1], t);
+                x1[k1] = cmul(x1[k1], t);
+            }
         }
         // ---- exchange 1 + step 2, one pass per column parity e (the buffer holds half a symbol) ----
         const int r1b = pi * 256 + n2i * 16, r1x = (pi << 2) ^ ((n2i >> 1) & 3);
 #pragma unroll
         for (int k1 = 0; k1 < 16; k1++) ex[w1_base + k1 * 16 + (w1_r ^ ((k1 >> 1) & 3))] = x0[k1];
+        lds_stores_done();
+        lds_loads_may_start();
 #pragma unroll
         for (int m = 0; m < 16; m++) x0[m] = ex[r1b + (m ^ r1x)];
+        lds_stores_done();
 #pragma unroll
         for (int k1 = 0; k1 < 16; k1++) ex[w1_base + k1 * 16 + (w1_r ^ ((k1 >> 1) & 3))] = x1[k1];
+        lds_stores_done();
+        lds_loads_may_start();
 #pragma unroll
         for (int m = 0; m < 16; m++) x1[m] = ex[r1b + (m ^ r1x)];
         __builtin_amdgcn_sched_barrier(0);
@@ -462,23 +386,28 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
         fft16(x1);
         __builtin_amdgcn_sched_barrier(0);
         {
-            // W2048^(n3*(k1+16*k2)), k1 = n2 of this lane, n3 = 2p (+1)
-            const int i0 = 2 * pi * n2i, st0 = 32 * pi, i1 = i0 + n2i, st1 = st0 + 16;
+            // W2048^(n3*(k1+16*k2)), k1 = n2 of this lane, n3 = 2p (+1): see the table layout at WaveLds
+            const int hi = n2i >> 3, kq = (n2i >> 2) & 1, klo = n2i & 3;
+            const float2 *t0 = tw + (pi ? hi * 24 + kq * 12 + (pi - 1) * 4 + klo : 48);
+            const float2 *t1 = tw + TW_E1 + hi * 32 + kq * 16 + pi * 4 + klo;
 #pragma unroll
             for (int k2 = 0; k2 < 16; k2++) {
-                x0[k2] = cmul(x0[k2], tw[i0 + st0 * k2]);
-                x1[k2] = cmul(x1[k2], tw[i1 + st1 * k2]);
+                x0[k2] = cmul(x0[k2], t0[49 * k2]);
+                x1[k2] = cmul(x1[k2], t1[64 * k2]);
             }
         }
         // ---- exchange 2 + step 3 in two passes over k2 (k2 < 8, then k2 >= 8) ----
         float2 X[4][8];
 #pragma unroll
         for (int h = 0; h < 2; h++) {
+            lds_stores_done();                                 // (the reads of the pass before are program-ordered loads)
 #pragma unroll
             for (int k2 = 0; k2 < 8; k2++) {
                 ex[w2_base + k2 * 16] = x0[8 * h + k2];
                 ex[w2_base + k2 * 16 + 128] = x1[8 * h + k2];
             }
+            lds_stores_done();
+            lds_loads_may_start();
             // lane v reads B[n3][k1v][k2 = 8h + 4c' + kk], c' = 0,1
 #pragma unroll
             for (int cc = 0; cc < 2; cc++) {
@@ -489,7 +418,10 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int c = 0; c < 4; c++) fft8(X[c]);
+        for (int c = 0; c < 4; c++) {
+            if constexpr (NCO) fft8_odd_scaled(X[c], codd);
+            else fft8(X[c]);
+        }
         __builtin_amdgcn_sched_barrier(0);
         // bin of X[c][k3] is lane + 64*(c + 4*k3)
         if (FFT_ONLY) {
@@ -517,22 +449,19 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
                 wanted = (kw[0] | kw[1] | kw[2]) != 0ull;
             }
         }
-#ifdef DAB_EXP_NOEPI
-        if (l > l_first && cur[3].x == 12345.f) {
-#else
         if (l > l_first && wanted) {
-#endif
             uint8_t *stg = reinterpret_cast<uint8_t *>(ex);
+            lds_stores_done();
 #pragma unroll
             for (int j = 0; j < 24; j++) {
                 const float2 d = cmulc(cur[j], prev[j]);
-                // A6: trunc(-127 * c / max(|re|,|im|)).  One v_rcp (1 ulp) instead of two IEEE divisions; the
-                // 2^-22 head-room makes the larger component land on exactly +-127 after the clamp, as an exact
-                // division gives.  A == 0 (erased carrier) yields 0 because d == 0 and the floor keeps sc finite.
+                // A6: trunc(-127 * c / max(|re|,|im|)).  One v_rcp (1 ulp) instead of two IEEE divisions; the 2^-22
+                // head-room keeps the larger component's product in [127, 127.0001], which the truncating conversion
+                // turns into exactly +-127 as an exact division gives (no clamp needed: nothing exceeds 127.0001).
+                // A == 0 (erased carrier) yields 0 because d == 0 and the floor keeps sc finite.
                 const float Amax = fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), 1.0e-30f);
                 const float sc = -127.00003f * __builtin_amdgcn_rcpf(Amax);
-                const int br = int(__builtin_amdgcn_fmed3f(d.x * sc, -127.0f, 127.0f));
-                const int bi = int(__builtin_amdgcn_fmed3f(d.y * sc, -127.0f, 127.0f));
+                const int br = int(d.x * sc), bi = int(d.y * sc);
                 const uint32_t nd = sm.nidx[(j >> 1) * 64 + lane];
                 const uint32_t ni = (j & 1) ? (nd >> 16) : (nd & 0xFFFFu);
                 stg[ni] = uint8_t(br);
@@ -546,15 +475,11 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
                     dq[bin >= 1280 ? bin - 1280 : bin + 767] = d;
                 }
             }
+            lds_stores_done();
+            lds_loads_may_start();
             const uint4 *sv = reinterpret_cast<const uint4 *>(stg) + lane;
             uint4 *o = reinterpret_cast<uint4 *>(a.soft + size_t(frame) * NB_FRAME_BITS + size_t(l - 1) * NB_SYM_BITS) + lane;
             const uint4 s0 = sv[0], s1 = sv[64], s2 = sv[128];
-#ifdef DAB_EXP_NT_ST
-            typedef unsigned v4u __attribute__((ext_vector_type(4)));
-            __builtin_nontemporal_store(v4u{s0.x, s0.y, s0.z, s0.w}, reinterpret_cast<v4u *>(o));
-            __builtin_nontemporal_store(v4u{s1.x, s1.y, s1.z, s1.w}, reinterpret_cast<v4u *>(o + 64));
-            __builtin_nontemporal_store(v4u{s2.x, s2.y, s2.z, s2.w}, reinterpret_cast<v4u *>(o + 128));
-#else
             if constexpr (SELECT) {
                 // wave-uniform selection words; one predicated 16-byte store per chunk
                 const unsigned long long *kw = a.keep + 3 * __builtin_amdgcn_readfirstlane(l - 1);
@@ -565,42 +490,78 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
             } else {
                 o[0] = s0; o[64] = s1; o[128] = s2;
             }
-#endif
         }
 #pragma unroll
         for (int j = 0; j < 24; j++) prev[j] = cur[j];
     }
 }
 
+// One wave per stream.  Restated by oracle.py stream_update() for the parity test.
+__global__ __launch_bounds__(64) void stream_update_kernel(StreamState *state, const float2 *cyc, const float2 *iq,
+                                                           size_t frame_stride, int frames_per_stream, float beta,
+                                                           float thr_null_start) {
+    const int s = blockIdx.x, lane = threadIdx.x;
+    const float2 *c = cyc + size_t(s) * frames_per_stream * NB_FRAME_SYMBOLS;
+    const int n = frames_per_stream * NB_FRAME_SYMBOLS;
+    float acc = 0.f;
+    for (int i = lane; i < n; i += 64) acc += atan2f(c[i].y, c[i].x);
+    acc = wave_sum(acc, lane);
+    // level of the stream's most recent frame: first 4096 samples (PRS and the start of the first data symbol)
+    const float4 *x = reinterpret_cast<const float4 *>(iq + (size_t(s) * frames_per_stream + (frames_per_stream - 1)) * frame_stride);
+    float l1 = 0.f;
+    for (int i = lane; i < 2048; i += 64) {
+        const float4 v = x[i];
+        l1 += fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w);
+    }
+    l1 = wave_sum(l1, lane) * (1.0f / 4096.0f);
+    if (lane == 0) {
+        StreamState st = state[s];
+        const float err = acc / float(n) * (1.0f / (6.283185307179586f * float(NB_FFT)));
+        constexpr float HALF = 0.5f / float(NB_FFT);
+        float f = st.fine_freq_offset - beta * err;
+        if (f > HALF) f -= 2.f * HALF;
+        if (f < -HALF) f += 2.f * HALF;
+        st.fine_freq_offset = f;
+        st.last_fine_error = err;
+        if (st.signal_average > 0.f && l1 < thr_null_start * st.signal_average) {
+            st.total_frames_desync += 1;
+            st.total_frames_read += frames_per_stream - 1;
+        } else {
+            st.total_frames_read += frames_per_stream;
+            st.signal_average = st.signal_average > 0.f ? 0.95f * st.signal_average + 0.05f * l1 : l1;
+        }
+        state[s] = st;
+    }
+}
+
 }  // namespace
 
-static bool use_v0() {
-    static const bool v = std::getenv("DABGPU_OFDM_V0") != nullptr;
-    return v;
+hipError_t launch_stream_update(StreamState *state, const float2 *cyc, const float2 *iq, size_t frame_stride,
+                                int n_streams, int frames_per_stream, float beta, float thr_null_start, hipStream_t s) {
+    if (n_streams <= 0 || frames_per_stream <= 0) return hipSuccess;
+    hipLaunchKernelGGL(stream_update_kernel, dim3(unsigned(n_streams)), dim3(64), 0, s, state, cyc, iq, frame_stride,
+                       frames_per_stream, beta, thr_null_start);
+    return hipGetLastError();
 }
 
 hipError_t launch_ofdm_demod(const OfdmTables &t, const OfdmArgs &a, int parts, hipStream_t s) {
     if (a.n_frames <= 0) return hipSuccess;
     if (parts <= 0 || parts > NB_DATA_SYMBOLS) return hipErrorInvalidValue;
+    if (a.state && a.frames_per_stream <= 0) return hipErrorInvalidValue;
     const int items = a.n_frames * parts;
-    if (use_v0() && (a.acq || a.keep)) return hipErrorInvalidValue;   // the first-generation kernel: aligned frames, all bits
-    if (use_v0()) {
-        hipLaunchKernelGGL(ofdm_kernel<false>, dim3(unsigned(items)), dim3(WG), 0, s, t, a, parts);
+    const bool nco = a.freq_offset != nullptr || a.acq != nullptr || a.state != nullptr;
+    const dim3 grid(unsigned((items + WAVES - 1) / WAVES)), block(64 * WAVES);
+    OfdmArgs b = a;
+    if (a.dqpsk) b.keep = nullptr;      // the constellation output covers every symbol: a selection is ignored there
+    if (b.dqpsk) {
+        if (nco) hipLaunchKernelGGL((ofdm_wave_kernel<false, true, false, true>), grid, block, 0, s, t, b, parts, items);
+        else hipLaunchKernelGGL((ofdm_wave_kernel<false, true, false, false>), grid, block, 0, s, t, b, parts, items);
+    } else if (b.keep) {
+        if (nco) hipLaunchKernelGGL((ofdm_wave_kernel<false, false, true, true>), grid, block, 0, s, t, b, parts, items);
+        else hipLaunchKernelGGL((ofdm_wave_kernel<false, false, true, false>), grid, block, 0, s, t, b, parts, items);
     } else {
-        const bool nco = a.freq_offset != nullptr || a.acq != nullptr;
-        const dim3 grid(unsigned((items + WAVES - 1) / WAVES)), block(64 * WAVES);
-        OfdmArgs b = a;
-        if (a.dqpsk) b.keep = nullptr;      // the constellation output covers every symbol: a selection is ignored there
-        if (b.dqpsk) {
-            if (nco) hipLaunchKernelGGL((ofdm_wave_kernel<false, true, false, true>), grid, block, 0, s, t, b, parts, items);
-            else hipLaunchKernelGGL((ofdm_wave_kernel<false, true, false, false>), grid, block, 0, s, t, b, parts, items);
-        } else if (b.keep) {
-            if (nco) hipLaunchKernelGGL((ofdm_wave_kernel<false, false, true, true>), grid, block, 0, s, t, b, parts, items);
-            else hipLaunchKernelGGL((ofdm_wave_kernel<false, false, true, false>), grid, block, 0, s, t, b, parts, items);
-        } else {
-            if (nco) hipLaunchKernelGGL((ofdm_wave_kernel<false, false, false, true>), grid, block, 0, s, t, b, parts, items);
-            else hipLaunchKernelGGL((ofdm_wave_kernel<false, false, false, false>), grid, block, 0, s, t, b, parts, items);
-        }
+        if (nco) hipLaunchKernelGGL((ofdm_wave_kernel<false, false, false, true>), grid, block, 0, s, t, b, parts, items);
+        else hipLaunchKernelGGL((ofdm_wave_kernel<false, false, false, false>), grid, block, 0, s, t, b, parts, items);
     }
     return hipGetLastError();
 }
@@ -608,14 +569,11 @@ hipError_t launch_ofdm_demod(const OfdmTables &t, const OfdmArgs &a, int parts, 
 hipError_t launch_fft_symbols(const OfdmTables &t, const OfdmArgs &a, int parts, hipStream_t s) {
     if (a.n_frames <= 0) return hipSuccess;
     if (parts <= 0 || parts > NB_FRAME_SYMBOLS) return hipErrorInvalidValue;
+    if (a.state && a.frames_per_stream <= 0) return hipErrorInvalidValue;
     const int items = a.n_frames * parts;
-    if (use_v0()) {
-        hipLaunchKernelGGL(ofdm_kernel<true>, dim3(unsigned(items)), dim3(WG), 0, s, t, a, parts);
-    } else {
-        const dim3 grid(unsigned((items + WAVES - 1) / WAVES)), block(64 * WAVES);
-        if (a.freq_offset) hipLaunchKernelGGL((ofdm_wave_kernel<true, false, false, true>), grid, block, 0, s, t, a, parts, items);
-        else hipLaunchKernelGGL((ofdm_wave_kernel<true, false, false, false>), grid, block, 0, s, t, a, parts, items);
-    }
+    const dim3 grid(unsigned((items + WAVES - 1) / WAVES)), block(64 * WAVES);
+    if (a.freq_offset || a.state) hipLaunchKernelGGL((ofdm_wave_kernel<true, false, false, true>), grid, block, 0, s, t, a, parts, items);
+    else hipLaunchKernelGGL((ofdm_wave_kernel<true, false, false, false>), grid, block, 0, s, t, a, parts, items);
     return hipGetLastError();
 }
 

@@ -175,9 +175,6 @@ __global__ __launch_bounds__(WGV) void viterbi_wave_kernel(Fetch fetch, CodeTabl
 // ============================================================================
 template <int XORMASK>
 __device__ __forceinline__ int lane_xchg(int m, int lane) {
-#ifdef DABGPU_VIT_SAFE_XCHG
-    return __shfl_xor(m, XORMASK);
-#else
     if constexpr (XORMASK == 1) {
         return __builtin_amdgcn_update_dpp(0, m, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
     } else if constexpr (XORMASK == 2) {
@@ -196,7 +193,6 @@ __device__ __forceinline__ int lane_xchg(int m, int lane) {
         const u2 r = __builtin_amdgcn_permlane32_swap(unsigned(m), unsigned(m), false, false);
         return (lane & 32) ? int(r.x) : int(r.y);
     }
-#endif
 }
 
 struct RotTables {
@@ -261,9 +257,7 @@ __global__ __launch_bounds__(WGV) void viterbi_rot_kernel(Fetch fetch, CodeTable
     // ---- A8: depuncture into LDS ----
     for (int i = lane; i < mother_bytes / 4; i += 64) m4[i] = 0;
     __syncthreads();
-#ifndef DAB_EXP_NO_DEPUNCT
     for (int i = lane; i < code.n_punct; i += 64) mother[code.mother_pos[i]] = fetch(cw, i);
-#endif
     __syncthreads();
 
     // ---- per-lane sign tables for the six layout phases ----
@@ -284,11 +278,7 @@ __global__ __launch_bounds__(WGV) void viterbi_rot_kernel(Fetch fetch, CodeTable
     int metric = (lane == 0) ? 0 : -VITERBI_INIT_PENALTY;
     unsigned dec = 0;
     int cw0 = m4[lane], cw1 = m4[64 + (lane & 31)];
-#ifdef DAB_EXP_NO_FORWARD
-    for (int c = 0; c < 0; c++) {
-#else
     for (int c = 0; c < nchunks; c++) {
-#endif
         const int a0 = cw0, a1 = cw1;
         const int tn = (c + 1) * 96;
         cw0 = m4[min(tn + lane, nsteps - 1)];              // prefetch; clamped so it never leaves the codeword
@@ -412,9 +402,7 @@ template <class Fetch, Tail TAIL>
 hipError_t launch_wave(Fetch f, const CodeTables &c, int n_codewords, uint8_t *out, uint8_t *crc_ok,
                        hipStream_t s) {
     if (n_codewords <= 0) return hipSuccess;
-    static const bool force_v0 = std::getenv("DABGPU_VITERBI_V0") != nullptr;
-    const bool rot = !force_v0 && c.nsteps >= 102 && (c.nsteps - 6) % 96 == 0 &&
-                     viterbi_rot_lds_bytes(c.nsteps) <= 160 * 1024;
+    const bool rot = c.nsteps >= 102 && (c.nsteps - 6) % 96 == 0 && viterbi_rot_lds_bytes(c.nsteps) <= 160 * 1024;
     const size_t per_wave = rot ? viterbi_rot_lds_bytes(c.nsteps) : viterbi_wave_lds_bytes(c.nsteps);
     int lds_per_wave = int((per_wave + 255) & ~size_t(255));
     // 4 waves per workgroup normally; long codewords (high bit rates) need more LDS per wave -> fewer waves
@@ -424,12 +412,6 @@ hipError_t launch_wave(Fetch f, const CodeTables &c, int n_codewords, uint8_t *o
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const unsigned grid = unsigned((n_codewords + waves - 1) / waves);
     lds = balanced_lds_bytes(grid, lds, 8);
-    const void *kern = rot ? reinterpret_cast<const void *>(viterbi_rot_kernel<Fetch, TAIL>)
-                           : reinterpret_cast<const void *>(viterbi_wave_kernel<Fetch, TAIL>);
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-        if (e != hipSuccess) return e;
-    }
     if (rot)
         hipLaunchKernelGGL((viterbi_rot_kernel<Fetch, TAIL>), dim3(grid), dim3(64 * waves), lds, s, f, c, n_codewords, out,
                            crc_ok, lds_per_wave);
@@ -439,7 +421,24 @@ hipError_t launch_wave(Fetch f, const CodeTables &c, int n_codewords, uint8_t *o
     return hipGetLastError();
 }
 
+template <class Fetch, Tail TAIL>
+hipError_t allow_full_lds() {
+    for (const void *k : {reinterpret_cast<const void *>(viterbi_rot_kernel<Fetch, TAIL>),
+                          reinterpret_cast<const void *>(viterbi_wave_kernel<Fetch, TAIL>)}) {
+        const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 }  // namespace
+
+hipError_t init_viterbi_kernel_attributes() {
+    hipError_t e = allow_full_lds<FetchFic, Tail::kFic>();
+    if (e == hipSuccess) e = allow_full_lds<FetchPlain, Tail::kBytes>();
+    if (e == hipSuccess) e = allow_full_lds<FetchMsc, Tail::kBytes>();
+    return e;
+}
 
 hipError_t launch_fic_decode(const CodeTables &c, const int8_t *soft, size_t soft_stride, int n_frames,
                              uint8_t *fib, uint8_t *crc_ok, hipStream_t s) {

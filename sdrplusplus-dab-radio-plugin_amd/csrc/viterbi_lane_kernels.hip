@@ -22,7 +22,6 @@
 // in place by packed add/sub/max on both halves at once; for q = 0 it is the two halves of one register (one
 // half-swap).  Nothing ever moves.
 #include <algorithm>
-#include <cstdlib>
 #include <vector>
 
 #include "kernels.hpp"
@@ -111,10 +110,7 @@ __device__ __forceinline__ int desc_extra(const LSrcMsc &s) { return s.d_force >
 // in LDS with 16-byte loads along the codewords; then every thread assembles the 4 soft bytes of (step, lane)
 // from LDS and the stores run along the lanes: M[group][step][lane].
 // ---------------------------------------------------------------------------------------------------------
-#ifndef DAB_PREP_STEPS
-#define DAB_PREP_STEPS 64
-#endif
-constexpr int PREP_STEPS = DAB_PREP_STEPS;
+constexpr int PREP_STEPS = 64;
 // bytes per staged row: the span (<= 4 bytes per step) rounded up to 16-byte chunks + one chunk of alignment slack,
 // padded to an odd number of dwords (64 steps: 17 chunks + 4 = 276 B = 69 dwords)
 constexpr int PREP_PITCH = ((4 * PREP_STEPS + 15) / 16 + 1) * 16 + 4;
@@ -618,33 +614,17 @@ hipError_t run_lane(Src f, bool vec16, bool fusable, const CodeTables &c, const 
     uint32_t *M = reinterpret_cast<uint32_t *>(sc.base);
     uint2 *dec = reinterpret_cast<uint2 *>(M + size_t(groups) * c.nsteps * 64);
     const unsigned fgrid = unsigned((groups + 3) / 4);
-    static const bool no_fuse = std::getenv("DABGPU_LANE_NOFUSE") != nullptr;
-    if (fusable && vec16 && lt.fused_desc && lt.fused_tiles && !no_fuse) {
+    if (fusable && vec16 && lt.fused_desc && lt.fused_tiles && !sc.unfused) {
         const size_t lds = balanced_lds_bytes(fgrid, size_t(4) * (64 + Src::PRE) * FPITCH, 3);
-        const void *kern = reinterpret_cast<const void *>(lane_forward_fused_kernel<Src>);
-        if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-            if (e != hipSuccess) return e;
-        }
         hipLaunchKernelGGL((lane_forward_fused_kernel<Src>), dim3(fgrid), dim3(256), lds, s, f, lt.fused_desc, lt.fused_tiles,
                            c.nsteps, groups, n_codewords, dec);
     } else {
         hipLaunchKernelGGL((lane_prep_kernel<Src>), dim3(unsigned((c.nsteps + PREP_STEPS - 1) / PREP_STEPS), unsigned(groups)),
                            dim3(256), 0, s, f, lt.punct_idx, c.nsteps, n_codewords, int(vec16), M);
         const size_t fwd_lds = balanced_lds_bytes(fgrid, 0, 8);
-        if (fwd_lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lane_forward_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, int(fwd_lds));
-            if (e != hipSuccess) return e;
-        }
         hipLaunchKernelGGL(lane_forward_kernel, dim3(fgrid), dim3(256), fwd_lds, s, M, c.nsteps, groups, dec);
     }
     const size_t tb_lds = size_t(64) * (nwords | 1) * 4;
-    if (tb_lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lane_traceback_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, int(tb_lds));
-        if (e != hipSuccess) return e;
-    }
     hipLaunchKernelGGL(lane_traceback_kernel, dim3(unsigned(groups)), dim3(64), tb_lds, s, dec, c.nsteps, n_codewords,
                        c.prbs_bytes, out, crc_ok);
     return hipGetLastError();
@@ -653,6 +633,20 @@ hipError_t run_lane(Src f, bool vec16, bool fusable, const CodeTables &c, const 
 inline bool aligned16(const void *p, size_t stride) { return ((reinterpret_cast<uintptr_t>(p) | stride) & 15) == 0; }
 
 }  // namespace
+
+hipError_t init_lane_kernel_attributes() {
+    for (const void *k : {reinterpret_cast<const void *>(lane_forward_kernel),
+                          reinterpret_cast<const void *>(lane_forward_fused_kernel<LSrcFic>),
+                          reinterpret_cast<const void *>(lane_forward_fused_kernel<LSrcPlain>),
+                          reinterpret_cast<const void *>(lane_forward_fused_kernel<LSrcMsc>),
+                          reinterpret_cast<const void *>(lane_forward_grouped_kernel),
+                          reinterpret_cast<const void *>(lane_traceback_kernel),
+                          reinterpret_cast<const void *>(lane_traceback_grouped_kernel)}) {
+        const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
 
 size_t lane_scratch_bytes(int nsteps, int n_codewords) {
     const size_t groups = size_t((n_codewords + 63) / 64);
@@ -742,19 +736,8 @@ hipError_t launch_lane_group(const LaneGroupItem *items, int n, const LaneScratc
         }
         const unsigned fgrid = unsigned((pack.total_groups + 3) / 4);
         const size_t lds = balanced_lds_bytes(fgrid, size_t(4) * (64 + LSrcMsc::PRE) * FPITCH, 3);
-        hipError_t err;
-        if (lds > 64 * 1024) {
-            err = hipFuncSetAttribute(reinterpret_cast<const void *>(lane_forward_grouped_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-            if (err != hipSuccess) return err;
-        }
         hipLaunchKernelGGL(lane_forward_grouped_kernel, dim3(fgrid), dim3(256), lds, s, pack);
         const size_t tb_lds = size_t(64) * (max_nwords | 1) * 4;
-        if (tb_lds > 64 * 1024) {
-            err = hipFuncSetAttribute(reinterpret_cast<const void *>(lane_traceback_grouped_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, int(tb_lds));
-            if (err != hipSuccess) return err;
-        }
         hipLaunchKernelGGL(lane_traceback_grouped_kernel, dim3(unsigned(pack.total_groups)), dim3(64), tb_lds, s, pack);
     }
     return hipGetLastError();

@@ -35,8 +35,15 @@ EXPORTS = [
     "dabgpu_msc_decode_multi_dev", "dabgpu_dabplus_superframes_dev", "dabgpu_dabplus_superframes",
     "dabgpu_acquire_default_cfg", "dabgpu_acquire_dev", "dabgpu_acquire", "dabgpu_ofdm_demod_acquired_dev",
     "dabgpu_ofdm_set_soft_selection", "dabgpu_soft_selection", "dabgpu_uep_subchannel",
-    "dabgpu_host_alloc", "dabgpu_host_free", "dabgpu_decode_frames_dev",
+    "dabgpu_host_alloc", "dabgpu_host_free", "dabgpu_decode_frames_dev", "dabgpu_decode_frames",
+    "dabgpu_streams_reset", "dabgpu_stream_states", "dabgpu_set_stream_offsets", "dabgpu_ofdm_demod_streams_dev",
+    "dabgpu_ofdm_demod_streams", "dabgpu_get_stats",
 ]
+
+ABI_VERSION = 2
+FLAG_VITERBI_WAVE = 1 << 0
+FLAG_VITERBI_LANE = 1 << 1
+FLAG_LANE_UNFUSED = 1 << 2
 
 
 class DabGpuError(RuntimeError):
@@ -60,7 +67,19 @@ class DabParams(C.Structure):
 
 class Cfg(C.Structure):
     _fields_ = [("device", C.c_int32), ("max_frames", C.c_int32), ("transmission_mode", C.c_int32),
-                ("flags", C.c_int32)]
+                ("flags", C.c_int32), ("ofdm_symbol_runs", C.c_int32), ("reserved", C.c_int32 * 3)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("state", C.c_int32), ("fine_freq_offset", C.c_float), ("coarse_freq_offset", C.c_float),
+                ("net_freq_offset", C.c_float), ("signal_average", C.c_float), ("total_frames_read", C.c_int32),
+                ("total_frames_desync", C.c_int32), ("last_fine_error", C.c_float)]
+
+
+STREAM_STATE_DTYPE = np.dtype([("fine_freq_offset", np.float32), ("coarse_freq_offset", np.float32),
+                               ("signal_average", np.float32), ("last_fine_error", np.float32),
+                               ("total_frames_read", np.int32), ("total_frames_desync", np.int32),
+                               ("reserved", np.int32, (2,))])     # 32 bytes, device-resident
 
 
 class SyncResult(C.Structure):
@@ -144,6 +163,14 @@ def lib():
         L.dabgpu_dabplus_superframes.argtypes = [vp, vp, sz, i, i, vp, vp]
         L.dabgpu_msc_decode_multi_dev.argtypes = [vp, vp, i, vp, sz, i, i, vp, vp, vp, vp]
         L.dabgpu_decode_frames_dev.argtypes = [vp, vp, sz, i, i, vp, vp, vp, i, vp, vp, vp, vp]
+        L.dabgpu_decode_frames.argtypes = [vp, vp, sz, i, i, vp, vp, vp, i, vp, vp, vp]
+        L.dabgpu_streams_reset.argtypes = [vp, i]
+        L.dabgpu_stream_states.restype = C.c_void_p
+        L.dabgpu_stream_states.argtypes = [vp]
+        L.dabgpu_set_stream_offsets.argtypes = [vp, i, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.dabgpu_ofdm_demod_streams_dev.argtypes = [vp, vp, sz, i, i, C.c_float, vp, vp, vp, vp]
+        L.dabgpu_ofdm_demod_streams.argtypes = [vp, vp, sz, i, i, C.c_float, vp, vp, vp]
+        L.dabgpu_get_stats.argtypes = [vp, i, C.POINTER(Stats)]
         L.dabgpu_sync_prs_dev.argtypes = [vp, vp, sz, i, vp, i, vp, vp]
         L.dabgpu_sync_prs.argtypes = [vp, vp, sz, i, vp, i, vp]
         L.dabgpu_ofdm_set_soft_selection.argtypes = [vp, vp, i]
@@ -250,9 +277,9 @@ class Context:
     """Owns a dabgpu_ctx.  Host-array methods copy in/out and synchronise; *_dev methods take
     raw device addresses (e.g. torch.Tensor.data_ptr()) and a stream handle and only enqueue."""
 
-    def __init__(self, device=0, max_frames=64):
+    def __init__(self, device=0, max_frames=64, flags=0, ofdm_symbol_runs=0):
         self._h = C.c_void_p()
-        cfg = Cfg(device, max_frames, 1, 0)
+        cfg = Cfg(device, max_frames, 1, flags, ofdm_symbol_runs)
         _check(lib().dabgpu_create(C.byref(cfg), C.byref(self._h)), "dabgpu_create")
 
     def close(self):
@@ -287,12 +314,75 @@ class Context:
         _check(lib().dabgpu_last_kernel_ms(self._h, which, C.byref(ms)), "dabgpu_last_kernel_ms")
         return ms.value
 
+    # ---- closed-loop stream call
+    def streams_reset(self, n_streams):
+        _check(lib().dabgpu_streams_reset(self._h, n_streams), "dabgpu_streams_reset")
+
+    @property
+    def stream_states_ptr(self):
+        return lib().dabgpu_stream_states(self._h)
+
+    def set_stream_offsets(self, stream, fine=None, coarse=None):
+        f = None if fine is None else C.byref(C.c_float(fine))
+        c = None if coarse is None else C.byref(C.c_float(coarse))
+        _check(lib().dabgpu_set_stream_offsets(self._h, stream, f, c), "dabgpu_set_stream_offsets")
+
+    def get_stats(self, stream):
+        st = Stats()
+        _check(lib().dabgpu_get_stats(self._h, stream, C.byref(st)), "dabgpu_get_stats")
+        return st
+
+    def ofdm_demod_streams(self, iq, n_streams, beta=0.9, want_cyc=False, soft=None):
+        """iq: complex64 [n_streams*frames_per_stream][>=76*2552]; uses and updates the context's stream states.
+        `soft` may be an existing array (selected ranges only are overwritten when a selection is active)."""
+        iq = np.ascontiguousarray(iq, np.complex64)
+        n_frames, stride = iq.shape
+        if soft is None:
+            soft = np.zeros((n_frames, NB_FRAME_BITS), np.int8)
+        cyc = np.zeros((n_frames, NB_SYMBOLS), np.complex64) if want_cyc else None
+        _check(lib().dabgpu_ofdm_demod_streams(self._h, _p(iq), stride, n_streams, n_frames // n_streams, beta, _p(soft),
+                                               _p(cyc), None), "dabgpu_ofdm_demod_streams")
+        return soft, cyc
+
+    def ofdm_demod_streams_dev(self, d_iq, frame_stride, n_streams, frames_per_stream, beta, d_soft, d_cyc=None,
+                               d_dqpsk=None, stream=None):
+        _check(lib().dabgpu_ofdm_demod_streams_dev(self._h, d_iq, frame_stride, n_streams, frames_per_stream, beta, d_soft,
+                                                   d_cyc, d_dqpsk, stream), "dabgpu_ofdm_demod_streams_dev")
+
+    def decode_frames(self, soft, n_streams, scs, history_in=None, want_history=False):
+        """Host arrays: FIC + sub-channels `scs` of soft [n_streams*frames_per_stream][230400] in one call
+        (dabgpu_decode_frames).  -> fib, crc_ok, [out_i], [history_out_i] (or None)"""
+        soft = np.ascontiguousarray(soft, np.int8)
+        n_frames, stride = soft.shape
+        fps = n_frames // n_streams
+        n = len(scs)
+        arr = (Subchannel * max(n, 1))(*scs)
+        fib = np.zeros((n_frames, 12, 32), np.uint8)
+        ok = np.zeros((n_frames, 12), np.uint8)
+        outs = []
+        for sc in scs:
+            nb = lib().dabgpu_subchannel_bytes(C.byref(sc))
+            _check(min(nb, 0), "dabgpu_subchannel_bytes")
+            outs.append(np.zeros((n_streams, fps * 4, nb), np.uint8))
+        his = [None if history_in is None or history_in[k] is None else np.ascontiguousarray(history_in[k], np.int8)
+               for k in range(n)]
+        hos = [np.zeros((n_streams, 15, sc.length * 64), np.int8) if want_history else None for sc in scs]
+
+        def ptrs(lst):
+            if n == 0:
+                return None
+            return (C.c_void_p * n)(*[None if a is None else a.ctypes.data for a in lst])
+        _check(lib().dabgpu_decode_frames(self._h, _p(soft), stride, n_streams, fps, _p(fib), _p(ok), arr, n, ptrs(his),
+                                          ptrs(hos), ptrs(outs)), "dabgpu_decode_frames")
+        return fib, ok, outs, (hos if want_history else None)
+
     # ---- host arrays
-    def ofdm_demod_frames(self, iq, freq_offset=None, want_cyc=False, want_dqpsk=False):
+    def ofdm_demod_frames(self, iq, freq_offset=None, want_cyc=False, want_dqpsk=False, soft=None):
         """iq: complex64 [n_frames][>=76*2552], row f starting at the first PRS sample."""
         iq = np.ascontiguousarray(iq, np.complex64)
         n_frames, stride = iq.shape
-        soft = np.zeros((n_frames, NB_FRAME_BITS), np.int8)
+        if soft is None:
+            soft = np.zeros((n_frames, NB_FRAME_BITS), np.int8)
         fo = None if freq_offset is None else np.ascontiguousarray(freq_offset, np.float32)
         cyc = np.zeros((n_frames, NB_SYMBOLS), np.complex64) if want_cyc else None
         dq = np.zeros((n_frames, NB_SYMBOLS - 1, NB_CARRIERS), np.complex64) if want_dqpsk else None

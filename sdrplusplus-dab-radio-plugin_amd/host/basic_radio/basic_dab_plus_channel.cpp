@@ -45,8 +45,10 @@ void Basic_DAB_Plus_Channel::Process(tcb::span<const uint8_t> lf) {
             m_total_au_errors++;
             continue;
         }
-        const int b = st.au_start[a], e = st.au_start[a + 1];
-        if (b < 0 || e <= b || size_t(e) > m_data.size()) continue;
+        // the access unit handed on is the payload alone: its trailing CRC16 (already checked on the GPU) is dropped,
+        // which is what an AAC decoder / ADTS muxer behind the observer expects
+        const int b = st.au_start[a], e = st.au_start[a + 1] - 2;
+        if (b < 0 || e <= b || size_t(e) + 2 > m_data.size()) continue;
         if (m_controls.GetIsDecodeAudio())
             m_obs_au.Notify(a, st.num_aus, tcb::span<const uint8_t>(m_data.data() + b, size_t(e - b)));
     }

@@ -2,15 +2,20 @@
 
 #include "dab/constants/subchannel_protection_tables.h"
 
+#include <cstring>
 #include <stdexcept>
 #include <string>
 
 BasicRadio::BasicRadio(const DAB_Parameters &params, size_t /*nb_threads*/) : m_params(params), m_ctx(nullptr) {
-    dabgpu_cfg cfg{0, 1, 1, 0};
+    dabgpu_cfg cfg{};
+    cfg.device = GetDabGpuDefaultDevice();
+    cfg.max_frames = 1;
+    cfg.transmission_mode = 1;
     const int rc = dabgpu_create(&cfg, &m_ctx);
     if (rc != DABGPU_OK) throw std::runtime_error(std::string("BasicRadio: ") + dabgpu_strerror(rc));
     m_fib.resize(size_t(params.nb_fibs) * 32);
     m_crc.resize(size_t(params.nb_fibs));
+    m_frame.resize(size_t(params.nb_frame_bits));
 }
 
 BasicRadio::~BasicRadio() { dabgpu_destroy(m_ctx); }
@@ -26,7 +31,7 @@ int BasicRadio::add_subchannel_locked(const dabgpu_subchannel &sc) {
     Subchannel s;
     s.desc = sc;
     s.nbytes = nbytes;
-    for (auto &h : s.history) h.assign(size_t(15) * sc.length * 64, 0);
+    for (auto &h : s.history) h.resize(size_t(15) * sc.length * 64);
     s.out.resize(size_t(m_params.nb_cifs) * nbytes);
     m_subchannels.push_back(std::move(s));
     return int(m_subchannels.size()) - 1;
@@ -35,23 +40,35 @@ int BasicRadio::add_subchannel_locked(const dabgpu_subchannel &sc) {
 void BasicRadio::Process(tcb::span<const viterbi_bit_t> buf) {
     if (buf.size() != size_t(m_params.nb_frame_bits)) return;   // the reference drops short frames the same way
     std::lock_guard<std::mutex> lock(m_mutex);
-    // A7: first nb_fic_bits are the FIC, the rest is 4 CIFs
-    if (dabgpu_fic_decode(m_ctx, buf.data(), buf.size(), 1, m_fib.data(), m_crc.data()) == DABGPU_OK) {
-        for (uint8_t ok : m_crc) {
-            m_total_fibs++;
-            if (!ok) m_total_fib_errors++;
-        }
-        m_obs_fic.Notify(tcb::span<const uint8_t>(m_fib.data(), m_fib.size()),
-                         tcb::span<const uint8_t>(m_crc.data(), m_crc.size()));
-        for (size_t i = 0; i < m_crc.size(); i++)
-            if (m_crc[i]) m_fic_parser.ProcessFIB(tcb::span<const uint8_t>(m_fib.data() + 32 * i, 32));
-        if (m_auto_channels) update_channels_from_database();
-    }
-    for (size_t i = 0; i < m_subchannels.size(); i++) {
+    // A7..A12 in one call: the frame goes up once, the FIC and every registered sub-channel are decoded from that
+    // copy, FIBs / CRC flags / logical frames / de-interleaver state come back together
+    const size_t n_sub = m_subchannels.size();
+    m_call_sc.resize(n_sub);
+    m_call_hin.resize(n_sub);
+    m_call_hout.resize(n_sub);
+    m_call_out.resize(n_sub);
+    for (size_t i = 0; i < n_sub; i++) {
         Subchannel &s = m_subchannels[i];
-        const int rc = dabgpu_msc_decode(m_ctx, &s.desc, buf.data(), buf.size(), 1, 1, s.history[s.cur].data(),
-                                         s.history[s.cur ^ 1].data(), s.out.data());
-        if (rc != DABGPU_OK) continue;
+        m_call_sc[i] = s.desc;
+        m_call_hin[i] = s.history[s.cur].data();
+        m_call_hout[i] = s.history[s.cur ^ 1].data();
+        m_call_out[i] = s.out.data();
+    }
+    std::memcpy(m_frame.data(), buf.data(), buf.size());
+    const int rc = dabgpu_decode_frames(m_ctx, m_frame.data(), m_frame.size(), 1, 1, m_fib.data(), m_crc.data(),
+                                        m_call_sc.data(), int(n_sub), m_call_hin.data(), m_call_hout.data(),
+                                        m_call_out.data());
+    if (rc != DABGPU_OK) return;                                // no exceptions on the streaming path: the frame is lost
+    for (uint8_t ok : m_crc) {
+        m_total_fibs++;
+        if (!ok) m_total_fib_errors++;
+    }
+    m_obs_fic.Notify(tcb::span<const uint8_t>(m_fib.data(), m_fib.size()),
+                     tcb::span<const uint8_t>(m_crc.data(), m_crc.size()));
+    for (size_t i = 0; i < m_crc.size(); i++)
+        if (m_crc[i]) m_fic_parser.ProcessFIB(tcb::span<const uint8_t>(m_fib.data() + 32 * i, 32));
+    for (size_t i = 0; i < n_sub; i++) {
+        Subchannel &s = m_subchannels[i];
         s.cur ^= 1;
         for (int c = 0; c < m_params.nb_cifs; c++) {
             // the de-interleaver needs 16 CIFs before its first complete logical frame
@@ -62,6 +79,8 @@ void BasicRadio::Process(tcb::span<const viterbi_bit_t> buf) {
             if (s.dab) s.dab->Process(lf);
         }
     }
+    // sub-channels the FIC has announced by now join the call from the next frame on
+    if (m_auto_channels) update_channels_from_database();
 }
 
 // Open every audio component whose sub-channel the FIC has described (called with the mutex held).

@@ -20,12 +20,18 @@ OFDM_Demod::OFDM_Demod(const OFDM_Params &params, tcb::span<const std::complex<f
     dabgpu_get_mapper_reference(mapper.data(), int(mapper.size()), int(params.nb_fft));
     for (size_t i = 0; i < mapper.size(); i++)
         if (mapper[i] != carrier_mapper[i]) throw std::runtime_error("OFDM_Demod: carrier mapper differs from Mode I");
-    dabgpu_cfg cfg{0, 1, 1, 0};
-    const int rc = dabgpu_create(&cfg, &m_ctx);
+    dabgpu_cfg cfg{};
+    cfg.device = GetDabGpuDefaultDevice();
+    cfg.max_frames = 1;
+    cfg.transmission_mode = 1;
+    int rc = dabgpu_create(&cfg, &m_ctx);
+    if (rc == DABGPU_OK && (rc = dabgpu_streams_reset(m_ctx, 1)) != DABGPU_OK) {
+        dabgpu_destroy(m_ctx);
+        m_ctx = nullptr;
+    }
     if (rc != DABGPU_OK) throw std::runtime_error(std::string("OFDM_Demod: ") + dabgpu_strerror(rc));
     m_frame.resize(params.nb_frame_symbols * params.nb_symbol_period);
     m_soft.resize(size_t(params.nb_frame_symbols - 1) * params.nb_data_carriers * 2);
-    m_cyc.resize(params.nb_frame_symbols);
     m_frame_data_vec.resize(size_t(params.nb_frame_symbols - 1) * params.nb_data_carriers);
     Reset();
 }
@@ -48,6 +54,7 @@ void OFDM_Demod::Reset() {
     m_freq_coarse_offset = 0.0f;
     m_total_frames_read = 0;
     m_total_frames_desync = 0;
+    (void)dabgpu_streams_reset(m_ctx, 1);                       // the device-side loop state starts over as well
 }
 
 void OFDM_Demod::Process(tcb::span<const std::complex<float>> block) {
@@ -138,7 +145,7 @@ void OFDM_Demod::push_sample_block(const std::complex<float> *x, size_t n) {
 bool OFDM_Demod::synchronise_frame() {
     const float fine = m_freq_fine_offset + (m_is_acquiring ? 0.0f : m_freq_coarse_offset);
     int max_coarse = 0;
-    if (m_is_acquiring && m_cfg.sync.is_coarse_freq_correction)
+    if (m_cfg.sync.is_coarse_freq_correction && (m_is_acquiring || m_cfg.sync.coarse_freq_slow_beta > 0.0f))
         max_coarse = std::min(1023, int(m_cfg.sync.max_coarse_freq_correction_norm * float(m_params.nb_fft)));
     dabgpu_sync_result res;
     m_state = m_is_acquiring ? State::RUNNING_COARSE_FREQ_SYNC : State::RUNNING_FINE_TIME_SYNC;
@@ -151,6 +158,12 @@ bool OFDM_Demod::synchronise_frame() {
     if (m_is_acquiring) {
         m_freq_coarse_offset = -float(res.coarse_carriers) / float(m_params.nb_fft);
         m_is_acquiring = false;
+        if (dabgpu_set_stream_offsets(m_ctx, 0, nullptr, &m_freq_coarse_offset) != DABGPU_OK) return false;
+    } else if (res.coarse_carriers != 0 && m_cfg.sync.coarse_freq_slow_beta > 0.0f) {
+        // locked, yet the PRS sits k carriers off: drift.  Move a fraction of it per frame; the fine loop takes up
+        // what that leaves between whole carriers.
+        m_freq_coarse_offset -= m_cfg.sync.coarse_freq_slow_beta * float(res.coarse_carriers) / float(m_params.nb_fft);
+        if (dabgpu_set_stream_offsets(m_ctx, 0, nullptr, &m_freq_coarse_offset) != DABGPU_OK) return false;
     }
     // keep the FFT windows TIMING_MARGIN samples inside the cyclic prefix: time_offset is how early this frame's
     // windows are; steer the start of the next frame (never by more than a few samples once locked)
@@ -174,23 +187,18 @@ void OFDM_Demod::demodulate_frame() {
         return;
     }
     m_state = State::READING_SYMBOLS;
-    const float f = GetNetFrequencyOffset();
-    const int rc = dabgpu_ofdm_demod_frames(m_ctx, reinterpret_cast<const float *>(m_frame.data()), m_frame.size(), 1,
-                                            &f, m_soft.data(), reinterpret_cast<float *>(m_cyc.data()),
-                                            reinterpret_cast<float *>(m_frame_data_vec.data()));
+    // A2..A6 with the stream's own fine + coarse offset, then the fine-frequency loop, all on the device
+    int rc = dabgpu_ofdm_demod_streams(m_ctx, reinterpret_cast<const float *>(m_frame.data()), m_frame.size(), 1, 1,
+                                       m_cfg.sync.fine_freq_update_beta, m_soft.data(), nullptr,
+                                       reinterpret_cast<float *>(m_frame_data_vec.data()));
+    dabgpu_stats stats{};
+    if (rc == DABGPU_OK) rc = dabgpu_get_stats(m_ctx, 0, &stats);
     if (rc != DABGPU_OK) {   // no exceptions on the streaming path: count it as a lost frame
         m_total_frames_desync++;
         m_state = State::FINDING_NULL_POWER_DIP;
         return;
     }
-    // fine frequency loop: mean cyclic-prefix phase -> residual offset in cycles/sample
-    double acc = 0.0;
-    for (const auto &c : m_cyc) acc += std::atan2(double(c.imag()), double(c.real()));
-    const float err = float(acc / double(m_cyc.size()) / (2.0 * M_PI * double(m_params.nb_fft)));
-    m_freq_fine_offset -= m_cfg.sync.fine_freq_update_beta * err;
-    const float half_carrier = 0.5f / float(m_params.nb_fft);
-    if (m_freq_fine_offset > half_carrier) m_freq_fine_offset -= 2 * half_carrier;
-    if (m_freq_fine_offset < -half_carrier) m_freq_fine_offset += 2 * half_carrier;
+    m_freq_fine_offset = stats.fine_freq_offset;
     // desync check: the samples where the next null symbol should be are examined by the acquisition logic
     // only after a loss; here the signal level of the frame is refreshed
     float l1 = 0.0f;

@@ -6,17 +6,21 @@
 // (src/render_radio_block.cpp:96, 109, 192-207, 213-235).
 //
 // Row A1 of SURVEY.md section 8a lives here on the host: chunk reassembly and the null-symbol power-dip search.
-// Everything per sample runs on the GPU: rows A2..A6 in dabgpu_ofdm_demod_frames, and the coarse-frequency /
-// fine-time search on the phase reference symbol (section 8f-1) in dabgpu_sync_prs, which is run on every
-// frame's PRS: at acquisition it sets the coarse offset and rejects false locks (impulse_peak_threshold_db),
-// afterwards it tracks timing drift.  Differential demodulation is insensitive to a constant timing offset
-// inside the cyclic prefix, so the FFT windows are kept `TIMING_MARGIN` samples early.
+// Everything per sample runs on the GPU: rows A2..A6 and the fine-frequency loop in dabgpu_ofdm_demod_streams (the
+// offsets live in a dabgpu_stream_state on the device; the getters below return the copy dabgpu_get_stats fetched
+// after the last frame), and the coarse-frequency / fine-time search on the phase reference symbol (section 8f-1) in
+// dabgpu_sync_prs, which is run on every frame's PRS: at acquisition it sets the coarse offset and rejects false
+// locks (impulse_peak_threshold_db), afterwards it tracks timing drift and nudges the coarse offset
+// (coarse_freq_slow_beta).  The frame and soft-bit buffers are page-locked (dabgpu_host_alloc).  Differential
+// demodulation is insensitive to a constant timing offset inside the cyclic prefix, so the FFT windows are kept
+// `TIMING_MARGIN` samples early.
 #pragma once
 #include <complex>
 #include <cstdint>
 #include <vector>
 #include "dabgpu.h"
 #include "ofdm/ofdm_params.h"
+#include "utility/gpu_buffers.h"
 #include "utility/observable.h"
 #include "utility/span.h"
 #include "viterbi_config.h"
@@ -35,8 +39,13 @@ struct OFDM_Demod_Config {
         bool is_coarse_freq_correction = true;
         float fine_freq_update_beta = 0.9f;
         float max_coarse_freq_correction_norm = 0.1f;
+        // once locked, a residual of k whole carriers found on a frame's PRS moves the coarse offset by this
+        // fraction of k per frame (0 = keep the offset found at acquisition)
         float coarse_freq_slow_beta = 0.1f;
         float impulse_peak_threshold_db = 20.0f;
+        // INERT here: the reference weights impulse-response peaks by their distance from the expected position to
+        // choose between echoes; dabgpu_sync_prs takes the strongest tap, which is the same tap whenever the first
+        // path dominates.  Kept so that the GUI's slider (src/render_radio_block.cpp:225) has its field.
         float impulse_peak_distance_probability = 0.15f;
     } sync;
 };
@@ -69,7 +78,7 @@ public:
     int GetTotalFramesRead() const { return m_total_frames_read; }
     int GetTotalFramesDesync() const { return m_total_frames_desync; }
     OFDM_Demod_Config &GetConfig() { return m_cfg; }
-    tcb::span<const std::complex<float>> GetFrameDataVec() const { return m_frame_data_vec; }
+    tcb::span<const std::complex<float>> GetFrameDataVec() const { return {m_frame_data_vec.data(), m_frame_data_vec.size()}; }
     Observable<tcb::span<const viterbi_bit_t>> &On_OFDM_Frame() { return m_obs_on_ofdm_frame; }
 
     // extension: apply a known coarse offset (cycles/sample) until the device-side search exists
@@ -94,7 +103,7 @@ private:
     bool m_in_null;
     size_t m_null_blocks;
     std::vector<std::complex<float>> m_history;     // last TIMING_MARGIN + block samples, to start a frame early
-    std::vector<std::complex<float>> m_frame;       // 76 * 2552 samples being assembled
+    PinnedBuffer<std::complex<float>> m_frame;      // 76 * 2552 samples being assembled (page-locked: uploaded every frame)
     size_t m_frame_fill;
     size_t m_skip;                                  // samples to drop before the next frame starts
     size_t m_next_skip;                             // null-symbol gap to the next frame incl. timing correction
@@ -106,8 +115,7 @@ private:
     float m_freq_fine_offset, m_freq_coarse_offset;
     int m_total_frames_read, m_total_frames_desync;
     // outputs
-    std::vector<viterbi_bit_t> m_soft;
-    std::vector<std::complex<float>> m_cyc;
-    std::vector<std::complex<float>> m_frame_data_vec;
+    PinnedBuffer<viterbi_bit_t> m_soft;             // page-locked: downloaded every frame
+    PinnedBuffer<std::complex<float>> m_frame_data_vec;
     Observable<tcb::span<const viterbi_bit_t>> m_obs_on_ofdm_frame;
 };

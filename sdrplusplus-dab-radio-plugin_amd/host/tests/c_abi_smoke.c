@@ -5,7 +5,7 @@
 #include "dabgpu.h"
 
 int main(void) {
-    dabgpu_cfg cfg = {0, 2, 1, 0};
+    dabgpu_cfg cfg = {0, 2, 1, 0, 0, {0, 0, 0}};
     dabgpu_ctx *ctx = NULL;
     int rc = dabgpu_create(&cfg, &ctx);
     if (rc != DABGPU_OK) { printf("create: %s\n", dabgpu_strerror(rc)); return rc == DABGPU_ERR_NODEVICE ? 77 : 1; }

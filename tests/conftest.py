@@ -40,19 +40,14 @@ def ensemble_iq(ensemble):
     return ensemble.iq()
 
 
-def make_ctx(lane_mode=None, max_frames=64):
-    """Context with the Viterbi variant pinned: None = chosen by batch size (the default), 1 = the
-    codeword-per-lane kernels even for small batches, 0 = the wave-per-codeword kernels only."""
+def make_ctx(lane_mode=None, max_frames=64, ofdm_symbol_runs=0, unfused=False):
+    """Context with the Viterbi variant pinned through dabgpu_cfg.flags: None = chosen by batch size (the default),
+    1 = the codeword-per-lane kernels even for small batches, 0 = the wave-per-codeword kernels only."""
     import dabgpu
-    old = os.environ.pop("DABGPU_VITERBI_LANE", None)
-    if lane_mode is not None:
-        os.environ["DABGPU_VITERBI_LANE"] = str(lane_mode)
-    try:
-        return dabgpu.Context(device=0, max_frames=max_frames)
-    finally:
-        os.environ.pop("DABGPU_VITERBI_LANE", None)
-        if old is not None:
-            os.environ["DABGPU_VITERBI_LANE"] = old
+    flags = {None: 0, 0: dabgpu.FLAG_VITERBI_WAVE, 1: dabgpu.FLAG_VITERBI_LANE}[lane_mode]
+    if unfused:
+        flags |= dabgpu.FLAG_LANE_UNFUSED
+    return dabgpu.Context(device=0, max_frames=max_frames, flags=flags, ofdm_symbol_runs=ofdm_symbol_runs)
 
 
 @pytest.fixture(scope="session", params=["auto", "lane"])

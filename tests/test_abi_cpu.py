@@ -16,7 +16,7 @@ def test_header_symbols_are_all_exported(built):
     L = dabgpu.lib()
     for sym in declared:
         assert hasattr(L, sym), sym
-    assert L.dabgpu_abi_version() == 1
+    assert L.dabgpu_abi_version() == dabgpu.ABI_VERSION == 2
 
 
 def test_header_is_plain_c(tmp_path):
@@ -25,7 +25,7 @@ def test_header_is_plain_c(tmp_path):
     import subprocess
     src = tmp_path / "abi.c"
     src.write_text('#include "dabgpu.h"\n'
-                   'int main(void) { dabgpu_cfg c = {0, 1, 1, 0}; dabgpu_subchannel s = {0, 48, 0, 0, 3, 64};\n'
+                   'int main(void) { dabgpu_cfg c = {0, 1, 1, 0, 0, {0, 0, 0}}; dabgpu_subchannel s = {0, 48, 0, 0, 3, 64};\n'
                    '  dabgpu_bit_range r[9]; (void)c; return dabgpu_soft_selection(&s, 1, 1, r, 9) == 5 ? 0 : 1; }\n')
     inc = "-I" + os.path.join(ROOT, "include")
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", inc, str(src)])

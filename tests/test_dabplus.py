@@ -49,11 +49,14 @@ def test_oracle_superframe(bitrate, dac_rate, sbr):
     bad[2::s][:6] ^= 0xFF
     _, st, _ = O.dabplus_superframe(bad, s)
     assert st[2] >= 1 or st[0] == 0
+    # an all-zero window (silence, erasures) is NOT a super-frame although a zero header matches a zero check word
+    _, st, _ = O.dabplus_superframe(np.zeros_like(sf), s)
+    assert st[0] == 0 and st[3] == 0
 
 
 def _noisy_batch(rng):
     sfs, truth = [], []
-    for (br, dr, sb) in [(64, 1, 0)] * 6:
+    for (br, dr, sb) in [(64, 1, 0)] * 7:
         sf, starts, aus = synth.build_superframe(rng, br, dr, sb)
         truth.append(sf.copy())
         sfs.append(sf)
@@ -65,6 +68,7 @@ def _noisy_batch(rng):
     sfs[3, 0:960:8][:7] ^= 0x5A                                 # 7 errors in column 0: uncorrectable
     sfs[4, 20] ^= 0x01                                          # one bit inside an AU
     sfs[5] = rng.integers(0, 256, 960, dtype=np.uint8)          # garbage
+    sfs[6] = 0                                                  # all zero: must not pass the Fire code
     return sfs, truth
 
 
@@ -82,6 +86,7 @@ def test_gpu_superframes_match_oracle(ctx):
         assert st["au_start"][i].tolist() == oau.tolist()
     assert (out[2] == truth[2][:880]).all() and st["rs_corrected"][2] == 40
     assert st["rs_uncorrectable"][3] >= 1
+    assert st["firecode_ok"][6] == 0 and st["num_aus"][6] == 0
 
 
 @pytest.mark.gpu

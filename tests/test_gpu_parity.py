@@ -60,14 +60,13 @@ def test_ofdm_soft_bits_within_one_lsb(ctx, ensemble, ensemble_iq, snr, cfo):
             assert ((soft[f] > 0).astype(np.uint8) == ensemble.frame_bits[f]).all()
 
 
-def test_ofdm_group_splits_agree(built, ensemble_iq, monkeypatch):
-    """A frame may be cut into 1..75 symbol runs; results must not depend on the cut."""
+def test_ofdm_group_splits_agree(built, ensemble_iq):
+    """A frame may be cut into 1..75 symbol runs (dabgpu_cfg.ofdm_symbol_runs); results must not depend on the cut."""
     frames = _rx(ensemble_iq, 12.0, 0.2 / 2048)[:2]
     fo = np.full(2, -0.2 / 2048, np.float32)
     outs = []
-    for g in ("1", "2", "3", "7", "31", "75"):
-        monkeypatch.setenv("DABGPU_OFDM_PARTS", g)
-        with dabgpu.Context(device=0) as c:
+    for g in (1, 2, 3, 7, 31, 75):
+        with dabgpu.Context(device=0, ofdm_symbol_runs=g) as c:
             outs.append(c.ofdm_demod_frames(frames, fo, want_cyc=True))
     for soft, cyc, _ in outs[1:]:
         assert (soft == outs[0][0]).all()

@@ -17,12 +17,10 @@ SYMS = 76 * 2552
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("DAB_RANDOM_SEEDS", "8"))))
-def test_front_end_random(seed, monkeypatch):
+def test_front_end_random(seed):
     rng = np.random.default_rng(7000 + seed)
     parts = int(rng.choice([0, 1, 2, 5, 25, 75]))
-    if parts:
-        monkeypatch.setenv("DABGPU_OFDM_PARTS", str(parts))
-    c = make_ctx(None, 8)
+    c = make_ctx(None, 8, ofdm_symbol_runs=parts)
     n_frames = 3
     e = synth.Ensemble(seed=seed, n_frames=n_frames)
     snr = None if seed % 4 == 0 else float(rng.uniform(2.0, 30.0))

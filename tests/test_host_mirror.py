@@ -33,6 +33,15 @@ def test_reference_radio_block_compiles_unchanged(host_built):
     assert r.returncode == 0, r.stderr[-2000:]
 
 
+@pytest.mark.skipif(not os.path.exists("/root/reference/src/radio_block.cpp"), reason="reference not mounted")
+def test_reference_radio_block_links_against_the_mirror(host_built):
+    """Compile is not enough: the reference's radio_block.cpp is built to an object (in a temporary directory) and
+    linked with a five-line main against libdabhost.a + libdabgpu.so -- every OFDM_Demod / BasicRadio /
+    ThreadedRingBuffer / AudioPipeline member it uses has to be DEFINED somewhere.  Nothing is run."""
+    r = subprocess.run(["make", "-C", HOST, "check_reference_radio_block_links"], capture_output=True, text=True)
+    assert r.returncode == 0 and "linked:" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
 @pytest.mark.skipif(not os.path.exists("/root/reference/src/dab_module.cpp"), reason="reference not mounted")
 def test_reference_dab_module_compiles_unchanged(host_built):
     """The plugin's own module file against the mirror headers; SDR++'s headers are TEST-ONLY declarations under

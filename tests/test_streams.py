@@ -1,0 +1,142 @@
+"""Closed-loop front end (dabgpu_ofdm_demod_streams*, dabgpu_get_stats): per-stream frequency state kept on the
+device, updated from the cyclic-prefix correlations, consumed by the next call -- no host-supplied offset
+(/root/reference/src/render_radio_block.cpp:202-207, :216).  Also the host-pointer dabgpu_decode_frames."""
+import numpy as np
+import pytest
+
+import dabgpu
+from conftest import make_ctx
+from dabgpu import synth
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _rx(iq, snr, cfo, seed=0):
+    rng = np.random.default_rng(seed)
+    rx = synth.channel(iq.ravel(), snr_db=snr, cfo=cfo, rng=rng).reshape(iq.shape)
+    return np.ascontiguousarray(rx[:, synth.NB_NULL:])
+
+
+def _state0():
+    return dict(fine_freq_offset=np.float32(0), coarse_freq_offset=np.float32(0), signal_average=np.float32(0),
+                total_frames_read=0, total_frames_desync=0)
+
+
+def test_converges_from_a_wrong_offset_within_three_frames(built, ensemble, ensemble_iq):
+    """Unknown offset of 0.31 carriers, state starts at 0, one frame per call (the plugin's use): the third frame is
+    demodulated with the right correction and its FIBs are the transmitted ones."""
+    cfo = 0.31 / 2048
+    frames = _rx(ensemble_iq, 15.0, cfo)
+    c = make_ctx(None, 4)
+    c.streams_reset(1)
+    net = []
+    for f in range(4):
+        soft, _ = c.ofdm_demod_streams(frames[f:f + 1], 1, beta=0.9)
+        st = c.get_stats(0)
+        net.append(st.net_freq_offset)
+        assert st.total_frames_read == f + 1 and st.state == 4
+    assert abs(net[2] + cfo) * 2048 < 0.01, [n * 2048 for n in net]          # residual < 1 % of a carrier after 3 frames
+    fib, ok = c.fic_decode(soft)
+    assert ok.all() and (fib[0] == ensemble.fibs[3]).all()
+    assert st.signal_average > 0 and st.total_frames_desync == 0
+    c.close()
+
+
+def test_state_update_matches_the_restatement_and_drives_the_demodulator(built, ensemble_iq):
+    """Batch form: 2 streams x 2 frames per call, different offsets per stream.  The state after every call equals
+    the oracle's restatement applied to the call's own cyc output, and the soft bits equal those of the
+    open-loop call given the state's offset explicitly."""
+    cfos = [0.12 / 2048, -0.27 / 2048]
+    rx = [_rx(ensemble_iq[:4], 18.0, cfo, seed=k) for k, cfo in enumerate(cfos)]
+    c = make_ctx(None, 8)
+    c.streams_reset(2)
+    c.set_stream_offsets(1, fine=0.2 / 2048)                  # stream 1 starts from a guess, stream 0 from zero
+    states = [_state0(), _state0()]
+    states[1]["fine_freq_offset"] = np.float32(0.2 / 2048)
+    for call in range(2):
+        batch = np.concatenate([rx[0][2 * call:2 * call + 2], rx[1][2 * call:2 * call + 2]])
+        soft, cyc = c.ofdm_demod_streams(batch, 2, beta=0.75, want_cyc=True)
+        fo = np.repeat([states[0]["fine_freq_offset"], states[1]["fine_freq_offset"]], 2).astype(np.float32)
+        ref, ref_cyc, _ = c.ofdm_demod_frames(batch, fo, want_cyc=True)
+        assert (soft == ref).all() and np.array_equal(cyc, ref_cyc)
+        for s in range(2):
+            states[s] = O.stream_update(states[s], cyc[2 * s:2 * s + 2], batch[2 * s + 1], 0.75)
+            st = c.get_stats(s)
+            assert abs(st.fine_freq_offset - states[s]["fine_freq_offset"]) < 2e-9, (call, s)
+            assert abs(st.last_fine_error - states[s]["last_fine_error"]) < 2e-9
+            assert abs(st.signal_average - states[s]["signal_average"]) < 1e-5 * states[s]["signal_average"]
+            assert st.total_frames_read == states[s]["total_frames_read"] == 2 * (call + 1)
+            assert st.net_freq_offset == np.float32(st.fine_freq_offset + st.coarse_freq_offset)
+    # both loops have closed in on their stream's offset
+    for s in range(2):
+        assert abs(c.get_stats(s).net_freq_offset + cfos[s]) * 2048 < 0.03
+    c.close()
+
+
+def test_coarse_offset_and_level_drop(built, ensemble_iq):
+    """A whole-carrier offset stored with dabgpu_set_stream_offsets is applied on top of the fine one; a frame whose
+    level collapses is counted as a desync and leaves the level average alone."""
+    cfo = (3 + 0.05) / 2048
+    frames = _rx(ensemble_iq[:3], 20.0, cfo)
+    c = make_ctx(None, 4)
+    c.streams_reset(1)
+    c.set_stream_offsets(0, coarse=-3 / 2048)
+    soft, _ = c.ofdm_demod_streams(frames[0:1], 1, beta=1.0)
+    soft, _ = c.ofdm_demod_streams(frames[1:2], 1, beta=1.0)
+    fib, ok = c.fic_decode(soft)
+    assert ok.all()
+    st = c.get_stats(0)
+    assert st.coarse_freq_offset == np.float32(-3 / 2048) and abs(st.net_freq_offset + cfo) * 2048 < 0.02
+    level = st.signal_average
+    c.ofdm_demod_streams(frames[2:3] * np.complex64(0.01), 1, beta=0.0)
+    st = c.get_stats(0)
+    assert st.total_frames_desync == 1 and st.total_frames_read == 2 and st.signal_average == level
+    c.close()
+
+
+def test_stream_call_argument_checks(built):
+    c = make_ctx(None, 4)
+    L = dabgpu.lib()
+    iq = np.zeros((1, 76 * 2552), np.complex64)
+    soft = np.zeros((1, 230400), np.int8)
+    st = dabgpu.Stats()
+    import ctypes as C
+    assert L.dabgpu_get_stats(c._h, 0, C.byref(st)) == -1                     # no states yet
+    assert L.dabgpu_ofdm_demod_streams(c._h, iq.ctypes.data, iq.shape[1], 1, 1, 0.5, soft.ctypes.data, None, None) == -6
+    c.streams_reset(2)
+    assert L.dabgpu_get_stats(c._h, 2, C.byref(st)) == -1 and L.dabgpu_get_stats(c._h, 1, None) == -1
+    assert L.dabgpu_ofdm_demod_streams(c._h, iq.ctypes.data, iq.shape[1], 1, 1, 1.5, soft.ctypes.data, None, None) == -1
+    assert L.dabgpu_set_stream_offsets(c._h, 5, None, None) == -1
+    assert c.get_stats(1).total_frames_read == 0 and c.get_stats(1).state == 0
+    c.ofdm_demod_streams(np.zeros((0, 76 * 2552), np.complex64), 2)           # empty batch: nothing happens
+    assert c.get_stats(0).total_frames_read == 0
+    c.close()
+
+
+@pytest.mark.parametrize("lane_mode", [None, 1])
+def test_host_decode_frames_equals_separate_calls(built, ensemble, ensemble_iq, lane_mode):
+    """dabgpu_decode_frames (one upload, FIC + every sub-channel, one synchronisation) against dabgpu_fic_decode and
+    one dabgpu_msc_decode per sub-channel, with de-interleaver history carried over two calls."""
+    frames = _rx(ensemble_iq[:4], 14.0, 0.0)
+    c = make_ctx(lane_mode, 8)
+    soft, _, _ = c.ofdm_demod_frames(frames)
+    scs = [dabgpu.subchannel(ensemble.start_cu, 64, level=3), dabgpu.subchannel(ensemble.start_cu + 200, 32, level=2),
+           dabgpu.uep_subchannel(11, 400)]
+    hist = [None, None, None]
+    hist_ref = [None, None, None]
+    for call in range(2):
+        part = soft[2 * call:2 * call + 2]
+        fib, ok, outs, hos = c.decode_frames(part, 1, scs, history_in=hist, want_history=True)
+        rfib, rok = c.fic_decode(part)
+        assert (fib == rfib).all() and (ok == rok).all() and ok.all()
+        for k, sc in enumerate(scs):
+            ro, rh = c.msc_decode(sc, part, n_streams=1, history_in=hist_ref[k], want_history=True)
+            assert (outs[k] == ro).all(), (call, k)
+            assert (hos[k] == rh).all()
+            hist_ref[k] = rh
+        hist = hos
+    # no sub-channels at all is the FIC alone
+    fib, ok, outs, _ = c.decode_frames(soft[:1], 1, [])
+    assert ok.all() and outs == []
+    c.close()

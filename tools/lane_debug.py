@@ -3,10 +3,9 @@
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "sdrplusplus-dab-radio-plugin_amd")); sys.path.insert(0, ROOT)
-os.environ["DABGPU_VITERBI_LANE"] = "1"
 import numpy as np, dabgpu
 from oracle import oracle as O
-ctx = dabgpu.Context(0, 16)
+ctx = dabgpu.Context(0, 16, flags=dabgpu.FLAG_VITERBI_LANE)
 rng = np.random.default_rng(4)
 noise = rng.integers(-127, 128, size=(9, 9216), dtype=np.int8)
 noise[7] = 0

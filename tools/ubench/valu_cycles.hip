@@ -1,0 +1,137 @@
+// Micro-benchmark: shader cycles per wave64 instruction per SIMD on gfx950, measured INSIDE the kernel with
+// s_memtime (shader-clock ticks) so that DVFS cannot distort the figure, plus the clock the chip actually ran
+// at (s_memtime ticks per s_memrealtime tick, the latter a constant 100 MHz).
+// build: hipcc -O3 --offload-arch=gfx950 valu_cycles.hip -o valu_cycles ; run on the GPU box.
+//
+// Every mode issues blocks of 8 independent instructions (8 dependency chains per wave), `iters` x 8 blocks.
+// waves/SIMD = co-resident waves per SIMD (256-thread workgroups, one wave per SIMD each).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <algorithm>
+
+enum Mode { FMA, MULADD_E32, FMAC_E32, MAD_U64, RCP, CVT_I32, MED3, MAX3, LSHL_ADD, AND_PERM, PK_FMA, MUL_LO, SINCOS_HW, NMODES };
+static const char *NAMES[NMODES] = {"v_fma_f32 (VOP3, 3 src)", "v_mul_f32/v_add_f32 e32", "v_fmac_f32 e32", "v_mad_u64_u32", "v_rcp_f32",
+                                    "v_cvt_i32_f32", "v_med3_f32", "v_max3_f32", "v_lshl_add_u32", "v_and_b32/v_perm_b32", "v_pk_fma_f32",
+                                    "v_mul_lo_u32", "v_sin_f32/v_cos_f32"};
+
+#define REP8(S) S(0) S(1) S(2) S(3) S(4) S(5) S(6) S(7)
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k(unsigned long long *ticks, int iters) {
+    float a0 = threadIdx.x + 1.5f, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, p4 = {a1, a0}, p5 = {a3, a2}, p6 = {a5, a4}, p7 = {a7, a6};
+    typedef unsigned long long u64;
+    u64 q0 = threadIdx.x, q1 = q0 + 1, q2 = q0 + 2, q3 = q0 + 3, q4 = q0 + 4, q5 = q0 + 5, q6 = q0 + 6, q7 = q0 + 7;
+    const float c = 1.0001f, d = 0.5f;
+    const f2 pc = {c, c}, pd = {d, d};
+    const unsigned ic = 0x01010101u * (threadIdx.x & 3), id = 3;
+    const u64 t0 = __builtin_readcyclecounter();        // s_memtime
+    const u64 r0 = wall_clock64();                       // s_memrealtime, 100 MHz
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if constexpr (MODE == FMA) {
+                asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
+                             "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(d));
+            } else if constexpr (MODE == MULADD_E32) {
+                asm volatile("v_mul_f32_e32 %0, %8, %0\n v_add_f32_e32 %1, %9, %1\n v_mul_f32_e32 %2, %8, %2\n v_sub_f32_e32 %3, %3, %9\n"
+                             "v_mul_f32_e32 %4, %8, %4\n v_add_f32_e32 %5, %9, %5\n v_mul_f32_e32 %6, %8, %6\n v_sub_f32_e32 %7, %7, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(d));
+            } else if constexpr (MODE == FMAC_E32) {
+                asm volatile("v_fmac_f32_e32 %0, %8, %9\n v_fmac_f32_e32 %1, %8, %9\n v_fmac_f32_e32 %2, %8, %9\n v_fmac_f32_e32 %3, %8, %9\n"
+                             "v_fmac_f32_e32 %4, %8, %9\n v_fmac_f32_e32 %5, %8, %9\n v_fmac_f32_e32 %6, %8, %9\n v_fmac_f32_e32 %7, %8, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(d));
+            } else if constexpr (MODE == MAD_U64) {
+                asm volatile("v_mad_u64_u32 %0, vcc, %8, %9, %0\n v_mad_u64_u32 %1, vcc, %8, %9, %1\n v_mad_u64_u32 %2, vcc, %8, %9, %2\n"
+                             "v_mad_u64_u32 %3, vcc, %8, %9, %3\n v_mad_u64_u32 %4, vcc, %8, %9, %4\n v_mad_u64_u32 %5, vcc, %8, %9, %5\n"
+                             "v_mad_u64_u32 %6, vcc, %8, %9, %6\n v_mad_u64_u32 %7, vcc, %8, %9, %7\n"
+                             : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4), "+v"(q5), "+v"(q6), "+v"(q7) : "v"(ic), "v"(id) : "vcc");
+            } else if constexpr (MODE == RCP) {
+                asm volatile("v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3\n"
+                             "v_rcp_f32 %4, %4\n v_rcp_f32 %5, %5\n v_rcp_f32 %6, %6\n v_rcp_f32 %7, %7\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+            } else if constexpr (MODE == CVT_I32) {
+                asm volatile("v_cvt_i32_f32 %0, %0\n v_cvt_f32_i32 %1, %1\n v_cvt_i32_f32 %2, %2\n v_cvt_f32_i32 %3, %3\n"
+                             "v_cvt_i32_f32 %4, %4\n v_cvt_f32_i32 %5, %5\n v_cvt_i32_f32 %6, %6\n v_cvt_f32_i32 %7, %7\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+            } else if constexpr (MODE == MED3) {
+                asm volatile("v_med3_f32 %0, %0, %8, %9\n v_med3_f32 %1, %1, %8, %9\n v_med3_f32 %2, %2, %8, %9\n v_med3_f32 %3, %3, %8, %9\n"
+                             "v_med3_f32 %4, %4, %8, %9\n v_med3_f32 %5, %5, %8, %9\n v_med3_f32 %6, %6, %8, %9\n v_med3_f32 %7, %7, %8, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(d));
+            } else if constexpr (MODE == MAX3) {
+                asm volatile("v_max3_f32 %0, |%0|, |%8|, %9\n v_max3_f32 %1, |%1|, |%8|, %9\n v_max3_f32 %2, |%2|, |%8|, %9\n"
+                             "v_max3_f32 %3, |%3|, |%8|, %9\n v_max3_f32 %4, |%4|, |%8|, %9\n v_max3_f32 %5, |%5|, |%8|, %9\n"
+                             "v_max3_f32 %6, |%6|, |%8|, %9\n v_max3_f32 %7, |%7|, |%8|, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(d));
+            } else if constexpr (MODE == LSHL_ADD) {
+                asm volatile("v_lshl_add_u32 %0, %0, 1, %8\n v_lshl_add_u32 %1, %1, 1, %8\n v_lshl_add_u32 %2, %2, 1, %8\n"
+                             "v_lshl_add_u32 %3, %3, 1, %8\n v_lshl_add_u32 %4, %4, 1, %8\n v_lshl_add_u32 %5, %5, 1, %8\n"
+                             "v_lshl_add_u32 %6, %6, 1, %8\n v_lshl_add_u32 %7, %7, 1, %8\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(ic));
+            } else if constexpr (MODE == AND_PERM) {
+                asm volatile("v_and_b32 %0, %0, %8\n v_perm_b32 %1, %1, %9, %8\n v_and_b32 %2, %2, %8\n v_perm_b32 %3, %3, %9, %8\n"
+                             "v_and_b32 %4, %4, %8\n v_perm_b32 %5, %5, %9, %8\n v_and_b32 %6, %6, %8\n v_perm_b32 %7, %7, %9, %8\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(d));
+            } else if constexpr (MODE == PK_FMA) {
+                asm volatile("v_pk_fma_f32 %0, %0, %8, %9\n v_pk_fma_f32 %1, %1, %8, %9\n v_pk_fma_f32 %2, %2, %8, %9\n v_pk_fma_f32 %3, %3, %8, %9\n"
+                             "v_pk_fma_f32 %4, %4, %8, %9\n v_pk_fma_f32 %5, %5, %8, %9\n v_pk_fma_f32 %6, %6, %8, %9\n v_pk_fma_f32 %7, %7, %8, %9\n"
+                             : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(pc), "v"(pd));
+            } else if constexpr (MODE == MUL_LO) {
+                asm volatile("v_mul_lo_u32 %0, %0, %8\n v_mul_lo_u32 %1, %1, %8\n v_mul_lo_u32 %2, %2, %8\n v_mul_lo_u32 %3, %3, %8\n"
+                             "v_mul_lo_u32 %4, %4, %8\n v_mul_lo_u32 %5, %5, %8\n v_mul_lo_u32 %6, %6, %8\n v_mul_lo_u32 %7, %7, %8\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(id));
+            } else {
+                asm volatile("v_sin_f32 %0, %0\n v_cos_f32 %1, %1\n v_sin_f32 %2, %2\n v_cos_f32 %3, %3\n"
+                             "v_sin_f32 %4, %4\n v_cos_f32 %5, %5\n v_sin_f32 %6, %6\n v_cos_f32 %7, %7\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+            }
+        }
+    }
+    const u64 t1 = __builtin_readcyclecounter();
+    const u64 r1 = wall_clock64();
+    float sink = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y + p4.x + p4.y + p5.x +
+                 p5.y + p6.x + p6.y + p7.x + p7.y + float(q0 + q1 + q2 + q3 + q4 + q5 + q6 + q7);
+    if ((threadIdx.x & 63) == 0) {
+        const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+        ticks[2 * w] = t1 - t0;
+        ticks[2 * w + 1] = r1 - r0;
+    }
+    if (sink == 123.456f) ticks[0] = 0;
+}
+
+template <int MODE>
+void run(int waves_per_simd) {
+    const int blocks = 256 * waves_per_simd, iters = 4000;
+    unsigned long long *d;
+    hipMalloc(&d, size_t(blocks) * 4 * 2 * 8);
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, 100);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, iters);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    std::vector<unsigned long long> h(size_t(blocks) * 8);
+    hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
+    double st = 0, sr = 0;
+    for (size_t w = 0; w < h.size() / 2; w++) { st += double(h[2 * w]); sr += double(h[2 * w + 1]); }
+    const double n_inst = double(iters) * 64;                     // per wave
+    const double ticks_per_wave = st / double(h.size() / 2);
+    const double mhz = st / sr * 100.0;
+    printf("%-26s waves/SIMD %d  %8.3f ms  %6.2f shader cycles per wave-instruction per SIMD  (clock %4.0f MHz)\n", NAMES[MODE],
+           waves_per_simd, ms, ticks_per_wave / n_inst / waves_per_simd, mhz);
+    hipFree(d);
+}
+
+template <int M>
+void sweep() { for (int w : {1, 2, 3, 4}) run<M>(w); }
+
+int main() {
+    sweep<FMA>(); sweep<MULADD_E32>(); sweep<FMAC_E32>(); sweep<PK_FMA>(); sweep<MAD_U64>(); sweep<MUL_LO>(); sweep<RCP>(); sweep<SINCOS_HW>();
+    sweep<CVT_I32>(); sweep<MED3>(); sweep<MAX3>(); sweep<LSHL_ADD>(); sweep<AND_PERM>();
+    return 0;
+}
