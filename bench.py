@@ -5,12 +5,20 @@ One step = one pass of the hot path over one batch of synthetic input that is al
 resident in HBM: `--ensembles` independent DAB ensembles per GPU x `--frames` consecutive
 transmission frames each (default 64 x 256 = 16384 frames, 25.8 GB of cf32 IQ: BASELINE config 4,
 64 ensembles per GPU, >= 256 frames per stream).  Per step:
-  dabgpu_ofdm_demod_frames_dev -> dabgpu_decode_frames_dev (FIC + the sub-channel)
+  dabgpu_ofdm_demod_streams_dev -> dabgpu_decode_frames_dev (FIC + the sub-channel)
 all through the C ABI (include/dabgpu.h) on the current torch stream.  torch is plumbing:
 device buffers, stream, events, and torch.distributed (RCCL) for the barrier / max-reduce.
 
-Ensembles shard across GPUs with no data-path collective (weak scaling: 64 per rank).
-Prints ONE JSON line on rank 0.
+Nothing on the GPU side is told the frequency offsets the synthetic channel applied: the front end runs closed
+loop.  Per ensemble the carrier offset is a whole number of carriers (|k| <= 3) plus a fraction (|f| <= 0.4); before
+the timed region the coarse part is found on the first frame's phase reference symbol (dabgpu_sync_prs_dev) and the
+fine loop settles over three untimed calls; during the timed steps every call corrects with the stream's state in
+HBM and updates it from the cyclic-prefix correlations (a small kernel after the demodulation launch, inside the
+timed region).  `closed_loop` repeats the step on the same samples presented as unaligned captures: null-symbol
+search, per-frame frequency and timing from the PRS, demodulation where the frames lie.
+
+Ensembles shard across GPUs with no data-path collective (weak scaling: 64 per rank; global ensemble ids
+`id % world == rank`).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -34,25 +42,28 @@ ACS_FIC = 4 * 774 * 64                    # add-compare-selects per frame, FIC (
 ACS_MSC64 = 4 * 1542 * 64                 # one 64 kbit/s EEP 3-A subchannel (A12)
 
 
-def make_streams(torch, dev, n_ens, n_frames, n_unique, rank, snr_db):
-    """[n_ens][n_frames][196608] cf32 on the device, plus ground truth for verification."""
+def make_streams(torch, dev, ids, n_frames, n_unique, snr_db):
+    """IQ of the ensembles `ids` (global ids): [len(ids)][n_frames][196608] cf32 on the device, the carrier offsets
+    the channel applied (kept on the host, for the CPU baseline only) and the transmitted multiplexes."""
     from dabgpu import synth
-    ens = [synth.Ensemble(seed=0xDAB00000 + rank * 4096 + u, n_frames=4) for u in range(n_unique)]
+    ens = [synth.Ensemble(seed=0xDAB00000 + u, n_frames=4) for u in range(n_unique)]
     base = torch.from_numpy(np.stack([e.iq() for e in ens])).to(dev)        # [U][4][196608]
-    g = torch.Generator(device=dev)
-    g.manual_seed(0xDAB0 + rank)
     n = torch.arange(synth.NB_FRAME_SAMPLES * n_frames, device=dev, dtype=torch.float64)
-    iq = torch.empty((n_ens, n_frames, synth.NB_FRAME_SAMPLES), dtype=torch.complex64, device=dev)
-    cfo = (torch.rand(n_ens, generator=g, device=dev, dtype=torch.float64) * 0.8 - 0.4) / 2048.0
+    iq = torch.empty((len(ids), n_frames, synth.NB_FRAME_SAMPLES), dtype=torch.complex64, device=dev)
     sigma = float(np.sqrt(0.5 * 10 ** (-snr_db / 10)))
-    for s in range(n_ens):
-        clean = base[s % n_unique][torch.arange(n_frames, device=dev) % 4].reshape(-1)
-        rot = torch.exp(2j * np.pi * cfo[s] * n).to(torch.complex64)
+    cfos = []
+    for s, gid in enumerate(ids):
+        g = torch.Generator(device=dev)
+        g.manual_seed(0xDAB0 + gid)
+        r = np.random.default_rng(0xC0F0 + gid)
+        cfo = (int(r.integers(-3, 4)) + float(r.uniform(-0.4, 0.4))) / 2048.0     # whole carriers + a fraction
+        cfos.append(cfo)
+        clean = base[gid % n_unique][torch.arange(n_frames, device=dev) % 4].reshape(-1)
+        rot = torch.exp(2j * np.pi * cfo * n).to(torch.complex64)
         noise = torch.randn(clean.shape, generator=g, device=dev, dtype=torch.float32) + \
             1j * torch.randn(clean.shape, generator=g, device=dev, dtype=torch.float32)
         iq[s] = (clean * rot + sigma * noise).reshape(n_frames, -1)
-    fo = (-cfo).to(torch.float32).repeat_interleave(n_frames).contiguous()    # [n_ens*n_frames]
-    return iq, fo, ens
+    return iq, np.asarray(cfos), [ens[gid % n_unique] for gid in ids]
 
 
 def copy_ceiling(torch, dev):
@@ -106,20 +117,47 @@ def fftw_fft_stage(iq_host, seconds=3.0):
     return k / el
 
 
+def cpu_quota_cores():
+    """CPU time the container may use, in cores (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited/unknown."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if q == "max" else float(q) / float(p)
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / p
+    except Exception:
+        return None
+
+
 def cpu_baseline(iq_host, fo_host, sc_len_bits, mask, nsteps, budget_s, threads):
-    """Time the CPU oracle ('port', oracle/dab_oracle.c driven by oracle/oracle_bench.c) on the same workload:
-    OFDM demod + FIC + 4 MSC logical frames per transmission frame.  Bounded sample; one pthread per host core,
-    plus a single-thread figure (the reference plugin runs 1 OFDM + 1 decoder thread, dab_module.cpp:92)."""
+    """Time the CPU oracle ('port', oracle/dab_oracle.c driven by oracle/oracle_bench.c) on the same workload, on a
+    bounded sample.  Rows (SURVEY.md 8d / BASELINE.md 4.3):
+      single_core_value        one thread doing OFDM demod + FIC + 4 MSC logical frames per frame
+      ofdm_only_1_thread       BASELINE config 1: the front end alone on one thread
+      as_deployed_1_plus_1     one OFDM thread feeding one decoder thread through a 2-frame ring
+                               (/root/reference/src/dab_module.cpp:92, src/radio_block.cpp:23-44)
+      value                    every logical CPU the scheduler lists, one frame stream per thread; `effective_cores` =
+                               value / single_core_value says how many cores' worth of time the box actually granted"""
     from oracle import oracle as O
     n = iq_host.shape[0]
-    k1, t1 = O.bench_frames_timed(iq_host, fo_host, min(4.0, budget_s * 0.3), 1, mask, nsteps, sc_len_bits)
-    total, tn = O.bench_frames_timed(iq_host, fo_host, budget_s * 0.7, threads, mask, nsteps, sc_len_bits)
+    k1, t1 = O.bench_frames_timed(iq_host, fo_host, budget_s * 0.15, 1, mask, nsteps, sc_len_bits)
+    ko, to = O.bench_ofdm_only_timed(iq_host, fo_host, budget_s * 0.15)
+    kp, tp = O.bench_pipeline_timed(iq_host, fo_host, budget_s * 0.2, mask, nsteps, sc_len_bits)
+    total, tn = O.bench_frames_timed(iq_host, fo_host, budget_s * 0.5, threads, mask, nsteps, sc_len_bits)
     fftw = fftw_fft_stage(iq_host)
+    single = k1 / t1
     return {"fftw3f_fft_stage_frames_per_s_1_thread": fftw if fftw is not None else "FFTW3f: not available on this box",
             "value": total / tn, "unit": "frames/s", "cores": threads, "kind": "port",
+            "effective_cores": (total / tn) / single, "cgroup_cpu_quota_cores": cpu_quota_cores(),
             "sample": "%d frames (OFDM+FIC+64kbps EEP-3A MSC, %d distinct bench-input frames cycled) through "
                       "oracle/dab_oracle.c on %d pthreads in %.1f s" % (total, n, threads, tn),
-            "single_core_value": k1 / t1}
+            "single_core_value": single,
+            "ofdm_only_1_thread": {"value": ko / to, "unit": "frames/s", "sample": "%d frames in %.1f s (BASELINE config 1)" % (ko, to)},
+            "as_deployed_1_plus_1": {"value": kp / tp, "unit": "frames/s", "threads": 2,
+                                     "sample": "%d frames in %.1f s: one OFDM pthread -> 2-frame ring -> one decoder pthread" % (kp, tp)}}
 
 
 def main():
@@ -131,14 +169,16 @@ def main():
     ap.add_argument("--frames", type=int, default=256, help="consecutive frames per ensemble per step (multiple of 4)")
     ap.add_argument("--unique", type=int, default=8, help="distinct synthetic multiplexes generated on the host")
     ap.add_argument("--snr", type=float, default=20.0)
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=16.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--no-fft-stage", action="store_true", help="skip the unfused FFT-stage measurement")
     ap.add_argument("--no-selective", action="store_true", help="skip the extra selective-soft-output measurement")
+    ap.add_argument("--no-closed-loop", action="store_true", help="skip the unaligned-capture closed-loop measurement")
     args = ap.parse_args()
 
     import torch
     import dabgpu
     from dabgpu import synth
+    from dabgpu.shard import ensembles_of_rank, reduce_report
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -162,7 +202,8 @@ def main():
 
     E, F = args.ensembles, args.frames
     n_frames = E * F
-    iq, fo, ens = make_streams(torch, dev, E, F, min(args.unique, E), rank, args.snr)
+    ids = ensembles_of_rank(E * world, world, rank)              # this rank's share of the global ensemble list
+    iq, cfo_true, ens = make_streams(torch, dev, ids, F, min(args.unique, E * world), args.snr)
     soft = torch.empty((n_frames, dabgpu.NB_FRAME_BITS), dtype=torch.int8, device=dev)
     fib = torch.zeros((n_frames, 12, 32), dtype=torch.uint8, device=dev)
     crc = torch.zeros((n_frames, 12), dtype=torch.uint8, device=dev)
@@ -178,13 +219,22 @@ def main():
     stream = tstream.cuda_stream
     d_iq = iq.data_ptr() + synth.NB_NULL * 8          # first PRS sample of frame 0
     ofdm_ev, dec_ev = [], []
+    BETA = 0.9                                        # fine_freq_update_beta, the reference's default order of magnitude
+
+    # ---- acquisition, untimed: whole-carrier offset of every stream from its first PRS, then the fine loop settles
+    ctx.streams_reset(E)
+    sync_out = torch.zeros((E, 4), dtype=torch.int32, device=dev)
+    ctx.sync_prs_dev(d_iq, F * synth.NB_FRAME_SAMPLES, E, None, 200, sync_out.data_ptr(), stream)
+    torch.cuda.synchronize()
+    coarse_found = sync_out[:, 0].cpu().numpy()
+    for s in range(E):
+        ctx.set_stream_offsets(s, coarse=-float(coarse_found[s]) / 2048.0)
 
     def step(k, timed):
         if timed:
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
             ev[0].record()
-        ctx.ofdm_demod_frames_dev(d_iq, synth.NB_FRAME_SAMPLES, n_frames, fo.data_ptr(), soft.data_ptr(),
-                                  cyc.data_ptr(), None, stream)
+        ctx.ofdm_demod_streams_dev(d_iq, synth.NB_FRAME_SAMPLES, E, F, BETA, soft.data_ptr(), cyc.data_ptr(), None, stream)
         if timed:
             ev[1].record()
         # FIC + the sub-channel of every frame: what BasicRadio::Process does, one call for the batch
@@ -193,6 +243,12 @@ def main():
         if timed:
             ev[2].record()
             ofdm_ev.append((ev[0], ev[1])); dec_ev.append((ev[1], ev[2]))
+
+    for k in range(3):                                # settle the fine-frequency loop (part of acquisition, untimed)
+        ctx.ofdm_demod_streams_dev(d_iq, synth.NB_FRAME_SAMPLES, E, F, BETA, soft.data_ptr(), cyc.data_ptr(), None, stream)
+    torch.cuda.synchronize()
+    net = np.array([ctx.get_stats(s).net_freq_offset for s in range(E)])
+    loop_residual = float(np.abs(net + cfo_true).max() * 2048.0)            # carriers; reported, not used
 
     def barrier():
         torch.cuda.synchronize()
@@ -203,6 +259,9 @@ def main():
     for k in range(args.warmup):
         step(k, False)
     barrier()
+    # roofline.achieved is priced on the dominant kernel's own launches: HIP events recorded by the library around the
+    # fused front-end launch alone, on the launch stream, during the timed steps (dabgpu_set_timing / _mean_kernel_ms)
+    ctx.set_timing(True)
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(args.warmup + k, True)
@@ -217,19 +276,20 @@ def main():
     fic_ok = bool(crc_h.all())
     msc_ok = True
     for s in range(E):
-        e = ens[s % len(ens)]
+        e = ens[s]
         for f in range(F):
             fic_ok &= bool((fib_h[s * F + f] == e.fibs[f % 4]).all())
         # logical frame finished by CIF t was transmitted from CIF t-15 (cyclic 16-CIF multiplex);
         # with warm history every entry is valid
         for t in range(0 if args.warmup + args.steps >= 2 else 15, F * 4):
             msc_ok &= bool((msc_h[s, t] == e.msc_bytes[(t - 15) % 16]).all())
-    from dabgpu.shard import reduce_report
     elapsed, frames_total, (fic_ok, msc_ok) = reduce_report(dist, red_dev, elapsed, n_frames * args.steps,
                                                             [fic_ok, msc_ok])
 
-    ofdm_ms = float(np.mean([a.elapsed_time(b) for a, b in ofdm_ev]))
+    ofdm_call_ms = float(np.mean([a.elapsed_time(b) for a, b in ofdm_ev]))     # front-end call: kernel + state update
     dec_ms = float(np.mean([a.elapsed_time(b) for a, b in dec_ev]))
+    ofdm_ms, ofdm_launches = ctx.mean_kernel_ms(0)                             # the fused kernel's launches alone
+    ctx.set_timing(False)
 
     if rank == 0:
         value = frames_total / elapsed
@@ -251,12 +311,17 @@ def main():
             "config": {"workload": "%d ensembles/GPU x %d frames/step, Mode-I OFDM + FIC Viterbi + one 64 kbps "
                                    "EEP-3A MSC subchannel, IQ resident in HBM" % (E, F),
                        "ensembles_per_gpu": E, "frames_per_step_per_gpu": n_frames, "snr_db": args.snr,
-                       "sharding": "independent ensembles per rank, no data-path collective"},
+                       "carrier_offset": "unknown to the receiver: k + f carriers per ensemble, |k| <= 3, |f| <= 0.4",
+                       "frequency_correction": "closed loop on the device (dabgpu_ofdm_demod_streams_dev): coarse from the first PRS, "
+                                               "fine from the cyclic-prefix correlations of the previous call",
+                       "sharding": "independent ensembles per rank (global id % world == rank), no data-path collective"},
             "x_realtime": value / REALTIME_FPS,
             "fic_bit_exact": fic_ok, "msc_bit_exact": msc_ok,
-            "roofline": {"bound": "hbm", "kernel": "dabk::ofdm_wave_kernel<false,false> (fused A2..A6)", "achieved": achieved,
+            "fine_loop_residual_carriers": loop_residual,
+            "roofline": {"bound": "hbm", "kernel": "dabk::ofdm_wave_kernel<false,false,false,true> (fused A2..A6)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "avg_launch_ms": ofdm_ms, "frames_per_launch": n_frames,
+                         "traffic": traffic, "avg_launch_ms": ofdm_ms, "launches_timed": ofdm_launches,
+                         "front_end_call_ms": ofdm_call_ms, "frames_per_launch": n_frames,
                          "algorithmic_bytes_per_frame": A_OFDM,
                          "copy_ceiling": copy_ceiling(torch, dev)},
             # the channel decoder is integer add-compare-select work, not bandwidth: report ACS/s
@@ -264,6 +329,8 @@ def main():
                         "entry_point": "dabgpu_decode_frames_dev (FIC + sub-channel codewords in one grouped launch)"},
         }
         if not args.no_fft_stage:
+            # the unfused FFT stage with the offsets the closed loop arrived at (per frame, from the stream states)
+            fo = torch.from_numpy(np.repeat(net.astype(np.float32), F)).to(dev)
             spectra = torch.empty((n_frames, 76, 2048), dtype=torch.complex64, device=dev)
             evs = []
             for i in range(3 + 5):
@@ -315,16 +382,89 @@ def main():
                 "algorithmic_bytes_per_frame": a_sel,
                 "ofdm_achieved_GBps": a_sel * n_frames / (sel_ofdm * 1e-3) / 1e9,
                 "outputs_identical_to_whole_frame_run": sel_ok}
+        if not args.no_closed_loop:
+            out["closed_loop"] = closed_loop_leg(torch, dabgpu, synth, ctx, dev, stream, iq, ens, sc, soft, fib, crc, msc, hist,
+                                                 E, F, args.steps)
         if world == 1 and args.cpu_seconds > 0:
             k = min(n_frames, 64)
             iq_h = iq.reshape(n_frames, -1)[:k, synth.NB_NULL:].contiguous().cpu().numpy()
-            out["cpu_baseline"] = cpu_baseline(iq_h, fo[:k].cpu().numpy(), sc.length * 64, ens[0].mask,
-                                               64 * 24 + 6, args.cpu_seconds, len(os.sched_getaffinity(0)) or 1)
+            fo_h = np.repeat(-cfo_true, F)[:k].astype(np.float32)            # the oracle is handed the channel's offsets
+            out["cpu_baseline"] = cpu_baseline(iq_h, fo_h, sc.length * 64, ens[0].mask, 64 * 24 + 6, args.cpu_seconds,
+                                               len(os.sched_getaffinity(0)) or 1)
         print(json.dumps(out))
     ctx.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def closed_loop_leg(torch, dabgpu, synth, ctx, dev, stream, iq, ens, sc, soft, fib, crc, msc, hist, E, F, steps):
+    """The same samples as unaligned captures with nothing known about them: every ensemble's F frames form one
+    capture that starts at an arbitrary sample.  Per step: dabgpu_acquire_dev (null-symbol search, per-frame fractional
+    + whole-carrier frequency and timing from the PRS) -> dabgpu_ofdm_demod_acquired_dev (frames demodulated where
+    they lie) -> dabgpu_decode_frames_dev.  Frames that are cut off at either end of a capture are not found, so a
+    capture yields F-1 frames."""
+    L = synth.NB_FRAME_SAMPLES
+    rng = np.random.default_rng(0xACC)
+    off = int(rng.integers(3000, L - 3000))                       # where the captures begin inside their first frame
+    n_samples = F * L - off
+    d_cap = iq.data_ptr() + off * 8
+    acq = torch.zeros((E * F * 32,), dtype=torch.uint8, device=dev)
+    counts = torch.zeros((E,), dtype=torch.int32, device=dev)
+    for h in hist:
+        h.zero_()
+    soft.zero_(); fib.zero_(); crc.zero_(); msc.zero_()
+
+    def step(k):
+        ctx.acquire_dev(d_cap, F * L, E, n_samples, F, acq.data_ptr(), counts.data_ptr(), None, stream)
+        ctx.ofdm_demod_acquired_dev(d_cap, F * L, E, F, acq.data_ptr(), soft.data_ptr(), None, None, stream)
+        ctx.decode_frames_dev(soft.data_ptr(), dabgpu.NB_FRAME_BITS, E, F, fib.data_ptr(), crc.data_ptr(), [sc],
+                              [None], [None], [msc.data_ptr()], stream)
+    for k in range(2):
+        step(k)
+    torch.cuda.synchronize()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    t0 = time.perf_counter()
+    for k in range(steps):
+        if k == steps - 1:
+            evs[0].record()
+            ctx.acquire_dev(d_cap, F * L, E, n_samples, F, acq.data_ptr(), counts.data_ptr(), None, stream)
+            evs[1].record()
+            ctx.ofdm_demod_acquired_dev(d_cap, F * L, E, F, acq.data_ptr(), soft.data_ptr(), None, None, stream)
+            evs[2].record()
+            ctx.decode_frames_dev(soft.data_ptr(), dabgpu.NB_FRAME_BITS, E, F, fib.data_ptr(), crc.data_ptr(), [sc],
+                                  [None], [None], [msc.data_ptr()], stream)
+            evs[3].record()
+        else:
+            step(k)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    cnt = counts.cpu().numpy()
+    frames = acq.cpu().numpy().view(dabgpu.ACQUIRED_FRAME_DTYPE).reshape(E, F)
+    fib_h, crc_h, msc_h = fib.cpu().numpy().reshape(E, F, 12, 32), crc.cpu().numpy().reshape(E, F, 12), msc.cpu().numpy()
+    found = int(cnt.sum())
+    locked = 0
+    ok_fic, ok_msc = True, True
+    for s in range(E):
+        e = ens[s]
+        for i in range(int(cnt[s])):
+            fr = frames[s, i]
+            if (fr["flags"] & 3) != 3:
+                continue
+            locked += 1
+            j = int(round((int(fr["start"]) + off - synth.NB_NULL) / L))         # which transmitted frame this is
+            ok_fic &= bool(crc_h[s, i].all()) and bool((fib_h[s, i] == e.fibs[j % 4]).all())
+            for c in range(4):
+                t = 4 * i + c                                                     # CIF index inside the capture
+                if t >= 15:                                                       # de-interleaver filled (no carried history)
+                    ok_msc &= bool((msc_h[s, t] == e.msc_bytes[(4 * (j - i) + t - 15) % 16]).all())
+    return {"value": locked * steps / el, "unit": "frames/s", "ms_per_step": el / steps * 1e3,
+            "frames_found_per_step": found, "frames_locked_per_step": locked, "frames_in_the_captures": E * (F - 1),
+            "acquire_ms": evs[0].elapsed_time(evs[1]), "ofdm_ms": evs[1].elapsed_time(evs[2]),
+            "decode_ms": evs[2].elapsed_time(evs[3]),
+            "fic_bit_exact": ok_fic and locked > 0, "msc_bit_exact": ok_msc and locked > 0,
+            "what": "captures start %d samples into a frame; dabgpu_acquire_dev -> dabgpu_ofdm_demod_acquired_dev -> "
+                    "dabgpu_decode_frames_dev; no offset, timing or alignment supplied" % off}
 
 
 if __name__ == "__main__":

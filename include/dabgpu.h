@@ -457,12 +457,17 @@ int dabgpu_viterbi(dabgpu_ctx *ctx, const int8_t *punct, int n_codewords, const 
                    int nsteps, uint8_t *out_bytes);
 
 /* ------------------------------------------------------------------------ */
-/* Timing helper: average duration (ms) of the most recent launch of each      */
-/* kernel family, measured with hipEvents on the launch stream when             */
-/* dabgpu_set_timing(ctx,1) is on.  which: 0 = ofdm, 1 = fic, 2 = msc, 3 = fft */
+/* Timing helper: duration (ms) of the launches of each kernel family,         */
+/* measured with hipEvents on the launch stream, around the kernel launch       */
+/* alone, while dabgpu_set_timing(ctx,1) is on (every call to it starts a new   */
+/* measurement).  which: 0 = ofdm front end, 1 = fic, 2 = msc / grouped decode, */
+/* 3 = fft stage.  _last_ = the most recent launch; _mean_ = the mean over the  */
+/* launches since timing was switched on (at most the last 32) and how many     */
+/* that were.  Both wait for the launches they read.                            */
 /* ------------------------------------------------------------------------ */
 int dabgpu_set_timing(dabgpu_ctx *ctx, int enable);
 int dabgpu_last_kernel_ms(dabgpu_ctx *ctx, int which, float *ms);
+int dabgpu_mean_kernel_ms(dabgpu_ctx *ctx, int which, float *mean_ms, int *launches);
 
 #ifdef __cplusplus
 }

@@ -559,17 +559,21 @@ int oracle_null_search(const float *iq, int64_t n_samples, float thr_start, floa
     if (nb <= 0 || max_out <= 0) return 0;
     float *l1 = (float *)malloc(sizeof(float) * (size_t)nb);
     oracle_null_block_l1(iq, n_samples, l1);
-    /* mean: 64 strided partial sums in double, then the butterfly over 64 */
-    double p[64], q[64];
-    for (int j = 0; j < 64; j++) {
+    /* mean: 1024 strided partial sums in double, the butterfly over each group of 64, the 16 group sums in order */
+    double p[1024], q[64];
+    for (int j = 0; j < 1024; j++) {
         double a = 0.0;
-        for (int64_t b = j; b < nb; b += 64) a += (double)l1[b];
+        for (int64_t b = j; b < nb; b += 1024) a += (double)l1[b];
         p[j] = a;
     }
-    for (int off = 1; off < 64; off <<= 1) {
-        for (int j = 0; j < 64; j++) q[j] = p[j] + p[j ^ off];
-        memcpy(p, q, sizeof(p));
+    for (int w = 0; w < 16; w++) {
+        double *g = p + 64 * w;
+        for (int off = 1; off < 64; off <<= 1) {
+            for (int j = 0; j < 64; j++) q[j] = g[j] + g[j ^ off];
+            memcpy(g, q, sizeof(q));
+        }
     }
+    for (int w = 1; w < 16; w++) p[0] += p[64 * w];
     const float avg = (float)(p[0] / (double)nb);
     const float ts = thr_start * avg, te = thr_end * avg;
     const int max_blocks = 2 * DAB_NB_NULL_PERIOD / 64;                       /* 83 */

@@ -49,6 +49,8 @@ def lib():
         L.oracle_firecode.restype = C.c_uint16
         L.oracle_rs_decode.restype = C.c_int
         L.oracle_bench_frames_timed.restype = C.c_double
+        L.oracle_bench_ofdm_only_timed.restype = C.c_double
+        L.oracle_bench_pipeline_timed.restype = C.c_double
     return _LIB
 
 
@@ -241,6 +243,28 @@ def bench_frames_timed(iq, freq_offset, seconds, threads, mask, nsteps, sc_bits)
     done = C.c_long(0)
     el = lib().oracle_bench_frames_timed(_p(a), C.c_size_t(a.shape[1]), _p(fo), C.c_int(a.shape[0]), C.c_double(seconds),
                                          C.c_int(threads), _p(m), C.c_int(nsteps), C.c_int(sc_bits), C.byref(done))
+    return int(done.value), float(el)
+
+
+def bench_ofdm_only_timed(iq, freq_offset, seconds):
+    """BASELINE config 1: the front end alone (A2..A6) on one thread for about `seconds`; (frames_done, elapsed_s)."""
+    a = np.ascontiguousarray(iq, np.complex64)
+    fo = np.ascontiguousarray(freq_offset, np.float32)
+    done = C.c_long(0)
+    el = lib().oracle_bench_ofdm_only_timed(_p(a), C.c_size_t(a.shape[1]), _p(fo), C.c_int(a.shape[0]), C.c_double(seconds),
+                                            C.byref(done))
+    return int(done.value), float(el)
+
+
+def bench_pipeline_timed(iq, freq_offset, seconds, mask, nsteps, sc_bits):
+    """The plugin's deployment shape: one OFDM thread feeding one decoder thread through a two-frame ring
+    (/root/reference/src/dab_module.cpp:92, src/radio_block.cpp:23-44); (frames_decoded, elapsed_s)."""
+    a = np.ascontiguousarray(iq, np.complex64)
+    fo = np.ascontiguousarray(freq_offset, np.float32)
+    m = np.ascontiguousarray(mask, np.uint8)
+    done = C.c_long(0)
+    el = lib().oracle_bench_pipeline_timed(_p(a), C.c_size_t(a.shape[1]), _p(fo), C.c_int(a.shape[0]), C.c_double(seconds),
+                                           _p(m), C.c_int(nsteps), C.c_int(sc_bits), C.byref(done))
     return int(done.value), float(el)
 
 

@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -34,9 +35,12 @@ struct DeviceCode {
     }
 };
 
+// hipEvent pairs around the most recent launches of one kernel family (a ring: the launches are asynchronous, so
+// the pairs can only be read back after the stream has caught up)
+constexpr int TIMER_RING = 32;
 struct Timer {
-    hipEvent_t start = nullptr, stop = nullptr;
-    bool valid = false;
+    hipEvent_t start[TIMER_RING] = {}, stop[TIMER_RING] = {};
+    long recorded = 0;                   // launches timed since timing was switched on
 };
 
 }  // namespace
@@ -170,15 +174,16 @@ struct ScopedTimer {
     ScopedTimer(dabgpu_ctx *c, int w, hipStream_t st) : ctx(c), which(w), s(st) {
         if (ctx->timing) {
             Timer &t = ctx->timers[which];
-            if (!t.start) { (void)hipEventCreate(&t.start); (void)hipEventCreate(&t.stop); }
-            (void)hipEventRecord(t.start, s);
+            const int i = int(t.recorded % TIMER_RING);
+            if (!t.start[i]) { (void)hipEventCreate(&t.start[i]); (void)hipEventCreate(&t.stop[i]); }
+            (void)hipEventRecord(t.start[i], s);
         }
     }
     ~ScopedTimer() {
         if (ctx->timing) {
             Timer &t = ctx->timers[which];
-            (void)hipEventRecord(t.stop, s);
-            t.valid = true;
+            (void)hipEventRecord(t.stop[int(t.recorded % TIMER_RING)], s);
+            t.recorded++;
         }
     }
 };
@@ -421,10 +426,11 @@ void dabgpu_destroy(dabgpu_ctx *ctx) {
     if (ctx->d_lane_scratch) (void)hipFree(ctx->d_lane_scratch);
     if (ctx->d_acq_scratch) (void)hipFree(ctx->d_acq_scratch);
     for (void *p : ctx->keep_tables) (void)hipFree(p);
-    for (Timer &t : ctx->timers) {
-        if (t.start) (void)hipEventDestroy(t.start);
-        if (t.stop) (void)hipEventDestroy(t.stop);
-    }
+    for (Timer &t : ctx->timers)
+        for (int i = 0; i < TIMER_RING; i++) {
+            if (t.start[i]) (void)hipEventDestroy(t.start[i]);
+            if (t.stop[i]) (void)hipEventDestroy(t.stop[i]);
+        }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     }
     delete ctx;
@@ -452,6 +458,7 @@ void *dabgpu_stream(dabgpu_ctx *ctx) { return ctx ? reinterpret_cast<void *>(ctx
 int dabgpu_set_timing(dabgpu_ctx *ctx, int enable) {
     if (!ctx) return DABGPU_ERR_ARG;
     ctx->timing = enable != 0;
+    for (Timer &t : ctx->timers) t.recorded = 0;               // a new measurement starts
     return DABGPU_OK;
 }
 
@@ -459,9 +466,29 @@ int dabgpu_last_kernel_ms(dabgpu_ctx *ctx, int which, float *ms) {
     if (!ctx || !ms || which < 0 || which > 3) return DABGPU_ERR_ARG;
     DeviceGuard guard(ctx);
     Timer &t = ctx->timers[which];
-    if (!t.valid) return DABGPU_ERR_ARG;
-    HIP_TRY(hipEventSynchronize(t.stop));
-    HIP_TRY(hipEventElapsedTime(ms, t.start, t.stop));
+    if (t.recorded == 0) return DABGPU_ERR_ARG;
+    const int i = int((t.recorded - 1) % TIMER_RING);
+    HIP_TRY(hipEventSynchronize(t.stop[i]));
+    HIP_TRY(hipEventElapsedTime(ms, t.start[i], t.stop[i]));
+    return DABGPU_OK;
+}
+
+int dabgpu_mean_kernel_ms(dabgpu_ctx *ctx, int which, float *mean_ms, int *launches) {
+    if (!ctx || !mean_ms || which < 0 || which > 3) return DABGPU_ERR_ARG;
+    DeviceGuard guard(ctx);
+    Timer &t = ctx->timers[which];
+    const int n = int(std::min<long>(t.recorded, TIMER_RING));
+    if (n == 0) return DABGPU_ERR_ARG;
+    double sum = 0.0;
+    for (int k = 0; k < n; k++) {
+        const int i = int((t.recorded - 1 - k) % TIMER_RING);
+        float ms = 0.f;
+        HIP_TRY(hipEventSynchronize(t.stop[i]));
+        HIP_TRY(hipEventElapsedTime(&ms, t.start[i], t.stop[i]));
+        sum += double(ms);
+    }
+    *mean_ms = float(sum / n);
+    if (launches) *launches = n;
     return DABGPU_OK;
 }
 

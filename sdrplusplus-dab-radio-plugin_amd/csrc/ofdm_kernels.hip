@@ -496,25 +496,32 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
     }
 }
 
-// One wave per stream.  Restated by oracle.py stream_update() for the parity test.
-__global__ __launch_bounds__(64) void stream_update_kernel(StreamState *state, const float2 *cyc, const float2 *iq,
-                                                           size_t frame_stride, int frames_per_stream, float beta,
-                                                           float thr_null_start) {
-    const int s = blockIdx.x, lane = threadIdx.x;
+// One 1024-thread workgroup per stream.  Restated by oracle.py stream_update() for the parity test.
+constexpr int SU_THREADS = 1024;
+__global__ __launch_bounds__(SU_THREADS) void stream_update_kernel(StreamState *state, const float2 *cyc, const float2 *iq,
+                                                                   size_t frame_stride, int frames_per_stream, float beta,
+                                                                   float thr_null_start) {
+    __shared__ float red[2][SU_THREADS / 64];
+    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float2 *c = cyc + size_t(s) * frames_per_stream * NB_FRAME_SYMBOLS;
     const int n = frames_per_stream * NB_FRAME_SYMBOLS;
     float acc = 0.f;
-    for (int i = lane; i < n; i += 64) acc += atan2f(c[i].y, c[i].x);
-    acc = wave_sum(acc, lane);
+    for (int i = tid; i < n; i += SU_THREADS) acc += atan2f(c[i].y, c[i].x);
     // level of the stream's most recent frame: first 4096 samples (PRS and the start of the first data symbol)
     const float4 *x = reinterpret_cast<const float4 *>(iq + (size_t(s) * frames_per_stream + (frames_per_stream - 1)) * frame_stride);
     float l1 = 0.f;
-    for (int i = lane; i < 2048; i += 64) {
+    for (int i = tid; i < 2048; i += SU_THREADS) {
         const float4 v = x[i];
         l1 += fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w);
     }
-    l1 = wave_sum(l1, lane) * (1.0f / 4096.0f);
-    if (lane == 0) {
+    acc = wave_sum(acc, lane);
+    l1 = wave_sum(l1, lane);
+    if (lane == 0) { red[0][wave] = acc; red[1][wave] = l1; }
+    __syncthreads();
+    if (tid == 0) {
+        acc = 0.f; l1 = 0.f;
+        for (int w = 0; w < SU_THREADS / 64; w++) { acc += red[0][w]; l1 += red[1][w]; }
+        l1 *= 1.0f / 4096.0f;
         StreamState st = state[s];
         const float err = acc / float(n) * (1.0f / (6.283185307179586f * float(NB_FFT)));
         constexpr float HALF = 0.5f / float(NB_FFT);
@@ -539,7 +546,7 @@ __global__ __launch_bounds__(64) void stream_update_kernel(StreamState *state, c
 hipError_t launch_stream_update(StreamState *state, const float2 *cyc, const float2 *iq, size_t frame_stride,
                                 int n_streams, int frames_per_stream, float beta, float thr_null_start, hipStream_t s) {
     if (n_streams <= 0 || frames_per_stream <= 0) return hipSuccess;
-    hipLaunchKernelGGL(stream_update_kernel, dim3(unsigned(n_streams)), dim3(64), 0, s, state, cyc, iq, frame_stride,
+    hipLaunchKernelGGL(stream_update_kernel, dim3(unsigned(n_streams)), dim3(SU_THREADS), 0, s, state, cyc, iq, frame_stride,
                        frames_per_stream, beta, thr_null_start);
     return hipGetLastError();
 }

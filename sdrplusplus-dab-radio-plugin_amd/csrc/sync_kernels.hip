@@ -250,51 +250,98 @@ __global__ __launch_bounds__(256) void null_l1_kernel(const float2 *iq, size_t s
     }
 }
 
-// Dip search: one wave per stream.  Mean of the block norms (64 strided partial sums in double, XOR butterfly),
-// then the two-threshold state machine; 64 blocks are classified per trip with two ballots and the scalar
-// unit walks the events.
-__global__ __launch_bounds__(64) void null_dip_kernel(AcquireArgs a, int64_t nb) {
-    const int st = blockIdx.x;
-    const int lane = threadIdx.x;
-    const float *l1 = a.l1 + size_t(st) * nb;
+// ---- dip search ----
+// The search is a two-state machine over the block norms (below thr_start x mean: a dip begins; above thr_end x mean:
+// it ends, and a dip of plausible length is a null symbol).  One wave walking a whole stream is pure latency, so the
+// stream is cut into segments that are scanned in parallel; what a segment does depends on the state it is entered
+// in only up to its first block above the upper threshold -- after that block both possible machines coincide.  A
+// segment therefore reports (first high block h, first low block before it, the candidates and end state of a
+// state-0 machine started at h + 1), and one wave per stream stitches the segments together in order: the result is
+// exactly the sequential machine's (the oracle runs the plain loop).
+constexpr int MEAN_THREADS = 1024;
+constexpr int64_t SEG_BLOCKS = 16384;         // blocks per segment: 2^20 samples, about half a second
+
+struct DipSegment {                            // 32 bytes
+    int64_t h;                                 // first block above thr_end, or -1
+    int64_t l0;                                // first block below thr_start before h (anywhere, if h = -1), or -1
+    int64_t dip_begin_out;                     // tail machine: begin of the dip that is open at the segment's end
+    int32_t n_tail;                            // candidates of the tail machine
+    int32_t state_out;                         // tail machine's state at the segment's end
+};
+
+// Mean block norm of a stream: 1024 strided partial sums in double, XOR butterfly inside each wave, the sixteen wave
+// sums added in order (the fixed tree the oracle restates).
+__global__ __launch_bounds__(MEAN_THREADS) void null_mean_kernel(const float *l1_all, int64_t nb, float *avg) {
+    __shared__ double part[MEAN_THREADS / 64];
+    const int st = blockIdx.x, tid = threadIdx.x;
+    const float *l1 = l1_all + size_t(st) * nb;
     double acc = 0.0;
-    {   // same order of additions as the plain loop; eight loads in flight (one wave per stream: latency is all there is)
-        int64_t b = lane;
-        for (; b + 7 * 64 < nb; b += 8 * 64) {
-            float v[8];
+    int64_t b = tid;
+    for (; b + 7 * MEAN_THREADS < nb; b += 8 * MEAN_THREADS) {
+        float v[8];
 #pragma unroll
-            for (int j = 0; j < 8; j++) v[j] = l1[b + 64 * j];
+        for (int j = 0; j < 8; j++) v[j] = l1[b + MEAN_THREADS * j];
 #pragma unroll
-            for (int j = 0; j < 8; j++) acc += double(v[j]);
-        }
-        for (; b < nb; b += 64) acc += double(l1[b]);
+        for (int j = 0; j < 8; j++) acc += double(v[j]);
     }
+    for (; b < nb; b += MEAN_THREADS) acc += double(l1[b]);
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) acc += __shfl_xor(acc, off);
-    const float avg = float(acc / double(nb));
-    const float ts = __fmul_rn(a.thr_start, avg), te = __fmul_rn(a.thr_end, avg);
+    if ((tid & 63) == 0) part[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        double t = part[0];
+        for (int w = 1; w < MEAN_THREADS / 64; w++) t += part[w];
+        avg[st] = float(t / double(nb));
+    }
+}
+
+__device__ __forceinline__ bool dip_is_null_symbol(const AcquireArgs &a, int64_t dip_begin, int64_t end_block, int64_t *cand) {
     const int max_blocks = 2 * NB_NULL_PERIOD / 64;
+    const int64_t len = end_block - dip_begin;
+    const int64_t c = end_block * 64 - 48;
+    *cand = c;
+    return len >= a.min_blocks && len <= max_blocks && c >= 0 &&
+           c + int64_t(NB_FRAME_SYMBOLS) * NB_SYM_PERIOD + 512 <= a.n_samples;
+}
+
+// one wave per (segment, stream); 64 blocks are classified per trip with two ballots, the scalar unit walks the events
+__global__ __launch_bounds__(64) void null_segment_kernel(AcquireArgs a, int64_t nb, int n_seg, const float *avg,
+                                                          DipSegment *segs, int64_t *seg_cands) {
+    const int seg = blockIdx.x, st = blockIdx.y;
+    const int lane = threadIdx.x;
+    const float *l1 = a.l1 + size_t(st) * nb;
+    const float mean = avg[st];
+    const float ts = __fmul_rn(a.thr_start, mean), te = __fmul_rn(a.thr_end, mean);
+    const int64_t b0 = int64_t(seg) * SEG_BLOCKS, b1 = min(nb, b0 + SEG_BLOCKS);
+    int64_t *cands = seg_cands + (size_t(st) * n_seg + seg) * a.max_out;
+    int64_t h = -1, l0 = -1, dip_begin = 0;
     int count = 0, state = 0;
-    int64_t dip_begin = 0;
-    int64_t *cands = a.cands + size_t(st) * a.max_out;
     constexpr int AHEAD = 8;                                   // trips fetched together
     float vbuf[AHEAD];
-    for (int64_t base = 0; base < nb && count < a.max_out; base += 64) {
-        const int slot = int((base >> 6) % AHEAD);
+    for (int64_t base = b0; base < b1 && count < a.max_out; base += 64) {
+        const int slot = int(((base - b0) >> 6) % AHEAD);
         if (slot == 0) {
 #pragma unroll
             for (int j = 0; j < AHEAD; j++) {
                 const int64_t bj = base + 64 * j + lane;
-                vbuf[j] = bj < nb ? l1[bj] : 0.0f;
+                vbuf[j] = bj < b1 ? l1[bj] : 0.0f;
             }
         }
         const int64_t b = base + lane;
         float v = vbuf[0];
 #pragma unroll
         for (int j = 1; j < AHEAD; j++) v = (slot == j) ? vbuf[j] : v;
-        const unsigned long long low = __ballot(b < nb && v < ts);
-        const unsigned long long high = __ballot(b < nb && v > te);
-        int pos = 0;                                            // wave-uniform walk over this trip's events
+        const unsigned long long low = __ballot(b < b1 && v < ts);
+        const unsigned long long high = __ballot(b < b1 && v > te);
+        int pos = 0;
+        if (h < 0) {                                           // head: up to the first high block
+            if (l0 < 0 && low != 0ull && (high == 0ull || __builtin_ctzll(low) < __builtin_ctzll(high)))
+                l0 = base + __builtin_ctzll(low);
+            if (high == 0ull) continue;
+            h = base + __builtin_ctzll(high);
+            pos = __builtin_ctzll(high) + 1;                   // the tail machine starts behind it, in state 0
+        }
         while (pos < 64 && count < a.max_out) {
             const unsigned long long m = (state == 0 ? low : high) >> pos;
             if (m == 0ull) break;
@@ -304,16 +351,49 @@ __global__ __launch_bounds__(64) void null_dip_kernel(AcquireArgs a, int64_t nb)
                 state = 1;
                 dip_begin = bb;
             } else {
-                const int64_t len = bb - dip_begin;
-                const int64_t c = bb * 64 - 48;
-                if (len >= a.min_blocks && len <= max_blocks && c >= 0 &&
-                    c + int64_t(NB_FRAME_SYMBOLS) * NB_SYM_PERIOD + 512 <= a.n_samples) {
+                int64_t c;
+                if (dip_is_null_symbol(a, dip_begin, bb, &c)) {
                     if (lane == 0) cands[count] = c;
                     count++;
                 }
                 state = 0;
             }
             pos = bit + 1;
+        }
+    }
+    if (lane == 0) segs[size_t(st) * n_seg + seg] = DipSegment{h, l0, dip_begin, count, state};
+}
+
+// one wave per stream: the segments in order
+__global__ __launch_bounds__(64) void null_stitch_kernel(AcquireArgs a, int n_seg, const DipSegment *segs, const int64_t *seg_cands) {
+    const int st = blockIdx.x, lane = threadIdx.x;
+    int64_t *cands = a.cands + size_t(st) * a.max_out;
+    int count = 0, state = 0;
+    int64_t dip_begin = 0;
+    for (int s0 = 0; s0 < n_seg && count < a.max_out; s0 += 64) {
+        DipSegment mine = DipSegment{-1, -1, 0, 0, 0};
+        if (s0 + lane < n_seg) mine = segs[size_t(st) * n_seg + s0 + lane];
+        const int n_here = min(64, n_seg - s0);
+        for (int j = 0; j < n_here && count < a.max_out; j++) {
+            const int64_t h = __shfl(mine.h, j), l0 = __shfl(mine.l0, j);
+            if (h < 0) {                                       // no block above the upper threshold in this segment
+                if (state == 0 && l0 >= 0) { state = 1; dip_begin = l0; }
+                continue;
+            }
+            const bool open = state == 1 || l0 >= 0;
+            const int64_t begin = state == 1 ? dip_begin : l0;
+            int64_t c;
+            if (open && dip_is_null_symbol(a, begin, h, &c)) {
+                if (lane == 0) cands[count] = c;
+                count++;
+            }
+            const int n_tail = __shfl(mine.n_tail, j);
+            const int64_t *tc = seg_cands + (size_t(st) * n_seg + s0 + j) * a.max_out;
+            const int take = min(n_tail, a.max_out - count);
+            for (int i = lane; i < take; i += 64) cands[count + i] = tc[i];
+            count += take;
+            state = __shfl(mine.state_out, j);
+            dip_begin = __shfl(mine.dip_begin_out, j);
         }
     }
     if (lane == 0) a.counts[st] = count;
@@ -330,9 +410,15 @@ hipError_t launch_prs_sync(const SyncTables &t, const float2 *iq, size_t frame_s
     return hipGetLastError();
 }
 
+static size_t dip_segments(int64_t nb) { return size_t((nb + SEG_BLOCKS - 1) / SEG_BLOCKS); }
+static size_t al256(size_t v) { return (v + 255) & ~size_t(255); }
+
+// scratch layout: block norms | candidates | stream means | segment records | segment candidates
 size_t acquire_scratch_bytes(int n_streams, int64_t n_samples, int max_out) {
-    const size_t nb = size_t(n_samples / 64);
-    return ((size_t(n_streams) * nb * sizeof(float) + 255) & ~size_t(255)) + size_t(n_streams) * max_out * sizeof(int64_t);
+    const size_t nb = size_t(n_samples / 64), n_seg = dip_segments(int64_t(nb));
+    return al256(size_t(n_streams) * nb * sizeof(float)) + al256(size_t(n_streams) * max_out * sizeof(int64_t)) +
+           al256(size_t(n_streams) * sizeof(float)) + al256(size_t(n_streams) * n_seg * sizeof(DipSegment)) +
+           size_t(n_streams) * n_seg * max_out * sizeof(int64_t);
 }
 
 hipError_t launch_acquire(const SyncTables &t, const AcquireArgs &a, hipStream_t s) {
@@ -341,7 +427,18 @@ hipError_t launch_acquire(const SyncTables &t, const AcquireArgs &a, hipStream_t
     if (nb <= 0 || a.max_coarse < 0 || a.max_coarse > 1023) return hipErrorInvalidValue;
     const unsigned gx = unsigned(std::min<int64_t>((nb / 2 + 3) / 4 + 1, 4096));
     hipLaunchKernelGGL(null_l1_kernel, dim3(gx, unsigned(a.n_streams)), dim3(256), 0, s, a.iq, a.stream_stride, nb, a.l1);
-    hipLaunchKernelGGL(null_dip_kernel, dim3(unsigned(a.n_streams)), dim3(64), 0, s, a, nb);
+    // the rest of the scratch buffer follows the candidate lists (acquire_scratch_bytes)
+    const int n_seg = int(dip_segments(nb));
+    char *p = reinterpret_cast<char *>(a.cands) + al256(size_t(a.n_streams) * a.max_out * sizeof(int64_t));
+    float *avg = reinterpret_cast<float *>(p);
+    p += al256(size_t(a.n_streams) * sizeof(float));
+    DipSegment *segs = reinterpret_cast<DipSegment *>(p);
+    p += al256(size_t(a.n_streams) * n_seg * sizeof(DipSegment));
+    int64_t *seg_cands = reinterpret_cast<int64_t *>(p);
+    hipLaunchKernelGGL(null_mean_kernel, dim3(unsigned(a.n_streams)), dim3(MEAN_THREADS), 0, s, a.l1, nb, avg);
+    hipLaunchKernelGGL(null_segment_kernel, dim3(unsigned(n_seg), unsigned(a.n_streams)), dim3(64), 0, s, a, nb, n_seg, avg, segs,
+                       seg_cands);
+    hipLaunchKernelGGL(null_stitch_kernel, dim3(unsigned(a.n_streams)), dim3(64), 0, s, a, n_seg, segs, seg_cands);
     hipLaunchKernelGGL(prs_sync_kernel<true>, dim3(unsigned(a.n_streams) * unsigned(a.max_out)), dim3(WG), 0, s, t,
                        static_cast<const float2 *>(nullptr), size_t(0), static_cast<const float *>(nullptr), 0,
                        static_cast<SyncResult *>(nullptr), a);

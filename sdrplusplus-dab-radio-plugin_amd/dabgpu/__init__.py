@@ -37,7 +37,7 @@ EXPORTS = [
     "dabgpu_ofdm_set_soft_selection", "dabgpu_soft_selection", "dabgpu_uep_subchannel",
     "dabgpu_host_alloc", "dabgpu_host_free", "dabgpu_decode_frames_dev", "dabgpu_decode_frames",
     "dabgpu_streams_reset", "dabgpu_stream_states", "dabgpu_set_stream_offsets", "dabgpu_ofdm_demod_streams_dev",
-    "dabgpu_ofdm_demod_streams", "dabgpu_get_stats",
+    "dabgpu_ofdm_demod_streams", "dabgpu_get_stats", "dabgpu_mean_kernel_ms",
 ]
 
 ABI_VERSION = 2
@@ -186,6 +186,7 @@ def lib():
         L.dabgpu_acquire.argtypes = [vp, vp, sz, i, C.c_int64, C.POINTER(AcquireCfg), i, vp, vp]
         L.dabgpu_ofdm_demod_acquired_dev.argtypes = [vp, vp, sz, i, i, vp, vp, vp, vp, vp]
         L.dabgpu_last_kernel_ms.argtypes = [vp, i, C.POINTER(C.c_float)]
+        L.dabgpu_mean_kernel_ms.argtypes = [vp, i, C.POINTER(C.c_float), C.POINTER(C.c_int)]
         L.dabgpu_get_prs_reference.argtypes = [i, vp, i]
         L.dabgpu_get_mapper_reference.argtypes = [vp, i, i]
         _LIB = L
@@ -313,6 +314,12 @@ class Context:
         ms = C.c_float(0)
         _check(lib().dabgpu_last_kernel_ms(self._h, which, C.byref(ms)), "dabgpu_last_kernel_ms")
         return ms.value
+
+    def mean_kernel_ms(self, which):
+        """(mean ms, launches) of kernel family `which` since set_timing(True) (at most the last 32 launches)."""
+        ms, n = C.c_float(0), C.c_int(0)
+        _check(lib().dabgpu_mean_kernel_ms(self._h, which, C.byref(ms), C.byref(n)), "dabgpu_mean_kernel_ms")
+        return ms.value, n.value
 
     # ---- closed-loop stream call
     def streams_reset(self, n_streams):
@@ -487,6 +494,11 @@ class Context:
                               stream=None):
         _check(lib().dabgpu_ofdm_demod_frames_dev(self._h, d_iq, frame_stride, n_frames, d_freq_offset, d_soft,
                                                   d_cyc, d_dqpsk, stream), "dabgpu_ofdm_demod_frames_dev")
+
+    def sync_prs_dev(self, d_iq, frame_stride, n_frames, d_freq_offset, max_coarse, d_out, stream=None):
+        """d_out: [n_frames] dabgpu_sync_result (4 x 32 bit: coarse_carriers, time_offset, peak_to_mean, coarse ptm)."""
+        _check(lib().dabgpu_sync_prs_dev(self._h, d_iq, frame_stride, n_frames, d_freq_offset, max_coarse, d_out, stream),
+               "dabgpu_sync_prs_dev")
 
     def fft_symbols_dev(self, d_iq, frame_stride, n_frames, d_freq_offset, d_spectra, stream=None):
         _check(lib().dabgpu_fft_symbols_dev(self._h, d_iq, frame_stride, n_frames, d_freq_offset, d_spectra, stream),

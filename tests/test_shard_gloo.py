@@ -51,3 +51,47 @@ def test_two_rank_sharding_and_report():
 def test_single_process_report_passthrough():
     assert reduce_report(None, None, 0.5, 10, [True]) == (0.5, 10, [True])
     assert ensembles_of_rank(10, 4, 3) == [3, 7]
+
+
+import json
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run_bench(nproc, extra_env=None):
+    env = dict(os.environ)
+    env.update(extra_env or {})
+    args = ["--ensembles", "4", "--frames", "16", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--no-fft-stage",
+            "--no-selective", "--no-closed-loop"]
+    if nproc == 1:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
+               "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc)] + args
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                  # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_execute_end_to_end():
+    """The N>1 path of bench.py as the driver launches it -- torch.distributed.run, one process per rank, started as
+    a fresh child before anything in it touches the GPU -- with two ranks sharing the one GPU of the test box (gloo
+    carries the barrier and the three scalar reductions there; on a multi-GPU node the same code runs over RCCL).
+    Both ranks shard the global ensemble list, decode their own streams bit-exactly, and rank 0 reports the sum."""
+    one = _run_bench(1)
+    two = _run_bench(2, {"DABGPU_DIST_BACKEND": "gloo"})
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    for r in (one, two):
+        assert r["fic_bit_exact"] is True and r["msc_bit_exact"] is True and r["scaling"] == "weak"
+        assert r["config"]["frames_per_step_per_gpu"] == 64
+    # whole-job value: both ranks' frames over the slowest rank's time
+    frames_two = two["value"] * two["ms_per_step"] * 1e-3
+    frames_one = one["value"] * one["ms_per_step"] * 1e-3
+    assert abs(frames_one - 64) < 1e-6 * 64 and abs(frames_two - 128) < 1e-6 * 128

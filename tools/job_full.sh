@@ -1,0 +1,15 @@
+#!/bin/bash
+# GPU job: default bench line, rocprofv3 kernel stats, HBM traffic PMC passes, SQ PMC passes  (tag = $1)
+tag=${1:-r02}
+root=${GRAFT_REPO_ROOT:-$(pwd)}
+o=$root/gpurun_out/$tag; mkdir -p $o
+cd $root
+python3 bench.py > $o/bench.json 2> $o/bench.err
+tail -c 4000 $o/bench.json
+tools/prof.sh $tag --cpu-seconds 0 > $o/prof.log 2>&1
+cp gpurun_out/${tag}_kernel_stats.csv $o/kernel_stats.csv
+tools/pmc_traffic.sh 16384 > $o/pmc_traffic.log 2>&1
+cp gpurun_out/pmc_traffic.json $o/pmc_traffic.json
+tools/pmc_ofdm.sh $tag > $o/pmc_ofdm.log 2>&1
+cp gpurun_out/pmc_ofdm_$tag/summary.md $o/pmc_ofdm_summary.md
+cat $o/kernel_stats.csv; cat $o/pmc_traffic.json | tail -8
