@@ -531,6 +531,79 @@ def fig0_2(services):
     return fig0(2, body)
 
 
+def fig0_5(entries):
+    """Service component language, short form: [(subchannel_id, language), ...] (clause 8.1.2)."""
+    return fig0(5, b"".join(_bits((0, 1), (0, 1), (scid, 6), (lang, 8)) for scid, lang in entries))
+
+
+def fig0_6(lsn, ids, idlq=0, active=1, hard=1, ils=0, pd=0):
+    """Service linking (clause 8.1.15): one linkage set with an id list.  idlq 0 = DAB SIds, 1 = RDS PI codes,
+    3 = DRM service ids; ils = 1: every id is (ECC, id) given as a 24-bit number; pd = 1: 32-bit SIds."""
+    width = 32 if pd else (24 if ils else 16)
+    body = _bits((1, 1), (active, 1), (hard, 1), (ils, 1), (lsn, 12), (0, 1), (idlq, 2), (0, 1), (len(ids), 4))
+    body += b"".join(_bits((i, width)) for i in ids)
+    return fig0(6, body, pd=pd)
+
+
+def fig0_8(entries, pd=0):
+    """Service component global definition, short form: [(sid, scids, subchannel_id), ...] (clause 6.3.5)."""
+    w = 32 if pd else 16
+    return fig0(8, b"".join(_bits((sid, w), (0, 1), (0, 3), (scids, 4), (0, 1), (0, 1), (scid, 6)) for sid, scids, scid in entries), pd=pd)
+
+
+def fig0_9(ecc, lto_half_hours, inter_table=1):
+    """Country, LTO and international table (clause 8.1.3.2); lto in half hours, negative = west of UTC."""
+    return fig0(9, _bits((0, 1), (0, 1), (1 if lto_half_hours < 0 else 0, 1), (abs(lto_half_hours), 5), (ecc, 8), (inter_table, 8)))
+
+
+def fig0_17(entries):
+    """Programme type: [(sid, int_code, language or None), ...] (clause 8.1.5)."""
+    body = b""
+    for sid, code, lang in entries:
+        body += _bits((sid, 16), (0, 1), (0, 1), (0 if lang is None else 1, 1), (0, 1), (0, 4))
+        if lang is not None:
+            body += _bits((lang, 8))
+        body += _bits((0, 3), (code, 5))
+    return fig0(17, body)
+
+
+def fig0_21(entries, oe=0):
+    """Frequency information (clause 8.1.8), one block: entries [(id, rm, continuity, frequencies in Hz), ...] with
+    rm 0 = DAB ensemble (16 kHz steps), 8 = FM with RDS (87.5 MHz + 100 kHz steps), 6 = DRM (id is 24 bits, kHz)."""
+    blk = b""
+    for ident, rm, cont, freqs in entries:
+        if rm == 0:
+            fl = b"".join(_bits((0, 5), (f // 16000, 19)) for f in freqs)
+        elif rm == 8:
+            fl = bytes((f - 87500000) // 100000 for f in freqs)
+        else:
+            fl = bytes([ident >> 16]) + b"".join(_bits((0, 1), (f // 1000, 15)) for f in freqs)
+        assert len(fl) <= 7
+        blk += _bits((ident & 0xFFFF, 16), (rm, 4), (cont, 1), (len(fl), 3)) + fl
+    return fig0(21, _bits((0, 11), (len(blk), 5)) + blk, oe=oe)
+
+
+def fig0_24(entries, pd=0):
+    """Services in other ensembles: [(sid, [eid, ...]), ...] (clause 8.1.10.2)."""
+    w = 32 if pd else 16
+    return fig0(24, b"".join(_bits((sid, w), (0, 1), (0, 3), (len(eids), 4)) + b"".join(_bits((e, 16)) for e in eids)
+                             for sid, eids in entries), pd=pd, oe=1)
+
+
+def fig1_4(sid, scids, label, pd=0, charset=0):
+    """Service component label (clause 8.1.14.3)."""
+    text = label.encode("latin-1")[:16].ljust(16, b" ")
+    data = _bits((charset, 4), (0, 1), (4, 3), (pd, 1), (0, 3), (scids, 4), (sid, 32 if pd else 16)) + text + _bits((0xFF00, 16))
+    return _bits((1, 3), (len(data), 5)) + data
+
+
+def fig1_5(sid32, label, charset=0):
+    """Data service label: 32-bit service identifier (clause 8.1.14.2)."""
+    text = label.encode("latin-1")[:16].ljust(16, b" ")
+    data = _bits((charset, 4), (0, 1), (5, 3), (sid32, 32)) + text + _bits((0xFF00, 16))
+    return _bits((1, 3), (len(data), 5)) + data
+
+
 def mjd(year, month, day):
     """Modified Julian date of a calendar date (inverse of the standard's annex formula)."""
     a = (14 - month) // 12
@@ -620,6 +693,19 @@ class ServiceEnsemble:
                for (lab, sid, scid, *_rest) in self.dab_services]
         labels = [fig1(0, eid, label)] + [fig1(1, sid, lab) for (lab, sid, *_rest) in services]
         labels += [fig1(1, sid, lab) for (lab, sid, *_rest) in self.dab_services]
+        # what else a multiplex says about itself (one of these per CIF, in rotation with the labels): country and
+        # local time, component identifiers and labels, programme types, languages, a linkage set with its FM
+        # alternative and that station's frequencies, the neighbouring ensemble carrying the first service
+        all_sv = [(lab, sid, scid) for (lab, sid, scid, *_r) in services] + [(lab, sid, scid) for (lab, sid, scid, *_r) in self.dab_services]
+        first_sid = all_sv[0][1]
+        labels += [fig0_9(0xE1, 2, 1),
+                   fig0_8([(sid, 0, scid) for (_l, sid, scid) in all_sv[:5]]),
+                   fig0_17([(sid, 1 + k % 30, 0x09 if k == 0 else None) for k, (_l, sid, _s) in enumerate(all_sv[:5])]),
+                   fig0_5([(scid, 0x09 + k) for k, (_l, _sid, scid) in enumerate(all_sv[:8])]),
+                   fig0_6(0x123, [first_sid], idlq=0), fig0_6(0x123, [0xC479], idlq=1),
+                   fig0_21([(0xC479, 8, 1, [98300000, 101100000]), (0xC182, 0, 0, [225648000])]),
+                   fig0_24([(first_sid, [0xC182])])]
+        labels += [fig1_4(sid, 0, (lab + " main")[:16]) for (lab, sid, _s) in all_sv[:3]]
         self.fibs = np.zeros((n_frames, 12, 32), np.uint8)
         k = 0
         for f in range(n_frames):

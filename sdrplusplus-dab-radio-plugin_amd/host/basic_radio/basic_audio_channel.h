@@ -5,6 +5,7 @@
 #pragma once
 #include <cstdint>
 #include <string_view>
+#include "basic_radio/basic_slideshow.h"
 #include "dab/database/dab_database_entities.h"
 #include "utility/observable.h"
 #include "utility/span.h"
@@ -38,9 +39,12 @@ public:
     // programme-associated text needs the audio decoder's PAD extraction: never set here
     std::string_view GetDynamicLabel() const { return {}; }
     Basic_Audio_Controls &GetControls() { return m_controls; }
+    // slideshows come out of the audio decoder's PAD as well: always empty (render_radio_block.cpp:591)
+    Basic_Slideshow_Manager &GetSlideshowManager() { return m_slideshows; }
     Observable<BasicAudioParams, tcb::span<const uint8_t>> &OnAudioData() { return m_obs_audio; }
 
 protected:
     Basic_Audio_Controls m_controls;
+    Basic_Slideshow_Manager m_slideshows;
     Observable<BasicAudioParams, tcb::span<const uint8_t>> m_obs_audio;
 };

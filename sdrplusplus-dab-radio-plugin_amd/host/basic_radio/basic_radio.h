@@ -18,6 +18,7 @@
 #include "basic_radio/basic_audio_channel.h"
 #include "basic_radio/basic_dab_channel.h"
 #include "basic_radio/basic_dab_plus_channel.h"
+#include "basic_radio/basic_data_packet_channel.h"
 #include "dab/constants/dab_parameters.h"
 #include "dab/database/dab_database.h"
 #include "dab/database/dab_database_updater.h"
@@ -46,6 +47,8 @@ public:
         auto it = m_channels.find(id);
         return it == m_channels.end() ? nullptr : it->second.get();
     }
+    // packet-mode data sub-channels are not followed (render_radio_block.cpp:533): never a channel
+    Basic_Data_Packet_Channel *Get_Data_Packet_Channel(subchannel_id_t) { return nullptr; }
     // sub-channels listed in the FIC that cannot be decoded here (invalid profile, does not fit the CIF)
     int GetTotalUnsupportedSubchannels() const { return m_total_unsupported; }
     void SetAutoChannels(bool v) { m_auto_channels = v; }

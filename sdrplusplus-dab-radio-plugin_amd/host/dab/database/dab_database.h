@@ -9,6 +9,10 @@ struct DAB_Database {
     std::vector<Service> services;
     std::vector<ServiceComponent> service_components;
     std::vector<Subchannel> subchannels;
+    std::vector<LinkService> link_services;        // render_radio_block.cpp:601
+    std::vector<FM_Service> fm_services;           // :628
+    std::vector<DRM_Service> drm_services;         // :667
+    std::vector<OtherEnsemble> other_ensembles;
 };
 
 struct DAB_Database_Statistics {           // GetDatabaseStatistics(), render_radio_block.cpp:755

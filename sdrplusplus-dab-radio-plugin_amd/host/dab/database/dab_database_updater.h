@@ -47,11 +47,17 @@ public:
         changed();
         return m_db.subchannels.back();
     }
-    Service &GetService(uint32_t sid) {
+    Service *FindService(uint32_t sid) {
+        for (auto &s : m_db.services)
+            if (s.id.value == sid) return &s;
+        return nullptr;
+    }
+    Service &GetService(uint32_t sid, bool bits32 = false) {
         for (auto &s : m_db.services)
             if (s.id.value == sid) return s;
         m_db.services.emplace_back();
         m_db.services.back().id.value = sid;
+        m_db.services.back().id.type = bits32 ? ServiceIdType::BITS32 : ServiceIdType::BITS16;
         m_db.ensemble.nb_services = uint8_t(m_db.services.size());
         changed();
         return m_db.services.back();
@@ -68,6 +74,63 @@ public:
         changed();
         return c;
     }
+    // a value written once; a later different value is a conflict and is ignored
+    template <class T>
+    void set_once(T &dst, bool &has, const T &v) {
+        if (!has) { dst = v; has = true; changed(); }
+        else same(dst == v);
+    }
+    void SetCountryInfo(uint8_t ecc, int lto_tenths, uint8_t inter_table) {
+        Ensemble &e = m_db.ensemble;
+        if (!e.has_country_info) {
+            e.extended_country_code = ecc; e.local_time_offset = lto_tenths; e.international_table_id = inter_table;
+            e.has_country_info = true;
+            changed();
+        } else {
+            same(e.extended_country_code == ecc && e.local_time_offset == lto_tenths && e.international_table_id == inter_table);
+        }
+    }
+    LinkService &GetLinkService(lsn_t lsn, bool *is_new) {
+        for (auto &l : m_db.link_services)
+            if (l.id == lsn) { *is_new = false; return l; }
+        m_db.link_services.emplace_back();
+        m_db.link_services.back().id = lsn;
+        *is_new = true;
+        changed();
+        return m_db.link_services.back();
+    }
+    FM_Service &GetFMService(uint16_t pi) {
+        for (auto &f : m_db.fm_services)
+            if (f.RDS_PI_code == pi) return f;
+        m_db.fm_services.emplace_back();
+        m_db.fm_services.back().RDS_PI_code = pi;
+        changed();
+        return m_db.fm_services.back();
+    }
+    DRM_Service &GetDRMService(uint32_t code) {
+        for (auto &f : m_db.drm_services)
+            if (f.drm_code == code) return f;
+        m_db.drm_services.emplace_back();
+        m_db.drm_services.back().drm_code = code;
+        changed();
+        return m_db.drm_services.back();
+    }
+    OtherEnsemble &GetOtherEnsemble(uint16_t eid) {
+        for (auto &o : m_db.other_ensembles)
+            if (o.id == eid) return o;
+        m_db.other_ensembles.emplace_back();
+        m_db.other_ensembles.back().id = eid;
+        changed();
+        return m_db.other_ensembles.back();
+    }
+    template <class T>
+    void add_unique(std::vector<T> &v, T x) {
+        for (const T &y : v)
+            if (y == x) return;
+        if (v.size() < 64) { v.push_back(x); changed(); }      // a hostile FIC must not grow the lists without bound
+    }
+    void SetComponentLabel(ServiceComponent &c, const std::string &label) { set_string(c.label, label); }
+    std::vector<ServiceComponent> &Components() { return m_db.service_components; }
     void same(bool ok) { m_stats.nb_total++; if (!ok) m_stats.nb_conflicts++; }
     void changed() { m_stats.nb_total++; m_stats.nb_updates++; }
 

@@ -18,7 +18,9 @@
 #include <vector>
 
 #include "app_helpers/app_io_buffers.h"
+#include "dab/database/dab_database_text.h"
 #include "basic_radio/basic_radio.h"
+#include "dab/database/dab_database_text.h"
 #include "dab/constants/dab_parameters.h"
 #include "ofdm/dab_mapper_ref.h"
 #include "ofdm/dab_ofdm_params_ref.h"
@@ -118,22 +120,11 @@ int main(int argc, char **argv) {
         const auto &db = radio->GetDatabase();
         std::FILE *f = std::fopen((prefix + ".db").c_str(), "w");
         if (f) {
-            if (db.ensemble.cif_counter >= 0 || !db.ensemble.label.empty())
-                std::fprintf(f, "ensemble id=%04X label=[%s]\n", unsigned(db.ensemble.id.value), escape_label(db.ensemble.label).c_str());
+            // the multiplex as the FIC describes it (the date/time line is left out: it moves from frame to frame)
+            DAB_Misc_Info no_time;
+            print_database(f, db, no_time);
             auto subs = db.subchannels;
             std::sort(subs.begin(), subs.end(), [](const Subchannel &a, const Subchannel &b) { return a.id < b.id; });
-            for (const auto &sc : subs)
-                std::fprintf(f, "subchannel id=%d start=%d length=%d uep=%d uep_index=%d eep_type=%d eep_level=%d\n", sc.id,
-                             sc.start_address, sc.length, int(sc.is_uep), sc.uep_prot_index, int(sc.eep_type), sc.eep_prot_level);
-            auto svs = db.services;
-            std::sort(svs.begin(), svs.end(), [](const Service &a, const Service &b) { return a.id.value < b.id.value; });
-            for (const auto &sv : svs) {
-                std::fprintf(f, "service id=%04X label=[%s]\n", unsigned(sv.id.value), escape_label(sv.label).c_str());
-                for (const auto &c : db.service_components)
-                    if (c.service_id.value == sv.id.value)
-                        std::fprintf(f, "component service=%04X subchannel=%d tmid=%d ascty=%d primary=%d\n", unsigned(sv.id.value),
-                                     c.subchannel_id, int(c.transport_mode), int(c.audio_service_type), int(c.is_primary));
-            }
             for (const auto &sc : subs) {
                 if (auto *mp2 = dynamic_cast<Basic_DAB_Channel *>(radio->Get_Audio_Channel(sc.id))) {
                     const auto &ap = mp2->GetAudioParams();

@@ -3,6 +3,7 @@
 #include <cassert>
 #include <complex>
 #include <cstdio>
+#include <mutex>
 #include <numeric>
 #include <thread>
 #include <memory>
@@ -17,10 +18,31 @@
 #include "ofdm/dab_mapper_ref.h"
 #include "ofdm/dab_ofdm_params_ref.h"
 #include "ofdm/dab_prs_ref.h"
+#include "basic_radio/basic_data_packet_channel.h"
+#include "dab/constants/country_table.h"
+#include "dab/constants/language_table.h"
+#include "dab/constants/programme_type_table.h"
 #include "utility/observable.h"
 #include "utility/span.h"
 
 int main() {
+    {   // identifiers and the name tables behind the GUI's service / ensemble description
+        ServiceId s16, s32;
+        s16.value = 0xC221;
+        s32.value = 0xE0D12345; s32.type = ServiceIdType::BITS32;
+        assert(s16.get_country_code() == 0xC && s16.get_extended_country_code() == 0);
+        assert(s32.get_country_code() == 0xD && s32.get_extended_country_code() == 0xE0);
+        assert(GetCountryName(0xE1, 0xC) == "United Kingdom" && GetCountryName(0xE0, 0xD) == "Germany" &&
+               GetCountryName(0x12, 3) == "Unknown" && GetCountryName(0xF0, 3) == "Australia");
+        assert(GetLanguageName(0x09) == "English" && GetLanguageName(0x0F) == "French" && GetLanguageName(0x7F) == "Amharic" &&
+               GetLanguageName(0x45) == "Zulu" && GetLanguageName(0x56) == "Russian" && GetLanguageName(0x35) == "Unknown");
+        assert(GetProgrammeTypeName(1, 1).long_label == "News" && GetProgrammeTypeName(1, 24).short_label == "Jazz" &&
+               GetProgrammeTypeName(1, 29).long_label == "Documentary");
+        Subchannel sc;
+        Basic_Data_Packet_Channel ch(sc);
+        std::lock_guard<std::mutex> lock(ch.GetSlideshowManager().GetSlideshowsMutex());
+        assert(ch.GetSlideshowManager().GetSlideshows().empty());
+    }
     // span: mutable -> const conversion (dab_module.cpp passes span<complex<float>> to Process(span<const ...>))
     std::vector<std::complex<float>> v(8);
     tcb::span<std::complex<float>> m(v.data(), v.size());

@@ -47,7 +47,15 @@ def test_oracle_reads_back_what_the_multiplex_says(ensemble):
         assert (s["start_address"], s["length"], s["is_uep"], s["eep_type"], s["eep_prot_level"]) == (start, size, False, option, level - 1)
         sv = db.services[sid]
         assert sv["label"] == label
-        assert sv["components"] == [{"subchannel_id": scid, "transport_mode": 0, "audio_service_type": 63, "is_primary": True}]
+        (comp,) = sv["components"]
+        assert (comp["subchannel_id"], comp["transport_mode"], comp["audio_service_type"], comp["is_primary"]) == (scid, 0, 63, True)
+        assert comp["scids"] == 0 and comp["label"] == (label + " main")[:16] and comp["lang"] >= 0x09
+    # the rest of what the multiplex says about itself (FIG 0/9, 0/17, 0/6, 0/21, 0/24)
+    assert db.country == (0xE1, 10, 1)
+    assert [db.services[sid]["pty"] for (_l, sid, *_r) in SERVICES] == [1, 2, 3] and db.services[0xC221]["lang"] == 0x09
+    assert db.links == {0x123: {"active": 1, "hard": 1, "intl": 0, "service": 0xC221}}
+    assert db.fm == {0xC479: {"lsn": 0x123, "tc": True, "freqs": [98300000, 101100000]}}
+    assert db.other == {0xC182: {"cont": False, "freqs": [225648000], "services": [0xC221]}}
 
 
 def test_date_time_round_trip():
@@ -67,8 +75,8 @@ def test_host_parser_equals_oracle(parser_exe, ensemble, tmp_path):
     assert got[-1].startswith("datetime 2024-02-29 23:59:5")
     assert "fibs_bad_crc=0" in stats and "conflicts=0" in stats
     # FIBs damaged in transit must be ignored, not half-parsed
-    bad = fibs.copy()
-    bad[::7, 5] ^= 0x40                            # every FIG is repeated in later CIFs, so nothing is lost
+    bad = np.concatenate([fibs, fibs])             # the multiplex is cyclic: two rounds of it,
+    bad[::7, 5] ^= 0x40                            # no FIB damaged in both (60 FIBs per round, 60 % 7 != 0)
     got, stats = run_parser(parser_exe, bad, tmp_path)
     assert got == FO.parse_fibs(bad).lines() == FO.parse_fibs(fibs).lines()
     assert "fibs_bad_crc=%d" % len(bad[::7]) in stats
@@ -80,7 +88,7 @@ def test_host_parser_other_forms(parser_exe, tmp_path):
                           {"id": 5, "start": 100, "option": 3, "level": 1, "size": 12}]),       # reserved option: skipped
             synth.fig0(2, synth._bits((0xE0D12345, 32), (0, 1), (0, 3), (2, 4), (0, 2), (0, 6), (1, 6), (1, 1), (0, 1),
                                       (1, 2), (5, 6), (62, 6), (0, 1), (0, 1)), pd=1),           # 32-bit SId; one data component
-            synth.fig0(9, bytes([0x12, 0x34, 0x56])),                                            # unknown extension: skipped
+            synth.fig0(9, bytes([0x12, 0x34, 0x56])), synth.fig0(13, bytes([0x12, 0x34, 0x56])),   # 0/13: not followed, skipped
             synth.fig1(1, 0x1234, "Short"), synth.fig1(5, 0x1234, "Other kind")]
     fibs = synth.pack_fibs(figs)
     got, _ = run_parser(parser_exe, fibs, tmp_path)
@@ -89,9 +97,59 @@ def test_host_parser_other_forms(parser_exe, tmp_path):
     assert "subchannel id=1 start=0 length=0 uep=1 uep_index=37 eep_type=0 eep_level=0" in got
     assert "subchannel id=62 start=700 length=90 uep=0 uep_index=0 eep_type=1 eep_level=3" in got
     assert not any(l.startswith("subchannel id=5 ") for l in got)
-    assert "component service=E0D12345 subchannel=1 tmid=0 ascty=0 primary=1" in got
+    assert "component service=E0D12345 subchannel=1 tmid=0 ascty=0 primary=1 scids=-1 lang=0 label=[]" in got
     assert sum(l.startswith("component") for l in got) == 1
-    assert "service id=1234 label=[Short]" in got
+    assert "service id=1234 label=[Short] pty=-1 lang=0 bits32=0" in got
+    assert "service id=E0D12345 label=[] pty=-1 lang=0 bits32=1" in got
+    assert "ensemble_info ecc=34 lto=90 inter_table=86" in got         # the FIG 0/9 above: 0x12 = +18 half hours
+
+
+def test_host_parser_linking_and_frequency_forms(parser_exe, tmp_path):
+    """Every form of the FIGs behind the GUI's service / linked-services / component tabs, including the ones the
+    synthetic multiplex does not use: international and 32-bit id lists, DRM, a status-only linking entry, FIG 0/8
+    long form and extension byte, FIG 0/17 with language and complementary code, labels that arrive too early."""
+    S = synth
+    figs = [S.fig0_0(0xE1C5, 17),
+            S.fig1_4(0xC221, 2, "too early"),                                     # no FIG 0/8 yet: dropped
+            S.fig0_2([{"sid": 0xC221, "components": [{"subchannel": 3, "ascty": 63}, {"subchannel": 4, "ascty": 0, "primary": False}]}]),
+            S.fig0(2, S._bits((0xE0D12345, 32), (0, 1), (0, 3), (1, 4), (0, 2), (63, 6), (9, 6), (1, 1), (0, 1)), pd=1),
+            S.fig0_8([(0xC221, 0, 3), (0xC221, 2, 4)]),
+            S.fig0(8, S._bits((0xC221, 16), (1, 1), (0, 3), (5, 4), (1, 1), (0, 3), (0x123, 12), (0, 8))),   # long form + ext: skipped
+            S.fig0_8([(0xE0D12345, 1, 9)], pd=1),
+            S.fig1_4(0xC221, 2, "Second audio"), S.fig1_4(0xE0D12345, 1, "Data comp", pd=1), S.fig1_5(0xE0D12345, "Data service"),
+            S.fig1_5(0xE0D99999, "unknown service"),                               # not announced by FIG 0/2: dropped
+            S.fig0_9(0xE2, -7, 2),
+            S.fig0_17([(0xC221, 14, 0x0F), (0xBEEF, 3, None)]),                    # second service unknown: dropped
+            S.fig0(17, S._bits((0xC221, 16), (0, 1), (0, 1), (0, 1), (1, 1), (0, 4), (0, 3), (9, 5), (0, 3), (20, 5))),  # conflict + CC
+            S.fig0_5([(3, 0x08), (4, 0x1D), (50, 0x22)]),
+            S.fig0(5, S._bits((1, 1), (0, 3), (0x456, 12), (0x11, 8))),             # long form: skipped
+            S.fig0_6(0x0AB, [0xC221, 0xC222], idlq=0), S.fig0_6(0x0AB, [0xD311, 0xD312], idlq=1),
+            S.fig0_6(0x0AC, [0xE1C221, 0xE2D123], idlq=3, ils=1, hard=0), S.fig0_6(0x0AD, [0xE0D12345], pd=1, active=0),
+            S.fig0(6, S._bits((0, 1), (1, 1), (0, 1), (0, 1), (0x0AE, 12))),        # status only
+            S.fig0_21([(0xD311, 8, 1, [87600000, 107900000]), (0xE1C5, 0, 1, [174928000, 239200000])]),
+            S.fig0_21([(0xE2D123, 6, 0, [6095000, 15120000]), (0xD311, 8, 0, [87600000, 99900000])]),
+            S.fig0_24([(0xC221, [0xE1C6, 0xE1C7])]), S.fig0_24([(0xE0D12345, [0xE1C6])], pd=1)]
+    fibs = S.pack_fibs(figs)
+    got, stats = run_parser(parser_exe, fibs, tmp_path)
+    assert got == FO.parse_fibs(fibs).lines()
+    for want in ("ensemble_info ecc=E2 lto=-35 inter_table=2",
+                 "service id=C221 label=[] pty=14 lang=15 bits32=0",
+                 "component service=C221 subchannel=3 tmid=0 ascty=63 primary=1 scids=0 lang=8 label=[]",
+                 "component service=C221 subchannel=4 tmid=0 ascty=0 primary=0 scids=2 lang=29 label=[Second audio]",
+                 "service id=E0D12345 label=[Data service] pty=-1 lang=0 bits32=1",
+                 "component service=E0D12345 subchannel=9 tmid=0 ascty=63 primary=1 scids=1 lang=0 label=[Data comp]",
+                 "link lsn=171 active=1 hard=1 intl=0 service=C221",
+                 "link lsn=172 active=1 hard=0 intl=1 service=none",
+                 "link lsn=173 active=0 hard=1 intl=0 service=E0D12345",
+                 "fm pi=D311 lsn=171 tc=1 freqs=87600000,107900000,99900000",
+                 "fm pi=D312 lsn=171 tc=0 freqs=",
+                 "drm code=E1C221 lsn=172 tc=0 freqs=",
+                 "drm code=E2D123 lsn=172 tc=0 freqs=6095000,15120000",
+                 "other_ensemble id=E1C5 cont=1 freqs=174928000,239200000 services=",
+                 "other_ensemble id=E1C6 cont=0 freqs= services=C221,E0D12345"):
+        assert want in got, want
+    assert not any("lsn=174" in l for l in got) and not any("BEEF" in l or "E0D99999" in l for l in got)
+    assert "conflicts=1" in stats
 
 
 def test_host_parser_fuzz(parser_exe, tmp_path):
@@ -102,6 +160,14 @@ def test_host_parser_fuzz(parser_exe, tmp_path):
     # make FIG headers plausible more often: type 0/1 with assorted lengths at the start of the FIB
     fibs[:1500, 0] = rng.choice(np.array([0x05, 0x0D, 0x1D, 0x35, 0x15, 0x3F, 0x03], np.uint8), 1500)
     fibs[:1500, 1] &= 0x27
+    # ... and the extensions behind the linking / component / programme-type entities: 0/5 0/6 0/8 0/9 0/17 0/21 0/24
+    ext = rng.choice(np.array([5, 6, 8, 9, 17, 21, 24], np.uint8), 1200)
+    fibs[1500:2700, 0] = rng.choice(np.array([0x09, 0x12, 0x1D, 0x1C], np.uint8), 1200)
+    fibs[1500:2700, 1] = (fibs[1500:2700, 1] & 0x20) | ext
+    fibs[1500:2700, 2:6] &= rng.choice(np.array([0xFF, 0x0F, 0xC3], np.uint8), (1200, 4))   # small ids collide more often
+    fibs[2700:2900, 0] = 0x20 | rng.choice(np.array([22, 24, 25, 21], np.uint8), 200)      # FIG 1 with assorted lengths
+    fibs[2700:2900, 1] = (fibs[2700:2900, 1] & 0xF0) | rng.choice(np.array([0, 1, 4, 5], np.uint8), 200)
+    fibs[2700:2900, 2:7] &= 0x83
     for f in fibs:
         c = synth.crc16(f[:30])
         f[30], f[31] = c >> 8, c & 0xFF
@@ -190,8 +256,8 @@ def test_dab_layer2_service_on_uep_subchannel(built, tmp_path):
     assert r.returncode == 0 and "frames_desync=0" in r.stdout, r.stdout + r.stderr
     db = open(prefix + ".db").read().splitlines()
     assert "subchannel id=11 start=100 length=58 uep=1 uep_index=17 eep_type=0 eep_level=0" in db   # size from the table
-    assert "service id=C332 label=[Classic]" in db
-    assert "component service=C332 subchannel=11 tmid=0 ascty=0 primary=1" in db
+    assert any(l.startswith("service id=C332 label=[Classic] ") for l in db)
+    assert any(l.startswith("component service=C332 subchannel=11 tmid=0 ascty=0 primary=1 ") for l in db)
     mp2 = [l for l in db if l.startswith("channel subchannel=11")]
     assert len(mp2) == 1 and "header_errors=0" in mp2[0] and "rate=48000 stereo=1" in mp2[0]
     raw = np.fromfile(prefix + ".aus", np.uint8)
