@@ -412,6 +412,14 @@ int dabgpu_decode_frames(dabgpu_ctx *ctx, const int8_t *soft, size_t soft_stride
                          uint8_t *fib, uint8_t *crc_ok, const dabgpu_subchannel *sc, int n_subchannels,
                          const int8_t *const *history_in, int8_t *const *history_out, uint8_t *const *out);
 
+/* The same for ONE stream fed frame after frame, as the plugin does: the time de-interleaver state of every listed
+ * sub-channel stays on the device between calls (keyed by start address and size; a sub-channel seen for the first
+ * time starts from erasures), so a call is one upload of the soft bits, the decode, one download of all results.
+ * dabgpu_decode_stream_reset drops the kept state (Radio_Block::reset_radio). */
+int dabgpu_decode_stream_frames(dabgpu_ctx *ctx, const int8_t *soft, size_t soft_stride, int n_frames, uint8_t *fib,
+                                uint8_t *crc_ok, const dabgpu_subchannel *sc, int n_subchannels, uint8_t *const *out);
+int dabgpu_decode_stream_reset(dabgpu_ctx *ctx);
+
 /* ------------------------------------------------------------------------ */
 /* DAB+ audio super-frame: Fire code, RS(120,110), AU CRC.    */
 /* Replaces the checks the reference reports as the "Firecode / RS / AU"       */

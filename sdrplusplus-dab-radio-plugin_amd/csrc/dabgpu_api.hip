@@ -77,6 +77,16 @@ struct dabgpu_ctx {
     dabk::StreamState *d_states = nullptr;               // per-stream tracking state (dabgpu_streams_reset)
     int n_states = 0;
     float thr_null_start = 0.35f;        // desync threshold of the stream call (null_l1_search.thresh_null_start)
+    // dabgpu_decode_stream_frames: de-interleaver rings of the stream's sub-channels, kept on the device between calls
+    struct SubHistory {
+        int start_address, length;
+        size_t bytes;
+        int8_t *ring[2];
+        int cur;
+    };
+    std::vector<SubHistory> sub_history;
+    void *h_bounce = nullptr;            // page-locked landing area of that call's single download
+    size_t h_bounce_bytes = 0;
 };
 
 namespace {
@@ -414,6 +424,8 @@ void dabgpu_destroy(dabgpu_ctx *ctx) {
     DeviceGuard guard(ctx);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->d_states) (void)hipFree(ctx->d_states);
+    for (auto &h : ctx->sub_history) { (void)hipFree(h.ring[0]); (void)hipFree(h.ring[1]); }
+    if (ctx->h_bounce) (void)hipHostFree(ctx->h_bounce);
     if (ctx->d_twiddle) (void)hipFree(ctx->d_twiddle);
     if (ctx->d_bin_of_n) (void)hipFree(ctx->d_bin_of_n);
     if (ctx->d_n_of_vj) (void)hipFree(ctx->d_n_of_vj);
@@ -637,6 +649,8 @@ int dabgpu_streams_reset(dabgpu_ctx *ctx, int n_streams) {
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (n_streams > ctx->n_states) {
         if (ctx->d_states) (void)hipFree(ctx->d_states);
+    for (auto &h : ctx->sub_history) { (void)hipFree(h.ring[0]); (void)hipFree(h.ring[1]); }
+    if (ctx->h_bounce) (void)hipHostFree(ctx->h_bounce);
         ctx->d_states = nullptr;
         ctx->n_states = 0;
         if (hipMalloc(reinterpret_cast<void **>(&ctx->d_states), sizeof(dabk::StreamState) * size_t(n_streams)) != hipSuccess)
@@ -1160,6 +1174,52 @@ static int decode_grouped(dabgpu_ctx *ctx, uint8_t *d_fib, uint8_t *d_crc_ok, co
     return 0;
 }
 
+// Sub-channels that do not go through the grouped lane launch.  Small batches (each sub-channel below the lane
+// kernels' threshold: the plugin's one frame at a time) go through ONE launch of the wave-per-codeword kernel and one
+// for the history rings; anything else is decoded sub-channel by sub-channel.
+static int decode_subchannels(dabgpu_ctx *ctx, const dabgpu_subchannel *sc, int n_subchannels, const int8_t *d_soft,
+                              size_t soft_stride, int n_streams, int frames_per_stream, const int8_t *const *d_history_in,
+                              int8_t *const *d_history_out, uint8_t *const *d_out, void *stream) {
+    const long cw_each = long(n_streams) * frames_per_stream * NB_CIFS;
+    bool group = n_subchannels >= 2 && ctx->lane_mode <= 0 && (ctx->lane_mode == 0 || cw_each < LANE_MIN_CODEWORDS) &&
+                 d_soft && n_streams > 0 && frames_per_stream > 0;
+    std::vector<dabk::WaveGroupItem> items;
+    for (int i = 0; group && i < n_subchannels; i++) {
+        dab::PunctureProfile prof;
+        int rc = subchannel_profile(&sc[i], prof);
+        if (rc) return rc;
+        if (!dabk::wave_group_supported(prof.nsteps)) { group = false; break; }
+        DeviceCode *dc = nullptr;
+        if ((rc = get_code(ctx, std::move(prof), &dc))) return rc;
+        dabk::WaveGroupItem it{};
+        it.code = dc->tables(true);
+        it.args.soft = d_soft;
+        it.args.soft_stride = soft_stride;
+        it.args.n_streams = n_streams;
+        it.args.frames_per_stream = frames_per_stream;
+        it.args.start_bit = sc[i].start_address * CU_BITS;
+        it.args.nbits = sc[i].length * CU_BITS;
+        it.args.hist_in = d_history_in ? d_history_in[i] : nullptr;
+        it.args.hist_out = d_history_out ? d_history_out[i] : nullptr;
+        it.args.out = d_out[i];
+        if (it.args.hist_in && it.args.hist_in == it.args.hist_out) return DABGPU_ERR_ARG;
+        items.push_back(it);
+    }
+    if (group) {
+        hipStream_t s = pick_stream(ctx, stream);
+        ScopedTimer tm(ctx, 2, s);
+        HIP_TRY(dabk::launch_msc_decode_group(items.data(), int(items.size()), s));
+        return DABGPU_OK;
+    }
+    for (int i = 0; i < n_subchannels; i++) {
+        const int rc = dabgpu_msc_decode_dev(ctx, &sc[i], d_soft, soft_stride, n_streams, frames_per_stream,
+                                             d_history_in ? d_history_in[i] : nullptr,
+                                             d_history_out ? d_history_out[i] : nullptr, d_out[i], stream);
+        if (rc) return rc;
+    }
+    return DABGPU_OK;
+}
+
 int dabgpu_msc_decode_multi_dev(dabgpu_ctx *ctx, const dabgpu_subchannel *sc, int n_subchannels,
                                 const int8_t *d_soft, size_t soft_stride, int n_streams, int frames_per_stream,
                                 const int8_t *const *d_history_in, int8_t *const *d_history_out,
@@ -1183,13 +1243,8 @@ int dabgpu_msc_decode_multi_dev(dabgpu_ctx *ctx, const dabgpu_subchannel *sc, in
                                      frames_per_stream, d_history_in, d_history_out, d_out, stream);
         if (g <= 0) return g;                                  // done (0) or a real error (< 0); 1 = not applicable
     }
-    for (int i = 0; i < n_subchannels; i++) {
-        const int rc = dabgpu_msc_decode_dev(ctx, &sc[i], d_soft, soft_stride, n_streams, frames_per_stream,
-                                             d_history_in ? d_history_in[i] : nullptr,
-                                             d_history_out ? d_history_out[i] : nullptr, d_out[i], stream);
-        if (rc) return rc;
-    }
-    return DABGPU_OK;
+    return decode_subchannels(ctx, sc, n_subchannels, d_soft, soft_stride, n_streams, frames_per_stream, d_history_in,
+                              d_history_out, d_out, stream);
 }
 
 int dabgpu_decode_frames_dev(dabgpu_ctx *ctx, const int8_t *d_soft, size_t soft_stride, int n_streams,
@@ -1215,15 +1270,10 @@ int dabgpu_decode_frames_dev(dabgpu_ctx *ctx, const int8_t *d_soft, size_t soft_
     const int g = decode_grouped(ctx, d_fib, d_crc_ok, sc, n_subchannels, d_soft, soft_stride, n_streams, frames_per_stream,
                                  d_history_in, d_history_out, d_out, stream);
     if (g <= 0) return g;
-    int rc = dabgpu_fic_decode_dev(ctx, d_soft, soft_stride, n_streams * frames_per_stream, d_fib, d_crc_ok, stream);
+    const int rc = dabgpu_fic_decode_dev(ctx, d_soft, soft_stride, n_streams * frames_per_stream, d_fib, d_crc_ok, stream);
     if (rc) return rc;
-    for (int i = 0; i < n_subchannels; i++) {
-        rc = dabgpu_msc_decode_dev(ctx, &sc[i], d_soft, soft_stride, n_streams, frames_per_stream,
-                                   d_history_in ? d_history_in[i] : nullptr, d_history_out ? d_history_out[i] : nullptr,
-                                   d_out[i], stream);
-        if (rc) return rc;
-    }
-    return DABGPU_OK;
+    return decode_subchannels(ctx, sc, n_subchannels, d_soft, soft_stride, n_streams, frames_per_stream, d_history_in,
+                              d_history_out, d_out, stream);
 }
 
 int dabgpu_decode_frames(dabgpu_ctx *ctx, const int8_t *soft, size_t soft_stride, int n_streams, int frames_per_stream,
@@ -1284,6 +1334,88 @@ int dabgpu_decode_frames(dabgpu_ctx *ctx, const int8_t *soft, size_t soft_stride
         if (p_ho[i]) HIP_TRY(hipMemcpyAsync(history_out[i], p_ho[i], hist_bytes[i], hipMemcpyDeviceToHost, s));
     }
     HIP_TRY(hipStreamSynchronize(s));                                                  // one synchronisation
+    return DABGPU_OK;
+}
+
+int dabgpu_decode_stream_reset(dabgpu_ctx *ctx) {
+    if (!ctx) return DABGPU_ERR_ARG;
+    DeviceGuard guard(ctx);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (auto &h : ctx->sub_history) { (void)hipFree(h.ring[0]); (void)hipFree(h.ring[1]); }
+    ctx->sub_history.clear();
+    return DABGPU_OK;
+}
+
+int dabgpu_decode_stream_frames(dabgpu_ctx *ctx, const int8_t *soft, size_t soft_stride, int n_frames, uint8_t *fib,
+                                uint8_t *crc_ok, const dabgpu_subchannel *sc, int n_subchannels, uint8_t *const *out) {
+    if (!ctx || !soft || !fib || !crc_ok || n_frames < 0 || n_subchannels < 0) return DABGPU_ERR_ARG;
+    DeviceGuard guard(ctx);
+    if (n_subchannels > 0 && (!sc || !out)) return DABGPU_ERR_ARG;
+    if (n_frames == 0) return DABGPU_OK;
+    if (soft_stride < size_t(NB_FRAME_BITS) && n_frames > 1) return DABGPU_ERR_ARG;
+    auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
+    const size_t nb_fib = size_t(n_frames) * NB_FIBS * 32, nb_crc = size_t(n_frames) * NB_FIBS;
+    std::vector<size_t> out_off(n_subchannels), out_bytes(n_subchannels);
+    size_t res_total = al(nb_fib) + al(nb_crc);
+    std::vector<const int8_t *> p_hi(n_subchannels, nullptr);
+    std::vector<int8_t *> p_ho(n_subchannels, nullptr);
+    std::vector<int> hist_index(n_subchannels, -1);
+    hipStream_t s = ctx->stream;
+    for (int i = 0; i < n_subchannels; i++) {
+        const int nbytes = dabgpu_subchannel_bytes(&sc[i]);
+        if (nbytes < 0) return nbytes;
+        if (!out[i]) return DABGPU_ERR_ARG;
+        out_off[i] = res_total;
+        out_bytes[i] = size_t(n_frames) * NB_CIFS * size_t(nbytes);
+        res_total += al(out_bytes[i]);
+        // the sub-channel's ring from the call before, or a new (erased) one
+        for (size_t k = 0; k < ctx->sub_history.size(); k++)
+            if (ctx->sub_history[k].start_address == sc[i].start_address && ctx->sub_history[k].length == sc[i].length) hist_index[i] = int(k);
+        if (hist_index[i] < 0) {
+            dabgpu_ctx::SubHistory h{};
+            h.start_address = sc[i].start_address;
+            h.length = sc[i].length;
+            h.bytes = size_t(15) * sc[i].length * CU_BITS;
+            if (hipMalloc(reinterpret_cast<void **>(&h.ring[0]), h.bytes) != hipSuccess) return DABGPU_ERR_NOMEM;
+            if (hipMalloc(reinterpret_cast<void **>(&h.ring[1]), h.bytes) != hipSuccess) { (void)hipFree(h.ring[0]); return DABGPU_ERR_NOMEM; }
+            HIP_TRY(hipMemsetAsync(h.ring[0], 0, h.bytes, s));
+            hist_index[i] = int(ctx->sub_history.size());
+            ctx->sub_history.push_back(h);
+        }
+        const dabgpu_ctx::SubHistory &h = ctx->sub_history[size_t(hist_index[i])];
+        p_hi[i] = h.ring[h.cur];
+        p_ho[i] = h.ring[h.cur ^ 1];
+    }
+    const size_t nb_soft = size_t(n_frames - 1) * soft_stride + NB_FRAME_BITS;
+    void *d_soft, *d_res;
+    int rc;
+    if ((rc = stage(ctx, 1, nb_soft, &d_soft))) return rc;
+    if ((rc = stage(ctx, 3, res_total, &d_res))) return rc;
+    if (ctx->h_bounce_bytes < res_total) {
+        if (ctx->h_bounce) (void)hipHostFree(ctx->h_bounce);
+        ctx->h_bounce = nullptr;
+        ctx->h_bounce_bytes = 0;
+        if (hipHostMalloc(&ctx->h_bounce, res_total, hipHostMallocDefault) != hipSuccess) return DABGPU_ERR_NOMEM;
+        ctx->h_bounce_bytes = res_total;
+    }
+    HIP_TRY(hipMemcpyAsync(d_soft, soft, nb_soft, hipMemcpyHostToDevice, s));            // one upload
+    char *res = static_cast<char *>(d_res);
+    std::vector<uint8_t *> p_out(n_subchannels, nullptr);
+    for (int i = 0; i < n_subchannels; i++) p_out[i] = reinterpret_cast<uint8_t *>(res + out_off[i]);
+    rc = dabgpu_decode_frames_dev(ctx, static_cast<const int8_t *>(d_soft), soft_stride, 1, n_frames,
+                                  reinterpret_cast<uint8_t *>(res), reinterpret_cast<uint8_t *>(res + al(nb_fib)), sc, n_subchannels,
+                                  n_subchannels ? p_hi.data() : nullptr, n_subchannels ? p_ho.data() : nullptr,
+                                  n_subchannels ? p_out.data() : nullptr, s);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(ctx->h_bounce, d_res, res_total, hipMemcpyDeviceToHost, s));     // one download
+    HIP_TRY(hipStreamSynchronize(s));                                                   // one synchronisation
+    const char *hb = static_cast<const char *>(ctx->h_bounce);
+    std::memcpy(fib, hb, nb_fib);
+    std::memcpy(crc_ok, hb + al(nb_fib), nb_crc);
+    for (int i = 0; i < n_subchannels; i++) {
+        std::memcpy(out[i], hb + out_off[i], out_bytes[i]);
+        ctx->sub_history[size_t(hist_index[i])].cur ^= 1;
+    }
     return DABGPU_OK;
 }
 

@@ -148,6 +148,15 @@ struct MscArgs {
     uint8_t *out;              // [n_streams][frames*4][(nsteps-6)/8]
 };
 hipError_t launch_msc_decode(const CodeTables &c, const MscArgs &a, hipStream_t s);
+// Small batches of a whole multiplex: every sub-channel's codewords in one launch of the wave-per-codeword kernel and
+// all history rings in a second one (instead of one pair of launches per sub-channel).  nsteps must pass
+// wave_group_supported() (every DAB profile does).
+struct WaveGroupItem {
+    CodeTables code;
+    MscArgs args;
+};
+bool wave_group_supported(int nsteps);
+hipError_t launch_msc_decode_group(const WaveGroupItem *items, int n, hipStream_t s);
 
 // ---- large-batch variant: one codeword per lane (viterbi_lane_kernels.hip) ----
 struct LaneScratch {

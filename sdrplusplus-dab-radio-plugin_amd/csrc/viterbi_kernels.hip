@@ -230,22 +230,17 @@ __device__ __forceinline__ void rot_step(const RotTables &T, int lane, int w, in
     asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(dec), "=s"(carry_out) : "v"(dec), "s"(m));
 }
 
+// One wavefront decodes codeword `cw` in its LDS slab (every wave of the workgroup must call it: it contains
+// workgroup barriers, none of them inside a loop whose trip count depends on the codeword).
 template <class Fetch, Tail TAIL>
-__global__ __launch_bounds__(WGV) void viterbi_rot_kernel(Fetch fetch, CodeTables code, int n_codewords,
-                                                          uint8_t *out, uint8_t *crc_ok, int lds_per_wave) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int cw_raw = __builtin_amdgcn_readfirstlane(blockIdx.x * int(blockDim.x >> 6) + wave);   // wave-uniform
-    const bool active = cw_raw < n_codewords;
-    const int cw = active ? cw_raw : n_codewords - 1;
+__device__ __forceinline__ void rot_decode(const Fetch &fetch, const CodeTables &code, int cw, bool active, uint8_t *out,
+                                           uint8_t *crc_ok, unsigned char *slab, int lane) {
     const int nsteps = code.nsteps;
     const int nchunks = (nsteps - 6) / 96;
 
     // Per-wave LDS slab.  The survivor words W grow from the bottom (256 B per 32 steps) while the depunctured
     // codeword is consumed from a region that starts half-way up W's final extent: a W row is only written after
     // the codeword bytes it overlaps have been read (4 B/step consumed vs 8 B/step produced, offset = |W|/2).
-    unsigned char *slab = smem + size_t(wave) * lds_per_wave;
     const int ngroups = (nsteps - 6) / 32 + 1;
     const int mother_off = ngroups * 128;
     const int mother_bytes = (4 * nsteps + 255) & ~255;
@@ -370,6 +365,47 @@ __global__ __launch_bounds__(WGV) void viterbi_rot_kernel(Fetch fetch, CodeTable
     }
 }
 
+template <class Fetch, Tail TAIL>
+__global__ __launch_bounds__(WGV) void viterbi_rot_kernel(Fetch fetch, CodeTables code, int n_codewords,
+                                                          uint8_t *out, uint8_t *crc_ok, int lds_per_wave) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int cw_raw = __builtin_amdgcn_readfirstlane(blockIdx.x * int(blockDim.x >> 6) + wave);   // wave-uniform
+    const bool active = cw_raw < n_codewords;
+    rot_decode<Fetch, TAIL>(fetch, code, active ? cw_raw : n_codewords - 1, active, out, crc_ok,
+                            smem + size_t(wave) * lds_per_wave, lane);
+}
+
+// Grouped launch for small batches (the plugin's one frame at a time): the codewords of several sub-channels, each
+// with its own profile and length, in ONE launch -- one wavefront (= one workgroup) per codeword, the entry table by
+// value in the kernel arguments.  A whole multiplex is then three launches (FIC, sub-channels, history rings)
+// instead of one pair per sub-channel queueing up behind each other on the stream.
+constexpr int WAVE_GROUP_MAX = 24;
+struct WaveEntry {
+    FetchMsc fetch;
+    CodeTables code;
+    uint8_t *out;
+    int first_cw;
+};
+struct WaveEntryPack {
+    int n;
+    WaveEntry e[WAVE_GROUP_MAX];
+};
+__global__ __launch_bounds__(64) void viterbi_rot_grouped_kernel(const WaveEntryPack pack) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int cw = blockIdx.x;
+    int k = 0;
+    while (k + 1 < pack.n && cw >= pack.e[k + 1].first_cw) k++;
+    const WaveEntry &en = pack.e[k];
+    rot_decode<FetchMsc, Tail::kBytes>(en.fetch, en.code, cw - en.first_cw, true, en.out, nullptr, smem, int(threadIdx.x));
+}
+
+struct HistoryPack {
+    int n;
+    MscArgs a[WAVE_GROUP_MAX];
+};
+
 inline size_t viterbi_rot_lds_bytes(int nsteps) {
     const size_t mother = (size_t(4) * nsteps + 255) & ~size_t(255);
     const size_t groups = size_t((nsteps - 6) / 32 + 1);
@@ -378,11 +414,10 @@ inline size_t viterbi_rot_lds_bytes(int nsteps) {
 }
 
 // history ring update: hist_out[s][h] = CIF (4F - 15 + h), h = 0..14
-__global__ void msc_history_kernel(MscArgs a) {
+__device__ __forceinline__ void msc_history_body(const MscArgs &a, size_t first, size_t step) {
     const int cifs = a.frames_per_stream * NB_CIFS;
     const size_t total = size_t(a.n_streams) * 15 * a.nbits;
-    for (size_t idx = size_t(blockIdx.x) * blockDim.x + threadIdx.x; idx < total;
-         idx += size_t(gridDim.x) * blockDim.x) {
+    for (size_t idx = first; idx < total; idx += step) {
         const int i = int(idx % a.nbits);
         const int h = int((idx / a.nbits) % 15);
         const int s = int(idx / (size_t(a.nbits) * 15));
@@ -396,6 +431,13 @@ __global__ void msc_history_kernel(MscArgs a) {
         }
         a.hist_out[idx] = v;
     }
+}
+__global__ void msc_history_kernel(MscArgs a) {
+    msc_history_body(a, size_t(blockIdx.x) * blockDim.x + threadIdx.x, size_t(gridDim.x) * blockDim.x);
+}
+__global__ void msc_history_grouped_kernel(const HistoryPack pack) {
+    const MscArgs &a = pack.a[blockIdx.y];
+    if (a.hist_out) msc_history_body(a, size_t(blockIdx.x) * blockDim.x + threadIdx.x, size_t(gridDim.x) * blockDim.x);
 }
 
 template <class Fetch, Tail TAIL>
@@ -433,8 +475,45 @@ hipError_t allow_full_lds() {
 
 }  // namespace
 
+bool wave_group_supported(int nsteps) {
+    return nsteps >= 102 && (nsteps - 6) % 96 == 0 && viterbi_rot_lds_bytes(nsteps) <= 160 * 1024;
+}
+
+hipError_t launch_msc_decode_group(const WaveGroupItem *items, int n, hipStream_t s) {
+    for (int i0 = 0; i0 < n; i0 += WAVE_GROUP_MAX) {
+        const int m = std::min(WAVE_GROUP_MAX, n - i0);
+        WaveEntryPack pack{};
+        HistoryPack hp{};
+        pack.n = hp.n = m;
+        int total = 0;
+        size_t lds = 0, hist_items = 0;
+        for (int i = 0; i < m; i++) {
+            const WaveGroupItem &it = items[i0 + i];
+            const MscArgs &a = it.args;
+            if (!wave_group_supported(it.code.nsteps)) return hipErrorInvalidValue;
+            pack.e[i].fetch = FetchMsc{a.soft, a.soft_stride, a.hist_in, a.frames_per_stream, a.start_bit, a.nbits};
+            pack.e[i].code = it.code;
+            pack.e[i].out = a.out;
+            pack.e[i].first_cw = total;
+            total += a.n_streams * a.frames_per_stream * NB_CIFS;
+            lds = std::max(lds, (viterbi_rot_lds_bytes(it.code.nsteps) + 255) & ~size_t(255));
+            hp.a[i] = a;
+            if (a.hist_out) hist_items = std::max(hist_items, size_t(a.n_streams) * 15 * a.nbits);
+        }
+        if (total <= 0) continue;
+        hipLaunchKernelGGL(viterbi_rot_grouped_kernel, dim3(unsigned(total)), dim3(64), lds, s, pack);
+        if (hist_items)
+            hipLaunchKernelGGL(msc_history_grouped_kernel, dim3(unsigned(std::min<size_t>((hist_items + 255) / 256, 256)), unsigned(m)),
+                               dim3(256), 0, s, hp);
+    }
+    return hipGetLastError();
+}
+
 hipError_t init_viterbi_kernel_attributes() {
-    hipError_t e = allow_full_lds<FetchFic, Tail::kFic>();
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_rot_grouped_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    e = allow_full_lds<FetchFic, Tail::kFic>();
     if (e == hipSuccess) e = allow_full_lds<FetchPlain, Tail::kBytes>();
     if (e == hipSuccess) e = allow_full_lds<FetchMsc, Tail::kBytes>();
     return e;

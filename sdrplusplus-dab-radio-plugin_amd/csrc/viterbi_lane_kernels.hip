@@ -399,8 +399,15 @@ __device__ __forceinline__ void lane_forward_fused_body(const Src &src, const in
 #pragma unroll
     for (int r = 0; r < 32; r++) M[r] = pack16(-LANE_INIT2, -LANE_INIT2);
     M[0] = pack16(0, -LANE_INIT2);
+    // The window is wave-private and one wave's DS operations execute in order; these fences (no instruction) keep the
+    // compiler from moving window reads across the stores that refill it.
+    auto window_fence = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
     fetch(0);
     stash();
+    window_fence();
     // Descriptors of the next six steps are fetched while the current six are worked on: with one wave per SIMD
     // nothing else would hide their latency.  They are deliberately NOT restrict-qualified: as scalar loads they
     // share the LDS counter (lgkmcnt) and every wait for them also drains the window reads (measured slower).
@@ -443,7 +450,11 @@ __device__ __forceinline__ void lane_forward_fused_body(const Src &src, const in
                 for (int r = 0; r < 32; r++) M[r] = pk_sub(M[r], ref);
             }
         }
-        if (more) stash();                                     // the wave's own LDS reads above are already issued
+        if (more) {                                            // the wave's own LDS reads above are already issued
+            window_fence();
+            stash();
+            window_fence();
+        }
     }
 }
 

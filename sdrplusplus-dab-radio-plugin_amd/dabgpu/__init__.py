@@ -37,7 +37,8 @@ EXPORTS = [
     "dabgpu_ofdm_set_soft_selection", "dabgpu_soft_selection", "dabgpu_uep_subchannel",
     "dabgpu_host_alloc", "dabgpu_host_free", "dabgpu_decode_frames_dev", "dabgpu_decode_frames",
     "dabgpu_streams_reset", "dabgpu_stream_states", "dabgpu_set_stream_offsets", "dabgpu_ofdm_demod_streams_dev",
-    "dabgpu_ofdm_demod_streams", "dabgpu_get_stats", "dabgpu_mean_kernel_ms",
+    "dabgpu_ofdm_demod_streams", "dabgpu_get_stats", "dabgpu_mean_kernel_ms", "dabgpu_decode_stream_frames",
+    "dabgpu_decode_stream_reset",
 ]
 
 ABI_VERSION = 2
@@ -164,6 +165,8 @@ def lib():
         L.dabgpu_msc_decode_multi_dev.argtypes = [vp, vp, i, vp, sz, i, i, vp, vp, vp, vp]
         L.dabgpu_decode_frames_dev.argtypes = [vp, vp, sz, i, i, vp, vp, vp, i, vp, vp, vp, vp]
         L.dabgpu_decode_frames.argtypes = [vp, vp, sz, i, i, vp, vp, vp, i, vp, vp, vp]
+        L.dabgpu_decode_stream_frames.argtypes = [vp, vp, sz, i, vp, vp, vp, i, vp]
+        L.dabgpu_decode_stream_reset.argtypes = [vp]
         L.dabgpu_streams_reset.argtypes = [vp, i]
         L.dabgpu_stream_states.restype = C.c_void_p
         L.dabgpu_stream_states.argtypes = [vp]
@@ -382,6 +385,27 @@ class Context:
         _check(lib().dabgpu_decode_frames(self._h, _p(soft), stride, n_streams, fps, _p(fib), _p(ok), arr, n, ptrs(his),
                                           ptrs(hos), ptrs(outs)), "dabgpu_decode_frames")
         return fib, ok, outs, (hos if want_history else None)
+
+    def decode_stream_frames(self, soft, scs):
+        """Consecutive frames of one stream; the de-interleaver state stays in the context.  -> fib, crc_ok, [out_i]"""
+        soft = np.ascontiguousarray(soft, np.int8)
+        n_frames, stride = soft.shape
+        n = len(scs)
+        arr = (Subchannel * max(n, 1))(*scs)
+        fib = np.zeros((n_frames, 12, 32), np.uint8)
+        ok = np.zeros((n_frames, 12), np.uint8)
+        outs = []
+        for sc in scs:
+            nb = lib().dabgpu_subchannel_bytes(C.byref(sc))
+            _check(min(nb, 0), "dabgpu_subchannel_bytes")
+            outs.append(np.zeros((1, n_frames * 4, nb), np.uint8))
+        ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in outs]) if n else None
+        _check(lib().dabgpu_decode_stream_frames(self._h, _p(soft), stride, n_frames, _p(fib), _p(ok), arr, n, ptrs),
+               "dabgpu_decode_stream_frames")
+        return fib, ok, outs
+
+    def decode_stream_reset(self):
+        _check(lib().dabgpu_decode_stream_reset(self._h), "dabgpu_decode_stream_reset")
 
     # ---- host arrays
     def ofdm_demod_frames(self, iq, freq_offset=None, want_cyc=False, want_dqpsk=False, soft=None):

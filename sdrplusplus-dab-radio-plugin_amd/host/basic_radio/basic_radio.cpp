@@ -31,7 +31,6 @@ int BasicRadio::add_subchannel_locked(const dabgpu_subchannel &sc) {
     Subchannel s;
     s.desc = sc;
     s.nbytes = nbytes;
-    for (auto &h : s.history) h.resize(size_t(15) * sc.length * 64);
     s.out.resize(size_t(m_params.nb_cifs) * nbytes);
     m_subchannels.push_back(std::move(s));
     return int(m_subchannels.size()) - 1;
@@ -44,20 +43,15 @@ void BasicRadio::Process(tcb::span<const viterbi_bit_t> buf) {
     // copy, FIBs / CRC flags / logical frames / de-interleaver state come back together
     const size_t n_sub = m_subchannels.size();
     m_call_sc.resize(n_sub);
-    m_call_hin.resize(n_sub);
-    m_call_hout.resize(n_sub);
     m_call_out.resize(n_sub);
     for (size_t i = 0; i < n_sub; i++) {
-        Subchannel &s = m_subchannels[i];
-        m_call_sc[i] = s.desc;
-        m_call_hin[i] = s.history[s.cur].data();
-        m_call_hout[i] = s.history[s.cur ^ 1].data();
-        m_call_out[i] = s.out.data();
+        m_call_sc[i] = m_subchannels[i].desc;
+        m_call_out[i] = m_subchannels[i].out.data();
     }
     std::memcpy(m_frame.data(), buf.data(), buf.size());
-    const int rc = dabgpu_decode_frames(m_ctx, m_frame.data(), m_frame.size(), 1, 1, m_fib.data(), m_crc.data(),
-                                        m_call_sc.data(), int(n_sub), m_call_hin.data(), m_call_hout.data(),
-                                        m_call_out.data());
+    // (the time de-interleaver state of every sub-channel stays on the device between frames)
+    const int rc = dabgpu_decode_stream_frames(m_ctx, m_frame.data(), m_frame.size(), 1, m_fib.data(), m_crc.data(),
+                                               m_call_sc.data(), int(n_sub), m_call_out.data());
     if (rc != DABGPU_OK) return;                                // no exceptions on the streaming path: the frame is lost
     for (uint8_t ok : m_crc) {
         m_total_fibs++;
@@ -69,7 +63,6 @@ void BasicRadio::Process(tcb::span<const viterbi_bit_t> buf) {
         if (m_crc[i]) m_fic_parser.ProcessFIB(tcb::span<const uint8_t>(m_fib.data() + 32 * i, 32));
     for (size_t i = 0; i < n_sub; i++) {
         Subchannel &s = m_subchannels[i];
-        s.cur ^= 1;
         for (int c = 0; c < m_params.nb_cifs; c++) {
             // the de-interleaver needs 16 CIFs before its first complete logical frame
             if (++s.cifs_seen < 16) continue;

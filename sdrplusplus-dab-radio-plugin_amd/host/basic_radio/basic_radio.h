@@ -3,8 +3,8 @@
 // (src/render_radio_block.cpp:124), On_Audio_Channel() (src/radio_block.cpp:62).
 //
 // Process splits a frame into FIC and MSC (row A7) and runs rows A8..A12 on the GPU through libdabgpu: the FIC and
-// every registered sub-channel in ONE dabgpu_decode_frames call per frame (one upload of the 230400 soft bits, one
-// synchronisation; results land in page-locked buffers).  A sub-channel the FIC announces in frame f is decoded from
+// every registered sub-channel in ONE dabgpu_decode_stream_frames call per frame (one upload of the 230400 soft bits,
+// three launches, one download, one synchronisation; the de-interleaver state never leaves the device).  A sub-channel the FIC announces in frame f is decoded from
 // frame f+1 on.  The FIBs go through the FIG
 // parser into the database; every audio component found there (DAB+ or DAB, EEP or UEP sub-channel)
 // gets its sub-channel decoded and a Basic_DAB_Plus_Channel (8f-3) / Basic_DAB_Channel without being asked (On_Audio_Channel fires once per
@@ -67,8 +67,6 @@ private:
     struct Subchannel {
         dabgpu_subchannel desc;
         int nbytes;
-        PinnedBuffer<int8_t> history[2];  // 15 CIFs of de-interleaver state, ping-pong
-        int cur = 0;
         int cifs_seen = 0;
         PinnedBuffer<uint8_t> out;
         Basic_DAB_Plus_Channel *dab_plus = nullptr;   // set for sub-channels opened from the database
@@ -83,8 +81,6 @@ private:
     PinnedBuffer<uint8_t> m_fib, m_crc;
     PinnedBuffer<viterbi_bit_t> m_frame;                 // the frame's soft bits, staged for the single upload
     std::vector<dabgpu_subchannel> m_call_sc;            // argument arrays of the per-frame call
-    std::vector<const int8_t *> m_call_hin;
-    std::vector<int8_t *> m_call_hout;
     std::vector<uint8_t *> m_call_out;
     int m_total_fibs = 0, m_total_fib_errors = 0;
     Observable<subchannel_id_t, Basic_Audio_Channel &> m_obs_audio_channel;

@@ -140,3 +140,30 @@ def test_host_decode_frames_equals_separate_calls(built, ensemble, ensemble_iq, 
     fib, ok, outs, _ = c.decode_frames(soft[:1], 1, [])
     assert ok.all() and outs == []
     c.close()
+
+
+def test_stream_decoder_keeps_the_deinterleaver_state(built, ensemble, ensemble_iq):
+    """dabgpu_decode_stream_frames: frames of one stream fed one at a time, history kept on the device -- the same
+    bytes as one dabgpu_decode_frames over all of them; a sub-channel joining later starts from erasures; reset
+    forgets everything."""
+    frames = _rx(ensemble_iq[:5], 16.0, 0.0)
+    c = make_ctx(None, 8)
+    soft, _, _ = c.ofdm_demod_frames(frames)
+    a, b = dabgpu.subchannel(ensemble.start_cu, 64, level=3), dabgpu.subchannel(ensemble.start_cu + 100, 32, level=2)
+    rfib, rok, routs, _ = c.decode_frames(soft, 1, [a, b])
+    outs_a, outs_b = [], []
+    for f in range(5):
+        scs = [a] if f < 2 else [a, b]                   # the second sub-channel is announced from frame 2 on
+        fib, ok, outs = c.decode_stream_frames(soft[f:f + 1], scs)
+        assert (fib == rfib[f:f + 1]).all() and (ok == rok[f:f + 1]).all()
+        outs_a.append(outs[0][0])
+        if f >= 2:
+            outs_b.append(outs[1][0])
+    assert (np.concatenate(outs_a) == routs[0][0]).all()
+    late, _, louts, _ = c.decode_frames(soft[2:], 1, [b])        # b as if the stream began at frame 2
+    assert (np.concatenate(outs_b) == louts[0][0]).all()
+    c.decode_stream_reset()
+    _, _, outs = c.decode_stream_frames(soft[4:5], [a])
+    fresh = c.decode_frames(soft[4:5], 1, [a])[2][0]
+    assert (outs[0] == fresh).all()
+    c.close()

@@ -13,3 +13,8 @@ cp gpurun_out/pmc_traffic.json $o/pmc_traffic.json
 tools/pmc_ofdm.sh $tag > $o/pmc_ofdm.log 2>&1
 cp gpurun_out/pmc_ofdm_$tag/summary.md $o/pmc_ofdm_summary.md
 cat $o/kernel_stats.csv; cat $o/pmc_traffic.json | tail -8
+python3 tools/frame_latency.py > $o/frame_latency.txt 2>&1
+python3 tools/pcie_rate.py 1 > $o/pcie_rate.txt 2>&1; python3 tools/pcie_rate.py 64 >> $o/pcie_rate.txt 2>&1
+python3 tools/ensemble_time.py > $o/ensemble_time.txt 2>&1
+python3 tools/ofdm_bound.py 16384 5 > $o/ofdm_bound.txt 2>&1
+tail -3 $o/frame_latency.txt $o/pcie_rate.txt $o/ensemble_time.txt; cat $o/ofdm_bound.txt
