@@ -19,7 +19,7 @@ static const char *NAMES[NPAT] = {
     "calib ds_write_b64 conflict-free (lane*8)", "calib ds_write_b64 2-way (lane*16)", "calib ds_write_b64 4-way (lane*32)",
     "ofdm exchange 1 (32 wr64 + 32 rd64)", "ofdm exchange 2 (32 wr64 + 32 rd64)", "ofdm step-1 twiddles, natural table (15 rd64)",
     "ofdm step-2 twiddles, natural table (32 rd64)", "ofdm step-1 twiddles, [k1][n2] table (15 rd64)",
-    "ofdm step-2 twiddles, permuted table (32 rd64)", "ofdm soft-bit scatter (48 wr8)", "soft-bit scatter as (re,im) pairs (24 wr16)",
+    "ofdm step-2 twiddles, product table layout (32 rd64)", "ofdm soft-bit scatter (48 wr8)", "soft-bit scatter as (re,im) pairs (24 wr16)",
     "ofdm nidx reads (12 rd32)", "ofdm staging reads (3 rd128)"};
 static const int OPS[NPAT] = {32, 32, 32, 32, 32, 32, 64, 64, 15, 32, 15, 32, 48, 24, 12, 3};
 
@@ -95,11 +95,13 @@ __global__ __launch_bounds__(256, 3) void k(const float2 *twiddle, const uint32_
 #pragma unroll
             for (int k1 = 1; k1 < 16; k1++) { const float2 t = sm.t1[(k1 - 1) * 16 + n2]; acc.x += t.x; acc.y += t.y; }
         } else if constexpr (PAT == TW2_TABLE) {
-            // entry (e, k2, k1, p) at ((e*16 + k2)*2 + (k1>>3))*32 + (k1&7) + 8p : a 32-lane group reads 64 distinct banks
-            const int base = (n2 >> 3) * 32 + (n2 & 7) + 8 * p;
+            // the product's layout (ofdm_kernels.hip, WaveLds): even samples in blocks of 49 entries, odd ones in blocks of 64
+            const int hi = n2 >> 3, kq = (n2 >> 2) & 1, klo = n2 & 3;
+            const int b0 = p ? hi * 24 + kq * 12 + (p - 1) * 4 + klo : 48;
+            const int b1 = 784 + hi * 32 + kq * 16 + p * 4 + klo;
 #pragma unroll
             for (int k2 = 0; k2 < 16; k2++) {
-                const float2 a = tw[base + k2 * 64], b = tw[base + (16 + k2) * 64];
+                const float2 a = tw[b0 + k2 * 49], b = tw[b1 + k2 * 64];
                 acc.x += a.x + b.x; acc.y += a.y + b.y;
             }
         } else if constexpr (PAT == SCATTER_B8) {
