@@ -107,40 +107,6 @@ __device__ __forceinline__ void fft8_odd_scaled(float2 *v, const float2 (&c)[4])
     v[3] = cadd(e3, o3); v[7] = csub(e3, o3);
 }
 
-// wave-wide sum by XOR butterflies on the VALU (DPP / permlane swaps), result in every lane
-template <int XORMASK>
-__device__ __forceinline__ float lane_xor_f(float v, int lane) {
-    const int m = __float_as_int(v);
-    int r;
-    if constexpr (XORMASK == 1) {
-        r = __builtin_amdgcn_update_dpp(0, m, 0xB1, 0xF, 0xF, false);
-    } else if constexpr (XORMASK == 2) {
-        r = __builtin_amdgcn_update_dpp(0, m, 0x4E, 0xF, 0xF, false);
-    } else if constexpr (XORMASK == 4) {
-        r = __builtin_amdgcn_update_dpp(0, __builtin_amdgcn_update_dpp(0, m, 0x141, 0xF, 0xF, false), 0x1B, 0xF, 0xF, false);
-    } else if constexpr (XORMASK == 8) {
-        r = __builtin_amdgcn_update_dpp(0, m, 0x128, 0xF, 0xF, false);
-    } else if constexpr (XORMASK == 16) {
-        typedef unsigned u2 __attribute__((ext_vector_type(2)));
-        const u2 t = __builtin_amdgcn_permlane16_swap(unsigned(m), unsigned(m), false, false);
-        r = (lane & 16) ? int(t.x) : int(t.y);
-    } else {
-        typedef unsigned u2 __attribute__((ext_vector_type(2)));
-        const u2 t = __builtin_amdgcn_permlane32_swap(unsigned(m), unsigned(m), false, false);
-        r = (lane & 32) ? int(t.x) : int(t.y);
-    }
-    return __int_as_float(r);
-}
-__device__ __forceinline__ float wave_sum(float v, int lane) {
-    v += lane_xor_f<1>(v, lane);
-    v += lane_xor_f<2>(v, lane);
-    v += lane_xor_f<4>(v, lane);
-    v += lane_xor_f<8>(v, lane);
-    v += lane_xor_f<16>(v, lane);
-    v += lane_xor_f<32>(v, lane);
-    return v;
-}
-
 // The wave's private LDS exchanges are ordered by the hardware (one wave's DS operations execute in order); these
 // keep the compiler from moving the loads of a phase above the stores of the one before.  No instruction is emitted.
 __device__ __forceinline__ void lds_stores_done() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); }

@@ -228,7 +228,10 @@ __global__ __launch_bounds__(WG) void prs_sync_kernel(SyncTables tab, const floa
 
 // ---- null-symbol search (FINDING_NULL_POWER_DIP, /root/reference/src/render_radio_block.cpp:193) ----
 // L1 norm of every 64-sample block.  A wave takes two blocks per trip: lane j of a half holds samples 2j, 2j+1,
-// the 32 pair sums are combined by the XOR butterfly 1, 2, 4, 8, 16 (the fixed tree the oracle restates).
+// the 32 pair sums are combined by the XOR butterfly 1, 2, 4, 8, 16 (the fixed tree the oracle restates).  A wave
+// owns 32 consecutive blocks (16 KB of samples, four trips' loads in flight at a time) and writes their norms as ONE
+// 128-byte store: two dwords per wave, as a first version did, are partial cache lines that eight XCDs' L2s each
+// hold a piece of.
 __global__ __launch_bounds__(256) void null_l1_kernel(const float2 *iq, size_t stream_stride, int64_t nb, float *l1) {
     const int st = blockIdx.y;
     const int lane = threadIdx.x & 63;
@@ -236,17 +239,35 @@ __global__ __launch_bounds__(256) void null_l1_kernel(const float2 *iq, size_t s
     const int64_t n_waves = int64_t(gridDim.x) * 4;
     const float2 *x = iq + size_t(st) * stream_stride;
     float *o = l1 + size_t(st) * nb;
-    for (int64_t b2 = wave; 2 * b2 < nb; b2 += n_waves) {
-        const int64_t b = 2 * b2 + (lane >> 5);
-        float v = 0.0f;
-        if (b < nb) {
-            const float2 *p = x + b * 64 + 2 * (lane & 31);
-            const float2 s0 = p[0], s1 = p[1];
-            v = __fadd_rn(__fadd_rn(__fadd_rn(fabsf(s0.x), fabsf(s0.y)), fabsf(s1.x)), fabsf(s1.y));
-        }
+    const int64_t n_chunks = (nb + 31) / 32;
+    for (int64_t chunk = wave; chunk < n_chunks; chunk += n_waves) {
+        const int64_t b0 = chunk * 32;
+        float keep = 0.0f;
 #pragma unroll
-        for (int off = 1; off < 32; off <<= 1) v = __fadd_rn(v, __shfl_xor(v, off));
-        if ((lane & 31) == 0 && b < nb) o[b] = v;
+        for (int j0 = 0; j0 < 16; j0 += 4) {
+            float2 s0[4], s1[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                // (a block past the end re-reads the last one: no branch between the loads, the store is predicated)
+                const int64_t blk = min(b0 + 2 * (j0 + u) + (lane >> 5), nb - 1);
+                const float2 *p = x + blk * 64 + 2 * (lane & 31);
+                s0[u] = p[0];
+                s1[u] = p[1];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                float v = __fadd_rn(__fadd_rn(__fadd_rn(fabsf(s0[u].x), fabsf(s0[u].y)), fabsf(s1[u].x)), fabsf(s1[u].y));
+                // XOR butterfly inside each half-wave, on the VALU (DPP / row swap) instead of the LDS crossbar
+                v = __fadd_rn(v, lane_xor_f<1>(v, lane));
+                v = __fadd_rn(v, lane_xor_f<2>(v, lane));
+                v = __fadd_rn(v, lane_xor_f<4>(v, lane));
+                v = __fadd_rn(v, lane_xor_f<8>(v, lane));
+                v = __fadd_rn(v, lane_xor_f<16>(v, lane));
+                if ((lane & 31) == j0 + u) keep = v;           // every lane of the half has the sum: lane j keeps trip j's
+            }
+        }
+        const int64_t b = b0 + 2 * (lane & 31) + (lane >> 5);
+        if ((lane & 31) < 16 && b < nb) o[b] = keep;
     }
 }
 
@@ -425,7 +446,7 @@ hipError_t launch_acquire(const SyncTables &t, const AcquireArgs &a, hipStream_t
     if (a.n_streams <= 0 || a.max_out <= 0) return hipSuccess;
     const int64_t nb = a.n_samples / 64;
     if (nb <= 0 || a.max_coarse < 0 || a.max_coarse > 1023) return hipErrorInvalidValue;
-    const unsigned gx = unsigned(std::min<int64_t>((nb / 2 + 3) / 4 + 1, 4096));
+    const unsigned gx = unsigned(std::min<int64_t>(((nb + 31) / 32 + 3) / 4, 4096));
     hipLaunchKernelGGL(null_l1_kernel, dim3(gx, unsigned(a.n_streams)), dim3(256), 0, s, a.iq, a.stream_stride, nb, a.l1);
     // the rest of the scratch buffer follows the candidate lists (acquire_scratch_bytes)
     const int n_seg = int(dip_segments(nb));

@@ -187,3 +187,46 @@ def test_decode_frames_equals_separate_calls(mode, fps):
         c.decode_frames_dev(soft.data_ptr(), dabgpu.NB_FRAME_BITS, n_streams, fps, fib2.data_ptr(), ok2.data_ptr(),
                             [scs[0], dabgpu.subchannel(10, 64, level=3)], None, None, [out1[0].data_ptr()] * 2, None)
     ref.close(); c.close()
+
+
+def test_bench_shape_grouped_launch_equals_the_oracle_on_noise():
+    """The shape bench.py runs -- 64 streams x 256 frames, FIC + one 64 kbit/s EEP 3-A sub-channel in ONE grouped
+    lane launch (65 536 + 65 536 codewords) -- on pure noise, with carried de-interleaver history, against the oracle
+    for EVERY codeword (the C oracle decodes the 131 072 codewords in a few seconds)."""
+    E, F = 64, 256
+    n = E * F
+    sc = dabgpu.subchannel(0, 64, level=3)
+    nbits = sc.length * 64
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev); g.manual_seed(77)
+    soft = torch.zeros((n, dabgpu.NB_FRAME_BITS), dtype=torch.int8, device=dev)
+    soft[:, :dabgpu.NB_FIC_BITS] = torch.randint(-127, 128, (n, dabgpu.NB_FIC_BITS), dtype=torch.int8, device=dev, generator=g)
+    cifs = soft[:, dabgpu.NB_FIC_BITS:].view(n, 4, 55296)
+    cifs[:, :, :nbits] = torch.randint(-127, 128, (n, 4, nbits), dtype=torch.int8, device=dev, generator=g)
+    hist = torch.randint(-127, 128, (E, 15, nbits), dtype=torch.int8, device=dev, generator=g)
+    hout = torch.zeros_like(hist)
+    fib = torch.zeros((n, 12, 32), dtype=torch.uint8, device=dev)
+    ok = torch.zeros((n, 12), dtype=torch.uint8, device=dev)
+    out = torch.zeros((E, F * 4, 192), dtype=torch.uint8, device=dev)
+    c = make_ctx(None, max_frames=64)
+    c.set_timing(True)
+    c.decode_frames_dev(soft.data_ptr(), dabgpu.NB_FRAME_BITS, E, F, fib.data_ptr(), ok.data_ptr(), [sc], [hist.data_ptr()],
+                        [hout.data_ptr()], [out.data_ptr()], None)
+    c.sync()
+    assert c.mean_kernel_ms(2)[1] == 1                       # one grouped launch took all of it
+    fib_h, ok_h, out_h = fib.cpu().numpy(), ok.cpu().numpy(), out.cpu().numpy()
+    fic_h = soft[:, :dabgpu.NB_FIC_BITS].cpu().numpy()
+    for f in range(n):
+        ofib, ook = O.fic_decode(fic_h[f])
+        assert (fib_h[f] == np.asarray(ofib).reshape(12, 32)).all() and (ok_h[f] == ook).all(), f
+    sub = cifs[:, :, :nbits].cpu().numpy().reshape(E, F * 4, nbits)
+    hist_h = hist.cpu().numpy()
+    mask = O.eep_puncture_mask(0, 3, 64)[0]
+    for s in range(E):
+        rows = np.concatenate([hist_h[s], sub[s]])            # CIFs -15 .. 4F-1 of the stream
+        for t in range(F * 4):
+            de = O.time_deinterleave(rows[t:t + 16])
+            assert (out_h[s, t] == O.msc_decode_lf(de, mask, 64 * 24 + 6)).all(), (s, t)
+    # and the ring it leaves behind is the stream's last 15 CIFs
+    assert (hout.cpu().numpy() == sub[:, -15:]).all()
+    c.close()
