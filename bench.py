@@ -191,7 +191,9 @@ def main():
     dev = torch.device("cuda", dev_index)
     dist = None
     backend = os.environ.get("DABGPU_DIST_BACKEND", "nccl")      # "nccl" is RCCL on ROCm; "gloo" only for tests
-    if world > 1:
+    # DABGPU_DIST_FORCE=1 (tests): take the process-group path even for one rank, so that the RCCL barrier and
+    # reductions of the report execute on a single-GPU box
+    if world > 1 or os.environ.get("DABGPU_DIST_FORCE") == "1":
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)

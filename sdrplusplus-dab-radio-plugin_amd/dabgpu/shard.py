@@ -16,7 +16,7 @@ def reduce_report(dist, device, elapsed_s, frames_done, flags_ok):
     """max elapsed, sum frames, min of the correctness flags across ranks.
     `dist` is torch.distributed (or None for a single process)."""
     import torch
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return float(elapsed_s), int(frames_done), [bool(f) for f in flags_ok]
     t = torch.tensor([elapsed_s], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

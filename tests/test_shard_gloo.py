@@ -62,12 +62,12 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run_bench(nproc, extra_env=None):
+def _run_bench(nproc, extra_env=None, ensembles=4, frames=16):
     env = dict(os.environ)
     env.update(extra_env or {})
-    args = ["--ensembles", "4", "--frames", "16", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--no-fft-stage",
-            "--no-selective", "--no-closed-loop"]
-    if nproc == 1:
+    args = ["--ensembles", str(ensembles), "--frames", str(frames), "--steps", "2", "--warmup", "1", "--cpu-seconds", "0",
+            "--no-fft-stage", "--no-selective", "--no-closed-loop"]
+    if nproc == 1 and not (extra_env or {}).get("DABGPU_DIST_FORCE"):
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + args
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
@@ -95,3 +95,24 @@ def test_bench_two_ranks_execute_end_to_end():
     frames_two = two["value"] * two["ms_per_step"] * 1e-3
     frames_one = one["value"] * one["ms_per_step"] * 1e-3
     assert abs(frames_one - 64) < 1e-6 * 64 and abs(frames_two - 128) < 1e-6 * 128
+
+
+@pytest.mark.gpu
+def test_bench_config5_shape_512_ensembles_over_8_ranks():
+    """BASELINE config 5's sharding -- 512 ensembles, 64 per rank, 8 ranks -- executed with the eight ranks sharing the
+    test box's one GPU (16 frames per ensemble instead of 256 so that eight copies fit comfortably): every rank owns
+    the global ids `id % 8 == rank`, decodes its 64 streams bit-exactly, and rank 0 reports the whole job."""
+    r = _run_bench(8, {"DABGPU_DIST_BACKEND": "gloo"}, ensembles=64, frames=16)
+    assert r["n_gpus"] == 8 and r["fic_bit_exact"] is True and r["msc_bit_exact"] is True
+    assert r["config"]["ensembles_per_gpu"] == 64 and r["config"]["frames_per_step_per_gpu"] == 1024
+    assert abs(r["value"] * r["ms_per_step"] * 1e-3 - 8 * 1024) < 1e-3
+
+
+@pytest.mark.gpu
+def test_bench_rccl_branch_executes_with_one_rank():
+    """The `nccl` (= RCCL) branch of bench.py -- process group on the GPU, barrier, the three all-reduces of the report
+    on device tensors -- launched through torch.distributed.run with a single rank, which is all a one-GPU box can give
+    RCCL (two ranks on one device are refused); the multi-rank logic is covered by the gloo runs above."""
+    r = _run_bench(1, {"DABGPU_DIST_FORCE": "1", "DABGPU_DIST_BACKEND": "nccl"})
+    assert r["n_gpus"] == 1 and r["fic_bit_exact"] is True and r["msc_bit_exact"] is True
+    assert abs(r["value"] * r["ms_per_step"] * 1e-3 - 64) < 1e-3
