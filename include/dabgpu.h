@@ -414,7 +414,9 @@ int dabgpu_decode_frames(dabgpu_ctx *ctx, const int8_t *soft, size_t soft_stride
 
 /* The same for ONE stream fed frame after frame, as the plugin does: the time de-interleaver state of every listed
  * sub-channel stays on the device between calls (keyed by start address and size; a sub-channel seen for the first
- * time starts from erasures), so a call is one upload of the soft bits, the decode, one download of all results.
+ * time starts from erasures, and so does one that was left out of the previous call: a ring that misses a frame no
+ * longer continues the stream and is dropped), so a call is one upload of the soft bits, the decode, one download of
+ * all results.
  * dabgpu_decode_stream_reset drops the kept state (Radio_Block::reset_radio). */
 int dabgpu_decode_stream_frames(dabgpu_ctx *ctx, const int8_t *soft, size_t soft_stride, int n_frames, uint8_t *fib,
                                 uint8_t *crc_ok, const dabgpu_subchannel *sc, int n_subchannels, uint8_t *const *out);

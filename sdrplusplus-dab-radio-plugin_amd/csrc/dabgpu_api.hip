@@ -83,6 +83,7 @@ struct dabgpu_ctx {
         size_t bytes;
         int8_t *ring[2];
         int cur;
+        bool live;                       // decoded in the current call (a ring that misses a frame is stale: dropped)
     };
     std::vector<SubHistory> sub_history;
     void *h_bounce = nullptr;            // page-locked landing area of that call's single download
@@ -649,8 +650,6 @@ int dabgpu_streams_reset(dabgpu_ctx *ctx, int n_streams) {
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (n_streams > ctx->n_states) {
         if (ctx->d_states) (void)hipFree(ctx->d_states);
-    for (auto &h : ctx->sub_history) { (void)hipFree(h.ring[0]); (void)hipFree(h.ring[1]); }
-    if (ctx->h_bounce) (void)hipHostFree(ctx->h_bounce);
         ctx->d_states = nullptr;
         ctx->n_states = 0;
         if (hipMalloc(reinterpret_cast<void **>(&ctx->d_states), sizeof(dabk::StreamState) * size_t(n_streams)) != hipSuccess)
@@ -734,6 +733,7 @@ int dabgpu_ofdm_demod_streams(dabgpu_ctx *ctx, const float *iq, size_t frame_str
                               float *dqpsk) {
     if (!ctx || !iq || !soft || n_streams < 0 || frames_per_stream < 0) return DABGPU_ERR_ARG;
     DeviceGuard guard(ctx);
+    if (size_t(n_streams) * size_t(frames_per_stream) > size_t(0x7fffffff) / NB_DATA_SYMBOLS) return DABGPU_ERR_ARG;
     const int n_frames = n_streams * frames_per_stream;
     if (n_frames == 0) return DABGPU_OK;
     void *d_iq, *d_soft, *d_cyc = nullptr, *d_dq = nullptr;
@@ -1378,11 +1378,12 @@ int dabgpu_decode_stream_frames(dabgpu_ctx *ctx, const int8_t *soft, size_t soft
             h.bytes = size_t(15) * sc[i].length * CU_BITS;
             if (hipMalloc(reinterpret_cast<void **>(&h.ring[0]), h.bytes) != hipSuccess) return DABGPU_ERR_NOMEM;
             if (hipMalloc(reinterpret_cast<void **>(&h.ring[1]), h.bytes) != hipSuccess) { (void)hipFree(h.ring[0]); return DABGPU_ERR_NOMEM; }
-            HIP_TRY(hipMemsetAsync(h.ring[0], 0, h.bytes, s));
             hist_index[i] = int(ctx->sub_history.size());
             ctx->sub_history.push_back(h);
+            HIP_TRY(hipMemsetAsync(h.ring[0], 0, h.bytes, s));
         }
-        const dabgpu_ctx::SubHistory &h = ctx->sub_history[size_t(hist_index[i])];
+        dabgpu_ctx::SubHistory &h = ctx->sub_history[size_t(hist_index[i])];
+        h.live = true;
         p_hi[i] = h.ring[h.cur];
         p_ho[i] = h.ring[h.cur ^ 1];
     }
@@ -1416,6 +1417,14 @@ int dabgpu_decode_stream_frames(dabgpu_ctx *ctx, const int8_t *soft, size_t soft
         std::memcpy(out[i], hb + out_off[i], out_bytes[i]);
         ctx->sub_history[size_t(hist_index[i])].cur ^= 1;
     }
+    // a sub-channel left out of this call has missed a frame: its ring no longer continues the stream, and a later
+    // call starts it from erasures again (this also bounds the list over any number of reconfigurations)
+    size_t kept = 0;
+    for (auto &h : ctx->sub_history) {
+        if (h.live) { h.live = false; ctx->sub_history[kept++] = h; }
+        else { (void)hipFree(h.ring[0]); (void)hipFree(h.ring[1]); }
+    }
+    ctx->sub_history.resize(kept);
     return DABGPU_OK;
 }
 

@@ -167,3 +167,24 @@ def test_stream_decoder_keeps_the_deinterleaver_state(built, ensemble, ensemble_
     fresh = c.decode_frames(soft[4:5], 1, [a])[2][0]
     assert (outs[0] == fresh).all()
     c.close()
+
+
+def test_stream_decoder_drops_a_ring_that_missed_a_frame(built, ensemble, ensemble_iq):
+    """A sub-channel left out of one call starts from erasures when it comes back (its ring no longer continues the
+    stream); resizing the front end's stream table in between does not disturb the decoder's rings."""
+    frames = _rx(ensemble_iq[:5], 16.0, 0.0)
+    c = make_ctx(None, 8)
+    soft, _, _ = c.ofdm_demod_frames(frames)
+    a, b = dabgpu.subchannel(ensemble.start_cu, 64, level=3), dabgpu.subchannel(ensemble.start_cu + 100, 32, level=2)
+    c.streams_reset(1)
+    c.decode_stream_frames(soft[0:1], [a, b])
+    c.streams_reset(8)                                   # grows the state table: must leave the rings alone
+    out1 = c.decode_stream_frames(soft[1:2], [a, b])[2]
+    ref = c.decode_frames(soft[0:2], 1, [a, b])[2]
+    assert (out1[0][0] == ref[0][0][4:]).all() and (out1[1][0] == ref[1][0][4:]).all()
+    c.decode_stream_frames(soft[2:3], [a])               # b misses frame 2
+    out3 = c.decode_stream_frames(soft[3:4], [a, b])[2]
+    ref_a = c.decode_frames(soft[0:4], 1, [a])[2][0][0]
+    ref_b = c.decode_frames(soft[3:4], 1, [b])[2][0][0]  # b as if the stream began at frame 3
+    assert (out3[0][0] == ref_a[12:]).all() and (out3[1][0] == ref_b).all()
+    c.close()
