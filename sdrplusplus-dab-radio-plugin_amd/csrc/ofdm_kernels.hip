@@ -28,6 +28,7 @@
 #include "kernels.hpp"
 #include "dab_tables.hpp"
 #include "fft_common.hpp"
+#include "mem_stream.hpp"
 
 namespace dabk {
 
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
             if constexpr (!FFT_ONLY) {                        // not a demodulable frame: erased soft bits
                 uint4 *o = reinterpret_cast<uint4 *>(a.soft + size_t(frame) * NB_FRAME_BITS + size_t(l_first) * NB_SYM_BITS);
                 const int n16 = (l_last - l_first) * NB_SYM_BITS / 16;
-                for (int i = lane; i < n16; i += 64) o[i] = make_uint4(0u, 0u, 0u, 0u);
+                for (int i = lane; i < n16; i += 64) st_stream(o + i, make_uint4(0u, 0u, 0u, 0u));
             }
             return;
         }
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
             lds_loads_may_start();
             const int li = l - slot + lane;                     // symbol whose value lane `lane` carries out
             if (lane <= slot && (FFT_ONLY || li > l_first || li == 0))
-                a.cyc[size_t(frame) * NB_FRAME_SYMBOLS + li] = sm.cyc[wave][lane];
+                st_stream(a.cyc + size_t(frame) * NB_FRAME_SYMBOLS + li, sm.cyc[wave][lane]);
         }
     };
 
@@ -240,8 +241,8 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
                         if (i > 0 || lane >= 4) {
-                            const float2 c0 = cp[128 * i], c1 = cp[128 * i + 1];
-                            const float2 u0 = tail[128 * i], u1 = tail[128 * i + 1];
+                            const float2 c0 = ld_stream(cp + 128 * i), c1 = ld_stream(cp + 128 * i + 1);
+                            const float2 u0 = ld_stream(tail + 128 * i), u1 = ld_stream(tail + 128 * i + 1);
                             acc.x += c0.x * u0.x + c0.y * u0.y + c1.x * u1.x + c1.y * u1.y;      // conj(c) * u
                             acc.y += c0.x * u0.y - c0.y * u0.x + c1.x * u1.y - c1.y * u1.x;
                         }
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
             const float4 *rows = reinterpret_cast<const float4 *>(sym + NB_CP) + lane;
 #pragma unroll
             for (int n1 = 0; n1 < 16; n1++) {
-                const float4 v = rows[64 * n1];
+                const float4 v = ld_stream(rows + 64 * n1);
                 x0[n1] = make_float2(v.x, v.y);
                 x1[n1] = make_float2(v.z, v.w);
             }
@@ -273,8 +274,8 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
             const float2 *rows = sym + NB_CP + 2 * lane;
 #pragma unroll
             for (int n1 = 0; n1 < 16; n1++) {
-                x0[n1] = rows[128 * n1];
-                x1[n1] = rows[128 * n1 + 1];
+                x0[n1] = ld_stream(rows + 128 * n1);
+                x1[n1] = ld_stream(rows + 128 * n1 + 1);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -287,9 +288,9 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
                 if (i > 0 || lane >= 4) {
                     float4 c;
                     if (aligned16) {
-                        c = *reinterpret_cast<const float4 *>(cp + 128 * i);
+                        c = ld_stream(reinterpret_cast<const float4 *>(cp + 128 * i));
                     } else {
-                        const float2 c0 = cp[128 * i], c1 = cp[128 * i + 1];
+                        const float2 c0 = ld_stream(cp + 128 * i), c1 = ld_stream(cp + 128 * i + 1);
                         c = make_float4(c0.x, c0.y, c1.x, c1.y);
                     }
                     const float2 u0 = x0[12 + i], u1 = x1[12 + i];
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
 #pragma unroll
             for (int k3 = 0; k3 < 8; k3++)
 #pragma unroll
-                for (int c = 0; c < 4; c++) o[64 * (c + 4 * k3)] = X[c][k3];
+                for (int c = 0; c < 4; c++) st_stream(o + 64 * (c + 4 * k3), X[c][k3]);
             continue;
         }
         // ---- carrier registers: j<12 -> m=j ; j>=12 -> m=j+8 ; lane 0 holds bin 768 (m=12) instead of DC ----
@@ -438,7 +439,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
                     const int m = j < 12 ? j : j + 8;
                     int bin = lane + 64 * m;
                     if (j == 0 && lane == 0) bin = 768;
-                    dq[bin >= 1280 ? bin - 1280 : bin + 767] = d;
+                    st_stream(dq + (bin >= 1280 ? bin - 1280 : bin + 767), d);
                 }
             }
             lds_stores_done();
@@ -450,11 +451,11 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
                 // wave-uniform selection words; one predicated 16-byte store per chunk
                 const unsigned long long *kw = a.keep + 3 * __builtin_amdgcn_readfirstlane(l - 1);
                 const unsigned long long me = 1ull << lane;
-                if (kw[0] & me) o[0] = s0;
-                if (kw[1] & me) o[64] = s1;
-                if (kw[2] & me) o[128] = s2;
+                if (kw[0] & me) st_stream(o, s0);
+                if (kw[1] & me) st_stream(o + 64, s1);
+                if (kw[2] & me) st_stream(o + 128, s2);
             } else {
-                o[0] = s0; o[64] = s1; o[128] = s2;
+                st_stream(o, s0); st_stream(o + 64, s1); st_stream(o + 128, s2);
             }
         }
 #pragma unroll

@@ -16,6 +16,7 @@
 #include "kernels.hpp"
 #include "dab_tables.hpp"
 #include "fft_common.hpp"
+#include "mem_stream.hpp"
 
 namespace dabk {
 
@@ -251,8 +252,8 @@ __global__ __launch_bounds__(256) void null_l1_kernel(const float2 *iq, size_t s
                 // (a block past the end re-reads the last one: no branch between the loads, the store is predicated)
                 const int64_t blk = min(b0 + 2 * (j0 + u) + (lane >> 5), nb - 1);
                 const float2 *p = x + blk * 64 + 2 * (lane & 31);
-                s0[u] = p[0];
-                s1[u] = p[1];
+                s0[u] = ld_stream(p);
+                s1[u] = ld_stream(p + 1);
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {

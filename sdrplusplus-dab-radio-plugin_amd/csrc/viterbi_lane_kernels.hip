@@ -24,6 +24,7 @@
 #include <algorithm>
 #include <vector>
 
+#include "mem_stream.hpp"
 #include "kernels.hpp"
 #include "dab_tables.hpp"
 
@@ -288,7 +289,7 @@ __device__ __forceinline__ void lane_step(unsigned (&M)[32], uint32_t w, uint2 *
         lane_self<12>(M, kk, acc0, acc1);          lane_self<13>(M, kk, acc0, acc1);
         lane_self<14>(M, kk, acc0, acc1);          lane_self<15>(M, kk, acc0, acc1);
     }
-    *dec_out = make_uint2(acc0, acc1);
+    st_stream(dec_out, make_uint2(acc0, acc1));
 }
 
 // Four groups per workgroup (one per SIMD); the launcher pads the LDS request so that every CU gets the same
@@ -559,9 +560,9 @@ __device__ __forceinline__ void lane_traceback_body(const uint2 *dec, int nsteps
     // update is serial.
     uint2 d[32], dn[32];
 #pragma unroll
-    for (int i = 0; i < 6; i++) d[i] = src[size_t(nsteps - 1 - i) * 64];
+    for (int i = 0; i < 6; i++) d[i] = ld_stream(src + size_t(nsteps - 1 - i) * 64);
 #pragma unroll
-    for (int i = 0; i < 32; i++) dn[i] = src[size_t(nsteps - 7 - i) * 64];
+    for (int i = 0; i < 32; i++) dn[i] = ld_stream(src + size_t(nsteps - 7 - i) * 64);
 #pragma unroll
     for (int i = 0; i < 6; i++) lane_tb_step(d[i], nsteps - 1 - i, nsteps, p, q, word, row);
     for (int t1 = nsteps - 7; t1 >= 0; t1 -= 32) {            // nsteps - 6 is a multiple of 32
@@ -569,7 +570,7 @@ __device__ __forceinline__ void lane_traceback_body(const uint2 *dec, int nsteps
         for (int i = 0; i < 32; i++) d[i] = dn[i];
         if (t1 >= 32) {
 #pragma unroll
-            for (int i = 0; i < 32; i++) dn[i] = src[size_t(t1 - 32 - i) * 64];
+            for (int i = 0; i < 32; i++) dn[i] = ld_stream(src + size_t(t1 - 32 - i) * 64);
         }
 #pragma unroll
         for (int i = 0; i < 32; i++) lane_tb_step(d[i], t1 - i, nsteps, p, q, word, row);

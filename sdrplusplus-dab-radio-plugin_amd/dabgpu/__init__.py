@@ -127,6 +127,65 @@ class Subchannel(C.Structure):
 _LIB = None
 
 
+def load_library(path):
+    """Load one build of libdabgpu.so and declare its entry points.  lib() does this for the in-tree library; tools
+    that compare builds inside one process (tools/ab_inproc.py) load others and pass them to Context(library=...)."""
+    L = C.CDLL(path)
+    L.dabgpu_strerror.restype = C.c_char_p
+    L.dabgpu_stream.restype = C.c_void_p
+    L.dabgpu_stream.argtypes = [C.c_void_p]
+    L.dabgpu_destroy.restype = None
+    L.dabgpu_destroy.argtypes = [C.c_void_p]
+    vp, sz, i = C.c_void_p, C.c_size_t, C.c_int
+    L.dabgpu_create.argtypes = [C.POINTER(Cfg), C.POINTER(vp)]
+    L.dabgpu_sync.argtypes = [vp]
+    L.dabgpu_ofdm_demod_frames_dev.argtypes = [vp, vp, sz, i, vp, vp, vp, vp, vp]
+    L.dabgpu_ofdm_demod_frames.argtypes = [vp, vp, sz, i, vp, vp, vp, vp]
+    L.dabgpu_fft_symbols_dev.argtypes = [vp, vp, sz, i, vp, vp, vp]
+    L.dabgpu_fft_symbols.argtypes = [vp, vp, sz, i, vp, vp]
+    L.dabgpu_fic_decode_dev.argtypes = [vp, vp, sz, i, vp, vp, vp]
+    L.dabgpu_fic_decode.argtypes = [vp, vp, sz, i, vp, vp]
+    L.dabgpu_subchannel_bytes.argtypes = [C.POINTER(Subchannel)]
+    L.dabgpu_msc_decode_dev.argtypes = [vp, C.POINTER(Subchannel), vp, sz, i, i, vp, vp, vp, vp]
+    L.dabgpu_msc_decode.argtypes = [vp, C.POINTER(Subchannel), vp, sz, i, i, vp, vp, vp]
+    L.dabgpu_viterbi_dev.argtypes = [vp, vp, i, vp, i, vp, vp]
+    L.dabgpu_viterbi.argtypes = [vp, vp, i, vp, i, vp]
+    L.dabgpu_set_timing.argtypes = [vp, i]
+    L.dabgpu_dabplus_superframes_dev.argtypes = [vp, vp, sz, i, i, vp, vp, vp]
+    L.dabgpu_dabplus_superframes.argtypes = [vp, vp, sz, i, i, vp, vp]
+    L.dabgpu_msc_decode_multi_dev.argtypes = [vp, vp, i, vp, sz, i, i, vp, vp, vp, vp]
+    L.dabgpu_decode_frames_dev.argtypes = [vp, vp, sz, i, i, vp, vp, vp, i, vp, vp, vp, vp]
+    L.dabgpu_decode_frames.argtypes = [vp, vp, sz, i, i, vp, vp, vp, i, vp, vp, vp]
+    L.dabgpu_decode_stream_frames.argtypes = [vp, vp, sz, i, vp, vp, vp, i, vp]
+    L.dabgpu_decode_stream_reset.argtypes = [vp]
+    L.dabgpu_streams_reset.argtypes = [vp, i]
+    L.dabgpu_stream_states.restype = C.c_void_p
+    L.dabgpu_stream_states.argtypes = [vp]
+    L.dabgpu_set_stream_offsets.argtypes = [vp, i, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.dabgpu_ofdm_demod_streams_dev.argtypes = [vp, vp, sz, i, i, C.c_float, vp, vp, vp, vp]
+    L.dabgpu_ofdm_demod_streams.argtypes = [vp, vp, sz, i, i, C.c_float, vp, vp, vp]
+    L.dabgpu_get_stats.argtypes = [vp, i, C.POINTER(Stats)]
+    L.dabgpu_sync_prs_dev.argtypes = [vp, vp, sz, i, vp, i, vp, vp]
+    L.dabgpu_sync_prs.argtypes = [vp, vp, sz, i, vp, i, vp]
+    L.dabgpu_ofdm_set_soft_selection.argtypes = [vp, vp, i]
+    L.dabgpu_soft_selection.argtypes = [vp, i, i, vp, i]
+    L.dabgpu_uep_subchannel.argtypes = [i, i, C.POINTER(Subchannel)]
+    L.dabgpu_host_alloc.restype = C.c_void_p
+    L.dabgpu_host_alloc.argtypes = [sz]
+    L.dabgpu_host_free.restype = None
+    L.dabgpu_host_free.argtypes = [C.c_void_p]
+    L.dabgpu_acquire_default_cfg.restype = None
+    L.dabgpu_acquire_default_cfg.argtypes = [C.POINTER(AcquireCfg)]
+    L.dabgpu_acquire_dev.argtypes = [vp, vp, sz, i, C.c_int64, C.POINTER(AcquireCfg), i, vp, vp, vp]
+    L.dabgpu_acquire.argtypes = [vp, vp, sz, i, C.c_int64, C.POINTER(AcquireCfg), i, vp, vp]
+    L.dabgpu_ofdm_demod_acquired_dev.argtypes = [vp, vp, sz, i, i, vp, vp, vp, vp, vp]
+    L.dabgpu_last_kernel_ms.argtypes = [vp, i, C.POINTER(C.c_float)]
+    L.dabgpu_mean_kernel_ms.argtypes = [vp, i, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    L.dabgpu_get_prs_reference.argtypes = [i, vp, i]
+    L.dabgpu_get_mapper_reference.argtypes = [vp, i, i]
+    return L
+
+
 def lib():
     """Load libdabgpu.so (raises if it has not been built -- there is no fallback)."""
     global _LIB
@@ -139,60 +198,7 @@ def lib():
             import torch  # noqa: F401
         except Exception:
             pass
-        L = C.CDLL(LIB_PATH)
-        L.dabgpu_strerror.restype = C.c_char_p
-        L.dabgpu_stream.restype = C.c_void_p
-        L.dabgpu_stream.argtypes = [C.c_void_p]
-        L.dabgpu_destroy.restype = None
-        L.dabgpu_destroy.argtypes = [C.c_void_p]
-        vp, sz, i = C.c_void_p, C.c_size_t, C.c_int
-        L.dabgpu_create.argtypes = [C.POINTER(Cfg), C.POINTER(vp)]
-        L.dabgpu_sync.argtypes = [vp]
-        L.dabgpu_ofdm_demod_frames_dev.argtypes = [vp, vp, sz, i, vp, vp, vp, vp, vp]
-        L.dabgpu_ofdm_demod_frames.argtypes = [vp, vp, sz, i, vp, vp, vp, vp]
-        L.dabgpu_fft_symbols_dev.argtypes = [vp, vp, sz, i, vp, vp, vp]
-        L.dabgpu_fft_symbols.argtypes = [vp, vp, sz, i, vp, vp]
-        L.dabgpu_fic_decode_dev.argtypes = [vp, vp, sz, i, vp, vp, vp]
-        L.dabgpu_fic_decode.argtypes = [vp, vp, sz, i, vp, vp]
-        L.dabgpu_subchannel_bytes.argtypes = [C.POINTER(Subchannel)]
-        L.dabgpu_msc_decode_dev.argtypes = [vp, C.POINTER(Subchannel), vp, sz, i, i, vp, vp, vp, vp]
-        L.dabgpu_msc_decode.argtypes = [vp, C.POINTER(Subchannel), vp, sz, i, i, vp, vp, vp]
-        L.dabgpu_viterbi_dev.argtypes = [vp, vp, i, vp, i, vp, vp]
-        L.dabgpu_viterbi.argtypes = [vp, vp, i, vp, i, vp]
-        L.dabgpu_set_timing.argtypes = [vp, i]
-        L.dabgpu_dabplus_superframes_dev.argtypes = [vp, vp, sz, i, i, vp, vp, vp]
-        L.dabgpu_dabplus_superframes.argtypes = [vp, vp, sz, i, i, vp, vp]
-        L.dabgpu_msc_decode_multi_dev.argtypes = [vp, vp, i, vp, sz, i, i, vp, vp, vp, vp]
-        L.dabgpu_decode_frames_dev.argtypes = [vp, vp, sz, i, i, vp, vp, vp, i, vp, vp, vp, vp]
-        L.dabgpu_decode_frames.argtypes = [vp, vp, sz, i, i, vp, vp, vp, i, vp, vp, vp]
-        L.dabgpu_decode_stream_frames.argtypes = [vp, vp, sz, i, vp, vp, vp, i, vp]
-        L.dabgpu_decode_stream_reset.argtypes = [vp]
-        L.dabgpu_streams_reset.argtypes = [vp, i]
-        L.dabgpu_stream_states.restype = C.c_void_p
-        L.dabgpu_stream_states.argtypes = [vp]
-        L.dabgpu_set_stream_offsets.argtypes = [vp, i, C.POINTER(C.c_float), C.POINTER(C.c_float)]
-        L.dabgpu_ofdm_demod_streams_dev.argtypes = [vp, vp, sz, i, i, C.c_float, vp, vp, vp, vp]
-        L.dabgpu_ofdm_demod_streams.argtypes = [vp, vp, sz, i, i, C.c_float, vp, vp, vp]
-        L.dabgpu_get_stats.argtypes = [vp, i, C.POINTER(Stats)]
-        L.dabgpu_sync_prs_dev.argtypes = [vp, vp, sz, i, vp, i, vp, vp]
-        L.dabgpu_sync_prs.argtypes = [vp, vp, sz, i, vp, i, vp]
-        L.dabgpu_ofdm_set_soft_selection.argtypes = [vp, vp, i]
-        L.dabgpu_soft_selection.argtypes = [vp, i, i, vp, i]
-        L.dabgpu_uep_subchannel.argtypes = [i, i, C.POINTER(Subchannel)]
-        L.dabgpu_host_alloc.restype = C.c_void_p
-        L.dabgpu_host_alloc.argtypes = [sz]
-        L.dabgpu_host_free.restype = None
-        L.dabgpu_host_free.argtypes = [C.c_void_p]
-        L.dabgpu_acquire_default_cfg.restype = None
-        L.dabgpu_acquire_default_cfg.argtypes = [C.POINTER(AcquireCfg)]
-        L.dabgpu_acquire_dev.argtypes = [vp, vp, sz, i, C.c_int64, C.POINTER(AcquireCfg), i, vp, vp, vp]
-        L.dabgpu_acquire.argtypes = [vp, vp, sz, i, C.c_int64, C.POINTER(AcquireCfg), i, vp, vp]
-        L.dabgpu_ofdm_demod_acquired_dev.argtypes = [vp, vp, sz, i, i, vp, vp, vp, vp, vp]
-        L.dabgpu_last_kernel_ms.argtypes = [vp, i, C.POINTER(C.c_float)]
-        L.dabgpu_mean_kernel_ms.argtypes = [vp, i, C.POINTER(C.c_float), C.POINTER(C.c_int)]
-        L.dabgpu_get_prs_reference.argtypes = [i, vp, i]
-        L.dabgpu_get_mapper_reference.argtypes = [vp, i, i]
-        _LIB = L
+        _LIB = load_library(LIB_PATH)
     return _LIB
 
 
@@ -281,14 +287,15 @@ class Context:
     """Owns a dabgpu_ctx.  Host-array methods copy in/out and synchronise; *_dev methods take
     raw device addresses (e.g. torch.Tensor.data_ptr()) and a stream handle and only enqueue."""
 
-    def __init__(self, device=0, max_frames=64, flags=0, ofdm_symbol_runs=0):
+    def __init__(self, device=0, max_frames=64, flags=0, ofdm_symbol_runs=0, library=None):
         self._h = C.c_void_p()
+        self._lib = library if library is not None else lib()
         cfg = Cfg(device, max_frames, 1, flags, ofdm_symbol_runs)
-        _check(lib().dabgpu_create(C.byref(cfg), C.byref(self._h)), "dabgpu_create")
+        _check(self._lib.dabgpu_create(C.byref(cfg), C.byref(self._h)), "dabgpu_create")
 
     def close(self):
         if self._h:
-            lib().dabgpu_destroy(self._h)
+            self._lib.dabgpu_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -305,41 +312,41 @@ class Context:
 
     @property
     def stream(self):
-        return lib().dabgpu_stream(self._h)
+        return self._lib.dabgpu_stream(self._h)
 
     def sync(self):
-        _check(lib().dabgpu_sync(self._h), "dabgpu_sync")
+        _check(self._lib.dabgpu_sync(self._h), "dabgpu_sync")
 
     def set_timing(self, on):
-        _check(lib().dabgpu_set_timing(self._h, 1 if on else 0), "dabgpu_set_timing")
+        _check(self._lib.dabgpu_set_timing(self._h, 1 if on else 0), "dabgpu_set_timing")
 
     def last_kernel_ms(self, which):
         ms = C.c_float(0)
-        _check(lib().dabgpu_last_kernel_ms(self._h, which, C.byref(ms)), "dabgpu_last_kernel_ms")
+        _check(self._lib.dabgpu_last_kernel_ms(self._h, which, C.byref(ms)), "dabgpu_last_kernel_ms")
         return ms.value
 
     def mean_kernel_ms(self, which):
         """(mean ms, launches) of kernel family `which` since set_timing(True) (at most the last 32 launches)."""
         ms, n = C.c_float(0), C.c_int(0)
-        _check(lib().dabgpu_mean_kernel_ms(self._h, which, C.byref(ms), C.byref(n)), "dabgpu_mean_kernel_ms")
+        _check(self._lib.dabgpu_mean_kernel_ms(self._h, which, C.byref(ms), C.byref(n)), "dabgpu_mean_kernel_ms")
         return ms.value, n.value
 
     # ---- closed-loop stream call
     def streams_reset(self, n_streams):
-        _check(lib().dabgpu_streams_reset(self._h, n_streams), "dabgpu_streams_reset")
+        _check(self._lib.dabgpu_streams_reset(self._h, n_streams), "dabgpu_streams_reset")
 
     @property
     def stream_states_ptr(self):
-        return lib().dabgpu_stream_states(self._h)
+        return self._lib.dabgpu_stream_states(self._h)
 
     def set_stream_offsets(self, stream, fine=None, coarse=None):
         f = None if fine is None else C.byref(C.c_float(fine))
         c = None if coarse is None else C.byref(C.c_float(coarse))
-        _check(lib().dabgpu_set_stream_offsets(self._h, stream, f, c), "dabgpu_set_stream_offsets")
+        _check(self._lib.dabgpu_set_stream_offsets(self._h, stream, f, c), "dabgpu_set_stream_offsets")
 
     def get_stats(self, stream):
         st = Stats()
-        _check(lib().dabgpu_get_stats(self._h, stream, C.byref(st)), "dabgpu_get_stats")
+        _check(self._lib.dabgpu_get_stats(self._h, stream, C.byref(st)), "dabgpu_get_stats")
         return st
 
     def ofdm_demod_streams(self, iq, n_streams, beta=0.9, want_cyc=False, soft=None):
@@ -350,13 +357,13 @@ class Context:
         if soft is None:
             soft = np.zeros((n_frames, NB_FRAME_BITS), np.int8)
         cyc = np.zeros((n_frames, NB_SYMBOLS), np.complex64) if want_cyc else None
-        _check(lib().dabgpu_ofdm_demod_streams(self._h, _p(iq), stride, n_streams, n_frames // n_streams, beta, _p(soft),
+        _check(self._lib.dabgpu_ofdm_demod_streams(self._h, _p(iq), stride, n_streams, n_frames // n_streams, beta, _p(soft),
                                                _p(cyc), None), "dabgpu_ofdm_demod_streams")
         return soft, cyc
 
     def ofdm_demod_streams_dev(self, d_iq, frame_stride, n_streams, frames_per_stream, beta, d_soft, d_cyc=None,
                                d_dqpsk=None, stream=None):
-        _check(lib().dabgpu_ofdm_demod_streams_dev(self._h, d_iq, frame_stride, n_streams, frames_per_stream, beta, d_soft,
+        _check(self._lib.dabgpu_ofdm_demod_streams_dev(self._h, d_iq, frame_stride, n_streams, frames_per_stream, beta, d_soft,
                                                    d_cyc, d_dqpsk, stream), "dabgpu_ofdm_demod_streams_dev")
 
     def decode_frames(self, soft, n_streams, scs, history_in=None, want_history=False):
@@ -371,7 +378,7 @@ class Context:
         ok = np.zeros((n_frames, 12), np.uint8)
         outs = []
         for sc in scs:
-            nb = lib().dabgpu_subchannel_bytes(C.byref(sc))
+            nb = self._lib.dabgpu_subchannel_bytes(C.byref(sc))
             _check(min(nb, 0), "dabgpu_subchannel_bytes")
             outs.append(np.zeros((n_streams, fps * 4, nb), np.uint8))
         his = [None if history_in is None or history_in[k] is None else np.ascontiguousarray(history_in[k], np.int8)
@@ -382,7 +389,7 @@ class Context:
             if n == 0:
                 return None
             return (C.c_void_p * n)(*[None if a is None else a.ctypes.data for a in lst])
-        _check(lib().dabgpu_decode_frames(self._h, _p(soft), stride, n_streams, fps, _p(fib), _p(ok), arr, n, ptrs(his),
+        _check(self._lib.dabgpu_decode_frames(self._h, _p(soft), stride, n_streams, fps, _p(fib), _p(ok), arr, n, ptrs(his),
                                           ptrs(hos), ptrs(outs)), "dabgpu_decode_frames")
         return fib, ok, outs, (hos if want_history else None)
 
@@ -396,16 +403,16 @@ class Context:
         ok = np.zeros((n_frames, 12), np.uint8)
         outs = []
         for sc in scs:
-            nb = lib().dabgpu_subchannel_bytes(C.byref(sc))
+            nb = self._lib.dabgpu_subchannel_bytes(C.byref(sc))
             _check(min(nb, 0), "dabgpu_subchannel_bytes")
             outs.append(np.zeros((1, n_frames * 4, nb), np.uint8))
         ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in outs]) if n else None
-        _check(lib().dabgpu_decode_stream_frames(self._h, _p(soft), stride, n_frames, _p(fib), _p(ok), arr, n, ptrs),
+        _check(self._lib.dabgpu_decode_stream_frames(self._h, _p(soft), stride, n_frames, _p(fib), _p(ok), arr, n, ptrs),
                "dabgpu_decode_stream_frames")
         return fib, ok, outs
 
     def decode_stream_reset(self):
-        _check(lib().dabgpu_decode_stream_reset(self._h), "dabgpu_decode_stream_reset")
+        _check(self._lib.dabgpu_decode_stream_reset(self._h), "dabgpu_decode_stream_reset")
 
     # ---- host arrays
     def ofdm_demod_frames(self, iq, freq_offset=None, want_cyc=False, want_dqpsk=False, soft=None):
@@ -417,7 +424,7 @@ class Context:
         fo = None if freq_offset is None else np.ascontiguousarray(freq_offset, np.float32)
         cyc = np.zeros((n_frames, NB_SYMBOLS), np.complex64) if want_cyc else None
         dq = np.zeros((n_frames, NB_SYMBOLS - 1, NB_CARRIERS), np.complex64) if want_dqpsk else None
-        _check(lib().dabgpu_ofdm_demod_frames(self._h, _p(iq), stride, n_frames, _p(fo), _p(soft), _p(cyc), _p(dq)),
+        _check(self._lib.dabgpu_ofdm_demod_frames(self._h, _p(iq), stride, n_frames, _p(fo), _p(soft), _p(cyc), _p(dq)),
                "dabgpu_ofdm_demod_frames")
         return soft, cyc, dq
 
@@ -426,7 +433,7 @@ class Context:
         n_frames, stride = iq.shape
         fo = None if freq_offset is None else np.ascontiguousarray(freq_offset, np.float32)
         out = np.zeros((n_frames, NB_SYMBOLS, NB_FFT), np.complex64)
-        _check(lib().dabgpu_fft_symbols(self._h, _p(iq), stride, n_frames, _p(fo), _p(out)), "dabgpu_fft_symbols")
+        _check(self._lib.dabgpu_fft_symbols(self._h, _p(iq), stride, n_frames, _p(fo), _p(out)), "dabgpu_fft_symbols")
         return out
 
     def sync_prs(self, iq, freq_offset=None, max_coarse=200):
@@ -437,13 +444,13 @@ class Context:
         fo = None if freq_offset is None else np.ascontiguousarray(freq_offset, np.float32)
         out = np.zeros(n, dtype=[("coarse_carriers", np.int32), ("time_offset", np.int32),
                                  ("peak_to_mean", np.float32), ("coarse_peak_to_mean", np.float32)])
-        _check(lib().dabgpu_sync_prs(self._h, _p(iq), stride, n, _p(fo), max_coarse, _p(out)), "dabgpu_sync_prs")
+        _check(self._lib.dabgpu_sync_prs(self._h, _p(iq), stride, n, _p(fo), max_coarse, _p(out)), "dabgpu_sync_prs")
         return out
 
     def set_soft_selection(self, ranges):
         """ranges: iterable of (first_bit, count) in frame-bit coordinates, or None / empty for whole frames."""
         arr = np.array(list(ranges) if ranges is not None else [], np.int32).reshape(-1, 2)
-        _check(lib().dabgpu_ofdm_set_soft_selection(self._h, _p(arr) if len(arr) else None, len(arr)),
+        _check(self._lib.dabgpu_ofdm_set_soft_selection(self._h, _p(arr) if len(arr) else None, len(arr)),
                "dabgpu_ofdm_set_soft_selection")
 
     def acquire(self, iq, max_frames, cfg=None):
@@ -453,18 +460,18 @@ class Context:
         n_streams, n_samples = iq.shape
         out = np.zeros((n_streams, max_frames), ACQUIRED_FRAME_DTYPE)
         counts = np.zeros(n_streams, np.int32)
-        _check(lib().dabgpu_acquire(self._h, _p(iq), n_samples, n_streams, n_samples,
+        _check(self._lib.dabgpu_acquire(self._h, _p(iq), n_samples, n_streams, n_samples,
                                     None if cfg is None else C.byref(cfg), max_frames, _p(out), _p(counts)), "dabgpu_acquire")
         return out, counts
 
     def acquire_dev(self, d_iq, stream_stride, n_streams, n_samples, max_frames, d_out, d_counts, cfg=None, stream=None):
-        _check(lib().dabgpu_acquire_dev(self._h, d_iq, stream_stride, n_streams, n_samples,
+        _check(self._lib.dabgpu_acquire_dev(self._h, d_iq, stream_stride, n_streams, n_samples,
                                         None if cfg is None else C.byref(cfg), max_frames, d_out, d_counts, stream),
                "dabgpu_acquire_dev")
 
     def ofdm_demod_acquired_dev(self, d_iq, stream_stride, n_streams, max_frames, d_frames, d_soft, d_cyc=None,
                                 d_dqpsk=None, stream=None):
-        _check(lib().dabgpu_ofdm_demod_acquired_dev(self._h, d_iq, stream_stride, n_streams, max_frames, d_frames, d_soft,
+        _check(self._lib.dabgpu_ofdm_demod_acquired_dev(self._h, d_iq, stream_stride, n_streams, max_frames, d_frames, d_soft,
                                                     d_cyc, d_dqpsk, stream), "dabgpu_ofdm_demod_acquired_dev")
 
     def dabplus_superframes(self, sfs, bitrate_kbps):
@@ -476,7 +483,7 @@ class Context:
         st = np.zeros(n, dtype=[("firecode_ok", np.int32), ("rs_corrected", np.int32), ("rs_uncorrectable", np.int32),
                                 ("num_aus", np.int32), ("au_crc_mask", np.int32), ("au_start", np.int32, (8,)),
                                 ("reserved", np.int32, (3,))])
-        _check(lib().dabgpu_dabplus_superframes(self._h, _p(sfs), stride, n, bitrate_kbps, _p(out), _p(st)),
+        _check(self._lib.dabgpu_dabplus_superframes(self._h, _p(sfs), stride, n, bitrate_kbps, _p(out), _p(st)),
                "dabgpu_dabplus_superframes")
         return out, st
 
@@ -486,7 +493,7 @@ class Context:
         n_frames, stride = soft.shape
         fib = np.zeros((n_frames, 12, 32), np.uint8)
         ok = np.zeros((n_frames, 12), np.uint8)
-        _check(lib().dabgpu_fic_decode(self._h, _p(soft), stride, n_frames, _p(fib), _p(ok)), "dabgpu_fic_decode")
+        _check(self._lib.dabgpu_fic_decode(self._h, _p(soft), stride, n_frames, _p(fib), _p(ok)), "dabgpu_fic_decode")
         return fib, ok
 
     def msc_decode(self, sc, soft, n_streams, history_in=None, want_history=False):
@@ -494,12 +501,12 @@ class Context:
         soft = np.ascontiguousarray(soft, np.int8)
         n_frames, stride = soft.shape
         fps = n_frames // n_streams
-        nbytes = lib().dabgpu_subchannel_bytes(C.byref(sc))
+        nbytes = self._lib.dabgpu_subchannel_bytes(C.byref(sc))
         _check(min(nbytes, 0), "dabgpu_subchannel_bytes")
         out = np.zeros((n_streams, fps * 4, nbytes), np.uint8)
         hi = None if history_in is None else np.ascontiguousarray(history_in, np.int8)
         ho = np.zeros((n_streams, 15, sc.length * 64), np.int8) if want_history else None
-        _check(lib().dabgpu_msc_decode(self._h, C.byref(sc), _p(soft), stride, n_streams, fps, _p(hi), _p(ho), _p(out)),
+        _check(self._lib.dabgpu_msc_decode(self._h, C.byref(sc), _p(soft), stride, n_streams, fps, _p(hi), _p(ho), _p(out)),
                "dabgpu_msc_decode")
         return out, ho
 
@@ -510,26 +517,26 @@ class Context:
         nsteps = mask.size // 4
         n = punct.shape[0]
         out = np.zeros((n, (nsteps - 6) // 8), np.uint8)
-        _check(lib().dabgpu_viterbi(self._h, _p(punct), n, _p(mask), nsteps, _p(out)), "dabgpu_viterbi")
+        _check(self._lib.dabgpu_viterbi(self._h, _p(punct), n, _p(mask), nsteps, _p(out)), "dabgpu_viterbi")
         return out
 
     # ---- device pointers (ints), enqueue only
     def ofdm_demod_frames_dev(self, d_iq, frame_stride, n_frames, d_freq_offset, d_soft, d_cyc=None, d_dqpsk=None,
                               stream=None):
-        _check(lib().dabgpu_ofdm_demod_frames_dev(self._h, d_iq, frame_stride, n_frames, d_freq_offset, d_soft,
+        _check(self._lib.dabgpu_ofdm_demod_frames_dev(self._h, d_iq, frame_stride, n_frames, d_freq_offset, d_soft,
                                                   d_cyc, d_dqpsk, stream), "dabgpu_ofdm_demod_frames_dev")
 
     def sync_prs_dev(self, d_iq, frame_stride, n_frames, d_freq_offset, max_coarse, d_out, stream=None):
         """d_out: [n_frames] dabgpu_sync_result (4 x 32 bit: coarse_carriers, time_offset, peak_to_mean, coarse ptm)."""
-        _check(lib().dabgpu_sync_prs_dev(self._h, d_iq, frame_stride, n_frames, d_freq_offset, max_coarse, d_out, stream),
+        _check(self._lib.dabgpu_sync_prs_dev(self._h, d_iq, frame_stride, n_frames, d_freq_offset, max_coarse, d_out, stream),
                "dabgpu_sync_prs_dev")
 
     def fft_symbols_dev(self, d_iq, frame_stride, n_frames, d_freq_offset, d_spectra, stream=None):
-        _check(lib().dabgpu_fft_symbols_dev(self._h, d_iq, frame_stride, n_frames, d_freq_offset, d_spectra, stream),
+        _check(self._lib.dabgpu_fft_symbols_dev(self._h, d_iq, frame_stride, n_frames, d_freq_offset, d_spectra, stream),
                "dabgpu_fft_symbols_dev")
 
     def fic_decode_dev(self, d_soft, soft_stride, n_frames, d_fib, d_crc_ok, stream=None):
-        _check(lib().dabgpu_fic_decode_dev(self._h, d_soft, soft_stride, n_frames, d_fib, d_crc_ok, stream),
+        _check(self._lib.dabgpu_fic_decode_dev(self._h, d_soft, soft_stride, n_frames, d_fib, d_crc_ok, stream),
                "dabgpu_fic_decode_dev")
 
     def msc_decode_multi_dev(self, scs, d_soft, soft_stride, n_streams, frames_per_stream, d_hist_in, d_hist_out, d_out,
@@ -542,7 +549,7 @@ class Context:
                 return None
             return (C.c_void_p * n)(*[C.c_void_p(x) if x else None for x in lst])
         hi, ho, out = ptrs(d_hist_in), ptrs(d_hist_out), ptrs(d_out)
-        _check(lib().dabgpu_msc_decode_multi_dev(self._h, arr, n, d_soft, soft_stride, n_streams, frames_per_stream,
+        _check(self._lib.dabgpu_msc_decode_multi_dev(self._h, arr, n, d_soft, soft_stride, n_streams, frames_per_stream,
                                                  hi, ho, out, stream), "dabgpu_msc_decode_multi_dev")
 
     def decode_frames_dev(self, d_soft, soft_stride, n_streams, frames_per_stream, d_fib, d_crc_ok, scs, d_hist_in, d_hist_out,
@@ -554,11 +561,11 @@ class Context:
             if lst is None or n == 0:
                 return None
             return (C.c_void_p * n)(*[C.c_void_p(x) if x else None for x in lst])
-        _check(lib().dabgpu_decode_frames_dev(self._h, d_soft, soft_stride, n_streams, frames_per_stream, d_fib, d_crc_ok,
+        _check(self._lib.dabgpu_decode_frames_dev(self._h, d_soft, soft_stride, n_streams, frames_per_stream, d_fib, d_crc_ok,
                                               arr, n, ptrs(d_hist_in), ptrs(d_hist_out), ptrs(d_out), stream),
                "dabgpu_decode_frames_dev")
 
     def msc_decode_dev(self, sc, d_soft, soft_stride, n_streams, frames_per_stream, d_hist_in, d_hist_out, d_out,
                        stream=None):
-        _check(lib().dabgpu_msc_decode_dev(self._h, C.byref(sc), d_soft, soft_stride, n_streams, frames_per_stream,
+        _check(self._lib.dabgpu_msc_decode_dev(self._h, C.byref(sc), d_soft, soft_stride, n_streams, frames_per_stream,
                                            d_hist_in, d_hist_out, d_out, stream), "dabgpu_msc_decode_dev")

@@ -19,3 +19,13 @@ def t(fn, reps=10):
     e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / reps * 1e3
 print("lib", os.environ.get("DABGPU_LIB", "default"), "fic us %.1f" % t(lambda: ctx.fic_decode_dev(soft.data_ptr(), dabgpu.NB_FRAME_BITS, n, fib.data_ptr(), crc.data_ptr(), s)),
       "msc us %.1f" % t(lambda: ctx.msc_decode_dev(sc, soft.data_ptr(), dabgpu.NB_FRAME_BITS, E, F, None, None, msc.data_ptr(), s)))
+# the bench's grouped call: FIC + one sub-channel in one launch pair
+print("   grouped FIC+1 sub-channel us %.1f" % t(lambda: ctx.decode_frames_dev(soft.data_ptr(), dabgpu.NB_FRAME_BITS, E, F, fib.data_ptr(), crc.data_ptr(), [sc], None, None, [msc.data_ptr()], s)))
+# FIC + a full multiplex (18 sub-channels, 856 CUs) in grouped launches
+scs, cu = [], 0
+for br, lvl, k in ((64, 3, 10), (48, 3, 4), (32, 2, 3)):
+    for _ in range(k):
+        x = dabgpu.subchannel(cu, br, level=lvl); scs.append(x); cu += x.length
+scs.append(dabgpu.uep_subchannel(35, cu))
+outs = [torch.zeros((E, F * 4, x.bitrate_kbps * 3), dtype=torch.uint8, device=dev) for x in scs]
+print("   grouped FIC+18 sub-channels us %.1f" % t(lambda: ctx.decode_frames_dev(soft.data_ptr(), dabgpu.NB_FRAME_BITS, E, F, fib.data_ptr(), crc.data_ptr(), scs, None, None, [o.data_ptr() for o in outs], s), reps=3))
