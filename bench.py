@@ -42,14 +42,52 @@ ACS_FIC = 4 * 774 * 64                    # add-compare-selects per frame, FIC (
 ACS_MSC64 = 4 * 1542 * 64                 # one 64 kbit/s EEP 3-A subchannel (A12)
 
 
-def make_streams(torch, dev, ids, n_frames, n_unique, snr_db):
-    """IQ of the ensembles `ids` (global ids): [len(ids)][n_frames][196608] cf32 on the device, the carrier offsets
-    the channel applied (kept on the host, for the CPU baseline only) and the transmitted multiplexes."""
+def place_buffers(torch, dabgpu, ctx, dev, E, F, n_candidates, stream, decode):
+    """Where the IQ and soft-bit buffers of this rank live.  MI355X's HBM behaves as three domains of 96 GB (large
+    contiguous address ranges; profiles/r02_hbm_domains.txt maps them): a launch that reads from and writes to the SAME
+    domain pays ~12 % for the read/write turn-arounds (5.7 instead of 5.0 ms for a data mover of this kernel's shape),
+    while reading alone or writing alone runs at the same rate everywhere.  Which domain an allocation lands in is the
+    driver's choice, so -- as a long-running service would at start-up -- allocate a few candidates, time one whole
+    step (front end + channel decoder, on noise) on every (input, output) pair, keep the fastest pair and free the
+    rest.  Untimed set-up, reported in `config`; `--placement-candidates 1` takes the first allocation instead."""
+    L, n_frames = dabgpu.NB_FRAME_SAMPLES, E * F
+    iqs = [torch.zeros((n_frames, L), dtype=torch.complex64, device=dev) for _ in range(n_candidates)]
+    softs = [torch.zeros((n_frames, dabgpu.NB_FRAME_BITS), dtype=torch.int8, device=dev) for _ in range(n_candidates)]
+    if n_candidates == 1:
+        return iqs[0], softs[0], None
+    for iq in iqs:
+        torch.view_as_real(iq).normal_()
+    fo = torch.zeros((n_frames,), dtype=torch.float32, device=dev)
+    cyc = torch.zeros((n_frames, 76), dtype=torch.complex64, device=dev)
+    table = []
+    for iq in iqs:
+        row = []
+        for soft in softs:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            for k in range(3):
+                if k == 1:
+                    ev[0].record()
+                ctx.ofdm_demod_frames_dev(iq.data_ptr(), L, n_frames, fo.data_ptr(), soft.data_ptr(), cyc.data_ptr(), None, stream)
+                decode(soft)
+            ev[1].record()
+            torch.cuda.synchronize()
+            row.append(ev[0].elapsed_time(ev[1]) / 2)
+        table.append(row)
+    i, j = min(((a, b) for a in range(n_candidates) for b in range(n_candidates)), key=lambda ab: table[ab[0]][ab[1]])
+    iq, soft = iqs[i], softs[j]
+    del iqs, softs, fo, cyc
+    torch.cuda.empty_cache()
+    return iq, soft, {"candidates": n_candidates, "probe_step_ms": [[round(x, 3) for x in r] for r in table], "kept": [i, j]}
+
+
+def make_streams(torch, dev, ids, n_frames, n_unique, snr_db, iq):
+    """Fills `iq` ([len(ids) * n_frames][196608] cf32 on the device) with the ensembles `ids` (global ids); returns the
+    carrier offsets the channel applied (kept on the host, for the CPU baseline only) and the transmitted multiplexes."""
     from dabgpu import synth
     ens = [synth.Ensemble(seed=0xDAB00000 + u, n_frames=4) for u in range(n_unique)]
     base = torch.from_numpy(np.stack([e.iq() for e in ens])).to(dev)        # [U][4][196608]
     n = torch.arange(synth.NB_FRAME_SAMPLES * n_frames, device=dev, dtype=torch.float64)
-    iq = torch.empty((len(ids), n_frames, synth.NB_FRAME_SAMPLES), dtype=torch.complex64, device=dev)
+    iq = iq.view(len(ids), n_frames, synth.NB_FRAME_SAMPLES)
     sigma = float(np.sqrt(0.5 * 10 ** (-snr_db / 10)))
     cfos = []
     for s, gid in enumerate(ids):
@@ -63,7 +101,7 @@ def make_streams(torch, dev, ids, n_frames, n_unique, snr_db):
         noise = torch.randn(clean.shape, generator=g, device=dev, dtype=torch.float32) + \
             1j * torch.randn(clean.shape, generator=g, device=dev, dtype=torch.float32)
         iq[s] = (clean * rot + sigma * noise).reshape(n_frames, -1)
-    return iq, np.asarray(cfos), [ens[gid % n_unique] for gid in ids]
+    return np.asarray(cfos), [ens[gid % n_unique] for gid in ids]
 
 
 def copy_ceiling(torch, dev):
@@ -173,6 +211,8 @@ def main():
     ap.add_argument("--no-fft-stage", action="store_true", help="skip the unfused FFT-stage measurement")
     ap.add_argument("--no-selective", action="store_true", help="skip the extra selective-soft-output measurement")
     ap.add_argument("--no-closed-loop", action="store_true", help="skip the unaligned-capture closed-loop measurement")
+    ap.add_argument("--placement-candidates", type=int, default=3,
+                    help="IQ / soft-bit buffer candidates timed at set-up, the fastest pair is kept (1 = take the first)")
     args = ap.parse_args()
 
     import torch
@@ -205,8 +245,11 @@ def main():
     E, F = args.ensembles, args.frames
     n_frames = E * F
     ids = ensembles_of_rank(E * world, world, rank)              # this rank's share of the global ensemble list
-    iq, cfo_true, ens = make_streams(torch, dev, ids, F, min(args.unique, E * world), args.snr)
-    soft = torch.empty((n_frames, dabgpu.NB_FRAME_BITS), dtype=torch.int8, device=dev)
+    ctx = dabgpu.Context(device=dev_index, max_frames=n_frames)
+    torch.cuda.synchronize()
+    tstream = torch.cuda.Stream(device=dev)      # non-null handle: the C ABI treats NULL as "context stream"
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
     fib = torch.zeros((n_frames, 12, 32), dtype=torch.uint8, device=dev)
     crc = torch.zeros((n_frames, 12), dtype=torch.uint8, device=dev)
     sc = dabgpu.subchannel(0, 64, level=3)
@@ -214,11 +257,17 @@ def main():
     hist = [torch.zeros((E, 15, sc.length * 64), dtype=torch.int8, device=dev) for _ in range(2)]
     cyc = torch.zeros((n_frames, 76), dtype=torch.complex64, device=dev)
 
-    ctx = dabgpu.Context(device=dev_index, max_frames=n_frames)
-    torch.cuda.synchronize()
-    tstream = torch.cuda.Stream(device=dev)      # non-null handle: the C ABI treats NULL as "context stream"
-    torch.cuda.set_stream(tstream)
-    stream = tstream.cuda_stream
+    def decode_into(soft_buf, k=0):
+        # FIC + the sub-channel of every frame: what BasicRadio::Process does, one call for the batch
+        ctx.decode_frames_dev(soft_buf.data_ptr(), dabgpu.NB_FRAME_BITS, E, F, fib.data_ptr(), crc.data_ptr(), [sc],
+                              [hist[k & 1].data_ptr()], [hist[(k & 1) ^ 1].data_ptr()], [msc.data_ptr()], stream)
+
+    iq, soft, placement = place_buffers(torch, dabgpu, ctx, dev, E, F, max(1, args.placement_candidates), stream, decode_into)
+    cfo_true, ens = make_streams(torch, dev, ids, F, min(args.unique, E * world), args.snr, iq)
+    iq = iq.view(E, F, synth.NB_FRAME_SAMPLES)
+    for h in hist:
+        h.zero_()
+
     d_iq = iq.data_ptr() + synth.NB_NULL * 8          # first PRS sample of frame 0
     ofdm_ev, dec_ev = [], []
     BETA = 0.9                                        # fine_freq_update_beta, the reference's default order of magnitude
@@ -239,9 +288,7 @@ def main():
         ctx.ofdm_demod_streams_dev(d_iq, synth.NB_FRAME_SAMPLES, E, F, BETA, soft.data_ptr(), cyc.data_ptr(), None, stream)
         if timed:
             ev[1].record()
-        # FIC + the sub-channel of every frame: what BasicRadio::Process does, one call for the batch
-        ctx.decode_frames_dev(soft.data_ptr(), dabgpu.NB_FRAME_BITS, E, F, fib.data_ptr(), crc.data_ptr(), [sc],
-                              [hist[k & 1].data_ptr()], [hist[(k & 1) ^ 1].data_ptr()], [msc.data_ptr()], stream)
+        decode_into(soft, k)
         if timed:
             ev[2].record()
             ofdm_ev.append((ev[0], ev[1])); dec_ev.append((ev[1], ev[2]))
@@ -316,7 +363,8 @@ def main():
                        "carrier_offset": "unknown to the receiver: k + f carriers per ensemble, |k| <= 3, |f| <= 0.4",
                        "frequency_correction": "closed loop on the device (dabgpu_ofdm_demod_streams_dev): coarse from the first PRS, "
                                                "fine from the cyclic-prefix correlations of the previous call",
-                       "sharding": "independent ensembles per rank (global id % world == rank), no data-path collective"},
+                       "sharding": "independent ensembles per rank (global id % world == rank), no data-path collective",
+                       "buffer_placement": placement if placement is not None else "first allocation taken"},
             "x_realtime": value / REALTIME_FPS,
             "fic_bit_exact": fic_ok, "msc_bit_exact": msc_ok,
             "fine_loop_residual_carriers": loop_residual,
