@@ -51,6 +51,9 @@ def place_buffers(torch, dabgpu, ctx, dev, E, F, n_candidates, stream, decode):
     step (front end + channel decoder, on noise) on every (input, output) pair, keep the fastest pair and free the
     rest.  Untimed set-up, reported in `config`; `--placement-candidates 1` takes the first allocation instead."""
     L, n_frames = dabgpu.NB_FRAME_SAMPLES, E * F
+    pair_bytes = n_frames * (L * 8 + dabgpu.NB_FRAME_BITS)
+    free_bytes = torch.cuda.mem_get_info(dev)[0]
+    n_candidates = max(1, min(n_candidates, int(0.6 * free_bytes // pair_bytes)))   # the later legs need room as well
     iqs = [torch.zeros((n_frames, L), dtype=torch.complex64, device=dev) for _ in range(n_candidates)]
     softs = [torch.zeros((n_frames, dabgpu.NB_FRAME_BITS), dtype=torch.int8, device=dev) for _ in range(n_candidates)]
     if n_candidates == 1:
