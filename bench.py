@@ -42,45 +42,23 @@ ACS_FIC = 4 * 774 * 64                    # add-compare-selects per frame, FIC (
 ACS_MSC64 = 4 * 1542 * 64                 # one 64 kbit/s EEP 3-A subchannel (A12)
 
 
-def place_buffers(torch, dabgpu, ctx, dev, E, F, n_candidates, stream, decode):
+def place_buffers(torch, dabgpu, ctx, dev, n_frames, n_candidates):
     """Where the IQ and soft-bit buffers of this rank live.  MI355X's HBM behaves as three domains of 96 GB (large
     contiguous address ranges; profiles/r02_hbm_domains.txt maps them): a launch that reads from and writes to the SAME
     domain pays ~12 % for the read/write turn-arounds (5.7 instead of 5.0 ms for a data mover of this kernel's shape),
     while reading alone or writing alone runs at the same rate everywhere.  Which domain an allocation lands in is the
-    driver's choice, so -- as a long-running service would at start-up -- allocate a few candidates, time one whole
-    step (front end + channel decoder, on noise) on every (input, output) pair, keep the fastest pair and free the
-    rest.  Untimed set-up, reported in `config`; `--placement-candidates 1` takes the first allocation instead."""
-    L, n_frames = dabgpu.NB_FRAME_SAMPLES, E * F
-    pair_bytes = n_frames * (L * 8 + dabgpu.NB_FRAME_BITS)
-    free_bytes = torch.cuda.mem_get_info(dev)[0]
-    n_candidates = max(1, min(n_candidates, int(0.6 * free_bytes // pair_bytes)))   # the later legs need room as well
-    iqs = [torch.zeros((n_frames, L), dtype=torch.complex64, device=dev) for _ in range(n_candidates)]
-    softs = [torch.zeros((n_frames, dabgpu.NB_FRAME_BITS), dtype=torch.int8, device=dev) for _ in range(n_candidates)]
-    if n_candidates == 1:
-        return iqs[0], softs[0], None
-    for iq in iqs:
-        torch.view_as_real(iq).normal_()
-    fo = torch.zeros((n_frames,), dtype=torch.float32, device=dev)
-    cyc = torch.zeros((n_frames, 76), dtype=torch.complex64, device=dev)
-    table = []
-    for iq in iqs:
-        row = []
-        for soft in softs:
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-            for k in range(3):
-                if k == 1:
-                    ev[0].record()
-                ctx.ofdm_demod_frames_dev(iq.data_ptr(), L, n_frames, fo.data_ptr(), soft.data_ptr(), cyc.data_ptr(), None, stream)
-                decode(soft)
-            ev[1].record()
-            torch.cuda.synchronize()
-            row.append(ev[0].elapsed_time(ev[1]) / 2)
-        table.append(row)
-    i, j = min(((a, b) for a in range(n_candidates) for b in range(n_candidates)), key=lambda ab: table[ab[0]][ab[1]])
-    iq, soft = iqs[i], softs[j]
-    del iqs, softs, fo, cyc
-    torch.cuda.empty_cache()
-    return iq, soft, {"candidates": n_candidates, "probe_step_ms": [[round(x, 3) for x in r] for r in table], "kept": [i, j]}
+    driver's choice, so -- as a long-running service would at start-up -- the library allocates a few candidates,
+    times the front-end launch on every (input, output) pair, keeps the fastest pair and frees the rest
+    (dabgpu_alloc_frame_buffers).  Untimed set-up, reported in `config`; `--placement-candidates 1` is a plain
+    allocation."""
+    L = dabgpu.NB_FRAME_SAMPLES
+    d_iq, d_soft, table, kept = ctx.alloc_frame_buffers(n_frames, L, n_candidates)
+    iq = dabgpu.device_tensor(torch, d_iq, (n_frames, L), torch.complex64, dev)
+    soft = dabgpu.device_tensor(torch, d_soft, (n_frames, dabgpu.NB_FRAME_BITS), torch.int8, dev)
+    report = None
+    if table is not None:
+        report = {"candidates": n_candidates, "probe_front_end_ms": [[round(float(x), 3) for x in r] for r in table], "kept": list(kept)}
+    return iq, soft, report
 
 
 def make_streams(torch, dev, ids, n_frames, n_unique, snr_db, iq):
@@ -265,7 +243,7 @@ def main():
         ctx.decode_frames_dev(soft_buf.data_ptr(), dabgpu.NB_FRAME_BITS, E, F, fib.data_ptr(), crc.data_ptr(), [sc],
                               [hist[k & 1].data_ptr()], [hist[(k & 1) ^ 1].data_ptr()], [msc.data_ptr()], stream)
 
-    iq, soft, placement = place_buffers(torch, dabgpu, ctx, dev, E, F, max(1, args.placement_candidates), stream, decode_into)
+    iq, soft, placement = place_buffers(torch, dabgpu, ctx, dev, n_frames, max(1, min(8, args.placement_candidates)))
     cfo_true, ens = make_streams(torch, dev, ids, F, min(args.unique, E * world), args.snr, iq)
     iq = iq.view(E, F, synth.NB_FRAME_SAMPLES)
     for h in hist:
@@ -460,6 +438,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(iq_h, fo_h, sc.length * 64, ens[0].mask, 64 * 24 + 6, args.cpu_seconds,
                                                len(os.sched_getaffinity(0)) or 1)
         print(json.dumps(out))
+    d_bufs = (iq.data_ptr(), soft.data_ptr())
+    del iq, soft
+    ctx.free_frame_buffers(*d_bufs)
     ctx.close()
     if dist is not None:
         dist.barrier()

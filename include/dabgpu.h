@@ -132,6 +132,20 @@ void *dabgpu_stream(dabgpu_ctx *ctx);
 void *dabgpu_host_alloc(size_t bytes);
 void dabgpu_host_free(void *p);
 
+/* Device buffers for a batch user's IQ samples ([n_frames][frame_stride] cf32, frame_stride >= 196608 samples) and
+ * soft bits ([n_frames][230400] int8), placed for the front end: MI355X's HBM behaves as three domains of 96 GB, and
+ * a launch that reads its samples from the domain it writes its soft bits to runs ~12 % slower than one whose two
+ * streams are apart (profiles/r02_hbm_domains.txt).  Where hipMalloc puts a buffer is not visible, so
+ * this call allocates `candidates` (1..8, clamped to what fits in free memory) buffers of each kind, times the
+ * front-end launch on every (input, output) pair, keeps the fastest pair and frees the rest.  A set-up call: it
+ * synchronises, takes a few hundred milliseconds and leaves noise in the IQ buffer.  probe_ms (may be NULL) receives
+ * the candidates x candidates table of launch times, row = input candidate; kept (may be NULL) the chosen pair.
+ * candidates == 1 is a plain allocation.  Any device buffer is accepted by the _dev entry points; this is an
+ * optimisation for callers that own their buffers.  Release with dabgpu_free_frame_buffers (either may be NULL). */
+int dabgpu_alloc_frame_buffers(dabgpu_ctx *ctx, int n_frames, size_t frame_stride, int candidates, void **d_iq,
+                               int8_t **d_soft, float *probe_ms, int *kept);
+int dabgpu_free_frame_buffers(dabgpu_ctx *ctx, void *d_iq, int8_t *d_soft);
+
 /* ------------------------------------------------------------------------ */
 /* A2..A6: OFDM front end on time-aligned frames.                             */
 /* Replaces the READING_SYMBOLS work of OFDM_Demod::Process                    */

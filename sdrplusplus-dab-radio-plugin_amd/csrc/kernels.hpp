@@ -59,6 +59,8 @@ hipError_t launch_fft_symbols(const OfdmTables &t, const OfdmArgs &a, int parts,
 // per stream, fine -= beta * mean(arg cyc[frame][symbol]) / (2*pi*2048), wrapped to +-half a carrier; frame count;
 // L1 level of the stream's last frame (first 4096 samples) into the running average, counted as a desync when it
 // is below thr_null_start times the average so far.
+// noise-like floats in [0.5, 1) with random signs: timing probes must not run on zeros (they move ~6 % faster)
+hipError_t launch_fill_noise(void *p, size_t bytes, hipStream_t s);
 hipError_t launch_stream_update(StreamState *state, const float2 *cyc, const float2 *iq, size_t frame_stride,
                                 int n_streams, int frames_per_stream, float beta, float thr_null_start, hipStream_t s);
 

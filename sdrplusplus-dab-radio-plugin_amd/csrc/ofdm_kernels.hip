@@ -510,6 +510,22 @@ __global__ __launch_bounds__(SU_THREADS) void stream_update_kernel(StreamState *
 
 }  // namespace
 
+namespace {
+__global__ __launch_bounds__(256) void fill_noise_kernel(uint32_t *p, size_t n) {
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
+        uint32_t x = uint32_t(i) * 2654435761u + uint32_t(i >> 32) * 40503u + 12345u;
+        x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+        p[i] = (x & 0x807fffffu) | 0x3f000000u;
+    }
+}
+}  // namespace
+
+hipError_t launch_fill_noise(void *p, size_t bytes, hipStream_t s) {
+    if (bytes < 4) return hipSuccess;
+    hipLaunchKernelGGL(fill_noise_kernel, dim3(4096), dim3(256), 0, s, static_cast<uint32_t *>(p), bytes / 4);
+    return hipGetLastError();
+}
+
 hipError_t launch_stream_update(StreamState *state, const float2 *cyc, const float2 *iq, size_t frame_stride,
                                 int n_streams, int frames_per_stream, float beta, float thr_null_start, hipStream_t s) {
     if (n_streams <= 0 || frames_per_stream <= 0) return hipSuccess;

@@ -38,7 +38,7 @@ EXPORTS = [
     "dabgpu_host_alloc", "dabgpu_host_free", "dabgpu_decode_frames_dev", "dabgpu_decode_frames",
     "dabgpu_streams_reset", "dabgpu_stream_states", "dabgpu_set_stream_offsets", "dabgpu_ofdm_demod_streams_dev",
     "dabgpu_ofdm_demod_streams", "dabgpu_get_stats", "dabgpu_mean_kernel_ms", "dabgpu_decode_stream_frames",
-    "dabgpu_decode_stream_reset",
+    "dabgpu_decode_stream_reset", "dabgpu_alloc_frame_buffers", "dabgpu_free_frame_buffers",
 ]
 
 ABI_VERSION = 2
@@ -181,6 +181,8 @@ def load_library(path):
     L.dabgpu_ofdm_demod_acquired_dev.argtypes = [vp, vp, sz, i, i, vp, vp, vp, vp, vp]
     L.dabgpu_last_kernel_ms.argtypes = [vp, i, C.POINTER(C.c_float)]
     L.dabgpu_mean_kernel_ms.argtypes = [vp, i, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    L.dabgpu_alloc_frame_buffers.argtypes = [vp, i, sz, i, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_float), C.POINTER(i)]
+    L.dabgpu_free_frame_buffers.argtypes = [vp, vp, vp]
     L.dabgpu_get_prs_reference.argtypes = [i, vp, i]
     L.dabgpu_get_mapper_reference.argtypes = [vp, i, i]
     return L
@@ -275,6 +277,18 @@ class PinnedArray:
             pass
 
 
+def device_tensor(torch, address, shape, dtype, device):
+    """A torch tensor over device memory this library (or anybody else) owns -- no copy, no ownership: the memory must
+    outlive the tensor.  Goes through __cuda_array_interface__, which torch's HIP build honours."""
+    typestr = {torch.int8: "|i1", torch.uint8: "|u1", torch.float32: "<f4", torch.int32: "<i4", torch.complex64: "<c8"}[dtype]
+
+    class _Span:
+        pass
+    span = _Span()
+    span.__cuda_array_interface__ = {"shape": tuple(int(x) for x in shape), "typestr": typestr, "data": (int(address), False), "version": 2}
+    return torch.as_tensor(span, device=device)
+
+
 def uep_subchannel(table_index, start_address):
     """UEP subchannel descriptor from the protection-profile table index (FIG 0/1 short form)."""
     sc = Subchannel()
@@ -332,6 +346,21 @@ class Context:
         return ms.value, n.value
 
     # ---- closed-loop stream call
+    def alloc_frame_buffers(self, n_frames, frame_stride=NB_FRAME_SAMPLES, candidates=3):
+        """Device buffers for [n_frames][frame_stride] cf32 samples and [n_frames][230400] soft bits whose HBM
+        placement suits the front end (dabgpu_alloc_frame_buffers).  Returns (d_iq, d_soft, probe table or None, kept
+        pair): raw device addresses; release with free_frame_buffers."""
+        d_iq, d_soft = C.c_void_p(), C.c_void_p()
+        table = (C.c_float * (candidates * candidates))()
+        kept = (C.c_int * 2)()
+        _check(self._lib.dabgpu_alloc_frame_buffers(self._h, n_frames, frame_stride, candidates, C.byref(d_iq), C.byref(d_soft),
+                                                    table, kept), "dabgpu_alloc_frame_buffers")
+        t = np.array(table, dtype=np.float32).reshape(candidates, candidates)
+        return d_iq.value, d_soft.value, (t if candidates > 1 else None), (int(kept[0]), int(kept[1]))
+
+    def free_frame_buffers(self, d_iq, d_soft):
+        _check(self._lib.dabgpu_free_frame_buffers(self._h, d_iq, d_soft), "dabgpu_free_frame_buffers")
+
     def streams_reset(self, n_streams):
         _check(self._lib.dabgpu_streams_reset(self._h, n_streams), "dabgpu_streams_reset")
 

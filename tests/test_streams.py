@@ -188,3 +188,36 @@ def test_stream_decoder_drops_a_ring_that_missed_a_frame(built, ensemble, ensemb
     ref_b = c.decode_frames(soft[3:4], 1, [b])[2][0][0]  # b as if the stream began at frame 3
     assert (out3[0][0] == ref_a[12:]).all() and (out3[1][0] == ref_b).all()
     c.close()
+
+
+def test_alloc_frame_buffers_returns_a_usable_pair(built, ensemble, ensemble_iq):
+    """dabgpu_alloc_frame_buffers: candidates are timed, one (IQ, soft) pair is kept; the buffers hold whole frames
+    (null symbol included) and the front end run on them gives the soft bits of the host-pointer call."""
+    import torch
+    L = dabgpu.NB_FRAME_SAMPLES
+    rx = synth.channel(ensemble_iq.ravel(), snr_db=18.0, cfo=0.0, rng=np.random.default_rng(5)).reshape(ensemble_iq.shape)
+    n = rx.shape[0]
+    c = make_ctx(None, 8)
+    ref, _, _ = c.ofdm_demod_frames(np.ascontiguousarray(rx[:, synth.NB_NULL:]))
+    d_iq, d_soft, table, kept = c.alloc_frame_buffers(n, L, 2)
+    assert d_iq and d_soft and table.shape == (2, 2) and (table > 0).all() and kept[0] in (0, 1) and kept[1] in (0, 1)
+    dev = torch.device("cuda", 0)
+    iq = dabgpu.device_tensor(torch, d_iq, (n, L), torch.complex64, dev)
+    soft = dabgpu.device_tensor(torch, d_soft, (n, dabgpu.NB_FRAME_BITS), torch.int8, dev)
+    assert iq.data_ptr() == d_iq and soft.data_ptr() == d_soft
+    iq.copy_(torch.from_numpy(rx.astype(np.complex64)).to(dev))
+    torch.cuda.synchronize()
+    c.ofdm_demod_frames_dev(d_iq + synth.NB_NULL * 8, L, n, None, d_soft)
+    c.sync()
+    assert (soft.cpu().numpy() == ref).all()
+    del iq, soft
+    c.free_frame_buffers(d_iq, d_soft)
+    one = c.alloc_frame_buffers(n, L, 1)
+    assert one[2] is None and one[3] == (0, 0)
+    c.free_frame_buffers(one[0], one[1])
+    for bad in (dict(n_frames=0), dict(candidates=0), dict(candidates=9), dict(frame_stride=L - 2), dict(frame_stride=L + 1)):
+        kw = dict(n_frames=n, frame_stride=L, candidates=2)
+        kw.update(bad)
+        with pytest.raises(dabgpu.DabGpuError):
+            c.alloc_frame_buffers(kw["n_frames"], kw["frame_stride"], kw["candidates"])
+    c.close()
