@@ -192,8 +192,9 @@ def main():
     ap.add_argument("--no-fft-stage", action="store_true", help="skip the unfused FFT-stage measurement")
     ap.add_argument("--no-selective", action="store_true", help="skip the extra selective-soft-output measurement")
     ap.add_argument("--no-closed-loop", action="store_true", help="skip the unaligned-capture closed-loop measurement")
-    ap.add_argument("--placement-candidates", type=int, default=3,
-                    help="IQ / soft-bit buffer candidates timed at set-up, the fastest pair is kept (1 = take the first)")
+    ap.add_argument("--placement-candidates", type=int, default=4,
+                    help="IQ / soft-bit buffer candidates timed at set-up, the fastest pair is kept (1 = plain allocation); "
+                         "four pairs of the default shape span 118 GB, more than one 96 GB HBM domain")
     args = ap.parse_args()
 
     import torch
