@@ -10,6 +10,7 @@
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 constexpr int SYM = 2552 * 8, NULLB = 2656 * 8;
 
+template <int SLEEP>
 __global__ __launch_bounds__(256) void mover(const char *in, char *out, int n_items, size_t in_stride, size_t out_stride) {
     const int lane = threadIdx.x & 63;
     const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -26,6 +27,9 @@ __global__ __launch_bounds__(256) void mover(const char *in, char *out, int n_it
         for (int i = 0; i < 20; i++) if (i < 19 || lane < 60) v[i] = __builtin_nontemporal_load(p + 64 * i); else v[i] = acc;
 #pragma unroll
         for (int i = 0; i < 20; i++) acc += v[i];
+        // stand-in for the arithmetic of a symbol: the wave has nothing in flight for SLEEP x 1024 cycles
+#pragma unroll
+        for (int k = 0; k < SLEEP; k++) __builtin_amdgcn_s_sleep(16);
         if (l > l_first) {
             v4u *o = reinterpret_cast<v4u *>(fout + size_t(l - 1) * 3072) + lane;
 #pragma unroll
@@ -44,12 +48,13 @@ __global__ void fill_noise(unsigned *p, size_t n) {
 }
 
 static hipEvent_t e0, e1;
+template <int SLEEP = 0>
 float run(const char *in, char *out, int n_frames, size_t in_stride, size_t out_stride) {
     const int n_items = 3 * n_frames;
     float best = 1e9f;
     for (int rep = 0; rep < 4; rep++) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL(mover, dim3(unsigned((n_items + 3) / 4)), dim3(256), 51 * 1024, 0, in, out, n_items, in_stride, out_stride);
+        hipLaunchKernelGGL(mover<SLEEP>, dim3(unsigned((n_items + 3) / 4)), dim3(256), 51 * 1024, 0, in, out, n_items, in_stride, out_stride);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float t; hipEventElapsedTime(&t, e0, e1);
         if (rep > 0 && t < best) best = t;
@@ -71,6 +76,14 @@ int main(int argc, char **argv) {
     }
     const size_t ipads[] = {0, 256, 1024, 4096, 4096 + 256, 16384, 20416, 65536 + 256, 262144, 524288 + 4096 + 256};
     const size_t opads[] = {0, 256, 1024, 2048, 3072, 4096 + 256, 31744 /* -> 262144 */, 65536 + 256};
+    // a wave that computes between its loads has nothing in flight meanwhile: the same mover with s_sleep between a
+    // symbol's loads and the next symbol's (1024 cycles per unit), on every buffer pair
+    for (int k = 0; k < K; k++)
+        printf("pair %d, idle 0 / 2 / 4 / 6 / 8 / 12 / 16 x 1024 cycles per symbol: %.3f %.3f %.3f %.3f %.3f %.3f %.3f ms\n", k,
+               run<0>(in[k], out[k], n, FR, SO), run<2>(in[k], out[k], n, FR, SO), run<4>(in[k], out[k], n, FR, SO),
+               run<6>(in[k], out[k], n, FR, SO), run<8>(in[k], out[k], n, FR, SO), run<12>(in[k], out[k], n, FR, SO),
+               run<16>(in[k], out[k], n, FR, SO));
+    if (argc > 2) return 0;
     for (int k = 0; k < K; k++) {
         printf("%s input, buffer pair %d: rows = input frame stride 1572864 + pad, columns = output frame stride 230400 + pad; ms per 16384 frames\n      ", noise ? "noise" : "zero", k);
         for (size_t op : opads) printf(" %7zu", op);
