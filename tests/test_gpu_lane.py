@@ -230,3 +230,40 @@ def test_bench_shape_grouped_launch_equals_the_oracle_on_noise():
     # and the ring it leaves behind is the stream's last 15 CIFs
     assert (hout.cpu().numpy() == sub[:, -15:]).all()
     c.close()
+
+
+def test_more_sub_channels_than_one_grouped_launch_holds():
+    """30 sub-channels: the grouped launches carry 16 (lane kernels) or 24 (wave kernels) entries, longer lists are cut
+    into several launches.  Same bytes and history rings whichever family decodes them, and the same as one call per
+    sub-channel; the stream decoder (one frame per call, rings on the device) agrees as well."""
+    n_streams, fps = 1, 16
+    scs = [dabgpu.subchannel(6 * i, 8, level=3) for i in range(30)]
+    assert all(sc.length == 6 for sc in scs)
+    n = n_streams * fps
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev); g.manual_seed(4242)
+    soft = torch.randint(-127, 128, (n, dabgpu.NB_FRAME_BITS), dtype=torch.int8, device=dev, generator=g)
+    res = []
+    for mode in (0, 1):
+        c = make_ctx(mode, max_frames=8)
+        outs = [torch.zeros((n_streams, fps * 4, sc.bitrate_kbps * 3), dtype=torch.uint8, device=dev) for sc in scs]
+        hout = [torch.zeros((n_streams, 15, sc.length * 64), dtype=torch.int8, device=dev) for sc in scs]
+        c.msc_decode_multi_dev(scs, soft.data_ptr(), dabgpu.NB_FRAME_BITS, n_streams, fps, None,
+                               [h.data_ptr() for h in hout], [o.data_ptr() for o in outs], None)
+        c.sync()
+        res.append(([o.cpu().numpy() for o in outs], [h.cpu().numpy() for h in hout]))
+        c.close()
+    c = make_ctx(0, max_frames=8)
+    soft_h = soft.cpu().numpy()
+    for i, sc in enumerate(scs):
+        assert (res[0][0][i] == res[1][0][i]).all() and (res[0][1][i] == res[1][1][i]).all(), i
+        one, hist = c.msc_decode(sc, soft_h, n_streams, want_history=True)
+        assert (one == res[0][0][i]).all() and (hist == res[0][1][i]).all(), i
+    streamed = [[] for _ in scs]
+    for f in range(fps):
+        _, _, outs = c.decode_stream_frames(soft_h[f:f + 1], scs)
+        for i in range(len(scs)):
+            streamed[i].append(outs[i][0])
+    for i in range(len(scs)):
+        assert (np.concatenate(streamed[i]) == res[0][0][i][0]).all(), i
+    c.close()
