@@ -95,6 +95,25 @@ def test_gpu_acquire_matches_oracle(gctx, snr, cfo, cut):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cut", [132072, 131072, 133728, 131500])
+def test_gpu_null_search_across_segment_boundaries(gctx, cut):
+    """The dip search scans segments of 2^20 samples in parallel and stitches them.  Captures of 12 frames (three
+    segments) cut so that a null symbol straddles the first boundary, starts exactly on it, ends exactly on it, or has
+    its first quiet block just before it: the frames found are the sequential search's (the oracle's plain loop)."""
+    import dabgpu
+    x, starts, _, _ = capture(31, 12, cut, 0, 20.0, 1.2)
+    cfg = dabgpu.acquire_cfg(timing_margin=0)
+    frames, counts = gctx.acquire(x[None, :], 16, cfg)
+    cands = O.null_search(x, max_out=16)
+    assert counts[0] == len(cands) == len(starts)
+    for j, c in enumerate(cands):
+        r = O.acquire_candidate(x, c, margin=0)
+        g = frames[0, j]
+        assert (g["start"], g["coarse_carriers"], g["flags"]) == (r.start, r.coarse_carriers, r.flags), j
+        assert abs(int(g["start"]) - int(starts[j])) <= 8 and g["flags"] == 3
+
+
+@pytest.mark.gpu
 def test_gpu_unaligned_capture_to_fibs(gctx):
     """Whole chain with nothing known in advance: capture -> acquire -> demodulate in place -> FIC."""
     import torch
