@@ -22,6 +22,7 @@
 // in place by packed add/sub/max on both halves at once; for q = 0 it is the two halves of one register (one
 // half-swap).  Nothing ever moves.
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 #include "mem_stream.hpp"
@@ -538,6 +539,30 @@ __device__ __forceinline__ void lane_tb_step(const uint2 d, int t, int nsteps, u
     q = (q == 5) ? 0 : q + 1;                                // q(t-1) = (5 - (t-1)) mod 6
 }
 
+// The same step with everything that does not depend on the data known at compile time.  In the main loop the
+// replaced slot bit q and the output bit position follow a fixed pattern: blocks of 32 steps start where t & 31 == 31
+// (nsteps - 6 is a multiple of 32), so step i of a block writes bit i of the block's word, and q advances by one per
+// step from 0, 2, 4 in the three blocks of a 96-step round (nsteps - 6 is a multiple of 96 as well).  No scalar
+// compares, no branches, shifts by constants: about half the instructions of the generic step on the serial chain.
+template <int Q, int BIT>
+__device__ __forceinline__ void lane_tb_step_static(const uint2 d, unsigned &p, unsigned &word) {
+    constexpr unsigned rb = unsigned(Q > 0 ? Q - 1 : 0);
+    const unsigned R = p >> 1;
+    const unsigned I = ((R >> (rb + 1)) << rb) | (R & ((1u << rb) - 1u));
+    const unsigned sel = (I & 8u) ? d.y : d.x;
+    const unsigned h = (~sel >> (((((R >> rb) & 1u) << 1 | (p & 1u)) << 3) + (I & 7u))) & 1u;
+    word |= ((p >> Q) & 1u) << BIT;
+    p = (p & ~(1u << Q)) | (h << Q);
+}
+
+template <int Q0, int I>
+__device__ __forceinline__ void lane_tb_block_steps(const uint2 (&d)[32], unsigned &p, unsigned &word) {
+    if constexpr (I < 32) {
+        lane_tb_step_static<(Q0 + I) % 6, I>(d[I], p, word);
+        lane_tb_block_steps<Q0, I + 1>(d, p, word);
+    }
+}
+
 __device__ __forceinline__ unsigned crc16_byte_l(unsigned crc, unsigned byte) {
     crc = ((crc >> 8) | (crc << 8)) & 0xFFFFu;
     crc ^= byte;
@@ -565,15 +590,22 @@ __device__ __forceinline__ void lane_traceback_body(const uint2 *dec, int nsteps
     for (int i = 0; i < 32; i++) dn[i] = ld_stream(src + size_t(nsteps - 7 - i) * 64);
 #pragma unroll
     for (int i = 0; i < 6; i++) lane_tb_step(d[i], nsteps - 1 - i, nsteps, p, q, word, row);
-    for (int t1 = nsteps - 7; t1 >= 0; t1 -= 32) {            // nsteps - 6 is a multiple of 32
+    // (after the six tail steps q is back at 0 and word is empty)
+    auto block = [&](auto q0, int t1) {                         // steps t1 .. t1 - 31 -> word t1 >> 5
 #pragma unroll
         for (int i = 0; i < 32; i++) d[i] = dn[i];
         if (t1 >= 32) {
 #pragma unroll
             for (int i = 0; i < 32; i++) dn[i] = ld_stream(src + size_t(t1 - 32 - i) * 64);
         }
-#pragma unroll
-        for (int i = 0; i < 32; i++) lane_tb_step(d[i], t1 - i, nsteps, p, q, word, row);
+        unsigned w = 0;
+        lane_tb_block_steps<decltype(q0)::value, 0>(d, p, w);
+        row[t1 >> 5] = w;
+    };
+    for (int t1 = nsteps - 7; t1 >= 0; t1 -= 96) {            // nsteps - 6 is a multiple of 96
+        block(std::integral_constant<int, 0>{}, t1);
+        block(std::integral_constant<int, 2>{}, t1 - 32);
+        block(std::integral_constant<int, 4>{}, t1 - 64);
     }
     __syncthreads();
     // output: codewords of a group are adjacent in the output, so the tile is one contiguous run of dwords
