@@ -18,5 +18,7 @@ cd $root
   echo "## tools/ubench/cache_policy (sc0 / nt / sc1 bits on the mover's loads and stores)"
   timeout 600 ./tools/ubench/cache_policy
 } > $o/placement.txt 2>&1
+# (build/ab/libdabgpu_base.so: the library as of commit 122bffd, i.e. before the streaming accesses -- check that
+# commit out into a scratch tree, `make -C sdrplusplus-dab-radio-plugin_amd/csrc`, copy libdabgpu.so there)
 for m in ofdm fft select acquire decode multiplex; do python3 tools/ab_inproc.py $m 16384 5 3 build/ab/libdabgpu_base.so default 2>&1 | grep -v "amdgpu.ids"; done > $o/ab_nontemporal.txt 2>&1
 cat $o/placement.txt | tail -n 50; cat $o/ab_nontemporal.txt | grep -v "^#"
