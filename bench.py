@@ -363,21 +363,11 @@ def main():
         if not args.no_fft_stage:
             # the unfused FFT stage with the offsets the closed loop arrived at (per frame, from the stream states)
             fo = torch.from_numpy(np.repeat(net.astype(np.float32), F)).to(dev)
-            # (45 % of this stage's traffic is the spectra it writes: the output buffer is chosen as in place_buffers)
+            # (45 % of this stage's traffic is the spectra it writes: the output buffer goes where it does not share
+            # an HBM domain with the samples, dabgpu_device_alloc_apart)
             spec_bytes = n_frames * 76 * 2048 * 8
-            k_spec = max(1, min(args.placement_candidates, int(0.8 * torch.cuda.mem_get_info(dev)[0] // spec_bytes)))
-            cands, cand_ms = [torch.empty((n_frames, 76, 2048), dtype=torch.complex64, device=dev) for _ in range(k_spec)], []
-            for c in cands:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                ctx.fft_symbols_dev(d_iq, synth.NB_FRAME_SAMPLES, n_frames, fo.data_ptr(), c.data_ptr(), stream)
-                e0.record()
-                ctx.fft_symbols_dev(d_iq, synth.NB_FRAME_SAMPLES, n_frames, fo.data_ptr(), c.data_ptr(), stream)
-                e1.record()
-                torch.cuda.synchronize()
-                cand_ms.append(e0.elapsed_time(e1))
-            spectra = cands[int(np.argmin(cand_ms))]
-            del cands, c
-            torch.cuda.empty_cache()
+            d_spec, spec_probe = ctx.device_alloc_apart(spec_bytes, iq.data_ptr(), n_frames * synth.NB_FRAME_SAMPLES * 8)
+            spectra = dabgpu.device_tensor(torch, d_spec, (n_frames, 76, 2048), torch.complex64, dev)
             evs = []
             for i in range(3 + 5):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -392,8 +382,9 @@ def main():
             out["roofline_fft_stage"] = {"bound": "hbm", "kernel": "dabk::ofdm_wave_kernel<true,false> (FFT stage only)", "achieved": ach,
                                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                          "avg_launch_ms": fft_ms, "algorithmic_bytes_per_frame": A_FFT,
-                                         "output_placement_probe_ms": [round(x, 3) for x in cand_ms]}
+                                         "output_placement_probe_ms": [round(x, 3) for x in spec_probe]}
             del spectra
+            ctx.device_free(d_spec)
         if not args.no_selective:
             # The same step with the front end writing only what this workload decodes (FIC + the sub-channel,
             # dabgpu_ofdm_set_soft_selection): reported beside `value`, never as `value` -- the headline keeps the

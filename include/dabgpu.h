@@ -146,6 +146,15 @@ int dabgpu_alloc_frame_buffers(dabgpu_ctx *ctx, int n_frames, size_t frame_strid
                                int8_t **d_soft, float *probe_ms, int *kept);
 int dabgpu_free_frame_buffers(dabgpu_ctx *ctx, void *d_iq, int8_t *d_soft);
 
+/* The same idea for any other buffer a launch WRITES while it reads `d_other` (e.g. the spectra of
+ * dabgpu_fft_symbols_dev beside the IQ samples): up to three candidates of `bytes` are allocated some tens of GB
+ * apart, a probe that reads d_other and writes the candidate is timed on each, the fastest is returned.  With
+ * d_other == NULL, or buffers too small for the domains to matter (< 256 MB), a plain allocation.  probe_ms (may be
+ * NULL) receives three times, 0 for candidates that were not tried.  Release with dabgpu_device_free. */
+int dabgpu_device_alloc_apart(dabgpu_ctx *ctx, size_t bytes, const void *d_other, size_t other_bytes, void **d_out,
+                              float *probe_ms);
+int dabgpu_device_free(dabgpu_ctx *ctx, void *d_ptr);
+
 /* ------------------------------------------------------------------------ */
 /* A2..A6: OFDM front end on time-aligned frames.                             */
 /* Replaces the READING_SYMBOLS work of OFDM_Demod::Process                    */

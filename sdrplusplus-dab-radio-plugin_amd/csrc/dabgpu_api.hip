@@ -215,6 +215,58 @@ int pick_parts(const dabgpu_ctx *ctx, int n_frames, int total_syms) {
     return best;
 }
 
+// A device buffer of `bytes` that a launch will write while it reads [ref, ref + ref_bytes): candidates some tens of
+// GB apart (spacer allocations in between, released afterwards), the one on which a read-ref / write-candidate probe
+// runs fastest is kept -- the two streams then sit in different HBM domains if the address space in reach has any.
+// Plain hipMalloc when there is nothing to be apart from or the buffers are too small for it to matter.
+constexpr size_t PLACE_MIN_BYTES = size_t(256) << 20;
+int alloc_apart(dabgpu_ctx *ctx, size_t bytes, const void *ref, size_t ref_bytes, void **out, float *probe_ms) {
+    *out = nullptr;
+    if (probe_ms) probe_ms[0] = probe_ms[1] = probe_ms[2] = 0.f;
+    if (!ref || ref_bytes < PLACE_MIN_BYTES || bytes < PLACE_MIN_BYTES)
+        return hipMalloc(out, std::max<size_t>(bytes, 16)) == hipSuccess ? DABGPU_OK : DABGPU_ERR_NOMEM;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return DABGPU_ERR_HIP;
+    constexpr int K = 3;
+    void *cand[K] = {nullptr, nullptr, nullptr}, *spacer[K - 1] = {nullptr, nullptr};
+    const size_t spacer_bytes = std::min<size_t>(size_t(32) << 30, free_b / 8);
+    int n = 0;
+    for (int k = 0; k < K; k++) {
+        if (double(bytes) * (k + 1) + double(spacer_bytes) * k > 0.5 * double(free_b)) break;
+        if (k > 0 && hipMalloc(&spacer[k - 1], spacer_bytes) != hipSuccess) { spacer[k - 1] = nullptr; break; }
+        if (hipMalloc(&cand[k], bytes) != hipSuccess) { cand[k] = nullptr; break; }
+        n = k + 1;
+    }
+    (void)hipGetLastError();                                   // a candidate that did not fit is not an error
+    int rc = DABGPU_OK, best = 0;
+    if (n == 0) {
+        rc = hipMalloc(&cand[0], bytes) == hipSuccess ? DABGPU_OK : DABGPU_ERR_NOMEM;
+    } else if (n > 1) {
+        hipStream_t s = ctx->stream;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) rc = DABGPU_ERR_HIP;
+        const size_t in_b = std::min<size_t>(ref_bytes, size_t(2) << 30), out_b = std::min<size_t>(bytes, in_b / 6);
+        float best_ms = -1.f;
+        for (int k = 0; k < n && !rc; k++) {
+            float ms = 0.f;
+            if (dabk::launch_placement_probe(ref, in_b, cand[k], out_b, s) != hipSuccess || hipEventRecord(e0, s) != hipSuccess ||
+                dabk::launch_placement_probe(ref, in_b, cand[k], out_b, s) != hipSuccess || hipEventRecord(e1, s) != hipSuccess ||
+                hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess)
+                rc = DABGPU_ERR_HIP;
+            if (probe_ms) probe_ms[k] = ms;
+            if (!rc && (best_ms < 0.f || ms < best_ms)) { best_ms = ms; best = k; }
+        }
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    }
+    for (void *p : spacer) if (p) (void)hipFree(p);
+    for (int k = 0; k < K; k++)
+        if (cand[k] && (rc || k != best)) (void)hipFree(cand[k]);
+    if (rc) return rc;
+    *out = cand[best];
+    return DABGPU_OK;
+}
+
 // The codeword-per-lane Viterbi pays once a launch has enough codewords to give every SIMD a wave (one wave =
 // 64 codewords; its single-wave latency equals the wave-per-codeword kernels' time at ~24k codewords).
 constexpr int LANE_MIN_CODEWORDS = 24576;
@@ -232,6 +284,7 @@ bool use_lane(dabgpu_ctx *ctx, int nsteps, int n_codewords, hipStream_t s, dabk:
         ctx->d_lane_scratch = nullptr;
         ctx->lane_scratch_bytes = 0;
         if (hipMalloc(&ctx->d_lane_scratch, need) != hipSuccess) {
+            ctx->d_lane_scratch = nullptr;
             if (ctx->lane_mode > 0) *rc = DABGPU_ERR_NOMEM;
             return false;                                     // fall back to the wave kernels
         }
@@ -543,6 +596,22 @@ int dabgpu_alloc_frame_buffers(dabgpu_ctx *ctx, int n_frames, size_t frame_strid
             for (int j = 0; j < candidates; j++)
                 probe_ms[size_t(i) * candidates + j] = (i < K && j < K) ? table[size_t(i) * K + j] : 0.f;
     if (kept) { kept[0] = bi; kept[1] = bj; }
+    return DABGPU_OK;
+}
+
+int dabgpu_device_alloc_apart(dabgpu_ctx *ctx, size_t bytes, const void *d_other, size_t other_bytes, void **d_out,
+                              float *probe_ms) {
+    if (!ctx || !d_out || bytes == 0) return DABGPU_ERR_ARG;
+    DeviceGuard guard(ctx);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return alloc_apart(ctx, bytes, d_other, other_bytes, d_out, probe_ms);
+}
+
+int dabgpu_device_free(dabgpu_ctx *ctx, void *d_ptr) {
+    if (!ctx) return DABGPU_ERR_ARG;
+    DeviceGuard guard(ctx);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (d_ptr) HIP_TRY(hipFree(d_ptr));
     return DABGPU_OK;
 }
 
@@ -1250,7 +1319,10 @@ static int decode_grouped(dabgpu_ctx *ctx, uint8_t *d_fib, uint8_t *d_crc_ok, co
         if (ctx->d_lane_scratch) (void)hipFree(ctx->d_lane_scratch);
         ctx->d_lane_scratch = nullptr;
         ctx->lane_scratch_bytes = 0;
-        if (hipMalloc(&ctx->d_lane_scratch, need) != hipSuccess) return 1;
+        if (hipMalloc(&ctx->d_lane_scratch, need) != hipSuccess) {
+            ctx->d_lane_scratch = nullptr;
+            return 1;
+        }
         ctx->lane_scratch_bytes = need;
     }
     ScopedTimer tm(ctx, 2, s);

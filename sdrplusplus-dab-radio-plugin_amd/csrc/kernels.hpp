@@ -61,6 +61,9 @@ hipError_t launch_fft_symbols(const OfdmTables &t, const OfdmArgs &a, int parts,
 // is below thr_null_start times the average so far.
 // noise-like floats in [0.5, 1) with random signs: timing probes must not run on zeros (they move ~6 % faster)
 hipError_t launch_fill_noise(void *p, size_t bytes, hipStream_t s);
+// reads `in` and writes `out` at the same time (streaming, both whole): the launch is slower when the two buffers
+// share an HBM domain -- what the placement helpers time
+hipError_t launch_placement_probe(const void *in, size_t in_bytes, void *out, size_t out_bytes, hipStream_t s);
 hipError_t launch_stream_update(StreamState *state, const float2 *cyc, const float2 *iq, size_t frame_stride,
                                 int n_streams, int frames_per_stream, float beta, float thr_null_start, hipStream_t s);
 

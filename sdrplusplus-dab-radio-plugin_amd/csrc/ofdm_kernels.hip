@@ -25,6 +25,8 @@
 // tools/ubench/lds_conflict.hip, profiles/r02_ofdm_bound.md).  No workgroup barrier is needed after the tables are
 // loaded: a wave only talks to itself.  Soft bits are scattered as bytes into the (then idle) exchange buffer and
 // leave as three coalesced 16-byte stores per lane.
+#include <algorithm>
+
 #include "kernels.hpp"
 #include "dab_tables.hpp"
 #include "fft_common.hpp"
@@ -519,6 +521,41 @@ __global__ __launch_bounds__(256) void fill_noise_kernel(uint32_t *p, size_t n) 
     }
 }
 }  // namespace
+
+namespace {
+// the front end's access shape: a wave owns consecutive chunks, reads 20 KB (twenty 16-byte loads per lane) and writes
+// 3 KB per chunk, 12 waves per CU
+__global__ __launch_bounds__(256) void placement_probe_kernel(const char *in, char *out, int n_chunks, int chunks_per_wave) {
+    __shared__ char occupancy[52 * 1024];                       // three workgroups per CU, as the front end
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (n_chunks < 0) occupancy[threadIdx.x] = 1;               // (never: keeps the array)
+    uint4 acc = make_uint4(1u, 2u, 3u, 4u);
+    for (int c = 0; c < chunks_per_wave; c++) {
+        const int chunk = wave * chunks_per_wave + c;
+        if (chunk >= n_chunks) break;
+        const uint4 *p = reinterpret_cast<const uint4 *>(in + size_t(chunk) * 20480) + lane;
+        uint4 v[20];
+#pragma unroll
+        for (int i = 0; i < 20; i++) v[i] = ld_stream(p + 64 * i);
+#pragma unroll
+        for (int i = 0; i < 20; i++) { acc.x += v[i].x; acc.y ^= v[i].y; acc.z += v[i].z; acc.w ^= v[i].w; }
+        uint4 *o = reinterpret_cast<uint4 *>(out + size_t(chunk) * 3072) + lane;
+#pragma unroll
+        for (int i = 0; i < 3; i++) st_stream(o + 64 * i, acc);
+    }
+}
+}  // namespace
+
+hipError_t launch_placement_probe(const void *in, size_t in_bytes, void *out, size_t out_bytes, hipStream_t s) {
+    const size_t n_chunks = std::min<size_t>(std::min(in_bytes / 20480, out_bytes / 3072), size_t(1) << 20);
+    if (n_chunks == 0) return hipSuccess;
+    const int cpw = 8;
+    const unsigned grid = unsigned(((n_chunks + cpw - 1) / cpw + 3) / 4);
+    hipLaunchKernelGGL(placement_probe_kernel, dim3(grid), dim3(256), 0, s, static_cast<const char *>(in), static_cast<char *>(out),
+                       int(n_chunks), cpw);
+    return hipGetLastError();
+}
 
 hipError_t launch_fill_noise(void *p, size_t bytes, hipStream_t s) {
     if (bytes < 4) return hipSuccess;

@@ -39,6 +39,7 @@ EXPORTS = [
     "dabgpu_streams_reset", "dabgpu_stream_states", "dabgpu_set_stream_offsets", "dabgpu_ofdm_demod_streams_dev",
     "dabgpu_ofdm_demod_streams", "dabgpu_get_stats", "dabgpu_mean_kernel_ms", "dabgpu_decode_stream_frames",
     "dabgpu_decode_stream_reset", "dabgpu_alloc_frame_buffers", "dabgpu_free_frame_buffers",
+    "dabgpu_device_alloc_apart", "dabgpu_device_free",
 ]
 
 ABI_VERSION = 2
@@ -183,6 +184,8 @@ def load_library(path):
     L.dabgpu_mean_kernel_ms.argtypes = [vp, i, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     L.dabgpu_alloc_frame_buffers.argtypes = [vp, i, sz, i, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_float), C.POINTER(i)]
     L.dabgpu_free_frame_buffers.argtypes = [vp, vp, vp]
+    L.dabgpu_device_alloc_apart.argtypes = [vp, sz, vp, sz, C.POINTER(vp), C.POINTER(C.c_float)]
+    L.dabgpu_device_free.argtypes = [vp, vp]
     L.dabgpu_get_prs_reference.argtypes = [i, vp, i]
     L.dabgpu_get_mapper_reference.argtypes = [vp, i, i]
     return L
@@ -357,6 +360,18 @@ class Context:
                                                     table, kept), "dabgpu_alloc_frame_buffers")
         t = np.array(table, dtype=np.float32).reshape(candidates, candidates)
         return d_iq.value, d_soft.value, (t if candidates > 1 else None), (int(kept[0]), int(kept[1]))
+
+    def device_alloc_apart(self, nbytes, d_other=None, other_bytes=0):
+        """A device buffer that a launch can write while it reads `d_other` without the two sharing an HBM domain
+        (dabgpu_device_alloc_apart).  Returns (address, [three probe times in ms]); release with device_free."""
+        out = C.c_void_p()
+        ms = (C.c_float * 3)()
+        _check(self._lib.dabgpu_device_alloc_apart(self._h, nbytes, d_other, other_bytes, C.byref(out), ms),
+               "dabgpu_device_alloc_apart")
+        return out.value, [float(x) for x in ms]
+
+    def device_free(self, d_ptr):
+        _check(self._lib.dabgpu_device_free(self._h, d_ptr), "dabgpu_device_free")
 
     def free_frame_buffers(self, d_iq, d_soft):
         _check(self._lib.dabgpu_free_frame_buffers(self._h, d_iq, d_soft), "dabgpu_free_frame_buffers")

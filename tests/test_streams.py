@@ -221,3 +221,25 @@ def test_alloc_frame_buffers_returns_a_usable_pair(built, ensemble, ensemble_iq)
         with pytest.raises(dabgpu.DabGpuError):
             c.alloc_frame_buffers(kw["n_frames"], kw["frame_stride"], kw["candidates"])
     c.close()
+
+
+def test_device_alloc_apart(built):
+    """dabgpu_device_alloc_apart: small requests are plain allocations; a large one next to a large reference is
+    probed (three candidates at most) and usable; bad arguments are refused."""
+    import torch
+    c = make_ctx(None, 8)
+    p, ms = c.device_alloc_apart(4096)
+    assert p and ms == [0.0, 0.0, 0.0]
+    c.device_free(p)
+    dev = torch.device("cuda", 0)
+    ref = torch.zeros((1 << 30,), dtype=torch.uint8, device=dev)
+    p, ms = c.device_alloc_apart(512 << 20, ref.data_ptr(), ref.numel())
+    assert p and ms[0] > 0 and all(x >= 0 for x in ms)
+    t = dabgpu.device_tensor(torch, p, (512 << 20,), torch.uint8, dev)
+    t.fill_(7)
+    assert int(t[-1].item()) == 7
+    del t
+    c.device_free(p)
+    with pytest.raises(dabgpu.DabGpuError):
+        c.device_alloc_apart(0)
+    c.close()
