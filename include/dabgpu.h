@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DABGPU_ABI_VERSION 2
+#define DABGPU_ABI_VERSION 3   /* 3: + buffer placement helpers (alloc_frame_buffers, device_alloc_apart) */
 
 typedef enum dabgpu_status {
     DABGPU_OK = 0,

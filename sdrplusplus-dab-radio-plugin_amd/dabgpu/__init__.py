@@ -42,7 +42,7 @@ EXPORTS = [
     "dabgpu_device_alloc_apart", "dabgpu_device_free",
 ]
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 FLAG_VITERBI_WAVE = 1 << 0
 FLAG_VITERBI_LANE = 1 << 1
 FLAG_LANE_UNFUSED = 1 << 2

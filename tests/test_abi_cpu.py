@@ -16,7 +16,7 @@ def test_header_symbols_are_all_exported(built):
     L = dabgpu.lib()
     for sym in declared:
         assert hasattr(L, sym), sym
-    assert L.dabgpu_abi_version() == dabgpu.ABI_VERSION == 2
+    assert L.dabgpu_abi_version() == dabgpu.ABI_VERSION == 3
 
 
 def test_header_is_plain_c(tmp_path):
