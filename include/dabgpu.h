@@ -239,8 +239,8 @@ int dabgpu_ofdm_demod_streams(dabgpu_ctx *ctx, const float *iq, size_t frame_str
 int dabgpu_get_stats(dabgpu_ctx *ctx, int stream_index, dabgpu_stats *out);
 
 /* Soft-bit selection (batch receivers that decode the FIC and a few sub-channels and never look at the rest of the
- * frame): from the next call on, dabgpu_ofdm_demod_frames[_dev] and dabgpu_ofdm_demod_acquired_dev of this context
- * write only the listed parts of each frame's 230400 soft bits and leave the other bytes of `soft` untouched -- in
+ * frame): from the next call on, dabgpu_ofdm_demod_frames[_dev], dabgpu_ofdm_demod_streams[_dev] and
+ * dabgpu_ofdm_demod_acquired_dev of this context write only the listed parts of each frame's 230400 soft bits and leave the other bytes of `soft` untouched -- in
  * device memory and, for the host-pointer call, in the caller's host buffer (only the selected ranges are copied
  * back).  Symbols that carry no selected bit and are not the differential reference of one that does are not
  * transformed at all (their cyclic-prefix correlation is still produced when `cyc` is asked for).  The reference's
