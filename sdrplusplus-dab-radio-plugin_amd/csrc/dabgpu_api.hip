@@ -215,16 +215,17 @@ int pick_parts(const dabgpu_ctx *ctx, int n_frames, int total_syms) {
     return best;
 }
 
-// A device buffer of `bytes` that a launch will write while it reads [ref, ref + ref_bytes): candidates some tens of
-// GB apart (spacer allocations in between, released afterwards), the one on which a read-ref / write-candidate probe
-// runs fastest is kept -- the two streams then sit in different HBM domains if the address space in reach has any.
-// Plain hipMalloc when there is nothing to be apart from or the buffers are too small for it to matter.
+// Placement of large device buffers.  Candidates are allocated some tens of GB apart (spacer allocations in between,
+// released afterwards) so that they fall into different HBM domains if the address space in reach has any; a launch is
+// timed on each and the fastest candidate kept.  alloc_apart times a read-ref / write-candidate probe (a buffer that
+// some launch will write while it reads [ref, ref + ref_bytes)).  Plain hipMalloc when the buffers are too small for
+// any of this to matter.
 constexpr size_t PLACE_MIN_BYTES = size_t(256) << 20;
-int alloc_apart(dabgpu_ctx *ctx, size_t bytes, const void *ref, size_t ref_bytes, void **out, float *probe_ms) {
+// `work(candidate, stream)` enqueues the launch whose time decides (it may run several times; it must be idempotent)
+template <class Work>
+int alloc_timed(dabgpu_ctx *ctx, size_t bytes, hipStream_t s, Work work, void **out, float *probe_ms) {
     *out = nullptr;
     if (probe_ms) probe_ms[0] = probe_ms[1] = probe_ms[2] = 0.f;
-    if (!ref || ref_bytes < PLACE_MIN_BYTES || bytes < PLACE_MIN_BYTES)
-        return hipMalloc(out, std::max<size_t>(bytes, 16)) == hipSuccess ? DABGPU_OK : DABGPU_ERR_NOMEM;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return DABGPU_ERR_HIP;
     constexpr int K = 3;
@@ -242,16 +243,14 @@ int alloc_apart(dabgpu_ctx *ctx, size_t bytes, const void *ref, size_t ref_bytes
     if (n == 0) {
         rc = hipMalloc(&cand[0], bytes) == hipSuccess ? DABGPU_OK : DABGPU_ERR_NOMEM;
     } else if (n > 1) {
-        hipStream_t s = ctx->stream;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) rc = DABGPU_ERR_HIP;
-        const size_t in_b = std::min<size_t>(ref_bytes, size_t(2) << 30), out_b = std::min<size_t>(bytes, in_b / 6);
         float best_ms = -1.f;
         for (int k = 0; k < n && !rc; k++) {
             float ms = 0.f;
-            if (dabk::launch_placement_probe(ref, in_b, cand[k], out_b, s) != hipSuccess || hipEventRecord(e0, s) != hipSuccess ||
-                dabk::launch_placement_probe(ref, in_b, cand[k], out_b, s) != hipSuccess || hipEventRecord(e1, s) != hipSuccess ||
-                hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess)
+            if (work(cand[k], s) != hipSuccess || hipEventRecord(e0, s) != hipSuccess || work(cand[k], s) != hipSuccess ||
+                hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+                hipEventElapsedTime(&ms, e0, e1) != hipSuccess)
                 rc = DABGPU_ERR_HIP;
             if (probe_ms) probe_ms[k] = ms;
             if (!rc && (best_ms < 0.f || ms < best_ms)) { best_ms = ms; best = k; }
@@ -265,6 +264,18 @@ int alloc_apart(dabgpu_ctx *ctx, size_t bytes, const void *ref, size_t ref_bytes
     if (rc) return rc;
     *out = cand[best];
     return DABGPU_OK;
+}
+
+int alloc_apart(dabgpu_ctx *ctx, size_t bytes, const void *ref, size_t ref_bytes, void **out, float *probe_ms) {
+    if (!ref || ref_bytes < PLACE_MIN_BYTES || bytes < PLACE_MIN_BYTES) {
+        if (probe_ms) probe_ms[0] = probe_ms[1] = probe_ms[2] = 0.f;
+        *out = nullptr;
+        return hipMalloc(out, std::max<size_t>(bytes, 16)) == hipSuccess ? DABGPU_OK : DABGPU_ERR_NOMEM;
+    }
+    const size_t in_b = std::min<size_t>(ref_bytes, size_t(2) << 30), out_b = std::min<size_t>(bytes, in_b / 6);
+    return alloc_timed(ctx, bytes, ctx->stream,
+                       [&](void *cand, hipStream_t s) { return dabk::launch_placement_probe(ref, in_b, cand, out_b, s); }, out,
+                       probe_ms);
 }
 
 // The codeword-per-lane Viterbi pays once a launch has enough codewords to give every SIMD a wave (one wave =
