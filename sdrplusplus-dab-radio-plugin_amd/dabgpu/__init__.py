@@ -132,7 +132,11 @@ def load_library(path):
     """Load one build of libdabgpu.so and declare its entry points.  lib() does this for the in-tree library; tools
     that compare builds inside one process (tools/ab_inproc.py) load others and pass them to Context(library=...)."""
     L = C.CDLL(path)
+    L.dabgpu_abi_version.argtypes = []
     L.dabgpu_strerror.restype = C.c_char_p
+    L.dabgpu_strerror.argtypes = [C.c_int]
+    L.dabgpu_get_ofdm_params.argtypes = [C.c_int, C.c_void_p]
+    L.dabgpu_get_dab_params.argtypes = [C.c_int, C.c_void_p]
     L.dabgpu_stream.restype = C.c_void_p
     L.dabgpu_stream.argtypes = [C.c_void_p]
     L.dabgpu_destroy.restype = None
