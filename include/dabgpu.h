@@ -493,7 +493,8 @@ int dabgpu_viterbi(dabgpu_ctx *ctx, const int8_t *punct, int n_codewords, const 
 /* Timing helper: duration (ms) of the launches of each kernel family,         */
 /* measured with hipEvents on the launch stream, around the kernel launch       */
 /* alone, while dabgpu_set_timing(ctx,1) is on (every call to it starts a new   */
-/* measurement).  which: 0 = ofdm front end, 1 = fic, 2 = msc / grouped decode, */
+/* measurement).  which: 0 = ofdm front end, 1 = fic (alone), 2 = msc / grouped */
+/* decode (dabgpu_decode_frames*: the FIC is part of the grouped launch),        */
 /* 3 = fft stage.  _last_ = the most recent launch; _mean_ = the mean over the  */
 /* launches since timing was switched on (at most the last 32) and how many     */
 /* that were.  Both wait for the launches they read.                            */

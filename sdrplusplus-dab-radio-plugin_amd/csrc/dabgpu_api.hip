@@ -1349,7 +1349,8 @@ static int decode_grouped(dabgpu_ctx *ctx, uint8_t *d_fib, uint8_t *d_crc_ok, co
 // for the history rings; anything else is decoded sub-channel by sub-channel.
 static int decode_subchannels(dabgpu_ctx *ctx, const dabgpu_subchannel *sc, int n_subchannels, const int8_t *d_soft,
                               size_t soft_stride, int n_streams, int frames_per_stream, const int8_t *const *d_history_in,
-                              int8_t *const *d_history_out, uint8_t *const *d_out, void *stream) {
+                              int8_t *const *d_history_out, uint8_t *const *d_out, void *stream, uint8_t *d_fib = nullptr,
+                              uint8_t *d_crc_ok = nullptr) {
     const long cw_each = long(n_streams) * frames_per_stream * NB_CIFS;
     bool group = n_subchannels >= 2 && ctx->lane_mode <= 0 && (ctx->lane_mode == 0 || cw_each < LANE_MIN_CODEWORDS) &&
                  d_soft && n_streams > 0 && frames_per_stream > 0;
@@ -1378,8 +1379,15 @@ static int decode_subchannels(dabgpu_ctx *ctx, const dabgpu_subchannel *sc, int 
     if (group) {
         hipStream_t s = pick_stream(ctx, stream);
         ScopedTimer tm(ctx, 2, s);
-        HIP_TRY(dabk::launch_msc_decode_group(items.data(), int(items.size()), s));
+        // a small batch's FIC rides along: its four codewords per frame are shorter than any sub-channel's, a launch
+        // of their own would only queue up in front
+        dabk::WaveFicItem fic{ctx->fic.tables(true), d_soft, soft_stride, n_streams * frames_per_stream, d_fib, d_crc_ok};
+        HIP_TRY(dabk::launch_msc_decode_group(items.data(), int(items.size()), s, d_fib ? &fic : nullptr));
         return DABGPU_OK;
+    }
+    if (d_fib) {
+        const int rc = dabgpu_fic_decode_dev(ctx, d_soft, soft_stride, n_streams * frames_per_stream, d_fib, d_crc_ok, stream);
+        if (rc) return rc;
     }
     for (int i = 0; i < n_subchannels; i++) {
         const int rc = dabgpu_msc_decode_dev(ctx, &sc[i], d_soft, soft_stride, n_streams, frames_per_stream,
@@ -1440,10 +1448,9 @@ int dabgpu_decode_frames_dev(dabgpu_ctx *ctx, const int8_t *d_soft, size_t soft_
     const int g = decode_grouped(ctx, d_fib, d_crc_ok, sc, n_subchannels, d_soft, soft_stride, n_streams, frames_per_stream,
                                  d_history_in, d_history_out, d_out, stream);
     if (g <= 0) return g;
-    const int rc = dabgpu_fic_decode_dev(ctx, d_soft, soft_stride, n_streams * frames_per_stream, d_fib, d_crc_ok, stream);
-    if (rc) return rc;
+    // (the FIC goes into the sub-channels' grouped wave launch when there is one, else it gets its own)
     return decode_subchannels(ctx, sc, n_subchannels, d_soft, soft_stride, n_streams, frames_per_stream, d_history_in,
-                              d_history_out, d_out, stream);
+                              d_history_out, d_out, stream, d_fib, d_crc_ok);
 }
 
 int dabgpu_decode_frames(dabgpu_ctx *ctx, const int8_t *soft, size_t soft_stride, int n_streams, int frames_per_stream,

@@ -160,8 +160,16 @@ struct WaveGroupItem {
     CodeTables code;
     MscArgs args;
 };
+// the FIC of the same frames, decoded by the same launch (nullptr = not)
+struct WaveFicItem {
+    CodeTables code;
+    const int8_t *soft;
+    size_t soft_stride;
+    int n_frames;
+    uint8_t *fib, *crc_ok;
+};
 bool wave_group_supported(int nsteps);
-hipError_t launch_msc_decode_group(const WaveGroupItem *items, int n, hipStream_t s);
+hipError_t launch_msc_decode_group(const WaveGroupItem *items, int n, hipStream_t s, const WaveFicItem *fic = nullptr);
 
 // ---- large-batch variant: one codeword per lane (viterbi_lane_kernels.hip) ----
 struct LaneScratch {

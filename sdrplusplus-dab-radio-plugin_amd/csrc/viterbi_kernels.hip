@@ -390,11 +390,20 @@ struct WaveEntry {
 };
 struct WaveEntryPack {
     int n;
+    int n_fic;                        // FIC codewords (4 per frame) decoded by the first n_fic workgroups, or 0
+    FetchFic fic_fetch;
+    CodeTables fic_code;
+    uint8_t *fib, *crc_ok;
     WaveEntry e[WAVE_GROUP_MAX];
 };
 __global__ __launch_bounds__(64) void viterbi_rot_grouped_kernel(const WaveEntryPack pack) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int cw = blockIdx.x;
+    int cw = blockIdx.x;
+    if (cw < pack.n_fic) {            // one frame at a time the FIC's four codewords ride along with the sub-channels'
+        rot_decode<FetchFic, Tail::kFic>(pack.fic_fetch, pack.fic_code, cw, true, pack.fib, pack.crc_ok, smem, int(threadIdx.x));
+        return;
+    }
+    cw -= pack.n_fic;
     int k = 0;
     while (k + 1 < pack.n && cw >= pack.e[k + 1].first_cw) k++;
     const WaveEntry &en = pack.e[k];
@@ -479,7 +488,7 @@ bool wave_group_supported(int nsteps) {
     return nsteps >= 102 && (nsteps - 6) % 96 == 0 && viterbi_rot_lds_bytes(nsteps) <= 160 * 1024;
 }
 
-hipError_t launch_msc_decode_group(const WaveGroupItem *items, int n, hipStream_t s) {
+hipError_t launch_msc_decode_group(const WaveGroupItem *items, int n, hipStream_t s, const WaveFicItem *fic) {
     for (int i0 = 0; i0 < n; i0 += WAVE_GROUP_MAX) {
         const int m = std::min(WAVE_GROUP_MAX, n - i0);
         WaveEntryPack pack{};
@@ -487,6 +496,15 @@ hipError_t launch_msc_decode_group(const WaveGroupItem *items, int n, hipStream_
         pack.n = hp.n = m;
         int total = 0;
         size_t lds = 0, hist_items = 0;
+        if (fic && i0 == 0 && fic->n_frames > 0) {             // the FIC goes with the first launch
+            if (!wave_group_supported(fic->code.nsteps)) return hipErrorInvalidValue;
+            pack.n_fic = fic->n_frames * NB_FIC_GROUPS;
+            pack.fic_fetch = FetchFic{fic->soft, fic->soft_stride};
+            pack.fic_code = fic->code;
+            pack.fib = fic->fib;
+            pack.crc_ok = fic->crc_ok;
+            lds = (viterbi_rot_lds_bytes(fic->code.nsteps) + 255) & ~size_t(255);
+        }
         for (int i = 0; i < m; i++) {
             const WaveGroupItem &it = items[i0 + i];
             const MscArgs &a = it.args;
@@ -500,8 +518,8 @@ hipError_t launch_msc_decode_group(const WaveGroupItem *items, int n, hipStream_
             hp.a[i] = a;
             if (a.hist_out) hist_items = std::max(hist_items, size_t(a.n_streams) * 15 * a.nbits);
         }
-        if (total <= 0) continue;
-        hipLaunchKernelGGL(viterbi_rot_grouped_kernel, dim3(unsigned(total)), dim3(64), lds, s, pack);
+        if (total + pack.n_fic <= 0) continue;
+        hipLaunchKernelGGL(viterbi_rot_grouped_kernel, dim3(unsigned(total + pack.n_fic)), dim3(64), lds, s, pack);
         if (hist_items)
             hipLaunchKernelGGL(msc_history_grouped_kernel, dim3(unsigned(std::min<size_t>((hist_items + 255) / 256, 256)), unsigned(m)),
                                dim3(256), 0, s, hp);
