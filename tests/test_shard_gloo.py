@@ -62,11 +62,11 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run_bench(nproc, extra_env=None, ensembles=4, frames=16):
+def _run_bench(nproc, extra_env=None, ensembles=4, frames=16, more=()):
     env = dict(os.environ)
     env.update(extra_env or {})
     args = ["--ensembles", str(ensembles), "--frames", str(frames), "--steps", "2", "--warmup", "1", "--cpu-seconds", "0",
-            "--no-fft-stage", "--no-selective", "--no-closed-loop"]
+            "--no-fft-stage", "--no-selective", "--no-closed-loop"] + list(more)
     if nproc == 1 and not (extra_env or {}).get("DABGPU_DIST_FORCE"):
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + args
     else:
@@ -113,6 +113,7 @@ def test_bench_rccl_branch_executes_with_one_rank():
     """The `nccl` (= RCCL) branch of bench.py -- process group on the GPU, barrier, the three all-reduces of the report
     on device tensors -- launched through torch.distributed.run with a single rank, which is all a one-GPU box can give
     RCCL (two ranks on one device are refused); the multi-rank logic is covered by the gloo runs above."""
-    r = _run_bench(1, {"DABGPU_DIST_FORCE": "1", "DABGPU_DIST_BACKEND": "nccl"})
+    r = _run_bench(1, {"DABGPU_DIST_FORCE": "1", "DABGPU_DIST_BACKEND": "nccl"}, more=["--placement-candidates", "1"])
     assert r["n_gpus"] == 1 and r["fic_bit_exact"] is True and r["msc_bit_exact"] is True
+    assert r["config"]["buffer_placement"] == "first allocation taken"
     assert abs(r["value"] * r["ms_per_step"] * 1e-3 - 64) < 1e-3
