@@ -374,7 +374,8 @@ int dabgpu_fic_decode(dabgpu_ctx *ctx, const int8_t *soft, size_t soft_stride, i
 /* A12: one MSC subchannel.  Replaces the per-subchannel branch of             */
 /* BasicRadio::Process (/root/reference/src/radio_block.cpp:42); the           */
 /* descriptor mirrors the Subchannel entity the GUI prints                     */
-/* (/root/reference/src/render_formatters.cpp:9-25).                           */
+/* (/root/reference/src/render_formatters.cpp:9-25).  Any size up to a         */
+/* sub-channel that fills the CIF (864 capacity units).                        */
 /* ------------------------------------------------------------------------ */
 typedef struct dabgpu_subchannel {
     int32_t start_address;   /* first capacity unit (0..863)                  */

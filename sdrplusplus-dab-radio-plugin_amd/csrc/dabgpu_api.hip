@@ -125,9 +125,11 @@ int build_device_code(DeviceCode &dc) {
     pos.reserve(dc.prof.n_punct);
     for (size_t i = 0; i < dc.prof.mask.size(); i++)
         if (dc.prof.mask[i]) pos.push_back(uint16_t(i));
-    if (dc.prof.mask.size() > 65535 || int(pos.size()) != dc.prof.n_punct) return DABGPU_ERR_PROFILE;
-    int rc = upload(&dc.d_mother_pos, pos);
-    if (rc) return rc;
+    if (int(pos.size()) != dc.prof.n_punct) return DABGPU_ERR_PROFILE;
+    int rc = DABGPU_OK;
+    if (dabk::viterbi_fits(dc.prof.nsteps)) {                  // (only the wave-per-codeword kernels read this table)
+        if ((rc = upload(&dc.d_mother_pos, pos))) return rc;
+    }
     std::vector<int32_t> pidx(dc.prof.mask.size(), -1);
     for (size_t i = 0, j = 0; i < dc.prof.mask.size(); i++)
         if (dc.prof.mask[i]) pidx[i] = int32_t(j++);
@@ -283,10 +285,12 @@ int alloc_apart(dabgpu_ctx *ctx, size_t bytes, const void *ref, size_t ref_bytes
 constexpr int LANE_MIN_CODEWORDS = 24576;
 
 // returns true and a scratch descriptor when the lane kernels should take this launch
-bool use_lane(dabgpu_ctx *ctx, int nsteps, int n_codewords, hipStream_t s, dabk::LaneScratch *sc, int *rc) {
+// (`force`: the codeword is too long for the wave-per-codeword kernels' LDS slab -- the lane kernels keep their
+// survivors in HBM and take any length)
+bool use_lane(dabgpu_ctx *ctx, int nsteps, int n_codewords, hipStream_t s, dabk::LaneScratch *sc, int *rc, bool force = false) {
     *rc = DABGPU_OK;
-    if (ctx->lane_mode == 0 || !dabk::lane_supported(nsteps)) return false;
-    if (ctx->lane_mode < 0 && n_codewords < LANE_MIN_CODEWORDS) return false;
+    if (!dabk::lane_supported(nsteps)) return false;
+    if (!force && (ctx->lane_mode == 0 || (ctx->lane_mode < 0 && n_codewords < LANE_MIN_CODEWORDS))) return false;
     const size_t need = dabk::lane_scratch_bytes(nsteps, n_codewords);
     if (ctx->lane_scratch_bytes < need) {
         // growing the buffer must not race with work still using the old one
@@ -296,7 +300,7 @@ bool use_lane(dabgpu_ctx *ctx, int nsteps, int n_codewords, hipStream_t s, dabk:
         ctx->lane_scratch_bytes = 0;
         if (hipMalloc(&ctx->d_lane_scratch, need) != hipSuccess) {
             ctx->d_lane_scratch = nullptr;
-            if (ctx->lane_mode > 0) *rc = DABGPU_ERR_NOMEM;
+            if (ctx->lane_mode > 0 || force) *rc = DABGPU_ERR_NOMEM;
             return false;                                     // fall back to the wave kernels
         }
         ctx->lane_scratch_bytes = need;
@@ -1216,7 +1220,8 @@ int dabgpu_msc_decode_dev(dabgpu_ctx *ctx, const dabgpu_subchannel *sc, const in
     int rc = subchannel_profile(sc, prof);
     if (rc) return rc;
     if (n_streams == 0 || frames_per_stream == 0) return DABGPU_OK;
-    if (!dabk::viterbi_fits(prof.nsteps)) return DABGPU_ERR_CAPACITY;
+    const bool too_long = !dabk::viterbi_fits(prof.nsteps);   // above ~800 kbit/s: only the lane kernels hold it
+    if (too_long && !dabk::lane_supported(prof.nsteps)) return DABGPU_ERR_CAPACITY;
     DeviceCode *dc = nullptr;
     if ((rc = get_code(ctx, std::move(prof), &dc))) return rc;
     hipStream_t s = pick_stream(ctx, stream);
@@ -1233,12 +1238,13 @@ int dabgpu_msc_decode_dev(dabgpu_ctx *ctx, const dabgpu_subchannel *sc, const in
     ScopedTimer tm(ctx, 2, s);
     dabk::LaneScratch lsc{};
     int lrc;
-    if (use_lane(ctx, dc->prof.nsteps, n_streams * frames_per_stream * NB_CIFS, s, &lsc, &lrc)) {
+    if (use_lane(ctx, dc->prof.nsteps, n_streams * frames_per_stream * NB_CIFS, s, &lsc, &lrc, too_long)) {
         HIP_TRY(dabk::launch_msc_decode_lane(dc->tables(true), dc->lane_tables(), a, lsc, s));
         HIP_TRY(dabk::launch_msc_history(a, s));
         return DABGPU_OK;
     }
     if (lrc) return lrc;
+    if (too_long) return DABGPU_ERR_CAPACITY;
     HIP_TRY(dabk::launch_msc_decode(dc->tables(true), a, s));
     return DABGPU_OK;
 }
@@ -1655,7 +1661,8 @@ int dabgpu_viterbi_dev(dabgpu_ctx *ctx, const int8_t *d_punct, int n_codewords, 
     if (!ctx || !d_punct || !mask || !d_out_bytes || n_codewords < 0) return DABGPU_ERR_ARG;
     DeviceGuard guard(ctx);
     if (nsteps < 14 || ((nsteps - 6) & 7)) return DABGPU_ERR_ARG;
-    if (!dabk::viterbi_fits(nsteps)) return DABGPU_ERR_CAPACITY;
+    const bool too_long = !dabk::viterbi_fits(nsteps);
+    if (too_long && !dabk::lane_supported(nsteps)) return DABGPU_ERR_CAPACITY;
     dab::PunctureProfile prof;
     prof.mask.assign(mask, mask + 4 * size_t(nsteps));
     for (uint8_t &f : prof.mask) f = f ? 1 : 0;
@@ -1667,12 +1674,13 @@ int dabgpu_viterbi_dev(dabgpu_ctx *ctx, const int8_t *d_punct, int n_codewords, 
     hipStream_t s = pick_stream(ctx, stream);
     dabk::LaneScratch lsc{};
     int lrc;
-    if (use_lane(ctx, dc->prof.nsteps, n_codewords, s, &lsc, &lrc)) {
+    if (use_lane(ctx, dc->prof.nsteps, n_codewords, s, &lsc, &lrc, too_long)) {
         HIP_TRY(dabk::launch_viterbi_plain_lane(dc->tables(false), dc->lane_tables(), d_punct, n_codewords, lsc,
                                                 d_out_bytes, s));
         return DABGPU_OK;
     }
     if (lrc) return lrc;
+    if (too_long) return DABGPU_ERR_CAPACITY;
     HIP_TRY(dabk::launch_viterbi_plain(dc->tables(false), d_punct, n_codewords, d_out_bytes, s));
     return DABGPU_OK;
 }

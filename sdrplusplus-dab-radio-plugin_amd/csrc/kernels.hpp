@@ -220,10 +220,12 @@ hipError_t init_lane_kernel_attributes();
 
 // LDS bytes one codeword needs in the first (fallback) wave-per-codeword kernel
 inline size_t viterbi_wave_lds_bytes(int nsteps) { return size_t(nsteps) * 12 + 64; }
-// largest trellis either kernel can hold in one CU's 160 KB of LDS (8 B/step for DAB codeword lengths)
+// largest trellis the wave-per-codeword kernels take: it must fit one CU's 160 KB of LDS (8 B/step for DAB codeword
+// lengths) and its mother-bit positions 16 bits (CodeTables::mother_pos) -- about 680 kbit/s.  Longer codewords go to
+// the lane kernels, which keep survivors in HBM.
 inline bool viterbi_fits(int nsteps) {
     const bool rot = nsteps >= 102 && (nsteps - 6) % 96 == 0;
-    return (rot ? size_t(nsteps) * 8 + 4096 : viterbi_wave_lds_bytes(nsteps)) <= 160 * 1024;
+    return 4 * size_t(nsteps) <= 65535 && (rot ? size_t(nsteps) * 8 + 4096 : viterbi_wave_lds_bytes(nsteps)) <= 160 * 1024;
 }
 
 }  // namespace dabk

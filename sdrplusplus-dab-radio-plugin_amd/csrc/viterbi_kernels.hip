@@ -453,6 +453,7 @@ template <class Fetch, Tail TAIL>
 hipError_t launch_wave(Fetch f, const CodeTables &c, int n_codewords, uint8_t *out, uint8_t *crc_ok,
                        hipStream_t s) {
     if (n_codewords <= 0) return hipSuccess;
+    if (!viterbi_fits(c.nsteps) || !c.mother_pos) return hipErrorInvalidValue;     // longer codewords: lane kernels only
     const bool rot = c.nsteps >= 102 && (c.nsteps - 6) % 96 == 0 && viterbi_rot_lds_bytes(c.nsteps) <= 160 * 1024;
     const size_t per_wave = rot ? viterbi_rot_lds_bytes(c.nsteps) : viterbi_wave_lds_bytes(c.nsteps);
     int lds_per_wave = int((per_wave + 255) & ~size_t(255));
@@ -485,7 +486,7 @@ hipError_t allow_full_lds() {
 }  // namespace
 
 bool wave_group_supported(int nsteps) {
-    return nsteps >= 102 && (nsteps - 6) % 96 == 0 && viterbi_rot_lds_bytes(nsteps) <= 160 * 1024;
+    return nsteps >= 102 && (nsteps - 6) % 96 == 0 && viterbi_fits(nsteps) && viterbi_rot_lds_bytes(nsteps) <= 160 * 1024;
 }
 
 hipError_t launch_msc_decode_group(const WaveGroupItem *items, int n, hipStream_t s, const WaveFicItem *fic) {

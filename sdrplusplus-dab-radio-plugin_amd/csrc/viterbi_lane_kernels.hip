@@ -563,6 +563,11 @@ __device__ __forceinline__ void lane_tb_block_steps(const uint2 (&d)[32], unsign
     }
 }
 
+// does the traceback's output tile ([64][words | 1] dwords) fit into LDS?
+__host__ __device__ __forceinline__ bool lane_tile_fits(int nsteps) {
+    return size_t(64) * size_t(((nsteps - 6) >> 5) | 1) * 4 <= size_t(150) * 1024;
+}
+
 __device__ __forceinline__ unsigned crc16_byte_l(unsigned crc, unsigned byte) {
     crc = ((crc >> 8) | (crc << 8)) & 0xFFFFu;
     crc ^= byte;
@@ -572,13 +577,19 @@ __device__ __forceinline__ unsigned crc16_byte_l(unsigned crc, unsigned byte) {
     return crc;
 }
 
+// tile == nullptr: codewords too long for a [64][words] tile in LDS (above ~800 kbit/s): every decoded word goes
+// straight to its place in the output (one 4-byte store per lane per 32 steps); never the FIC.
 __device__ __forceinline__ void lane_traceback_body(const uint2 *dec, int nsteps, int n_codewords, int group,
                                                     const uint8_t *prbs_bytes, uint8_t *out, uint8_t *crc_ok, uint32_t *tile,
                                                     int lane) {
     const uint2 *src = dec + size_t(group) * nsteps * 64 + lane;
     const int nwords = (nsteps - 6) >> 5;
     const int pitch = nwords | 1;                             // odd -> rows start in different banks
-    uint32_t *row = tile + lane * pitch;
+    const bool direct = tile == nullptr;
+    const int nvalid_d = min(64, n_codewords - group * 64);
+    const uint32_t *prbs32_d = reinterpret_cast<const uint32_t *>(prbs_bytes);
+    uint32_t *out_d = reinterpret_cast<uint32_t *>(out + (size_t(group) * 64 + lane) * nwords * 4);
+    uint32_t *row = direct ? nullptr : tile + lane * pitch;
     unsigned p = 0, word = 0;
     int q = 5 - ((nsteps - 1) % 6);
     // The survivor words do not depend on the path: they are fetched a block of 32 steps ahead, only the slot
@@ -600,13 +611,20 @@ __device__ __forceinline__ void lane_traceback_body(const uint2 *dec, int nsteps
         }
         unsigned w = 0;
         lane_tb_block_steps<decltype(q0)::value, 0>(d, p, w);
-        row[t1 >> 5] = w;
+        if (!direct) {
+            row[t1 >> 5] = w;
+        } else if (lane < nvalid_d) {
+            uint32_t v = __builtin_bswap32(w);
+            if (prbs32_d) v ^= prbs32_d[t1 >> 5];
+            out_d[t1 >> 5] = v;
+        }
     };
     for (int t1 = nsteps - 7; t1 >= 0; t1 -= 96) {            // nsteps - 6 is a multiple of 96
         block(std::integral_constant<int, 0>{}, t1);
         block(std::integral_constant<int, 2>{}, t1 - 32);
         block(std::integral_constant<int, 4>{}, t1 - 64);
     }
+    if (direct) return;                                       // (wave-uniform: every lane of the workgroup leaves)
     __syncthreads();
     // output: codewords of a group are adjacent in the output, so the tile is one contiguous run of dwords
     const int nvalid = min(64, n_codewords - group * 64);
@@ -636,16 +654,17 @@ __device__ __forceinline__ void lane_traceback_body(const uint2 *dec, int nsteps
 
 __global__ __launch_bounds__(64) void lane_traceback_kernel(const uint2 *dec, int nsteps, int n_codewords,
                                                             const uint8_t *prbs_bytes, uint8_t *out, uint8_t *crc_ok) {
-    extern __shared__ uint32_t tile[];                        // [64][nwords + 1]
-    lane_traceback_body(dec, nsteps, n_codewords, blockIdx.x, prbs_bytes, out, crc_ok, tile, threadIdx.x);
+    extern __shared__ uint32_t tile[];                        // [64][nwords + 1], or nothing for over-long codewords
+    lane_traceback_body(dec, nsteps, n_codewords, blockIdx.x, prbs_bytes, out, crc_ok, lane_tile_fits(nsteps) ? tile : nullptr,
+                        threadIdx.x);
 }
 
 __global__ __launch_bounds__(64) void lane_traceback_grouped_kernel(const LaneEntryPack pack) {
     extern __shared__ uint32_t tile[];                        // sized for the longest entry
     const int group = blockIdx.x;
     const LaneEntry &en = pack.e[find_entry(pack, group)];
-    lane_traceback_body(en.dec, en.nsteps, en.n_codewords, group - en.first_group, en.prbs, en.out, en.crc_ok, tile,
-                        threadIdx.x);
+    lane_traceback_body(en.dec, en.nsteps, en.n_codewords, group - en.first_group, en.prbs, en.out, en.crc_ok,
+                        lane_tile_fits(en.nsteps) ? tile : nullptr, threadIdx.x);
 }
 
 template <class Src>
@@ -668,7 +687,7 @@ hipError_t run_lane(Src f, bool vec16, bool fusable, const CodeTables &c, const 
         const size_t fwd_lds = balanced_lds_bytes(fgrid, 0, 8);
         hipLaunchKernelGGL(lane_forward_kernel, dim3(fgrid), dim3(256), fwd_lds, s, M, c.nsteps, groups, dec);
     }
-    const size_t tb_lds = size_t(64) * (nwords | 1) * 4;
+    const size_t tb_lds = lane_tile_fits(c.nsteps) ? size_t(64) * (nwords | 1) * 4 : 0;
     hipLaunchKernelGGL(lane_traceback_kernel, dim3(unsigned(groups)), dim3(64), tb_lds, s, dec, c.nsteps, n_codewords,
                        c.prbs_bytes, out, crc_ok);
     return hipGetLastError();
@@ -700,8 +719,9 @@ size_t lane_scratch_bytes(int nsteps, int n_codewords) {
 }
 
 bool lane_supported(int nsteps) {
-    // whole phase cycles, whole 32-bit output words, and the traceback tile (64 x words) must fit in LDS
-    return nsteps >= 38 && nsteps % 6 == 0 && ((nsteps - 6) & 31) == 0 && size_t(64) * (((nsteps - 6) >> 5) | 1) * 4 <= 150 * 1024;
+    // whole phase cycles and whole 32-bit output words (any length: a codeword whose output tile does not fit into LDS
+    // writes its words directly, lane_traceback_body)
+    return nsteps >= 38 && nsteps % 6 == 0 && ((nsteps - 6) & 31) == 0;
 }
 
 hipError_t launch_fic_decode_lane(const CodeTables &c, const LaneTables &lt, const int8_t *soft, size_t soft_stride,
@@ -776,7 +796,7 @@ hipError_t launch_lane_group(const LaneGroupItem *items, int n, const LaneScratc
             e.groups = (e.n_codewords + 63) / 64;
             pack.total_groups += e.groups;
             p += size_t(e.groups) * 64 * size_t(e.nsteps) * sizeof(uint2);
-            max_nwords = std::max(max_nwords, (e.nsteps - 6) >> 5);
+            if (lane_tile_fits(e.nsteps)) max_nwords = std::max(max_nwords, (e.nsteps - 6) >> 5);
         }
         const unsigned fgrid = unsigned((pack.total_groups + 3) / 4);
         const size_t lds = balanced_lds_bytes(fgrid, size_t(4) * (64 + LSrcMsc::PRE) * FPITCH, 3);
