@@ -74,3 +74,43 @@ def test_over_long_subchannel_inside_a_multiplex(mode, fps):
         one, _ = w.msc_decode(sc, soft, 1)
         assert (outs[i] == one).all(), i
     w.close()
+
+
+def test_every_entry_point_accepts_empty_batches():
+    """Zero frames / streams / codewords / super-frames: DABGPU_OK, nothing written, no launch."""
+    import torch
+    c = make_ctx(None, 8)
+    L = dabgpu.lib()
+    dev = torch.device("cuda", 0)
+    buf = torch.zeros((1 << 20,), dtype=torch.uint8, device=dev)
+    d, h = buf.data_ptr(), c._h
+    sc = dabgpu.subchannel(0, 64, level=3)
+    import ctypes as C
+    mask = (C.c_uint8 * (4 * 102))(*([1] * 408))
+    assert L.dabgpu_ofdm_demod_frames_dev(h, d, 196608, 0, None, d, None, None, None) == 0
+    assert L.dabgpu_ofdm_demod_streams_dev(h, d, 196608, 0, 4, 0.5, d, None, None, None) == 0
+    assert L.dabgpu_fft_symbols_dev(h, d, 196608, 0, None, d, None) == 0
+    assert L.dabgpu_sync_prs_dev(h, d, 196608, 0, None, 10, d, None) == 0
+    assert L.dabgpu_acquire_dev(h, d, 0, 0, 100000, None, 4, d, d, None) == 0
+    assert L.dabgpu_ofdm_demod_acquired_dev(h, d, 0, 0, 4, d, d, None, None, None) == 0
+    assert L.dabgpu_fic_decode_dev(h, d, 230400, 0, d, d, None) == 0
+    assert L.dabgpu_msc_decode_dev(h, C.byref(sc), d, 230400, 0, 4, None, None, d, None) == 0
+    assert L.dabgpu_msc_decode_dev(h, C.byref(sc), d, 230400, 2, 0, None, None, d, None) == 0
+    assert L.dabgpu_msc_decode_multi_dev(h, None, 0, d, 230400, 1, 1, None, None, None, None) == -1   # no list at all
+    arr = (dabgpu.Subchannel * 1)(sc)
+    outs = (C.c_void_p * 1)(d)
+    assert L.dabgpu_msc_decode_multi_dev(h, arr, 1, d, 230400, 0, 4, None, None, outs, None) == 0
+    assert L.dabgpu_decode_frames_dev(h, d, 230400, 0, 4, d, d, arr, 1, None, None, outs, None) == 0
+    assert L.dabgpu_decode_frames_dev(h, d, 230400, 1, 0, d, d, None, 0, None, None, None, None) == 0
+    assert L.dabgpu_viterbi_dev(h, d, 0, mask, 102, d, None) == 0
+    assert L.dabgpu_dabplus_superframes_dev(h, d, 960, 0, 64, d, d, None) == 0
+    assert L.dabgpu_streams_reset(h, 0) == 0
+    c.sync()
+    assert int(buf.sum().item()) == 0
+    # the host-pointer variants
+    z = np.zeros((0, dabgpu.NB_FRAME_BITS), np.int8)
+    fib, ok = c.fic_decode(z)
+    assert fib.shape[0] == 0 and ok.shape[0] == 0
+    fib, ok, outs2, _ = c.decode_frames(z, 1, [sc])
+    assert fib.shape[0] == 0
+    c.close()
