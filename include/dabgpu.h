@@ -108,7 +108,8 @@ typedef struct dabgpu_cfg {
 
 /* Which kernels decode (results are identical; the default picks by batch size).  Meant for tests and timing. */
 #define DABGPU_FLAG_NONE 0
-#define DABGPU_FLAG_VITERBI_WAVE  (1 << 0) /* channel decoder: one wavefront per codeword, always              */
+#define DABGPU_FLAG_VITERBI_WAVE  (1 << 0) /* channel decoder: one wavefront per codeword, always (codewords    */
+                                           /* above ~680 kbit/s do not fit its LDS slab: those go per lane)      */
 #define DABGPU_FLAG_VITERBI_LANE  (1 << 1) /* one codeword per lane wherever the length allows, any batch size */
 #define DABGPU_FLAG_LANE_UNFUSED  (1 << 2) /* lane decoder: separate depuncture pass before the forward pass   */
 
