@@ -57,7 +57,11 @@ def place_buffers(torch, dabgpu, ctx, dev, n_frames, n_candidates):
     soft = dabgpu.device_tensor(torch, d_soft, (n_frames, dabgpu.NB_FRAME_BITS), torch.int8, dev)
     report = None
     if table is not None:
-        report = {"candidates": n_candidates, "probe_front_end_ms": [[round(float(x), 3) for x in r] for r in table], "kept": list(kept)}
+        flat = [float(x) for r in table for x in r]
+        report = {"candidates": n_candidates, "probe_front_end_ms": [[round(float(x), 3) for x in r] for r in table], "kept": list(kept),
+                  "front_end_ms_plain_alloc": round(float(table[0][0]), 3),          # the pair a plain allocation would have got
+                  "front_end_ms_kept_pair": round(float(table[kept[0]][kept[1]]), 3),
+                  "probe_min_ms": round(min(flat), 3), "probe_max_ms": round(max(flat), 3)}
     return iq, soft, report
 
 
@@ -179,6 +183,42 @@ def cpu_baseline(iq_host, fo_host, sc_len_bits, mask, nsteps, budget_s, threads)
                                      "sample": "%d frames in %.1f s: one OFDM pthread -> 2-frame ring -> one decoder pthread" % (kp, tp)}}
 
 
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves.  This process has
+    not imported torch.cuda nor made any HIP call, and it never will: it starts `python -m torch.distributed.run` as a
+    fresh child (one rank per GPU, rendezvous on 127.0.0.1), hands rank 0's single JSON line on, and exits with the
+    child's code.  A run that does not come back as exactly one line with n_gpus == N is an error, never a silent
+    one-rank result."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: what RCCL needs on this driver
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT)
+    out, _ = p.communicate()
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    for l in out.splitlines():
+        if not l.startswith("{"):
+            print(l, file=sys.stderr)
+    if p.returncode != 0:
+        raise SystemExit(p.returncode)
+    if len(lines) != 1:
+        raise SystemExit("bench.py --gpus %d: expected one JSON line from rank 0, got %d" % (n, len(lines)))
+    if json.loads(lines[0]).get("n_gpus") != n:
+        raise SystemExit("bench.py --gpus %d: the job reports n_gpus = %r" % (n, json.loads(lines[0]).get("n_gpus")))
+    print(lines[0])
+    raise SystemExit(0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -192,27 +232,42 @@ def main():
     ap.add_argument("--no-fft-stage", action="store_true", help="skip the unfused FFT-stage measurement")
     ap.add_argument("--no-selective", action="store_true", help="skip the extra selective-soft-output measurement")
     ap.add_argument("--no-closed-loop", action="store_true", help="skip the unaligned-capture closed-loop measurement")
+    ap.add_argument("--sustained-seconds", type=float, default=3.0,
+                    help="length of the extra `sustained` leg: the same step repeated for this long, so that the package's "
+                         "power-limited steady state is in the record (0 = skip)")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the sustained leg")
     ap.add_argument("--placement-candidates", type=int, default=4,
                     help="IQ / soft-bit buffer candidates timed at set-up, the fastest pair is kept (1 = plain allocation); "
                          "four pairs of the default shape span 118 GB, more than one 96 GB HBM domain")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)                # never returns; nothing above this line has touched the GPU
 
     import torch
     import dabgpu
     from dabgpu import synth
-    from dabgpu.shard import ensembles_of_rank, reduce_report
+    from dabgpu.shard import ensembles_of_rank, reduce_report, gather_per_rank
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d: launch with torch.distributed.run "
+                         "--nproc-per-node == --gpus, or plainly as `python bench.py --gpus N`" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a gfx950 GPU (libdabgpu has no CPU fallback)")
     n_dev = torch.cuda.device_count()
+    backend = os.environ.get("DABGPU_DIST_BACKEND", "nccl")      # "nccl" is RCCL on ROCm; "gloo" only for tests
+    if world > n_dev and backend == "nccl":
+        # RCCL refuses two ranks on one device; ranks sharing a GPU (tests on a one-GPU box) must say so explicitly
+        raise SystemExit("bench.py --gpus %d: only %d device(s) visible (DABGPU_DIST_BACKEND=gloo lets test ranks share one)"
+                         % (world, n_dev))
     dev_index = local_rank % n_dev        # (== local_rank on a real multi-GPU node; lets a 1-GPU box run 2 test ranks)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
-    backend = os.environ.get("DABGPU_DIST_BACKEND", "nccl")      # "nccl" is RCCL on ROCm; "gloo" only for tests
     # DABGPU_DIST_FORCE=1 (tests): take the process-group path even for one rank, so that the RCCL barrier and
     # reductions of the report execute on a single-GPU box
     if world > 1 or os.environ.get("DABGPU_DIST_FORCE") == "1":
@@ -222,7 +277,9 @@ def main():
         else:
             dist.init_process_group(backend)
     red_dev = dev if backend == "nccl" else torch.device("cpu")
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    dist_world = dist.get_world_size() if dist is not None else 1
+    if dist_world != world:
+        raise SystemExit("process group has %d ranks, WORLD_SIZE says %d" % (dist_world, world))
 
     E, F = args.ensembles, args.frames
     n_frames = E * F
@@ -314,6 +371,7 @@ def main():
         # with warm history every entry is valid
         for t in range(0 if args.warmup + args.steps >= 2 else 15, F * 4):
             msc_ok &= bool((msc_h[s, t] == e.msc_bytes[(t - 15) % 16]).all())
+    elapsed_rank = elapsed
     elapsed, frames_total, (fic_ok, msc_ok) = reduce_report(dist, red_dev, elapsed, n_frames * args.steps,
                                                             [fic_ok, msc_ok])
 
@@ -321,22 +379,36 @@ def main():
     dec_ms = float(np.mean([a.elapsed_time(b) for a, b in dec_ev]))
     ofdm_ms, ofdm_launches = ctx.mean_kernel_ms(0)                             # the fused kernel's launches alone
     ctx.set_timing(False)
+    kept_pair = placement["kept"] if placement is not None else [0, 0]
+    # one row per rank, so that an imbalance between the GPUs of a node is visible in the line
+    per_rank = gather_per_rank(dist, red_dev, [n_frames * args.steps / elapsed_rank, ofdm_ms, dec_ms, dev_index,
+                                               kept_pair[0], kept_pair[1]])
 
     if rank == 0:
         value = frames_total / elapsed
         achieved = A_OFDM * n_frames / (ofdm_ms * 1e-3) / 1e9
-        traffic = None
+        # HBM bytes per launch cannot be counted inside this run (PMC counters need rocprofv3 around the process, in
+        # passes of their own): the figure is the one the tracked PMC run of this same command measured, and the line
+        # says so; null when that file does not describe this launch shape
+        traffic, traffic_source = None, "not measured in this run"
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 if tj.get("frames_per_launch") == n_frames:
                     traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_source = "profiles/pmc_traffic.json (rocprofv3 --pmc, separate run of this command: " \
+                                     "TCC_EA0_RDREQ/WRREQ-derived FETCH_SIZE x 2 + WRITE_SIZE, tools/pmc_traffic.sh); not measured in this run"
             except Exception:
                 traffic = None
         out = {
             "metric": "DAB Mode-I frames/sec (OFDM+Viterbi)", "value": value, "unit": "frames/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "rccl_world": dist_world,
+            "collective_backend": (backend + (" (RCCL over xGMI)" if backend == "nccl" else " (test ranks sharing a GPU)"))
+                                  if dist is not None else "none (one rank)",
+            "per_rank": [{"rank": i, "frames_per_s": r[0], "front_end_kernel_ms": r[1], "decoder_ms": r[2], "device": int(r[3]),
+                          "kept_placement_pair": [int(r[4]), int(r[5])]} for i, r in enumerate(per_rank)],
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%d ensembles/GPU x %d frames/step, Mode-I OFDM + FIC Viterbi + one 64 kbps "
@@ -352,7 +424,7 @@ def main():
             "fine_loop_residual_carriers": loop_residual,
             "roofline": {"bound": "hbm", "kernel": "dabk::ofdm_wave_kernel<false,false,false,true> (fused A2..A6)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "avg_launch_ms": ofdm_ms, "launches_timed": ofdm_launches,
+                         "traffic": traffic, "traffic_source": traffic_source, "avg_launch_ms": ofdm_ms, "launches_timed": ofdm_launches,
                          "front_end_call_ms": ofdm_call_ms, "frames_per_launch": n_frames,
                          "algorithmic_bytes_per_frame": A_OFDM,
                          "copy_ceiling": copy_ceiling(torch, dev)},
@@ -360,6 +432,30 @@ def main():
             "decoder": {"fic_and_msc_ms": dec_ms, "acs_per_s": (ACS_FIC + ACS_MSC64) * n_frames / (dec_ms * 1e-3),
                         "entry_point": "dabgpu_decode_frames_dev (FIC + sub-channel codewords in one grouped launch)"},
         }
+        if not args.no_sustained and args.sustained_seconds > 0:
+            # The same step, repeated for >= --sustained-seconds: the 10-step timed region above lasts 0.1 s, shorter than
+            # the package's power controller takes to settle (the front end runs at the 1400 W limit), so the
+            # steady state gets a leg of its own.  Reported beside `value`, never as `value`.
+            ms0 = elapsed / args.steps * 1e3
+            n_sus = int(min(20000, max(args.steps, np.ceil(args.sustained_seconds * 1e3 / ms0))))
+            ctx.set_timing(True)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for k in range(n_sus):
+                step(args.warmup + args.steps + k, False)
+            torch.cuda.synchronize()
+            sus_s = time.perf_counter() - t1
+            sus_ofdm_ms, sus_launches = ctx.mean_kernel_ms(0)
+            ctx.set_timing(False)
+            fib_u, crc_u, msc_u = fib.cpu().numpy(), crc.cpu().numpy(), msc.cpu().numpy()
+            sus_ach = A_OFDM * n_frames / (sus_ofdm_ms * 1e-3) / 1e9
+            out["sustained"] = {"steps": n_sus, "seconds": sus_s, "ms_per_step": sus_s / n_sus * 1e3,
+                                "value": n_frames * n_sus / sus_s, "unit": "frames/s",
+                                "x_realtime": n_frames * n_sus / sus_s / REALTIME_FPS,
+                                "front_end_kernel_ms": sus_ofdm_ms, "launches_timed": sus_launches,
+                                "roofline_frac": sus_ach / HBM_PEAK_GBS,
+                                "outputs_identical_to_timed_run": bool((fib_u == fib_h).all() and (crc_u == crc_h).all()
+                                                                       and (msc_u == msc_h).all())}
         if not args.no_fft_stage:
             # the unfused FFT stage with the offsets the closed loop arrived at (per frame, from the stream states)
             fo = torch.from_numpy(np.repeat(net.astype(np.float32), F)).to(dev)

@@ -26,8 +26,22 @@ def esc(label):
     return "".join(c if (0x20 <= ord(c) < 0x7F and c not in "\\[]") else "\\x%02X" % ord(c) for c in label)
 
 
+MAX_ENTITIES = 1024      # cap of every entity list (the host-side updater's MAX_ENTITIES)
+
+
+def _entity(table, key, fresh):
+    """table[key], created from `fresh` if new -- unless the table is full: then a scratch entity nobody lists."""
+    if key in table:
+        return table[key]
+    if len(table) >= MAX_ENTITIES:
+        return fresh
+    table[key] = fresh
+    return fresh
+
+
 class Database:
     def __init__(self):
+        self.n_components = 0     # over all services (the updater keeps one capped list)
         self.ensemble = {"id": None, "label": "", "cif_count": None}
         self.subchannels = {}     # id -> {start_address, length, is_uep, uep_prot_index, eep_type, eep_prot_level}
         self.services = {}        # sid -> {label, components: [{subchannel_id, transport_mode, audio_service_type, is_primary}]}
@@ -139,7 +153,7 @@ def _fig0_2(d, pd, db):
         i += idlen + 1
         if i + 2 * n > len(d):
             return
-        sv = db.services.setdefault(sid, {"label": "", "components": [], "bits32": bool(pd)})
+        sv = _entity(db.services, sid, {"label": "", "components": [], "bits32": bool(pd)})
         for _ in range(n):
             b0, b1 = d[i], d[i + 1]
             i += 2
@@ -148,8 +162,9 @@ def _fig0_2(d, pd, db):
                 continue
             comp = {"subchannel_id": b1 >> 2, "transport_mode": 0, "audio_service_type": b0 & 0x3F,
                     "is_primary": bool(b1 & 2)}
-            if not any(c["subchannel_id"] == comp["subchannel_id"] for c in sv["components"]):
+            if not any(c["subchannel_id"] == comp["subchannel_id"] for c in sv["components"]) and db.n_components < MAX_ENTITIES:
                 sv["components"].append(comp)
+                db.n_components += 1
 
 
 def _add_unique(lst, x):
@@ -197,7 +212,7 @@ def _fig0_6(d, pd, db):
         idlen = 4 if pd else (3 if ils else 2)
         if i + idlen * count > len(d):
             return
-        link = db.links.setdefault(lsn, {"active": la, "hard": hard, "intl": ils, "service": None})
+        link = _entity(db.links, lsn, {"active": la, "hard": hard, "intl": ils, "service": None})
         for k in range(count):
             ident = int.from_bytes(bytes(d[i:i + idlen]), "big")
             i += idlen
@@ -205,11 +220,11 @@ def _fig0_6(d, pd, db):
                 if k == 0 and link["service"] is None:
                     link["service"] = ident if pd else ident & 0xFFFF
             elif idlq == 1:
-                m = db.fm.setdefault(ident & 0xFFFF, {"lsn": None, "tc": False, "freqs": []})
+                m = _entity(db.fm, ident & 0xFFFF, {"lsn": None, "tc": False, "freqs": []})
                 if m["lsn"] is None:
                     m["lsn"] = lsn
             elif idlq == 3:
-                m = db.drm.setdefault(ident & 0xFFFFFF, {"lsn": None, "tc": False, "freqs": []})
+                m = _entity(db.drm, ident & 0xFFFFFF, {"lsn": None, "tc": False, "freqs": []})
                 if m["lsn"] is None:
                     m["lsn"] = lsn
 
@@ -279,19 +294,19 @@ def _fig0_21(d, db):
             fl = blk[j:j + n]
             j += n
             if rm == 0:
-                o = db.other.setdefault(ident, {"cont": False, "freqs": [], "services": []})
+                o = _entity(db.other, ident, {"cont": False, "freqs": [], "services": []})
                 o["cont"] = o["cont"] or bool(cont)
                 for k in range(0, n - 2, 3):
                     _add_unique(o["freqs"], (((fl[k] & 7) << 16) | (fl[k + 1] << 8) | fl[k + 2]) * 16000)
             elif rm == 8:
-                m = db.fm.setdefault(ident, {"lsn": None, "tc": False, "freqs": []})
+                m = _entity(db.fm, ident, {"lsn": None, "tc": False, "freqs": []})
                 m["tc"] = m["tc"] or bool(cont)
                 for k in range(n):
                     _add_unique(m["freqs"], 87500000 + 100000 * fl[k])
             elif rm == 6:
                 if n < 1:
                     continue
-                m = db.drm.setdefault((fl[0] << 16) | ident, {"lsn": None, "tc": False, "freqs": []})
+                m = _entity(db.drm, (fl[0] << 16) | ident, {"lsn": None, "tc": False, "freqs": []})
                 m["tc"] = m["tc"] or bool(cont)
                 for k in range(1, n - 1, 2):
                     _add_unique(m["freqs"], (((fl[k] & 0x7F) << 8) | fl[k + 1]) * 1000)
@@ -307,7 +322,7 @@ def _fig0_24(d, pd, db):
         if i + 2 * count > len(d):
             return
         for _ in range(count):
-            o = db.other.setdefault((d[i] << 8) | d[i + 1], {"cont": False, "freqs": [], "services": []})
+            o = _entity(db.other, (d[i] << 8) | d[i + 1], {"cont": False, "freqs": [], "services": []})
             _add_unique(o["services"], sid)
             i += 2
 
@@ -366,7 +381,7 @@ def parse_fib(fib, db):
                     if not db.ensemble["label"]:
                         db.ensemble["label"] = _label(body[3:19])
                 else:
-                    sv = db.services.setdefault(ident, {"label": "", "components": []})
+                    sv = _entity(db.services, ident, {"label": "", "components": []})
                     if not sv["label"]:
                         sv["label"] = _label(body[3:19])
             elif ext == 5 and flen >= 23:

@@ -59,8 +59,10 @@ struct dabgpu_ctx {
     DeviceCode fic;
     std::map<std::vector<uint8_t>, std::unique_ptr<DeviceCode>> codes;   // keyed by puncture mask
     // staging for the host-pointer entry points
-    void *d_stage[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t stage_bytes[6] = {0, 0, 0, 0, 0, 0};
+    // slots 0..5: staging of the host-pointer entry points; slot 6: the stream call's own cyclic-prefix correlations
+    // (it runs on a caller's stream, so it must not share a slot with calls that run on the context stream)
+    void *d_stage[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t stage_bytes[7] = {0, 0, 0, 0, 0, 0, 0};
     bool timing = false;
     Timer timers[4];
     int ofdm_parts_override = 0;
@@ -76,6 +78,8 @@ struct dabgpu_ctx {
     std::vector<dabgpu_bit_range> keep_ranges;           // the current selection, merged, for the host-pointer copy-back
     dabk::StreamState *d_states = nullptr;               // per-stream tracking state (dabgpu_streams_reset)
     int n_states = 0;
+    hipEvent_t ev_states = nullptr;      // recorded behind the last launch that reads or writes d_states, on ITS stream
+    bool ev_states_pending = false;
     float thr_null_start = 0.35f;        // desync threshold of the stream call (null_l1_search.thresh_null_start)
     // dabgpu_decode_stream_frames: de-interleaver rings of the stream's sub-channels, kept on the device between calls
     struct SubHistory {
@@ -1529,6 +1533,9 @@ int dabgpu_decode_stream_reset(dabgpu_ctx *ctx) {
     return DABGPU_OK;
 }
 
+static int decode_stream_frames_body(dabgpu_ctx *ctx, const int8_t *soft, size_t soft_stride, int n_frames, uint8_t *fib,
+                                     uint8_t *crc_ok, const dabgpu_subchannel *sc, int n_subchannels, uint8_t *const *out);
+
 int dabgpu_decode_stream_frames(dabgpu_ctx *ctx, const int8_t *soft, size_t soft_stride, int n_frames, uint8_t *fib,
                                 uint8_t *crc_ok, const dabgpu_subchannel *sc, int n_subchannels, uint8_t *const *out) {
     if (!ctx || !soft || !fib || !crc_ok || n_frames < 0 || n_subchannels < 0) return DABGPU_ERR_ARG;
@@ -1536,6 +1543,20 @@ int dabgpu_decode_stream_frames(dabgpu_ctx *ctx, const int8_t *soft, size_t soft
     if (n_subchannels > 0 && (!sc || !out)) return DABGPU_ERR_ARG;
     if (n_frames == 0) return DABGPU_OK;
     if (soft_stride < size_t(NB_FRAME_BITS) && n_frames > 1) return DABGPU_ERR_ARG;
+    const int rc = decode_stream_frames_body(ctx, soft, soft_stride, n_frames, fib, crc_ok, sc, n_subchannels, out);
+    if (rc != DABGPU_OK) {
+        // A call that failed part-way leaves rings that have missed this frame (and `live` marks on some of them): no
+        // ring continues the stream any more.  All of them go; the next call starts every sub-channel from erasures.
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipGetLastError();
+        for (auto &h : ctx->sub_history) { (void)hipFree(h.ring[0]); (void)hipFree(h.ring[1]); }
+        ctx->sub_history.clear();
+    }
+    return rc;
+}
+
+static int decode_stream_frames_body(dabgpu_ctx *ctx, const int8_t *soft, size_t soft_stride, int n_frames, uint8_t *fib,
+                                     uint8_t *crc_ok, const dabgpu_subchannel *sc, int n_subchannels, uint8_t *const *out) {
     auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
     const size_t nb_fib = size_t(n_frames) * NB_FIBS * 32, nb_crc = size_t(n_frames) * NB_FIBS;
     std::vector<size_t> out_off(n_subchannels), out_bytes(n_subchannels);

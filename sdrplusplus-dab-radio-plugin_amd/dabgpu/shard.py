@@ -25,3 +25,15 @@ def reduce_report(dist, device, elapsed_s, frames_done, flags_ok):
     f = torch.tensor([int(bool(x)) for x in flags_ok], dtype=torch.int64, device=device)
     dist.all_reduce(f, op=dist.ReduceOp.MIN)
     return float(t.item()), int(n.item()), [bool(x) for x in f.tolist()]
+
+
+def gather_per_rank(dist, device, values):
+    """Every rank's row of floats, in rank order, on every rank (one all_gather of len(values) doubles)."""
+    import torch
+    row = [float(v) for v in values]
+    if dist is None or not dist.is_initialized():
+        return [row]
+    t = torch.tensor(row, dtype=torch.float64, device=device)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [o.tolist() for o in out]

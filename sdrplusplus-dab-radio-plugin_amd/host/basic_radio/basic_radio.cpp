@@ -25,9 +25,16 @@ int BasicRadio::AddSubchannel(const dabgpu_subchannel &sc) {
     return add_subchannel_locked(sc);
 }
 
+// A sub-channel joins the per-frame call only if that call will accept it: inside the CIF and clear of every
+// sub-channel already in the call (dabgpu_decode_frames_dev rejects a whole call whose sub-channels overlap -- one
+// bad FIG 0/1 must not be able to silence the FIC and every other service).
 int BasicRadio::add_subchannel_locked(const dabgpu_subchannel &sc) {
     const int nbytes = dabgpu_subchannel_bytes(&sc);
     if (nbytes < 0) return nbytes;
+    if (sc.start_address < 0 || sc.length <= 0 || sc.start_address + sc.length > 864) return DABGPU_ERR_ARG;
+    for (const Subchannel &o : m_subchannels)
+        if (sc.start_address < o.desc.start_address + o.desc.length && o.desc.start_address < sc.start_address + sc.length)
+            return DABGPU_ERR_ARG;
     Subchannel s;
     s.desc = sc;
     s.nbytes = nbytes;
@@ -52,15 +59,18 @@ void BasicRadio::Process(tcb::span<const viterbi_bit_t> buf) {
     // (the time de-interleaver state of every sub-channel stays on the device between frames)
     const int rc = dabgpu_decode_stream_frames(m_ctx, m_frame.data(), m_frame.size(), 1, m_fib.data(), m_crc.data(),
                                                m_call_sc.data(), int(n_sub), m_call_out.data());
-    if (rc != DABGPU_OK) return;                                // no exceptions on the streaming path: the frame is lost
-    for (uint8_t ok : m_crc) {
-        m_total_fibs++;
-        if (!ok) m_total_fib_errors++;
+    if (rc != DABGPU_OK) {
+        // No exceptions on the streaming path.  The sub-channels' frame is lost (their de-interleaver rings on the device
+        // were dropped by the failed call, so they start over), but the FIC must keep flowing: it is what repairs a
+        // bad configuration.
+        m_total_frames_lost++;
+        for (Subchannel &s : m_subchannels) s.cifs_seen = 0;
+        if (dabgpu_fic_decode(m_ctx, m_frame.data(), m_frame.size(), 1, m_fib.data(), m_crc.data()) != DABGPU_OK) return;
+        process_fibs_locked();
+        if (m_auto_channels) update_channels_from_database();
+        return;
     }
-    m_obs_fic.Notify(tcb::span<const uint8_t>(m_fib.data(), m_fib.size()),
-                     tcb::span<const uint8_t>(m_crc.data(), m_crc.size()));
-    for (size_t i = 0; i < m_crc.size(); i++)
-        if (m_crc[i]) m_fic_parser.ProcessFIB(tcb::span<const uint8_t>(m_fib.data() + 32 * i, 32));
+    process_fibs_locked();
     for (size_t i = 0; i < n_sub; i++) {
         Subchannel &s = m_subchannels[i];
         for (int c = 0; c < m_params.nb_cifs; c++) {
@@ -74,6 +84,18 @@ void BasicRadio::Process(tcb::span<const viterbi_bit_t> buf) {
     }
     // sub-channels the FIC has announced by now join the call from the next frame on
     if (m_auto_channels) update_channels_from_database();
+}
+
+// FIB counters, the On_FIC observers and the FIG parser (mutex held)
+void BasicRadio::process_fibs_locked() {
+    for (uint8_t ok : m_crc) {
+        m_total_fibs++;
+        if (!ok) m_total_fib_errors++;
+    }
+    m_obs_fic.Notify(tcb::span<const uint8_t>(m_fib.data(), m_fib.size()),
+                     tcb::span<const uint8_t>(m_crc.data(), m_crc.size()));
+    for (size_t i = 0; i < m_crc.size(); i++)
+        if (m_crc[i]) m_fic_parser.ProcessFIB(tcb::span<const uint8_t>(m_fib.data() + 32 * i, 32));
 }
 
 // Open every audio component whose sub-channel the FIC has described (called with the mutex held).
@@ -111,7 +133,19 @@ void BasicRadio::update_channels_from_database() {
             sc.bitrate_kbps = int(CalculateEEPBitrate(*sub));
             ok = sc.bitrate_kbps > 0;
         }
-        const int idx = ok ? add_subchannel_locked(sc) : -1;
+        int idx = -1;
+        if (ok) {
+            // a sub-channel registered by hand (AddSubchannel) that the FIC now announces with the same range and
+            // profile is already open: the audio channel attaches to it instead of claiming the range twice
+            for (size_t k = 0; k < m_subchannels.size() && idx < 0; k++) {
+                const dabgpu_subchannel &d = m_subchannels[k].desc;
+                if (d.start_address == sc.start_address && d.length == sc.length && d.bitrate_kbps == sc.bitrate_kbps &&
+                    d.is_uep == sc.is_uep && d.eep_type == sc.eep_type && d.protection_level == sc.protection_level && !m_subchannels[k].dab_plus &&
+                    !m_subchannels[k].dab)
+                    idx = int(k);
+            }
+            if (idx < 0) idx = add_subchannel_locked(sc);
+        }
         if (idx < 0) {
             m_rejected.push_back(sub->id);
             m_total_unsupported++;

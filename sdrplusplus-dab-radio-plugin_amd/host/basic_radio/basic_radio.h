@@ -62,6 +62,8 @@ public:
     int AddSubchannel(const dabgpu_subchannel &sc);
     int GetTotalFIBs() const { return m_total_fibs; }
     int GetTotalFIBErrors() const { return m_total_fib_errors; }
+    // frames whose sub-channels could not be decoded (the per-frame GPU call failed; the FIC was decoded on its own)
+    int GetTotalFramesLost() const { return m_total_frames_lost; }
 
 private:
     struct Subchannel {
@@ -73,6 +75,7 @@ private:
         Basic_DAB_Channel *dab = nullptr;
     };
     void update_channels_from_database();
+    void process_fibs_locked();
     int add_subchannel_locked(const dabgpu_subchannel &sc);
     const DAB_Parameters m_params;
     dabgpu_ctx *m_ctx;
@@ -95,4 +98,5 @@ private:
     bool m_pending_components = false;                   // a component whose sub-channel is not described yet
     bool m_auto_channels = true;
     int m_total_unsupported = 0;
+    int m_total_frames_lost = 0;
 };

@@ -2,6 +2,7 @@
 // A field is written once; a later FIG carrying a different value for it counts as a conflict and is ignored
 // (a corrupted FIB that slipped through the CRC must not rewrite the multiplex).
 #pragma once
+#include <algorithm>
 #include <string>
 #include "dab/dab_misc_info.h"
 #include "dab/database/dab_database.h"
@@ -38,14 +39,19 @@ public:
     const DAB_Misc_Info &GetMiscInfo() const { return m_misc; }
     void SetEnsembleLabel(const std::string &label) { set_string(m_db.ensemble.label, label); }
 
+    // Entities are found or created by id with a linear search, under the radio mutex: every list is capped, so a
+    // hostile or garbage FIC that passes the CRC cannot grow them (24-bit DRM ids, 16-bit PI codes / EIds, 32-bit
+    // service ids ...) into quadratic work.  An entity beyond the cap lands in a scratch object that nobody lists, and
+    // counts as a conflict.
+    static constexpr size_t MAX_ENTITIES = 1024;
+
     Subchannel &GetSubchannel(subchannel_id_t id, bool *is_new) {
         for (auto &s : m_db.subchannels)
             if (s.id == id) { *is_new = false; return s; }
-        m_db.subchannels.emplace_back();
-        m_db.subchannels.back().id = id;
         *is_new = true;
-        changed();
-        return m_db.subchannels.back();
+        Subchannel &s = create(m_db.subchannels, m_sink_subchannel);
+        s.id = id;
+        return s;
     }
     Service *FindService(uint32_t sid) {
         for (auto &s : m_db.services)
@@ -55,23 +61,20 @@ public:
     Service &GetService(uint32_t sid, bool bits32 = false) {
         for (auto &s : m_db.services)
             if (s.id.value == sid) return s;
-        m_db.services.emplace_back();
-        m_db.services.back().id.value = sid;
-        m_db.services.back().id.type = bits32 ? ServiceIdType::BITS32 : ServiceIdType::BITS16;
-        m_db.ensemble.nb_services = uint8_t(m_db.services.size());
-        changed();
-        return m_db.services.back();
+        Service &s = create(m_db.services, m_sink_service);
+        s.id.value = sid;
+        s.id.type = bits32 ? ServiceIdType::BITS32 : ServiceIdType::BITS16;
+        m_db.ensemble.nb_services = uint8_t(std::min<size_t>(m_db.services.size(), 255));
+        return s;
     }
     void SetServiceLabel(uint32_t sid, const std::string &label) { set_string(GetService(sid).label, label); }
     ServiceComponent &GetServiceComponent(uint32_t sid, subchannel_id_t subchannel_id, bool *is_new) {
         for (auto &c : m_db.service_components)
             if (c.service_id.value == sid && c.subchannel_id == subchannel_id) { *is_new = false; return c; }
-        m_db.service_components.emplace_back();
-        auto &c = m_db.service_components.back();
+        auto &c = create(m_db.service_components, m_sink_component);
         c.service_id.value = sid;
         c.subchannel_id = subchannel_id;
         *is_new = true;
-        changed();
         return c;
     }
     // a value written once; a later different value is a conflict and is ignored
@@ -93,35 +96,31 @@ public:
     LinkService &GetLinkService(lsn_t lsn, bool *is_new) {
         for (auto &l : m_db.link_services)
             if (l.id == lsn) { *is_new = false; return l; }
-        m_db.link_services.emplace_back();
-        m_db.link_services.back().id = lsn;
         *is_new = true;
-        changed();
-        return m_db.link_services.back();
+        LinkService &l = create(m_db.link_services, m_sink_link);
+        l.id = lsn;
+        return l;
     }
     FM_Service &GetFMService(uint16_t pi) {
         for (auto &f : m_db.fm_services)
             if (f.RDS_PI_code == pi) return f;
-        m_db.fm_services.emplace_back();
-        m_db.fm_services.back().RDS_PI_code = pi;
-        changed();
-        return m_db.fm_services.back();
+        FM_Service &f = create(m_db.fm_services, m_sink_fm);
+        f.RDS_PI_code = pi;
+        return f;
     }
     DRM_Service &GetDRMService(uint32_t code) {
         for (auto &f : m_db.drm_services)
             if (f.drm_code == code) return f;
-        m_db.drm_services.emplace_back();
-        m_db.drm_services.back().drm_code = code;
-        changed();
-        return m_db.drm_services.back();
+        DRM_Service &f = create(m_db.drm_services, m_sink_drm);
+        f.drm_code = code;
+        return f;
     }
     OtherEnsemble &GetOtherEnsemble(uint16_t eid) {
         for (auto &o : m_db.other_ensembles)
             if (o.id == eid) return o;
-        m_db.other_ensembles.emplace_back();
-        m_db.other_ensembles.back().id = eid;
-        changed();
-        return m_db.other_ensembles.back();
+        OtherEnsemble &o = create(m_db.other_ensembles, m_sink_other);
+        o.id = eid;
+        return o;
     }
     template <class T>
     void add_unique(std::vector<T> &v, T x) {
@@ -135,6 +134,25 @@ public:
     void changed() { m_stats.nb_total++; m_stats.nb_updates++; }
 
 private:
+    // a new entity at the end of its list, or (list full) the scratch object, reset
+    template <class T>
+    T &create(std::vector<T> &v, T &sink) {
+        if (v.size() >= MAX_ENTITIES) {
+            same(false);
+            sink = T{};
+            return sink;
+        }
+        v.emplace_back();
+        changed();
+        return v.back();
+    }
+    Subchannel m_sink_subchannel;
+    Service m_sink_service;
+    ServiceComponent m_sink_component;
+    LinkService m_sink_link;
+    FM_Service m_sink_fm;
+    DRM_Service m_sink_drm;
+    OtherEnsemble m_sink_other;
     void set_string(std::string &dst, const std::string &v) {
         if (dst.empty() && !v.empty()) { dst = v; changed(); }
         else same(dst == v);

@@ -175,6 +175,26 @@ def test_host_parser_fuzz(parser_exe, tmp_path):
     assert got == FO.parse_fibs(fibs).lines()
 
 
+def test_host_parser_entity_lists_are_capped(parser_exe, tmp_path):
+    """A FIC that announces thousands of distinct services, DRM / FM services, other ensembles and linkage sets (each
+    FIB CRC-valid) must not grow the database without bound: every entity list stops at 1024 entries, the overflow is
+    counted as conflicts, and both parsers agree on what is kept."""
+    S = synth
+    figs = [S.fig0_0(0xE1C5, 1)]
+    for k in range(1500):
+        figs.append(S.fig0_2([{"sid": 0x1000 + k, "components": [{"subchannel": k % 64, "ascty": 63}]}]))
+        figs.append(S.fig0_21([(0x200000 + k, 6, 0, [6095000]), (0x3000 + k, 8, 0, [87600000]), (0x4000 + k, 0, 1, [174928000])]))
+        figs.append(S.fig0_6(k & 0xFFF, [0x1000 + k], idlq=0))
+    fibs = S.pack_fibs(figs)
+    got, stats = run_parser(parser_exe, fibs, tmp_path)
+    want = FO.parse_fibs(fibs).lines()
+    assert got == want
+    for kind in ("service ", "drm ", "fm ", "other_ensemble ", "link ", "component "):
+        n = sum(l.startswith(kind) for l in got)
+        assert n == 1024, (kind, n)
+    assert int(stats.split("conflicts=")[1]) >= 5 * (1500 - 1024)
+
+
 def test_host_parser_under_sanitizers(tmp_path):
     """The same fuzz input through an AddressSanitizer + UBSan build of the parser (CPU build only: the pool has no
     GPU sanitizers)."""

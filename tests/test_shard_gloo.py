@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from dabgpu.shard import ensembles_of_rank, reduce_report
+from dabgpu.shard import ensembles_of_rank, reduce_report, gather_per_rank
 
 
 def _free_port():
@@ -25,8 +25,9 @@ def _worker(rank, world, port, q):
     mine = ensembles_of_rank(128, world, rank)
     elapsed, frames, flags = reduce_report(dist, torch.device("cpu"), 1.0 + rank, len(mine) * 16,
                                            [True, rank == 0])
+    rows = gather_per_rank(dist, torch.device("cpu"), [10.0 * rank, rank + 0.5])
     dist.barrier()
-    q.put((rank, mine, elapsed, frames, flags))
+    q.put((rank, mine, elapsed, frames, flags, rows))
     dist.destroy_process_group()
 
 
@@ -44,13 +45,15 @@ def test_two_rank_sharding_and_report():
         assert p.exitcode == 0
     owned = res[0][1] + res[1][1]
     assert sorted(owned) == list(range(128)) and not set(res[0][1]) & set(res[1][1])
-    for _, _, elapsed, frames, flags in res:
+    for _, _, elapsed, frames, flags, rows in res:
         assert elapsed == 2.0 and frames == 128 * 16 and flags == [True, False]
+        assert rows == [[0.0, 0.5], [10.0, 1.5]]                      # every rank sees every rank's row, in rank order
 
 
 def test_single_process_report_passthrough():
     assert reduce_report(None, None, 0.5, 10, [True]) == (0.5, 10, [True])
     assert ensembles_of_rank(10, 4, 3) == [3, 7]
+    assert gather_per_rank(None, None, [1, 2.5]) == [[1.0, 2.5]]
 
 
 import json
@@ -66,7 +69,7 @@ def _run_bench(nproc, extra_env=None, ensembles=4, frames=16, more=()):
     env = dict(os.environ)
     env.update(extra_env or {})
     args = ["--ensembles", str(ensembles), "--frames", str(frames), "--steps", "2", "--warmup", "1", "--cpu-seconds", "0",
-            "--no-fft-stage", "--no-selective", "--no-closed-loop"] + list(more)
+            "--no-fft-stage", "--no-selective", "--no-closed-loop", "--no-sustained"] + list(more)
     if nproc == 1 and not (extra_env or {}).get("DABGPU_DIST_FORCE"):
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + args
     else:
@@ -77,6 +80,58 @@ def _run_bench(nproc, extra_env=None, ensembles=4, frames=16, more=()):
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]                  # ONE JSON line, from rank 0
     return json.loads(lines[0])
+
+
+def _plain_bench(gpus, env_extra, timeout=900):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    env.update(env_extra)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--ensembles", "4", "--frames", "16", "--steps", "2",
+           "--warmup", "1", "--cpu-seconds", "0", "--no-fft-stage", "--no-selective", "--no-closed-loop", "--no-sustained"]
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+
+
+def test_bench_gpus_2_starts_two_ranks_by_itself_or_fails():
+    """`python bench.py --gpus 2` with no launcher around it must start two ranks itself (a fresh torch.distributed.run
+    child) and must never come back as a one-rank result.  On this GPU-less host both ranks stop at "needs a gfx950
+    GPU": the parent relays the failure -- non-zero exit, no JSON line."""
+    r = _plain_bench(2, {})
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert "needs a gfx950 GPU" in r.stderr or "device(s) visible" in r.stderr, r.stderr[-2000:]
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    """--gpus 2 inside a one-rank environment (WORLD_SIZE=1) is an error, not a one-GPU measurement labelled n_gpus 1."""
+    r = _plain_bench(2, {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.gpu
+def test_plain_bench_gpus_2_reports_two_ranks():
+    """The form the driver's SCALE run may use: `python bench.py --gpus 2`, no torchrun.  Two ranks are started by
+    bench.py itself (sharing this box's one GPU, so gloo carries the reductions; with >= 2 devices the default RCCL
+    backend is taken) and the line says n_gpus 2 with one per_rank row each."""
+    r = _plain_bench(2, {"DABGPU_DIST_BACKEND": "gloo"})
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["rccl_world"] == 2 and len(j["per_rank"]) == 2
+    assert [p["rank"] for p in j["per_rank"]] == [0, 1] and all(p["frames_per_s"] > 0 for p in j["per_rank"])
+    assert j["fic_bit_exact"] is True and j["msc_bit_exact"] is True
+    assert abs(j["value"] * j["ms_per_step"] * 1e-3 - 128) < 1e-3
+
+
+@pytest.mark.gpu
+def test_plain_bench_gpus_2_without_two_devices_fails_under_rccl():
+    """With the default backend (RCCL) two ranks need two devices: on the one-GPU box the run must fail loudly."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("box has two devices")
+    r = _plain_bench(2, {})
+    assert r.returncode != 0 and "device(s) visible" in r.stderr
 
 
 @pytest.mark.gpu
