@@ -576,32 +576,87 @@ def closed_loop_leg(torch, dabgpu, synth, ctx, dev, stream, iq, ens, sc, soft, f
             step(k)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    cnt = counts.cpu().numpy()
-    frames = acq.cpu().numpy().view(dabgpu.ACQUIRED_FRAME_DTYPE).reshape(E, F)
-    fib_h, crc_h, msc_h = fib.cpu().numpy().reshape(E, F, 12, 32), crc.cpu().numpy().reshape(E, F, 12), msc.cpu().numpy()
-    found = int(cnt.sum())
-    locked = 0
-    ok_fic, ok_msc = True, True
-    for s in range(E):
-        e = ens[s]
-        for i in range(int(cnt[s])):
-            fr = frames[s, i]
-            if (fr["flags"] & 3) != 3:
-                continue
-            locked += 1
-            j = int(round((int(fr["start"]) + off - synth.NB_NULL) / L))         # which transmitted frame this is
-            ok_fic &= bool(crc_h[s, i].all()) and bool((fib_h[s, i] == e.fibs[j % 4]).all())
-            for c in range(4):
-                t = 4 * i + c                                                     # CIF index inside the capture
-                if t >= 15:                                                       # de-interleaver filled (no carried history)
-                    ok_msc &= bool((msc_h[s, t] == e.msc_bytes[(4 * (j - i) + t - 15) % 16]).all())
-    return {"value": locked * steps / el, "unit": "frames/s", "ms_per_step": el / steps * 1e3,
-            "frames_found_per_step": found, "frames_locked_per_step": locked, "frames_in_the_captures": E * (F - 1),
-            "acquire_ms": evs[0].elapsed_time(evs[1]), "ofdm_ms": evs[1].elapsed_time(evs[2]),
-            "decode_ms": evs[2].elapsed_time(evs[3]),
-            "fic_bit_exact": ok_fic and locked > 0, "msc_bit_exact": ok_msc and locked > 0,
-            "what": "captures start %d samples into a frame; dabgpu_acquire_dev -> dabgpu_ofdm_demod_acquired_dev -> "
-                    "dabgpu_decode_frames_dev; no offset, timing or alignment supplied" % off}
+    def verify():
+        """(frames found, frames locked, FIC bit-exact, MSC bit-exact) of what the last step left in the buffers"""
+        cnt = counts.cpu().numpy()
+        frames = acq.cpu().numpy().view(dabgpu.ACQUIRED_FRAME_DTYPE).reshape(E, F)
+        fib_h, crc_h, msc_h = fib.cpu().numpy().reshape(E, F, 12, 32), crc.cpu().numpy().reshape(E, F, 12), msc.cpu().numpy()
+        found = int(cnt.sum())
+        locked = 0
+        ok_fic, ok_msc = True, True
+        for s in range(E):
+            e = ens[s]
+            for i in range(int(cnt[s])):
+                fr = frames[s, i]
+                if (fr["flags"] & 3) != 3:
+                    continue
+                locked += 1
+                j = int(round((int(fr["start"]) + off - synth.NB_NULL) / L))         # which transmitted frame this is
+                ok_fic &= bool(crc_h[s, i].all()) and bool((fib_h[s, i] == e.fibs[j % 4]).all())
+                for c in range(4):
+                    t = 4 * i + c                                                     # CIF index inside the capture
+                    if t >= 15:                                                       # de-interleaver filled (no carried history)
+                        ok_msc &= bool((msc_h[s, t] == e.msc_bytes[(4 * (j - i) + t - 15) % 16]).all())
+        return found, locked, ok_fic and locked > 0, ok_msc and locked > 0
+
+    found, locked, ok_fic, ok_msc = verify()
+    out = {"value": locked * steps / el, "unit": "frames/s", "ms_per_step": el / steps * 1e3,
+           "frames_found_per_step": found, "frames_locked_per_step": locked, "frames_in_the_captures": E * (F - 1),
+           "acquire_ms": evs[0].elapsed_time(evs[1]), "ofdm_ms": evs[1].elapsed_time(evs[2]),
+           "decode_ms": evs[2].elapsed_time(evs[3]),
+           "fic_bit_exact": ok_fic, "msc_bit_exact": ok_msc,
+           "what": "captures start %d samples into a frame; dabgpu_acquire_dev -> dabgpu_ofdm_demod_acquired_dev -> "
+                   "dabgpu_decode_frames_dev; no offset, timing or alignment supplied" % off}
+
+    # ---- tracking: the streams are acquired ONCE (step 0: the sequence above + dabgpu_track_start_dev); every later
+    # capture goes through dabgpu_ofdm_demod_tracked_dev alone -- per frame a PRS synchronisation at the position the
+    # stream's state predicts (no second pass over the capture for the null-symbol search), demodulation where the frame
+    # lies, then the state update (fine-frequency loop, next frame start, drift).  The same buffer stands for the next
+    # capture: it "begins" found-frames x 196608 samples later, which puts the next frame where this call's first one was.
+    per_stream = found // E
+    advance = per_stream * L
+    soft.zero_(); fib.zero_(); crc.zero_(); msc.zero_()
+    ctx.streams_reset(E)
+    ctx.acquire_dev(d_cap, F * L, E, n_samples, F, acq.data_ptr(), counts.data_ptr(), None, stream)
+    ctx.track_start_dev(acq.data_ptr(), counts.data_ptr(), E, F, advance, stream)
+    acq.zero_(); counts.zero_()
+
+    def tstep():
+        ctx.ofdm_demod_tracked_dev(d_cap, F * L, E, n_samples, F, advance, soft.data_ptr(), acq.data_ptr(), counts.data_ptr(),
+                                   None, None, None, stream)
+        ctx.decode_frames_dev(soft.data_ptr(), dabgpu.NB_FRAME_BITS, E, F, fib.data_ptr(), crc.data_ptr(), [sc],
+                              [None], [None], [msc.data_ptr()], stream)
+    for k in range(2):
+        tstep()
+    torch.cuda.synchronize()
+    tev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    t0 = time.perf_counter()
+    for k in range(steps):
+        if k == steps - 1:
+            tev[0].record()
+            ctx.ofdm_demod_tracked_dev(d_cap, F * L, E, n_samples, F, advance, soft.data_ptr(), acq.data_ptr(), counts.data_ptr(),
+                                       None, None, None, stream)
+            tev[1].record()
+            ctx.decode_frames_dev(soft.data_ptr(), dabgpu.NB_FRAME_BITS, E, F, fib.data_ptr(), crc.data_ptr(), [sc],
+                                  [None], [None], [msc.data_ptr()], stream)
+            tev[2].record()
+        else:
+            tstep()
+    torch.cuda.synchronize()
+    tel = time.perf_counter() - t0
+    tfound, tlocked, tfic, tmsc = verify()
+    stats = [ctx.get_stats(s) for s in range(E)]
+    out["tracking"] = {"value": tlocked * steps / tel, "unit": "frames/s", "ms_per_step": tel / steps * 1e3,
+                       "frames_found_per_step": tfound, "frames_locked_per_step": tlocked,
+                       "track_sync_demod_update_ms": tev[0].elapsed_time(tev[1]), "decode_ms": tev[1].elapsed_time(tev[2]),
+                       "fic_bit_exact": tfic, "msc_bit_exact": tmsc,
+                       "streams_tracking": int(sum(st.tracking for st in stats)),
+                       "frames_desync_total": int(sum(st.total_frames_desync for st in stats)),
+                       "max_abs_drift_samples_per_frame": float(max(abs(st.drift) for st in stats)),
+                       "what": "acquired once (dabgpu_acquire_dev + dabgpu_track_start_dev, untimed); every step: "
+                               "dabgpu_ofdm_demod_tracked_dev (PRS synchronisation at the predicted positions, demodulation in "
+                               "place, state update on the device) -> dabgpu_decode_frames_dev"}
+    return out
 
 
 if __name__ == "__main__":

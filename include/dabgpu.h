@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DABGPU_ABI_VERSION 3   /* 3: + buffer placement helpers (alloc_frame_buffers, device_alloc_apart) */
+#define DABGPU_ABI_VERSION 4   /* 4: + timing tracking (64-byte stream state, tracked / frame calls, peak rule in the acquire cfg) */
 
 typedef enum dabgpu_status {
     DABGPU_OK = 0,
@@ -202,18 +202,27 @@ int dabgpu_ofdm_demod_frames(dabgpu_ctx *ctx, const float *iq, size_t frame_stri
 /* (s, f) starts at iq + (s*frames_per_stream + f)*frame_stride.               */
 /* cyc may be NULL (the library keeps the correlations in its own scratch).    */
 /* ------------------------------------------------------------------------ */
-typedef struct dabgpu_stream_state {      /* DEVICE memory, 32 bytes */
+typedef struct dabgpu_stream_state {      /* DEVICE memory, 64 bytes */
     float fine_freq_offset;               /* cycles/sample, within +-0.5/2048                     */
     float coarse_freq_offset;             /* cycles/sample (whole carriers: -k/2048)              */
     float signal_average;                 /* running mean of |re|+|im| per sample                 */
     float last_fine_error;                /* residual the most recent call measured, cycles/sample */
     int32_t total_frames_read;
-    int32_t total_frames_desync;          /* frames whose level fell below thresh_null_start x average */
-    int32_t reserved[2];
+    int32_t total_frames_desync;          /* frames lost: level below thresh_null_start x average, PRS not found, */
+                                          /* or (tracked calls) begun before the capture did                      */
+    int32_t tracking;                     /* tracked calls: 1 = next_frame_start is valid                         */
+    int32_t last_time_offset;             /* tracked calls: where the most recent frame's impulse-response peak    */
+                                          /* sat relative to the predicted position, samples                       */
+    double next_frame_start;              /* first sample of the next frame (PRS prefix minus timing_margin),      */
+                                          /* relative to the first sample of the NEXT capture                      */
+    float drift;                          /* samples per frame the frame period differs from 196608                */
+    float last_peak_to_mean;              /* impulse-response peak / mean of the most recent frame                 */
+    int32_t reserved[4];
 } dabgpu_stream_state;
 
 typedef struct dabgpu_stats {             /* HOST copy with the derived fields the GUI prints */
-    int32_t state;                        /* OFDM_Demod::State value: 0 before the first frame, 4 = READING_SYMBOLS */
+    int32_t state;                        /* OFDM_Demod::State value: 0 before the first frame (and after a tracked */
+                                          /* stream lost every frame of a call), 4 = READING_SYMBOLS               */
     float fine_freq_offset;
     float coarse_freq_offset;
     float net_freq_offset;
@@ -221,6 +230,11 @@ typedef struct dabgpu_stats {             /* HOST copy with the derived fields t
     int32_t total_frames_read;
     int32_t total_frames_desync;
     float last_fine_error;
+    int32_t tracking;
+    int32_t last_time_offset;
+    double next_frame_start;
+    float drift;
+    float last_peak_to_mean;
 } dabgpu_stats;
 
 /* (re)create the context's stream states, all zero */
@@ -236,8 +250,13 @@ int dabgpu_ofdm_demod_streams_dev(dabgpu_ctx *ctx, const void *d_iq, size_t fram
 int dabgpu_ofdm_demod_streams(dabgpu_ctx *ctx, const float *iq, size_t frame_stride, int n_streams,
                               int frames_per_stream, float fine_freq_update_beta, int8_t *soft, float *cyc,
                               float *dqpsk);
-/* the seven scalars of src/render_radio_block.cpp:192-207 for one stream (synchronises the context stream) */
+/* the seven scalars of src/render_radio_block.cpp:192-207 for one stream.  Ordering: the states are read and written
+ * by the stream calls on whatever stream those were given; dabgpu_get_stats, dabgpu_set_stream_offsets and
+ * dabgpu_streams_reset first wait (on the host) for the most recent such call to finish, wherever it ran. */
 int dabgpu_get_stats(dabgpu_ctx *ctx, int stream_index, dabgpu_stats *out);
+/* signal_l1.update_beta (src/render_radio_block.cpp:235) and null_l1_search.thresh_null_start (:226-233) of the stream
+ * calls' level average and desync count; defaults 0.95 / 0.35 */
+int dabgpu_set_stream_loop(dabgpu_ctx *ctx, float signal_update_beta, float thr_null_start);
 
 /* Soft-bit selection (batch receivers that decode the FIC and a few sub-channels and never look at the rest of the
  * frame): from the next call on, dabgpu_ofdm_demod_frames[_dev], dabgpu_ofdm_demod_streams[_dev] and
@@ -335,6 +354,13 @@ typedef struct dabgpu_acquire_cfg {
     int32_t max_coarse_carriers; /* coarse search range (200)                                        */
     float min_peak_to_mean;      /* lock threshold on the impulse response (30 = 14.8 dB)            */
     int32_t timing_margin;       /* samples the FFT windows are kept inside the cyclic prefix (64)   */
+    /* which tap of the channel impulse response a frame is aligned to:                                  */
+    float impulse_peak_distance_probability; /* taps are scored |h|^2 w^2, w = 1 - (1 - p) |offset - expected| / 2552 */
+                                 /* (src/render_radio_block.cpp:225; 0.15; 1 = unweighted)           */
+    float first_path_rel;        /* > 0: the earliest tap within 504 samples before the scored peak  */
+                                 /* with at least max(rel x peak power, 16 x mean) replaces it, so   */
+                                 /* that a stronger LATE echo still falls inside the cyclic prefix   */
+                                 /* (0.25 = -6 dB); 0 = the scored peak itself, the reference's rule */
 } dabgpu_acquire_cfg;
 
 typedef struct dabgpu_acquired_frame {
@@ -356,6 +382,78 @@ int dabgpu_acquire(dabgpu_ctx *ctx, const float *iq, size_t stream_stride, int n
 int dabgpu_ofdm_demod_acquired_dev(dabgpu_ctx *ctx, const void *d_iq, size_t stream_stride, int n_streams,
                                    int max_frames, const dabgpu_acquired_frame *d_frames, int8_t *d_soft, void *d_cyc,
                                    void *d_dqpsk, void *stream);
+
+/* ------------------------------------------------------------------------ */
+/* Timing tracking: what OFDM_Demod's RUNNING_FINE_TIME_SYNC state does on     */
+/* every frame once locked (/root/reference/src/render_radio_block.cpp:196;    */
+/* knobs impulse_peak_threshold_db, impulse_peak_distance_probability,         */
+/* :224-225) -- for batches of streams, with the position kept on the device.  */
+/*                                                                            */
+/* A stream is acquired ONCE (dabgpu_acquire_dev on its first capture, then     */
+/* dabgpu_track_start_dev).  Every later capture goes through                  */
+/* dabgpu_ofdm_demod_tracked_dev alone: per stream, the frames the state        */
+/* predicts inside the capture (start_i = next_frame_start + i*(196608+drift)) */
+/* are synchronised on their own PRS (impulse response -> exact start, lock),   */
+/* demodulated where they lie with the stream's fine + coarse offset, and the   */
+/* state is moved on: fine-frequency loop from the cyclic-prefix correlations, */
+/* next_frame_start and drift from a line through the measured starts.         */
+/*   n_samples  samples per stream in this capture                             */
+/*   advance    the next capture of every stream will begin this many samples   */
+/*              after this one began.  Frames are only taken whole (+512        */
+/*              samples), so consecutive captures must overlap by at least one  */
+/*              frame + 512 + the drift: advance <= n_samples - 197632.         */
+/*   frames     [n_streams][max_frames] as dabgpu_acquire_dev writes them        */
+/*              (flags 3 = demodulated); counts[s] = frame slots of stream s     */
+/*              that lay inside the capture.  soft / cyc / dqpsk as             */
+/*              dabgpu_ofdm_demod_acquired_dev (slots without a locked frame:    */
+/*              erased soft bits).  cyc may be NULL.                            */
+/* A stream none of whose frames locked in a call stops tracking (state 0 in     */
+/* dabgpu_get_stats): acquire it again.                                         */
+/* ------------------------------------------------------------------------ */
+typedef struct dabgpu_track_cfg {
+    float fine_freq_update_beta;              /* 0.9                                                   */
+    float signal_update_beta;                 /* signal_l1.update_beta, 0.95                           */
+    float thr_null_start;                     /* 0.35                                                  */
+    float min_peak_to_mean;                   /* impulse_peak_threshold_db as a power ratio (100)      */
+    float impulse_peak_distance_probability;  /* 0.15, see dabgpu_acquire_cfg                          */
+    float first_path_rel;                     /* 0.25, see dabgpu_acquire_cfg                          */
+    float drift_beta;                         /* share of a measured drift error taken per call (0.5)  */
+    float coarse_freq_slow_beta;              /* frame call: see below (0.1)                           */
+    int32_t timing_margin;                    /* 64 (batch calls); the frame call uses the host's own   */
+    int32_t max_coarse_carriers;              /* frame call: whole-carrier search range, 0 = off (204) */
+    int32_t reserved[2];
+} dabgpu_track_cfg;
+void dabgpu_track_default_cfg(dabgpu_track_cfg *cfg);
+int dabgpu_track_start_dev(dabgpu_ctx *ctx, const dabgpu_acquired_frame *d_frames, const int32_t *d_counts, int n_streams,
+                           int max_frames, int64_t advance, void *stream);
+int dabgpu_ofdm_demod_tracked_dev(dabgpu_ctx *ctx, const void *d_iq, size_t stream_stride, int n_streams,
+                                  int64_t n_samples, int max_frames, int64_t advance, const dabgpu_track_cfg *cfg,
+                                  int8_t *d_soft, void *d_cyc, void *d_dqpsk, dabgpu_acquired_frame *d_frames,
+                                  int32_t *d_counts, void *stream);
+
+/* One frame of one stream from host memory, everything in ONE call: what OFDM_Demod does between "76 symbols are in
+ * the buffer" and the On_OFDM_Frame callback (RUNNING_COARSE_FREQ_SYNC / RUNNING_FINE_TIME_SYNC / READING_SYMBOLS,
+ * /root/reference/src/render_radio_block.cpp:195-197; src/radio_block.cpp:25).  One upload of the frame; on the
+ * device: synchronisation on the PRS, the coarse-offset update, demodulation with the stream's offsets, fine loop,
+ * counters, level; one download of {soft bits, sync result, statistics}; one synchronisation.
+ *   iq         76 * 2552 cf32 as the caller assembled them: iq[0] is its guess of the first PRS prefix sample,
+ *              `cfg->timing_margin` samples early
+ *   acquiring  != 0: first frame after a null-symbol detection -- the stream's fine offset is set from this PRS's own
+ *              cyclic prefix (so that already this frame is demodulated with it) and the whole-carrier offset found on
+ *              this PRS is STORED as its coarse offset (cfg->max_coarse_carriers > 0); 0: a residual of k carriers
+ *              moves the coarse offset by coarse_freq_slow_beta * k
+ *   result->flags  bit 0 = PRS found (peak_to_mean >= min_peak_to_mean), bit 1 = the FFT windows lie inside the
+ *              cyclic prefix (0 <= sync.time_offset <= 488); only a frame with both is demodulated (others: erased
+ *              soft bits, counted as desync)
+ *   dqpsk      optional [75][1536] cf32 (GetFrameDataVec) */
+typedef struct dabgpu_frame_result {
+    dabgpu_sync_result sync;
+    int32_t flags;
+    int32_t reserved;
+    dabgpu_stats stats;
+} dabgpu_frame_result;
+int dabgpu_ofdm_demod_stream_frame(dabgpu_ctx *ctx, int stream_index, const float *iq, int acquiring,
+                                   const dabgpu_track_cfg *cfg, int8_t *soft, float *dqpsk, dabgpu_frame_result *result);
 
 /* ------------------------------------------------------------------------ */
 /* A7..A11: FIC.  Replaces the FIC branch of BasicRadio::Process              */

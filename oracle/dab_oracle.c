@@ -598,6 +598,13 @@ int oracle_null_search(const float *iq, int64_t n_samples, float thr_start, floa
 void oracle_acquire_candidate(const float *iq, int64_t n_samples, int64_t cand, int max_coarse,
                               float min_peak_to_mean, int margin, oracle_acquired_frame *out)
 {
+    oracle_acquire_candidate_ex(iq, n_samples, cand, max_coarse, min_peak_to_mean, margin, 1.0f, 0.0f, out);
+}
+
+void oracle_acquire_candidate_ex(const float *iq, int64_t n_samples, int64_t cand, int max_coarse,
+                                 float min_peak_to_mean, int margin, float distance_prob, float first_path_rel,
+                                 oracle_acquired_frame *out)
+{
     const float *x = iq + 2 * (size_t)cand;
     double cr = 0.0, ci = 0.0;
     for (int i = 64; i < 440; i++) {
@@ -609,7 +616,7 @@ void oracle_acquire_candidate(const float *iq, int64_t n_samples, int64_t cand, 
     const float fine = (float)(-atan2(ci, cr) / (2.0 * M_PI * (double)DAB_NB_FFT));
     int32_t k, toff;
     float ptm, cptm;
-    oracle_sync_prs(x, fine, max_coarse, &k, &toff, &ptm, &cptm);
+    oracle_sync_prs_ex(x, fine, max_coarse, 0, distance_prob, first_path_rel, &k, &toff, &ptm, &cptm);
     out->start = cand + toff - margin;
     out->coarse_carriers = k;
     out->fine_offset = fine;
@@ -625,6 +632,13 @@ void oracle_acquire_candidate(const float *iq, int64_t n_samples, int64_t cand, 
 /* ------------------------------------------------------------------------- */
 void oracle_sync_prs(const float *sym, float freq_offset, int max_coarse, int32_t *k_out, int32_t *toff,
                      float *peak_to_mean, float *coarse_peak_to_mean)
+{
+    oracle_sync_prs_ex(sym, freq_offset, max_coarse, 0, 1.0f, 0.0f, k_out, toff, peak_to_mean, coarse_peak_to_mean);
+}
+
+void oracle_sync_prs_ex(const float *sym, float freq_offset, int max_coarse, int expected, float distance_prob,
+                        float first_path_rel, int32_t *k_out, int32_t *toff, float *peak_to_mean,
+                        float *coarse_peak_to_mean)
 {
     const int32_t dphi = (int32_t)lrint((double)freq_offset * 4294967296.0);
     float *y = (float *)malloc(sizeof(float) * 2 * DAB_NB_FFT);
@@ -692,14 +706,30 @@ void oracle_sync_prs(const float *sym, float freq_offset, int max_coarse, int32_
         Z[2 * b] = zr; Z[2 * b + 1] = -zi;                          /* conj */
     }
     oracle_fft2048(Z, H);
+    /* which tap: score = |h|^2 w^2, w = 1 - (1 - p) |t - expected| / 2552 (first maximum); then, if asked for, the
+       earliest tap within a cyclic prefix before it that reaches max(rel * peak power, 16 * mean) */
+    float *M = (float *)malloc(sizeof(float) * DAB_NB_FFT);
     float pk = -1.0f, tot = 0.0f;
     int pi = 0;
+    const float decay = (1.0f - distance_prob) * (1.0f / (float)DAB_NB_SYM_PERIOD);
     for (int n = 0; n < DAB_NB_FFT; n++) {
         const float m = H[2 * n] * H[2 * n] + H[2 * n + 1] * H[2 * n + 1];
+        M[n] = m;
         tot += m;
-        if (m > pk) { pk = m; pi = n; }
+        const int t = (n < DAB_NB_FFT / 2) ? n : n - DAB_NB_FFT;
+        const float w = 1.0f - decay * (float)abs(t - expected);
+        const float sc = (m * w) * w;
+        if (sc > pk) { pk = sc; pi = n; }
     }
+    const float peak = M[pi], mean = tot / (float)DAB_NB_FFT;
+    if (first_path_rel > 0.0f) {
+        const float a = first_path_rel * peak, b = 16.0f * mean;
+        const float thr = a > b ? a : b;
+        for (int d = DAB_NB_CP; d >= 1; d--)
+            if (M[(pi - d) & (DAB_NB_FFT - 1)] >= thr) { pi = (pi - d) & (DAB_NB_FFT - 1); break; }
+    }
+    free(M);
     *toff = (pi < DAB_NB_FFT / 2) ? pi : pi - DAB_NB_FFT;
-    *peak_to_mean = pk / (tot / (float)DAB_NB_FFT);
+    *peak_to_mean = peak / mean;
     free(y); free(X); free(Q); free(Z); free(H);
 }

@@ -129,6 +129,17 @@ void oracle_ofdm_demod_frame(const float *iq, float freq_offset, int8_t *soft,
  *   *peak_to_mean = |h|^2 peak / mean,  *coarse_peak_to_mean = |D_k|^2 peak / mean over the scanned k */
 void oracle_sync_prs(const float *sym, float freq_offset, int max_coarse, int32_t *k, int32_t *toff,
                      float *peak_to_mean, float *coarse_peak_to_mean);
+/* The same with the tap choice of the GUI's "Impulse peak distance weight"
+ * (impulse_peak_distance_probability, /root/reference/src/render_radio_block.cpp:225) [RECALL: the weighting lives in
+ * the absent DAB-Radio sources; this is the form this oracle fixes]:
+ *   score[n] = |h[n]|^2 * w^2,  w = 1 - (1 - distance_prob) * |t(n) - expected| / 2552,  t(n) the signed offset;
+ *   the peak is the first maximum of the score; *peak_to_mean = |h[peak]|^2 / mean (unweighted).
+ *   first_path_rel > 0: the EARLIEST tap within 504 samples before the peak with |h|^2 >= max(first_path_rel *
+ *   |h[peak]|^2, 16 * mean) replaces it (alignment to the first significant path; 0 = the scored peak itself).
+ * max_coarse = 0: no whole-carrier search (k = 0). */
+void oracle_sync_prs_ex(const float *sym, float freq_offset, int max_coarse, int expected, float distance_prob,
+                        float first_path_rel, int32_t *k, int32_t *toff, float *peak_to_mean,
+                        float *coarse_peak_to_mean);
 
 /* ---- acquisition on an unaligned capture (first half) ----
  * Stands behind the FINDING_NULL_POWER_DIP / READING_NULL_AND_PRS states of OFDM_Demod
@@ -160,6 +171,10 @@ typedef struct oracle_acquired_frame {
 } oracle_acquired_frame;
 void oracle_acquire_candidate(const float *iq, int64_t n_samples, int64_t cand, int max_coarse,
                               float min_peak_to_mean, int margin, oracle_acquired_frame *out);
+/* with the tap choice of oracle_sync_prs_ex (expected offset 0) */
+void oracle_acquire_candidate_ex(const float *iq, int64_t n_samples, int64_t cand, int max_coarse,
+                                 float min_peak_to_mean, int margin, float distance_prob, float first_path_rel,
+                                 oracle_acquired_frame *out);
 
 /* ---- DAB+ audio super-frame (dabplus_oracle.c) ---- */
 uint16_t oracle_firecode(const uint8_t *bytes, int n);

@@ -196,7 +196,7 @@ def ofdm_demod_frame(iq, freq_offset=0.0, want_spectra=False, want_cyc=False, wa
     return soft, spectra, cyc, dq
 
 
-def stream_update(state, cyc, iq_last_frame, beta, thr_null_start=0.35):
+def stream_update(state, cyc, iq_last_frame, beta, thr_null_start=0.35, signal_beta=0.95):
     """Restatement of the fine-frequency loop and counters of the stream call (TEST INFRASTRUCTURE; parity unpinned:
     the loop runs inside the absent DAB-Radio OFDM_Demod, its existence and knobs are visible at
     /root/reference/src/render_radio_block.cpp:202-207, :216).  state: dict with fine_freq_offset,
@@ -221,7 +221,8 @@ def stream_update(state, cyc, iq_last_frame, beta, thr_null_start=0.35):
         new["total_frames_read"] = state["total_frames_read"] + frames - 1
     else:
         new["total_frames_read"] = state["total_frames_read"] + frames
-        new["signal_average"] = np.float32(0.95 * state["signal_average"] + 0.05 * l1) if state["signal_average"] > 0 else l1
+        sb = np.float32(signal_beta)
+        new["signal_average"] = (sb * np.float32(state["signal_average"]) + (np.float32(1.0) - sb) * l1) if state["signal_average"] > 0 else l1
     return new
 
 
@@ -268,13 +269,15 @@ def bench_pipeline_timed(iq, freq_offset, seconds, mask, nsteps, sc_bits):
     return int(done.value), float(el)
 
 
-def sync_prs(sym, freq_offset=0.0, max_coarse=200):
-    """sym: complex64[2552] from the candidate PRS start -> (coarse_carriers, time_offset, peak_to_mean, coarse_ptm)."""
+def sync_prs(sym, freq_offset=0.0, max_coarse=200, expected=0, distance_prob=1.0, first_path_rel=0.0):
+    """sym: complex64[2552] from the candidate PRS start -> (coarse_carriers, time_offset, peak_to_mean, coarse_ptm).
+    expected / distance_prob / first_path_rel: the tap choice of oracle_sync_prs_ex (defaults = strongest tap)."""
     a = np.ascontiguousarray(sym, np.complex64)
     assert a.size >= NB_SYM
     k, t = C.c_int32(0), C.c_int32(0)
     p, cp = C.c_float(0), C.c_float(0)
-    lib().oracle_sync_prs(_p(a), C.c_float(freq_offset), C.c_int(max_coarse), C.byref(k), C.byref(t), C.byref(p), C.byref(cp))
+    lib().oracle_sync_prs_ex(_p(a), C.c_float(freq_offset), C.c_int(max_coarse), C.c_int(expected), C.c_float(distance_prob),
+                             C.c_float(first_path_rel), C.byref(k), C.byref(t), C.byref(p), C.byref(cp))
     return k.value, t.value, p.value, cp.value
 
 
@@ -302,12 +305,138 @@ def null_search(iq, thr_start=0.35, thr_end=0.75, min_blocks=30, max_out=64):
     return out[:n]
 
 
-def acquire_candidate(iq, cand, max_coarse=200, min_peak_to_mean=30.0, margin=0):
+def acquire_candidate(iq, cand, max_coarse=200, min_peak_to_mean=30.0, margin=0, distance_prob=0.15, first_path_rel=0.25):
+    """(defaults of the tap choice = dabgpu_acquire_default_cfg's)"""
     a = np.ascontiguousarray(iq, np.complex64).ravel()
     r = AcquiredFrame()
-    lib().oracle_acquire_candidate(_p(a), C.c_int64(a.size), C.c_int64(int(cand)), C.c_int(max_coarse),
-                                   C.c_float(min_peak_to_mean), C.c_int(margin), C.byref(r))
+    lib().oracle_acquire_candidate_ex(_p(a), C.c_int64(a.size), C.c_int64(int(cand)), C.c_int(max_coarse),
+                                      C.c_float(min_peak_to_mean), C.c_int(margin), C.c_float(distance_prob),
+                                      C.c_float(first_path_rel), C.byref(r))
     return r
+
+
+# ---- timing tracking (TEST INFRASTRUCTURE; parity unpinned) ------------------------------------------------------
+# Restates what the reference's OFDM_Demod does in RUNNING_FINE_TIME_SYNC on every frame once locked
+# (/root/reference/src/render_radio_block.cpp:196; knobs :224-225) in the batch form of dabgpu_ofdm_demod_tracked_dev:
+# positions predicted from a per-stream state, each frame synchronised on its own PRS, the state moved on by a line
+# through the measured starts.  The DSP lives in the absent DAB-Radio sub-module; this is the form the oracle fixes.
+FRAME_LEN = 76 * 2552
+L_FRAME = 196608
+
+
+def track_predict(state, n_samples, max_frames):
+    """-> (j0, [candidate start of slot i for the slots inside the capture]) from state['next_frame_start'], ['drift']"""
+    nxt = float(state["next_frame_start"])
+    period = float(L_FRAME) + float(np.float32(state["drift"]))
+    j0 = int(np.ceil(-nxt / period)) if nxt < 0.0 else 0
+    cands = []
+    for i in range(max_frames):
+        c = int(np.rint(nxt + float(j0 + i) * period))
+        if c < 0 or c + FRAME_LEN + 512 > n_samples:
+            break
+        cands.append(c)
+    return j0, cands
+
+
+def track_sync(iq, state, max_frames, margin=64, min_peak_to_mean=100.0, distance_prob=0.15, first_path_rel=0.25):
+    """Frames of one stream's capture `iq` (complex64 [n_samples]) as dabgpu_ofdm_demod_tracked_dev finds them:
+    -> list of dicts (start, freq_offset, peak_to_mean, flags, time_offset), one per slot inside the capture."""
+    a = np.ascontiguousarray(iq, np.complex64).ravel()
+    out = []
+    if not state["tracking"]:
+        return out
+    _, cands = track_predict(state, a.size, max_frames)
+    fo = np.float32(state["fine_freq_offset"]) + np.float32(state["coarse_freq_offset"])
+    for c in cands:
+        _, toff, ptm, _ = sync_prs(a[c:c + NB_SYM], float(fo), 0, expected=margin, distance_prob=distance_prob,
+                                   first_path_rel=first_path_rel)
+        start = c + toff - margin
+        flags = (1 if ptm >= min_peak_to_mean else 0) | (2 if (start >= 0 and start + FRAME_LEN <= a.size) else 0)
+        out.append({"start": start, "freq_offset": fo, "peak_to_mean": ptm, "flags": flags, "time_offset": toff, "cand": c})
+    return out
+
+
+def track_update(state, frames, cyc, iq, n_samples, max_frames, advance, fine_beta=0.9, drift_beta=0.5, signal_beta=0.95,
+                 thr_null_start=0.35):
+    """State after a tracked call: `frames` from track_sync, `cyc` complex [len(frames)][76] of the demodulated frames
+    (rows of unlocked frames are ignored), `iq` the capture.  Returns (new state dict, count)."""
+    st = dict(state)
+    if not state["tracking"]:
+        return st, 0
+    nxt = float(state["next_frame_start"])
+    period = float(L_FRAME) + float(np.float32(state["drift"]))
+    j0, cands = track_predict(state, n_samples, max_frames)
+    count = len(cands)
+    locked = [i for i in range(count) if (frames[i]["flags"] & 3) == 3]
+    n = len(locked)
+    desync = j0 + (count - n)
+    if n > 0:
+        ang = np.angle(np.asarray(cyc)[locked].astype(np.complex128)).sum()
+        err = np.float32(np.float32(ang / (n * 76.0)) * np.float32(1.0 / (6.283185307179586 * 2048.0)))
+        half = np.float32(0.5 / 2048.0)
+        f = np.float32(state["fine_freq_offset"]) - np.float32(fine_beta) * err
+        if f > half:
+            f -= 2 * half
+        if f < -half:
+            f += 2 * half
+        st["fine_freq_offset"] = np.float32(f)
+        st["last_fine_error"] = err
+        last = locked[-1]
+        st["last_time_offset"] = int(frames[last]["start"] - int(np.rint(nxt + float(j0 + last) * period)))
+        st["last_peak_to_mean"] = np.float32(frames[last]["peak_to_mean"])
+        x = np.asarray(iq[frames[last]["start"]:frames[last]["start"] + 4096])
+        l1 = np.float32((np.abs(x.real).astype(np.float64) + np.abs(x.imag).astype(np.float64)).sum() / 4096.0)
+        if state["signal_average"] > 0 and l1 < np.float32(thr_null_start) * np.float32(state["signal_average"]):
+            desync += 1
+        else:
+            sb = np.float32(signal_beta)
+            st["signal_average"] = (sb * np.float32(state["signal_average"]) + (np.float32(1) - sb) * l1) if state["signal_average"] > 0 else l1
+    alpha = slope = slope_hat = gain = 0.0
+    if n >= 2:
+        i = np.array(locked, np.float64)
+        r = np.array([float(frames[k]["start"]) - (nxt + float(j0 + k) * period) for k in locked], np.float64)
+        sn, si, sii, sr, sir = float(n), i.sum(), (i * i).sum(), r.sum(), (i * r).sum()
+        slope = (sn * sir - si * sr) / (sn * sii - si * si)
+        alpha = (sr - slope * si) / sn
+        slope_hat = slope
+        gain = float(np.float32(drift_beta)) * min(1.0, n * 0.25)
+    elif n == 1:
+        k = locked[0]
+        alpha = float(frames[k]["start"]) - (nxt + float(j0 + k) * period)
+        slope_hat = alpha if count == 1 else 0.0
+        gain = float(np.float32(drift_beta)) * 0.125
+    if count > 0 and n == 0:
+        st["tracking"] = 0
+    st["next_frame_start"] = nxt + float(j0 + count) * period + alpha + slope * count - float(advance)
+    st["drift"] = np.float32(float(np.float32(state["drift"])) + gain * slope_hat)
+    st["total_frames_read"] = state["total_frames_read"] + n
+    st["total_frames_desync"] = state["total_frames_desync"] + desync
+    return st, count
+
+
+def track_start(state, frames, advance):
+    """State after dabgpu_track_start_dev: `frames` = the acquisition result of one stream (list of AcquiredFrame)."""
+    st = dict(state)
+    locked = [f for f in frames if (f.flags & 3) == 3]
+    if not locked:
+        st["tracking"] = 0
+        return st
+    s0 = locked[0].start
+    y = np.array([float(f.start - s0) for f in locked], np.float64)
+    j = np.rint(y / float(L_FRAME))
+    n = float(len(locked))
+    drift = 0.0
+    if n >= 4:
+        drift = (n * (j * y).sum() - j.sum() * y.sum()) / (n * (j * j).sum() - j.sum() ** 2) - float(L_FRAME)
+    st["drift"] = np.float32(drift)
+    st["next_frame_start"] = float(locked[-1].start) + float(L_FRAME) + float(np.float32(drift)) - float(advance)
+    st["fine_freq_offset"] = np.float32(sum(float(f.fine_offset) for f in locked) / n)
+    st["coarse_freq_offset"] = np.float32(-float(locked[-1].coarse_carriers) / 2048.0)
+    st["tracking"] = 1
+    st["total_frames_read"] = state["total_frames_read"] + int(n)
+    st["last_time_offset"] = 0
+    st["last_peak_to_mean"] = np.float32(locked[-1].peak_to_mean)
+    return st
 
 
 def firecode(data):

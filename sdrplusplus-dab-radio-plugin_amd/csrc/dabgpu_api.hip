@@ -81,6 +81,7 @@ struct dabgpu_ctx {
     hipEvent_t ev_states = nullptr;      // recorded behind the last launch that reads or writes d_states, on ITS stream
     bool ev_states_pending = false;
     float thr_null_start = 0.35f;        // desync threshold of the stream call (null_l1_search.thresh_null_start)
+    float signal_beta = 0.95f;           // signal_l1.update_beta of the stream call
     // dabgpu_decode_stream_frames: de-interleaver rings of the stream's sub-channels, kept on the device between calls
     struct SubHistory {
         int start_address, length;
@@ -516,6 +517,7 @@ void dabgpu_destroy(dabgpu_ctx *ctx) {
             if (t.start[i]) (void)hipEventDestroy(t.start[i]);
             if (t.stop[i]) (void)hipEventDestroy(t.stop[i]);
         }
+    if (ctx->ev_states) (void)hipEventDestroy(ctx->ev_states);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     }
     delete ctx;
@@ -817,11 +819,31 @@ int dabgpu_ofdm_demod_frames(dabgpu_ctx *ctx, const float *iq, size_t frame_stri
 }
 
 // ---------------------------------------------------------------------------- closed-loop stream call
-static_assert(sizeof(dabgpu_stream_state) == 32 && sizeof(dabk::StreamState) == 32, "stream state layout");
+static_assert(sizeof(dabgpu_stream_state) == 64 && sizeof(dabk::StreamState) == 64, "stream state layout");
+static_assert(offsetof(dabgpu_stream_state, next_frame_start) == offsetof(dabk::StreamState, next_frame_start) &&
+              offsetof(dabgpu_stream_state, drift) == offsetof(dabk::StreamState, drift), "stream state layout");
+
+// The stream states are read and written by launches on whatever stream the caller passed: remember the most recent
+// one, so that the host-side accessors can wait for exactly that work.
+static int note_state_use(dabgpu_ctx *ctx, hipStream_t s) {
+    if (!ctx->ev_states && hipEventCreateWithFlags(&ctx->ev_states, hipEventDisableTiming) != hipSuccess) return DABGPU_ERR_HIP;
+    HIP_TRY(hipEventRecord(ctx->ev_states, s));
+    ctx->ev_states_pending = true;
+    return DABGPU_OK;
+}
+static int wait_state_use(dabgpu_ctx *ctx) {
+    if (ctx->ev_states_pending) {
+        HIP_TRY(hipEventSynchronize(ctx->ev_states));
+        ctx->ev_states_pending = false;
+    }
+    return DABGPU_OK;
+}
 
 int dabgpu_streams_reset(dabgpu_ctx *ctx, int n_streams) {
     if (!ctx || n_streams < 0) return DABGPU_ERR_ARG;
     DeviceGuard guard(ctx);
+    int wrc = wait_state_use(ctx);
+    if (wrc) return wrc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (n_streams > ctx->n_states) {
         if (ctx->d_states) (void)hipFree(ctx->d_states);
@@ -842,6 +864,8 @@ dabgpu_stream_state *dabgpu_stream_states(dabgpu_ctx *ctx) {
 int dabgpu_set_stream_offsets(dabgpu_ctx *ctx, int stream_index, const float *fine, const float *coarse) {
     if (!ctx || stream_index < 0 || stream_index >= ctx->n_states) return DABGPU_ERR_ARG;
     DeviceGuard guard(ctx);
+    int wrc = wait_state_use(ctx);
+    if (wrc) return wrc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     dabk::StreamState *st = ctx->d_states + stream_index;
     if (fine) HIP_TRY(hipMemcpy(&st->fine_freq_offset, fine, sizeof(float), hipMemcpyHostToDevice));
@@ -849,13 +873,9 @@ int dabgpu_set_stream_offsets(dabgpu_ctx *ctx, int stream_index, const float *fi
     return DABGPU_OK;
 }
 
-int dabgpu_get_stats(dabgpu_ctx *ctx, int stream_index, dabgpu_stats *out) {
-    if (!ctx || !out || stream_index < 0 || stream_index >= ctx->n_states) return DABGPU_ERR_ARG;
-    DeviceGuard guard(ctx);
-    dabk::StreamState st;
-    HIP_TRY(hipMemcpyAsync(&st, ctx->d_states + stream_index, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    out->state = (st.total_frames_read > 0) ? 4 : 0;           // READING_SYMBOLS / FINDING_NULL_POWER_DIP
+static void stats_of(const dabk::StreamState &st, dabgpu_stats *out) {
+    // READING_SYMBOLS / FINDING_NULL_POWER_DIP (a tracked stream that lost every frame of a call is searching again)
+    out->state = (st.total_frames_read > 0 && !(st.tracking == 0 && st.next_frame_start != 0.0)) ? 4 : 0;
     out->fine_freq_offset = st.fine_freq_offset;
     out->coarse_freq_offset = st.coarse_freq_offset;
     out->net_freq_offset = st.fine_freq_offset + st.coarse_freq_offset;
@@ -863,6 +883,30 @@ int dabgpu_get_stats(dabgpu_ctx *ctx, int stream_index, dabgpu_stats *out) {
     out->total_frames_read = st.total_frames_read;
     out->total_frames_desync = st.total_frames_desync;
     out->last_fine_error = st.last_fine_error;
+    out->tracking = st.tracking;
+    out->last_time_offset = st.last_time_offset;
+    out->next_frame_start = st.next_frame_start;
+    out->drift = st.drift;
+    out->last_peak_to_mean = st.last_peak_to_mean;
+}
+
+int dabgpu_get_stats(dabgpu_ctx *ctx, int stream_index, dabgpu_stats *out) {
+    if (!ctx || !out || stream_index < 0 || stream_index >= ctx->n_states) return DABGPU_ERR_ARG;
+    DeviceGuard guard(ctx);
+    int wrc = wait_state_use(ctx);
+    if (wrc) return wrc;
+    dabk::StreamState st;
+    HIP_TRY(hipMemcpyAsync(&st, ctx->d_states + stream_index, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    stats_of(st, out);
+    return DABGPU_OK;
+}
+
+int dabgpu_set_stream_loop(dabgpu_ctx *ctx, float signal_update_beta, float thr_null_start) {
+    if (!ctx || !(signal_update_beta >= 0.f && signal_update_beta <= 1.f) || !(thr_null_start >= 0.f && thr_null_start <= 1.f))
+        return DABGPU_ERR_ARG;
+    ctx->signal_beta = signal_update_beta;
+    ctx->thr_null_start = thr_null_start;
     return DABGPU_OK;
 }
 
@@ -881,7 +925,7 @@ int dabgpu_ofdm_demod_streams_dev(dabgpu_ctx *ctx, const void *d_iq, size_t fram
     if (n_frames == 0) return DABGPU_OK;
     hipStream_t s = pick_stream(ctx, stream);
     if (!d_cyc) {                                               // the loop needs the correlations: keep them here
-        if ((rc = stage(ctx, 3, size_t(n_frames) * NB_FRAME_SYMBOLS * sizeof(float2), &d_cyc))) return rc;
+        if ((rc = stage(ctx, 6, size_t(n_frames) * NB_FRAME_SYMBOLS * sizeof(float2), &d_cyc))) return rc;
     }
     dabk::OfdmTables tab{ctx->d_twiddle, ctx->d_bin_of_n, ctx->d_n_of_vj};
     dabk::OfdmArgs a{};
@@ -899,8 +943,8 @@ int dabgpu_ofdm_demod_streams_dev(dabgpu_ctx *ctx, const void *d_iq, size_t fram
         HIP_TRY(dabk::launch_ofdm_demod(tab, a, pick_parts(ctx, n_frames, NB_DATA_SYMBOLS), s));
     }
     HIP_TRY(dabk::launch_stream_update(ctx->d_states, a.cyc, a.iq, frame_stride, n_streams, frames_per_stream,
-                                       fine_freq_update_beta, ctx->thr_null_start, s));
-    return DABGPU_OK;
+                                       fine_freq_update_beta, ctx->thr_null_start, ctx->signal_beta, s));
+    return note_state_use(ctx, s);
 }
 
 int dabgpu_ofdm_demod_streams(dabgpu_ctx *ctx, const float *iq, size_t frame_stride, int n_streams,
@@ -1009,6 +1053,12 @@ void dabgpu_acquire_default_cfg(dabgpu_acquire_cfg *cfg) {
     cfg->max_coarse_carriers = 200;
     cfg->min_peak_to_mean = 30.0f;
     cfg->timing_margin = 64;
+    cfg->impulse_peak_distance_probability = 0.15f;
+    cfg->first_path_rel = 0.25f;
+}
+
+static bool peak_rule_ok(float distance_prob, float first_path_rel) {
+    return distance_prob >= 0.f && distance_prob <= 1.f && first_path_rel >= 0.f && first_path_rel <= 1.f;
 }
 
 int dabgpu_acquire_dev(dabgpu_ctx *ctx, const void *d_iq, size_t stream_stride, int n_streams, int64_t n_samples,
@@ -1022,7 +1072,8 @@ int dabgpu_acquire_dev(dabgpu_ctx *ctx, const void *d_iq, size_t stream_stride, 
     dabgpu_acquire_cfg c;
     if (cfg) c = *cfg; else dabgpu_acquire_default_cfg(&c);
     if (c.max_coarse_carriers < 0 || c.max_coarse_carriers > 1023 || c.min_null_blocks < 1 || c.timing_margin < 0 ||
-        c.timing_margin > NB_CP || !(c.thr_null_start > 0.f) || !(c.thr_null_end >= c.thr_null_start))
+        c.timing_margin > NB_CP || !(c.thr_null_start > 0.f) || !(c.thr_null_end >= c.thr_null_start) ||
+        !peak_rule_ok(c.impulse_peak_distance_probability, c.first_path_rel))
         return DABGPU_ERR_ARG;
     if (n_streams == 0) return DABGPU_OK;
     hipStream_t s = pick_stream(ctx, stream);
@@ -1051,6 +1102,9 @@ int dabgpu_acquire_dev(dabgpu_ctx *ctx, const void *d_iq, size_t stream_stride, 
     a.max_coarse = c.max_coarse_carriers;
     a.min_peak_to_mean = c.min_peak_to_mean;
     a.margin = c.timing_margin;
+    a.rule.distance_prob = c.impulse_peak_distance_probability;
+    a.rule.expected = 0;
+    a.rule.first_path_rel = c.first_path_rel;
     a.max_out = max_frames;
     a.l1 = static_cast<float *>(ctx->d_acq_scratch);
     const size_t l1_bytes = (size_t(n_streams) * size_t(n_samples / 64) * sizeof(float) + 255) & ~size_t(255);
@@ -1113,6 +1167,178 @@ int dabgpu_ofdm_demod_acquired_dev(dabgpu_ctx *ctx, const void *d_iq, size_t str
     a.keep = ctx->d_keep;
     ScopedTimer tm(ctx, 0, s);
     HIP_TRY(dabk::launch_ofdm_demod(tab, a, pick_parts(ctx, a.n_frames, NB_DATA_SYMBOLS), s));
+    return DABGPU_OK;
+}
+
+// ---------------------------------------------------------------------------- timing tracking
+void dabgpu_track_default_cfg(dabgpu_track_cfg *cfg) {
+    if (!cfg) return;
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->fine_freq_update_beta = 0.9f;
+    cfg->signal_update_beta = 0.95f;
+    cfg->thr_null_start = 0.35f;
+    cfg->min_peak_to_mean = 100.0f;
+    cfg->impulse_peak_distance_probability = 0.15f;
+    cfg->first_path_rel = 0.25f;
+    cfg->drift_beta = 0.5f;
+    cfg->coarse_freq_slow_beta = 0.1f;
+    cfg->timing_margin = 64;
+    cfg->max_coarse_carriers = 204;
+}
+
+static int track_cfg(const dabgpu_track_cfg *cfg, dabgpu_track_cfg &c) {
+    if (cfg) c = *cfg; else dabgpu_track_default_cfg(&c);
+    auto unit = [](float v) { return v >= 0.f && v <= 1.f; };
+    if (!unit(c.fine_freq_update_beta) || !unit(c.signal_update_beta) || !unit(c.thr_null_start) || !unit(c.drift_beta) ||
+        !unit(c.coarse_freq_slow_beta) || !peak_rule_ok(c.impulse_peak_distance_probability, c.first_path_rel) ||
+        !(c.min_peak_to_mean >= 0.f) || c.timing_margin < 0 || c.timing_margin > NB_CP || c.max_coarse_carriers < 0 ||
+        c.max_coarse_carriers > 1023)
+        return DABGPU_ERR_ARG;
+    return DABGPU_OK;
+}
+
+int dabgpu_track_start_dev(dabgpu_ctx *ctx, const dabgpu_acquired_frame *d_frames, const int32_t *d_counts, int n_streams,
+                           int max_frames, int64_t advance, void *stream) {
+    if (!ctx || !d_frames || !d_counts || n_streams < 0 || max_frames <= 0 || advance < 0) return DABGPU_ERR_ARG;
+    DeviceGuard guard(ctx);
+    if (n_streams > ctx->n_states) return DABGPU_ERR_CAPACITY;   // dabgpu_streams_reset first
+    if (n_streams == 0) return DABGPU_OK;
+    hipStream_t s = pick_stream(ctx, stream);
+    HIP_TRY(dabk::launch_track_start(ctx->d_states, reinterpret_cast<const dabk::AcquiredFrame *>(d_frames), d_counts, n_streams,
+                                     max_frames, advance, s));
+    return note_state_use(ctx, s);
+}
+
+// the three launches of a tracked call on `s`: PRS synchronisation at the predicted positions, demodulation of the frames
+// where they lie, state update
+static int tracked_launches(dabgpu_ctx *ctx, dabk::StreamState *states, const void *d_iq, size_t stream_stride, int n_streams,
+                            int64_t n_samples, int max_frames, int64_t advance, const dabgpu_track_cfg &c, int fixed_start,
+                            int acquiring, int8_t *d_soft, void *d_cyc, void *d_dqpsk, dabgpu_acquired_frame *d_frames,
+                            dabgpu_sync_result *d_sync, int32_t *d_counts, hipStream_t s) {
+    dabk::SyncTables stab{ctx->d_twiddle, ctx->d_prs_qt, ctx->d_sync_pairs, ctx->n_sync_pairs, ctx->d_sync_fs};
+    dabk::TrackArgs t{};
+    t.state = states;
+    t.iq = static_cast<const float2 *>(d_iq);
+    t.stream_stride = stream_stride;
+    t.n_streams = n_streams;
+    t.n_samples = n_samples;
+    t.max_out = max_frames;
+    t.margin = c.timing_margin;
+    t.min_peak_to_mean = c.min_peak_to_mean;
+    t.rule.distance_prob = c.impulse_peak_distance_probability;
+    t.rule.first_path_rel = c.first_path_rel;
+    t.fixed_start = fixed_start;
+    t.max_coarse = fixed_start ? c.max_coarse_carriers : 0;
+    t.acquiring = acquiring;
+    t.coarse_slow_beta = c.coarse_freq_slow_beta;
+    t.out = reinterpret_cast<dabk::AcquiredFrame *>(d_frames);
+    t.sync_out = reinterpret_cast<dabk::SyncResult *>(d_sync);
+    HIP_TRY(dabk::launch_track_sync(stab, t, s));
+    dabk::OfdmTables tab{ctx->d_twiddle, ctx->d_bin_of_n, ctx->d_n_of_vj};
+    dabk::OfdmArgs a{};
+    a.iq = static_cast<const float2 *>(d_iq);
+    a.frame_stride = stream_stride;
+    a.n_frames = n_streams * max_frames;
+    a.soft = d_soft;
+    a.cyc = static_cast<float2 *>(d_cyc);
+    a.dqpsk = static_cast<float2 *>(d_dqpsk);
+    a.acq = reinterpret_cast<const dabk::AcquiredFrame *>(d_frames);
+    a.acq_per_stream = max_frames;
+    a.keep = ctx->d_keep;
+    {
+        ScopedTimer tm(ctx, 0, s);
+        HIP_TRY(dabk::launch_ofdm_demod(tab, a, pick_parts(ctx, a.n_frames, NB_DATA_SYMBOLS), s));
+    }
+    dabk::TrackUpdateArgs u{};
+    u.state = states;
+    u.frames = t.out;
+    u.cyc = a.cyc;
+    u.iq = t.iq;
+    u.stream_stride = stream_stride;
+    u.n_streams = n_streams;
+    u.n_samples = n_samples;
+    u.max_out = max_frames;
+    u.advance = advance;
+    u.fine_beta = c.fine_freq_update_beta;
+    u.drift_beta = c.drift_beta;
+    u.signal_beta = c.signal_update_beta;
+    u.thr_null_start = c.thr_null_start;
+    u.fixed_start = fixed_start;
+    u.counts = d_counts;
+    HIP_TRY(dabk::launch_track_update(u, s));
+    return note_state_use(ctx, s);
+}
+
+int dabgpu_ofdm_demod_tracked_dev(dabgpu_ctx *ctx, const void *d_iq, size_t stream_stride, int n_streams,
+                                  int64_t n_samples, int max_frames, int64_t advance, const dabgpu_track_cfg *cfg,
+                                  int8_t *d_soft, void *d_cyc, void *d_dqpsk, dabgpu_acquired_frame *d_frames,
+                                  int32_t *d_counts, void *stream) {
+    if (!ctx || !d_iq || !d_soft || !d_frames || !d_counts || n_streams < 0 || max_frames <= 0 || n_samples < 0 || advance < 0)
+        return DABGPU_ERR_ARG;
+    DeviceGuard guard(ctx);
+    if ((reinterpret_cast<uintptr_t>(d_iq) & 7u) || (reinterpret_cast<uintptr_t>(d_soft) & 15u)) return DABGPU_ERR_ARG;
+    if (n_streams > 1 && stream_stride < size_t(n_samples)) return DABGPU_ERR_ARG;
+    if (n_streams > ctx->n_states) return DABGPU_ERR_CAPACITY;   // dabgpu_streams_reset first
+    if (size_t(n_streams) * size_t(max_frames) > size_t(0x7fffffff) / NB_DATA_SYMBOLS) return DABGPU_ERR_ARG;
+    dabgpu_track_cfg c;
+    int rc = track_cfg(cfg, c);
+    if (rc) return rc;
+    if (n_streams == 0) return DABGPU_OK;
+    hipStream_t s = pick_stream(ctx, stream);
+    if (!d_cyc && (rc = stage(ctx, 6, size_t(n_streams) * max_frames * NB_FRAME_SYMBOLS * sizeof(float2), &d_cyc))) return rc;
+    return tracked_launches(ctx, ctx->d_states, d_iq, stream_stride, n_streams, n_samples, max_frames, advance, c, 0, 0, d_soft,
+                            d_cyc, d_dqpsk, d_frames, nullptr, d_counts, s);
+}
+
+int dabgpu_ofdm_demod_stream_frame(dabgpu_ctx *ctx, int stream_index, const float *iq, int acquiring,
+                                   const dabgpu_track_cfg *cfg, int8_t *soft, float *dqpsk, dabgpu_frame_result *result) {
+    if (!ctx || !iq || !soft || !result || stream_index < 0 || stream_index >= ctx->n_states) return DABGPU_ERR_ARG;
+    DeviceGuard guard(ctx);
+    dabgpu_track_cfg c;
+    int rc = track_cfg(cfg, c);
+    if (rc) return rc;
+    constexpr size_t nb_iq = size_t(NB_FRAME_SYMBOLS) * NB_SYM_PERIOD * sizeof(float2);
+    constexpr size_t nb_dq = size_t(NB_DATA_SYMBOLS) * NB_CARRIERS * sizeof(float2);
+    auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
+    // one result block: soft bits | acquired frame | sync result | state  (| constellation, in a buffer of its own)
+    const size_t off_fr = al(NB_FRAME_BITS), off_sy = off_fr + al(sizeof(dabgpu_acquired_frame)),
+                 off_st = off_sy + al(sizeof(dabgpu_sync_result)), nb_res = off_st + al(sizeof(dabk::StreamState));
+    void *d_iq, *d_res, *d_cyc, *d_dq = nullptr;
+    if ((rc = stage(ctx, 0, nb_iq, &d_iq))) return rc;
+    if ((rc = stage(ctx, 1, nb_res, &d_res))) return rc;
+    if ((rc = stage(ctx, 6, NB_FRAME_SYMBOLS * sizeof(float2), &d_cyc))) return rc;
+    if (dqpsk && (rc = stage(ctx, 4, nb_dq, &d_dq))) return rc;
+    if (ctx->h_bounce_bytes < nb_res) {
+        if (ctx->h_bounce) (void)hipHostFree(ctx->h_bounce);
+        ctx->h_bounce = nullptr;
+        ctx->h_bounce_bytes = 0;
+        if (hipHostMalloc(&ctx->h_bounce, nb_res, hipHostMallocDefault) != hipSuccess) return DABGPU_ERR_NOMEM;
+        ctx->h_bounce_bytes = nb_res;
+    }
+    if ((rc = wait_state_use(ctx))) return rc;
+    hipStream_t s = ctx->stream;
+    char *res = static_cast<char *>(d_res);
+    HIP_TRY(hipMemcpyAsync(d_iq, iq, nb_iq, hipMemcpyHostToDevice, s));                    // one upload
+    dabk::StreamState *st = ctx->d_states + stream_index;
+    rc = tracked_launches(ctx, st, d_iq, nb_iq / sizeof(float2), 1, int64_t(nb_iq / sizeof(float2)), 1, 0, c, 1, acquiring ? 1 : 0,
+                          reinterpret_cast<int8_t *>(res), d_cyc, d_dq, reinterpret_cast<dabgpu_acquired_frame *>(res + off_fr),
+                          reinterpret_cast<dabgpu_sync_result *>(res + off_sy), nullptr, s);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(res + off_st, st, sizeof(dabk::StreamState), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(ctx->h_bounce, d_res, nb_res, hipMemcpyDeviceToHost, s));        // one download
+    if (dqpsk) HIP_TRY(hipMemcpyAsync(dqpsk, d_dq, nb_dq, hipMemcpyDeviceToHost, s));       // (+ the constellation, when asked for)
+    HIP_TRY(hipStreamSynchronize(s));                                                    // one synchronisation
+    ctx->ev_states_pending = false;
+    const char *hb = static_cast<const char *>(ctx->h_bounce);
+    std::memcpy(soft, hb, NB_FRAME_BITS);
+    dabgpu_acquired_frame fr;
+    std::memcpy(&fr, hb + off_fr, sizeof(fr));
+    std::memcpy(&result->sync, hb + off_sy, sizeof(result->sync));
+    dabk::StreamState hs;
+    std::memcpy(&hs, hb + off_st, sizeof(hs));
+    result->flags = fr.flags;
+    result->reserved = 0;
+    stats_of(hs, &result->stats);
     return DABGPU_OK;
 }
 

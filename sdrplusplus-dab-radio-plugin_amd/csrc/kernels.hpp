@@ -15,9 +15,10 @@ struct OfdmTables {
     const uint16_t *n_of_vj;   // [12][64][2] data index of carrier registers 2jj, 2jj+1 of lane v (wave kernel)
 };
 
-// Per-stream tracking state kept in device memory between launches (== dabgpu_stream_state, 32 bytes): the
+// Per-stream tracking state kept in device memory between launches (== dabgpu_stream_state, 64 bytes): the
 // frequency offsets OFDM_Demod shows through GetFineFrequencyOffset / GetCoarseFrequencyOffset
-// (/root/reference/src/render_radio_block.cpp:202-207) and its frame counters.
+// (/root/reference/src/render_radio_block.cpp:202-207), its frame counters, and -- what RUNNING_FINE_TIME_SYNC
+// maintains frame by frame (:196) -- where the stream's next frame starts.
 struct StreamState {
     float fine_freq_offset;    // cycles/sample, within +-0.5 carrier
     float coarse_freq_offset;  // cycles/sample, whole carriers
@@ -25,7 +26,12 @@ struct StreamState {
     float last_fine_error;     // residual the most recent update measured, cycles/sample
     int32_t total_frames_read;
     int32_t total_frames_desync;
-    int32_t reserved[2];
+    int32_t tracking;          // 1: next_frame_start is valid (set by track_start, cleared when every frame of a call is lost)
+    int32_t last_time_offset;  // impulse-response peak position of the most recent frame relative to its predicted one, samples
+    double next_frame_start;   // first sample (PRS prefix minus margin) of the next frame, relative to the NEXT capture
+    float drift;               // samples per frame by which the frame period differs from 196608
+    float last_peak_to_mean;
+    int32_t reserved[4];
 };
 
 struct OfdmArgs {
@@ -65,7 +71,8 @@ hipError_t launch_fill_noise(void *p, size_t bytes, hipStream_t s);
 // share an HBM domain -- what the placement helpers time
 hipError_t launch_placement_probe(const void *in, size_t in_bytes, void *out, size_t out_bytes, hipStream_t s);
 hipError_t launch_stream_update(StreamState *state, const float2 *cyc, const float2 *iq, size_t frame_stride,
-                                int n_streams, int frames_per_stream, float beta, float thr_null_start, hipStream_t s);
+                                int n_streams, int frames_per_stream, float beta, float thr_null_start, float signal_beta,
+                                hipStream_t s);
 
 // ---- synchronisation on the PRS (sync_kernels.hip) -----------------------------
 struct SyncTables {
@@ -83,6 +90,19 @@ struct SyncResult {            // == dabgpu_sync_result
 };
 hipError_t launch_prs_sync(const SyncTables &t, const float2 *iq, size_t frame_stride, int n_frames,
                            const float *freq_offset, int max_coarse, SyncResult *out, hipStream_t s);
+
+// Which tap of the channel impulse response a frame is aligned to (impulse_peak_distance_probability,
+// /root/reference/src/render_radio_block.cpp:225):
+//   score[n] = |h[n]|^2 * w(n)^2,  w(n) = 1 - (1 - distance_prob) * |t(n) - expected| / 2552,  t(n) the signed offset
+//   peak = first maximum of the score;  peak_to_mean uses the unweighted |h[peak]|^2
+//   first_path_rel > 0: the earliest tap within a cyclic prefix (504 samples) before the peak whose power is at least
+//   max(first_path_rel * |h[peak]|^2, 16 * mean) replaces it -- the window is aligned to the first significant
+//   path, so that a stronger late echo still falls inside the prefix.  0 = the reference's rule (weighted maximum).
+struct PeakRule {
+    float distance_prob = 1.0f;
+    int expected = 0;
+    float first_path_rel = 0.0f;
+};
 
 // ---- acquisition on unaligned captures (sync_kernels.hip) ----------------------
 struct AcquiredFrame {         // == dabgpu_acquired_frame (32 bytes)
@@ -104,6 +124,7 @@ struct AcquireArgs {
     int max_coarse;            // carriers
     float min_peak_to_mean;
     int margin;                // samples the FFT windows are kept inside the cyclic prefix
+    PeakRule rule;
     int max_out;               // frames per stream
     float *l1;                 // scratch [n_streams][n_samples/64]
     int64_t *cands;            // scratch [n_streams][max_out]
@@ -112,6 +133,71 @@ struct AcquireArgs {
 };
 size_t acquire_scratch_bytes(int n_streams, int64_t n_samples, int max_out);
 hipError_t launch_acquire(const SyncTables &t, const AcquireArgs &a, hipStream_t s);
+
+// ---- per-stream timing tracking (sync_kernels.hip) -------------------------------
+// Batch mode (fixed_start = 0): frame slot i of stream s is predicted from the stream's state at
+//   p_i = next_frame_start + (j0 + i) * (196608 + drift),  j0 = frames that would start before the capture (missed),
+// synchronised on its PRS at llrint(p_i) (impulse response with the state's net frequency offset applied, PeakRule)
+// and written as an AcquiredFrame for the demodulator; slots whose frame (+512 samples) does not fit the capture, and
+// every slot of a stream that is not tracking, get flags 0 / start -1.
+// Frame mode (fixed_start = 1; the host mirror's one frame per call): the frame is the stream's first 76*2552 samples
+// as the host assembled it (max_out = 1, start stays 0); max_coarse > 0 also runs the whole-carrier search:
+// acquiring != 0 SETS the state's coarse offset from it (the search then runs with the fine offset alone), otherwise a
+// residual of k carriers moves it by coarse_slow_beta * k; bit 1 of flags = the window lies inside the prefix
+// (0 <= time offset <= 488).
+struct TrackArgs {
+    StreamState *state;
+    const float2 *iq;          // stream s at iq + s*stream_stride
+    size_t stream_stride;
+    int n_streams;
+    int64_t n_samples;
+    int max_out;
+    int margin;
+    float min_peak_to_mean;
+    PeakRule rule;             // expected is set to `margin` by the launcher
+    int fixed_start;
+    int max_coarse;
+    int acquiring;
+    float coarse_slow_beta;
+    AcquiredFrame *out;        // [n_streams][max_out]
+    SyncResult *sync_out;      // [n_streams][max_out] or nullptr
+};
+hipError_t launch_track_sync(const SyncTables &t, const TrackArgs &a, hipStream_t s);
+
+// After the demodulation of those frames, one workgroup per stream:
+//   fine loop   fine -= beta * mean(arg cyc) / (2 pi 2048) over the locked frames, wrapped to +-half a carrier
+//   timing      residuals r_i = start_i - p_i of the n locked frames; with n >= 2 a least-squares line
+//               r = alpha + slope*i, drift += drift_beta * min(1, n/4) * slope; with n = 1: alpha = r, slope = 0 and
+//               (one slot per call only) drift += drift_beta/8 * r;
+//               next_frame_start = p(count) + alpha + slope*count - advance
+//               (count = frame slots inside the capture, p(count) with the OLD drift)
+//   counters    total_frames_read += locked, total_frames_desync += missed + unlocked; no locked frame at all in a
+//               call that had frames: tracking = 0
+//   level       L1 mean of the first 4096 samples of the last locked frame into the running average
+//               (signal_beta * average + (1 - signal_beta) * level); a level below thr_null_start * average counts one
+//               more desync and leaves the average alone
+//   counts[s]   = count
+struct TrackUpdateArgs {
+    StreamState *state;
+    const AcquiredFrame *frames;
+    const float2 *cyc;         // [n_streams*max_out][76]
+    const float2 *iq;
+    size_t stream_stride;
+    int n_streams;
+    int64_t n_samples;
+    int max_out;
+    int64_t advance;           // samples between the first sample of this capture and of the next one
+    float fine_beta, drift_beta, signal_beta, thr_null_start;
+    int fixed_start;
+    int32_t *counts;           // [n_streams] or nullptr
+};
+hipError_t launch_track_update(const TrackUpdateArgs &a, hipStream_t s);
+// Start tracking from an acquisition result (dabgpu_acquire_dev on the same capture): per stream, a least-squares line
+// through the starts of the locked frames against their frame number round((start - first)/196608) gives the drift
+// (0 with fewer than 4 locked frames); next_frame_start = start_last + 196608 + drift - advance; fine offset = mean of
+// the locked frames', coarse = the last locked frame's; tracking = 1 (0 when no frame locked).
+hipError_t launch_track_start(StreamState *state, const AcquiredFrame *frames, const int32_t *counts, int n_streams,
+                              int max_out, int64_t advance, hipStream_t s);
 
 // ---- DAB+ audio super-frame (dabplus_kernels.hip) ------------------------------
 struct SuperframeStatus {      // == dabgpu_superframe_status

@@ -469,7 +469,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
 constexpr int SU_THREADS = 1024;
 __global__ __launch_bounds__(SU_THREADS) void stream_update_kernel(StreamState *state, const float2 *cyc, const float2 *iq,
                                                                    size_t frame_stride, int frames_per_stream, float beta,
-                                                                   float thr_null_start) {
+                                                                   float thr_null_start, float signal_beta) {
     __shared__ float red[2][SU_THREADS / 64];
     const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float2 *c = cyc + size_t(s) * frames_per_stream * NB_FRAME_SYMBOLS;
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(SU_THREADS) void stream_update_kernel(StreamState *
             st.total_frames_read += frames_per_stream - 1;
         } else {
             st.total_frames_read += frames_per_stream;
-            st.signal_average = st.signal_average > 0.f ? 0.95f * st.signal_average + 0.05f * l1 : l1;
+            st.signal_average = st.signal_average > 0.f ? signal_beta * st.signal_average + (1.0f - signal_beta) * l1 : l1;
         }
         state[s] = st;
     }
@@ -564,10 +564,11 @@ hipError_t launch_fill_noise(void *p, size_t bytes, hipStream_t s) {
 }
 
 hipError_t launch_stream_update(StreamState *state, const float2 *cyc, const float2 *iq, size_t frame_stride,
-                                int n_streams, int frames_per_stream, float beta, float thr_null_start, hipStream_t s) {
+                                int n_streams, int frames_per_stream, float beta, float thr_null_start, float signal_beta,
+                                hipStream_t s) {
     if (n_streams <= 0 || frames_per_stream <= 0) return hipSuccess;
     hipLaunchKernelGGL(stream_update_kernel, dim3(unsigned(n_streams)), dim3(SU_THREADS), 0, s, state, cyc, iq, frame_stride,
-                       frames_per_stream, beta, thr_null_start);
+                       frames_per_stream, beta, thr_null_start, signal_beta);
     return hipGetLastError();
 }
 

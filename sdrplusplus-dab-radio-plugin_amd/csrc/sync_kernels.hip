@@ -71,22 +71,68 @@ __device__ __forceinline__ void block_argmax_sum(SyncLds &sm, int tid, float m, 
     __syncthreads();
 }
 
-// ACQ = false: candidates at a fixed stride, correction given, SyncResult out.
-// ACQ = true : candidates from the null search; the fractional frequency error is first measured on the cyclic
-//              prefix of the PRS (products 64..439 of the prefix against the samples 2048 later: inside the prefix
-//              for any candidate within +-64 samples), then the same search; AcquiredFrame out.
-template <bool ACQ>
+// Fractional frequency error from the cyclic prefix of the PRS: products first .. first+375 of the candidate's prefix
+// against the samples 2048 later (inside the prefix for any candidate within +-64 samples of first - 64 early);
+// -angle / (2 pi 2048) cycles per sample.  Block-wide; ends with a barrier.
+__device__ __forceinline__ float cp_fine_offset(SyncLds &sm, const float2 *sym, int first, int tid) {
+    double cr = 0.0, ci = 0.0;
+    for (int i = first + tid; i < first + 376; i += WG) {
+        const float2 a = sym[i], b = sym[i + NB_FFT];
+        cr += double(__fadd_rn(__fmul_rn(a.x, b.x), __fmul_rn(a.y, b.y)));      // conj(a) * b
+        ci += double(__fsub_rn(__fmul_rn(a.x, b.y), __fmul_rn(a.y, b.x)));
+    }
+    sm.red_d[0][tid] = cr;
+    sm.red_d[1][tid] = ci;
+    __syncthreads();
+    for (int off = WG / 2; off > 0; off >>= 1) {
+        if (tid < off) {
+            sm.red_d[0][tid] += sm.red_d[0][tid + off];
+            sm.red_d[1][tid] += sm.red_d[1][tid + off];
+        }
+        __syncthreads();
+    }
+    const float fine = float(-atan2(sm.red_d[1][0], sm.red_d[0][0]) / (2.0 * 3.14159265358979323846 * double(NB_FFT)));
+    __syncthreads();
+    return fine;
+}
+
+constexpr int MODE_PLAIN = 0, MODE_ACQ = 1, MODE_TRACK = 2;
+constexpr int FRAME_LEN = NB_FRAME_SYMBOLS * NB_SYM_PERIOD;
+
+// where the stream's state says frame slot i starts: p_i = next + (j0 + i) * period, j0 = frames that begin before
+// the capture does.  The same arithmetic (double) in track_sync, track_update and the oracle.
+struct Predictor {
+    double next, period;
+    int j0;
+    __device__ Predictor(const StreamState &st) {
+        next = st.next_frame_start;
+        period = double(NB_FRAME_SAMPLES) + double(st.drift);
+        j0 = next < 0.0 ? int(ceil(-next / period)) : 0;
+    }
+    __device__ double at(int i) const { return next + double(j0 + i) * period; }
+    __device__ static bool fits(int64_t cand, int64_t n_samples) { return cand >= 0 && cand + FRAME_LEN + 512 <= n_samples; }
+};
+
+// MODE_PLAIN: candidates at a fixed stride, correction given, SyncResult out.
+// MODE_ACQ  : candidates from the null search; the fractional frequency error is first measured on the cyclic
+//             prefix of the PRS (products 64..439 of the prefix against the samples 2048 later: inside the prefix
+//             for any candidate within +-64 samples), then the same search; AcquiredFrame out.
+// MODE_TRACK: candidates predicted from the stream states (TrackArgs); correction = the state's fine + coarse offset;
+//             the whole-carrier search only when asked for (max_coarse > 0); AcquiredFrame out.
+template <int MODE>
 __global__ __launch_bounds__(WG) void prs_sync_kernel(SyncTables tab, const float2 *iq, size_t frame_stride,
                                                       const float *freq_offset, int max_coarse, SyncResult *out,
-                                                      AcquireArgs acq) {
+                                                      AcquireArgs acq, TrackArgs trk) {
     __shared__ SyncLds sm;
     const int tid = threadIdx.x;
     const int frame = blockIdx.x;
     const float2 *sym;
     uint32_t dphi;
     int64_t cand = 0;
-    float fine = 0.0f;
-    if constexpr (ACQ) {
+    float fine = 0.0f, coarse = 0.0f;
+    PeakRule rule;
+    bool do_coarse = true;
+    if constexpr (MODE == MODE_ACQ) {
         const int st = frame / acq.max_out, j = frame - st * acq.max_out;
         if (j >= acq.counts[st]) {
             if (tid == 0) acq.out[frame] = AcquiredFrame{-1, 0.f, 0, 0.f, 0.f, 0.f, 0};
@@ -94,25 +140,36 @@ __global__ __launch_bounds__(WG) void prs_sync_kernel(SyncTables tab, const floa
         }
         cand = acq.cands[frame];
         sym = acq.iq + size_t(st) * acq.stream_stride + cand;
-        double cr = 0.0, ci = 0.0;
-        for (int i = 64 + tid; i < 440; i += WG) {
-            const float2 a = sym[i], b = sym[i + NB_FFT];
-            cr += double(__fadd_rn(__fmul_rn(a.x, b.x), __fmul_rn(a.y, b.y)));      // conj(a) * b
-            ci += double(__fsub_rn(__fmul_rn(a.x, b.y), __fmul_rn(a.y, b.x)));
-        }
-        sm.red_d[0][tid] = cr;
-        sm.red_d[1][tid] = ci;
-        __syncthreads();
-        for (int off = WG / 2; off > 0; off >>= 1) {
-            if (tid < off) {
-                sm.red_d[0][tid] += sm.red_d[0][tid + off];
-                sm.red_d[1][tid] += sm.red_d[1][tid + off];
-            }
-            __syncthreads();
-        }
-        fine = float(-atan2(sm.red_d[1][0], sm.red_d[0][0]) / (2.0 * 3.14159265358979323846 * double(NB_FFT)));
+        fine = cp_fine_offset(sm, sym, 64, tid);
         dphi = uint32_t(__double2ll_rn(double(fine) * 4294967296.0));
         max_coarse = acq.max_coarse;
+        rule = acq.rule;
+    } else if constexpr (MODE == MODE_TRACK) {
+        const int st = frame / trk.max_out, i = frame - st * trk.max_out;
+        const StreamState ss = trk.state[st];
+        bool have = true;
+        if (!trk.fixed_start) {
+            const Predictor pr(ss);
+            cand = __double2ll_rn(pr.at(i));
+            have = ss.tracking != 0 && Predictor::fits(cand, trk.n_samples);
+        }
+        if (!have) {
+            if (tid == 0) {
+                trk.out[frame] = AcquiredFrame{-1, 0.f, 0, 0.f, 0.f, 0.f, 0};
+                if (trk.sync_out) trk.sync_out[frame] = SyncResult{0, 0, 0.f, 0.f};
+            }
+            return;
+        }
+        sym = trk.iq + size_t(st) * trk.stream_stride + cand;
+        fine = ss.fine_freq_offset;
+        // first frame after a null-symbol detection: the fine offset starts from this PRS's own cyclic prefix, so that
+        // the frame is already demodulated with it (the loop then refines it)
+        if (trk.fixed_start && trk.acquiring) fine = cp_fine_offset(sm, sym, trk.margin, tid);
+        coarse = (trk.fixed_start && trk.acquiring && trk.max_coarse > 0) ? 0.0f : ss.coarse_freq_offset;
+        dphi = uint32_t(__double2ll_rn(double(__fadd_rn(fine, coarse)) * 4294967296.0));
+        max_coarse = trk.max_coarse;
+        do_coarse = max_coarse > 0;
+        rule = trk.rule;
     } else {
         sym = iq + size_t(frame) * frame_stride;
         dphi = dphi_of(freq_offset, frame);
@@ -133,44 +190,48 @@ __global__ __launch_bounds__(WG) void prs_sync_kernel(SyncTables tab, const floa
         }
         block_fft2048(v, sm.t1, sm.x, sm.tw, tid);
     }
-    // ---- Q[b] = X[b+1] conj X[b] -> t1 ----
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-        const int b = tid + r * WG;
-        sm.t1[b] = cmulc(sm.x[(b + 1) & (NB_FFT - 1)], sm.x[b]);
-    }
-    __syncthreads();
-    // ---- coarse frequency: D_k = sum_b Q[b+k] conj S[b] for ALL shifts at once as a circular correlation,
-    //      D = IFFT(FFT(Q) conj FFT(S)); FFT(S) is a table, |IFFT(Z)| = |FFT(conj Z)| (the common 1/N does not
-    //      change a peak-to-mean ratio).  Two more transforms instead of (2 max + 1) x 1535 complex adds. ----
-    {
-        float2 v[8];
-#pragma unroll
-        for (int r = 0; r < 8; r++) v[r] = sm.t1[tid + r * WG];
-        __syncthreads();                                       // t1 is the transform's scratch from here on
-        block_fft2048(v, sm.t1, sm.y, sm.tw, tid);
+    float best_m, total;
+    int khat = 0;
+    float coarse_ptm = 0.0f;
+    if (do_coarse) {                                           // (uniform over the workgroup)
+        // ---- Q[b] = X[b+1] conj X[b] -> t1 ----
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const int b = tid + r * WG;
-            const float2 z = cmulc(sm.y[b], tab.pair_spectrum[b]);
-            v[r] = make_float2(z.x, -z.y);
+            sm.t1[b] = cmulc(sm.x[(b + 1) & (NB_FFT - 1)], sm.x[b]);
         }
         __syncthreads();
-        block_fft2048(v, sm.t1, sm.y, sm.tw, tid);
+        // ---- coarse frequency: D_k = sum_b Q[b+k] conj S[b] for ALL shifts at once as a circular correlation,
+        //      D = IFFT(FFT(Q) conj FFT(S)); FFT(S) is a table, |IFFT(Z)| = |FFT(conj Z)| (the common 1/N does not
+        //      change a peak-to-mean ratio).  Two more transforms instead of (2 max + 1) x 1535 complex adds. ----
+        {
+            float2 v[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) v[r] = sm.t1[tid + r * WG];
+            __syncthreads();                                   // t1 is the transform's scratch from here on
+            block_fft2048(v, sm.t1, sm.y, sm.tw, tid);
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int b = tid + r * WG;
+                const float2 z = cmulc(sm.y[b], tab.pair_spectrum[b]);
+                v[r] = make_float2(z.x, -z.y);
+            }
+            __syncthreads();
+            block_fft2048(v, sm.t1, sm.y, sm.tw, tid);
+        }
+        float my_m = -1.0f, my_s = 0.0f;
+        int my_k = 0x7fffffff;
+        for (int idx = tid; idx <= 2 * max_coarse; idx += WG) {
+            const float2 d = sm.y[(idx - max_coarse) & (NB_FFT - 1)];
+            const float m = d.x * d.x + d.y * d.y;
+            my_s += m;
+            if (m > my_m) { my_m = m; my_k = idx; }
+        }
+        int best_idx;
+        block_argmax_sum(sm, tid, my_m, my_k, my_s, best_m, best_idx, total);
+        khat = best_idx - max_coarse;
+        coarse_ptm = best_m / (total / float(2 * max_coarse + 1));
     }
-    float my_m = -1.0f, my_s = 0.0f;
-    int my_k = 0x7fffffff;
-    for (int idx = tid; idx <= 2 * max_coarse; idx += WG) {
-        const float2 d = sm.y[(idx - max_coarse) & (NB_FFT - 1)];
-        const float m = d.x * d.x + d.y * d.y;
-        my_s += m;
-        if (m > my_m) { my_m = m; my_k = idx; }
-    }
-    float best_m, total;
-    int best_idx;
-    block_argmax_sum(sm, tid, my_m, my_k, my_s, best_m, best_idx, total);
-    const int khat = best_idx - max_coarse;
-    const float coarse_ptm = best_m / (total / float(2 * max_coarse + 1));
 
     // ---- fine time: |IFFT(Z)| = |FFT(conj Z)|, Z[b] = X[b+k^] conj R[b] on carriers ----
     {
@@ -189,23 +250,40 @@ __global__ __launch_bounds__(WG) void prs_sync_kernel(SyncTables tab, const floa
         __syncthreads();          // everyone has read x[] before the FFT overwrites it
         block_fft2048(v, sm.t1, sm.x, sm.tw, tid);
     }
-    my_m = -1.0f;
-    my_s = 0.0f;
+    // power of every tap into y[].x (kept for the first-path scan), weighted score for the peak choice (PeakRule)
+    float my_m = -1.0f, my_s = 0.0f;
     int my_n = 0x7fffffff;
+    const float decay = __fmul_rn(__fsub_rn(1.0f, rule.distance_prob), 1.0f / float(NB_SYM_PERIOD));
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         const int n = tid + r * WG;
         const float2 h = sm.x[n];
-        const float m = h.x * h.x + h.y * h.y;
+        const float m = __fadd_rn(__fmul_rn(h.x, h.x), __fmul_rn(h.y, h.y));
+        sm.y[n].x = m;
         my_s += m;
-        if (m > my_m) { my_m = m; my_n = n; }
+        const int t = n < NB_FFT / 2 ? n : n - NB_FFT;
+        const float w = __fsub_rn(1.0f, __fmul_rn(decay, float(abs(t - rule.expected))));
+        const float sc = __fmul_rn(__fmul_rn(m, w), w);
+        if (sc > my_m) { my_m = sc; my_n = n; }
     }
     int best_n;
-    block_argmax_sum(sm, tid, my_m, my_n, my_s, best_m, best_n, total);
+    block_argmax_sum(sm, tid, my_m, my_n, my_s, best_m, best_n, total);   // (its barriers make y[] visible)
+    const float peak = sm.y[best_n].x;
+    const float mean = total / float(NB_FFT);
+    if (rule.first_path_rel > 0.0f) {
+        const float thr = fmaxf(__fmul_rn(rule.first_path_rel, peak), __fmul_rn(16.0f, mean));
+        float my_d = 0.0f;
+        for (int d = tid + 1; d <= NB_CP; d += WG)
+            if (sm.y[(best_n - d) & (NB_FFT - 1)].x >= thr) my_d = float(d);
+        float dmax, dsum;
+        int dummy;
+        block_argmax_sum(sm, tid, my_d, tid, 0.0f, dmax, dummy, dsum);
+        best_n = (best_n - int(dmax)) & (NB_FFT - 1);
+    }
     if (tid == 0) {
         const int toff = best_n < NB_FFT / 2 ? best_n : best_n - NB_FFT;
-        const float ptm = best_m / (total / float(NB_FFT));
-        if constexpr (ACQ) {
+        const float ptm = peak / mean;
+        if constexpr (MODE == MODE_ACQ) {
             AcquiredFrame r;
             r.start = cand + toff - acq.margin;
             r.coarse_carriers = khat;
@@ -214,8 +292,33 @@ __global__ __launch_bounds__(WG) void prs_sync_kernel(SyncTables tab, const floa
             r.peak_to_mean = ptm;
             r.coarse_peak_to_mean = coarse_ptm;
             r.flags = (ptm >= acq.min_peak_to_mean ? 1 : 0) |
-                      ((r.start >= 0 && r.start + int64_t(NB_FRAME_SYMBOLS) * NB_SYM_PERIOD <= acq.n_samples) ? 2 : 0);
+                      ((r.start >= 0 && r.start + int64_t(FRAME_LEN) <= acq.n_samples) ? 2 : 0);
             acq.out[frame] = r;
+        } else if constexpr (MODE == MODE_TRACK) {
+            AcquiredFrame r;
+            const bool locked = ptm >= trk.min_peak_to_mean;
+            if (trk.fixed_start) {
+                // the host assembled the frame: it is demodulated where it lies; what moves is the coarse offset
+                const int st = frame;                          // max_out == 1
+                if (do_coarse && locked) {
+                    if (trk.acquiring) coarse = -float(khat) / float(NB_FFT);
+                    else if (khat != 0) coarse = __fsub_rn(coarse, __fmul_rn(trk.coarse_slow_beta, float(khat) / float(NB_FFT)));
+                    trk.state[st].coarse_freq_offset = coarse;
+                }
+                if (trk.acquiring) trk.state[st].fine_freq_offset = fine;
+                r.start = 0;
+                r.flags = (locked ? 1 : 0) | ((toff >= 0 && toff <= NB_CP - 16) ? 2 : 0);
+            } else {
+                r.start = cand + toff - trk.margin;
+                r.flags = (locked ? 1 : 0) | ((r.start >= 0 && r.start + int64_t(FRAME_LEN) <= trk.n_samples) ? 2 : 0);
+            }
+            r.coarse_carriers = khat;
+            r.fine_offset = fine;
+            r.freq_offset = __fadd_rn(fine, coarse);
+            r.peak_to_mean = ptm;
+            r.coarse_peak_to_mean = coarse_ptm;
+            trk.out[frame] = r;
+            if (trk.sync_out) trk.sync_out[frame] = SyncResult{khat, toff, ptm, coarse_ptm};
         } else {
             SyncResult r;
             r.coarse_carriers = khat;
@@ -225,6 +328,155 @@ __global__ __launch_bounds__(WG) void prs_sync_kernel(SyncTables tab, const floa
             out[frame] = r;
         }
     }
+}
+
+// ---- timing tracking: state update after the demodulation of the tracked frames (TrackUpdateArgs) ----
+__global__ __launch_bounds__(WG) void track_update_kernel(TrackUpdateArgs a) {
+    __shared__ double red[6][WG];
+    __shared__ int red_last[WG];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    StreamState st = a.state[s];
+    if (!a.fixed_start && !st.tracking) {
+        if (tid == 0 && a.counts) a.counts[s] = 0;
+        return;
+    }
+    const Predictor pr(st);
+    // frame slots inside the capture (the same test track_sync made)
+    int count = a.max_out;
+    if (!a.fixed_start) {
+        count = 0;
+        while (count < a.max_out && Predictor::fits(__double2ll_rn(pr.at(count)), a.n_samples)) count++;
+    }
+    const AcquiredFrame *fr = a.frames + size_t(s) * a.max_out;
+    const float2 *cyc = a.cyc + size_t(s) * a.max_out * NB_FRAME_SYMBOLS;
+    // sums over the locked frames: n, i, i^2, r, i*r, and the cyclic-prefix angles
+    double sn = 0, si = 0, sii = 0, sr = 0, sir = 0, sang = 0;
+    int last = -1;
+    for (int i = tid; i < count; i += WG) {
+        const AcquiredFrame f = fr[i];
+        if ((f.flags & 3) != 3) continue;
+        const double r = double(f.start) - pr.at(i);
+        sn += 1.0; si += double(i); sii += double(i) * double(i); sr += r; sir += double(i) * r;
+        last = i;
+    }
+    for (int k = tid; k < count * NB_FRAME_SYMBOLS; k += WG) {
+        const int i = k / NB_FRAME_SYMBOLS;
+        if ((fr[i].flags & 3) != 3) continue;
+        const float2 c = cyc[k];
+        sang += double(atan2f(c.y, c.x));
+    }
+    red[0][tid] = sn; red[1][tid] = si; red[2][tid] = sii; red[3][tid] = sr; red[4][tid] = sir; red[5][tid] = sang;
+    red_last[tid] = last;
+    __syncthreads();
+    for (int off = WG / 2; off > 0; off >>= 1) {
+        if (tid < off) {
+#pragma unroll
+            for (int q = 0; q < 6; q++) red[q][tid] += red[q][tid + off];
+            red_last[tid] = max(red_last[tid], red_last[tid + off]);
+        }
+        __syncthreads();
+    }
+    sn = red[0][0]; si = red[1][0]; sii = red[2][0]; sr = red[3][0]; sir = red[4][0]; sang = red[5][0];
+    last = red_last[0];
+    __syncthreads();
+    // level of the last locked frame: its first 4096 samples
+    float l1 = 0.f;
+    if (last >= 0) {
+        const float2 *x = a.iq + size_t(s) * a.stream_stride + fr[last].start;
+        for (int i = tid; i < 4096; i += WG) l1 += fabsf(x[i].x) + fabsf(x[i].y);
+    }
+    red[0][tid] = double(l1);
+    __syncthreads();
+    for (int off = WG / 2; off > 0; off >>= 1) {
+        if (tid < off) red[0][tid] += red[0][tid + off];
+        __syncthreads();
+    }
+    if (tid != 0) return;
+    l1 = float(red[0][0] * (1.0 / 4096.0));
+    const int n_locked = int(sn);
+    int desync = (a.fixed_start ? 0 : pr.j0) + (count - n_locked);
+    if (n_locked > 0) {
+        // fine-frequency loop
+        const float err = float(sang / (sn * double(NB_FRAME_SYMBOLS))) * (1.0f / (6.283185307179586f * float(NB_FFT)));
+        constexpr float HALF = 0.5f / float(NB_FFT);
+        float f = st.fine_freq_offset - a.fine_beta * err;
+        if (f > HALF) f -= 2.f * HALF;
+        if (f < -HALF) f += 2.f * HALF;
+        st.fine_freq_offset = f;
+        st.last_fine_error = err;
+        if (!a.fixed_start) st.last_time_offset = int32_t(fr[last].start - __double2ll_rn(pr.at(last)));
+        st.last_peak_to_mean = fr[last].peak_to_mean;
+        if (st.signal_average > 0.f && l1 < a.thr_null_start * st.signal_average) desync++;
+        else st.signal_average = st.signal_average > 0.f ? a.signal_beta * st.signal_average + (1.0f - a.signal_beta) * l1 : l1;
+    }
+    if (!a.fixed_start) {
+        double alpha = 0.0, slope = 0.0, slope_hat = 0.0, gain = 0.0;
+        if (n_locked >= 2) {
+            const double det = sn * sii - si * si;             // > 0: distinct slots
+            slope = (sn * sir - si * sr) / det;
+            alpha = (sr - slope * si) / sn;
+            slope_hat = slope;
+            gain = double(a.drift_beta) * fmin(1.0, sn * 0.25);
+        } else if (n_locked == 1) {
+            alpha = sr;
+            // one frame per call: its residual IS the drift error of one period (the position was extrapolated one
+            // period from the previous frame); a lone survivor among several slots says nothing about the slope
+            slope_hat = count == 1 ? alpha : 0.0;
+            gain = double(a.drift_beta) * 0.125;
+        }
+        if (count > 0 && n_locked == 0) st.tracking = 0;        // every frame of the call lost: acquire again
+        st.next_frame_start = pr.at(count) + alpha + slope * double(count) - double(a.advance);
+        st.drift = float(double(st.drift) + gain * slope_hat);
+    }
+    st.total_frames_read += n_locked;
+    st.total_frames_desync += desync;
+    a.state[s] = st;
+    if (a.counts) a.counts[s] = count;
+}
+
+// one wave per stream; see launch_track_start in kernels.hpp
+__global__ __launch_bounds__(64) void track_start_kernel(StreamState *state, const AcquiredFrame *frames, const int32_t *counts,
+                                                         int max_out, int64_t advance) {
+    const int s = blockIdx.x, lane = threadIdx.x;
+    const AcquiredFrame *fr = frames + size_t(s) * max_out;
+    const int count = min(counts[s], max_out);
+    // first and last locked frame
+    int first = 0x7fffffff, last = -1;
+    for (int i = lane; i < count; i += 64)
+        if ((fr[i].flags & 3) == 3) { first = min(first, i); last = max(last, i); }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { first = min(first, __shfl_xor(first, off)); last = max(last, __shfl_xor(last, off)); }
+    StreamState st = state[s];
+    if (last < 0) {
+        if (lane == 0) { st.tracking = 0; state[s] = st; }
+        return;
+    }
+    const int64_t s0 = fr[first].start;
+    double sn = 0, sj = 0, sjj = 0, sy = 0, sjy = 0, sf = 0;
+    for (int i = lane; i < count; i += 64) {
+        const AcquiredFrame f = fr[i];
+        if ((f.flags & 3) != 3) continue;
+        const double y = double(f.start - s0);
+        const double j = double(__double2ll_rn(y / double(NB_FRAME_SAMPLES)));
+        sn += 1.0; sj += j; sjj += j * j; sy += y; sjy += j * y; sf += double(f.fine_offset);
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        sn += __shfl_xor(sn, off); sj += __shfl_xor(sj, off); sjj += __shfl_xor(sjj, off);
+        sy += __shfl_xor(sy, off); sjy += __shfl_xor(sjy, off); sf += __shfl_xor(sf, off);
+    }
+    if (lane != 0) return;
+    double drift = 0.0;
+    if (sn >= 4.0) drift = (sn * sjy - sj * sy) / (sn * sjj - sj * sj) - double(NB_FRAME_SAMPLES);
+    st.drift = float(drift);
+    st.next_frame_start = double(fr[last].start) + double(NB_FRAME_SAMPLES) + double(st.drift) - double(advance);
+    st.fine_freq_offset = float(sf / sn);
+    st.coarse_freq_offset = -float(fr[last].coarse_carriers) / float(NB_FFT);
+    st.tracking = 1;
+    st.total_frames_read += int(sn);
+    st.last_time_offset = 0;
+    st.last_peak_to_mean = fr[last].peak_to_mean;
+    state[s] = st;
 }
 
 // ---- null-symbol search (FINDING_NULL_POWER_DIP, /root/reference/src/render_radio_block.cpp:193) ----
@@ -427,8 +679,32 @@ hipError_t launch_prs_sync(const SyncTables &t, const float2 *iq, size_t frame_s
                            const float *freq_offset, int max_coarse, SyncResult *out, hipStream_t s) {
     if (n_frames <= 0) return hipSuccess;
     if (max_coarse < 0 || max_coarse > 1023) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(prs_sync_kernel<false>, dim3(unsigned(n_frames)), dim3(WG), 0, s, t, iq, frame_stride,
-                       freq_offset, max_coarse, out, AcquireArgs{});
+    hipLaunchKernelGGL(prs_sync_kernel<MODE_PLAIN>, dim3(unsigned(n_frames)), dim3(WG), 0, s, t, iq, frame_stride,
+                       freq_offset, max_coarse, out, AcquireArgs{}, TrackArgs{});
+    return hipGetLastError();
+}
+
+hipError_t launch_track_sync(const SyncTables &t, const TrackArgs &a, hipStream_t s) {
+    if (a.n_streams <= 0 || a.max_out <= 0) return hipSuccess;
+    if (a.max_coarse < 0 || a.max_coarse > 1023 || (a.fixed_start && a.max_out != 1)) return hipErrorInvalidValue;
+    TrackArgs b = a;
+    b.rule.expected = a.margin;
+    hipLaunchKernelGGL(prs_sync_kernel<MODE_TRACK>, dim3(unsigned(a.n_streams) * unsigned(a.max_out)), dim3(WG), 0, s, t,
+                       static_cast<const float2 *>(nullptr), size_t(0), static_cast<const float *>(nullptr), 0,
+                       static_cast<SyncResult *>(nullptr), AcquireArgs{}, b);
+    return hipGetLastError();
+}
+
+hipError_t launch_track_update(const TrackUpdateArgs &a, hipStream_t s) {
+    if (a.n_streams <= 0 || a.max_out <= 0) return hipSuccess;
+    hipLaunchKernelGGL(track_update_kernel, dim3(unsigned(a.n_streams)), dim3(WG), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_track_start(StreamState *state, const AcquiredFrame *frames, const int32_t *counts, int n_streams,
+                              int max_out, int64_t advance, hipStream_t s) {
+    if (n_streams <= 0 || max_out <= 0) return hipSuccess;
+    hipLaunchKernelGGL(track_start_kernel, dim3(unsigned(n_streams)), dim3(64), 0, s, state, frames, counts, max_out, advance);
     return hipGetLastError();
 }
 
@@ -461,9 +737,9 @@ hipError_t launch_acquire(const SyncTables &t, const AcquireArgs &a, hipStream_t
     hipLaunchKernelGGL(null_segment_kernel, dim3(unsigned(n_seg), unsigned(a.n_streams)), dim3(64), 0, s, a, nb, n_seg, avg, segs,
                        seg_cands);
     hipLaunchKernelGGL(null_stitch_kernel, dim3(unsigned(a.n_streams)), dim3(64), 0, s, a, n_seg, segs, seg_cands);
-    hipLaunchKernelGGL(prs_sync_kernel<true>, dim3(unsigned(a.n_streams) * unsigned(a.max_out)), dim3(WG), 0, s, t,
+    hipLaunchKernelGGL(prs_sync_kernel<MODE_ACQ>, dim3(unsigned(a.n_streams) * unsigned(a.max_out)), dim3(WG), 0, s, t,
                        static_cast<const float2 *>(nullptr), size_t(0), static_cast<const float *>(nullptr), 0,
-                       static_cast<SyncResult *>(nullptr), a);
+                       static_cast<SyncResult *>(nullptr), a, TrackArgs{});
     return hipGetLastError();
 }
 

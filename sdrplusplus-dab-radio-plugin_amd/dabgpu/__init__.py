@@ -40,9 +40,11 @@ EXPORTS = [
     "dabgpu_ofdm_demod_streams", "dabgpu_get_stats", "dabgpu_mean_kernel_ms", "dabgpu_decode_stream_frames",
     "dabgpu_decode_stream_reset", "dabgpu_alloc_frame_buffers", "dabgpu_free_frame_buffers",
     "dabgpu_device_alloc_apart", "dabgpu_device_free",
+    "dabgpu_set_stream_loop", "dabgpu_track_default_cfg", "dabgpu_track_start_dev", "dabgpu_ofdm_demod_tracked_dev",
+    "dabgpu_ofdm_demod_stream_frame",
 ]
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 FLAG_VITERBI_WAVE = 1 << 0
 FLAG_VITERBI_LANE = 1 << 1
 FLAG_LANE_UNFUSED = 1 << 2
@@ -75,13 +77,18 @@ class Cfg(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("state", C.c_int32), ("fine_freq_offset", C.c_float), ("coarse_freq_offset", C.c_float),
                 ("net_freq_offset", C.c_float), ("signal_average", C.c_float), ("total_frames_read", C.c_int32),
-                ("total_frames_desync", C.c_int32), ("last_fine_error", C.c_float)]
+                ("total_frames_desync", C.c_int32), ("last_fine_error", C.c_float), ("tracking", C.c_int32),
+                ("last_time_offset", C.c_int32), ("next_frame_start", C.c_double), ("drift", C.c_float),
+                ("last_peak_to_mean", C.c_float)]
 
 
 STREAM_STATE_DTYPE = np.dtype([("fine_freq_offset", np.float32), ("coarse_freq_offset", np.float32),
                                ("signal_average", np.float32), ("last_fine_error", np.float32),
                                ("total_frames_read", np.int32), ("total_frames_desync", np.int32),
-                               ("reserved", np.int32, (2,))])     # 32 bytes, device-resident
+                               ("tracking", np.int32), ("last_time_offset", np.int32),
+                               ("next_frame_start", np.float64), ("drift", np.float32), ("last_peak_to_mean", np.float32),
+                               ("reserved", np.int32, (4,))])     # 64 bytes, device-resident
+assert STREAM_STATE_DTYPE.itemsize == 64
 
 
 class SyncResult(C.Structure):
@@ -91,7 +98,19 @@ class SyncResult(C.Structure):
 
 class AcquireCfg(C.Structure):
     _fields_ = [("thr_null_start", C.c_float), ("thr_null_end", C.c_float), ("min_null_blocks", C.c_int32),
-                ("max_coarse_carriers", C.c_int32), ("min_peak_to_mean", C.c_float), ("timing_margin", C.c_int32)]
+                ("max_coarse_carriers", C.c_int32), ("min_peak_to_mean", C.c_float), ("timing_margin", C.c_int32),
+                ("impulse_peak_distance_probability", C.c_float), ("first_path_rel", C.c_float)]
+
+
+class TrackCfg(C.Structure):
+    _fields_ = [("fine_freq_update_beta", C.c_float), ("signal_update_beta", C.c_float), ("thr_null_start", C.c_float),
+                ("min_peak_to_mean", C.c_float), ("impulse_peak_distance_probability", C.c_float),
+                ("first_path_rel", C.c_float), ("drift_beta", C.c_float), ("coarse_freq_slow_beta", C.c_float),
+                ("timing_margin", C.c_int32), ("max_coarse_carriers", C.c_int32), ("reserved", C.c_int32 * 2)]
+
+
+class FrameResult(C.Structure):
+    _fields_ = [("sync", SyncResult), ("flags", C.c_int32), ("reserved", C.c_int32), ("stats", Stats)]
 
 
 ACQUIRED_FRAME_DTYPE = np.dtype([("start", np.int64), ("freq_offset", np.float32), ("coarse_carriers", np.int32),
@@ -113,6 +132,17 @@ def acquire_cfg(**kw):
     """dabgpu_acquire_default_cfg(), then the given fields overridden."""
     c = AcquireCfg()
     lib().dabgpu_acquire_default_cfg(C.byref(c))
+    for k, v in kw.items():
+        if not hasattr(c, k):
+            raise AttributeError(k)
+        setattr(c, k, v)
+    return c
+
+
+def track_cfg(**kw):
+    """dabgpu_track_default_cfg(), then the given fields overridden."""
+    c = TrackCfg()
+    lib().dabgpu_track_default_cfg(C.byref(c))
     for k, v in kw.items():
         if not hasattr(c, k):
             raise AttributeError(k)
@@ -190,6 +220,12 @@ def load_library(path):
     L.dabgpu_free_frame_buffers.argtypes = [vp, vp, vp]
     L.dabgpu_device_alloc_apart.argtypes = [vp, sz, vp, sz, C.POINTER(vp), C.POINTER(C.c_float)]
     L.dabgpu_device_free.argtypes = [vp, vp]
+    L.dabgpu_set_stream_loop.argtypes = [vp, C.c_float, C.c_float]
+    L.dabgpu_track_default_cfg.restype = None
+    L.dabgpu_track_default_cfg.argtypes = [C.POINTER(TrackCfg)]
+    L.dabgpu_track_start_dev.argtypes = [vp, vp, vp, i, i, C.c_int64, vp]
+    L.dabgpu_ofdm_demod_tracked_dev.argtypes = [vp, vp, sz, i, C.c_int64, i, C.c_int64, C.POINTER(TrackCfg), vp, vp, vp, vp, vp, vp]
+    L.dabgpu_ofdm_demod_stream_frame.argtypes = [vp, i, vp, i, C.POINTER(TrackCfg), vp, vp, C.POINTER(FrameResult)]
     L.dabgpu_get_prs_reference.argtypes = [i, vp, i]
     L.dabgpu_get_mapper_reference.argtypes = [vp, i, i]
     return L
@@ -396,6 +432,31 @@ class Context:
         st = Stats()
         _check(self._lib.dabgpu_get_stats(self._h, stream, C.byref(st)), "dabgpu_get_stats")
         return st
+
+    def set_stream_loop(self, signal_update_beta=0.95, thr_null_start=0.35):
+        _check(self._lib.dabgpu_set_stream_loop(self._h, signal_update_beta, thr_null_start), "dabgpu_set_stream_loop")
+
+    def track_start_dev(self, d_frames, d_counts, n_streams, max_frames, advance, stream=None):
+        _check(self._lib.dabgpu_track_start_dev(self._h, d_frames, d_counts, n_streams, max_frames, advance, stream),
+               "dabgpu_track_start_dev")
+
+    def ofdm_demod_tracked_dev(self, d_iq, stream_stride, n_streams, n_samples, max_frames, advance, d_soft, d_frames, d_counts,
+                               cfg=None, d_cyc=None, d_dqpsk=None, stream=None):
+        _check(self._lib.dabgpu_ofdm_demod_tracked_dev(self._h, d_iq, stream_stride, n_streams, n_samples, max_frames, advance,
+                                                   None if cfg is None else C.byref(cfg), d_soft, d_cyc, d_dqpsk, d_frames,
+                                                   d_counts, stream), "dabgpu_ofdm_demod_tracked_dev")
+
+    def ofdm_demod_stream_frame(self, iq, stream=0, acquiring=False, cfg=None, want_dqpsk=False):
+        """One frame (76*2552 cf32, host) of stream `stream` in one call -> soft [230400], FrameResult, dqpsk or None."""
+        iq = np.ascontiguousarray(iq, np.complex64).reshape(-1)
+        assert iq.size >= FRAME_USED_SAMPLES
+        soft = np.zeros(NB_FRAME_BITS, np.int8)
+        dq = np.zeros((NB_SYMBOLS - 1, NB_CARRIERS), np.complex64) if want_dqpsk else None
+        res = FrameResult()
+        _check(self._lib.dabgpu_ofdm_demod_stream_frame(self._h, stream, _p(iq), int(bool(acquiring)),
+                                                    None if cfg is None else C.byref(cfg), _p(soft), _p(dq), C.byref(res)),
+               "dabgpu_ofdm_demod_stream_frame")
+        return soft, res, dq
 
     def ofdm_demod_streams(self, iq, n_streams, beta=0.9, want_cyc=False, soft=None):
         """iq: complex64 [n_streams*frames_per_stream][>=76*2552]; uses and updates the context's stream states.

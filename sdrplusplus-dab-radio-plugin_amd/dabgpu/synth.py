@@ -321,9 +321,90 @@ def modulate_frame(bits):
     return out
 
 
-def channel(iq, snr_db=None, cfo=0.0, rng=None, phase0=0.0):
-    """cfo in cycles/sample; AWGN relative to unit signal power."""
+_RESAMPLE_TAPS, _RESAMPLE_PHASES = 24, 2048
+
+
+def _resample_table():
+    """[phases + 1][taps] windowed-sinc (Kaiser, beta 8) interpolation weights: row q interpolates at a fraction q / phases
+    between sample `half - 1` and `half` of its taps.  The DAB signal occupies 75 % of the band; with 24 taps and the
+    fraction quantised to 1/2048 sample the interpolation error stays below -60 dB."""
+    taps, ph = _RESAMPLE_TAPS, _RESAMPLE_PHASES
+    half = taps // 2
+    k = np.arange(-half + 1, half + 1, dtype=np.float64)
+    frac = np.arange(ph + 1, dtype=np.float64)[:, None] / ph
+    arg = k[None, :] - frac
+    w = np.sinc(arg) * np.i0(8.0 * np.sqrt(np.clip(1.0 - (arg / (half + 0.5)) ** 2, 0.0, 1.0))) / np.i0(8.0)
+    return (w / w.sum(axis=1, keepdims=True)).astype(np.float32)
+
+
+def resample(x, ppm, chunk=1 << 20):
+    """The stream as a receiver whose sample clock runs `ppm` parts per million FAST sees it: y[n] = x((n + 12) / (1 +
+    ppm e-6)) -- more samples per transmitted frame, the frame period grows to 196608 (1 + ppm e-6) samples.
+    x: complex numpy array, or a torch tensor (complex64, any device: long streams are resampled on the GPU)."""
+    taps, ph = _RESAMPLE_TAPS, _RESAMPLE_PHASES
+    half = taps // 2
+    ratio = 1.0 / (1.0 + ppm * 1e-6)
+    n_out = int(np.floor((x.shape[0] - 1) / ratio)) - taps
+    table = _resample_table()
+    if not isinstance(x, np.ndarray):                                # torch
+        import torch
+        tab = torch.from_numpy(table).to(x.device)
+        k = torch.arange(-half + 1, half + 1, device=x.device)
+        out = torch.empty(n_out, dtype=torch.complex64, device=x.device)
+        for a in range(0, n_out, chunk):
+            b = min(n_out, a + chunk)
+            t = (torch.arange(a, b, dtype=torch.float64, device=x.device) + half) * ratio
+            i0 = torch.floor(t).to(torch.int64)
+            q = torch.round((t - i0) * ph).to(torch.int64)
+            out[a:b] = (x[i0[:, None] + k[None, :]] * tab[q]).sum(dim=1)
+        return out
+    x = np.asarray(x, np.complex64)
+    k = np.arange(-half + 1, half + 1)
+    out = np.empty(n_out, np.complex64)
+    for a in range(0, n_out, chunk):
+        b = min(n_out, a + chunk)
+        t = (np.arange(a, b, dtype=np.float64) + half) * ratio       # positions in x (shifted so that no index is < 0)
+        i0 = np.floor(t).astype(np.int64)
+        q = np.rint((t - i0) * ph).astype(np.int64)
+        out[a:b] = (x[i0[:, None] + k[None, :]] * table[q]).sum(axis=1)
+    return out
+
+
+def fading_gain(n, rng, doppler, rice_k=4.0, fs=2.048e6, oscillators=8):
+    """Slow flat fading: a line-of-sight component plus a sum of `oscillators` sinusoids with Doppler shifts up to
+    `doppler` Hz (Jakes), unit mean power; rice_k = LOS / scattered power."""
+    t = np.arange(n, dtype=np.float64) / fs
+    g = np.zeros(n, np.complex128)
+    for _ in range(oscillators):
+        fd = doppler * np.cos(rng.uniform(0, 2 * np.pi))
+        g += np.exp(1j * (2 * np.pi * fd * t + rng.uniform(0, 2 * np.pi)))
+    g *= np.sqrt(1.0 / (oscillators * (rice_k + 1.0)))
+    return g + np.sqrt(rice_k / (rice_k + 1.0))
+
+
+def channel(iq, snr_db=None, cfo=0.0, rng=None, phase0=0.0, paths=None, sco_ppm=0.0, fading_hz=0.0, rice_k=4.0, gain=None):
+    """The synthetic channel.  In the order a signal meets them:
+      paths      multipath: [(delay in samples, complex gain), ...]; the first path is usually (0, 1).  The total is
+                 normalised to unit power, so snr_db keeps its meaning.  None = one path.
+      fading_hz  slow flat fading with this maximum Doppler shift (0 = none), Rice factor rice_k
+      gain       optional per-sample real gain (array, e.g. a level step between frames)
+      sco_ppm    sample-clock offset of the receiver (resample(): the frame period becomes 196608 (1 + ppm e-6) samples)
+      cfo        carrier offset in cycles/sample, phase0 in cycles
+      snr_db     AWGN relative to unit signal power (None = noiseless)"""
     x = np.asarray(iq, np.complex64).astype(np.complex128)
+    if paths:
+        y = np.zeros_like(x)
+        norm = np.sqrt(sum(abs(g) ** 2 for _, g in paths))
+        for d, g in paths:
+            d = int(d)
+            y[d:] += (g / norm) * x[:x.size - d]
+        x = y
+    if fading_hz > 0.0:
+        x = x * fading_gain(x.size, rng, fading_hz, rice_k)
+    if gain is not None:
+        x = x * np.asarray(gain, np.float64)
+    if sco_ppm != 0.0:
+        x = resample(x, sco_ppm).astype(np.complex128)
     n = np.arange(x.size)
     if cfo != 0.0 or phase0 != 0.0:
         x = x * np.exp(2j * np.pi * (cfo * n + phase0))

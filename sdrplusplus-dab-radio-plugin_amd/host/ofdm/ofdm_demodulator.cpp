@@ -54,6 +54,8 @@ void OFDM_Demod::Reset() {
     m_freq_coarse_offset = 0.0f;
     m_total_frames_read = 0;
     m_total_frames_desync = 0;
+    m_host_desyncs = 0;
+    m_device_desyncs_seen = 0;
     (void)dabgpu_streams_reset(m_ctx, 1);                       // the device-side loop state starts over as well
 }
 
@@ -141,74 +143,63 @@ void OFDM_Demod::push_sample_block(const std::complex<float> *x, size_t n) {
     }
 }
 
-// Coarse frequency + fine time on the frame's PRS (GPU).  Returns false when the frame must be dropped.
-bool OFDM_Demod::synchronise_frame() {
-    const float fine = m_freq_fine_offset + (m_is_acquiring ? 0.0f : m_freq_coarse_offset);
-    int max_coarse = 0;
-    if (m_cfg.sync.is_coarse_freq_correction && (m_is_acquiring || m_cfg.sync.coarse_freq_slow_beta > 0.0f))
-        max_coarse = std::min(1023, int(m_cfg.sync.max_coarse_freq_correction_norm * float(m_params.nb_fft)));
-    dabgpu_sync_result res;
-    m_state = m_is_acquiring ? State::RUNNING_COARSE_FREQ_SYNC : State::RUNNING_FINE_TIME_SYNC;
-    if (dabgpu_sync_prs(m_ctx, reinterpret_cast<const float *>(m_frame.data()), m_frame.size(), 1, &fine, max_coarse,
-                        &res) != DABGPU_OK)
-        return false;
-    m_last_time_offset = res.time_offset;
-    m_last_peak_db = 10.0f * std::log10(std::max(res.peak_to_mean, 1e-9f));
-    if (m_last_peak_db < m_cfg.sync.impulse_peak_threshold_db) return false;      // not a PRS: false lock / lost
-    if (m_is_acquiring) {
-        m_freq_coarse_offset = -float(res.coarse_carriers) / float(m_params.nb_fft);
-        m_is_acquiring = false;
-        if (dabgpu_set_stream_offsets(m_ctx, 0, nullptr, &m_freq_coarse_offset) != DABGPU_OK) return false;
-    } else if (res.coarse_carriers != 0 && m_cfg.sync.coarse_freq_slow_beta > 0.0f) {
-        // locked, yet the PRS sits k carriers off: drift.  Move a fraction of it per frame; the fine loop takes up
-        // what that leaves between whole carriers.
-        m_freq_coarse_offset -= m_cfg.sync.coarse_freq_slow_beta * float(res.coarse_carriers) / float(m_params.nb_fft);
-        if (dabgpu_set_stream_offsets(m_ctx, 0, nullptr, &m_freq_coarse_offset) != DABGPU_OK) return false;
-    }
-    // keep the FFT windows TIMING_MARGIN samples inside the cyclic prefix: time_offset is how early this frame's
-    // windows are; steer the start of the next frame (never by more than a few samples once locked)
-    const int err = res.time_offset - int(TIMING_MARGIN);
-    const long skip = long(m_params.nb_null_period) + err;
-    m_next_skip = size_t(std::max(0L, skip));
-    // windows outside the cyclic prefix (late, or more than a CP early) cannot be demodulated
-    return res.time_offset >= 0 && res.time_offset <= int(m_params.nb_cyclic_prefix) - 16;
-}
-
+// One frame: ONE call into libdabgpu (dabgpu_ofdm_demod_stream_frame) -- the frame goes up once; synchronisation on
+// the PRS (coarse frequency at acquisition, fine time always), the coarse-offset update, demodulation with the
+// stream's own offsets, the fine-frequency loop, the counters and the level average all run on the device; soft bits,
+// sync result and statistics come back in one download behind one synchronisation.  (Round 2 made three synchronous
+// calls here: dabgpu_sync_prs, dabgpu_ofdm_demod_streams, dabgpu_get_stats.)
 void OFDM_Demod::demodulate_frame() {
     m_next_skip = m_params.nb_null_period;
-    if (!synchronise_frame()) {
-        m_total_frames_desync++;
-        if (m_last_peak_db < m_cfg.sync.impulse_peak_threshold_db) {
-            m_state = State::FINDING_NULL_POWER_DIP;
-            m_in_null = false;
-            return;
-        }
-        m_state = State::READING_SYMBOLS;      // timing was off: the next frame starts at the corrected position
-        return;
-    }
-    m_state = State::READING_SYMBOLS;
-    // A2..A6 with the stream's own fine + coarse offset, then the fine-frequency loop, all on the device
-    int rc = dabgpu_ofdm_demod_streams(m_ctx, reinterpret_cast<const float *>(m_frame.data()), m_frame.size(), 1, 1,
-                                       m_cfg.sync.fine_freq_update_beta, m_soft.data(), nullptr,
-                                       reinterpret_cast<float *>(m_frame_data_vec.data()));
-    dabgpu_stats stats{};
-    if (rc == DABGPU_OK) rc = dabgpu_get_stats(m_ctx, 0, &stats);
+    dabgpu_track_cfg cfg;
+    dabgpu_track_default_cfg(&cfg);
+    cfg.fine_freq_update_beta = m_cfg.sync.fine_freq_update_beta;
+    cfg.signal_update_beta = m_cfg.signal_l1.update_beta;
+    cfg.thr_null_start = m_cfg.null_l1_search.thresh_null_start;
+    cfg.min_peak_to_mean = std::pow(10.0f, 0.1f * m_cfg.sync.impulse_peak_threshold_db);
+    cfg.impulse_peak_distance_probability = m_cfg.sync.impulse_peak_distance_probability;
+    cfg.coarse_freq_slow_beta = m_cfg.sync.coarse_freq_slow_beta;
+    cfg.timing_margin = int(TIMING_MARGIN);
+    cfg.max_coarse_carriers = 0;
+    if (m_cfg.sync.is_coarse_freq_correction && (m_is_acquiring || m_cfg.sync.coarse_freq_slow_beta > 0.0f))
+        cfg.max_coarse_carriers = std::min(1023, int(m_cfg.sync.max_coarse_freq_correction_norm * float(m_params.nb_fft)));
+    m_state = m_is_acquiring ? State::RUNNING_COARSE_FREQ_SYNC : State::RUNNING_FINE_TIME_SYNC;
+    dabgpu_frame_result res{};
+    const int rc = dabgpu_ofdm_demod_stream_frame(m_ctx, 0, reinterpret_cast<const float *>(m_frame.data()), m_is_acquiring ? 1 : 0,
+                                                  &cfg, m_soft.data(), reinterpret_cast<float *>(m_frame_data_vec.data()), &res);
     if (rc != DABGPU_OK) {   // no exceptions on the streaming path: count it as a lost frame
+        m_host_desyncs++;
         m_total_frames_desync++;
         m_state = State::FINDING_NULL_POWER_DIP;
+        m_in_null = false;
         return;
     }
-    m_freq_fine_offset = stats.fine_freq_offset;
-    // desync check: the samples where the next null symbol should be are examined by the acquisition logic
-    // only after a loss; here the signal level of the frame is refreshed
-    float l1 = 0.0f;
-    for (size_t i = 0; i < 4096; i++) l1 += std::fabs(m_frame[i].real()) + std::fabs(m_frame[i].imag());
-    l1 /= 4096.0f;
-    if (l1 < m_cfg.null_l1_search.thresh_null_start * m_signal_l1_average) {
-        m_total_frames_desync++;
+    // a demodulated frame that still raised the device's desync count: its level fell under the null threshold
+    const bool level_lost = (res.flags & 3) == 3 && res.stats.total_frames_desync > m_device_desyncs_seen;
+    m_device_desyncs_seen = res.stats.total_frames_desync;
+    m_last_time_offset = res.sync.time_offset;
+    m_last_peak_db = 10.0f * std::log10(std::max(res.sync.peak_to_mean, 1e-9f));
+    // the getters the GUI polls (src/render_radio_block.cpp:202-207): the device's values after this frame
+    m_freq_fine_offset = res.stats.fine_freq_offset;
+    m_freq_coarse_offset = res.stats.coarse_freq_offset;
+    m_total_frames_read = res.stats.total_frames_read;
+    m_total_frames_desync = res.stats.total_frames_desync + m_host_desyncs;
+    if (res.stats.signal_average > 0.0f) m_signal_l1_average = res.stats.signal_average;       // live while locked
+    if (!(res.flags & 1)) {                                   // not a PRS: false lock / signal lost -> search again
         m_state = State::FINDING_NULL_POWER_DIP;
+        m_in_null = false;
         return;
     }
-    m_total_frames_read++;
+    m_is_acquiring = false;
+    // keep the FFT windows TIMING_MARGIN samples inside the cyclic prefix: time_offset is how early this frame's
+    // windows are; steer the start of the next frame
+    const int err = res.sync.time_offset - int(TIMING_MARGIN);
+    m_next_skip = size_t(std::max(0L, long(m_params.nb_null_period) + err));
+    m_state = State::READING_SYMBOLS;
+    if (!(res.flags & 2)) return;                             // windows outside the prefix: next frame at the corrected position
+    if (level_lost) {                                         // the signal is gone
+        m_state = State::FINDING_NULL_POWER_DIP;
+        m_in_null = false;
+        return;
+    }
     m_obs_on_ofdm_frame.Notify(tcb::span<const viterbi_bit_t>(m_soft.data(), m_soft.size()));
 }

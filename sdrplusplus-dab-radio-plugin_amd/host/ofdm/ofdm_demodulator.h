@@ -6,12 +6,14 @@
 // (src/render_radio_block.cpp:96, 109, 192-207, 213-235).
 //
 // Row A1 of SURVEY.md section 8a lives here on the host: chunk reassembly and the null-symbol power-dip search.
-// Everything per sample runs on the GPU: rows A2..A6 and the fine-frequency loop in dabgpu_ofdm_demod_streams (the
-// offsets live in a dabgpu_stream_state on the device; the getters below return the copy dabgpu_get_stats fetched
-// after the last frame), and the coarse-frequency / fine-time search on the phase reference symbol (section 8f-1) in
-// dabgpu_sync_prs, which is run on every frame's PRS: at acquisition it sets the coarse offset and rejects false
-// locks (impulse_peak_threshold_db), afterwards it tracks timing drift and nudges the coarse offset
-// (coarse_freq_slow_beta).  The frame and soft-bit buffers are page-locked (dabgpu_host_alloc).  Differential
+// Everything per sample runs on the GPU, in ONE call per frame (dabgpu_ofdm_demod_stream_frame: one upload, one
+// download, one synchronisation): the coarse-frequency / fine-time search on the phase reference symbol (section 8f-1)
+// on every frame's PRS -- at acquisition it sets the coarse offset and rejects false locks
+// (impulse_peak_threshold_db), afterwards it tracks timing drift and nudges the coarse offset
+// (coarse_freq_slow_beta); the tap it aligns to is scored by impulse_peak_distance_probability --, rows A2..A6 with the
+// stream's own offsets, the fine-frequency loop, the counters and the level average (signal_l1.update_beta).  The
+// offsets live in a dabgpu_stream_state on the device; the getters below return the copy that came back with the last
+// frame.  The frame and soft-bit buffers are page-locked (dabgpu_host_alloc).  Differential
 // demodulation is insensitive to a constant timing offset inside the cyclic prefix, so the FFT windows are kept
 // `TIMING_MARGIN` samples early.
 #pragma once
@@ -43,9 +45,8 @@ struct OFDM_Demod_Config {
         // fraction of k per frame (0 = keep the offset found at acquisition)
         float coarse_freq_slow_beta = 0.1f;
         float impulse_peak_threshold_db = 20.0f;
-        // INERT here: the reference weights impulse-response peaks by their distance from the expected position to
-        // choose between echoes; dabgpu_sync_prs takes the strongest tap, which is the same tap whenever the first
-        // path dominates.  Kept so that the GUI's slider (src/render_radio_block.cpp:225) has its field.
+        // taps of the channel impulse response are scored |h|^2 w^2, w = 1 - (1 - p) |offset - expected| / 2552
+        // (dabgpu_track_cfg; the GUI's slider at src/render_radio_block.cpp:225)
         float impulse_peak_distance_probability = 0.15f;
     } sync;
 };
@@ -81,8 +82,12 @@ public:
     tcb::span<const std::complex<float>> GetFrameDataVec() const { return {m_frame_data_vec.data(), m_frame_data_vec.size()}; }
     Observable<tcb::span<const viterbi_bit_t>> &On_OFDM_Frame() { return m_obs_on_ofdm_frame; }
 
-    // extension: apply a known coarse offset (cycles/sample) until the device-side search exists
-    void SetCoarseFrequencyOffset(float f) { m_freq_coarse_offset = f; }
+    // extension: apply a known coarse offset (cycles/sample); it goes to the device-side state the demodulation reads
+    // (with is_coarse_freq_correction on, the next acquisition overwrites it)
+    void SetCoarseFrequencyOffset(float f) {
+        m_freq_coarse_offset = f;
+        (void)dabgpu_set_stream_offsets(m_ctx, 0, nullptr, &f);
+    }
     int GetFineTimeOffset() const { return m_last_time_offset; }
     float GetImpulsePeakDb() const { return m_last_peak_db; }
 
@@ -92,7 +97,6 @@ private:
 
     void push_sample_block(const std::complex<float> *x, size_t n);
     void demodulate_frame();
-    bool synchronise_frame();
 
     const OFDM_Params m_params;
     OFDM_Demod_Config m_cfg;
@@ -114,6 +118,8 @@ private:
     // tracking
     float m_freq_fine_offset, m_freq_coarse_offset;
     int m_total_frames_read, m_total_frames_desync;
+    int m_host_desyncs = 0;            // lost frames the device never saw (failed calls)
+    int m_device_desyncs_seen = 0;
     // outputs
     PinnedBuffer<viterbi_bit_t> m_soft;             // page-locked: downloaded every frame
     PinnedBuffer<std::complex<float>> m_frame_data_vec;

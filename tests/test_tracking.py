@@ -1,0 +1,388 @@
+"""Per-stream timing tracking on the device (ABI v4): what OFDM_Demod's RUNNING_FINE_TIME_SYNC state does on every
+frame once locked (/root/reference/src/render_radio_block.cpp:196, knobs :224-225), for batches of streams.
+A stream is acquired once; afterwards dabgpu_ofdm_demod_tracked_dev predicts every frame from the stream's state,
+synchronises it on its own PRS, demodulates it where it lies and moves the state on.
+CPU part: the oracle's restatement against known answers.  GPU part: kernels against the oracle (frame starts equal,
+state within float tolerance, soft bits within 1 LSB), against the transmitted FIBs, and the long-run lock test:
+a stream whose sample clock is off by +-100 ppm stays locked for 256 frames."""
+import types
+
+import numpy as np
+import pytest
+
+from dabgpu import synth
+from oracle import oracle as O
+
+L = synth.NB_FRAME_SAMPLES
+NULL = synth.NB_NULL
+SYMS = 76 * 2552
+HALF = 12                      # group delay of synth.resample
+
+
+def short_stream(seed, n_frames, ppm, cfo_carriers, snr, cut):
+    """n_frames of a cyclic multiplex through a channel with a sample-clock offset, cut `cut` samples into frame 0.
+    -> (iq, position of every frame's first PRS-prefix sample in iq (float), ensemble)"""
+    e = synth.Ensemble(seed=seed, n_frames=4)
+    tx = np.tile(e.iq().ravel(), (n_frames + 3) // 4)[:n_frames * L]
+    rng = np.random.default_rng(seed)
+    x = synth.channel(tx, snr_db=snr, cfo=cfo_carriers / 2048.0, rng=rng, sco_ppm=ppm)
+    pos = (np.arange(n_frames) * L + NULL) * (1.0 + ppm * 1e-6) - HALF - cut
+    return x[cut:], pos, e
+
+
+def fresh_state():
+    return {"fine_freq_offset": np.float32(0), "coarse_freq_offset": np.float32(0), "signal_average": np.float32(0),
+            "last_fine_error": np.float32(0), "total_frames_read": 0, "total_frames_desync": 0, "tracking": 0,
+            "last_time_offset": 0, "next_frame_start": 0.0, "drift": np.float32(0), "last_peak_to_mean": np.float32(0)}
+
+
+def oracle_acquire(x, max_frames, margin=64):
+    out = []
+    for c in O.null_search(x, max_out=max_frames):
+        out.append(O.acquire_candidate(x, c, margin=margin))
+    return out
+
+
+def test_oracle_tracks_a_drifting_stream():
+    """Acquire on the first capture, track over the following ones: every frame is found at its true position
+    (+-1 sample), the drift estimate converges to ppm * 196608 samples per frame, nothing is lost."""
+    ppm = 80.0
+    x, pos, e = short_stream(7, 12, ppm, 1.3, 18.0, 50000)
+    n_cap, adv = 3 * L + 8192, 2 * L
+    fr = oracle_acquire(x[:n_cap], 4)
+    assert len(fr) == 2 and all(f.flags == 3 for f in fr)
+    st = O.track_start(fresh_state(), fr, adv)
+    assert st["tracking"] == 1 and st["total_frames_read"] == 2 and st["drift"] == 0       # two frames: no drift yet
+    found = [int(f.start) for f in fr]
+    base = 0
+    for call in range(4):
+        base += adv
+        cap = x[base:base + n_cap]
+        frames = O.track_sync(cap, st, 4)
+        assert len(frames) == 2 and all(f["flags"] == 3 for f in frames), (call, frames)
+        cyc = np.stack([O.ofdm_demod_frame(cap[f["start"]:f["start"] + SYMS], float(f["freq_offset"]), want_cyc=True)[2]
+                        for f in frames])
+        st, count = O.track_update(st, frames, cyc, cap, cap.size, 4, adv)
+        assert count == 2 and st["tracking"] == 1
+        found += [base + f["start"] for f in frames]
+    want = pos[1:1 + len(found)] - 64                                      # frame 0 is cut; default margin 64
+    assert np.abs(np.array(found) - want).max() <= 1.0
+    assert st["total_frames_read"] == len(found) and st["total_frames_desync"] == 0
+    assert 0.5 * ppm * 1e-6 * L < float(st["drift"]) < 1.1 * ppm * 1e-6 * L     # two frames per call: a quarter of the error per call
+    assert abs(float(st["fine_freq_offset"]) * 2048 + 0.3) < 0.02           # 1.3 carriers: coarse -1, fine -0.3
+
+
+def test_oracle_first_path_rule_and_distance_weight():
+    """Two-path channel with the LATE echo 3 dB stronger: the strongest-tap rule locks to the echo, the first-path rule
+    (first_path_rel 0.25) to the first arrival; the distance weight prefers a tap near the expected position over an
+    equally strong one far away."""
+    e = synth.Ensemble(seed=3, n_frames=4)
+    tx = e.iq().ravel()
+    rng = np.random.default_rng(3)
+    delay = 200
+    x = synth.channel(tx, snr_db=25.0, rng=rng, paths=[(0, 1.0), (delay, np.sqrt(2.0) * np.exp(0.7j))])
+    sym = x[NULL - 64:NULL - 64 + 2552]                                       # window 64 samples early
+    _, t_peak, ptm, _ = O.sync_prs(sym, 0.0, 0)
+    _, t_first, ptm2, _ = O.sync_prs(sym, 0.0, 0, expected=64, distance_prob=0.15, first_path_rel=0.25)
+    assert t_peak == 64 + delay and t_first == 64 and ptm > 100 and ptm2 == pytest.approx(ptm, rel=1e-6)
+    # equal taps at 64 and at 64 + 400: unweighted picks whichever is numerically larger, weighted the near one
+    x = synth.channel(tx, snr_db=None, paths=[(0, 1.0), (400, 1.02)])
+    sym = x[NULL - 64:NULL - 64 + 2552]
+    assert O.sync_prs(sym, 0.0, 0)[1] == 464
+    assert O.sync_prs(sym, 0.0, 0, expected=64, distance_prob=0.15)[1] == 64
+
+
+# ------------------------------------------------------------------------------------------------------------ GPU
+@pytest.fixture(scope="module")
+def tctx(built):
+    from conftest import make_ctx
+    c = make_ctx(None, 64)
+    yield c
+    c.close()
+
+
+def read_states(torch, ctx, n):
+    import dabgpu
+    t = dabgpu.device_tensor(torch, ctx.stream_states_ptr, (n * 64,), torch.uint8, torch.device("cuda", 0))
+    return t.cpu().numpy().view(dabgpu.STREAM_STATE_DTYPE).copy()
+
+
+def as_frames(rec):
+    return [types.SimpleNamespace(start=int(r["start"]), flags=int(r["flags"]), fine_offset=np.float32(r["fine_offset"]),
+                                  coarse_carriers=int(r["coarse_carriers"]), peak_to_mean=np.float32(r["peak_to_mean"]))
+            for r in rec]
+
+
+def state_dict(rec):
+    d = {k: rec[k] for k in rec.dtype.names if k != "reserved"}
+    for k in ("total_frames_read", "total_frames_desync", "tracking", "last_time_offset"):
+        d[k] = int(d[k])
+    d["next_frame_start"] = float(d["next_frame_start"])
+    return d
+
+
+def check_state(got, want, what):
+    for k in ("total_frames_read", "total_frames_desync", "tracking", "last_time_offset"):
+        assert int(got[k]) == int(want[k]), (what, k, got[k], want[k])
+    assert abs(float(got["next_frame_start"]) - float(want["next_frame_start"])) <= 1e-4, what
+    assert abs(float(got["drift"]) - float(want["drift"])) <= 1e-5 + 1e-5 * abs(float(want["drift"])), what
+    assert abs(float(got["fine_freq_offset"]) - float(want["fine_freq_offset"])) <= 2e-9, what
+    assert abs(float(got["last_fine_error"]) - float(want["last_fine_error"])) <= 2e-9, what
+    assert float(got["coarse_freq_offset"]) == float(want["coarse_freq_offset"]), what
+    assert abs(float(got["signal_average"]) - float(want["signal_average"])) <= 1e-5 * float(want["signal_average"]) + 1e-12, what
+    assert abs(float(got["last_peak_to_mean"]) - float(want["last_peak_to_mean"])) <= 2e-3 * float(want["last_peak_to_mean"]) + 1e-12, what
+
+
+@pytest.mark.gpu
+def test_gpu_tracked_call_equals_the_oracle(tctx):
+    """Two streams with different clock and carrier offsets: acquisition -> dabgpu_track_start_dev -> three tracked calls.
+    Frame starts and flags equal the oracle's, the states agree to float tolerance, soft bits are within 1 LSB of the
+    oracle's demodulation of the same samples, FIBs are the transmitted ones."""
+    import torch
+    import dabgpu
+    dev = torch.device("cuda", 0)
+    specs = [(60.0, 2.31, 16.0, 41000), (-35.0, -1.42, 13.0, 97531)]
+    streams = [short_stream(50 + i, 12, *sp) for i, sp in enumerate(specs)]
+    n_cap, adv, MF = 3 * L + 8192, 2 * L, 4
+    n_total = min(s[0].size for s in streams)
+    xs = np.stack([s[0][:n_total] for s in streams])
+    d_x = torch.from_numpy(xs).to(dev)
+    S = len(streams)
+    tctx.streams_reset(S)
+    frames = torch.zeros((S, MF, 32), dtype=torch.uint8, device=dev)
+    counts = torch.zeros(S, dtype=torch.int32, device=dev)
+    soft = torch.zeros((S * MF, dabgpu.NB_FRAME_BITS), dtype=torch.int8, device=dev)
+    cyc = torch.zeros((S * MF, 76), dtype=torch.complex64, device=dev)
+    fib = torch.zeros((S * MF, 12, 32), dtype=torch.uint8, device=dev)
+    ok = torch.zeros((S * MF, 12), dtype=torch.uint8, device=dev)
+    # ---- call 0: acquisition, then tracking starts
+    tctx.acquire_dev(d_x.data_ptr(), n_total, S, n_cap, MF, frames.data_ptr(), counts.data_ptr())
+    tctx.track_start_dev(frames.data_ptr(), counts.data_ptr(), S, MF, adv)
+    tctx.sync()
+    fr = frames.cpu().numpy().view(dabgpu.ACQUIRED_FRAME_DTYPE).reshape(S, MF)
+    cnt = counts.cpu().numpy()
+    got = read_states(torch, tctx, S)
+    ostate = []
+    for s in range(S):
+        assert cnt[s] == 2
+        want = O.track_start(fresh_state(), as_frames(fr[s, :cnt[s]]), adv)
+        check_state(got[s], want, "start %d" % s)
+        ostate.append(state_dict(got[s]))                  # continue from the device's own state (float-identical inputs)
+    # ---- calls 1..3: tracked
+    base = 0
+    for call in range(1, 4):
+        base += adv
+        before = read_states(torch, tctx, S)
+        tctx.ofdm_demod_tracked_dev(d_x.data_ptr() + base * 8, n_total, S, n_cap, MF, adv, soft.data_ptr(), frames.data_ptr(),
+                                    counts.data_ptr(), d_cyc=cyc.data_ptr())
+        tctx.fic_decode_dev(soft.data_ptr(), dabgpu.NB_FRAME_BITS, S * MF, fib.data_ptr(), ok.data_ptr())
+        tctx.sync()
+        fr = frames.cpu().numpy().view(dabgpu.ACQUIRED_FRAME_DTYPE).reshape(S, MF)
+        cnt = counts.cpu().numpy()
+        after = read_states(torch, tctx, S)
+        soft_h = soft.cpu().numpy().reshape(S, MF, -1)
+        cyc_h = cyc.cpu().numpy().reshape(S, MF, 76)
+        fib_h, ok_h = fib.cpu().numpy().reshape(S, MF, 12, 32), ok.cpu().numpy().reshape(S, MF, 12)
+        for s in range(S):
+            cap = xs[s, base:base + n_cap]
+            st0 = state_dict(before[s])
+            of = O.track_sync(cap, st0, MF)
+            assert cnt[s] == len(of) == 2, (call, s, cnt[s], len(of))
+            for j, f in enumerate(of):
+                g = fr[s, j]
+                assert (int(g["start"]), int(g["flags"])) == (f["start"], f["flags"]), (call, s, j)
+                assert g["flags"] == 3
+                assert float(g["freq_offset"]) == float(f["freq_offset"])
+                assert abs(g["peak_to_mean"] - f["peak_to_mean"]) <= 2e-3 * f["peak_to_mean"]
+                osoft, _, ocyc, _ = O.ofdm_demod_frame(cap[f["start"]:f["start"] + SYMS], float(f["freq_offset"]), want_cyc=True)
+                assert np.abs(soft_h[s, j].astype(np.int32) - osoft.astype(np.int32)).max() <= 1
+                assert np.allclose(cyc_h[s, j], ocyc, rtol=1e-3, atol=1e-3 * np.abs(ocyc).max())
+                # truth: which transmitted frame this is, from its position
+                k = int(round(((base + f["start"] + 64 + HALF + specs[s][3]) / (1 + specs[s][0] * 1e-6) - NULL) / L))
+                assert ok_h[s, j].all() and (fib_h[s, j] == streams[s][2].fibs[k % 4]).all(), (call, s, j, k)
+                assert abs(base + f["start"] + 64 - streams[s][1][k]) <= 1.0
+            assert (fr[s, cnt[s]:]["flags"] == 0).all() and not soft_h[s, cnt[s]:].any()
+            want, count = O.track_update(st0, of, cyc_h[s, :len(of)], cap, n_cap, MF, adv)
+            assert count == cnt[s]
+            check_state(after[s], want, "call %d stream %d" % (call, s))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ppms", [(100.0, -100.0)])
+def test_gpu_stream_off_by_100ppm_stays_locked_for_256_frames(tctx, ppms):
+    """streams resampled by +100 and -100 ppm (frame period +-19.7 samples), acquired ONCE, then
+    tracked through 16 captures of 16 frames: every frame is demodulated exactly once, FIBs bit-exact against the
+    transmitted ones for all of them, no desync, drift estimate on the mark."""
+    import torch
+    import dabgpu
+    dev = torch.device("cuda", 0)
+    NF, C = 262, 16
+    S = len(ppms)
+    n_cap, adv, MF = (C + 1) * L + 4096, C * L, C + 2
+    ens, xs = [], []
+    for s, ppm in enumerate(ppms):
+        e = synth.Ensemble(seed=900 + s, n_frames=4)
+        tx = torch.from_numpy(e.iq().ravel()).to(dev).repeat((NF + 3) // 4)[:NF * L]
+        x = synth.resample(tx, ppm)
+        n = torch.arange(x.shape[0], device=dev, dtype=torch.float64)
+        cfo = (1.7 - 3.1 * s) / 2048.0
+        x = x * torch.exp(2j * np.pi * cfo * n).to(torch.complex64)
+        g = torch.Generator(device=dev); g.manual_seed(77 + s)
+        sigma = float(np.sqrt(0.5 * 10 ** (-17.0 / 10)))
+        x = x + sigma * (torch.randn(x.shape, generator=g, device=dev) + 1j * torch.randn(x.shape, generator=g, device=dev))
+        ens.append(e); xs.append(x[70000 + 11111 * s:])
+    n_total = min(int(x.shape[0]) for x in xs)
+    d_x = torch.stack([x[:n_total] for x in xs]).contiguous()
+    del xs
+    tctx.streams_reset(S)
+    frames = torch.zeros((S, MF, 32), dtype=torch.uint8, device=dev)
+    counts = torch.zeros(S, dtype=torch.int32, device=dev)
+    soft = torch.zeros((S * MF, dabgpu.NB_FRAME_BITS), dtype=torch.int8, device=dev)
+    fib = torch.zeros((S * MF, 12, 32), dtype=torch.uint8, device=dev)
+    ok = torch.zeros((S * MF, 12), dtype=torch.uint8, device=dev)
+    seen = [[] for _ in range(S)]
+    base, call = 0, 0
+    while base + n_cap <= n_total:
+        p = d_x.data_ptr() + base * 8
+        if call == 0:
+            tctx.acquire_dev(p, n_total, S, n_cap, MF, frames.data_ptr(), counts.data_ptr())
+            tctx.ofdm_demod_acquired_dev(p, n_total, S, MF, frames.data_ptr(), soft.data_ptr())
+            tctx.track_start_dev(frames.data_ptr(), counts.data_ptr(), S, MF, adv)
+        else:
+            tctx.ofdm_demod_tracked_dev(p, n_total, S, n_cap, MF, adv, soft.data_ptr(), frames.data_ptr(), counts.data_ptr())
+        tctx.fic_decode_dev(soft.data_ptr(), dabgpu.NB_FRAME_BITS, S * MF, fib.data_ptr(), ok.data_ptr())
+        tctx.sync()
+        fr = frames.cpu().numpy().view(dabgpu.ACQUIRED_FRAME_DTYPE).reshape(S, MF)
+        cnt = counts.cpu().numpy()
+        fib_h, ok_h = fib.cpu().numpy().reshape(S, MF, 12, 32), ok.cpu().numpy().reshape(S, MF, 12)
+        for s in range(S):
+            for j in range(cnt[s]):
+                assert fr[s, j]["flags"] == 3, (call, s, j, fr[s, j])
+                pos = base + int(fr[s, j]["start"]) + 64 + HALF + 70000 + 11111 * s
+                k = int(round((pos / (1 + ppms[s] * 1e-6) - NULL) / L))
+                assert abs(pos / (1 + ppms[s] * 1e-6) - NULL - k * L) <= 1.5, (call, s, j)
+                assert ok_h[s, j].all() and (fib_h[s, j] == ens[s].fibs[k % 4]).all(), (call, s, j, k)
+                seen[s].append(k)
+        base += adv
+        call += 1
+    assert call >= 16
+    st = read_states(torch, tctx, S)
+    for s in range(S):
+        assert len(seen[s]) >= 256 and seen[s] == list(range(seen[s][0], seen[s][0] + len(seen[s]))), s   # each frame once, in order
+        assert st[s]["tracking"] == 1 and st[s]["total_frames_desync"] == 0
+        assert st[s]["total_frames_read"] == len(seen[s])
+        assert abs(float(st[s]["drift"]) - ppms[s] * 1e-6 * L) < 0.05
+        stats = tctx.get_stats(s)
+        assert stats.state == 4 and stats.tracking == 1 and abs(stats.drift - st[s]["drift"]) == 0
+
+
+@pytest.mark.gpu
+def test_gpu_tracking_drops_out_on_noise_and_counts_missed_frames(tctx):
+    """A tracked stream whose capture turns into noise loses every frame of the call: tracking stops (state 0), the
+    frames count as desync, soft bits are erased.  A capture that begins late (frames before it) counts them missed."""
+    import torch
+    import dabgpu
+    dev = torch.device("cuda", 0)
+    x, pos, e = short_stream(61, 10, 0.0, 0.4, 20.0, 30000)
+    n_cap, adv, MF = 3 * L + 8192, 2 * L, 4
+    d_x = torch.from_numpy(x).to(dev)
+    rng = np.random.default_rng(5)
+    noise = torch.from_numpy((rng.standard_normal(n_cap) + 1j * rng.standard_normal(n_cap)).astype(np.complex64)).to(dev)
+    tctx.streams_reset(1)
+    frames = torch.zeros((1, MF, 32), dtype=torch.uint8, device=dev)
+    counts = torch.zeros(1, dtype=torch.int32, device=dev)
+    soft = torch.full((MF, dabgpu.NB_FRAME_BITS), 9, dtype=torch.int8, device=dev)
+    tctx.acquire_dev(d_x.data_ptr(), x.size, 1, n_cap, MF, frames.data_ptr(), counts.data_ptr())
+    tctx.track_start_dev(frames.data_ptr(), counts.data_ptr(), 1, MF, adv + L)         # the next capture begins a frame late
+    tctx.ofdm_demod_tracked_dev(d_x.data_ptr() + (adv + L) * 8, x.size, 1, n_cap, MF, adv, soft.data_ptr(), frames.data_ptr(),
+                                counts.data_ptr())
+    tctx.sync()
+    st = read_states(torch, tctx, 1)[0]
+    fr = frames.cpu().numpy().view(dabgpu.ACQUIRED_FRAME_DTYPE).reshape(MF)
+    assert counts.cpu().numpy()[0] == 2 and (fr[:2]["flags"] == 3).all()
+    assert st["total_frames_desync"] == 1 and st["total_frames_read"] == 4 and st["tracking"] == 1   # one frame fell between
+    tctx.ofdm_demod_tracked_dev(noise.data_ptr(), n_cap, 1, n_cap, MF, adv, soft.data_ptr(), frames.data_ptr(), counts.data_ptr())
+    tctx.sync()
+    st = read_states(torch, tctx, 1)[0]
+    assert counts.cpu().numpy()[0] == 2 and st["tracking"] == 0 and st["total_frames_desync"] == 3
+    assert not soft.cpu().numpy().any()
+    assert tctx.get_stats(0).state == 0
+    # not tracking: a tracked call does nothing but say so
+    soft.fill_(9)
+    tctx.ofdm_demod_tracked_dev(d_x.data_ptr(), x.size, 1, n_cap, MF, adv, soft.data_ptr(), frames.data_ptr(), counts.data_ptr())
+    tctx.sync()
+    assert counts.cpu().numpy()[0] == 0 and not soft.cpu().numpy().any()
+    L_ = dabgpu.lib()
+    assert L_.dabgpu_ofdm_demod_tracked_dev(tctx._h, None, 0, 1, 10, 1, 0, None, None, None, None, None, None, None) == -1
+    with pytest.raises(dabgpu.DabGpuError):
+        tctx.ofdm_demod_tracked_dev(d_x.data_ptr(), x.size, 1, n_cap, MF, adv, soft.data_ptr(), frames.data_ptr(),
+                                    counts.data_ptr(), cfg=dabgpu.track_cfg(drift_beta=2.0))
+
+
+@pytest.mark.gpu
+def test_gpu_frame_call_equals_the_three_call_sequence_and_the_oracle(tctx):
+    """dabgpu_ofdm_demod_stream_frame (one upload, one download, one synchronisation) against the oracle: the sync
+    result of the acquiring frame, the coarse offset it stores, soft bits within 1 LSB of the oracle's demodulation with
+    the offsets the call used, the fine loop's state after it; then the round-2 sequence dabgpu_sync_prs +
+    dabgpu_ofdm_demod_streams + dabgpu_get_stats on a second context gives the same soft bits."""
+    import dabgpu
+    from conftest import make_ctx
+    e = synth.Ensemble(seed=77, n_frames=4)
+    rng = np.random.default_rng(77)
+    cfo = -2.27 / 2048.0
+    iq = synth.channel(e.iq().ravel(), snr_db=15.0, cfo=cfo, rng=rng)
+    M = 128
+    cfg = dabgpu.track_cfg(timing_margin=M, min_peak_to_mean=100.0)
+    tctx.streams_reset(1)
+    other = make_ctx(None, 4)
+    other.streams_reset(1)
+    fine = np.float32(0.0)
+    for f in range(4):
+        frame = iq[f * L + NULL - M:f * L + NULL - M + SYMS]
+        soft, res, dq = tctx.ofdm_demod_stream_frame(frame, 0, acquiring=(f == 0), cfg=cfg, want_dqpsk=(f == 1))
+        coarse_before = np.float32(0.0) if f == 0 else np.float32(2.0 / 2048.0)
+        if f == 0:
+            # acquiring: the fine offset starts from the PRS's own cyclic prefix (products M .. M+375)
+            a, b = frame[M:M + 376], frame[M + 2048:M + 2048 + 376]
+            cr = (a.real * b.real + a.imag * b.imag).astype(np.float64).sum()
+            ci = (a.real * b.imag - a.imag * b.real).astype(np.float64).sum()
+            fine = np.float32(-np.arctan2(ci, cr) / (2.0 * np.pi * 2048.0))
+            assert abs(float(fine) * 2048 - 0.27) < 0.03
+        k, toff, ptm, cptm = O.sync_prs(frame[:2552], float(np.float32(fine + coarse_before)), 204, expected=M, distance_prob=0.15,
+                                        first_path_rel=0.25)
+        assert (res.sync.coarse_carriers, res.sync.time_offset) == (k, toff) and res.flags == 3
+        assert k == (-2 if f == 0 else 0) and toff == M
+        assert abs(res.sync.peak_to_mean - ptm) <= 2e-3 * ptm and abs(res.sync.coarse_peak_to_mean - cptm) <= 2e-3 * cptm
+        assert res.stats.coarse_freq_offset == np.float32(2.0 / 2048.0)
+        net = np.float32(fine + np.float32(2.0 / 2048.0))
+        osoft, _, ocyc, odq = O.ofdm_demod_frame(frame, float(net), want_cyc=True, want_dqpsk=True)
+        assert np.abs(soft.astype(np.int32) - osoft.astype(np.int32)).max() <= 1
+        if dq is not None:
+            assert np.abs(dq - odq).max() <= 2e-4 * np.abs(odq).max()
+        st = O.stream_update({"fine_freq_offset": fine, "coarse_freq_offset": net - fine, "signal_average": np.float32(0) if f == 0 else level,
+                              "total_frames_read": f, "total_frames_desync": 0}, ocyc[None, :], frame, 0.9)
+        assert abs(res.stats.fine_freq_offset - st["fine_freq_offset"]) <= 2e-9
+        assert res.stats.total_frames_read == f + 1 and res.stats.total_frames_desync == 0 and res.stats.state == 4
+        assert abs(res.stats.signal_average - st["signal_average"]) <= 1e-5 * st["signal_average"]
+        # the round-2 three-call sequence on another context, started from the same offsets
+        sres = other.sync_prs(frame[None, :2552], np.array([fine + coarse_before], np.float32), 204)[0]
+        assert sres["coarse_carriers"] == k
+        if f == 0:
+            other.set_stream_offsets(0, fine=float(fine), coarse=2.0 / 2048.0)
+        soft3, _ = other.ofdm_demod_streams(frame[None, :], 1, 0.9)
+        assert (soft3[0] == soft).all()
+        assert other.get_stats(0).fine_freq_offset == res.stats.fine_freq_offset
+        fine, level = np.float32(res.stats.fine_freq_offset), np.float32(res.stats.signal_average)
+        fib, ok = tctx.fic_decode(soft[None, :])
+        assert ok.all() and (fib[0] == e.fibs[f]).all()                  # already the acquiring frame decodes
+    # a frame that is not a PRS: nothing is demodulated, the frame counts as lost, the level stays
+    noise = (rng.standard_normal(SYMS) + 1j * rng.standard_normal(SYMS)).astype(np.complex64)
+    soft, res, _ = tctx.ofdm_demod_stream_frame(noise, 0, acquiring=False, cfg=cfg)
+    assert res.flags & 1 == 0 and not soft.any() and res.stats.total_frames_desync == 1 and res.stats.total_frames_read == 4
+    # the level average is live: a 6 dB step moves it by (1 - beta) of the difference per frame
+    cfg2 = dabgpu.track_cfg(timing_margin=M, signal_update_beta=0.5)
+    frame = 2.0 * iq[NULL - M:NULL - M + SYMS]
+    before = res.stats.signal_average
+    _, res, _ = tctx.ofdm_demod_stream_frame(frame, 0, acquiring=False, cfg=cfg2)
+    assert res.flags == 3 and res.stats.signal_average == pytest.approx(1.5 * before, rel=0.05)
+    other.close()
