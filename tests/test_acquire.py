@@ -154,6 +154,78 @@ def test_gpu_unaligned_capture_to_fibs(gctx):
     assert odd > 0                                                       # the 8-byte-aligned load path was exercised
 
 
+def multipath_capture(seed, paths, snr, cfo_carriers, cut, ppm=0.0):
+    e = synth.Ensemble(seed=seed, n_frames=4)
+    rng = np.random.default_rng(seed)
+    x = synth.channel(e.iq().ravel(), snr_db=snr, cfo=cfo_carriers / 2048.0, rng=rng, paths=paths, sco_ppm=ppm)[cut:]
+    half = 12 if ppm else 0
+    starts = np.array([(k * FRAME + NULL) * (1 + ppm * 1e-6) - half - cut for k in range(1, 4)])
+    return x, starts[starts + SYMS + 512 <= x.size], e
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("echo_db,delay", [(3.0, 200), (2.0, 330), (-4.0, 120), (0.0, 60)])
+def test_gpu_acquisition_aligns_to_the_first_significant_path(gctx, echo_db, delay):
+    """An echo up to 3 dB STRONGER than the first arrival, anywhere inside the cyclic prefix: acquisition (default
+    cfg: first_path_rel 0.25) aligns the frame to the first path -- so the echo falls inside the prefix and the FIBs
+    decode --, exactly as the oracle does on the same samples; with the reference's rule (first_path_rel 0, weighted
+    maximum) the stronger echo wins and the frame starts `delay` samples late."""
+    import dabgpu
+    g = 10 ** (echo_db / 20.0)
+    x, starts, e = multipath_capture(70 + delay, [(0, 1.0), (delay, g * np.exp(0.9j))], 22.0, 1.6, 40000)
+    frames, counts = gctx.acquire(x[None, :], 4)
+    assert counts[0] == len(starts) == 2
+    for j in range(2):
+        r = O.acquire_candidate(x, O.null_search(x, max_out=4)[j], margin=64)
+        gfr = frames[0, j]
+        assert (gfr["start"], gfr["coarse_carriers"], gfr["flags"]) == (r.start, r.coarse_carriers, r.flags)
+        assert gfr["flags"] == 3 and abs(int(gfr["start"]) + 64 - starts[j]) <= 1           # the FIRST path
+    # demodulate where the frames lie: the transmitted FIBs
+    import torch
+    dev = torch.device("cuda", 0)
+    d_x = torch.from_numpy(x).to(dev)
+    d_fr = torch.from_numpy(frames.view(np.uint8).reshape(-1)).to(dev)
+    soft = torch.zeros((4, dabgpu.NB_FRAME_BITS), dtype=torch.int8, device=dev)
+    gctx.ofdm_demod_acquired_dev(d_x.data_ptr(), x.size, 1, 4, d_fr.data_ptr(), soft.data_ptr())
+    gctx.sync()
+    fib, ok = gctx.fic_decode(soft.cpu().numpy()[:2])
+    assert ok.all() and (fib == e.fibs[1:3]).all()
+    # the reference's rule on the same capture: the strongest (weighted) tap
+    ref_rule = dabgpu.acquire_cfg(first_path_rel=0.0)
+    fr2, _ = gctx.acquire(x[None, :], 4, ref_rule)
+    late = int(fr2[0, 0]["start"]) + 64 - starts[0]
+    assert abs(late - (delay if echo_db > 0.5 else 0)) <= 1 or (abs(echo_db) <= 0.5 and abs(late - delay) <= 1)
+
+
+@pytest.mark.gpu
+def test_gpu_acquisition_under_clock_offset_and_fading(gctx):
+    """Three streams in one call: +120 ppm, -120 ppm, and 8 Hz fading with an echo.  Every whole frame is found at its
+    true first-path position (+-1 sample) and its FIBs decode."""
+    import torch
+    import dabgpu
+    dev = torch.device("cuda", 0)
+    caps = [multipath_capture(81, None, 18.0, -2.3, 51000, ppm=120.0), multipath_capture(82, None, 18.0, 0.7, 20000, ppm=-120.0)]
+    e3 = synth.Ensemble(seed=83, n_frames=4)
+    rng = np.random.default_rng(83)
+    x3 = synth.channel(e3.iq().ravel(), snr_db=22.0, cfo=3.1 / 2048, rng=rng, paths=[(0, 1.0), (150, 0.7j)], fading_hz=8.0)[33333:]
+    caps.append((x3, np.array([k * FRAME + NULL - 33333.0 for k in range(1, 4)]), e3))
+    n = min(c[0].size for c in caps)
+    iq = np.stack([c[0][:n] for c in caps])
+    frames, counts = gctx.acquire(iq, 4)
+    d_x = torch.from_numpy(iq).to(dev)
+    d_fr = torch.from_numpy(frames.view(np.uint8).reshape(-1)).to(dev)
+    soft = torch.zeros((12, dabgpu.NB_FRAME_BITS), dtype=torch.int8, device=dev)
+    gctx.ofdm_demod_acquired_dev(d_x.data_ptr(), n, 3, 4, d_fr.data_ptr(), soft.data_ptr())
+    gctx.sync()
+    fib, ok = gctx.fic_decode(soft.cpu().numpy())
+    for s, (x, starts, e) in enumerate(caps):
+        starts = starts[starts + SYMS + 512 <= n]
+        assert counts[s] == len(starts) >= 2
+        for j in range(counts[s]):
+            assert frames[s, j]["flags"] == 3 and abs(int(frames[s, j]["start"]) + 64 - starts[j]) <= 1.5
+            assert ok[4 * s + j].all() and (fib[4 * s + j] == e.fibs[1 + j]).all()
+
+
 @pytest.mark.gpu
 def test_gpu_acquire_rejects_noise_and_bad_arguments(gctx):
     import dabgpu

@@ -60,6 +60,47 @@ def test_ofdm_soft_bits_within_one_lsb(ctx, ensemble, ensemble_iq, snr, cfo):
             assert ((soft[f] > 0).astype(np.uint8) == ensemble.frame_bits[f]).all()
 
 
+# Realistic channels: echoes inside the cyclic prefix (incl. a LATE one stronger than the first
+# path), a sample-clock offset, slow flat fading, a level step between frames.  Parity = soft bits within 1 LSB of the
+# oracle on the same samples; truth = the transmitted FIBs come back at an SNR where the CRC passes.
+CHANNELS = {
+    "three_taps": dict(snr_db=22.0, paths=[(0, 1.0), (37, 0.5 * np.exp(1.0j)), (180, 0.35 * np.exp(-2.0j))]),
+    "late_echo_2dB_stronger": dict(snr_db=24.0, paths=[(0, 1.0), (250, 1.26 * np.exp(0.4j))]),
+    "echo_at_the_prefix_edge": dict(snr_db=24.0, paths=[(0, 1.0), (430, 0.4 * np.exp(2.2j))]),
+    "fading_5Hz": dict(snr_db=22.0, fading_hz=5.0, rice_k=4.0),
+    "sco_50ppm": dict(snr_db=20.0, sco_ppm=50.0),
+    "sco_minus_80ppm_with_echo": dict(snr_db=24.0, sco_ppm=-80.0, paths=[(0, 1.0), (90, 0.6 * np.exp(-0.5j))]),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CHANNELS))
+def test_ofdm_parity_and_truth_through_realistic_channels(ctx, ensemble, ensemble_iq, name):
+    kw = dict(CHANNELS[name])
+    rng = np.random.default_rng(sum(map(ord, name)))
+    cfo = 0.23 / 2048
+    ppm = kw.get("sco_ppm", 0.0)
+    n_frames = 4
+    rx = synth.channel(ensemble_iq[:n_frames + 1].ravel(), cfo=cfo, rng=rng, **kw)
+    # frame f's first PRS sample in the received stream (the resampler stretches positions and delays by 12 samples);
+    # the FFT windows are kept 32 samples early, as every caller of the front end does (timing margin)
+    half = 12 if ppm else 0
+    starts = [int(round((f * synth.NB_FRAME_SAMPLES + synth.NB_NULL) * (1 + ppm * 1e-6))) - half - 32 for f in range(n_frames)]
+    frames = np.stack([rx[s:s + 76 * 2552] for s in starts])
+    if name == "fading_5Hz":
+        frames[2] *= 3.0                                  # and a 9.5 dB level step between frames
+    fo = np.full(n_frames, -cfo, np.float32)
+    soft, cyc, _ = ctx.ofdm_demod_frames(frames, fo, want_cyc=True)
+    for f in range(n_frames):
+        osoft, _, ocyc, _ = O.ofdm_demod_frame(frames[f], float(fo[f]), want_cyc=True)
+        assert np.abs(soft[f].astype(np.int32) - osoft.astype(np.int32)).max() <= SOFT_TOL
+        assert np.abs(cyc[f] - ocyc).max() <= 1e-3 * np.abs(ocyc).max()
+    fib, ok = ctx.fic_decode(soft)
+    assert ok.all() and (fib == ensemble.fibs[:n_frames]).all()
+    # the fine-frequency estimate from the cyclic-prefix correlations survives the channel
+    err = np.angle(cyc.astype(np.complex128)).mean() / (2 * np.pi * 2048)
+    assert abs(err) * 2048 < 0.03
+
+
 def test_ofdm_group_splits_agree(built, ensemble_iq):
     """A frame may be cut into 1..75 symbol runs (dabgpu_cfg.ofdm_symbol_runs); results must not depend on the cut."""
     frames = _rx(ensemble_iq, 12.0, 0.2 / 2048)[:2]
