@@ -155,32 +155,59 @@ def cpu_quota_cores():
         return None
 
 
-def cpu_baseline(iq_host, fo_host, sc_len_bits, mask, nsteps, budget_s, threads):
-    """Time the CPU oracle ('port', oracle/dab_oracle.c driven by oracle/oracle_bench.c) on the same workload, on a
-    bounded sample.  Rows (SURVEY.md 8d / BASELINE.md 4.3):
+def cpu_rows(O, iq_host, fo_host, sc_len_bits, mask, nsteps, budget_s, threads, simd):
+    """The rows SURVEY.md 8d / BASELINE.md 4.3 ask for, for one CPU implementation:
       single_core_value        one thread doing OFDM demod + FIC + 4 MSC logical frames per frame
       ofdm_only_1_thread       BASELINE config 1: the front end alone on one thread
       as_deployed_1_plus_1     one OFDM thread feeding one decoder thread through a 2-frame ring
                                (/root/reference/src/dab_module.cpp:92, src/radio_block.cpp:23-44)
       value                    every logical CPU the scheduler lists, one frame stream per thread; `effective_cores` =
                                value / single_core_value says how many cores' worth of time the box actually granted"""
-    from oracle import oracle as O
     n = iq_host.shape[0]
-    k1, t1 = O.bench_frames_timed(iq_host, fo_host, budget_s * 0.15, 1, mask, nsteps, sc_len_bits)
-    ko, to = O.bench_ofdm_only_timed(iq_host, fo_host, budget_s * 0.15)
-    kp, tp = O.bench_pipeline_timed(iq_host, fo_host, budget_s * 0.2, mask, nsteps, sc_len_bits)
-    total, tn = O.bench_frames_timed(iq_host, fo_host, budget_s * 0.5, threads, mask, nsteps, sc_len_bits)
-    fftw = fftw_fft_stage(iq_host)
+    k1, t1 = O.bench_frames_timed(iq_host, fo_host, budget_s * 0.15, 1, mask, nsteps, sc_len_bits, simd=simd)
+    ko, to = O.bench_ofdm_only_timed(iq_host, fo_host, budget_s * 0.15, simd=simd)
+    kp, tp = O.bench_pipeline_timed(iq_host, fo_host, budget_s * 0.2, mask, nsteps, sc_len_bits, simd=simd)
+    total, tn = O.bench_frames_timed(iq_host, fo_host, budget_s * 0.5, threads, mask, nsteps, sc_len_bits, simd=simd)
     single = k1 / t1
-    return {"fftw3f_fft_stage_frames_per_s_1_thread": fftw if fftw is not None else "FFTW3f: not available on this box",
-            "value": total / tn, "unit": "frames/s", "cores": threads, "kind": "port",
-            "effective_cores": (total / tn) / single, "cgroup_cpu_quota_cores": cpu_quota_cores(),
+    what = "oracle/simd_port.c" if simd else "oracle/dab_oracle.c"
+    return {"value": total / tn, "unit": "frames/s", "cores": threads,
+            "effective_cores": (total / tn) / single,
             "sample": "%d frames (OFDM+FIC+64kbps EEP-3A MSC, %d distinct bench-input frames cycled) through "
-                      "oracle/dab_oracle.c on %d pthreads in %.1f s" % (total, n, threads, tn),
+                      "%s on %d pthreads in %.1f s" % (total, n, what, threads, tn),
             "single_core_value": single,
             "ofdm_only_1_thread": {"value": ko / to, "unit": "frames/s", "sample": "%d frames in %.1f s (BASELINE config 1)" % (ko, to)},
             "as_deployed_1_plus_1": {"value": kp / tp, "unit": "frames/s", "threads": 2,
                                      "sample": "%d frames in %.1f s: one OFDM pthread -> 2-frame ring -> one decoder pthread" % (kp, tp)}}
+
+
+def cpu_baseline(iq_host, fo_host, sc_len_bits, mask, nsteps, budget_s, threads, truth_fibs=None):
+    """Two CPU implementations timed on the same bounded sample of the workload, on the host cores of the GPU box:
+      "port"       the oracle (oracle/dab_oracle.c): scalar, libm sin/cos per sample, radix-2 FFT, exact int32 Viterbi --
+                   the checker, timed as it is;
+      "simd_port"  oracle/simd_port.c, the path written as a CPU implementation of the reference's class is written
+                   (table-driven NCO, four-step FFT in AVX loops, 16-bit saturating AVX2 Viterbi; `-O3 -march=native
+                   -ffast-math`, the reference's flags, built on this box): what "the reference FFTW3f/AVX2 path" would
+                   be in the neighbourhood of.  FFTW3f itself is timed too when the box has it.
+    Stated baselines, never the target."""
+    from oracle import oracle as O
+    fftw = fftw_fft_stage(iq_host)
+    out = cpu_rows(O, iq_host, fo_host, sc_len_bits, mask, nsteps, budget_s * 0.5, threads, False)
+    out.update({"kind": "port", "cgroup_cpu_quota_cores": cpu_quota_cores(),
+                "fftw3f_fft_stage_frames_per_s_1_thread": fftw if fftw is not None else "FFTW3f: not available on this box"})
+    try:
+        simd = cpu_rows(O, iq_host, fo_host, sc_len_bits, mask, nsteps, budget_s * 0.5, threads, True)
+        simd["kind"] = "simd_port"
+        simd["isa"] = O.simd_isa()
+        if truth_fibs is not None:                       # it must decode the bench's own inputs to the transmitted FIBs
+            ok = True
+            for f in range(min(4, iq_host.shape[0])):
+                fib, crc = O.simd_fic_decode(O.simd_ofdm_demod_frame(iq_host[f], float(fo_host[f])))
+                ok &= bool(crc.all()) and bool((fib == truth_fibs[f]).all())
+            simd["decodes_bench_inputs_to_transmitted_fibs"] = ok
+        out["simd_port"] = simd
+    except Exception as e:                               # no compiler on the box: say so instead of dropping the row silently
+        out["simd_port"] = "not available: %s" % e
+    return out
 
 
 def free_port():
@@ -228,7 +255,7 @@ def main():
     ap.add_argument("--frames", type=int, default=256, help="consecutive frames per ensemble per step (multiple of 4)")
     ap.add_argument("--unique", type=int, default=8, help="distinct synthetic multiplexes generated on the host")
     ap.add_argument("--snr", type=float, default=20.0)
-    ap.add_argument("--cpu-seconds", type=float, default=16.0, help="CPU baseline budget (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=24.0, help="CPU baseline budget, both implementations together (0 = skip)")
     ap.add_argument("--no-fft-stage", action="store_true", help="skip the unfused FFT-stage measurement")
     ap.add_argument("--no-selective", action="store_true", help="skip the extra selective-soft-output measurement")
     ap.add_argument("--no-closed-loop", action="store_true", help="skip the unaligned-capture closed-loop measurement")
@@ -524,7 +551,8 @@ def main():
             iq_h = iq.reshape(n_frames, -1)[:k, synth.NB_NULL:].contiguous().cpu().numpy()
             fo_h = np.repeat(-cfo_true, F)[:k].astype(np.float32)            # the oracle is handed the channel's offsets
             out["cpu_baseline"] = cpu_baseline(iq_h, fo_h, sc.length * 64, ens[0].mask, 64 * 24 + 6, args.cpu_seconds,
-                                               len(os.sched_getaffinity(0)) or 1)
+                                               len(os.sched_getaffinity(0)) or 1,
+                                               truth_fibs=[ens[0].fibs[f % 4] for f in range(4)])
         print(json.dumps(out))
     d_bufs = (iq.data_ptr(), soft.data_ptr())
     del iq, soft

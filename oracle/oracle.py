@@ -226,6 +226,74 @@ def stream_update(state, cyc, iq_last_frame, beta, thr_null_start=0.35, signal_b
     return new
 
 
+# ---- the SIMD port (oracle/simd_port.c): cpu_baseline's second implementation, NOT the oracle ----------------------
+_SIMD = None
+
+
+def simd_lib():
+    """libsimdport built `-O3 -march=native -ffast-math` FOR THIS HOST: the object is keyed by the CPU's feature flags
+    (oracle/_native/libsimdport_<hash>.so), so one built on another machine is never loaded here."""
+    global _SIMD
+    if _SIMD is None:
+        import hashlib
+        try:
+            flags = [l for l in open("/proc/cpuinfo") if l.startswith("flags")][0]
+        except Exception:
+            flags = "unknown"
+        src = [os.path.join(_HERE, f) for f in ("simd_port.c", "oracle_bench.c", "dab_oracle.c", "dab_oracle.h")]
+        key = hashlib.sha1((flags + "".join(str(os.path.getmtime(f)) for f in src)).encode()).hexdigest()[:12]
+        out_dir = os.path.join(_HERE, "_native")
+        so = os.path.join(out_dir, "libsimdport_%s.so" % key)
+        if not os.path.exists(so):
+            try:
+                os.makedirs(out_dir, exist_ok=True)
+                tmp = so + ".%d.tmp" % os.getpid()
+                subprocess.check_call(["make", "-C", _HERE, "simd", "SIMD_OUT=" + tmp], stdout=subprocess.DEVNULL)
+                os.replace(tmp, so)
+            except Exception:                                   # read-only tree: build under the temporary directory
+                import tempfile
+                so = os.path.join(tempfile.gettempdir(), "libsimdport_%s_%d.so" % (key, os.getuid()))
+                if not os.path.exists(so):
+                    subprocess.check_call(["make", "-C", _HERE, "simd", "SIMD_OUT=" + so], stdout=subprocess.DEVNULL)
+        _SIMD = C.CDLL(so)
+        for n in ("bench_frames", "bench_frames_timed", "bench_ofdm_only_timed", "bench_pipeline_timed"):
+            getattr(_SIMD, "simd_" + n).restype = C.c_double
+        _SIMD.simd_port_isa.restype = C.c_char_p
+    return _SIMD
+
+
+def simd_isa():
+    return simd_lib().simd_port_isa().decode()
+
+
+def simd_ofdm_demod_frame(iq, freq_offset=0.0):
+    a = np.ascontiguousarray(iq, np.complex64)
+    assert a.size >= NB_SYMBOLS * NB_SYM
+    soft = np.zeros(NB_FRAME_BITS, np.int8)
+    simd_lib().simd_ofdm_demod_frame(_p(a), C.c_float(freq_offset), _p(soft))
+    return soft
+
+
+def simd_fic_decode(soft):
+    s = np.ascontiguousarray(soft[:NB_FIC_BITS], np.int8)
+    fib = np.zeros((12, 32), np.uint8)
+    ok = np.zeros(12, np.uint8)
+    simd_lib().simd_fic_decode(_p(s), _p(fib), _p(ok))
+    return fib, ok
+
+
+def simd_msc_decode_lf(deint, mask, nsteps):
+    d = np.ascontiguousarray(deint, np.int8)
+    m = np.ascontiguousarray(mask, np.uint8)
+    out = np.zeros((nsteps - 6) // 8, np.uint8)
+    simd_lib().simd_msc_decode_lf(_p(d), _p(m), C.c_int(nsteps), _p(out))
+    return out
+
+
+def _bench_fn(name, simd):
+    return getattr(simd_lib(), "simd_" + name) if simd else getattr(lib(), "oracle_" + name)
+
+
 def bench_frames(iq, freq_offset, total, threads, mask, nsteps, sc_bits):
     """Wall seconds for `total` frames of the whole per-frame hot path over `threads` pthreads.
     iq: complex64 [n_frames][76*2552]."""
@@ -236,35 +304,36 @@ def bench_frames(iq, freq_offset, total, threads, mask, nsteps, sc_bits):
                                            C.c_int(threads), _p(m), C.c_int(nsteps), C.c_int(sc_bits)))
 
 
-def bench_frames_timed(iq, freq_offset, seconds, threads, mask, nsteps, sc_bits):
-    """Run the per-frame hot path on `threads` pthreads for about `seconds`; returns (frames_done, elapsed_s)."""
+def bench_frames_timed(iq, freq_offset, seconds, threads, mask, nsteps, sc_bits, simd=False):
+    """Run the per-frame hot path on `threads` pthreads for about `seconds`; returns (frames_done, elapsed_s).
+    simd=True: the SIMD port instead of the oracle (the same harness, oracle_bench.c compiled with -DBENCH_SIMD)."""
     a = np.ascontiguousarray(iq, np.complex64)
     fo = np.ascontiguousarray(freq_offset, np.float32)
     m = np.ascontiguousarray(mask, np.uint8)
     done = C.c_long(0)
-    el = lib().oracle_bench_frames_timed(_p(a), C.c_size_t(a.shape[1]), _p(fo), C.c_int(a.shape[0]), C.c_double(seconds),
+    el = _bench_fn("bench_frames_timed", simd)(_p(a), C.c_size_t(a.shape[1]), _p(fo), C.c_int(a.shape[0]), C.c_double(seconds),
                                          C.c_int(threads), _p(m), C.c_int(nsteps), C.c_int(sc_bits), C.byref(done))
     return int(done.value), float(el)
 
 
-def bench_ofdm_only_timed(iq, freq_offset, seconds):
+def bench_ofdm_only_timed(iq, freq_offset, seconds, simd=False):
     """BASELINE config 1: the front end alone (A2..A6) on one thread for about `seconds`; (frames_done, elapsed_s)."""
     a = np.ascontiguousarray(iq, np.complex64)
     fo = np.ascontiguousarray(freq_offset, np.float32)
     done = C.c_long(0)
-    el = lib().oracle_bench_ofdm_only_timed(_p(a), C.c_size_t(a.shape[1]), _p(fo), C.c_int(a.shape[0]), C.c_double(seconds),
+    el = _bench_fn("bench_ofdm_only_timed", simd)(_p(a), C.c_size_t(a.shape[1]), _p(fo), C.c_int(a.shape[0]), C.c_double(seconds),
                                             C.byref(done))
     return int(done.value), float(el)
 
 
-def bench_pipeline_timed(iq, freq_offset, seconds, mask, nsteps, sc_bits):
+def bench_pipeline_timed(iq, freq_offset, seconds, mask, nsteps, sc_bits, simd=False):
     """The plugin's deployment shape: one OFDM thread feeding one decoder thread through a two-frame ring
     (/root/reference/src/dab_module.cpp:92, src/radio_block.cpp:23-44); (frames_decoded, elapsed_s)."""
     a = np.ascontiguousarray(iq, np.complex64)
     fo = np.ascontiguousarray(freq_offset, np.float32)
     m = np.ascontiguousarray(mask, np.uint8)
     done = C.c_long(0)
-    el = lib().oracle_bench_pipeline_timed(_p(a), C.c_size_t(a.shape[1]), _p(fo), C.c_int(a.shape[0]), C.c_double(seconds),
+    el = _bench_fn("bench_pipeline_timed", simd)(_p(a), C.c_size_t(a.shape[1]), _p(fo), C.c_int(a.shape[0]), C.c_double(seconds),
                                            _p(m), C.c_int(nsteps), C.c_int(sc_bits), C.byref(done))
     return int(done.value), float(el)
 

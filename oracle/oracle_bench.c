@@ -11,6 +11,23 @@
 
 #include "dab_oracle.h"
 
+/* The same harness times two implementations: the oracle (default) and, compiled a second time with -DBENCH_SIMD into
+   libsimdport.so, the SIMD port of simd_port.c (entry points simd_bench_*). */
+#ifdef BENCH_SIMD
+void simd_ofdm_demod_frame(const float *iq, float freq_offset, int8_t *soft);
+void simd_fic_decode(const int8_t *soft9216, uint8_t *fib384, uint8_t *crc_ok12);
+void simd_msc_decode_lf(const int8_t *deint, const uint8_t *mask, int nsteps, uint8_t *out_bytes);
+#define DEMOD(iq, fo, soft) simd_ofdm_demod_frame(iq, fo, soft)
+#define FIC(soft, fib, ok) simd_fic_decode(soft, fib, ok)
+#define MSC_LF(deint, mask, nsteps, out) simd_msc_decode_lf(deint, mask, nsteps, out)
+#define NAME(x) simd_##x
+#else
+#define DEMOD(iq, fo, soft) oracle_ofdm_demod_frame(iq, fo, soft, NULL, NULL, NULL)
+#define FIC(soft, fib, ok) oracle_fic_decode(soft, fib, ok)
+#define MSC_LF(deint, mask, nsteps, out) oracle_msc_decode_lf(deint, mask, nsteps, out)
+#define NAME(x) oracle_##x
+#endif
+
 typedef struct {
     const float *iq;
     size_t stride;          /* complex samples between frames */
@@ -38,15 +55,15 @@ static void *worker(void *arg)
             if ((double)now.tv_sec + 1e-9 * (double)now.tv_nsec >= j->deadline) break;
         }
         const int f = (j->first + k) % j->n_frames;
-        oracle_ofdm_demod_frame(j->iq + 2 * (size_t)f * j->stride, j->fo ? j->fo[f] : 0.0f, soft, NULL, NULL, NULL);
-        oracle_fic_decode(soft, fib, ok);
+        DEMOD(j->iq + 2 * (size_t)f * j->stride, j->fo ? j->fo[f] : 0.0f, soft);
+        FIC(soft, fib, ok);
         for (int c = 0; c < DAB_NB_CIFS; c++) {
             /* the frame's own 4 CIFs stand in for the 16-CIF window: same arithmetic, same memory traffic */
             const int8_t *cifs[16];
             for (int i = 0; i < 16; i++)
                 cifs[i] = soft + DAB_NB_FIC_BITS + (size_t)((c + i) & 3) * DAB_NB_CIF_BITS;
             oracle_time_deinterleave(cifs, j->sc_bits, deint);
-            oracle_msc_decode_lf(deint, j->mask, j->nsteps, out);
+            MSC_LF(deint, j->mask, j->nsteps, out);
             j->checksum += out[0];
         }
         j->checksum += fib[0] + ok[0];
@@ -57,7 +74,7 @@ static void *worker(void *arg)
 }
 
 /* returns elapsed seconds for `total` frames over `threads` threads */
-double oracle_bench_frames(const float *iq, size_t stride, const float *fo, int n_frames, int total, int threads,
+double NAME(bench_frames)(const float *iq, size_t stride, const float *fo, int n_frames, int total, int threads,
                            const uint8_t *mask, int nsteps, int sc_bits)
 {
     pthread_t *tid = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)threads);
@@ -79,7 +96,7 @@ double oracle_bench_frames(const float *iq, size_t stride, const float *fo, int 
 
 /* time-bounded variant: every thread processes frames until `seconds` have passed; returns elapsed seconds and
    stores the total number of frames completed in *frames_done */
-double oracle_bench_frames_timed(const float *iq, size_t stride, const float *fo, int n_frames, double seconds,
+double NAME(bench_frames_timed)(const float *iq, size_t stride, const float *fo, int n_frames, double seconds,
                                  int threads, const uint8_t *mask, int nsteps, int sc_bits, long *frames_done)
 {
     pthread_t *tid = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)threads);
@@ -106,7 +123,7 @@ double oracle_bench_frames_timed(const float *iq, size_t stride, const float *fo
  * ------------------------------------------------------------------------------------------------ */
 
 /* one thread, front end only; returns elapsed seconds, *frames_done frames */
-double oracle_bench_ofdm_only_timed(const float *iq, size_t stride, const float *fo, int n_frames, double seconds,
+double NAME(bench_ofdm_only_timed)(const float *iq, size_t stride, const float *fo, int n_frames, double seconds,
                                     long *frames_done)
 {
     int8_t *soft = (int8_t *)malloc(DAB_NB_FRAME_BITS);
@@ -119,7 +136,7 @@ double oracle_bench_ofdm_only_timed(const float *iq, size_t stride, const float 
         clock_gettime(CLOCK_MONOTONIC, &t1);
         if ((double)t1.tv_sec + 1e-9 * (double)t1.tv_nsec >= deadline) break;
         const int f = (int)(k % n_frames);
-        oracle_ofdm_demod_frame(iq + 2 * (size_t)f * stride, fo ? fo[f] : 0.0f, soft, NULL, NULL, NULL);
+        DEMOD(iq + 2 * (size_t)f * stride, fo ? fo[f] : 0.0f, soft);
         checksum += (unsigned)soft[17];
     }
     *frames_done = k + (checksum == 0xFFFFFFFFu ? 1 : 0) * 0;
@@ -154,7 +171,7 @@ static void *pipe_ofdm_thread(void *arg)
         clock_gettime(CLOCK_MONOTONIC, &now);
         if ((double)now.tv_sec + 1e-9 * (double)now.tv_nsec >= p->deadline) break;
         const int f = (int)(k % p->n_frames);
-        oracle_ofdm_demod_frame(p->iq + 2 * (size_t)f * p->stride, p->fo ? p->fo[f] : 0.0f, soft, NULL, NULL, NULL);
+        DEMOD(p->iq + 2 * (size_t)f * p->stride, p->fo ? p->fo[f] : 0.0f, soft);
         pthread_mutex_lock(&p->mu);
         while (p->count == 2) pthread_cond_wait(&p->not_full, &p->mu);     /* the writer blocks: back-pressure */
         memcpy(p->slot[p->head], soft, DAB_NB_FRAME_BITS);
@@ -187,13 +204,13 @@ static void *pipe_decoder_thread(void *arg)
         p->count--;
         pthread_cond_signal(&p->not_full);
         pthread_mutex_unlock(&p->mu);
-        oracle_fic_decode(soft, fib, ok);
+        FIC(soft, fib, ok);
         for (int c = 0; c < DAB_NB_CIFS; c++) {
             const int8_t *cifs[16];
             for (int i = 0; i < 16; i++)
                 cifs[i] = soft + DAB_NB_FIC_BITS + (size_t)((c + i) & 3) * DAB_NB_CIF_BITS;
             oracle_time_deinterleave(cifs, p->sc_bits, deint);
-            oracle_msc_decode_lf(deint, p->mask, p->nsteps, out);
+            MSC_LF(deint, p->mask, p->nsteps, out);
             p->checksum += out[0];
         }
         p->checksum += fib[0] + ok[0];
@@ -204,7 +221,7 @@ static void *pipe_decoder_thread(void *arg)
 }
 
 /* one OFDM thread -> 2-frame ring -> one decoder thread; returns elapsed seconds, *frames_done decoded frames */
-double oracle_bench_pipeline_timed(const float *iq, size_t stride, const float *fo, int n_frames, double seconds,
+double NAME(bench_pipeline_timed)(const float *iq, size_t stride, const float *fo, int n_frames, double seconds,
                                    const uint8_t *mask, int nsteps, int sc_bits, long *frames_done)
 {
     pipe_t p;
