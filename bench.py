@@ -42,27 +42,44 @@ ACS_FIC = 4 * 774 * 64                    # add-compare-selects per frame, FIC (
 ACS_MSC64 = 4 * 1542 * 64                 # one 64 kbit/s EEP 3-A subchannel (A12)
 
 
-def place_buffers(torch, dabgpu, ctx, dev, n_frames, n_candidates):
+def place_buffers(torch, dabgpu, ctx, dev, n_frames, mode, n_candidates):
     """Where the IQ and soft-bit buffers of this rank live.  MI355X's HBM behaves as three domains of 96 GB (large
     contiguous address ranges; profiles/r02_hbm_domains.txt maps them): a launch that reads from and writes to the SAME
     domain pays ~12 % for the read/write turn-arounds (5.7 instead of 5.0 ms for a data mover of this kernel's shape),
     while reading alone or writing alone runs at the same rate everywhere.  Which domain an allocation lands in is the
-    driver's choice, so -- as a long-running service would at start-up -- the library allocates a few candidates,
-    times the front-end launch on every (input, output) pair, keeps the fastest pair and frees the rest
-    (dabgpu_alloc_frame_buffers).  Untimed set-up, reported in `config`; `--placement-candidates 1` is a plain
-    allocation."""
+    driver's choice, so the library places the pair itself:
+      "placed"      (default) dabgpu_alloc_frame_buffers_placed: physical memory in 1 GiB chunks through the virtual
+                    memory API, each chunk's domain found with a small data mover (~30 ms), IQ mapped over one domain and
+                    the soft bits over another; never more than 1.2 x the final footprint held
+      "candidates"  round 2's dabgpu_alloc_frame_buffers: n candidates of each buffer (4 x 29.6 GB), the front end timed
+                    on every pair, the fastest kept
+      "plain"       two hipMallocs
+    Untimed set-up, reported in `config`."""
     L = dabgpu.NB_FRAME_SAMPLES
-    d_iq, d_soft, table, kept = ctx.alloc_frame_buffers(n_frames, L, n_candidates)
+    report = None
+    if mode == "placed":
+        d_iq, d_soft, rep = ctx.alloc_frame_buffers_placed(n_frames, L)
+        kept = (0, 0)
+        report = {"method": "domain-aware arena" if rep.method == 1 else "plain allocation (buffers too small for placement, or "
+                  "no virtual-memory API)", "chunks_taken": rep.n_chunks, "chunk_bytes": int(rep.chunk_bytes),
+                  "chunk_domains": rep.domains.decode(), "iq_chunk_domains": rep.iq_map.decode(),
+                  "soft_chunk_domains": rep.soft_map.decode(), "domains_seen": rep.n_domains,
+                  "soft_bits_written_beside_same_domain_reads_per_mille": rep.conflicts, "classify_ms": round(rep.classify_ms, 2),
+                  "setup_peak_bytes": int(rep.setup_peak_bytes),
+                  "setup_peak_over_final_footprint": round(rep.setup_peak_bytes / (n_frames * (L * 8 + dabgpu.NB_FRAME_BITS)), 3),
+                  "front_end_ms_on_placed_pair": round(rep.front_end_ms, 3)}
+    else:
+        d_iq, d_soft, table, kept = ctx.alloc_frame_buffers(n_frames, L, n_candidates if mode == "candidates" else 1)
+        if table is not None:
+            flat = [float(x) for r in table for x in r]
+            report = {"method": "timed candidates", "candidates": n_candidates,
+                      "probe_front_end_ms": [[round(float(x), 3) for x in r] for r in table], "kept": list(kept),
+                      "front_end_ms_plain_alloc": round(float(table[0][0]), 3),          # the pair a plain allocation would have got
+                      "front_end_ms_kept_pair": round(float(table[kept[0]][kept[1]]), 3),
+                      "probe_min_ms": round(min(flat), 3), "probe_max_ms": round(max(flat), 3)}
     iq = dabgpu.device_tensor(torch, d_iq, (n_frames, L), torch.complex64, dev)
     soft = dabgpu.device_tensor(torch, d_soft, (n_frames, dabgpu.NB_FRAME_BITS), torch.int8, dev)
-    report = None
-    if table is not None:
-        flat = [float(x) for r in table for x in r]
-        report = {"candidates": n_candidates, "probe_front_end_ms": [[round(float(x), 3) for x in r] for r in table], "kept": list(kept),
-                  "front_end_ms_plain_alloc": round(float(table[0][0]), 3),          # the pair a plain allocation would have got
-                  "front_end_ms_kept_pair": round(float(table[kept[0]][kept[1]]), 3),
-                  "probe_min_ms": round(min(flat), 3), "probe_max_ms": round(max(flat), 3)}
-    return iq, soft, report
+    return iq, soft, report, kept
 
 
 def make_streams(torch, dev, ids, n_frames, n_unique, snr_db, iq):
@@ -263,9 +280,11 @@ def main():
                     help="length of the extra `sustained` leg: the same step repeated for this long, so that the package's "
                          "power-limited steady state is in the record (0 = skip)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the sustained leg")
+    ap.add_argument("--placement", choices=["placed", "candidates", "plain"], default="placed",
+                    help="how the IQ / soft-bit buffers are placed in HBM (place_buffers)")
     ap.add_argument("--placement-candidates", type=int, default=4,
-                    help="IQ / soft-bit buffer candidates timed at set-up, the fastest pair is kept (1 = plain allocation); "
-                         "four pairs of the default shape span 118 GB, more than one 96 GB HBM domain")
+                    help="--placement candidates: buffers of each kind timed at set-up (four pairs of the default shape "
+                         "span 118 GB, more than one 96 GB HBM domain); 1 = --placement plain")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -328,7 +347,10 @@ def main():
         ctx.decode_frames_dev(soft_buf.data_ptr(), dabgpu.NB_FRAME_BITS, E, F, fib.data_ptr(), crc.data_ptr(), [sc],
                               [hist[k & 1].data_ptr()], [hist[(k & 1) ^ 1].data_ptr()], [msc.data_ptr()], stream)
 
-    iq, soft, placement = place_buffers(torch, dabgpu, ctx, dev, n_frames, max(1, min(8, args.placement_candidates)))
+    if args.placement == "candidates" and args.placement_candidates <= 1:
+        args.placement = "plain"
+    iq, soft, placement, kept_pair = place_buffers(torch, dabgpu, ctx, dev, n_frames, args.placement,
+                                                   max(1, min(8, args.placement_candidates)))
     cfo_true, ens = make_streams(torch, dev, ids, F, min(args.unique, E * world), args.snr, iq)
     iq = iq.view(E, F, synth.NB_FRAME_SAMPLES)
     for h in hist:
@@ -406,7 +428,6 @@ def main():
     dec_ms = float(np.mean([a.elapsed_time(b) for a, b in dec_ev]))
     ofdm_ms, ofdm_launches = ctx.mean_kernel_ms(0)                             # the fused kernel's launches alone
     ctx.set_timing(False)
-    kept_pair = placement["kept"] if placement is not None else [0, 0]
     # one row per rank, so that an imbalance between the GPUs of a node is visible in the line
     per_rank = gather_per_rank(dist, red_dev, [n_frames * args.steps / elapsed_rank, ofdm_ms, dec_ms, dev_index,
                                                kept_pair[0], kept_pair[1]])

@@ -147,6 +147,32 @@ int dabgpu_alloc_frame_buffers(dabgpu_ctx *ctx, int n_frames, size_t frame_strid
                                int8_t **d_soft, float *probe_ms, int *kept);
 int dabgpu_free_frame_buffers(dabgpu_ctx *ctx, void *d_iq, int8_t *d_soft);
 
+/* The same pair of buffers, placed DETERMINISTICALLY and within 1.2 x their size: physical memory is taken in chunks
+ * through the virtual-memory API (hipMemCreate; 1 GiB chunks for the samples, 256 MiB ones for the soft bits), every
+ * chunk's HBM domain is found with a small data mover (a launch that reads chunk a and writes chunk b is ~10 % slower
+ * when they share a domain: two passes, ~40 ms), the IQ buffer is mapped over chunks of the most plentiful domain(s)
+ * and every 256 MiB of the soft-bit buffer over a chunk whose domain differs from the ~1.7 GiB of samples that are
+ * read WHILE it is written (the front end walks both buffers in frame order); the chunks left over are released.  Falls back to a plain allocation (method 0) for small buffers or when
+ * the virtual-memory API is not available.  The report (may be NULL) says what was found and what one front-end
+ * launch on the placed pair takes.  Release with dabgpu_free_frame_buffers. */
+typedef struct dabgpu_placement_report {
+    int32_t method;             /* 0 = plain hipMalloc, 1 = domain-aware arena                                 */
+    int32_t n_chunks;           /* physical chunks taken during set-up                                         */
+    int32_t iq_chunks, soft_chunks;   /* chunks (of either size) each buffer is mapped over                    */
+    int32_t n_domains;          /* distinct HBM domains seen among the chunks (1..3)                           */
+    int32_t conflicts;          /* per mille of the soft bits that are written beside reads from their own domain */
+    uint64_t chunk_bytes;
+    uint64_t setup_peak_bytes;  /* device memory held at the peak of the set-up                                */
+    float classify_ms;          /* time spent finding the domains                                              */
+    float front_end_ms;         /* one timed front-end launch on the placed pair (noise input)                 */
+    char domains[72];           /* one letter per chunk in allocation order: 'A' 'B' 'C' for the 1 GiB chunks, */
+                                /* 'a' 'b' 'c' for the 256 MiB ones; NUL-terminated                            */
+    char iq_map[72];            /* the chunks of the IQ buffer in address order, same letters                  */
+    char soft_map[24];          /* the chunks of the soft-bit buffer in address order                          */
+} dabgpu_placement_report;
+int dabgpu_alloc_frame_buffers_placed(dabgpu_ctx *ctx, int n_frames, size_t frame_stride, void **d_iq, int8_t **d_soft,
+                                      dabgpu_placement_report *report);
+
 /* The same idea for any other buffer a launch WRITES while it reads `d_other` (e.g. the spectra of
  * dabgpu_fft_symbols_dev beside the IQ samples): up to three candidates of `bytes` are allocated some tens of GB
  * apart, a probe that reads d_other and writes the candidate is timed on each, the fastest is returned.  With

@@ -93,6 +93,13 @@ struct dabgpu_ctx {
     std::vector<SubHistory> sub_history;
     void *h_bounce = nullptr;            // page-locked landing area of that call's single download
     size_t h_bounce_bytes = 0;
+    // buffers handed out by dabgpu_alloc_frame_buffers_placed: virtual ranges mapped over physical chunks
+    struct Mapped {
+        void *va;
+        size_t bytes, chunk;             // reserved = mapped bytes; scratch while mapping
+        std::vector<hipMemGenericAllocationHandle_t> handles;
+    };
+    std::vector<Mapped> mapped;
 };
 
 namespace {
@@ -492,6 +499,8 @@ int dabgpu_create(const dabgpu_cfg *cfg, dabgpu_ctx **out) {
     return DABGPU_OK;
 }
 
+static bool release_mapped(dabgpu_ctx *ctx, void *p);
+
 void dabgpu_destroy(dabgpu_ctx *ctx) {
     if (!ctx) return;
     {
@@ -517,6 +526,7 @@ void dabgpu_destroy(dabgpu_ctx *ctx) {
             if (t.start[i]) (void)hipEventDestroy(t.start[i]);
             if (t.stop[i]) (void)hipEventDestroy(t.stop[i]);
         }
+    while (!ctx->mapped.empty()) (void)release_mapped(ctx, ctx->mapped.back().va);
     if (ctx->ev_states) (void)hipEventDestroy(ctx->ev_states);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     }
@@ -533,13 +543,323 @@ void dabgpu_host_free(void *p) {
     if (p) (void)hipHostFree(p);
 }
 
+// releases a range handed out by the placed allocator; false when `p` is not one of them
+static bool release_mapped(dabgpu_ctx *ctx, void *p) {
+    for (size_t i = 0; i < ctx->mapped.size(); i++) {
+        dabgpu_ctx::Mapped &m = ctx->mapped[i];
+        if (m.va != p) continue;
+        (void)hipMemUnmap(m.va, m.bytes);
+        for (auto h : m.handles) (void)hipMemRelease(h);
+        (void)hipMemAddressFree(m.va, m.bytes);
+        ctx->mapped.erase(ctx->mapped.begin() + long(i));
+        return true;
+    }
+    return false;
+}
+
 int dabgpu_free_frame_buffers(dabgpu_ctx *ctx, void *d_iq, int8_t *d_soft) {
     if (!ctx) return DABGPU_ERR_ARG;
     DeviceGuard guard(ctx);
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    if (d_iq) HIP_TRY(hipFree(d_iq));
-    if (d_soft) HIP_TRY(hipFree(d_soft));
+    HIP_TRY(hipDeviceSynchronize());
+    if (d_iq && !release_mapped(ctx, d_iq)) HIP_TRY(hipFree(d_iq));
+    if (d_soft && !release_mapped(ctx, d_soft)) HIP_TRY(hipFree(d_soft));
     return DABGPU_OK;
+}
+
+// ---- domain-aware placement (dabgpu_alloc_frame_buffers_placed) ----
+namespace {
+struct Chunks {
+    struct Item {
+        hipMemGenericAllocationHandle_t h;
+        size_t bytes, off;                                   // offset inside the probe mapping
+    };
+    std::vector<Item> items;
+    char *va = nullptr;                                      // probe mapping
+    size_t reserved = 0, mapped = 0;
+    ~Chunks() {
+        if (va) {
+            if (mapped) (void)hipMemUnmap(va, mapped);
+            (void)hipMemAddressFree(va, reserved);
+        }
+        for (auto &x : items) if (x.h) (void)hipMemRelease(x.h);
+        (void)hipGetLastError();
+    }
+    char *at(int i) const { return va + items[size_t(i)].off; }
+};
+
+// time of a mover launch that reads chunk a and writes (a sixth of its size of) chunk b: min of two after a warm-up
+float pair_ms(const Chunks &c, int a, int b, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+    const size_t in_b = c.items[size_t(a)].bytes, out_b = std::min(c.items[size_t(b)].bytes, in_b / 6);
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; rep++) {
+        if (hipEventRecord(e0, s) != hipSuccess || dabk::launch_placement_probe(c.at(a), in_b, c.at(b), out_b, s) != hipSuccess ||
+            hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess)
+            return -1.f;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return -1.f;
+        if (rep > 0) best = std::min(best, ms);
+    }
+    return best;
+}
+
+// Chunks whose pairing with `ref` is slow share its domain.  The times of `idx` fall into two groups ~10 % apart; with
+// no gap, the pairing of ref with itself (the same-domain time by construction) says which group everything is in.
+bool same_domain_as(const Chunks &c, int ref, const std::vector<int> &idx, hipStream_t s, hipEvent_t e0, hipEvent_t e1,
+                    std::vector<int> &same, std::vector<int> &other) {
+    if (idx.empty()) return true;
+    std::vector<float> t(idx.size());
+    float lo = 1e30f, hi = 0.f;
+    for (size_t k = 0; k < idx.size(); k++) {
+        if ((t[k] = pair_ms(c, ref, idx[k], s, e0, e1)) < 0.f) return false;
+        lo = std::min(lo, t[k]);
+        hi = std::max(hi, t[k]);
+    }
+    if (hi > 1.04f * lo) {
+        const float thr = 0.5f * (lo + hi);
+        for (size_t k = 0; k < idx.size(); k++) (t[k] > thr ? same : other).push_back(idx[k]);
+        return true;
+    }
+    const float self = pair_ms(c, ref, ref, s, e0, e1);
+    if (self < 0.f) return false;
+    (lo > 0.97f * self ? same : other) = idx;
+    return true;
+}
+}  // namespace
+
+int dabgpu_alloc_frame_buffers_placed(dabgpu_ctx *ctx, int n_frames, size_t frame_stride, void **d_iq, int8_t **d_soft,
+                                      dabgpu_placement_report *report) {
+    if (!ctx || !d_iq || !d_soft || n_frames <= 0) return DABGPU_ERR_ARG;
+    if (frame_stride < size_t(NB_FRAME_SAMPLES) || (frame_stride & 1u)) return DABGPU_ERR_ARG;
+    if (size_t(n_frames) > size_t(0x7fffffff) / NB_DATA_SYMBOLS) return DABGPU_ERR_ARG;
+    DeviceGuard guard(ctx);
+    *d_iq = nullptr;
+    *d_soft = nullptr;
+    dabgpu_placement_report rep;
+    std::memset(&rep, 0, sizeof(rep));
+    const size_t iq_bytes = size_t(n_frames) * frame_stride * sizeof(float2);
+    const size_t soft_bytes = size_t(n_frames) * NB_FRAME_BITS;
+    // IQ in 1 GiB chunks; the soft bits in 256 MiB chunks: each is written beside only ~1.7 GiB of samples, so where
+    // the IQ buffer has to change domain only one or two of them cannot avoid both of its neighbours' domains
+    const size_t CH = size_t(1) << 30, CS = size_t(256) << 20;
+    auto plain = [&]() -> int {
+        if (hipMalloc(d_iq, iq_bytes) != hipSuccess) return DABGPU_ERR_NOMEM;
+        if (hipMalloc(reinterpret_cast<void **>(d_soft), soft_bytes) != hipSuccess) {
+            (void)hipFree(*d_iq);
+            *d_iq = nullptr;
+            return DABGPU_ERR_NOMEM;
+        }
+        rep.method = 0;
+        rep.setup_peak_bytes = iq_bytes + soft_bytes;
+        if (report) *report = rep;
+        return DABGPU_OK;
+    };
+    const int n_iq = int((iq_bytes + CH - 1) / CH), n_soft = int((soft_bytes + CS - 1) / CS);
+    // (nothing is gained below a few GB, and rounding to whole chunks would cost too much)
+    if (iq_bytes < 4 * CH || n_iq > 60 || n_soft > 20) return plain();
+    // what may be held during set-up: 1.2 x the buffers; a third of the spare as whole IQ-size chunks, the rest small
+    const size_t budget = size_t(1.2 * double(iq_bytes + soft_bytes));
+    const size_t need = size_t(n_iq) * CH + size_t(n_soft) * CS;
+    const size_t spare = budget > need ? budget - need : 0;
+    int n_big = n_iq + int(spare / 3 / CH);
+    int n_small = n_soft + int((spare - size_t(n_big - n_iq) * CH) / CS);
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    while (n_big > n_iq && size_t(n_big) * CH + size_t(n_small) * CS > free_b - free_b / 16) n_big--;
+    while (n_small > n_soft && size_t(n_big) * CH + size_t(n_small) * CS > free_b - free_b / 16) n_small--;
+    if (size_t(n_big) * CH + size_t(n_small) * CS > free_b - free_b / 16) return plain();
+    const int n_total = n_big + n_small;
+    if (n_total > 70) return plain();
+    hipStream_t s = ctx->stream;
+    HIP_TRY(hipStreamSynchronize(s));
+
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = ctx->device;
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    Chunks c;
+    c.reserved = size_t(n_big) * CH + size_t(n_small) * CS;
+    void *va = nullptr;
+    if (hipMemAddressReserve(&va, c.reserved, 0, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); return plain(); }
+    c.va = static_cast<char *>(va);
+    bool ok = true;
+    for (int i = 0; i < n_total && ok; i++) {
+        const size_t bytes = i < n_big ? CH : CS;
+        hipMemGenericAllocationHandle_t h;
+        if (hipMemCreate(&h, bytes, &prop, 0) != hipSuccess) { ok = false; break; }
+        if (hipMemMap(c.va + c.mapped, bytes, 0, h, 0) != hipSuccess) { (void)hipMemRelease(h); ok = false; break; }
+        c.items.push_back(Chunks::Item{h, bytes, c.mapped});
+        c.mapped += bytes;
+    }
+    if (!ok || hipMemSetAccess(c.va, c.mapped, &acc, 1) != hipSuccess) { (void)hipGetLastError(); return plain(); }
+    rep.n_chunks = n_total;
+    rep.chunk_bytes = CH;
+    rep.setup_peak_bytes = c.mapped;
+
+    // ---- which domain is every chunk in? ----
+    hipEvent_t e0 = nullptr, e1 = nullptr, ec0 = nullptr, ec1 = nullptr;
+    int rc = DABGPU_OK;
+    std::vector<int> dom(size_t(n_total), 0);
+    int n_dom = 1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventCreate(&ec0) != hipSuccess ||
+        hipEventCreate(&ec1) != hipSuccess || dabk::launch_fill_noise(c.va, c.mapped, s) != hipSuccess)
+        rc = DABGPU_ERR_HIP;
+    if (!rc) {
+        (void)hipEventRecord(ec0, s);
+        std::vector<int> rest, a_set, others;
+        for (int i = 1; i < n_total; i++) rest.push_back(i);
+        if (!same_domain_as(c, 0, rest, s, e0, e1, a_set, others)) rc = DABGPU_ERR_HIP;
+        if (!rc && !others.empty()) {
+            n_dom = 2;
+            const int r2 = others[0];                          // (the first of them is an IQ-size chunk whenever one is)
+            std::vector<int> rest2(others.begin() + 1, others.end()), b_set, c_set;
+            if (!same_domain_as(c, r2, rest2, s, e0, e1, b_set, c_set)) rc = DABGPU_ERR_HIP;
+            b_set.push_back(r2);
+            for (int i : b_set) dom[size_t(i)] = 1;
+            for (int i : c_set) dom[size_t(i)] = 2;
+            if (!c_set.empty()) n_dom = 3;
+        }
+        (void)hipEventRecord(ec1, s);
+        (void)hipEventSynchronize(ec1);
+        (void)hipEventElapsedTime(&rep.classify_ms, ec0, ec1);
+    }
+    rep.n_domains = n_dom;
+    for (int i = 0; i < n_total && i < 71; i++) rep.domains[i] = char((i < n_big ? 'A' : 'a') + dom[size_t(i)]);   // small chunks in lower case
+
+    // ---- IQ: the domain with the most bytes first (1 GiB chunks, then 256 MiB ones); the soft bits, piece by piece:
+    //      a chunk whose domain the samples read beside that piece are not in ----
+    std::vector<int> iq_sel, soft_sel;
+    std::vector<char> used(size_t(n_total), 0);
+    size_t iq_mapped = 0, soft_mapped = 0;
+    if (!rc) {
+        size_t bytes_in[3] = {0, 0, 0};
+        for (int i = 0; i < n_total; i++) bytes_in[dom[size_t(i)]] += c.items[size_t(i)].bytes;
+        int order[3] = {0, 1, 2};
+        std::sort(order, order + 3, [&](int x, int y) { return bytes_in[x] != bytes_in[y] ? bytes_in[x] > bytes_in[y] : x < y; });
+        // leave the other domains what the soft bits need of them whenever the first domain can carry the samples alone
+        for (int k = 0; k < 3 && iq_mapped < iq_bytes; k++)
+            for (int pass = 0; pass < 2 && iq_mapped < iq_bytes; pass++)          // pass 0: 1 GiB chunks, pass 1: 256 MiB ones
+                for (int i = (pass ? n_big : 0); i < (pass ? n_total : n_big) && iq_mapped < iq_bytes; i++) {
+                    if (used[size_t(i)] || dom[size_t(i)] != order[k]) continue;
+                    if (pass == 0 && iq_bytes - iq_mapped < CH && bytes_in[order[k]] > 0) {
+                        // less than a whole big chunk is missing: small chunks of this domain first, if there are enough
+                        size_t small_left = 0;
+                        for (int j = n_big; j < n_total; j++) if (!used[size_t(j)] && dom[size_t(j)] == order[k]) small_left += CS;
+                        if (small_left >= iq_bytes - iq_mapped) break;
+                    }
+                    iq_sel.push_back(i);
+                    used[size_t(i)] = 1;
+                    iq_mapped += c.items[size_t(i)].bytes;
+                }
+        // domain of the samples at byte offset x of the IQ buffer
+        std::vector<size_t> iq_end;
+        { size_t e = 0; for (int i : iq_sel) { e += c.items[size_t(i)].bytes; iq_end.push_back(e); } }
+        auto iq_bytes_by_domain = [&](double lo, double hi, double w[3]) {
+            w[0] = w[1] = w[2] = 0.0;
+            size_t begin = 0;
+            for (size_t k = 0; k < iq_sel.size(); k++) {
+                const double a0 = std::max(lo, double(begin)), a1 = std::min(hi, double(iq_end[k]));
+                if (a1 > a0) w[dom[size_t(iq_sel[k])]] += a1 - a0;
+                begin = iq_end[k];
+            }
+        };
+        const double iq_per_soft = double(frame_stride * sizeof(float2)) / double(NB_FRAME_BITS);
+        const double slack = 1.5 * double(CH);                // samples of the ~1000 frames in flight
+        double shared = 0.0;
+        while (soft_mapped < soft_bytes) {
+            int best = -1;
+            double best_cost = 0.0;
+            for (int i = 0; i < n_total; i++) {
+                if (used[size_t(i)]) continue;
+                const size_t sz = c.items[size_t(i)].bytes;
+                double w[3];
+                iq_bytes_by_domain(double(soft_mapped) * iq_per_soft - slack, double(std::min(soft_bytes, soft_mapped + sz)) * iq_per_soft + slack, w);
+                const double tot = w[0] + w[1] + w[2];
+                const double cost = tot > 0.0 ? w[dom[size_t(i)]] / tot : 0.0;
+                // the least overlap wins; between equals a small chunk (a big one is kept for where it is needed)
+                if (best < 0 || cost < best_cost - 1e-9 || (cost < best_cost + 1e-9 && sz < c.items[size_t(best)].bytes)) { best = i; best_cost = cost; }
+            }
+            if (best < 0) { rc = DABGPU_ERR_NOMEM; break; }
+            soft_sel.push_back(best);
+            used[size_t(best)] = 1;
+            const size_t sz = std::min(c.items[size_t(best)].bytes, soft_bytes - soft_mapped);
+            shared += best_cost * double(sz);
+            soft_mapped += c.items[size_t(best)].bytes;
+        }
+        rep.conflicts = int(1000.0 * shared / double(soft_bytes) + 0.5);   // per mille of the soft bits written beside same-domain reads
+        rep.iq_chunks = int(iq_sel.size());
+        rep.soft_chunks = int(soft_sel.size());
+        for (size_t k = 0; k < iq_sel.size() && k < 71; k++) rep.iq_map[k] = char((iq_sel[k] < n_big ? 'A' : 'a') + dom[size_t(iq_sel[k])]);
+        for (size_t k = 0; k < soft_sel.size() && k < 23; k++) rep.soft_map[k] = char((soft_sel[k] < n_big ? 'A' : 'a') + dom[size_t(soft_sel[k])]);
+    }
+    // ---- final mappings; the chunks nobody took go back ----
+    dabgpu_ctx::Mapped m_iq{nullptr, iq_mapped, 0, {}}, m_soft{nullptr, soft_mapped, 0, {}};
+    if (!rc) {
+        (void)hipStreamSynchronize(s);
+        if (hipMemUnmap(c.va, c.mapped) != hipSuccess) rc = DABGPU_ERR_HIP;
+        c.mapped = 0;
+    }
+    auto map_over = [&](dabgpu_ctx::Mapped &m, const std::vector<int> &sel) -> int {
+        if (hipMemAddressReserve(&m.va, m.bytes, 0, nullptr, 0) != hipSuccess) return DABGPU_ERR_NOMEM;
+        size_t off = 0;
+        for (size_t k = 0; k < sel.size(); k++) {
+            Chunks::Item &it = c.items[size_t(sel[k])];
+            if (hipMemMap(static_cast<char *>(m.va) + off, it.bytes, 0, it.h, 0) != hipSuccess) return DABGPU_ERR_HIP;
+            m.handles.push_back(it.h);
+            it.h = nullptr;                                    // owned by the mapping from here on
+            off += it.bytes;
+            m.chunk = off;                                     // bytes mapped so far
+        }
+        return hipMemSetAccess(m.va, m.bytes, &acc, 1) == hipSuccess ? DABGPU_OK : DABGPU_ERR_HIP;
+    };
+    if (!rc) rc = map_over(m_iq, iq_sel);
+    if (!rc) rc = map_over(m_soft, soft_sel);
+    if (rc) {
+        for (dabgpu_ctx::Mapped *m : {&m_iq, &m_soft}) {
+            if (!m->va) continue;
+            if (m->chunk) (void)hipMemUnmap(m->va, m->chunk);
+            for (auto h : m->handles) (void)hipMemRelease(h);
+            (void)hipMemAddressFree(m->va, m->bytes);
+        }
+        (void)hipGetLastError();
+    } else {
+        ctx->mapped.push_back(m_iq);
+        ctx->mapped.push_back(m_soft);
+        *d_iq = m_iq.va;
+        *d_soft = static_cast<int8_t *>(m_soft.va);
+        rep.method = 1;
+        // one timed front-end launch on the pair (the IQ buffer still holds the classification's noise)
+        void *d_fo = nullptr, *d_cyc = nullptr;
+        const size_t fo_bytes = sizeof(float) * size_t(n_frames), cyc_bytes = size_t(n_frames) * NB_FRAME_SYMBOLS * sizeof(float2);
+        if (hipMalloc(&d_fo, fo_bytes) == hipSuccess && hipMalloc(&d_cyc, cyc_bytes) == hipSuccess &&
+            hipMemsetAsync(d_fo, 0, fo_bytes, s) == hipSuccess) {
+            const bool was_timing = ctx->timing;
+            ctx->timing = false;
+            const unsigned long long *keep = ctx->d_keep;
+            ctx->d_keep = nullptr;
+            int prc = DABGPU_OK;
+            for (int r = 0; r < 3 && !prc; r++) {
+                if (r == 1) (void)hipEventRecord(e0, s);
+                prc = dabgpu_ofdm_demod_frames_dev(ctx, static_cast<char *>(*d_iq) + size_t(NB_NULL_PERIOD) * sizeof(float2), frame_stride,
+                                                   n_frames, static_cast<const float *>(d_fo), *d_soft, d_cyc, nullptr, s);
+            }
+            float ms = 0.f;
+            if (!prc && hipEventRecord(e1, s) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
+                hipEventElapsedTime(&ms, e0, e1) == hipSuccess)
+                rep.front_end_ms = 0.5f * ms;
+            ctx->timing = was_timing;
+            ctx->d_keep = keep;
+        }
+        (void)hipStreamSynchronize(s);
+        if (d_fo) (void)hipFree(d_fo);
+        if (d_cyc) (void)hipFree(d_cyc);
+        (void)hipGetLastError();
+    }
+    for (hipEvent_t e : {e0, e1, ec0, ec1}) if (e) (void)hipEventDestroy(e);
+    if (report) *report = rep;
+    return rc;                                               // (~Chunks releases the chunks nobody took)
 }
 
 int dabgpu_alloc_frame_buffers(dabgpu_ctx *ctx, int n_frames, size_t frame_stride, int candidates, void **d_iq,

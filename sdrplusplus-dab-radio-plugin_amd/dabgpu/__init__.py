@@ -41,7 +41,7 @@ EXPORTS = [
     "dabgpu_decode_stream_reset", "dabgpu_alloc_frame_buffers", "dabgpu_free_frame_buffers",
     "dabgpu_device_alloc_apart", "dabgpu_device_free",
     "dabgpu_set_stream_loop", "dabgpu_track_default_cfg", "dabgpu_track_start_dev", "dabgpu_ofdm_demod_tracked_dev",
-    "dabgpu_ofdm_demod_stream_frame",
+    "dabgpu_ofdm_demod_stream_frame", "dabgpu_alloc_frame_buffers_placed",
 ]
 
 ABI_VERSION = 4
@@ -107,6 +107,13 @@ class TrackCfg(C.Structure):
                 ("min_peak_to_mean", C.c_float), ("impulse_peak_distance_probability", C.c_float),
                 ("first_path_rel", C.c_float), ("drift_beta", C.c_float), ("coarse_freq_slow_beta", C.c_float),
                 ("timing_margin", C.c_int32), ("max_coarse_carriers", C.c_int32), ("reserved", C.c_int32 * 2)]
+
+
+class PlacementReport(C.Structure):
+    _fields_ = [("method", C.c_int32), ("n_chunks", C.c_int32), ("iq_chunks", C.c_int32), ("soft_chunks", C.c_int32),
+                ("n_domains", C.c_int32), ("conflicts", C.c_int32), ("chunk_bytes", C.c_uint64), ("setup_peak_bytes", C.c_uint64),
+                ("classify_ms", C.c_float), ("front_end_ms", C.c_float), ("domains", C.c_char * 72), ("iq_map", C.c_char * 72),
+                ("soft_map", C.c_char * 24)]
 
 
 class FrameResult(C.Structure):
@@ -218,6 +225,7 @@ def load_library(path):
     L.dabgpu_mean_kernel_ms.argtypes = [vp, i, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     L.dabgpu_alloc_frame_buffers.argtypes = [vp, i, sz, i, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_float), C.POINTER(i)]
     L.dabgpu_free_frame_buffers.argtypes = [vp, vp, vp]
+    L.dabgpu_alloc_frame_buffers_placed.argtypes = [vp, i, sz, C.POINTER(vp), C.POINTER(vp), C.POINTER(PlacementReport)]
     L.dabgpu_device_alloc_apart.argtypes = [vp, sz, vp, sz, C.POINTER(vp), C.POINTER(C.c_float)]
     L.dabgpu_device_free.argtypes = [vp, vp]
     L.dabgpu_set_stream_loop.argtypes = [vp, C.c_float, C.c_float]
@@ -400,6 +408,15 @@ class Context:
                                                     table, kept), "dabgpu_alloc_frame_buffers")
         t = np.array(table, dtype=np.float32).reshape(candidates, candidates)
         return d_iq.value, d_soft.value, (t if candidates > 1 else None), (int(kept[0]), int(kept[1]))
+
+    def alloc_frame_buffers_placed(self, n_frames, frame_stride=NB_FRAME_SAMPLES):
+        """The same pair of buffers placed by HBM domain inside 1.2 x their size (dabgpu_alloc_frame_buffers_placed).
+        -> (d_iq, d_soft, PlacementReport); release with free_frame_buffers."""
+        d_iq, d_soft = C.c_void_p(), C.c_void_p()
+        rep = PlacementReport()
+        _check(self._lib.dabgpu_alloc_frame_buffers_placed(self._h, n_frames, frame_stride, C.byref(d_iq), C.byref(d_soft),
+                                                       C.byref(rep)), "dabgpu_alloc_frame_buffers_placed")
+        return d_iq.value, d_soft.value, rep
 
     def device_alloc_apart(self, nbytes, d_other=None, other_bytes=0):
         """A device buffer that a launch can write while it reads `d_other` without the two sharing an HBM domain

@@ -168,7 +168,7 @@ def test_bench_rccl_branch_executes_with_one_rank():
     """The `nccl` (= RCCL) branch of bench.py -- process group on the GPU, barrier, the three all-reduces of the report
     on device tensors -- launched through torch.distributed.run with a single rank, which is all a one-GPU box can give
     RCCL (two ranks on one device are refused); the multi-rank logic is covered by the gloo runs above."""
-    r = _run_bench(1, {"DABGPU_DIST_FORCE": "1", "DABGPU_DIST_BACKEND": "nccl"}, more=["--placement-candidates", "1"])
+    r = _run_bench(1, {"DABGPU_DIST_FORCE": "1", "DABGPU_DIST_BACKEND": "nccl"}, more=["--placement", "plain"])
     assert r["n_gpus"] == 1 and r["fic_bit_exact"] is True and r["msc_bit_exact"] is True
     assert r["config"]["buffer_placement"] == "first allocation taken"
     assert abs(r["value"] * r["ms_per_step"] * 1e-3 - 64) < 1e-3

@@ -223,6 +223,57 @@ def test_alloc_frame_buffers_returns_a_usable_pair(built, ensemble, ensemble_iq)
     c.close()
 
 
+def test_alloc_frame_buffers_placed(built, ensemble_iq):
+    """dabgpu_alloc_frame_buffers_placed: a small request is a plain allocation; a 5 GiB one goes through the
+    virtual-memory arena (1 GiB / 256 MiB chunks, domain classification, mapped ranges): the set-up holds at most 1.2 x
+    the footprint, the buffers behave like any device memory (torch tensors over them, the
+    front end run on them gives the host-pointer call's soft bits), and releasing them gives the memory back."""
+    import torch
+    L = dabgpu.NB_FRAME_SAMPLES
+    dev = torch.device("cuda", 0)
+    c = make_ctx(None, 8)
+    d_iq, d_soft, rep = c.alloc_frame_buffers_placed(8, L)
+    assert rep.method == 0 and d_iq and d_soft
+    c.free_frame_buffers(d_iq, d_soft)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    n = 3000                                                   # 4.4 GiB of samples, 0.64 GiB of soft bits
+    d_iq, d_soft, rep = c.alloc_frame_buffers_placed(n, L)
+    assert rep.method == 1, rep.method
+    final = n * (L * 8 + dabgpu.NB_FRAME_BITS)
+    assert 5 <= rep.iq_chunks <= 8 and 1 <= rep.soft_chunks <= 3 and rep.n_chunks >= 8 and rep.chunk_bytes == 1 << 30
+    assert rep.setup_peak_bytes <= 1.2 * final                        # never more than 1.2 x the buffers during set-up
+    doms = rep.domains.decode()
+    assert len(doms) == rep.n_chunks and set(doms.upper()) <= set("ABC") and 1 <= rep.n_domains <= 3
+    assert doms[:5].isupper() and doms[5:].islower()                  # IQ-size chunks first, then the 256 MiB ones
+    assert len(rep.iq_map.decode()) == rep.iq_chunks and len(rep.soft_map.decode()) == rep.soft_chunks
+    assert rep.front_end_ms > 0 and rep.classify_ms > 0 and 0 <= rep.conflicts <= 1000
+    if rep.conflicts == 0 and rep.n_domains > 1:
+        assert not set(rep.soft_map.decode().upper()) & set(rep.iq_map.decode().upper()[:2])
+    held = free0 - torch.cuda.mem_get_info()[0]
+    assert held <= rep.setup_peak_bytes + (64 << 20) and held >= final, held     # the chunks nobody took were released
+    rx = synth.channel(ensemble_iq.ravel(), snr_db=18.0, cfo=0.0, rng=np.random.default_rng(6)).reshape(ensemble_iq.shape)
+    k = rx.shape[0]
+    ref, _, _ = c.ofdm_demod_frames(np.ascontiguousarray(rx[:, synth.NB_NULL:]))
+    iq = dabgpu.device_tensor(torch, d_iq, (n, L), torch.complex64, dev)
+    soft = dabgpu.device_tensor(torch, d_soft, (n, dabgpu.NB_FRAME_BITS), torch.int8, dev)
+    # frames straddling the 1 GiB chunk boundaries: frame 682 starts below 1 GiB and ends above it
+    for base in (0, 680, n - k):
+        iq[base:base + k].copy_(torch.from_numpy(rx.astype(np.complex64)).to(dev))
+    torch.cuda.synchronize()
+    c.ofdm_demod_frames_dev(d_iq + synth.NB_NULL * 8, L, n, None, d_soft)
+    c.sync()
+    for base in (0, 680, n - k):
+        assert (soft[base:base + k].cpu().numpy() == ref).all(), base
+    del iq, soft
+    c.free_frame_buffers(d_iq, d_soft)
+    torch.cuda.synchronize()
+    assert free0 - torch.cuda.mem_get_info()[0] <= 64 << 20
+    with pytest.raises(dabgpu.DabGpuError):
+        c.alloc_frame_buffers_placed(0, L)
+    c.close()
+
+
 def test_device_alloc_apart(built):
     """dabgpu_device_alloc_apart: small requests are plain allocations; a large one next to a large reference is
     probed (three candidates at most) and usable; bad arguments are refused."""
