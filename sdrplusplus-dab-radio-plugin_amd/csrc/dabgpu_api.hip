@@ -213,20 +213,33 @@ struct ScopedTimer {
     }
 };
 
-// How many contiguous symbol runs to cut each frame into.  One run = one wavefront (8 resident per CU).
-// Cost model: rounds of resident waves x symbols per run (+1 for the re-read reference symbol); pick the
-// cheapest, preferring fewer cuts.
-int pick_parts(const dabgpu_ctx *ctx, int n_frames, int total_syms) {
-    if (ctx->ofdm_parts_override > 0 && ctx->ofdm_parts_override <= total_syms) return ctx->ofdm_parts_override;
+// How a launch's frames are cut into runs of consecutive symbols (one run = one wavefront; 12 resident per CU).  A cut
+// costs one more transform and one more symbol read (the run's differential reference), so cuts are made only where they
+// buy balance: as many whole frames as fill the resident wave slots an integer number of times go first, uncut; the
+// frames behind them -- which alone would leave most slots idle for the length of a frame -- are cut into `parts`.
+// Cost model, in symbol transforms per wave slot: rounds x (symbols per item + 1).
+struct RunPlan {
+    int uncut_frames, parts;
+};
+RunPlan plan_runs(const dabgpu_ctx *ctx, int n_frames, int total_syms) {
+    if (ctx->ofdm_parts_override > 0 && ctx->ofdm_parts_override <= total_syms) return RunPlan{0, ctx->ofdm_parts_override};
     const long slots = long(ctx->wave_slots);
-    long best_cost = -1;
-    int best = 1;
-    for (int p = 1; p <= total_syms; p++) {
-        const long rounds = (long(n_frames) * p + slots - 1) / slots;
-        const long cost = rounds * ((total_syms + p - 1) / p + 1);
-        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = p; }
-    }
-    return best;
+    auto uniform = [&](long frames, int *best_p) {
+        long best_cost = -1;
+        *best_p = 1;
+        for (int p = 1; p <= total_syms && frames > 0; p++) {
+            const long rounds = (frames * p + slots - 1) / slots;
+            const long cost = rounds * ((total_syms + p - 1) / p + 1);
+            if (best_cost < 0 || cost < best_cost) { best_cost = cost; *best_p = p; }
+        }
+        return best_cost < 0 ? 0 : best_cost;
+    };
+    int p_all = 1, p_tail = 1;
+    const long cost_all = uniform(n_frames, &p_all);
+    const long whole = long(n_frames) / slots * slots;
+    const long cost_mixed = whole / slots * (total_syms + 1) + uniform(long(n_frames) - whole, &p_tail);
+    if (whole > 0 && cost_mixed < cost_all) return RunPlan{int(whole), p_tail};
+    return RunPlan{0, p_all};
 }
 
 // Placement of large device buffers.  Candidates are allocated some tens of GB apart (spacer allocations in between,
@@ -1031,7 +1044,9 @@ int dabgpu_ofdm_demod_frames_dev(dabgpu_ctx *ctx, const void *d_iq, size_t frame
     a.dqpsk = static_cast<float2 *>(d_dqpsk);
     a.keep = ctx->d_keep;
     ScopedTimer tm(ctx, 0, s);
-    HIP_TRY(dabk::launch_ofdm_demod(tab, a, pick_parts(ctx, n_frames, NB_DATA_SYMBOLS), s));
+    const RunPlan plan = plan_runs(ctx, n_frames, NB_DATA_SYMBOLS);
+    a.uncut_frames = plan.uncut_frames;
+    HIP_TRY(dabk::launch_ofdm_demod(tab, a, plan.parts, s));
     return DABGPU_OK;
 }
 
@@ -1092,7 +1107,9 @@ int dabgpu_fft_symbols_dev(dabgpu_ctx *ctx, const void *d_iq, size_t frame_strid
     a.n_frames = n_frames;
     a.spectra = static_cast<float2 *>(d_spectra);
     ScopedTimer tm(ctx, 3, s);
-    HIP_TRY(dabk::launch_fft_symbols(tab, a, pick_parts(ctx, n_frames, NB_FRAME_SYMBOLS), s));
+    const RunPlan plan = plan_runs(ctx, n_frames, NB_FRAME_SYMBOLS);
+    a.uncut_frames = plan.uncut_frames;
+    HIP_TRY(dabk::launch_fft_symbols(tab, a, plan.parts, s));
     return DABGPU_OK;
 }
 
@@ -1260,7 +1277,9 @@ int dabgpu_ofdm_demod_streams_dev(dabgpu_ctx *ctx, const void *d_iq, size_t fram
     a.frames_per_stream = frames_per_stream;
     {
         ScopedTimer tm(ctx, 0, s);
-        HIP_TRY(dabk::launch_ofdm_demod(tab, a, pick_parts(ctx, n_frames, NB_DATA_SYMBOLS), s));
+        const RunPlan plan = plan_runs(ctx, n_frames, NB_DATA_SYMBOLS);
+        a.uncut_frames = plan.uncut_frames;
+        HIP_TRY(dabk::launch_ofdm_demod(tab, a, plan.parts, s));
     }
     HIP_TRY(dabk::launch_stream_update(ctx->d_states, a.cyc, a.iq, frame_stride, n_streams, frames_per_stream,
                                        fine_freq_update_beta, ctx->thr_null_start, ctx->signal_beta, s));
@@ -1486,7 +1505,9 @@ int dabgpu_ofdm_demod_acquired_dev(dabgpu_ctx *ctx, const void *d_iq, size_t str
     a.acq_per_stream = max_frames;
     a.keep = ctx->d_keep;
     ScopedTimer tm(ctx, 0, s);
-    HIP_TRY(dabk::launch_ofdm_demod(tab, a, pick_parts(ctx, a.n_frames, NB_DATA_SYMBOLS), s));
+    const RunPlan plan = plan_runs(ctx, a.n_frames, NB_DATA_SYMBOLS);
+    a.uncut_frames = plan.uncut_frames;
+    HIP_TRY(dabk::launch_ofdm_demod(tab, a, plan.parts, s));
     return DABGPU_OK;
 }
 
@@ -1567,7 +1588,9 @@ static int tracked_launches(dabgpu_ctx *ctx, dabk::StreamState *states, const vo
     a.keep = ctx->d_keep;
     {
         ScopedTimer tm(ctx, 0, s);
-        HIP_TRY(dabk::launch_ofdm_demod(tab, a, pick_parts(ctx, a.n_frames, NB_DATA_SYMBOLS), s));
+        const RunPlan plan = plan_runs(ctx, a.n_frames, NB_DATA_SYMBOLS);
+        a.uncut_frames = plan.uncut_frames;
+        HIP_TRY(dabk::launch_ofdm_demod(tab, a, plan.parts, s));
     }
     dabk::TrackUpdateArgs u{};
     u.state = states;

@@ -54,10 +54,14 @@ struct OfdmArgs {
     // stream's fine + coarse offset; freq_offset is ignored
     const StreamState *state = nullptr;
     int frames_per_stream = 0;
+    // the first `uncut_frames` frames of the launch are ONE run each (no symbol is transformed twice); only the frames
+    // behind them -- the ones that would otherwise leave most of the chip idle at the end of the launch -- are cut
+    // into `parts` runs
+    int uncut_frames = 0;
 };
 
-// fused A2..A6.  Each frame is cut into `parts` contiguous runs of data symbols (1..75); a run re-reads
-// the symbol before it as differential reference.
+// fused A2..A6.  Frames behind the first a.uncut_frames are cut into `parts` contiguous runs of data symbols (1..75);
+// a run re-reads the symbol before it as differential reference.
 hipError_t launch_ofdm_demod(const OfdmTables &t, const OfdmArgs &a, int parts, hipStream_t s);
 // A2+A3 only; parts in 1..76.
 hipError_t launch_fft_symbols(const OfdmTables &t, const OfdmArgs &a, int parts, hipStream_t s);

@@ -155,8 +155,15 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
     // symbol counter, the NCO increment) in SGPRs: -5 % VALU instructions, -8 % time.
     const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES + wave);
     if (item >= n_items) return;
-    const int frame = item / parts;
-    const int part = item - frame * parts;
+    // whole frames first (one run each), then the cut ones: the launch ends on short items
+    int frame = item, part = 0;
+    if (item >= a.uncut_frames) {
+        const int j = item - a.uncut_frames;
+        frame = a.uncut_frames + j / parts;
+        part = j - (frame - a.uncut_frames) * parts;
+    } else {
+        parts = 1;
+    }
     const float2 *fiq = a.iq + size_t(frame) * a.frame_stride;
     // fused: data symbols (l_first, l_last]; l_first is only the differential reference
     const int l_first = FFT_ONLY ? (NB_FRAME_SYMBOLS * part) / parts : (NB_DATA_SYMBOLS * part) / parts;
@@ -576,7 +583,8 @@ hipError_t launch_ofdm_demod(const OfdmTables &t, const OfdmArgs &a, int parts, 
     if (a.n_frames <= 0) return hipSuccess;
     if (parts <= 0 || parts > NB_DATA_SYMBOLS) return hipErrorInvalidValue;
     if (a.state && a.frames_per_stream <= 0) return hipErrorInvalidValue;
-    const int items = a.n_frames * parts;
+    if (a.uncut_frames < 0 || a.uncut_frames > a.n_frames) return hipErrorInvalidValue;
+    const int items = a.uncut_frames + (a.n_frames - a.uncut_frames) * parts;
     const bool nco = a.freq_offset != nullptr || a.acq != nullptr || a.state != nullptr;
     const dim3 grid(unsigned((items + WAVES - 1) / WAVES)), block(64 * WAVES);
     OfdmArgs b = a;
@@ -598,7 +606,8 @@ hipError_t launch_fft_symbols(const OfdmTables &t, const OfdmArgs &a, int parts,
     if (a.n_frames <= 0) return hipSuccess;
     if (parts <= 0 || parts > NB_FRAME_SYMBOLS) return hipErrorInvalidValue;
     if (a.state && a.frames_per_stream <= 0) return hipErrorInvalidValue;
-    const int items = a.n_frames * parts;
+    if (a.uncut_frames < 0 || a.uncut_frames > a.n_frames) return hipErrorInvalidValue;
+    const int items = a.uncut_frames + (a.n_frames - a.uncut_frames) * parts;
     const dim3 grid(unsigned((items + WAVES - 1) / WAVES)), block(64 * WAVES);
     if (a.freq_offset || a.state) hipLaunchKernelGGL((ofdm_wave_kernel<true, false, false, true>), grid, block, 0, s, t, a, parts, items);
     else hipLaunchKernelGGL((ofdm_wave_kernel<true, false, false, false>), grid, block, 0, s, t, a, parts, items);

@@ -114,6 +114,35 @@ def test_ofdm_group_splits_agree(built, ensemble_iq):
         assert np.array_equal(cyc, outs[0][1])
 
 
+def test_ofdm_large_batch_run_plan_agrees_with_fixed_cuts(built, ensemble_iq):
+    """Above 3072 frames a launch sends whole frames first (one run each, no symbol transformed twice) and cuts only
+    the frames behind them (plan_runs): 3072 + 45 frames give the same soft bits and correlations as the same frames cut
+    into three runs each."""
+    import torch
+    dev = torch.device("cuda", 0)
+    frames = _rx(ensemble_iq, 14.0, 0.3 / 2048)
+    n = 3072 + 45
+    base = torch.from_numpy(frames).to(dev)
+    iq = base.repeat((n + base.shape[0] - 1) // base.shape[0], 1)[:n].contiguous()
+    fo = torch.full((n,), -0.3 / 2048, dtype=torch.float32, device=dev)
+    outs = []
+    for runs in (0, 3):
+        with dabgpu.Context(device=0, max_frames=n, ofdm_symbol_runs=runs) as c:
+            soft = torch.zeros((n, dabgpu.NB_FRAME_BITS), dtype=torch.int8, device=dev)
+            cyc = torch.zeros((n, 76), dtype=torch.complex64, device=dev)
+            torch.cuda.synchronize()                       # (the fills above run on torch's stream, the launch on the context's)
+            c.ofdm_demod_frames_dev(iq.data_ptr(), iq.shape[1], n, fo.data_ptr(), soft.data_ptr(), cyc.data_ptr())
+            c.sync()
+            outs.append((soft, cyc))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    k = frames.shape[0]
+    with dabgpu.Context(device=0) as c:
+        ref, _, _ = c.ofdm_demod_frames(frames, np.full(k, -0.3 / 2048, np.float32))
+    got = outs[0][0].cpu().numpy()
+    for f in (0, 1, 3071, 3072, n - 1):
+        assert (got[f] == ref[f % k]).all(), f
+
+
 def test_ofdm_empty_and_bad_arguments(ctx):
     soft, _, _ = ctx.ofdm_demod_frames(np.zeros((0, 76 * 2552), np.complex64))
     assert soft.shape == (0, 230400)

@@ -1,13 +1,8 @@
 #!/bin/bash
-# GPU job: A/B of library variants in one session.  usage: tools/job_ab.sh <tag> <tool.py> "<tool args>" <rounds> name1 name2 ...
-# (variant "default" = the in-tree libdabgpu.so, otherwise build/ab/libdabgpu_<name>.so)
-tag=$1; tool=$2; args=$3; rounds=$4; shift 4
-root=${GRAFT_REPO_ROOT:-$(pwd)}; o=$root/gpurun_out/$tag; mkdir -p $o; cd $root
-for r in $(seq 1 $rounds); do
-  for v in "$@"; do
-    if [ "$v" = default ]; then unset DABGPU_LIB; else export DABGPU_LIB=$root/build/ab/libdabgpu_$v.so; fi
-    echo "== round $r variant $v" >> $o/ab.txt
-    python3 $tool $args 2>&1 | grep -v amdgpu.ids >> $o/ab.txt
-  done
-done
+# GPU job: in-process A/B of the in-tree library against build/ab/libdabgpu_base.so (modes in $2), tag = $1
+tag=${1:-r03_ab}; modes=${2:-"ofdm fft"}
+root=${GRAFT_REPO_ROOT:-$(pwd)}
+o=$root/gpurun_out/$tag; mkdir -p $o
+cd $root
+for m in $modes; do python3 tools/ab_inproc.py $m 16384 5 3 build/ab/libdabgpu_base.so default 2>&1 | grep -v "amdgpu.ids"; done > $o/ab.txt 2>&1
 cat $o/ab.txt
