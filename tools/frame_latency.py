@@ -68,3 +68,43 @@ print("one frame, FIC + %d sub-channels (%d CUs), host buffers: before %.2f ms (
       "dabgpu_decode_frames %.2f ms (1 upload, 1 synchronisation, histories over PCIe)  dabgpu_decode_stream_frames %.3f ms "
       "(histories on the device, 1 upload + 1 download) = %.0f x real time" % (n, cu, t_before, n + 1, n + 1, t_after, t_stream,
                                                                                 96.0 / t_stream))
+
+# ---- the front end of the same use: one frame of IQ from host memory through OFDM_Demod's per-frame work ----
+# round 2: three synchronous calls (dabgpu_sync_prs, dabgpu_ofdm_demod_streams, dabgpu_get_stats: the PRS crosses PCIe
+# twice, three stream synchronisations); round 3: dabgpu_ofdm_demod_stream_frame (one upload, one download, one
+# synchronisation, everything in between on the device)
+from dabgpu import synth
+e = synth.Ensemble(seed=1, n_frames=4)
+iq = synth.channel(e.iq().ravel(), snr_db=20.0, cfo=0.2 / 2048, rng=rng)
+M = 128
+frame = np.ascontiguousarray(iq[synth.NB_NULL - M:synth.NB_NULL - M + 76 * 2552])
+p_iq = dabgpu.PinnedArray(frame.shape, np.complex64); p_iq.array[:] = frame
+p_sft = dabgpu.PinnedArray((dabgpu.NB_FRAME_BITS,), np.int8)
+p_dq = dabgpu.PinnedArray((75, 1536), np.complex64)
+octx = dabgpu.Context(0, 1); octx.streams_reset(1)
+res3 = dabgpu.SyncResult(); st3 = dabgpu.Stats()
+fine = C.c_float(0.0)
+
+
+def three_calls(dq):
+    assert L.dabgpu_sync_prs(octx._h, p_iq.array.ctypes.data, 76 * 2552, 1, C.byref(fine), 204, C.byref(res3)) == 0
+    assert L.dabgpu_ofdm_demod_streams(octx._h, p_iq.array.ctypes.data, 76 * 2552, 1, 1, C.c_float(0.9), p_sft.array.ctypes.data,
+                                       None, dq) == 0
+    assert L.dabgpu_get_stats(octx._h, 0, C.byref(st3)) == 0
+
+
+cfg = dabgpu.track_cfg(timing_margin=M)
+fres = dabgpu.FrameResult()
+
+
+def one_call(dq):
+    assert L.dabgpu_ofdm_demod_stream_frame(octx._h, 0, p_iq.array.ctypes.data, 0, C.byref(cfg), p_sft.array.ctypes.data, dq,
+                                            C.byref(fres)) == 0
+
+
+for name, dq in (("soft bits only", None), ("+ the 75 x 1536 constellation the GUI plots (GetFrameDataVec)", p_dq.array.ctypes.data)):
+    t3 = timeit(lambda: three_calls(dq))
+    t1 = timeit(lambda: one_call(dq))
+    print("one frame of IQ (1.55 MB) from page-locked host memory, %s: sync_prs + demod_streams + get_stats %.3f ms  ->  "
+          "dabgpu_ofdm_demod_stream_frame %.3f ms = %.0f x real time" % (name, t3, t1, 96.0 / t1))
+assert fres.flags == 3

@@ -6,7 +6,7 @@ o=$root/gpurun_out/$tag; mkdir -p $o
 cd $root
 python3 bench.py > $o/bench.json 2> $o/bench.err
 tail -c 4000 $o/bench.json
-tools/prof.sh $tag --cpu-seconds 0 --no-closed-loop > $o/prof.log 2>&1
+tools/prof.sh $tag --cpu-seconds 0 --no-closed-loop --no-sustained --no-selective > $o/prof.log 2>&1
 cp gpurun_out/${tag}_kernel_stats.csv $o/kernel_stats.csv
 tools/pmc_traffic.sh 16384 > $o/pmc_traffic.log 2>&1
 cp gpurun_out/pmc_traffic.json $o/pmc_traffic.json
