@@ -121,11 +121,18 @@ struct Predictor {
 //             the whole-carrier search only when asked for (max_coarse > 0); AcquiredFrame out.
 template <int MODE>
 __global__ __launch_bounds__(WG) void prs_sync_kernel(SyncTables tab, const float2 *iq, size_t frame_stride,
-                                                      const float *freq_offset, int max_coarse, SyncResult *out,
-                                                      AcquireArgs acq, TrackArgs trk) {
+                                                      const float *freq_offset, int max_coarse_arg, SyncResult *out,
+                                                      AcquireArgs acq, TrackArgs trk, int n_total) {
     __shared__ SyncLds sm;
     const int tid = threadIdx.x;
-    const int frame = blockIdx.x;
+    // the tables go to LDS once per workgroup; a workgroup then takes every gridDim.x-th candidate
+    for (int i = tid; i < NB_FFT; i += WG) {
+        sm.tw[i] = tab.twiddle[i];
+        sm.qt[i] = tab.prs_qt[i];
+    }
+    __syncthreads();
+    for (int frame = blockIdx.x; frame < n_total; frame += gridDim.x) {
+    int max_coarse = max_coarse_arg;
     const float2 *sym;
     uint32_t dphi;
     int64_t cand = 0;
@@ -136,7 +143,7 @@ __global__ __launch_bounds__(WG) void prs_sync_kernel(SyncTables tab, const floa
         const int st = frame / acq.max_out, j = frame - st * acq.max_out;
         if (j >= acq.counts[st]) {
             if (tid == 0) acq.out[frame] = AcquiredFrame{-1, 0.f, 0, 0.f, 0.f, 0.f, 0};
-            return;
+            continue;
         }
         cand = acq.cands[frame];
         sym = acq.iq + size_t(st) * acq.stream_stride + cand;
@@ -158,7 +165,7 @@ __global__ __launch_bounds__(WG) void prs_sync_kernel(SyncTables tab, const floa
                 trk.out[frame] = AcquiredFrame{-1, 0.f, 0, 0.f, 0.f, 0.f, 0};
                 if (trk.sync_out) trk.sync_out[frame] = SyncResult{0, 0, 0.f, 0.f};
             }
-            return;
+            continue;
         }
         sym = trk.iq + size_t(st) * trk.stream_stride + cand;
         fine = ss.fine_freq_offset;
@@ -174,11 +181,6 @@ __global__ __launch_bounds__(WG) void prs_sync_kernel(SyncTables tab, const floa
         sym = iq + size_t(frame) * frame_stride;
         dphi = dphi_of(freq_offset, frame);
     }
-    for (int i = tid; i < NB_FFT; i += WG) {
-        sm.tw[i] = tab.twiddle[i];
-        sm.qt[i] = tab.prs_qt[i];
-    }
-    __syncthreads();
     // ---- X = FFT(nco * window) ----
     {
         float2 v[8];
@@ -327,6 +329,8 @@ __global__ __launch_bounds__(WG) void prs_sync_kernel(SyncTables tab, const floa
             r.coarse_peak_to_mean = coarse_ptm;
             out[frame] = r;
         }
+    }
+    __syncthreads();                                           // the reduction buffers are reused by the next candidate
     }
 }
 
@@ -675,12 +679,16 @@ __global__ __launch_bounds__(64) void null_stitch_kernel(AcquireArgs a, int n_se
 
 }  // namespace
 
+// two workgroups fit a CU (73 KB of LDS each); eight rounds' worth of workgroups, each walking the candidates with that
+// stride, keeps the tail short and loads the tables once per eight candidates
+static unsigned sync_grid(int n) { return unsigned(std::max(1, std::min(n, 4096))); }
+
 hipError_t launch_prs_sync(const SyncTables &t, const float2 *iq, size_t frame_stride, int n_frames,
                            const float *freq_offset, int max_coarse, SyncResult *out, hipStream_t s) {
     if (n_frames <= 0) return hipSuccess;
     if (max_coarse < 0 || max_coarse > 1023) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(prs_sync_kernel<MODE_PLAIN>, dim3(unsigned(n_frames)), dim3(WG), 0, s, t, iq, frame_stride,
-                       freq_offset, max_coarse, out, AcquireArgs{}, TrackArgs{});
+    hipLaunchKernelGGL(prs_sync_kernel<MODE_PLAIN>, dim3(sync_grid(n_frames)), dim3(WG), 0, s, t, iq, frame_stride,
+                       freq_offset, max_coarse, out, AcquireArgs{}, TrackArgs{}, n_frames);
     return hipGetLastError();
 }
 
@@ -689,9 +697,9 @@ hipError_t launch_track_sync(const SyncTables &t, const TrackArgs &a, hipStream_
     if (a.max_coarse < 0 || a.max_coarse > 1023 || (a.fixed_start && a.max_out != 1)) return hipErrorInvalidValue;
     TrackArgs b = a;
     b.rule.expected = a.margin;
-    hipLaunchKernelGGL(prs_sync_kernel<MODE_TRACK>, dim3(unsigned(a.n_streams) * unsigned(a.max_out)), dim3(WG), 0, s, t,
+    hipLaunchKernelGGL(prs_sync_kernel<MODE_TRACK>, dim3(sync_grid(a.n_streams * a.max_out)), dim3(WG), 0, s, t,
                        static_cast<const float2 *>(nullptr), size_t(0), static_cast<const float *>(nullptr), 0,
-                       static_cast<SyncResult *>(nullptr), AcquireArgs{}, b);
+                       static_cast<SyncResult *>(nullptr), AcquireArgs{}, b, a.n_streams * a.max_out);
     return hipGetLastError();
 }
 
@@ -737,9 +745,9 @@ hipError_t launch_acquire(const SyncTables &t, const AcquireArgs &a, hipStream_t
     hipLaunchKernelGGL(null_segment_kernel, dim3(unsigned(n_seg), unsigned(a.n_streams)), dim3(64), 0, s, a, nb, n_seg, avg, segs,
                        seg_cands);
     hipLaunchKernelGGL(null_stitch_kernel, dim3(unsigned(a.n_streams)), dim3(64), 0, s, a, n_seg, segs, seg_cands);
-    hipLaunchKernelGGL(prs_sync_kernel<MODE_ACQ>, dim3(unsigned(a.n_streams) * unsigned(a.max_out)), dim3(WG), 0, s, t,
+    hipLaunchKernelGGL(prs_sync_kernel<MODE_ACQ>, dim3(sync_grid(a.n_streams * a.max_out)), dim3(WG), 0, s, t,
                        static_cast<const float2 *>(nullptr), size_t(0), static_cast<const float *>(nullptr), 0,
-                       static_cast<SyncResult *>(nullptr), a, TrackArgs{});
+                       static_cast<SyncResult *>(nullptr), a, TrackArgs{}, a.n_streams * a.max_out);
     return hipGetLastError();
 }
 
