@@ -280,6 +280,8 @@ def main():
                     help="length of the extra `sustained` leg: the same step repeated for this long, so that the package's "
                          "power-limited steady state is in the record (0 = skip)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the sustained leg")
+    ap.add_argument("--no-plain-compare", action="store_true",
+                    help="skip timing the front end on a plainly allocated copy of the buffers beside the placed pair")
     ap.add_argument("--placement", choices=["placed", "candidates", "plain"], default="placed",
                     help="how the IQ / soft-bit buffers are placed in HBM (place_buffers)")
     ap.add_argument("--placement-candidates", type=int, default=4,
@@ -480,6 +482,30 @@ def main():
             "decoder": {"fic_and_msc_ms": dec_ms, "acs_per_s": (ACS_FIC + ACS_MSC64) * n_frames / (dec_ms * 1e-3),
                         "entry_point": "dabgpu_decode_frames_dev (FIC + sub-channel codewords in one grouped launch)"},
         }
+        if args.placement == "placed" and placement is not None and not args.no_plain_compare:
+            # what two plain allocations would have given in this very process: the same front-end call (open loop, the
+            # offsets the closed loop arrived at) on a torch-allocated pair holding the same samples, beside the placed pair
+            fo_cmp = torch.from_numpy(np.repeat(net.astype(np.float32), F)).to(dev)
+            iq_p = torch.empty((n_frames, synth.NB_FRAME_SAMPLES), dtype=torch.complex64, device=dev)
+            soft_p = torch.empty((n_frames, dabgpu.NB_FRAME_BITS), dtype=torch.int8, device=dev)
+            iq_p.copy_(iq.reshape(n_frames, -1))
+            res = {}
+            for name, a, b in (("placed", iq.data_ptr(), soft.data_ptr()), ("plain_alloc", iq_p.data_ptr(), soft_p.data_ptr())):
+                evs = []
+                for i in range(2 + 5):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    ctx.ofdm_demod_frames_dev(a + synth.NB_NULL * 8, synth.NB_FRAME_SAMPLES, n_frames, fo_cmp.data_ptr(), b,
+                                              cyc.data_ptr(), None, stream)
+                    e1.record()
+                    if i >= 2:
+                        evs.append((e0, e1))
+                torch.cuda.synchronize()
+                res[name] = round(float(np.mean([x.elapsed_time(y) for x, y in evs])), 3)
+            placement["front_end_ms_same_call_placed"] = res["placed"]
+            placement["front_end_ms_same_call_plain_alloc"] = res["plain_alloc"]
+            placement["plain_alloc_outputs_identical"] = bool(torch.equal(soft_p, soft))
+            del iq_p, soft_p
         if not args.no_sustained and args.sustained_seconds > 0:
             # The same step, repeated for >= --sustained-seconds: the 10-step timed region above lasts 0.1 s, shorter than
             # the package's power controller takes to settle (the front end runs at the 1400 W limit), so the
@@ -526,7 +552,9 @@ def main():
             out["roofline_fft_stage"] = {"bound": "hbm", "kernel": "dabk::ofdm_wave_kernel<true,false> (FFT stage only)", "achieved": ach,
                                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                          "avg_launch_ms": fft_ms, "algorithmic_bytes_per_frame": A_FFT,
-                                         "output_placement_probe_ms": [round(x, 3) for x in spec_probe]}
+                                         "output_placement": {"mover_ms_on_placed_buffer": round(spec_probe[0], 3),
+                                                              "written_beside_same_domain_reads_per_mille": round(spec_probe[1], 1),
+                                                              "classify_ms": round(spec_probe[2], 1)}}
             del spectra
             ctx.device_free(d_spec)
         if not args.no_selective:

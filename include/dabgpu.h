@@ -173,11 +173,14 @@ typedef struct dabgpu_placement_report {
 int dabgpu_alloc_frame_buffers_placed(dabgpu_ctx *ctx, int n_frames, size_t frame_stride, void **d_iq, int8_t **d_soft,
                                       dabgpu_placement_report *report);
 
-/* The same idea for any other buffer a launch WRITES while it reads `d_other` (e.g. the spectra of
- * dabgpu_fft_symbols_dev beside the IQ samples): up to three candidates of `bytes` are allocated some tens of GB
- * apart, a probe that reads d_other and writes the candidate is timed on each, the fastest is returned.  With
- * d_other == NULL, or buffers too small for the domains to matter (< 256 MB), a plain allocation.  probe_ms (may be
- * NULL) receives three times, 0 for candidates that were not tried.  Release with dabgpu_device_free. */
+/* The same for any other buffer a launch WRITES while it reads `d_other`, both walked front to back in step (e.g. the
+ * spectra of dabgpu_fft_symbols_dev beside the IQ samples): physical chunks (1 GiB, or 256 MiB below 8 GiB; at most
+ * 1.2 x `bytes` held during set-up), their HBM domains among themselves, the domain of every GiB of d_other against one
+ * representative chunk per domain, then every piece of the new buffer over a chunk whose domain the part of d_other
+ * read beside it is not in; the chunks left over are released.  With d_other == NULL, or buffers too small for the
+ * domains to matter (< 256 MB), a plain allocation.  probe_ms (may be NULL, 3 floats): [0] the time of a small mover
+ * on the result (first GiB of d_other -> start of the buffer), [1] per mille of the buffer left beside same-domain
+ * reads, [2] milliseconds spent classifying; all 0 for a plain allocation.  Release with dabgpu_device_free. */
 int dabgpu_device_alloc_apart(dabgpu_ctx *ctx, size_t bytes, const void *d_other, size_t other_bytes, void **d_out,
                               float *probe_ms);
 int dabgpu_device_free(dabgpu_ctx *ctx, void *d_ptr);

@@ -242,68 +242,7 @@ RunPlan plan_runs(const dabgpu_ctx *ctx, int n_frames, int total_syms) {
     return RunPlan{0, p_all};
 }
 
-// Placement of large device buffers.  Candidates are allocated some tens of GB apart (spacer allocations in between,
-// released afterwards) so that they fall into different HBM domains if the address space in reach has any; a launch is
-// timed on each and the fastest candidate kept.  alloc_apart times a read-ref / write-candidate probe (a buffer that
-// some launch will write while it reads [ref, ref + ref_bytes)).  Plain hipMalloc when the buffers are too small for
-// any of this to matter.
-constexpr size_t PLACE_MIN_BYTES = size_t(256) << 20;
-// `work(candidate, stream)` enqueues the launch whose time decides (it may run several times; it must be idempotent)
-template <class Work>
-int alloc_timed(dabgpu_ctx *ctx, size_t bytes, hipStream_t s, Work work, void **out, float *probe_ms) {
-    *out = nullptr;
-    if (probe_ms) probe_ms[0] = probe_ms[1] = probe_ms[2] = 0.f;
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return DABGPU_ERR_HIP;
-    constexpr int K = 3;
-    void *cand[K] = {nullptr, nullptr, nullptr}, *spacer[K - 1] = {nullptr, nullptr};
-    const size_t spacer_bytes = std::min<size_t>(size_t(32) << 30, free_b / 8);
-    int n = 0;
-    for (int k = 0; k < K; k++) {
-        if (double(bytes) * (k + 1) + double(spacer_bytes) * k > 0.5 * double(free_b)) break;
-        if (k > 0 && hipMalloc(&spacer[k - 1], spacer_bytes) != hipSuccess) { spacer[k - 1] = nullptr; break; }
-        if (hipMalloc(&cand[k], bytes) != hipSuccess) { cand[k] = nullptr; break; }
-        n = k + 1;
-    }
-    (void)hipGetLastError();                                   // a candidate that did not fit is not an error
-    int rc = DABGPU_OK, best = 0;
-    if (n == 0) {
-        rc = hipMalloc(&cand[0], bytes) == hipSuccess ? DABGPU_OK : DABGPU_ERR_NOMEM;
-    } else if (n > 1) {
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) rc = DABGPU_ERR_HIP;
-        float best_ms = -1.f;
-        for (int k = 0; k < n && !rc; k++) {
-            float ms = 0.f;
-            if (work(cand[k], s) != hipSuccess || hipEventRecord(e0, s) != hipSuccess || work(cand[k], s) != hipSuccess ||
-                hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
-                hipEventElapsedTime(&ms, e0, e1) != hipSuccess)
-                rc = DABGPU_ERR_HIP;
-            if (probe_ms) probe_ms[k] = ms;
-            if (!rc && (best_ms < 0.f || ms < best_ms)) { best_ms = ms; best = k; }
-        }
-        if (e0) (void)hipEventDestroy(e0);
-        if (e1) (void)hipEventDestroy(e1);
-    }
-    for (void *p : spacer) if (p) (void)hipFree(p);
-    for (int k = 0; k < K; k++)
-        if (cand[k] && (rc || k != best)) (void)hipFree(cand[k]);
-    if (rc) return rc;
-    *out = cand[best];
-    return DABGPU_OK;
-}
-
-int alloc_apart(dabgpu_ctx *ctx, size_t bytes, const void *ref, size_t ref_bytes, void **out, float *probe_ms) {
-    if (!ref || ref_bytes < PLACE_MIN_BYTES || bytes < PLACE_MIN_BYTES) {
-        if (probe_ms) probe_ms[0] = probe_ms[1] = probe_ms[2] = 0.f;
-        *out = nullptr;
-        return hipMalloc(out, std::max<size_t>(bytes, 16)) == hipSuccess ? DABGPU_OK : DABGPU_ERR_NOMEM;
-    }
-    const size_t in_b = std::min<size_t>(ref_bytes, size_t(2) << 30), out_b = std::min<size_t>(bytes, in_b / 6);
-    return alloc_timed(ctx, bytes, ctx->stream,
-                       [&](void *cand, hipStream_t s) { return dabk::launch_placement_probe(ref, in_b, cand, out_b, s); }, out,
-                       probe_ms);
-}
+constexpr size_t PLACE_MIN_BYTES = size_t(256) << 20;      // below this the HBM domains do not matter
 
 // The codeword-per-lane Viterbi pays once a launch has enough codewords to give every SIMD a wave (one wave =
 // 64 codewords; its single-wave latency equals the wave-per-codeword kernels' time at ~24k codewords).
@@ -600,12 +539,11 @@ struct Chunks {
     char *at(int i) const { return va + items[size_t(i)].off; }
 };
 
-// time of a mover launch that reads chunk a and writes (a sixth of its size of) chunk b: min of two after a warm-up
-float pair_ms(const Chunks &c, int a, int b, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
-    const size_t in_b = c.items[size_t(a)].bytes, out_b = std::min(c.items[size_t(b)].bytes, in_b / 6);
+// time of a mover launch that reads [in, in + in_b) and writes [out, out + out_b): min of two after a warm-up
+float mover_ms(const void *in, size_t in_b, void *out, size_t out_b, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
     float best = 1e30f;
     for (int rep = 0; rep < 3; rep++) {
-        if (hipEventRecord(e0, s) != hipSuccess || dabk::launch_placement_probe(c.at(a), in_b, c.at(b), out_b, s) != hipSuccess ||
+        if (hipEventRecord(e0, s) != hipSuccess || dabk::launch_placement_probe(in, in_b, out, out_b, s) != hipSuccess ||
             hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess)
             return -1.f;
         float ms = 0.f;
@@ -613,6 +551,31 @@ float pair_ms(const Chunks &c, int a, int b, hipStream_t s, hipEvent_t e0, hipEv
         if (rep > 0) best = std::min(best, ms);
     }
     return best;
+}
+bool same_domain_as(const Chunks &c, int ref, const std::vector<int> &idx, hipStream_t s, hipEvent_t e0, hipEvent_t e1,
+                    std::vector<int> &same, std::vector<int> &other);
+// ... reading chunk a and writing (a sixth of its size of) chunk b
+float pair_ms(const Chunks &c, int a, int b, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+    const size_t in_b = c.items[size_t(a)].bytes;
+    return mover_ms(c.at(a), in_b, c.at(b), std::min(c.items[size_t(b)].bytes, in_b / 6), s, e0, e1);
+}
+
+// Every chunk's domain (0, 1, 2 in order of first appearance) in two passes: against chunk 0, then against the first
+// chunk that differed.  Returns the number of domains seen, or -1.
+int classify_chunks(const Chunks &c, hipStream_t s, hipEvent_t e0, hipEvent_t e1, std::vector<int> &dom) {
+    const int n = int(c.items.size());
+    dom.assign(size_t(n), 0);
+    std::vector<int> rest, a_set, others;
+    for (int i = 1; i < n; i++) rest.push_back(i);
+    if (!same_domain_as(c, 0, rest, s, e0, e1, a_set, others)) return -1;
+    if (others.empty()) return 1;
+    const int r2 = others[0];
+    std::vector<int> rest2(others.begin() + 1, others.end()), b_set, c_set;
+    if (!same_domain_as(c, r2, rest2, s, e0, e1, b_set, c_set)) return -1;
+    b_set.push_back(r2);
+    for (int i : b_set) dom[size_t(i)] = 1;
+    for (int i : c_set) dom[size_t(i)] = 2;
+    return c_set.empty() ? 2 : 3;
 }
 
 // Chunks whose pairing with `ref` is slow share its domain.  The times of `idx` fall into two groups ~10 % apart; with
@@ -721,19 +684,8 @@ int dabgpu_alloc_frame_buffers_placed(dabgpu_ctx *ctx, int n_frames, size_t fram
         rc = DABGPU_ERR_HIP;
     if (!rc) {
         (void)hipEventRecord(ec0, s);
-        std::vector<int> rest, a_set, others;
-        for (int i = 1; i < n_total; i++) rest.push_back(i);
-        if (!same_domain_as(c, 0, rest, s, e0, e1, a_set, others)) rc = DABGPU_ERR_HIP;
-        if (!rc && !others.empty()) {
-            n_dom = 2;
-            const int r2 = others[0];                          // (the first of them is an IQ-size chunk whenever one is)
-            std::vector<int> rest2(others.begin() + 1, others.end()), b_set, c_set;
-            if (!same_domain_as(c, r2, rest2, s, e0, e1, b_set, c_set)) rc = DABGPU_ERR_HIP;
-            b_set.push_back(r2);
-            for (int i : b_set) dom[size_t(i)] = 1;
-            for (int i : c_set) dom[size_t(i)] = 2;
-            if (!c_set.empty()) n_dom = 3;
-        }
+        n_dom = classify_chunks(c, s, e0, e1, dom);
+        if (n_dom < 0) { rc = DABGPU_ERR_HIP; n_dom = 1; }
         (void)hipEventRecord(ec1, s);
         (void)hipEventSynchronize(ec1);
         (void)hipEventElapsedTime(&rep.classify_ms, ec0, ec1);
@@ -875,6 +827,142 @@ int dabgpu_alloc_frame_buffers_placed(dabgpu_ctx *ctx, int n_frames, size_t fram
     return rc;                                               // (~Chunks releases the chunks nobody took)
 }
 
+// A buffer that a launch WRITES while it reads [ref, ref + ref_bytes), both walked front to back in step: physical
+// chunks (1.2 x bytes at most), their domains among themselves, the domain of every GiB of `ref` against one
+// representative chunk per domain, then every piece of the new buffer over a chunk whose domain the part of `ref` read
+// beside it is not in.  probe_ms: [0] mover time on the result (first GiB of ref -> start of the buffer), [1] per mille of
+// the buffer left beside same-domain reads, [2] ms spent classifying.
+static int alloc_apart(dabgpu_ctx *ctx, size_t bytes, const void *ref, size_t ref_bytes, void **out, float *probe_ms) {
+    if (probe_ms) probe_ms[0] = probe_ms[1] = probe_ms[2] = 0.f;
+    *out = nullptr;
+    auto plain = [&]() { return hipMalloc(out, std::max<size_t>(bytes, 16)) == hipSuccess ? DABGPU_OK : DABGPU_ERR_NOMEM; };
+    if (!ref || ref_bytes < PLACE_MIN_BYTES || bytes < PLACE_MIN_BYTES) return plain();
+    const size_t CH = bytes >= (size_t(8) << 30) ? size_t(1) << 30 : size_t(256) << 20;
+    const int n_need = int((bytes + CH - 1) / CH);
+    int n_total = std::max(n_need + 1, int(1.2 * double(bytes) / double(CH)));
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    while (n_total > n_need && size_t(n_total) * CH > free_b - free_b / 16) n_total--;
+    if (n_total > 70 || size_t(n_total) * CH > free_b - free_b / 16) return plain();
+    hipStream_t s = ctx->stream;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = ctx->device;
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    Chunks c;
+    c.reserved = size_t(n_total) * CH;
+    void *va = nullptr;
+    if (hipMemAddressReserve(&va, c.reserved, 0, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); return plain(); }
+    c.va = static_cast<char *>(va);
+    bool ok = true;
+    for (int i = 0; i < n_total && ok; i++) {
+        hipMemGenericAllocationHandle_t h;
+        if (hipMemCreate(&h, CH, &prop, 0) != hipSuccess) { ok = false; break; }
+        if (hipMemMap(c.va + c.mapped, CH, 0, h, 0) != hipSuccess) { (void)hipMemRelease(h); ok = false; break; }
+        c.items.push_back(Chunks::Item{h, CH, c.mapped});
+        c.mapped += CH;
+    }
+    if (!ok || hipMemSetAccess(c.va, c.mapped, &acc, 1) != hipSuccess) { (void)hipGetLastError(); return plain(); }
+    hipEvent_t e0 = nullptr, e1 = nullptr, ec0 = nullptr, ec1 = nullptr;
+    int rc = DABGPU_OK;
+    std::vector<int> dom, sel;
+    double shared = 0.0;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventCreate(&ec0) != hipSuccess ||
+        hipEventCreate(&ec1) != hipSuccess || dabk::launch_fill_noise(c.va, c.mapped, s) != hipSuccess)
+        rc = DABGPU_ERR_HIP;
+    if (!rc) {
+        (void)hipEventRecord(ec0, s);
+        const int n_dom = classify_chunks(c, s, e0, e1, dom);
+        if (n_dom < 0) rc = DABGPU_ERR_HIP;
+        // the domain of every piece of ref: the representative it is slow against (none: a domain no chunk is in)
+        const size_t RP = size_t(1) << 30;
+        const int n_ref = int((ref_bytes + RP - 1) / RP);
+        std::vector<int> ref_dom(size_t(n_ref), -1), repr(3, -1);
+        for (int i = n_total - 1; i >= 0 && !rc; i--) repr[size_t(dom[size_t(i)])] = i;
+        for (int r = 0; r < n_ref && !rc; r++) {
+            const char *in = static_cast<const char *>(ref) + size_t(r) * RP;
+            const size_t in_b = std::min(RP, ref_bytes - size_t(r) * RP);
+            if (in_b < (size_t(64) << 20)) { ref_dom[size_t(r)] = r > 0 ? ref_dom[size_t(r) - 1] : -1; continue; }
+            float t[3] = {0.f, 0.f, 0.f}, lo = 1e30f, hi = 0.f;
+            for (int d = 0; d < n_dom; d++) {
+                t[d] = mover_ms(in, in_b, c.at(repr[size_t(d)]), std::min(CH, in_b / 6), s, e0, e1);
+                if (t[d] < 0.f) { rc = DABGPU_ERR_HIP; break; }
+                lo = std::min(lo, t[d]);
+                hi = std::max(hi, t[d]);
+            }
+            if (rc) break;
+            if (n_dom > 1 && hi > 1.04f * lo) {
+                for (int d = 0; d < n_dom; d++) if (t[d] == hi) ref_dom[size_t(r)] = d;
+            } else if (n_dom == 1) {
+                // one domain among the chunks: is ref in it?  chunk 0 against itself is the same-domain time
+                const float self = pair_ms(c, 0, 0, s, e0, e1) * float(double(in_b) / double(CH));
+                if (t[0] > 0.97f * self) ref_dom[size_t(r)] = 0;
+            }
+        }
+        // every piece of the buffer: the chunk least beside its own domain
+        std::vector<char> used(size_t(n_total), 0);
+        const double ratio = double(ref_bytes) / double(bytes);
+        for (int m = 0; m < n_need && !rc; m++) {
+            const double lo_b = double(m) * double(CH) * ratio - 1.5 * double(RP), hi_b = double(m + 1) * double(CH) * ratio + 1.5 * double(RP);
+            double w[3] = {0.0, 0.0, 0.0}, tot = 0.0;
+            for (int r = 0; r < n_ref; r++) {
+                const double a0 = std::max(lo_b, double(r) * double(RP)), a1 = std::min(hi_b, std::min(double(ref_bytes), double(r + 1) * double(RP)));
+                if (a1 <= a0) continue;
+                tot += a1 - a0;
+                if (ref_dom[size_t(r)] >= 0) w[ref_dom[size_t(r)]] += a1 - a0;
+            }
+            int best = -1;
+            for (int i = 0; i < n_total; i++) {
+                if (used[size_t(i)]) continue;
+                if (best < 0 || w[dom[size_t(i)]] < w[dom[size_t(best)]] - 1e-9) best = i;
+            }
+            sel.push_back(best);
+            used[size_t(best)] = 1;
+            if (tot > 0.0) shared += w[dom[size_t(best)]] / tot;
+        }
+        (void)hipEventRecord(ec1, s);
+        (void)hipEventSynchronize(ec1);
+        float cms = 0.f;
+        (void)hipEventElapsedTime(&cms, ec0, ec1);
+        if (probe_ms) { probe_ms[1] = float(1000.0 * shared / double(n_need)); probe_ms[2] = cms; }
+    }
+    dabgpu_ctx::Mapped m{nullptr, CH * size_t(n_need), 0, {}};
+    if (!rc) {
+        (void)hipStreamSynchronize(s);
+        if (hipMemUnmap(c.va, c.mapped) != hipSuccess) rc = DABGPU_ERR_HIP;
+        c.mapped = 0;
+    }
+    if (!rc && hipMemAddressReserve(&m.va, m.bytes, 0, nullptr, 0) != hipSuccess) rc = DABGPU_ERR_NOMEM;
+    for (size_t k = 0; k < sel.size() && !rc; k++) {
+        Chunks::Item &it = c.items[size_t(sel[k])];
+        if (hipMemMap(static_cast<char *>(m.va) + CH * k, CH, 0, it.h, 0) != hipSuccess) { rc = DABGPU_ERR_HIP; break; }
+        m.handles.push_back(it.h);
+        it.h = nullptr;
+        m.chunk = CH * (k + 1);
+    }
+    if (!rc && hipMemSetAccess(m.va, m.bytes, &acc, 1) != hipSuccess) rc = DABGPU_ERR_HIP;
+    if (rc) {
+        if (m.va) {
+            if (m.chunk) (void)hipMemUnmap(m.va, m.chunk);
+            for (auto h : m.handles) (void)hipMemRelease(h);
+            (void)hipMemAddressFree(m.va, m.bytes);
+        }
+        (void)hipGetLastError();
+    } else {
+        ctx->mapped.push_back(m);
+        *out = m.va;
+        if (probe_ms) {
+            const size_t in_b = std::min(ref_bytes, size_t(1) << 30);
+            probe_ms[0] = mover_ms(ref, in_b, m.va, std::min(m.bytes, in_b / 6), s, e0, e1);
+        }
+    }
+    for (hipEvent_t e : {e0, e1, ec0, ec1}) if (e) (void)hipEventDestroy(e);
+    return rc;
+}
+
 int dabgpu_alloc_frame_buffers(dabgpu_ctx *ctx, int n_frames, size_t frame_stride, int candidates, void **d_iq,
                                int8_t **d_soft, float *probe_ms, int *kept) {
     if (!ctx || !d_iq || !d_soft || n_frames <= 0 || candidates < 1 || candidates > 8) return DABGPU_ERR_ARG;
@@ -964,8 +1052,8 @@ int dabgpu_device_alloc_apart(dabgpu_ctx *ctx, size_t bytes, const void *d_other
 int dabgpu_device_free(dabgpu_ctx *ctx, void *d_ptr) {
     if (!ctx) return DABGPU_ERR_ARG;
     DeviceGuard guard(ctx);
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    if (d_ptr) HIP_TRY(hipFree(d_ptr));
+    HIP_TRY(hipDeviceSynchronize());
+    if (d_ptr && !release_mapped(ctx, d_ptr)) HIP_TRY(hipFree(d_ptr));
     return DABGPU_OK;
 }
 

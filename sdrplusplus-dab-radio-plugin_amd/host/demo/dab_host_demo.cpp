@@ -6,7 +6,7 @@
 // database, <prefix>.aus holds every CRC-clean DAB+ access unit as records
 // {u8 sub-channel id, u8 index, u8 units in super-frame, u16le length, bytes}.
 //
-//   dab_host_demo <iq.cf32> <out_prefix> [chunk_samples] [coarse_offset_cycles_per_sample] [bitrate start_cu level]
+//   dab_host_demo <iq.cf32> <out_prefix> [chunk_samples] [coarse_offset_cycles_per_sample] [bitrate start_cu level] [signal_l1.update_beta]
 #include <algorithm>
 #include <complex>
 #include <cstdio>
@@ -52,6 +52,7 @@ int main(int argc, char **argv) {
         return 3;
     }
     demod->SetCoarseFrequencyOffset(coarse);
+    if (argc > 8) demod->GetConfig().signal_l1.update_beta = float(std::atof(argv[8]));   // the GUI's "L1 signal update beta"
     if (argc > 7) {
         dabgpu_subchannel sc{};
         sc.bitrate_kbps = std::atoi(argv[5]);

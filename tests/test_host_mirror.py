@@ -141,3 +141,29 @@ def test_demo_through_realistic_channels(host_built, tmp_path, name, kw):
             assert (fib[f] == ens.fibs[f + lost]).all()
     ok = [(msc[i] == ens.msc_bytes[i + 4 * lost]).all() for i in range(msc.shape[0])]
     assert msc.shape[0] == 4 * (n_frames - lost) - 15 and all(ok[4:]), ok
+
+
+@pytest.mark.gpu
+def test_signal_level_getter_stays_live_while_locked(host_built, tmp_path):
+    """GetSignalAverage() (the GUI's "Signal level", /root/reference/src/render_radio_block.cpp:205) follows the signal
+    WHILE the demodulator is locked: the level average lives in the device-side stream state, moves by
+    (1 - signal_l1.update_beta) of the difference per frame (:235) and comes back with every frame.  A stream whose second
+    half is 3 x stronger: no desync, every FIB decoded, and the level the getter reports at the end is the new one."""
+    n_frames = 12
+    ens = synth.Ensemble(seed=55, n_frames=n_frames)
+    rng = np.random.default_rng(55)
+    tx = ens.iq().ravel()
+    x = synth.channel(np.concatenate([tx[-30000:], tx, tx[:synth.NB_NULL + 5000]]), snr_db=25.0, cfo=0.1 / 2048, rng=rng)
+    levels = {}
+    for name, gain in (("flat", 1.0), ("step", 3.0)):
+        y = x.copy()
+        y[30000 + 6 * synth.NB_FRAME_SAMPLES:] *= np.float32(gain)
+        path = tmp_path / ("iq_%s.cf32" % name)
+        y.astype(np.complex64).tofile(path)
+        r = subprocess.run([os.path.join(HOST, "dab_host_demo"), str(path), str(tmp_path / name), "65536", "0", "64", "0", "3", "0.5"],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "frames_desync=0" in r.stdout and "frames_read=%d" % n_frames in r.stdout, r.stdout + r.stderr
+        levels[name] = float(r.stdout.split("level=")[1].split()[0])
+        crc = np.fromfile(str(tmp_path / name) + ".crc", np.uint8).reshape(-1, 12)
+        assert crc.shape[0] == n_frames and crc.all()
+    assert levels["step"] == pytest.approx(3.0 * levels["flat"], rel=0.05)      # six frames at beta 0.5: within 2 %

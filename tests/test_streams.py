@@ -275,8 +275,9 @@ def test_alloc_frame_buffers_placed(built, ensemble_iq):
 
 
 def test_device_alloc_apart(built):
-    """dabgpu_device_alloc_apart: small requests are plain allocations; a large one next to a large reference is
-    probed (three candidates at most) and usable; bad arguments are refused."""
+    """dabgpu_device_alloc_apart: small requests are plain allocations; a large one next to a large reference goes through
+    the chunk arena (never more than 1.2 x its size + one chunk held), is usable like any device memory and goes back
+    on free; bad arguments are refused."""
     import torch
     c = make_ctx(None, 8)
     p, ms = c.device_alloc_apart(4096)
@@ -284,13 +285,18 @@ def test_device_alloc_apart(built):
     c.device_free(p)
     dev = torch.device("cuda", 0)
     ref = torch.zeros((1 << 30,), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
     p, ms = c.device_alloc_apart(512 << 20, ref.data_ptr(), ref.numel())
-    assert p and ms[0] > 0 and all(x >= 0 for x in ms)
+    assert p and ms[0] > 0 and 0 <= ms[1] <= 1000 and ms[2] > 0
+    assert free0 - torch.cuda.mem_get_info()[0] <= (512 << 20) + (64 << 20)      # two 256 MiB chunks, the spare released
     t = dabgpu.device_tensor(torch, p, (512 << 20,), torch.uint8, dev)
     t.fill_(7)
-    assert int(t[-1].item()) == 7
+    assert int(t[-1].item()) == 7 and int(t[(256 << 20) - 1].item()) == 7
     del t
     c.device_free(p)
+    torch.cuda.synchronize()
+    assert free0 - torch.cuda.mem_get_info()[0] <= 64 << 20
     with pytest.raises(dabgpu.DabGpuError):
         c.device_alloc_apart(0)
     c.close()
