@@ -390,6 +390,12 @@ typedef struct dabgpu_acquire_cfg {
                                  /* with at least max(rel x peak power, 16 x mean) replaces it, so   */
                                  /* that a stronger LATE echo still falls inside the cyclic prefix   */
                                  /* (0.25 = -6 dB); 0 = the scored peak itself, the reference's rule */
+    int32_t level_chunk_blocks;  /* the null thresholds follow the LOCAL level: mean block norm over    */
+                                 /* chunks of this many 64-sample blocks, averaged over chunks c-2..c+2 */
+                                 /* (power of two, 64..16384; 256 = 8 ms chunks, a 40 ms window) -- the   */
+                                 /* batch counterpart of the reference's running average                */
+                                 /* (signal_l1.update_beta, :235); 0 = the mean of the whole capture     */
+    int32_t reserved;
 } dabgpu_acquire_cfg;
 
 typedef struct dabgpu_acquired_frame {

@@ -555,6 +555,12 @@ void oracle_null_block_l1(const float *iq, int64_t n_samples, float *l1)
 int oracle_null_search(const float *iq, int64_t n_samples, float thr_start, float thr_end, int min_blocks,
                        int max_out, int64_t *cands)
 {
+    return oracle_null_search_ex(iq, n_samples, thr_start, thr_end, min_blocks, 0, max_out, cands);
+}
+
+int oracle_null_search_ex(const float *iq, int64_t n_samples, float thr_start, float thr_end, int min_blocks,
+                          int level_chunk, int max_out, int64_t *cands)
+{
     const int64_t nb = n_samples / 64;
     if (nb <= 0 || max_out <= 0) return 0;
     float *l1 = (float *)malloc(sizeof(float) * (size_t)nb);
@@ -575,11 +581,43 @@ int oracle_null_search(const float *iq, int64_t n_samples, float thr_start, floa
     }
     for (int w = 1; w < 16; w++) p[0] += p[64 * w];
     const float avg = (float)(p[0] / (double)nb);
-    const float ts = thr_start * avg, te = thr_end * avg;
+    /* local level: mean of every chunk of level_chunk blocks (64 strided partial sums in double, the butterfly over
+       them), the level at a block = mean of the chunk means c-2 .. c+2 that exist */
+    double *cm = NULL;
+    int64_t nc = 0;
+    if (level_chunk > 0) {
+        nc = (nb + level_chunk - 1) / level_chunk;
+        cm = (double *)malloc(sizeof(double) * (size_t)nc);
+        for (int64_t c = 0; c < nc; c++) {
+            const int64_t b0 = c * level_chunk, b1 = (b0 + level_chunk < nb) ? b0 + level_chunk : nb;
+            double g[64], h[64];
+            for (int j = 0; j < 64; j++) {
+                double a = 0.0;
+                for (int64_t b = b0 + j; b < b1; b += 64) a += (double)l1[b];
+                g[j] = a;
+            }
+            for (int off = 1; off < 64; off <<= 1) {
+                for (int j = 0; j < 64; j++) h[j] = g[j] + g[j ^ off];
+                memcpy(g, h, sizeof(h));
+            }
+            cm[c] = g[0] / (double)(b1 - b0);
+        }
+    }
+    float ts = thr_start * avg, te = thr_end * avg;
     const int max_blocks = 2 * DAB_NB_NULL_PERIOD / 64;                       /* 83 */
     int count = 0, state = 0;
     int64_t dip_begin = 0;
     for (int64_t b = 0; b < nb && count < max_out; b++) {
+        if (cm && (b % level_chunk) == 0) {
+            const int64_t c = b / level_chunk;
+            double a = 0.0;
+            int k = 0;
+            for (int64_t j = c - 2; j <= c + 2; j++)
+                if (j >= 0 && j < nc) { a += cm[j]; k++; }
+            const float level = (float)(a / (double)k);
+            ts = thr_start * level;
+            te = thr_end * level;
+        }
         if (state == 0) {
             if (l1[b] < ts) { state = 1; dip_begin = b; }
         } else if (l1[b] > te) {
@@ -592,6 +630,7 @@ int oracle_null_search(const float *iq, int64_t n_samples, float thr_start, floa
         }
     }
     free(l1);
+    free(cm);
     return count;
 }
 

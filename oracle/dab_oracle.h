@@ -154,6 +154,11 @@ void oracle_sync_prs_ex(const float *sym, float freq_offset, int max_coarse, int
 void oracle_null_block_l1(const float *iq, int64_t n_samples, float *l1);
 int  oracle_null_search(const float *iq, int64_t n_samples, float thr_start, float thr_end, int min_blocks,
                         int max_out, int64_t *cands);
+/* level_chunk > 0: the thresholds follow the LOCAL signal level instead of the capture's mean -- the mean block norm of
+ * every chunk of level_chunk blocks, averaged over the chunks c-2 .. c+2 (what the reference's running average
+ * signal_l1.update_beta does for a stream: a slow fade must not look like a null symbol); 0 = the capture's mean. */
+int  oracle_null_search_ex(const float *iq, int64_t n_samples, float thr_start, float thr_end, int min_blocks,
+                           int level_chunk, int max_out, int64_t *cands);
 /* One candidate -> frame: fractional frequency error from the cyclic prefix of the PRS (samples 64..439 of the
  * candidate's prefix against the samples 2048 later), then oracle_sync_prs with that correction.
  *   fine_offset     = -angle(sum conj(x[i]) x[i+2048]) / (2 pi 2048)   cycles/sample

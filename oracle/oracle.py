@@ -364,13 +364,14 @@ def null_block_l1(iq):
     return out
 
 
-def null_search(iq, thr_start=0.35, thr_end=0.75, min_blocks=30, max_out=64):
-    """Candidate PRS starts (sample indices) of every whole frame in an unaligned capture."""
+def null_search(iq, thr_start=0.35, thr_end=0.75, min_blocks=30, max_out=64, level_chunk=256):
+    """Candidate PRS starts (sample indices) of every whole frame in an unaligned capture.  level_chunk: blocks per
+    chunk of the local level estimate (0 = thresholds relative to the capture's mean); default = dabgpu_acquire_default_cfg's."""
     a = np.ascontiguousarray(iq, np.complex64).ravel()
     out = np.zeros(max_out, np.int64)
-    lib().oracle_null_search.restype = C.c_int
-    n = lib().oracle_null_search(_p(a), C.c_int64(a.size), C.c_float(thr_start), C.c_float(thr_end), C.c_int(min_blocks),
-                                 C.c_int(max_out), _p(out))
+    lib().oracle_null_search_ex.restype = C.c_int
+    n = lib().oracle_null_search_ex(_p(a), C.c_int64(a.size), C.c_float(thr_start), C.c_float(thr_end), C.c_int(min_blocks),
+                                    C.c_int(level_chunk), C.c_int(max_out), _p(out))
     return out[:n]
 
 

@@ -1482,6 +1482,8 @@ void dabgpu_acquire_default_cfg(dabgpu_acquire_cfg *cfg) {
     cfg->timing_margin = 64;
     cfg->impulse_peak_distance_probability = 0.15f;
     cfg->first_path_rel = 0.25f;
+    cfg->level_chunk_blocks = 256;
+    cfg->reserved = 0;
 }
 
 static bool peak_rule_ok(float distance_prob, float first_path_rel) {
@@ -1500,7 +1502,9 @@ int dabgpu_acquire_dev(dabgpu_ctx *ctx, const void *d_iq, size_t stream_stride, 
     if (cfg) c = *cfg; else dabgpu_acquire_default_cfg(&c);
     if (c.max_coarse_carriers < 0 || c.max_coarse_carriers > 1023 || c.min_null_blocks < 1 || c.timing_margin < 0 ||
         c.timing_margin > NB_CP || !(c.thr_null_start > 0.f) || !(c.thr_null_end >= c.thr_null_start) ||
-        !peak_rule_ok(c.impulse_peak_distance_probability, c.first_path_rel))
+        !peak_rule_ok(c.impulse_peak_distance_probability, c.first_path_rel) ||
+        (c.level_chunk_blocks != 0 && (c.level_chunk_blocks < 64 || c.level_chunk_blocks > 16384 ||
+                                       (c.level_chunk_blocks & (c.level_chunk_blocks - 1)))))
         return DABGPU_ERR_ARG;
     if (n_streams == 0) return DABGPU_OK;
     hipStream_t s = pick_stream(ctx, stream);
@@ -1525,6 +1529,7 @@ int dabgpu_acquire_dev(dabgpu_ctx *ctx, const void *d_iq, size_t stream_stride, 
     a.n_samples = n_samples;
     a.thr_start = c.thr_null_start;
     a.thr_end = c.thr_null_end;
+    a.level_chunk = c.level_chunk_blocks;
     a.min_blocks = c.min_null_blocks;
     a.max_coarse = c.max_coarse_carriers;
     a.min_peak_to_mean = c.min_peak_to_mean;

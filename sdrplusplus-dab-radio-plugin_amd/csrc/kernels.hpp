@@ -123,7 +123,9 @@ struct AcquireArgs {
     size_t stream_stride;      // complex samples
     int n_streams;
     int64_t n_samples;         // per stream
-    float thr_start, thr_end;  // null-symbol dip thresholds relative to the mean block L1
+    float thr_start, thr_end;  // null-symbol dip thresholds relative to the (local) mean block L1
+    int level_chunk;           // blocks per chunk of the local level estimate (power of two, 64..16384); 0 = capture mean
+    const double *chunk_mean;  // scratch [n_streams][ceil(nb / level_chunk)], set by launch_acquire
     int min_blocks;            // shortest dip (64-sample blocks) accepted as a null symbol
     int max_coarse;            // carriers
     float min_peak_to_mean;

@@ -574,6 +574,31 @@ __global__ __launch_bounds__(MEAN_THREADS) void null_mean_kernel(const float *l1
     }
 }
 
+// Local level: the mean block norm of every chunk of `chunk` blocks -- one wave per chunk: 64 strided partial sums in
+// double, XOR butterfly (the fixed tree the oracle restates).  The thresholds at a block use the mean of the chunk means
+// c-2 .. c+2 that exist (local_level below): what the reference's running average (signal_l1.update_beta) does for a
+// stream -- a slow fade must not look like a null symbol, nor hide one.
+__global__ __launch_bounds__(64) void null_level_kernel(const float *l1_all, int64_t nb, int chunk, int64_t nc, double *cm_all) {
+    const int st = blockIdx.y, lane = threadIdx.x;
+    const float *l1 = l1_all + size_t(st) * nb;
+    for (int64_t c = blockIdx.x; c < nc; c += gridDim.x) {
+        const int64_t b0 = c * chunk, b1 = min(nb, b0 + chunk);
+        double acc = 0.0;
+        for (int64_t b = b0 + lane; b < b1; b += 64) acc += double(l1[b]);
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) acc += __shfl_xor(acc, off);
+        if (lane == 0) cm_all[size_t(st) * nc + c] = acc / double(b1 - b0);
+    }
+}
+
+__device__ __forceinline__ float local_level(const double *cm, int64_t nc, int64_t c) {
+    double a = 0.0;
+    int k = 0;
+    for (int64_t j = c - 2; j <= c + 2; j++)
+        if (j >= 0 && j < nc) { a += cm[j]; k++; }
+    return float(a / double(k));
+}
+
 __device__ __forceinline__ bool dip_is_null_symbol(const AcquireArgs &a, int64_t dip_begin, int64_t end_block, int64_t *cand) {
     const int max_blocks = 2 * NB_NULL_PERIOD / 64;
     const int64_t len = end_block - dip_begin;
@@ -589,8 +614,14 @@ __global__ __launch_bounds__(64) void null_segment_kernel(AcquireArgs a, int64_t
     const int seg = blockIdx.x, st = blockIdx.y;
     const int lane = threadIdx.x;
     const float *l1 = a.l1 + size_t(st) * nb;
-    const float mean = avg[st];
-    const float ts = __fmul_rn(a.thr_start, mean), te = __fmul_rn(a.thr_end, mean);
+    float ts = 0.f, te = 0.f;
+    const int64_t nc = a.level_chunk ? (nb + a.level_chunk - 1) / a.level_chunk : 0;
+    const double *cm = a.level_chunk ? a.chunk_mean + size_t(st) * nc : nullptr;
+    if (!a.level_chunk) {
+        const float mean = avg[st];
+        ts = __fmul_rn(a.thr_start, mean);
+        te = __fmul_rn(a.thr_end, mean);
+    }
     const int64_t b0 = int64_t(seg) * SEG_BLOCKS, b1 = min(nb, b0 + SEG_BLOCKS);
     int64_t *cands = seg_cands + (size_t(st) * n_seg + seg) * a.max_out;
     int64_t h = -1, l0 = -1, dip_begin = 0;
@@ -605,6 +636,11 @@ __global__ __launch_bounds__(64) void null_segment_kernel(AcquireArgs a, int64_t
                 const int64_t bj = base + 64 * j + lane;
                 vbuf[j] = bj < b1 ? l1[bj] : 0.0f;
             }
+        }
+        if (a.level_chunk && ((base - b0) & int64_t(a.level_chunk - 1)) == 0) {   // a trip of 64 blocks lies inside one chunk
+            const float level = local_level(cm, nc, base / a.level_chunk);
+            ts = __fmul_rn(a.thr_start, level);
+            te = __fmul_rn(a.thr_end, level);
         }
         const int64_t b = base + lane;
         float v = vbuf[0];
@@ -724,7 +760,7 @@ size_t acquire_scratch_bytes(int n_streams, int64_t n_samples, int max_out) {
     const size_t nb = size_t(n_samples / 64), n_seg = dip_segments(int64_t(nb));
     return al256(size_t(n_streams) * nb * sizeof(float)) + al256(size_t(n_streams) * max_out * sizeof(int64_t)) +
            al256(size_t(n_streams) * sizeof(float)) + al256(size_t(n_streams) * n_seg * sizeof(DipSegment)) +
-           size_t(n_streams) * n_seg * max_out * sizeof(int64_t);
+           al256(size_t(n_streams) * n_seg * max_out * sizeof(int64_t)) + al256(size_t(n_streams) * (nb / 64 + 1) * sizeof(double));
 }
 
 hipError_t launch_acquire(const SyncTables &t, const AcquireArgs &a, hipStream_t s) {
@@ -741,13 +777,24 @@ hipError_t launch_acquire(const SyncTables &t, const AcquireArgs &a, hipStream_t
     DipSegment *segs = reinterpret_cast<DipSegment *>(p);
     p += al256(size_t(a.n_streams) * n_seg * sizeof(DipSegment));
     int64_t *seg_cands = reinterpret_cast<int64_t *>(p);
-    hipLaunchKernelGGL(null_mean_kernel, dim3(unsigned(a.n_streams)), dim3(MEAN_THREADS), 0, s, a.l1, nb, avg);
-    hipLaunchKernelGGL(null_segment_kernel, dim3(unsigned(n_seg), unsigned(a.n_streams)), dim3(64), 0, s, a, nb, n_seg, avg, segs,
+    p += al256(size_t(a.n_streams) * n_seg * a.max_out * sizeof(int64_t));
+    AcquireArgs b = a;
+    if (a.level_chunk) {
+        if (a.level_chunk < 64 || a.level_chunk > SEG_BLOCKS || (a.level_chunk & (a.level_chunk - 1))) return hipErrorInvalidValue;
+        const int64_t nc = (nb + a.level_chunk - 1) / a.level_chunk;
+        double *cm = reinterpret_cast<double *>(p);
+        b.chunk_mean = cm;
+        hipLaunchKernelGGL(null_level_kernel, dim3(unsigned(std::min<int64_t>(nc, 4096)), unsigned(a.n_streams)), dim3(64), 0, s, a.l1, nb,
+                           a.level_chunk, nc, cm);
+    } else {
+        hipLaunchKernelGGL(null_mean_kernel, dim3(unsigned(a.n_streams)), dim3(MEAN_THREADS), 0, s, a.l1, nb, avg);
+    }
+    hipLaunchKernelGGL(null_segment_kernel, dim3(unsigned(n_seg), unsigned(a.n_streams)), dim3(64), 0, s, b, nb, n_seg, avg, segs,
                        seg_cands);
-    hipLaunchKernelGGL(null_stitch_kernel, dim3(unsigned(a.n_streams)), dim3(64), 0, s, a, n_seg, segs, seg_cands);
+    hipLaunchKernelGGL(null_stitch_kernel, dim3(unsigned(a.n_streams)), dim3(64), 0, s, b, n_seg, segs, seg_cands);
     hipLaunchKernelGGL(prs_sync_kernel<MODE_ACQ>, dim3(sync_grid(a.n_streams * a.max_out)), dim3(WG), 0, s, t,
                        static_cast<const float2 *>(nullptr), size_t(0), static_cast<const float *>(nullptr), 0,
-                       static_cast<SyncResult *>(nullptr), a, TrackArgs{}, a.n_streams * a.max_out);
+                       static_cast<SyncResult *>(nullptr), b, TrackArgs{}, a.n_streams * a.max_out);
     return hipGetLastError();
 }
 

@@ -99,7 +99,8 @@ class SyncResult(C.Structure):
 class AcquireCfg(C.Structure):
     _fields_ = [("thr_null_start", C.c_float), ("thr_null_end", C.c_float), ("min_null_blocks", C.c_int32),
                 ("max_coarse_carriers", C.c_int32), ("min_peak_to_mean", C.c_float), ("timing_margin", C.c_int32),
-                ("impulse_peak_distance_probability", C.c_float), ("first_path_rel", C.c_float)]
+                ("impulse_peak_distance_probability", C.c_float), ("first_path_rel", C.c_float),
+                ("level_chunk_blocks", C.c_int32), ("reserved", C.c_int32)]
 
 
 class TrackCfg(C.Structure):

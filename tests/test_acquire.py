@@ -63,6 +63,30 @@ def test_oracle_ignores_short_dips_and_silence():
     assert len(O.null_search(np.zeros(4096, np.complex64))) == 0
 
 
+def faded_capture(seed=17, n_frames=10, depth_db=14.0, hz=3.0):
+    """A capture whose level swings by `depth_db` at `hz` (a deep slow fade), cut at an odd place."""
+    e = synth.Ensemble(seed=seed, n_frames=4)
+    tx = np.tile(e.iq().ravel(), (n_frames + 3) // 4)[:n_frames * FRAME]
+    t = np.arange(tx.size) / 2.048e6
+    lo = 10 ** (-depth_db / 20.0)
+    gain = lo + (1.0 - lo) * 0.5 * (1.0 + np.cos(2 * np.pi * hz * t))
+    rng = np.random.default_rng(seed)
+    x = synth.channel(tx, snr_db=28.0, cfo=0.8 / 2048, rng=rng, gain=gain)[70001:]
+    starts = np.array([k * FRAME + NULL - 70001 for k in range(1, n_frames) if k * FRAME + NULL - 70001 + SYMS + 512 <= x.size])
+    return x, starts, e
+
+
+def test_oracle_null_search_follows_the_local_level():
+    """Thresholds relative to the capture's mean lose frames in a deep slow fade (the faded signal sits below
+    thr_start x mean: one endless 'dip'); relative to the local level (level_chunk 256 = the default) every frame is
+    found -- what the reference's running level average does for a stream."""
+    x, starts, _ = faded_capture()
+    local = O.null_search(x, level_chunk=256)
+    whole = O.null_search(x, level_chunk=0)
+    assert len(local) == len(starts) and (np.abs(local - starts) <= 96).all()
+    assert len(whole) < len(starts)
+
+
 # ------------------------------------------------------------------ GPU
 @pytest.fixture(scope="module")
 def gctx(built):
@@ -92,6 +116,32 @@ def test_gpu_acquire_matches_oracle(gctx, snr, cfo, cut):
             assert abs(g["peak_to_mean"] - r.peak_to_mean) <= 2e-3 * r.peak_to_mean
             assert abs(g["coarse_peak_to_mean"] - r.coarse_peak_to_mean) <= 2e-3 * r.coarse_peak_to_mean
         assert (frames[s, counts[s]:]["flags"] == 0).all() and (frames[s, counts[s]:]["start"] == -1).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chunk", [256, 64, 4096, 0])
+def test_gpu_null_search_with_local_level_matches_oracle(gctx, chunk):
+    """The local-level thresholds (dabgpu_acquire_cfg.level_chunk_blocks) on a deeply faded capture and on a plain one:
+    the same candidates as the oracle's sequential search, for several chunk sizes and for the capture-mean rule."""
+    import dabgpu
+    cfg = dabgpu.acquire_cfg(timing_margin=0, level_chunk_blocks=chunk)
+    xf, starts, _ = faded_capture()
+    xp, _, _, _ = capture(33, 10, 70001, 0, 18.0, -1.7)
+    n = min(xf.size, xp.size)
+    iq = np.stack([xf[:n], xp[:n]])
+    frames, counts = gctx.acquire(iq, 12, cfg)
+    for s in range(2):
+        cands = O.null_search(iq[s], max_out=12, level_chunk=chunk)
+        assert counts[s] == len(cands), (chunk, s, counts[s], len(cands))
+        for j, c in enumerate(cands):
+            r = O.acquire_candidate(iq[s], c, margin=0)
+            g = frames[s, j]
+            assert (g["start"], g["coarse_carriers"], g["flags"]) == (r.start, r.coarse_carriers, r.flags), (chunk, s, j)
+    if chunk in (64, 256):
+        st = starts[starts + SYMS + 512 <= n]
+        assert counts[0] == len(st) and (np.abs(frames[0, :counts[0]]["start"] - st) <= 2).all()
+    with pytest.raises(dabgpu.DabGpuError):
+        gctx.acquire(iq, 12, dabgpu.acquire_cfg(level_chunk_blocks=100))
 
 
 @pytest.mark.gpu

@@ -356,15 +356,14 @@ def test_gpu_tracking_through_random_channels(tctx):
     assert call >= 5
     st = read_states(torch, tctx, S)
     for s in range(S):
-        # acquisition finds frames by their null symbols against the capture's mean level: under fading it may miss one
-        # (the tracked calls do not depend on the level: from the second capture on every frame is there, once, in order)
+        # acquisition finds the frames by their null symbols against the LOCAL level (dabgpu_acquire_cfg.level_chunk_blocks):
+        # with thresholds relative to the capture's mean a fade cost this test two of the eight frames of stream 1
         first = [k for c, k in seen[s] if c == 0]
         rest = [k for c, k in seen[s] if c > 0]
-        assert len(first) >= 5 and first == sorted(set(first))
-        assert rest[0] - first[-1] in (1, 2), (s, seen[s])            # (a frame the acquisition missed at the capture's end)
-        assert rest == list(range(rest[0], rest[0] + len(rest))) and len(rest) >= 30, (s, seen[s])
-        # (desyncs: the frame missed at the hand-over, and at most one frame whose level a fade took below the null threshold)
-        assert st[s]["tracking"] == 1 and 0 <= st[s]["total_frames_desync"] - (rest[0] - first[-1] - 1) <= 1
+        assert first == list(range(first[0], first[0] + 8)), (s, first)
+        assert rest == list(range(first[-1] + 1, first[-1] + 1 + len(rest))) and len(rest) >= 30, (s, seen[s])
+        # (desyncs: at most one frame whose level a fade took below the null threshold -- it is demodulated all the same)
+        assert st[s]["tracking"] == 1 and st[s]["total_frames_desync"] <= 1
         assert abs(float(st[s]["drift"]) - meta[s][0] * 1e-6 * L) < 0.5, (s, st[s]["drift"], meta[s])
 
 
