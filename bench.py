@@ -694,15 +694,16 @@ def closed_loop_leg(torch, dabgpu, synth, ctx, dev, stream, iq, ens, sc, soft, f
     advance = per_stream * L
     soft.zero_(); fib.zero_(); crc.zero_(); msc.zero_()
     ctx.streams_reset(E)
-    ctx.acquire_dev(d_cap, F * L, E, n_samples, F, acq.data_ptr(), counts.data_ptr(), None, stream)
-    ctx.track_start_dev(acq.data_ptr(), counts.data_ptr(), E, F, advance, stream)
-    acq.zero_(); counts.zero_()
+    tcfg = dabgpu.track_cfg(auto_acquire=1)          # streams that are not tracking are acquired inside the call
 
     def tstep():
         ctx.ofdm_demod_tracked_dev(d_cap, F * L, E, n_samples, F, advance, soft.data_ptr(), acq.data_ptr(), counts.data_ptr(),
-                                   None, None, None, stream)
+                                   tcfg, None, None, stream)
         ctx.decode_frames_dev(soft.data_ptr(), dabgpu.NB_FRAME_BITS, E, F, fib.data_ptr(), crc.data_ptr(), [sc],
                               [None], [None], [msc.data_ptr()], stream)
+    tstep()                                          # the first call: every stream acquired (untimed, as in a receiver's life)
+    torch.cuda.synchronize()
+    assert all(ctx.get_stats(s).tracking == 1 for s in range(E)), "auto-acquisition did not lock every stream"
     for k in range(2):
         tstep()
     torch.cuda.synchronize()
@@ -712,7 +713,7 @@ def closed_loop_leg(torch, dabgpu, synth, ctx, dev, stream, iq, ens, sc, soft, f
         if k == steps - 1:
             tev[0].record()
             ctx.ofdm_demod_tracked_dev(d_cap, F * L, E, n_samples, F, advance, soft.data_ptr(), acq.data_ptr(), counts.data_ptr(),
-                                       None, None, None, stream)
+                                       tcfg, None, None, stream)
             tev[1].record()
             ctx.decode_frames_dev(soft.data_ptr(), dabgpu.NB_FRAME_BITS, E, F, fib.data_ptr(), crc.data_ptr(), [sc],
                                   [None], [None], [msc.data_ptr()], stream)
@@ -730,9 +731,11 @@ def closed_loop_leg(torch, dabgpu, synth, ctx, dev, stream, iq, ens, sc, soft, f
                        "streams_tracking": int(sum(st.tracking for st in stats)),
                        "frames_desync_total": int(sum(st.total_frames_desync for st in stats)),
                        "max_abs_drift_samples_per_frame": float(max(abs(st.drift) for st in stats)),
-                       "what": "acquired once (dabgpu_acquire_dev + dabgpu_track_start_dev, untimed); every step: "
-                               "dabgpu_ofdm_demod_tracked_dev (PRS synchronisation at the predicted positions, demodulation in "
-                               "place, state update on the device) -> dabgpu_decode_frames_dev"}
+                       "auto_acquire": True,
+                       "what": "ONE entry point from the first capture on: dabgpu_ofdm_demod_tracked_dev with cfg.auto_acquire -- the "
+                               "first call (untimed) acquired every stream inside the call; every timed step: PRS synchronisation at "
+                               "the predicted positions, demodulation in place, state update on the device (a stream that lost "
+                               "lock would be re-acquired by the next call) -> dabgpu_decode_frames_dev"}
     return out
 
 

@@ -443,7 +443,8 @@ int dabgpu_ofdm_demod_acquired_dev(dabgpu_ctx *ctx, const void *d_iq, size_t str
 /*              dabgpu_ofdm_demod_acquired_dev (slots without a locked frame:    */
 /*              erased soft bits).  cyc may be NULL.                            */
 /* A stream none of whose frames locked in a call stops tracking (state 0 in     */
-/* dabgpu_get_stats): acquire it again.                                         */
+/* dabgpu_get_stats): acquire it again -- or set cfg.auto_acquire and the next   */
+/* call does (then the very first call needs no dabgpu_acquire_dev either).      */
 /* ------------------------------------------------------------------------ */
 typedef struct dabgpu_track_cfg {
     float fine_freq_update_beta;              /* 0.9                                                   */
@@ -455,12 +456,21 @@ typedef struct dabgpu_track_cfg {
     float drift_beta;                         /* share of a measured drift error taken per call (0.5)  */
     float coarse_freq_slow_beta;              /* frame call: see below (0.1)                           */
     int32_t timing_margin;                    /* 64 (batch calls); the frame call uses the host's own   */
-    int32_t max_coarse_carriers;              /* frame call: whole-carrier search range, 0 = off (204) */
-    int32_t reserved[2];
+    int32_t max_coarse_carriers;              /* frame call and auto-acquisition: whole-carrier search */
+                                              /* range, 0 = off (204)                                  */
+    int32_t auto_acquire;                     /* tracked call: != 0 = streams that are not tracking    */
+                                              /* (never acquired, or lost) are ACQUIRED inside the     */
+                                              /* call -- null-symbol search + PRS on their capture as  */
+                                              /* dabgpu_acquire_dev does, their frames demodulated     */
+                                              /* with the others', their tracking started; streams     */
+                                              /* that are tracking cost nothing extra.  One call does  */
+                                              /* everything from the first capture on (0)              */
+    int32_t reserved;
 } dabgpu_track_cfg;
 void dabgpu_track_default_cfg(dabgpu_track_cfg *cfg);
+/* only_lost != 0: streams that are tracking keep their state (re-acquisition of the lost ones beside them) */
 int dabgpu_track_start_dev(dabgpu_ctx *ctx, const dabgpu_acquired_frame *d_frames, const int32_t *d_counts, int n_streams,
-                           int max_frames, int64_t advance, void *stream);
+                           int max_frames, int64_t advance, int only_lost, void *stream);
 int dabgpu_ofdm_demod_tracked_dev(dabgpu_ctx *ctx, const void *d_iq, size_t stream_stride, int n_streams,
                                   int64_t n_samples, int max_frames, int64_t advance, const dabgpu_track_cfg *cfg,
                                   int8_t *d_soft, void *d_cyc, void *d_dqpsk, dabgpu_acquired_frame *d_frames,

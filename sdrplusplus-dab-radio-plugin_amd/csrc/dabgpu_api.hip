@@ -1490,29 +1490,10 @@ static bool peak_rule_ok(float distance_prob, float first_path_rel) {
     return distance_prob >= 0.f && distance_prob <= 1.f && first_path_rel >= 0.f && first_path_rel <= 1.f;
 }
 
-int dabgpu_acquire_dev(dabgpu_ctx *ctx, const void *d_iq, size_t stream_stride, int n_streams, int64_t n_samples,
-                       const dabgpu_acquire_cfg *cfg, int max_frames, dabgpu_acquired_frame *d_out, int32_t *d_counts,
-                       void *stream) {
-    static_assert(sizeof(dabgpu_acquired_frame) == 32 && sizeof(dabk::AcquiredFrame) == 32, "acquired-frame layout");
-    if (!ctx || !d_iq || !d_out || !d_counts || n_streams < 0 || max_frames <= 0 || n_samples < 0) return DABGPU_ERR_ARG;
-    DeviceGuard guard(ctx);
-    if (reinterpret_cast<uintptr_t>(d_iq) & 7u) return DABGPU_ERR_ARG;
-    if (n_streams > 1 && stream_stride < size_t(n_samples)) return DABGPU_ERR_ARG;
-    dabgpu_acquire_cfg c;
-    if (cfg) c = *cfg; else dabgpu_acquire_default_cfg(&c);
-    if (c.max_coarse_carriers < 0 || c.max_coarse_carriers > 1023 || c.min_null_blocks < 1 || c.timing_margin < 0 ||
-        c.timing_margin > NB_CP || !(c.thr_null_start > 0.f) || !(c.thr_null_end >= c.thr_null_start) ||
-        !peak_rule_ok(c.impulse_peak_distance_probability, c.first_path_rel) ||
-        (c.level_chunk_blocks != 0 && (c.level_chunk_blocks < 64 || c.level_chunk_blocks > 16384 ||
-                                       (c.level_chunk_blocks & (c.level_chunk_blocks - 1)))))
-        return DABGPU_ERR_ARG;
-    if (n_streams == 0) return DABGPU_OK;
-    hipStream_t s = pick_stream(ctx, stream);
-    if (n_samples < 64) {                                      // nothing to search: no frames anywhere
-        HIP_TRY(hipMemsetAsync(d_counts, 0, sizeof(int32_t) * n_streams, s));
-        HIP_TRY(hipMemsetAsync(d_out, 0, sizeof(dabgpu_acquired_frame) * size_t(n_streams) * max_frames, s));
-        return DABGPU_OK;
-    }
+// scratch + argument block of the acquisition kernels (dabgpu_acquire_dev, auto-acquisition of the tracked call)
+static int acquire_args(dabgpu_ctx *ctx, const void *d_iq, size_t stream_stride, int n_streams, int64_t n_samples,
+                        const dabgpu_acquire_cfg &c, int max_frames, dabgpu_acquired_frame *d_out, int32_t *d_counts,
+                        hipStream_t s, dabk::AcquireArgs &a) {
     const size_t need = dabk::acquire_scratch_bytes(n_streams, n_samples, max_frames);
     if (ctx->acq_scratch_bytes < need) {
         HIP_TRY(hipStreamSynchronize(s));
@@ -1522,7 +1503,6 @@ int dabgpu_acquire_dev(dabgpu_ctx *ctx, const void *d_iq, size_t stream_stride, 
         if (hipMalloc(&ctx->d_acq_scratch, need) != hipSuccess) return DABGPU_ERR_NOMEM;
         ctx->acq_scratch_bytes = need;
     }
-    dabk::AcquireArgs a{};
     a.iq = static_cast<const float2 *>(d_iq);
     a.stream_stride = stream_stride;
     a.n_streams = n_streams;
@@ -1543,6 +1523,35 @@ int dabgpu_acquire_dev(dabgpu_ctx *ctx, const void *d_iq, size_t stream_stride, 
     a.cands = reinterpret_cast<int64_t *>(static_cast<char *>(ctx->d_acq_scratch) + l1_bytes);
     a.out = reinterpret_cast<dabk::AcquiredFrame *>(d_out);
     a.counts = d_counts;
+    return DABGPU_OK;
+}
+
+int dabgpu_acquire_dev(dabgpu_ctx *ctx, const void *d_iq, size_t stream_stride, int n_streams, int64_t n_samples,
+                       const dabgpu_acquire_cfg *cfg, int max_frames, dabgpu_acquired_frame *d_out, int32_t *d_counts,
+                       void *stream) {
+    static_assert(sizeof(dabgpu_acquired_frame) == 32 && sizeof(dabk::AcquiredFrame) == 32, "acquired-frame layout");
+    if (!ctx || !d_iq || !d_out || !d_counts || n_streams < 0 || max_frames <= 0 || n_samples < 0) return DABGPU_ERR_ARG;
+    DeviceGuard guard(ctx);
+    if (reinterpret_cast<uintptr_t>(d_iq) & 7u) return DABGPU_ERR_ARG;
+    if (n_streams > 1 && stream_stride < size_t(n_samples)) return DABGPU_ERR_ARG;
+    dabgpu_acquire_cfg c;
+    if (cfg) c = *cfg; else dabgpu_acquire_default_cfg(&c);
+    if (c.max_coarse_carriers < 0 || c.max_coarse_carriers > 1023 || c.min_null_blocks < 1 || c.timing_margin < 0 ||
+        c.timing_margin > NB_CP || !(c.thr_null_start > 0.f) || !(c.thr_null_end >= c.thr_null_start) ||
+        !peak_rule_ok(c.impulse_peak_distance_probability, c.first_path_rel) ||
+        (c.level_chunk_blocks != 0 && (c.level_chunk_blocks < 64 || c.level_chunk_blocks > 16384 ||
+                                       (c.level_chunk_blocks & (c.level_chunk_blocks - 1)))))
+        return DABGPU_ERR_ARG;
+    if (n_streams == 0) return DABGPU_OK;
+    hipStream_t s = pick_stream(ctx, stream);
+    int rc2;
+    if (n_samples < 64) {                                      // nothing to search: no frames anywhere
+        HIP_TRY(hipMemsetAsync(d_counts, 0, sizeof(int32_t) * n_streams, s));
+        HIP_TRY(hipMemsetAsync(d_out, 0, sizeof(dabgpu_acquired_frame) * size_t(n_streams) * max_frames, s));
+        return DABGPU_OK;
+    }
+    dabk::AcquireArgs a{};
+    if ((rc2 = acquire_args(ctx, d_iq, stream_stride, n_streams, n_samples, c, max_frames, d_out, d_counts, s, a))) return rc2;
     dabk::SyncTables tab{ctx->d_twiddle, ctx->d_prs_qt, ctx->d_sync_pairs, ctx->n_sync_pairs, ctx->d_sync_fs};
     HIP_TRY(dabk::launch_acquire(tab, a, s));
     return DABGPU_OK;
@@ -1618,6 +1627,7 @@ void dabgpu_track_default_cfg(dabgpu_track_cfg *cfg) {
     cfg->coarse_freq_slow_beta = 0.1f;
     cfg->timing_margin = 64;
     cfg->max_coarse_carriers = 204;
+    cfg->auto_acquire = 0;
 }
 
 static int track_cfg(const dabgpu_track_cfg *cfg, dabgpu_track_cfg &c) {
@@ -1632,14 +1642,25 @@ static int track_cfg(const dabgpu_track_cfg *cfg, dabgpu_track_cfg &c) {
 }
 
 int dabgpu_track_start_dev(dabgpu_ctx *ctx, const dabgpu_acquired_frame *d_frames, const int32_t *d_counts, int n_streams,
-                           int max_frames, int64_t advance, void *stream) {
+                           int max_frames, int64_t advance, int only_lost, void *stream) {
     if (!ctx || !d_frames || !d_counts || n_streams < 0 || max_frames <= 0 || advance < 0) return DABGPU_ERR_ARG;
     DeviceGuard guard(ctx);
     if (n_streams > ctx->n_states) return DABGPU_ERR_CAPACITY;   // dabgpu_streams_reset first
     if (n_streams == 0) return DABGPU_OK;
     hipStream_t s = pick_stream(ctx, stream);
     HIP_TRY(dabk::launch_track_start(ctx->d_states, reinterpret_cast<const dabk::AcquiredFrame *>(d_frames), d_counts, n_streams,
-                                     max_frames, advance, s));
+                                     max_frames, advance, only_lost ? 1 : 0, s));
+    if (only_lost) {
+        // (tracking = 2 marks "started in this call" for the tracked call's own use; a stand-alone start has no update
+        // launch behind it: turn the marks into 1 here)
+        dabk::TrackUpdateArgs u{};
+        u.state = ctx->d_states;
+        u.n_streams = n_streams;
+        u.max_out = 1;
+        u.fixed_start = 0;
+        u.settle_only = 1;
+        HIP_TRY(dabk::launch_track_update(u, s));
+    }
     return note_state_use(ctx, s);
 }
 
@@ -1648,7 +1669,7 @@ int dabgpu_track_start_dev(dabgpu_ctx *ctx, const dabgpu_acquired_frame *d_frame
 static int tracked_launches(dabgpu_ctx *ctx, dabk::StreamState *states, const void *d_iq, size_t stream_stride, int n_streams,
                             int64_t n_samples, int max_frames, int64_t advance, const dabgpu_track_cfg &c, int fixed_start,
                             int acquiring, int8_t *d_soft, void *d_cyc, void *d_dqpsk, dabgpu_acquired_frame *d_frames,
-                            dabgpu_sync_result *d_sync, int32_t *d_counts, hipStream_t s) {
+                            dabgpu_sync_result *d_sync, int32_t *d_counts, hipStream_t s, const dabk::AcquireArgs *auto_acq = nullptr) {
     dabk::SyncTables stab{ctx->d_twiddle, ctx->d_prs_qt, ctx->d_sync_pairs, ctx->n_sync_pairs, ctx->d_sync_fs};
     dabk::TrackArgs t{};
     t.state = states;
@@ -1668,6 +1689,8 @@ static int tracked_launches(dabgpu_ctx *ctx, dabk::StreamState *states, const vo
     t.out = reinterpret_cast<dabk::AcquiredFrame *>(d_frames);
     t.sync_out = reinterpret_cast<dabk::SyncResult *>(d_sync);
     HIP_TRY(dabk::launch_track_sync(stab, t, s));
+    // streams that are not tracking: acquired here (their rows of d_frames / d_counts; the pass above left them empty)
+    if (auto_acq) HIP_TRY(dabk::launch_acquire(stab, *auto_acq, s));
     dabk::OfdmTables tab{ctx->d_twiddle, ctx->d_bin_of_n, ctx->d_n_of_vj};
     dabk::OfdmArgs a{};
     a.iq = static_cast<const float2 *>(d_iq);
@@ -1701,6 +1724,9 @@ static int tracked_launches(dabgpu_ctx *ctx, dabk::StreamState *states, const vo
     u.thr_null_start = c.thr_null_start;
     u.fixed_start = fixed_start;
     u.counts = d_counts;
+    // ... and their tracking starts from what the acquisition found (marked 2; the update launch makes it 1)
+    if (auto_acq)
+        HIP_TRY(dabk::launch_track_start(states, t.out, d_counts, n_streams, max_frames, advance, 1, s));
     HIP_TRY(dabk::launch_track_update(u, s));
     return note_state_use(ctx, s);
 }
@@ -1722,8 +1748,20 @@ int dabgpu_ofdm_demod_tracked_dev(dabgpu_ctx *ctx, const void *d_iq, size_t stre
     if (n_streams == 0) return DABGPU_OK;
     hipStream_t s = pick_stream(ctx, stream);
     if (!d_cyc && (rc = stage(ctx, 6, size_t(n_streams) * max_frames * NB_FRAME_SYMBOLS * sizeof(float2), &d_cyc))) return rc;
+    dabk::AcquireArgs acq{};
+    if (c.auto_acquire && n_samples >= 64) {
+        dabgpu_acquire_cfg ac;
+        dabgpu_acquire_default_cfg(&ac);
+        ac.thr_null_start = c.thr_null_start;
+        ac.max_coarse_carriers = c.max_coarse_carriers;
+        ac.timing_margin = c.timing_margin;
+        ac.impulse_peak_distance_probability = c.impulse_peak_distance_probability;
+        ac.first_path_rel = c.first_path_rel;
+        if ((rc = acquire_args(ctx, d_iq, stream_stride, n_streams, n_samples, ac, max_frames, d_frames, d_counts, s, acq))) return rc;
+        acq.skip_tracked = ctx->d_states;
+    }
     return tracked_launches(ctx, ctx->d_states, d_iq, stream_stride, n_streams, n_samples, max_frames, advance, c, 0, 0, d_soft,
-                            d_cyc, d_dqpsk, d_frames, nullptr, d_counts, s);
+                            d_cyc, d_dqpsk, d_frames, nullptr, d_counts, s, (c.auto_acquire && n_samples >= 64) ? &acq : nullptr);
 }
 
 int dabgpu_ofdm_demod_stream_frame(dabgpu_ctx *ctx, int stream_index, const float *iq, int acquiring,

@@ -136,6 +136,9 @@ struct AcquireArgs {
     int64_t *cands;            // scratch [n_streams][max_out]
     AcquiredFrame *out;        // [n_streams][max_out]; entries >= counts[s] get flags 0, start -1
     int32_t *counts;           // [n_streams]
+    // auto-acquisition inside a tracked call: streams whose state says tracking == 1 are left alone entirely (nothing
+    // read, nothing written -- their rows of `out` and `counts` belong to the tracking pass)
+    const StreamState *skip_tracked = nullptr;
 };
 size_t acquire_scratch_bytes(int n_streams, int64_t n_samples, int max_out);
 hipError_t launch_acquire(const SyncTables &t, const AcquireArgs &a, hipStream_t s);
@@ -196,14 +199,17 @@ struct TrackUpdateArgs {
     float fine_beta, drift_beta, signal_beta, thr_null_start;
     int fixed_start;
     int32_t *counts;           // [n_streams] or nullptr
+    int settle_only = 0;       // only turn "started in this call" marks (tracking == 2) into 1
 };
 hipError_t launch_track_update(const TrackUpdateArgs &a, hipStream_t s);
 // Start tracking from an acquisition result (dabgpu_acquire_dev on the same capture): per stream, a least-squares line
 // through the starts of the locked frames against their frame number round((start - first)/196608) gives the drift
 // (0 with fewer than 4 locked frames); next_frame_start = start_last + 196608 + drift - advance; fine offset = mean of
 // the locked frames', coarse = the last locked frame's; tracking = 1 (0 when no frame locked).
+// only_lost != 0: streams that are tracking keep their state; the others start with tracking = 2 ("started in this
+// call"), which the track_update launch behind it turns into 1 without touching anything else.
 hipError_t launch_track_start(StreamState *state, const AcquiredFrame *frames, const int32_t *counts, int n_streams,
-                              int max_out, int64_t advance, hipStream_t s);
+                              int max_out, int64_t advance, int only_lost, hipStream_t s);
 
 // ---- DAB+ audio super-frame (dabplus_kernels.hip) ------------------------------
 struct SuperframeStatus {      // == dabgpu_superframe_status

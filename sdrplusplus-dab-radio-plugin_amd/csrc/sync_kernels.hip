@@ -141,6 +141,7 @@ __global__ __launch_bounds__(WG) void prs_sync_kernel(SyncTables tab, const floa
     bool do_coarse = true;
     if constexpr (MODE == MODE_ACQ) {
         const int st = frame / acq.max_out, j = frame - st * acq.max_out;
+        if (acq.skip_tracked && acq.skip_tracked[st].tracking == 1) continue;
         if (j >= acq.counts[st]) {
             if (tid == 0) acq.out[frame] = AcquiredFrame{-1, 0.f, 0, 0.f, 0.f, 0.f, 0};
             continue;
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(WG) void prs_sync_kernel(SyncTables tab, const floa
         if (!trk.fixed_start) {
             const Predictor pr(ss);
             cand = __double2ll_rn(pr.at(i));
-            have = ss.tracking != 0 && Predictor::fits(cand, trk.n_samples);
+            have = ss.tracking == 1 && Predictor::fits(cand, trk.n_samples);
         }
         if (!have) {
             if (tid == 0) {
@@ -340,6 +341,11 @@ __global__ __launch_bounds__(WG) void track_update_kernel(TrackUpdateArgs a) {
     __shared__ int red_last[WG];
     const int s = blockIdx.x, tid = threadIdx.x;
     StreamState st = a.state[s];
+    if (!a.fixed_start && st.tracking == 2) {                  // started in this very call (auto-acquisition): nothing to update
+        if (tid == 0) a.state[s].tracking = 1;
+        return;
+    }
+    if (a.settle_only) return;
     if (!a.fixed_start && !st.tracking) {
         if (tid == 0 && a.counts) a.counts[s] = 0;
         return;
@@ -440,8 +446,9 @@ __global__ __launch_bounds__(WG) void track_update_kernel(TrackUpdateArgs a) {
 
 // one wave per stream; see launch_track_start in kernels.hpp
 __global__ __launch_bounds__(64) void track_start_kernel(StreamState *state, const AcquiredFrame *frames, const int32_t *counts,
-                                                         int max_out, int64_t advance) {
+                                                         int max_out, int64_t advance, int only_lost) {
     const int s = blockIdx.x, lane = threadIdx.x;
+    if (only_lost && state[s].tracking == 1) return;
     const AcquiredFrame *fr = frames + size_t(s) * max_out;
     const int count = min(counts[s], max_out);
     // first and last locked frame
@@ -476,7 +483,7 @@ __global__ __launch_bounds__(64) void track_start_kernel(StreamState *state, con
     st.next_frame_start = double(fr[last].start) + double(NB_FRAME_SAMPLES) + double(st.drift) - double(advance);
     st.fine_freq_offset = float(sf / sn);
     st.coarse_freq_offset = -float(fr[last].coarse_carriers) / float(NB_FFT);
-    st.tracking = 1;
+    st.tracking = only_lost ? 2 : 1;
     st.total_frames_read += int(sn);
     st.last_time_offset = 0;
     st.last_peak_to_mean = fr[last].peak_to_mean;
@@ -489,8 +496,10 @@ __global__ __launch_bounds__(64) void track_start_kernel(StreamState *state, con
 // owns 32 consecutive blocks (16 KB of samples, four trips' loads in flight at a time) and writes their norms as ONE
 // 128-byte store: two dwords per wave, as a first version did, are partial cache lines that eight XCDs' L2s each
 // hold a piece of.
-__global__ __launch_bounds__(256) void null_l1_kernel(const float2 *iq, size_t stream_stride, int64_t nb, float *l1) {
+__global__ __launch_bounds__(256) void null_l1_kernel(const float2 *iq, size_t stream_stride, int64_t nb, float *l1,
+                                                      const StreamState *skip_tracked) {
     const int st = blockIdx.y;
+    if (skip_tracked && skip_tracked[st].tracking == 1) return;
     const int lane = threadIdx.x & 63;
     const int64_t wave = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
     const int64_t n_waves = int64_t(gridDim.x) * 4;
@@ -549,9 +558,11 @@ struct DipSegment {                            // 32 bytes
 
 // Mean block norm of a stream: 1024 strided partial sums in double, XOR butterfly inside each wave, the sixteen wave
 // sums added in order (the fixed tree the oracle restates).
-__global__ __launch_bounds__(MEAN_THREADS) void null_mean_kernel(const float *l1_all, int64_t nb, float *avg) {
+__global__ __launch_bounds__(MEAN_THREADS) void null_mean_kernel(const float *l1_all, int64_t nb, float *avg,
+                                                                 const StreamState *skip_tracked) {
     __shared__ double part[MEAN_THREADS / 64];
     const int st = blockIdx.x, tid = threadIdx.x;
+    if (skip_tracked && skip_tracked[st].tracking == 1) return;
     const float *l1 = l1_all + size_t(st) * nb;
     double acc = 0.0;
     int64_t b = tid;
@@ -578,8 +589,10 @@ __global__ __launch_bounds__(MEAN_THREADS) void null_mean_kernel(const float *l1
 // double, XOR butterfly (the fixed tree the oracle restates).  The thresholds at a block use the mean of the chunk means
 // c-2 .. c+2 that exist (local_level below): what the reference's running average (signal_l1.update_beta) does for a
 // stream -- a slow fade must not look like a null symbol, nor hide one.
-__global__ __launch_bounds__(64) void null_level_kernel(const float *l1_all, int64_t nb, int chunk, int64_t nc, double *cm_all) {
+__global__ __launch_bounds__(64) void null_level_kernel(const float *l1_all, int64_t nb, int chunk, int64_t nc, double *cm_all,
+                                                        const StreamState *skip_tracked) {
     const int st = blockIdx.y, lane = threadIdx.x;
+    if (skip_tracked && skip_tracked[st].tracking == 1) return;
     const float *l1 = l1_all + size_t(st) * nb;
     for (int64_t c = blockIdx.x; c < nc; c += gridDim.x) {
         const int64_t b0 = c * chunk, b1 = min(nb, b0 + chunk);
@@ -613,6 +626,7 @@ __global__ __launch_bounds__(64) void null_segment_kernel(AcquireArgs a, int64_t
                                                           DipSegment *segs, int64_t *seg_cands) {
     const int seg = blockIdx.x, st = blockIdx.y;
     const int lane = threadIdx.x;
+    if (a.skip_tracked && a.skip_tracked[st].tracking == 1) return;
     const float *l1 = a.l1 + size_t(st) * nb;
     float ts = 0.f, te = 0.f;
     const int64_t nc = a.level_chunk ? (nb + a.level_chunk - 1) / a.level_chunk : 0;
@@ -681,6 +695,7 @@ __global__ __launch_bounds__(64) void null_segment_kernel(AcquireArgs a, int64_t
 // one wave per stream: the segments in order
 __global__ __launch_bounds__(64) void null_stitch_kernel(AcquireArgs a, int n_seg, const DipSegment *segs, const int64_t *seg_cands) {
     const int st = blockIdx.x, lane = threadIdx.x;
+    if (a.skip_tracked && a.skip_tracked[st].tracking == 1) return;
     int64_t *cands = a.cands + size_t(st) * a.max_out;
     int count = 0, state = 0;
     int64_t dip_begin = 0;
@@ -746,9 +761,9 @@ hipError_t launch_track_update(const TrackUpdateArgs &a, hipStream_t s) {
 }
 
 hipError_t launch_track_start(StreamState *state, const AcquiredFrame *frames, const int32_t *counts, int n_streams,
-                              int max_out, int64_t advance, hipStream_t s) {
+                              int max_out, int64_t advance, int only_lost, hipStream_t s) {
     if (n_streams <= 0 || max_out <= 0) return hipSuccess;
-    hipLaunchKernelGGL(track_start_kernel, dim3(unsigned(n_streams)), dim3(64), 0, s, state, frames, counts, max_out, advance);
+    hipLaunchKernelGGL(track_start_kernel, dim3(unsigned(n_streams)), dim3(64), 0, s, state, frames, counts, max_out, advance, only_lost);
     return hipGetLastError();
 }
 
@@ -768,7 +783,7 @@ hipError_t launch_acquire(const SyncTables &t, const AcquireArgs &a, hipStream_t
     const int64_t nb = a.n_samples / 64;
     if (nb <= 0 || a.max_coarse < 0 || a.max_coarse > 1023) return hipErrorInvalidValue;
     const unsigned gx = unsigned(std::min<int64_t>(((nb + 31) / 32 + 3) / 4, 4096));
-    hipLaunchKernelGGL(null_l1_kernel, dim3(gx, unsigned(a.n_streams)), dim3(256), 0, s, a.iq, a.stream_stride, nb, a.l1);
+    hipLaunchKernelGGL(null_l1_kernel, dim3(gx, unsigned(a.n_streams)), dim3(256), 0, s, a.iq, a.stream_stride, nb, a.l1, a.skip_tracked);
     // the rest of the scratch buffer follows the candidate lists (acquire_scratch_bytes)
     const int n_seg = int(dip_segments(nb));
     char *p = reinterpret_cast<char *>(a.cands) + al256(size_t(a.n_streams) * a.max_out * sizeof(int64_t));
@@ -785,9 +800,9 @@ hipError_t launch_acquire(const SyncTables &t, const AcquireArgs &a, hipStream_t
         double *cm = reinterpret_cast<double *>(p);
         b.chunk_mean = cm;
         hipLaunchKernelGGL(null_level_kernel, dim3(unsigned(std::min<int64_t>(nc, 4096)), unsigned(a.n_streams)), dim3(64), 0, s, a.l1, nb,
-                           a.level_chunk, nc, cm);
+                           a.level_chunk, nc, cm, a.skip_tracked);
     } else {
-        hipLaunchKernelGGL(null_mean_kernel, dim3(unsigned(a.n_streams)), dim3(MEAN_THREADS), 0, s, a.l1, nb, avg);
+        hipLaunchKernelGGL(null_mean_kernel, dim3(unsigned(a.n_streams)), dim3(MEAN_THREADS), 0, s, a.l1, nb, avg, a.skip_tracked);
     }
     hipLaunchKernelGGL(null_segment_kernel, dim3(unsigned(n_seg), unsigned(a.n_streams)), dim3(64), 0, s, b, nb, n_seg, avg, segs,
                        seg_cands);

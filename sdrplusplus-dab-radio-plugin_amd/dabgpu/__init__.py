@@ -107,7 +107,7 @@ class TrackCfg(C.Structure):
     _fields_ = [("fine_freq_update_beta", C.c_float), ("signal_update_beta", C.c_float), ("thr_null_start", C.c_float),
                 ("min_peak_to_mean", C.c_float), ("impulse_peak_distance_probability", C.c_float),
                 ("first_path_rel", C.c_float), ("drift_beta", C.c_float), ("coarse_freq_slow_beta", C.c_float),
-                ("timing_margin", C.c_int32), ("max_coarse_carriers", C.c_int32), ("reserved", C.c_int32 * 2)]
+                ("timing_margin", C.c_int32), ("max_coarse_carriers", C.c_int32), ("auto_acquire", C.c_int32), ("reserved", C.c_int32)]
 
 
 class PlacementReport(C.Structure):
@@ -232,7 +232,7 @@ def load_library(path):
     L.dabgpu_set_stream_loop.argtypes = [vp, C.c_float, C.c_float]
     L.dabgpu_track_default_cfg.restype = None
     L.dabgpu_track_default_cfg.argtypes = [C.POINTER(TrackCfg)]
-    L.dabgpu_track_start_dev.argtypes = [vp, vp, vp, i, i, C.c_int64, vp]
+    L.dabgpu_track_start_dev.argtypes = [vp, vp, vp, i, i, C.c_int64, i, vp]
     L.dabgpu_ofdm_demod_tracked_dev.argtypes = [vp, vp, sz, i, C.c_int64, i, C.c_int64, C.POINTER(TrackCfg), vp, vp, vp, vp, vp, vp]
     L.dabgpu_ofdm_demod_stream_frame.argtypes = [vp, i, vp, i, C.POINTER(TrackCfg), vp, vp, C.POINTER(FrameResult)]
     L.dabgpu_get_prs_reference.argtypes = [i, vp, i]
@@ -454,9 +454,9 @@ class Context:
     def set_stream_loop(self, signal_update_beta=0.95, thr_null_start=0.35):
         _check(self._lib.dabgpu_set_stream_loop(self._h, signal_update_beta, thr_null_start), "dabgpu_set_stream_loop")
 
-    def track_start_dev(self, d_frames, d_counts, n_streams, max_frames, advance, stream=None):
-        _check(self._lib.dabgpu_track_start_dev(self._h, d_frames, d_counts, n_streams, max_frames, advance, stream),
-               "dabgpu_track_start_dev")
+    def track_start_dev(self, d_frames, d_counts, n_streams, max_frames, advance, stream=None, only_lost=False):
+        _check(self._lib.dabgpu_track_start_dev(self._h, d_frames, d_counts, n_streams, max_frames, advance, int(bool(only_lost)),
+                                            stream), "dabgpu_track_start_dev")
 
     def ofdm_demod_tracked_dev(self, d_iq, stream_stride, n_streams, n_samples, max_frames, advance, d_soft, d_frames, d_counts,
                                cfg=None, d_cyc=None, d_dqpsk=None, stream=None):

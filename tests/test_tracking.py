@@ -368,6 +368,85 @@ def test_gpu_tracking_through_random_channels(tctx):
 
 
 @pytest.mark.gpu
+def test_gpu_auto_acquire_equals_the_explicit_sequence_and_heals_a_lost_stream(tctx):
+    """cfg.auto_acquire: ONE call does everything.  From fresh states the first tracked call acquires every stream and
+    starts its tracking -- frames, soft bits and states equal to dabgpu_acquire_dev + dabgpu_ofdm_demod_acquired_dev +
+    dabgpu_track_start_dev on another context; later calls equal plain tracked calls.  Then stream 1's capture turns into
+    noise for one call (it stops tracking, stream 0 carries on untouched) and comes back: the next call re-acquires it by
+    itself while stream 0 is still only tracked."""
+    import torch
+    import dabgpu
+    from conftest import make_ctx
+    dev = torch.device("cuda", 0)
+    specs = [(45.0, 1.6, 18.0, 52000), (-70.0, -2.2, 18.0, 88000)]
+    streams = [short_stream(80 + i, 16, *sp) for i, sp in enumerate(specs)]
+    n_cap, adv, MF = 3 * L + 8192, 2 * L, 4
+    n_total = min(s[0].size for s in streams)
+    xs = np.stack([s[0][:n_total] for s in streams])
+    d_x = torch.from_numpy(xs).to(dev)
+    rng = np.random.default_rng(9)
+    d_noise = torch.from_numpy((rng.standard_normal(n_cap) + 1j * rng.standard_normal(n_cap)).astype(np.complex64)).to(dev)
+    S = 2
+    other = make_ctx(None, 64)
+    auto = dabgpu.track_cfg(auto_acquire=1)
+    bufs = {}
+    for name, c in (("auto", tctx), ("explicit", other)):
+        c.streams_reset(S)
+        bufs[name] = dict(frames=torch.zeros((S, MF, 32), dtype=torch.uint8, device=dev), counts=torch.zeros(S, dtype=torch.int32, device=dev),
+                          soft=torch.zeros((S * MF, dabgpu.NB_FRAME_BITS), dtype=torch.int8, device=dev))
+    torch.cuda.synchronize()
+
+    def call(name, c, p, stride, first):
+        b = bufs[name]
+        if name == "auto":
+            c.ofdm_demod_tracked_dev(p, stride, S, n_cap, MF, adv, b["soft"].data_ptr(), b["frames"].data_ptr(), b["counts"].data_ptr(), cfg=auto)
+        elif first:
+            c.acquire_dev(p, stride, S, n_cap, MF, b["frames"].data_ptr(), b["counts"].data_ptr())
+            c.ofdm_demod_acquired_dev(p, stride, S, MF, b["frames"].data_ptr(), b["soft"].data_ptr())
+            c.track_start_dev(b["frames"].data_ptr(), b["counts"].data_ptr(), S, MF, adv)
+        else:
+            c.ofdm_demod_tracked_dev(p, stride, S, n_cap, MF, adv, b["soft"].data_ptr(), b["frames"].data_ptr(), b["counts"].data_ptr())
+        c.sync()
+        fr = b["frames"].cpu().numpy().view(dabgpu.ACQUIRED_FRAME_DTYPE).reshape(S, MF)
+        return fr, b["counts"].cpu().numpy(), b["soft"].cpu().numpy().reshape(S, MF, -1), read_states(torch, c, S)
+
+    base = 0
+    for k in range(3):                                               # auto == explicit, call by call
+        p = d_x.data_ptr() + base * 8
+        fa, ca, sa, sta = call("auto", tctx, p, n_total, k == 0)
+        fe, ce, se, ste = call("explicit", other, p, n_total, k == 0)
+        assert (ca == ce).all() and (ca == 2).all(), (k, ca, ce)
+        for s in range(S):
+            for f in ("start", "flags", "coarse_carriers", "freq_offset", "peak_to_mean"):
+                assert (fa[s, :2][f] == fe[s, :2][f]).all(), (k, s, f)
+            assert (fa[s, :2]["flags"] == 3).all() and (sa[s] == se[s]).all()
+            for f in sta.dtype.names:
+                if f != "reserved":
+                    assert sta[s][f] == ste[s][f], (k, s, f, sta[s][f], ste[s][f])
+        base += adv
+    # stream 1 turns into noise for one capture: build that capture pair in a scratch buffer (stream 0 real, stream 1 noise)
+    mixed = torch.stack([d_x[0, base:base + n_cap], d_noise]).contiguous()
+    torch.cuda.synchronize()
+    fa, ca, sa, sta = call("auto", tctx, mixed.data_ptr(), n_cap, False)
+    assert ca[0] == 2 and (fa[0, :2]["flags"] == 3).all() and sta[0]["tracking"] == 1
+    assert sta[1]["tracking"] == 0 and not sa[1].any()                # lost: nothing demodulated
+    lost_desync = int(sta[1]["total_frames_desync"])
+    base += adv
+    fa, ca, sa, sta = call("auto", tctx, d_x.data_ptr() + base * 8, n_total, False)
+    assert sta[0]["tracking"] == 1 and sta[1]["tracking"] == 1 and ca[1] == 2 and (fa[1, :2]["flags"] == 3).all()
+    assert fa[1, 0]["coarse_carriers"] == -2 and fa[0, 0]["coarse_carriers"] == 0    # stream 1 went through the carrier search again
+    fib, ok = tctx.fic_decode(sa.reshape(S * MF, -1))
+    for s in range(S):
+        for j in range(2):
+            kf = int(round(((base + int(fa[s, j]["start"]) + 64 + HALF + specs[s][3]) / (1 + specs[s][0] * 1e-6) - NULL) / L))
+            assert ok[s * MF + j].all() and (fib[s * MF + j] == streams[s][2].fibs[kf % 4]).all(), (s, j)
+    base += adv
+    fa, ca, sa, sta = call("auto", tctx, d_x.data_ptr() + base * 8, n_total, False)                 # and both are tracked on
+    assert (ca == 2).all() and (fa[:, :2]["flags"] == 3).all() and int(sta[1]["total_frames_desync"]) == lost_desync
+    other.close()
+
+
+@pytest.mark.gpu
 def test_gpu_tracking_drops_out_on_noise_and_counts_missed_frames(tctx):
     """A tracked stream whose capture turns into noise loses every frame of the call: tracking stops (state 0), the
     frames count as desync, soft bits are erased.  A capture that begins late (frames before it) counts them missed."""
