@@ -12,6 +12,7 @@
 // Both FFTs are the 256-thread LDS Stockham of fft_common.hpp; the correlation is adds only because R is a
 // fourth root of unity.  Results are integers plus two peak-to-mean ratios for thresholding.
 #include <algorithm>
+#include <type_traits>
 
 #include "kernels.hpp"
 #include "dab_tables.hpp"
@@ -35,6 +36,17 @@ struct SyncLds {
     int red_i[WG];
     float red_s[WG];
 };
+// The tracking pass of a batch call needs neither the whole-carrier search (no y) nor the cyclic-prefix estimate (no
+// red_d), and reads its twiddles from the L1/L2-resident global table: 37 KB instead of 73 KB, four workgroups per CU
+// instead of two -- the kernel is all barriers and latency, occupancy is what it runs on.
+struct SyncLdsLite {
+    float2 t1[NB_FFT];
+    float2 x[NB_FFT];
+    int8_t qt[NB_FFT];
+    float red_m[WG];
+    int red_i[WG];
+    float red_s[WG];
+};
 
 // X * (-j)^q  (= X * conj(R) for R = j^q)
 __device__ __forceinline__ float2 rot_mq(float2 v, int q) {
@@ -47,7 +59,8 @@ __device__ __forceinline__ float2 rot_mq(float2 v, int q) {
 }
 
 // block-wide argmax with "first maximum" semantics (smaller index wins ties) and the sum of all values
-__device__ __forceinline__ void block_argmax_sum(SyncLds &sm, int tid, float m, int idx, float s, float &best_m,
+template <class Lds>
+__device__ __forceinline__ void block_argmax_sum(Lds &sm, int tid, float m, int idx, float s, float &best_m,
                                                  int &best_i, float &total) {
     sm.red_m[tid] = m;
     sm.red_i[tid] = idx;
@@ -119,17 +132,25 @@ struct Predictor {
 //             for any candidate within +-64 samples), then the same search; AcquiredFrame out.
 // MODE_TRACK: candidates predicted from the stream states (TrackArgs); correction = the state's fine + coarse offset;
 //             the whole-carrier search only when asked for (max_coarse > 0); AcquiredFrame out.
-template <int MODE>
+template <int MODE, bool LITE = false>
 __global__ __launch_bounds__(WG) void prs_sync_kernel(SyncTables tab, const float2 *iq, size_t frame_stride,
                                                       const float *freq_offset, int max_coarse_arg, SyncResult *out,
                                                       AcquireArgs acq, TrackArgs trk, int n_total) {
-    __shared__ SyncLds sm;
+    using Lds = typename std::conditional<LITE, SyncLdsLite, SyncLds>::type;
+    __shared__ Lds sm;
     const int tid = threadIdx.x;
     // the tables go to LDS once per workgroup; a workgroup then takes every gridDim.x-th candidate
-    for (int i = tid; i < NB_FFT; i += WG) {
-        sm.tw[i] = tab.twiddle[i];
-        sm.qt[i] = tab.prs_qt[i];
+    const float2 *tw;
+    float *pw;                                                 // |h|^2 of every tap (a buffer that is idle by then)
+    if constexpr (LITE) {
+        tw = tab.twiddle;
+        pw = reinterpret_cast<float *>(sm.t1);
+    } else {
+        for (int i = tid; i < NB_FFT; i += WG) sm.tw[i] = tab.twiddle[i];
+        tw = sm.tw;
+        pw = reinterpret_cast<float *>(sm.y);
     }
+    for (int i = tid; i < NB_FFT; i += WG) sm.qt[i] = tab.prs_qt[i];
     __syncthreads();
     for (int frame = blockIdx.x; frame < n_total; frame += gridDim.x) {
     int max_coarse = max_coarse_arg;
@@ -172,7 +193,8 @@ __global__ __launch_bounds__(WG) void prs_sync_kernel(SyncTables tab, const floa
         fine = ss.fine_freq_offset;
         // first frame after a null-symbol detection: the fine offset starts from this PRS's own cyclic prefix, so that
         // the frame is already demodulated with it (the loop then refines it)
-        if (trk.fixed_start && trk.acquiring) fine = cp_fine_offset(sm, sym, trk.margin, tid);
+        if constexpr (!LITE)
+            if (trk.fixed_start && trk.acquiring) fine = cp_fine_offset(sm, sym, trk.margin, tid);
         coarse = (trk.fixed_start && trk.acquiring && trk.max_coarse > 0) ? 0.0f : ss.coarse_freq_offset;
         dphi = uint32_t(__double2ll_rn(double(__fadd_rn(fine, coarse)) * 4294967296.0));
         max_coarse = trk.max_coarse;
@@ -191,11 +213,12 @@ __global__ __launch_bounds__(WG) void prs_sync_kernel(SyncTables tab, const floa
             v[r] = sym[NB_CP + n];
             if (dphi != 0u) v[r] = cmul(v[r], nco(uint32_t(n), dphi));
         }
-        block_fft2048(v, sm.t1, sm.x, sm.tw, tid);
+        block_fft2048(v, sm.t1, sm.x, tw, tid);
     }
     float best_m, total;
     int khat = 0;
     float coarse_ptm = 0.0f;
+    if constexpr (!LITE)
     if (do_coarse) {                                           // (uniform over the workgroup)
         // ---- Q[b] = X[b+1] conj X[b] -> t1 ----
 #pragma unroll
@@ -251,9 +274,9 @@ __global__ __launch_bounds__(WG) void prs_sync_kernel(SyncTables tab, const floa
             v[r] = z;
         }
         __syncthreads();          // everyone has read x[] before the FFT overwrites it
-        block_fft2048(v, sm.t1, sm.x, sm.tw, tid);
+        block_fft2048(v, sm.t1, sm.x, tw, tid);
     }
-    // power of every tap into y[].x (kept for the first-path scan), weighted score for the peak choice (PeakRule)
+    // power of every tap into pw[] (kept for the first-path scan), weighted score for the peak choice (PeakRule)
     float my_m = -1.0f, my_s = 0.0f;
     int my_n = 0x7fffffff;
     const float decay = __fmul_rn(__fsub_rn(1.0f, rule.distance_prob), 1.0f / float(NB_SYM_PERIOD));
@@ -262,7 +285,7 @@ __global__ __launch_bounds__(WG) void prs_sync_kernel(SyncTables tab, const floa
         const int n = tid + r * WG;
         const float2 h = sm.x[n];
         const float m = __fadd_rn(__fmul_rn(h.x, h.x), __fmul_rn(h.y, h.y));
-        sm.y[n].x = m;
+        pw[n] = m;
         my_s += m;
         const int t = n < NB_FFT / 2 ? n : n - NB_FFT;
         const float w = __fsub_rn(1.0f, __fmul_rn(decay, float(abs(t - rule.expected))));
@@ -271,13 +294,13 @@ __global__ __launch_bounds__(WG) void prs_sync_kernel(SyncTables tab, const floa
     }
     int best_n;
     block_argmax_sum(sm, tid, my_m, my_n, my_s, best_m, best_n, total);   // (its barriers make y[] visible)
-    const float peak = sm.y[best_n].x;
+    const float peak = pw[best_n];
     const float mean = total / float(NB_FFT);
     if (rule.first_path_rel > 0.0f) {
         const float thr = fmaxf(__fmul_rn(rule.first_path_rel, peak), __fmul_rn(16.0f, mean));
         float my_d = 0.0f;
         for (int d = tid + 1; d <= NB_CP; d += WG)
-            if (sm.y[(best_n - d) & (NB_FFT - 1)].x >= thr) my_d = float(d);
+            if (pw[(best_n - d) & (NB_FFT - 1)] >= thr) my_d = float(d);
         float dmax, dsum;
         int dummy;
         block_argmax_sum(sm, tid, my_d, tid, 0.0f, dmax, dummy, dsum);
@@ -336,9 +359,10 @@ __global__ __launch_bounds__(WG) void prs_sync_kernel(SyncTables tab, const floa
 }
 
 // ---- timing tracking: state update after the demodulation of the tracked frames (TrackUpdateArgs) ----
-__global__ __launch_bounds__(WG) void track_update_kernel(TrackUpdateArgs a) {
-    __shared__ double red[6][WG];
-    __shared__ int red_last[WG];
+constexpr int TU = 1024;          // threads per stream: the kernel is one workgroup per stream and lives on loads in flight
+__global__ __launch_bounds__(TU) void track_update_kernel(TrackUpdateArgs a) {
+    __shared__ double red[6][TU];
+    __shared__ int red_last[TU];
     const int s = blockIdx.x, tid = threadIdx.x;
     StreamState st = a.state[s];
     if (!a.fixed_start && st.tracking == 2) {                  // started in this very call (auto-acquisition): nothing to update
@@ -362,14 +386,14 @@ __global__ __launch_bounds__(WG) void track_update_kernel(TrackUpdateArgs a) {
     // sums over the locked frames: n, i, i^2, r, i*r, and the cyclic-prefix angles
     double sn = 0, si = 0, sii = 0, sr = 0, sir = 0, sang = 0;
     int last = -1;
-    for (int i = tid; i < count; i += WG) {
+    for (int i = tid; i < count; i += TU) {
         const AcquiredFrame f = fr[i];
         if ((f.flags & 3) != 3) continue;
         const double r = double(f.start) - pr.at(i);
         sn += 1.0; si += double(i); sii += double(i) * double(i); sr += r; sir += double(i) * r;
         last = i;
     }
-    for (int k = tid; k < count * NB_FRAME_SYMBOLS; k += WG) {
+    for (int k = tid; k < count * NB_FRAME_SYMBOLS; k += TU) {
         const int i = k / NB_FRAME_SYMBOLS;
         if ((fr[i].flags & 3) != 3) continue;
         const float2 c = cyc[k];
@@ -378,7 +402,7 @@ __global__ __launch_bounds__(WG) void track_update_kernel(TrackUpdateArgs a) {
     red[0][tid] = sn; red[1][tid] = si; red[2][tid] = sii; red[3][tid] = sr; red[4][tid] = sir; red[5][tid] = sang;
     red_last[tid] = last;
     __syncthreads();
-    for (int off = WG / 2; off > 0; off >>= 1) {
+    for (int off = TU / 2; off > 0; off >>= 1) {
         if (tid < off) {
 #pragma unroll
             for (int q = 0; q < 6; q++) red[q][tid] += red[q][tid + off];
@@ -393,11 +417,11 @@ __global__ __launch_bounds__(WG) void track_update_kernel(TrackUpdateArgs a) {
     float l1 = 0.f;
     if (last >= 0) {
         const float2 *x = a.iq + size_t(s) * a.stream_stride + fr[last].start;
-        for (int i = tid; i < 4096; i += WG) l1 += fabsf(x[i].x) + fabsf(x[i].y);
+        for (int i = tid; i < 4096; i += TU) l1 += fabsf(x[i].x) + fabsf(x[i].y);
     }
     red[0][tid] = double(l1);
     __syncthreads();
-    for (int off = WG / 2; off > 0; off >>= 1) {
+    for (int off = TU / 2; off > 0; off >>= 1) {
         if (tid < off) red[0][tid] += red[0][tid + off];
         __syncthreads();
     }
@@ -748,15 +772,20 @@ hipError_t launch_track_sync(const SyncTables &t, const TrackArgs &a, hipStream_
     if (a.max_coarse < 0 || a.max_coarse > 1023 || (a.fixed_start && a.max_out != 1)) return hipErrorInvalidValue;
     TrackArgs b = a;
     b.rule.expected = a.margin;
-    hipLaunchKernelGGL(prs_sync_kernel<MODE_TRACK>, dim3(sync_grid(a.n_streams * a.max_out)), dim3(WG), 0, s, t,
-                       static_cast<const float2 *>(nullptr), size_t(0), static_cast<const float *>(nullptr), 0,
-                       static_cast<SyncResult *>(nullptr), AcquireArgs{}, b, a.n_streams * a.max_out);
+    if (!a.fixed_start && a.max_coarse == 0)
+        hipLaunchKernelGGL((prs_sync_kernel<MODE_TRACK, true>), dim3(sync_grid(a.n_streams * a.max_out)), dim3(WG), 0, s, t,
+                           static_cast<const float2 *>(nullptr), size_t(0), static_cast<const float *>(nullptr), 0,
+                           static_cast<SyncResult *>(nullptr), AcquireArgs{}, b, a.n_streams * a.max_out);
+    else
+        hipLaunchKernelGGL(prs_sync_kernel<MODE_TRACK>, dim3(sync_grid(a.n_streams * a.max_out)), dim3(WG), 0, s, t,
+                           static_cast<const float2 *>(nullptr), size_t(0), static_cast<const float *>(nullptr), 0,
+                           static_cast<SyncResult *>(nullptr), AcquireArgs{}, b, a.n_streams * a.max_out);
     return hipGetLastError();
 }
 
 hipError_t launch_track_update(const TrackUpdateArgs &a, hipStream_t s) {
     if (a.n_streams <= 0 || a.max_out <= 0) return hipSuccess;
-    hipLaunchKernelGGL(track_update_kernel, dim3(unsigned(a.n_streams)), dim3(WG), 0, s, a);
+    hipLaunchKernelGGL(track_update_kernel, dim3(unsigned(a.n_streams)), dim3(TU), 0, s, a);
     return hipGetLastError();
 }
 
@@ -782,7 +811,10 @@ hipError_t launch_acquire(const SyncTables &t, const AcquireArgs &a, hipStream_t
     if (a.n_streams <= 0 || a.max_out <= 0) return hipSuccess;
     const int64_t nb = a.n_samples / 64;
     if (nb <= 0 || a.max_coarse < 0 || a.max_coarse > 1023) return hipErrorInvalidValue;
-    const unsigned gx = unsigned(std::min<int64_t>(((nb + 31) / 32 + 3) / 4, 4096));
+    // enough workgroups for the whole chip over ALL streams (each walks its stream's chunks with the grid's stride): a
+    // launch whose streams are all skipped (auto-acquisition beside tracked streams) then costs microseconds
+    const int64_t per_stream = std::max<int64_t>(16, 8192 / std::max(1, a.n_streams));
+    const unsigned gx = unsigned(std::min<int64_t>(((nb + 31) / 32 + 3) / 4, std::min<int64_t>(per_stream, 4096)));
     hipLaunchKernelGGL(null_l1_kernel, dim3(gx, unsigned(a.n_streams)), dim3(256), 0, s, a.iq, a.stream_stride, nb, a.l1, a.skip_tracked);
     // the rest of the scratch buffer follows the candidate lists (acquire_scratch_bytes)
     const int n_seg = int(dip_segments(nb));
@@ -799,7 +831,7 @@ hipError_t launch_acquire(const SyncTables &t, const AcquireArgs &a, hipStream_t
         const int64_t nc = (nb + a.level_chunk - 1) / a.level_chunk;
         double *cm = reinterpret_cast<double *>(p);
         b.chunk_mean = cm;
-        hipLaunchKernelGGL(null_level_kernel, dim3(unsigned(std::min<int64_t>(nc, 4096)), unsigned(a.n_streams)), dim3(64), 0, s, a.l1, nb,
+        hipLaunchKernelGGL(null_level_kernel, dim3(unsigned(std::min<int64_t>(nc, 4 * per_stream)), unsigned(a.n_streams)), dim3(64), 0, s, a.l1, nb,
                            a.level_chunk, nc, cm, a.skip_tracked);
     } else {
         hipLaunchKernelGGL(null_mean_kernel, dim3(unsigned(a.n_streams)), dim3(MEAN_THREADS), 0, s, a.l1, nb, avg, a.skip_tracked);
