@@ -25,6 +25,18 @@ int main(void) {
     rc = dabgpu_fic_decode(ctx, soft, 230400, 2, fib, ok);
     if (rc) { printf("fic: %s\n", dabgpu_strerror(rc)); return 1; }
     for (i = 0; i < 12; i++) bad += ok[12 + i] != 0;                         /* noise never passes a CRC16 (1 in 65536) */
+    /* the per-frame call of the host mirror (ABI v4): a frame of noise is "not a PRS" -- nothing demodulated, one desync */
+    {
+        dabgpu_track_cfg tcfg;
+        dabgpu_frame_result res;
+        dabgpu_track_default_cfg(&tcfg);
+        rc = dabgpu_streams_reset(ctx, 1);
+        if (!rc) rc = dabgpu_ofdm_demod_stream_frame(ctx, 0, iq + 2 * n, 1, &tcfg, soft, NULL, &res);
+        if (rc) { printf("frame call: %s\n", dabgpu_strerror(rc)); return 1; }
+        bad += (res.flags & 1) != 0;
+        bad += res.stats.total_frames_desync != 1 || res.stats.total_frames_read != 0;
+        for (i = 0; i < 230400; i++) bad += soft[i] != 0;
+    }
     printf("c abi ok: abi=%d erasures_nonzero=%d\n", dabgpu_abi_version(), bad);
     dabgpu_host_free(iq);
     free(soft);
