@@ -32,9 +32,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "sdrplusplus-dab-radio-plugin_amd"))
 sys.path.insert(0, ROOT)
 
-# algorithmic HBM bytes per frame (DESIGN.md "Measurement"): the fused front end reads the
-# 76 symbols of 2552 cf32 samples once and writes 230400 int8 soft bits.
-A_OFDM = 76 * 2552 * 8 + 230400            # 1 782 016 B
+# algorithmic HBM bytes per frame (DESIGN.md "Measurement").  Round 3: the closed-loop front end no longer reads the
+# cyclic prefixes at all (decision-directed fine-frequency loop): the useful 2048 samples of the 76 symbols in, 230400
+# int8 soft bits out.  A_OFDM_CP is what the kernel moves when the caller asks for the cyclic-prefix correlations
+# (rounds 1-2, and the `with_cyclic_prefix_correlations` leg below); SURVEY 8(d)'s A_ofdm = 1 803 264 B also counts the
+# null symbol, which no kernel here ever read.
+A_OFDM = 76 * 2048 * 8 + 230400            # 1 475 584 B
+A_OFDM_CP = 76 * 2552 * 8 + 230400         # 1 782 016 B
+A_OFDM_SURVEY = 196608 * 8 + 230400        # 1 803 264 B
 A_FFT = 76 * 2552 * 8 + 76 * 2048 * 8      # 2 796 800 B (unfused FFT stage)
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: 8 TB/s spec
 REALTIME_FPS = 1.0 / 0.096
@@ -280,6 +285,8 @@ def main():
                     help="length of the extra `sustained` leg: the same step repeated for this long, so that the package's "
                          "power-limited steady state is in the record (0 = skip)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the sustained leg")
+    ap.add_argument("--no-cp-leg", action="store_true",
+                    help="skip the leg that runs the step with the cyclic-prefix correlations (rounds 1-2's data flow)")
     ap.add_argument("--no-plain-compare", action="store_true",
                     help="skip timing the front end on a plainly allocated copy of the buffers beside the placed pair")
     ap.add_argument("--placement", choices=["placed", "candidates", "plain"], default="placed",
@@ -375,7 +382,8 @@ def main():
         if timed:
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
             ev[0].record()
-        ctx.ofdm_demod_streams_dev(d_iq, synth.NB_FRAME_SAMPLES, E, F, BETA, soft.data_ptr(), cyc.data_ptr(), None, stream)
+        # (no correlation buffer passed: the fine loop runs decision-directed and the cyclic prefixes are never read)
+        ctx.ofdm_demod_streams_dev(d_iq, synth.NB_FRAME_SAMPLES, E, F, BETA, soft.data_ptr(), None, None, stream)
         if timed:
             ev[1].record()
         decode_into(soft, k)
@@ -383,8 +391,12 @@ def main():
             ev[2].record()
             ofdm_ev.append((ev[0], ev[1])); dec_ev.append((ev[1], ev[2]))
 
-    for k in range(3):                                # settle the fine-frequency loop (part of acquisition, untimed)
+    # settle the fine-frequency loop (part of acquisition, untimed): first on the cyclic-prefix correlations, whose range
+    # is +-half a carrier, then decision-directed (range +-0.1 carrier), as the timed steps run
+    for k in range(3):
         ctx.ofdm_demod_streams_dev(d_iq, synth.NB_FRAME_SAMPLES, E, F, BETA, soft.data_ptr(), cyc.data_ptr(), None, stream)
+    ctx.set_stream_loop(decision_directed=True)      # from here on calls without a correlation buffer skip the prefixes
+    ctx.ofdm_demod_streams_dev(d_iq, synth.NB_FRAME_SAMPLES, E, F, BETA, soft.data_ptr(), None, None, stream)
     torch.cuda.synchronize()
     net = np.array([ctx.get_stats(s).net_freq_offset for s in range(E)])
     loop_residual = float(np.abs(net + cfo_true).max() * 2048.0)            # carriers; reported, not used
@@ -445,7 +457,7 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("frames_per_launch") == n_frames:
+                if tj.get("frames_per_launch") == n_frames and tj.get("mode") == "decision-directed, no cyclic prefix read":
                     traffic = tj.get("hbm_bytes_per_launch")
                     traffic_source = "profiles/pmc_traffic.json (rocprofv3 --pmc, separate run of this command: " \
                                      "TCC_EA0_RDREQ/WRREQ-derived FETCH_SIZE x 2 + WRITE_SIZE, tools/pmc_traffic.sh); not measured in this run"
@@ -466,7 +478,9 @@ def main():
                        "ensembles_per_gpu": E, "frames_per_step_per_gpu": n_frames, "snr_db": args.snr,
                        "carrier_offset": "unknown to the receiver: k + f carriers per ensemble, |k| <= 3, |f| <= 0.4",
                        "frequency_correction": "closed loop on the device (dabgpu_ofdm_demod_streams_dev): coarse from the first PRS, "
-                                               "fine from the cyclic-prefix correlations of the previous call",
+                                               "fine: settled on the cyclic-prefix correlations (untimed), then decision-directed "
+                                               "(fourth power of the differential symbols of the previous call; the cyclic prefixes "
+                                               "are never read in the timed steps)",
                        "sharding": "independent ensembles per rank (global id % world == rank), no data-path collective",
                        "buffer_placement": placement if placement is not None else "first allocation taken"},
             "x_realtime": value / REALTIME_FPS,
@@ -477,6 +491,10 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_source, "avg_launch_ms": ofdm_ms, "launches_timed": ofdm_launches,
                          "front_end_call_ms": ofdm_call_ms, "frames_per_launch": n_frames,
                          "algorithmic_bytes_per_frame": A_OFDM,
+                         "algorithmic_bytes_note": "76 x 2048 cf32 in + 230400 int8 out: the cyclic prefixes (19.7 % of the samples) "
+                                                   "are not read any more; priced on SURVEY 8(d)'s A_ofdm (1 803 264 B, prefixes "
+                                                   "and null symbol included) the same launch would read achieved_on_survey_bytes",
+                         "achieved_on_survey_bytes": A_OFDM_SURVEY * n_frames / (ofdm_ms * 1e-3) / 1e9,
                          "copy_ceiling": copy_ceiling(torch, dev)},
             # the channel decoder is integer add-compare-select work, not bandwidth: report ACS/s
             "decoder": {"fic_and_msc_ms": dec_ms, "acs_per_s": (ACS_FIC + ACS_MSC64) * n_frames / (dec_ms * 1e-3),
@@ -495,8 +513,8 @@ def main():
                 for i in range(2 + 5):
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                    ctx.ofdm_demod_frames_dev(a + synth.NB_NULL * 8, synth.NB_FRAME_SAMPLES, n_frames, fo_cmp.data_ptr(), b,
-                                              cyc.data_ptr(), None, stream)
+                    ctx.ofdm_demod_frames_dd_dev(a + synth.NB_NULL * 8, synth.NB_FRAME_SAMPLES, n_frames, fo_cmp.data_ptr(), b,
+                                                 cyc.data_ptr(), stream)
                     e1.record()
                     if i >= 2:
                         evs.append((e0, e1))
@@ -506,6 +524,32 @@ def main():
             placement["front_end_ms_same_call_plain_alloc"] = res["plain_alloc"]
             placement["plain_alloc_outputs_identical"] = bool(torch.equal(soft_p, soft))
             del iq_p, soft_p
+        if not args.no_cp_leg:
+            # The step as rounds 1-2 ran it: the caller asks for the cyclic-prefix correlations (the reference's estimator),
+            # so the prefixes are read and the loop runs on them -- 21 % more bytes through the same kernel.
+            torch.cuda.synchronize()
+            evs = []
+            t1 = time.perf_counter()
+            for k in range(2 + args.steps):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                ctx.ofdm_demod_streams_dev(d_iq, synth.NB_FRAME_SAMPLES, E, F, BETA, soft.data_ptr(), cyc.data_ptr(), None, stream)
+                e1.record()
+                decode_into(soft, args.warmup + args.steps + k)
+                if k == 1:
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                if k >= 2:
+                    evs.append((e0, e1))
+            torch.cuda.synchronize()
+            cp_s = time.perf_counter() - t1
+            cp_ms = float(np.mean([x.elapsed_time(y) for x, y in evs]))
+            fib_c, crc_c, msc_c = fib.cpu().numpy(), crc.cpu().numpy(), msc.cpu().numpy()
+            out["with_cyclic_prefix_correlations"] = {
+                "value": n_frames * args.steps / cp_s, "unit": "frames/s", "ms_per_step": cp_s / args.steps * 1e3,
+                "front_end_call_ms": cp_ms, "algorithmic_bytes_per_frame": A_OFDM_CP,
+                "roofline_frac": A_OFDM_CP * n_frames / (cp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "outputs_identical_to_timed_run": bool((fib_c == fib_h).all() and (crc_c == crc_h).all() and (msc_c == msc_h).all())}
         if not args.no_sustained and args.sustained_seconds > 0:
             # The same step, repeated for >= --sustained-seconds: the 10-step timed region above lasts 0.1 s, shorter than
             # the package's power controller takes to settle (the front end runs at the 1400 W limit), so the

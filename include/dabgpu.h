@@ -213,6 +213,19 @@ int dabgpu_ofdm_demod_frames_dev(dabgpu_ctx *ctx, const void *d_iq, size_t frame
                                  void *stream);
 int dabgpu_ofdm_demod_frames(dabgpu_ctx *ctx, const float *iq, size_t frame_stride, int n_frames,
                              const float *freq_offset, int8_t *soft, float *cyc, float *dqpsk);
+/* The same front end WITHOUT reading a single cyclic-prefix sample (17 % of the bytes of an HBM-bound kernel), with the
+ * decision-directed frequency-error sums a loop needs instead of the cyclic-prefix correlations:
+ *   dd4  [n_frames][76] cf32; the SUM of entries 1..75 of a frame = sum over its 75 data symbols and 256 of each
+ *        symbol's carriers (FFT bins v + 64 m, v < 64, m in {0, 1, 30, 31}, bin 0 replaced by 768) of (X_l conj X_{l-1})^4
+ *        (how the sum is spread over the entries depends on how the launch cut the frame into runs: a run's total sits
+ *        in the entry of its last symbol, its other entries are 0).  Whatever two bits a differential
+ *        symbol carries, its fourth power is -|d|^4 exp(j 4 theta) with theta = 2 pi * (residual offset, cycles per
+ *        sample) * 2552: angle(-sum) / (4 * 2 pi * 2552) is the residual, unambiguous within +-0.1 carrier (the loop
+ *        must have been brought that close first: acquisition's estimate from the PRS prefix is).  Entry 0 of a frame
+ *        is not written.
+ * The closed-loop calls below run on this when the caller does not ask for the correlations (d_cyc == NULL). */
+int dabgpu_ofdm_demod_frames_dd_dev(dabgpu_ctx *ctx, const void *d_iq, size_t frame_stride, int n_frames,
+                                    const float *d_freq_offset, int8_t *d_soft, void *d_dd4, void *stream);
 
 /* ------------------------------------------------------------------------ */
 /* Closed-loop front end: per-stream tracking state kept in device memory.    */
@@ -229,7 +242,9 @@ int dabgpu_ofdm_demod_frames(dabgpu_ctx *ctx, const float *iq, size_t frame_stri
 /* -beta * (mean angle of the frames' cyclic-prefix correlations)/(2*pi*2048), */
 /* kept within +-half a carrier; the next call uses the new value.  Frame      */
 /* (s, f) starts at iq + (s*frames_per_stream + f)*frame_stride.               */
-/* cyc may be NULL (the library keeps the correlations in its own scratch).    */
+/* cyc may be NULL: the library keeps what the loop needs in its own scratch --  */
+/* the correlations, or (dabgpu_set_stream_loop(.., decision_directed = 1)) the  */
+/* dd4 sums, in which case the cyclic prefixes are not read at all.              */
 /* ------------------------------------------------------------------------ */
 typedef struct dabgpu_stream_state {      /* DEVICE memory, 64 bytes */
     float fine_freq_offset;               /* cycles/sample, within +-0.5/2048                     */
@@ -284,8 +299,15 @@ int dabgpu_ofdm_demod_streams(dabgpu_ctx *ctx, const float *iq, size_t frame_str
  * dabgpu_streams_reset first wait (on the host) for the most recent such call to finish, wherever it ran. */
 int dabgpu_get_stats(dabgpu_ctx *ctx, int stream_index, dabgpu_stats *out);
 /* signal_l1.update_beta (src/render_radio_block.cpp:235) and null_l1_search.thresh_null_start (:226-233) of the stream
- * calls' level average and desync count; defaults 0.95 / 0.35 */
-int dabgpu_set_stream_loop(dabgpu_ctx *ctx, float signal_update_beta, float thr_null_start);
+ * calls' level average and desync count (defaults 0.95 / 0.35), and which estimator the fine-frequency loop of
+ * dabgpu_ofdm_demod_streams_dev runs on when the caller passes no correlation buffer (d_cyc == NULL):
+ *   decision_directed == 0 (default)  the cyclic-prefix correlations, kept in the library's scratch: pulls in from
+ *                                     +-half a carrier, as the reference's loop does
+ *   decision_directed != 0            the dd4 sums of dabgpu_ofdm_demod_frames_dd_dev: the cyclic prefixes are not read
+ *                                     (17 % fewer bytes).  Range +-0.1 carrier: switch it on once the loop has settled
+ *                                     (a few calls on the correlations) -- beyond it the loop would lock a multiple of
+ *                                     0.1 carrier off and the symbols would come out rotated. */
+int dabgpu_set_stream_loop(dabgpu_ctx *ctx, float signal_update_beta, float thr_null_start, int decision_directed);
 
 /* Soft-bit selection (batch receivers that decode the FIC and a few sub-channels and never look at the rest of the
  * frame): from the next call on, dabgpu_ofdm_demod_frames[_dev], dabgpu_ofdm_demod_streams[_dev] and
@@ -441,7 +463,8 @@ int dabgpu_ofdm_demod_acquired_dev(dabgpu_ctx *ctx, const void *d_iq, size_t str
 /*              (flags 3 = demodulated); counts[s] = frame slots of stream s     */
 /*              that lay inside the capture.  soft / cyc / dqpsk as             */
 /*              dabgpu_ofdm_demod_acquired_dev (slots without a locked frame:    */
-/*              erased soft bits).  cyc may be NULL.                            */
+/*              erased soft bits).  cyc may be NULL (cfg.decision_directed       */
+/*              then chooses what the fine loop runs on).                        */
 /* A stream none of whose frames locked in a call stops tracking (state 0 in     */
 /* dabgpu_get_stats): acquire it again -- or set cfg.auto_acquire and the next   */
 /* call does (then the very first call needs no dabgpu_acquire_dev either).      */
@@ -458,6 +481,10 @@ typedef struct dabgpu_track_cfg {
     int32_t timing_margin;                    /* 64 (batch calls); the frame call uses the host's own   */
     int32_t max_coarse_carriers;              /* frame call and auto-acquisition: whole-carrier search */
                                               /* range, 0 = off (204)                                  */
+    int32_t decision_directed;                /* tracked call with d_cyc == NULL: fine loop on the dd4 */
+                                              /* sums, no cyclic prefix read (1; acquisition leaves    */
+                                              /* the fine offset well inside their +-0.1 carrier);     */
+                                              /* 0 = on the cyclic-prefix correlations                 */
     int32_t auto_acquire;                     /* tracked call: != 0 = streams that are not tracking    */
                                               /* (never acquired, or lost) are ACQUIRED inside the     */
                                               /* call -- null-symbol search + PRS on their capture as  */
@@ -465,7 +492,6 @@ typedef struct dabgpu_track_cfg {
                                               /* with the others', their tracking started; streams     */
                                               /* that are tracking cost nothing extra.  One call does  */
                                               /* everything from the first capture on (0)              */
-    int32_t reserved;
 } dabgpu_track_cfg;
 void dabgpu_track_default_cfg(dabgpu_track_cfg *cfg);
 /* only_lost != 0: streams that are tracking keep their state (re-acquisition of the lost ones beside them) */

@@ -366,6 +366,12 @@ void oracle_fft2048(const float *in, float *out)
 void oracle_ofdm_demod_frame(const float *iq, float freq_offset, int8_t *soft,
                              float *spectra, float *cyc, float *dqpsk)
 {
+    oracle_ofdm_demod_frame_dd(iq, freq_offset, soft, spectra, cyc, dqpsk, NULL);
+}
+
+void oracle_ofdm_demod_frame_dd(const float *iq, float freq_offset, int8_t *soft,
+                                float *spectra, float *cyc, float *dqpsk, float *dd4)
+{
     const int32_t dphi = (int32_t)lrint((double)freq_offset * 4294967296.0);
     float *y = (float *)malloc(sizeof(float) * 2 * DAB_NB_SYM_PERIOD);
     float *X[2];
@@ -412,6 +418,26 @@ void oracle_ofdm_demod_frame(const float *iq, float freq_offset, int8_t *soft,
             d[2 * i + 1] = ai * br - ar * bi;
         }
         if (dqpsk) memcpy(dqpsk + (size_t)(l - 1) * 2 * DAB_NB_CARRIERS, d, sizeof(float) * 2 * DAB_NB_CARRIERS);
+        /* decision-directed frequency error: sum of (X_l conj X_{l-1})^4 over the 256 bins v + 64 m, v = 0..63,
+           m = 0, 1, 30, 31 (the carriers nearest the centre, which a sample-clock offset rotates least), bin 0 (DC,
+           not a carrier) replaced by bin 768 */
+        if (dd4) {
+            static const int ms[4] = {0, 1, 30, 31};
+            double sr = 0.0, si = 0.0;
+            for (int k = 0; k < 4; k++)
+                for (int v = 0; v < 64; v++) {
+                    int bin = v + 64 * ms[k];
+                    if (bin == 0) bin = 768;
+                    const float ar = Xc[2 * bin], ai = Xc[2 * bin + 1];
+                    const float br = Xp[2 * bin], bi = Xp[2 * bin + 1];
+                    const float dr = ar * br + ai * bi, di = ai * br - ar * bi;
+                    const float zr = dr * dr - di * di, zi = 2.0f * dr * di;
+                    sr += (double)(zr * zr - zi * zi);
+                    si += (double)(2.0f * zr * zi);
+                }
+            dd4[2 * l] = (float)sr;
+            dd4[2 * l + 1] = (float)si;
+        }
         /* A5+A6: frequency de-interleave + L-infinity normalise + quantise */
         int8_t *o = soft + (size_t)(l - 1) * DAB_NB_SYM_BITS;
         for (int n = 0; n < DAB_NB_CARRIERS; n++) {

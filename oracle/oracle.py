@@ -196,7 +196,23 @@ def ofdm_demod_frame(iq, freq_offset=0.0, want_spectra=False, want_cyc=False, wa
     return soft, spectra, cyc, dq
 
 
-def stream_update(state, cyc, iq_last_frame, beta, thr_null_start=0.35, signal_beta=0.95):
+def ofdm_demod_frame_dd(iq, freq_offset=0.0):
+    """-> (soft, dd4): dd4 complex64[76], the decision-directed frequency-error sums (entry 0 unused)."""
+    a = np.ascontiguousarray(iq, np.complex64)
+    assert a.size == NB_SYMBOLS * NB_SYM
+    soft = np.zeros(NB_FRAME_BITS, np.int8)
+    dd4 = np.zeros(NB_SYMBOLS, np.complex64)
+    lib().oracle_ofdm_demod_frame_dd(_p(a), C.c_float(freq_offset), _p(soft), None, None, None, _p(dd4))
+    return soft, dd4
+
+
+def dd_error(dd4):
+    """Residual frequency offset (cycles/sample) from dd4 sums of any shape [..., 76]: angle(-sum over l >= 1) / (4 2 pi 2552)."""
+    s = np.asarray(dd4, np.complex128)[..., 1:].sum()
+    return np.float32(np.arctan2(-s.imag, -s.real) / (4.0 * 2.0 * np.pi * 2552.0))
+
+
+def stream_update(state, cyc, iq_last_frame, beta, thr_null_start=0.35, signal_beta=0.95, dd=False):
     """Restatement of the fine-frequency loop and counters of the stream call (TEST INFRASTRUCTURE; parity unpinned:
     the loop runs inside the absent DAB-Radio OFDM_Demod, its existence and knobs are visible at
     /root/reference/src/render_radio_block.cpp:202-207, :216).  state: dict with fine_freq_offset,
@@ -204,7 +220,10 @@ def stream_update(state, cyc, iq_last_frame, beta, thr_null_start=0.35, signal_b
     iq_last_frame: the stream's most recent frame from its first PRS sample.  Returns the new dict."""
     n = cyc.size
     frames = cyc.shape[0]
-    err = np.float32(np.angle(cyc.astype(np.complex128)).sum() / n / (2.0 * np.pi * 2048.0))
+    if dd:                                                       # `cyc` holds dd4 sums: the decision-directed loop
+        err = dd_error(cyc)
+    else:
+        err = np.float32(np.angle(cyc.astype(np.complex128)).sum() / n / (2.0 * np.pi * 2048.0))
     half = np.float32(0.5 / 2048.0)
     f = np.float32(state["fine_freq_offset"]) - np.float32(beta) * err
     if f > half:
@@ -427,7 +446,7 @@ def track_sync(iq, state, max_frames, margin=64, min_peak_to_mean=100.0, distanc
 
 
 def track_update(state, frames, cyc, iq, n_samples, max_frames, advance, fine_beta=0.9, drift_beta=0.5, signal_beta=0.95,
-                 thr_null_start=0.35):
+                 thr_null_start=0.35, dd=False):
     """State after a tracked call: `frames` from track_sync, `cyc` complex [len(frames)][76] of the demodulated frames
     (rows of unlocked frames are ignored), `iq` the capture.  Returns (new state dict, count)."""
     st = dict(state)
@@ -441,8 +460,11 @@ def track_update(state, frames, cyc, iq, n_samples, max_frames, advance, fine_be
     n = len(locked)
     desync = j0 + (count - n)
     if n > 0:
-        ang = np.angle(np.asarray(cyc)[locked].astype(np.complex128)).sum()
-        err = np.float32(np.float32(ang / (n * 76.0)) * np.float32(1.0 / (6.283185307179586 * 2048.0)))
+        if dd:
+            err = dd_error(np.asarray(cyc)[locked])
+        else:
+            ang = np.angle(np.asarray(cyc)[locked].astype(np.complex128)).sum()
+            err = np.float32(np.float32(ang / (n * 76.0)) * np.float32(1.0 / (6.283185307179586 * 2048.0)))
         half = np.float32(0.5 / 2048.0)
         f = np.float32(state["fine_freq_offset"]) - np.float32(fine_beta) * err
         if f > half:

@@ -82,6 +82,7 @@ struct dabgpu_ctx {
     bool ev_states_pending = false;
     float thr_null_start = 0.35f;        // desync threshold of the stream call (null_l1_search.thresh_null_start)
     float signal_beta = 0.95f;           // signal_l1.update_beta of the stream call
+    bool loop_dd = false;                // stream call without a correlation buffer: decision-directed fine loop
     // dabgpu_decode_stream_frames: de-interleaver rings of the stream's sub-channels, kept on the device between calls
     struct SubHistory {
         int start_address, length;
@@ -1138,6 +1139,31 @@ int dabgpu_ofdm_demod_frames_dev(dabgpu_ctx *ctx, const void *d_iq, size_t frame
     return DABGPU_OK;
 }
 
+int dabgpu_ofdm_demod_frames_dd_dev(dabgpu_ctx *ctx, const void *d_iq, size_t frame_stride, int n_frames,
+                                    const float *d_freq_offset, int8_t *d_soft, void *d_dd4, void *stream) {
+    if (!ctx || !d_soft || !d_dd4) return DABGPU_ERR_ARG;
+    DeviceGuard guard(ctx);
+    int rc = check_iq(d_iq, frame_stride, n_frames);
+    if (rc) return rc;
+    if (reinterpret_cast<uintptr_t>(d_soft) & 15u) return DABGPU_ERR_ARG;
+    if (n_frames == 0) return DABGPU_OK;
+    hipStream_t s = pick_stream(ctx, stream);
+    dabk::OfdmTables tab{ctx->d_twiddle, ctx->d_bin_of_n, ctx->d_n_of_vj};
+    dabk::OfdmArgs a{};
+    a.iq = static_cast<const float2 *>(d_iq);
+    a.frame_stride = frame_stride;
+    a.freq_offset = d_freq_offset;
+    a.n_frames = n_frames;
+    a.soft = d_soft;
+    a.dd4 = static_cast<float2 *>(d_dd4);
+    a.keep = ctx->d_keep;
+    ScopedTimer tm(ctx, 0, s);
+    const RunPlan plan = plan_runs(ctx, n_frames, NB_DATA_SYMBOLS);
+    a.uncut_frames = plan.uncut_frames;
+    HIP_TRY(dabk::launch_ofdm_demod(tab, a, plan.parts, s));
+    return DABGPU_OK;
+}
+
 int dabgpu_ofdm_set_soft_selection(dabgpu_ctx *ctx, const dabgpu_bit_range *ranges, int n_ranges) {
     if (!ctx || n_ranges < 0 || (n_ranges > 0 && !ranges)) return DABGPU_ERR_ARG;
     DeviceGuard guard(ctx);
@@ -1327,11 +1353,12 @@ int dabgpu_get_stats(dabgpu_ctx *ctx, int stream_index, dabgpu_stats *out) {
     return DABGPU_OK;
 }
 
-int dabgpu_set_stream_loop(dabgpu_ctx *ctx, float signal_update_beta, float thr_null_start) {
+int dabgpu_set_stream_loop(dabgpu_ctx *ctx, float signal_update_beta, float thr_null_start, int decision_directed) {
     if (!ctx || !(signal_update_beta >= 0.f && signal_update_beta <= 1.f) || !(thr_null_start >= 0.f && thr_null_start <= 1.f))
         return DABGPU_ERR_ARG;
     ctx->signal_beta = signal_update_beta;
     ctx->thr_null_start = thr_null_start;
+    ctx->loop_dd = decision_directed != 0;
     return DABGPU_OK;
 }
 
@@ -1349,9 +1376,13 @@ int dabgpu_ofdm_demod_streams_dev(dabgpu_ctx *ctx, const void *d_iq, size_t fram
     if (reinterpret_cast<uintptr_t>(d_soft) & 15u) return DABGPU_ERR_ARG;
     if (n_frames == 0) return DABGPU_OK;
     hipStream_t s = pick_stream(ctx, stream);
-    if (!d_cyc) {                                               // the loop needs the correlations: keep them here
-        if ((rc = stage(ctx, 6, size_t(n_frames) * NB_FRAME_SYMBOLS * sizeof(float2), &d_cyc))) return rc;
-    }
+    // No correlation output asked for: the loop's input stays in the library's scratch -- the correlations, or, once the
+    // caller has switched the loop to decision-directed (dabgpu_set_stream_loop), the fourth-power sums of the
+    // differential symbols: then the cyclic prefixes are not read at all, 17 % fewer bytes for an HBM-bound kernel.
+    const bool dd = d_cyc == nullptr && ctx->loop_dd;
+    void *d_dd = nullptr;
+    if (dd && (rc = stage(ctx, 6, size_t(n_frames) * NB_FRAME_SYMBOLS * sizeof(float2), &d_dd))) return rc;
+    if (!dd && !d_cyc && (rc = stage(ctx, 6, size_t(n_frames) * NB_FRAME_SYMBOLS * sizeof(float2), &d_cyc))) return rc;
     dabk::OfdmTables tab{ctx->d_twiddle, ctx->d_bin_of_n, ctx->d_n_of_vj};
     dabk::OfdmArgs a{};
     a.iq = static_cast<const float2 *>(d_iq);
@@ -1359,6 +1390,7 @@ int dabgpu_ofdm_demod_streams_dev(dabgpu_ctx *ctx, const void *d_iq, size_t fram
     a.n_frames = n_frames;
     a.soft = d_soft;
     a.cyc = static_cast<float2 *>(d_cyc);
+    a.dd4 = static_cast<float2 *>(d_dd);
     a.dqpsk = static_cast<float2 *>(d_dqpsk);
     a.keep = ctx->d_keep;
     a.state = ctx->d_states;
@@ -1369,8 +1401,8 @@ int dabgpu_ofdm_demod_streams_dev(dabgpu_ctx *ctx, const void *d_iq, size_t fram
         a.uncut_frames = plan.uncut_frames;
         HIP_TRY(dabk::launch_ofdm_demod(tab, a, plan.parts, s));
     }
-    HIP_TRY(dabk::launch_stream_update(ctx->d_states, a.cyc, a.iq, frame_stride, n_streams, frames_per_stream,
-                                       fine_freq_update_beta, ctx->thr_null_start, ctx->signal_beta, s));
+    HIP_TRY(dabk::launch_stream_update(ctx->d_states, dd ? a.dd4 : a.cyc, a.iq, frame_stride, n_streams, frames_per_stream,
+                                       fine_freq_update_beta, ctx->thr_null_start, ctx->signal_beta, dd ? 1 : 0, s));
     return note_state_use(ctx, s);
 }
 
@@ -1627,6 +1659,7 @@ void dabgpu_track_default_cfg(dabgpu_track_cfg *cfg) {
     cfg->coarse_freq_slow_beta = 0.1f;
     cfg->timing_margin = 64;
     cfg->max_coarse_carriers = 204;
+    cfg->decision_directed = 1;
     cfg->auto_acquire = 0;
 }
 
@@ -1669,7 +1702,8 @@ int dabgpu_track_start_dev(dabgpu_ctx *ctx, const dabgpu_acquired_frame *d_frame
 static int tracked_launches(dabgpu_ctx *ctx, dabk::StreamState *states, const void *d_iq, size_t stream_stride, int n_streams,
                             int64_t n_samples, int max_frames, int64_t advance, const dabgpu_track_cfg &c, int fixed_start,
                             int acquiring, int8_t *d_soft, void *d_cyc, void *d_dqpsk, dabgpu_acquired_frame *d_frames,
-                            dabgpu_sync_result *d_sync, int32_t *d_counts, hipStream_t s, const dabk::AcquireArgs *auto_acq = nullptr) {
+                            dabgpu_sync_result *d_sync, int32_t *d_counts, hipStream_t s, const dabk::AcquireArgs *auto_acq = nullptr,
+                            void *d_dd4 = nullptr) {
     dabk::SyncTables stab{ctx->d_twiddle, ctx->d_prs_qt, ctx->d_sync_pairs, ctx->n_sync_pairs, ctx->d_sync_fs};
     dabk::TrackArgs t{};
     t.state = states;
@@ -1698,6 +1732,7 @@ static int tracked_launches(dabgpu_ctx *ctx, dabk::StreamState *states, const vo
     a.n_frames = n_streams * max_frames;
     a.soft = d_soft;
     a.cyc = static_cast<float2 *>(d_cyc);
+    a.dd4 = static_cast<float2 *>(d_dd4);
     a.dqpsk = static_cast<float2 *>(d_dqpsk);
     a.acq = reinterpret_cast<const dabk::AcquiredFrame *>(d_frames);
     a.acq_per_stream = max_frames;
@@ -1711,7 +1746,8 @@ static int tracked_launches(dabgpu_ctx *ctx, dabk::StreamState *states, const vo
     dabk::TrackUpdateArgs u{};
     u.state = states;
     u.frames = t.out;
-    u.cyc = a.cyc;
+    u.cyc = a.cyc ? a.cyc : a.dd4;
+    u.dd = a.cyc ? 0 : 1;
     u.iq = t.iq;
     u.stream_stride = stream_stride;
     u.n_streams = n_streams;
@@ -1747,7 +1783,11 @@ int dabgpu_ofdm_demod_tracked_dev(dabgpu_ctx *ctx, const void *d_iq, size_t stre
     if (rc) return rc;
     if (n_streams == 0) return DABGPU_OK;
     hipStream_t s = pick_stream(ctx, stream);
-    if (!d_cyc && (rc = stage(ctx, 6, size_t(n_streams) * max_frames * NB_FRAME_SYMBOLS * sizeof(float2), &d_cyc))) return rc;
+    // (no correlation output asked for: by default a decision-directed loop, the cyclic prefixes are not read -- see
+    // the stream call; acquisition leaves the fine offset well inside that estimator's range)
+    void *d_dd = nullptr;
+    if (!d_cyc && (rc = stage(ctx, 6, size_t(n_streams) * max_frames * NB_FRAME_SYMBOLS * sizeof(float2), c.decision_directed ? &d_dd : &d_cyc)))
+        return rc;
     dabk::AcquireArgs acq{};
     if (c.auto_acquire && n_samples >= 64) {
         dabgpu_acquire_cfg ac;
@@ -1761,7 +1801,7 @@ int dabgpu_ofdm_demod_tracked_dev(dabgpu_ctx *ctx, const void *d_iq, size_t stre
         acq.skip_tracked = ctx->d_states;
     }
     return tracked_launches(ctx, ctx->d_states, d_iq, stream_stride, n_streams, n_samples, max_frames, advance, c, 0, 0, d_soft,
-                            d_cyc, d_dqpsk, d_frames, nullptr, d_counts, s, (c.auto_acquire && n_samples >= 64) ? &acq : nullptr);
+                            d_cyc, d_dqpsk, d_frames, nullptr, d_counts, s, (c.auto_acquire && n_samples >= 64) ? &acq : nullptr, d_dd);
 }
 
 int dabgpu_ofdm_demod_stream_frame(dabgpu_ctx *ctx, int stream_index, const float *iq, int acquiring,

@@ -41,6 +41,10 @@ struct OfdmArgs {
     int n_frames;
     int8_t *soft;              // [n_frames][230400]
     float2 *cyc;               // [n_frames][76] or nullptr
+    // decision-directed frequency error (no cyclic prefix is read): [n_frames][76]; the sum of a frame's entries 1..75 =
+    // sum over its data symbols and a fixed subset of 256 carriers (the ones nearest the centre) of (X_l conj X_{l-1})^4 (a run's total in the entry
+    // of its last symbol, zeros in its others); entry 0 is never written.  Ignored when cyc is set.
+    float2 *dd4 = nullptr;
     float2 *dqpsk;             // [n_frames][75][1536] or nullptr
     float2 *spectra;           // FFT-only mode: [n_frames][76][2048]
     // acquired mode (acq != nullptr): frame f belongs to stream f / acq_per_stream, which starts at
@@ -74,9 +78,10 @@ hipError_t launch_fill_noise(void *p, size_t bytes, hipStream_t s);
 // reads `in` and writes `out` at the same time (streaming, both whole): the launch is slower when the two buffers
 // share an HBM domain -- what the placement helpers time
 hipError_t launch_placement_probe(const void *in, size_t in_bytes, void *out, size_t out_bytes, hipStream_t s);
+// dd != 0: `cyc` holds the front end's dd4 output instead; the error is angle(-sum of all entries l >= 1) / (4 * 2 pi * 2552)
 hipError_t launch_stream_update(StreamState *state, const float2 *cyc, const float2 *iq, size_t frame_stride,
                                 int n_streams, int frames_per_stream, float beta, float thr_null_start, float signal_beta,
-                                hipStream_t s);
+                                int dd, hipStream_t s);
 
 // ---- synchronisation on the PRS (sync_kernels.hip) -----------------------------
 struct SyncTables {
@@ -190,6 +195,7 @@ struct TrackUpdateArgs {
     StreamState *state;
     const AcquiredFrame *frames;
     const float2 *cyc;         // [n_streams*max_out][76]
+    int dd = 0;                // cyc holds dd4 sums (see OfdmArgs::dd4)
     const float2 *iq;
     size_t stream_stride;
     int n_streams;

@@ -208,6 +208,9 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
     // The correlation of symbol l is one 8-byte value: written on its own it is a partial cache line that the
     // memory side has to read-modify-write.  They are collected in LDS and leave 32 at a time (or at the end of the
     // run; the last symbol of a run always has a value: only a run's reference symbol l_first > 0 has none).
+    float2 *const qout = a.cyc;
+    const bool dd = !FFT_ONLY && a.cyc == nullptr && a.dd4 != nullptr;
+    float2 ddacc = make_float2(0.f, 0.f);                       // decision-directed frequency-error sum of this lane over the run
     auto put_cyc = [&](const int l, const float2 c) {
         const int slot = (l - l_first) & 31;                    // wave-uniform
         if (lane == 0) sm.cyc[wave][slot] = c;
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
             lds_loads_may_start();
             const int li = l - slot + lane;                     // symbol whose value lane `lane` carries out
             if (lane <= slot && (FFT_ONLY || li > l_first || li == 0))
-                st_stream(a.cyc + size_t(frame) * NB_FRAME_SYMBOLS + li, sm.cyc[wave][lane]);
+                st_stream(qout + size_t(frame) * NB_FRAME_SYMBOLS + li, sm.cyc[wave][lane]);
         }
     };
 
@@ -416,6 +419,23 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
             cur[j] = X[m & 3][m >> 2];
         }
         if (lane == 0) cur[0] = X[0][3];
+        // ---- decision-directed frequency error: the fourth power of a differential symbol is -|d|^4 exp(j 4 theta)
+        // whatever its two bits are, theta = 2 pi (residual offset) 2552.  Four of the lane's 24 carriers are used: the
+        // 256 nearest the centre (bins lane, lane + 64, lane + 1920, lane + 1984 = carriers -128..127), because a sample
+        // clock that is off by e rotates carrier k by 2 pi k e 2552/2048 per symbol on top of theta -- times four, 150 ppm
+        // would turn the outer carriers' terms around (cos(4 x 0.9) < 0) while these lose 4 % and, being symmetric
+        // about the centre, stay unbiased.  Summed per lane over the whole run and reduced once at its end: what the
+        // loop needs, without a single cyclic-prefix sample being read.
+        if (dd && l > l_first) {
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) {
+                const int j = jj < 2 ? jj : 20 + jj;            // m = 0, 1, 30, 31
+                const float2 d = cmulc(cur[j], prev[j]);
+                const float2 z = make_float2(d.x * d.x - d.y * d.y, 2.0f * d.x * d.y);
+                ddacc.x += z.x * z.x - z.y * z.y;
+                ddacc.y += 2.0f * z.x * z.y;
+            }
+        }
         // soft-bit selection: bit k of the symbol's 192-bit word = its 16-byte chunk k is wanted.  A symbol nobody
         // wants skips the whole epilogue (its spectrum is still the next symbol's reference).
         bool wanted = true;
@@ -470,19 +490,37 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
 #pragma unroll
         for (int j = 0; j < 24; j++) prev[j] = cur[j];
     }
+    if (dd) {
+        // the run's sum goes to the entry of its last symbol, zeros to its other entries (one narrow store per lane)
+        const float sx = wave_sum(ddacc.x, lane), sy = wave_sum(ddacc.y, lane);
+        const int nrun = l_last - l_first;
+        for (int i = lane; i < nrun; i += 64)
+            st_stream(a.dd4 + size_t(frame) * NB_FRAME_SYMBOLS + l_first + 1 + i,
+                      i == nrun - 1 ? make_float2(sx, sy) : make_float2(0.f, 0.f));
+    }
 }
 
 // One 1024-thread workgroup per stream.  Restated by oracle.py stream_update() for the parity test.
 constexpr int SU_THREADS = 1024;
 __global__ __launch_bounds__(SU_THREADS) void stream_update_kernel(StreamState *state, const float2 *cyc, const float2 *iq,
                                                                    size_t frame_stride, int frames_per_stream, float beta,
-                                                                   float thr_null_start, float signal_beta) {
+                                                                   float thr_null_start, float signal_beta, int dd) {
     __shared__ float red[2][SU_THREADS / 64];
+    __shared__ double red_dd[2][SU_THREADS / 64];
     const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float2 *c = cyc + size_t(s) * frames_per_stream * NB_FRAME_SYMBOLS;
     const int n = frames_per_stream * NB_FRAME_SYMBOLS;
     float acc = 0.f;
-    for (int i = tid; i < n; i += SU_THREADS) acc += atan2f(c[i].y, c[i].x);
+    double sx = 0.0, sy = 0.0;
+    if (dd) {
+        for (int i = tid; i < n; i += SU_THREADS)
+            if (i % NB_FRAME_SYMBOLS) { sx += double(c[i].x); sy += double(c[i].y); }      // entry 0 of a frame is never written
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { sx += __shfl_xor(sx, off); sy += __shfl_xor(sy, off); }
+        if (lane == 0) { red_dd[0][wave] = sx; red_dd[1][wave] = sy; }
+    } else {
+        for (int i = tid; i < n; i += SU_THREADS) acc += atan2f(c[i].y, c[i].x);
+    }
     // level of the stream's most recent frame: first 4096 samples (PRS and the start of the first data symbol)
     const float4 *x = reinterpret_cast<const float4 *>(iq + (size_t(s) * frames_per_stream + (frames_per_stream - 1)) * frame_stride);
     float l1 = 0.f;
@@ -499,7 +537,13 @@ __global__ __launch_bounds__(SU_THREADS) void stream_update_kernel(StreamState *
         for (int w = 0; w < SU_THREADS / 64; w++) { acc += red[0][w]; l1 += red[1][w]; }
         l1 *= 1.0f / 4096.0f;
         StreamState st = state[s];
-        const float err = acc / float(n) * (1.0f / (6.283185307179586f * float(NB_FFT)));
+        float err = acc / float(n) * (1.0f / (6.283185307179586f * float(NB_FFT)));
+        if (dd) {
+            sx = 0.0; sy = 0.0;
+            for (int w = 0; w < SU_THREADS / 64; w++) { sx += red_dd[0][w]; sy += red_dd[1][w]; }
+            // sum = -A exp(j 4 theta), theta = 2 pi r 2552
+            err = float(atan2(-sy, -sx) / (4.0 * 6.283185307179586 * double(NB_SYM_PERIOD)));
+        }
         constexpr float HALF = 0.5f / float(NB_FFT);
         float f = st.fine_freq_offset - beta * err;
         if (f > HALF) f -= 2.f * HALF;
@@ -572,10 +616,10 @@ hipError_t launch_fill_noise(void *p, size_t bytes, hipStream_t s) {
 
 hipError_t launch_stream_update(StreamState *state, const float2 *cyc, const float2 *iq, size_t frame_stride,
                                 int n_streams, int frames_per_stream, float beta, float thr_null_start, float signal_beta,
-                                hipStream_t s) {
+                                int dd, hipStream_t s) {
     if (n_streams <= 0 || frames_per_stream <= 0) return hipSuccess;
     hipLaunchKernelGGL(stream_update_kernel, dim3(unsigned(n_streams)), dim3(SU_THREADS), 0, s, state, cyc, iq, frame_stride,
-                       frames_per_stream, beta, thr_null_start, signal_beta);
+                       frames_per_stream, beta, thr_null_start, signal_beta, dd);
     return hipGetLastError();
 }
 

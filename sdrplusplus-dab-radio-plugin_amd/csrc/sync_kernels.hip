@@ -361,7 +361,7 @@ __global__ __launch_bounds__(WG) void prs_sync_kernel(SyncTables tab, const floa
 // ---- timing tracking: state update after the demodulation of the tracked frames (TrackUpdateArgs) ----
 constexpr int TU = 1024;          // threads per stream: the kernel is one workgroup per stream and lives on loads in flight
 __global__ __launch_bounds__(TU) void track_update_kernel(TrackUpdateArgs a) {
-    __shared__ double red[6][TU];
+    __shared__ double red[7][TU];
     __shared__ int red_last[TU];
     const int s = blockIdx.x, tid = threadIdx.x;
     StreamState st = a.state[s];
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(TU) void track_update_kernel(TrackUpdateArgs a) {
     const AcquiredFrame *fr = a.frames + size_t(s) * a.max_out;
     const float2 *cyc = a.cyc + size_t(s) * a.max_out * NB_FRAME_SYMBOLS;
     // sums over the locked frames: n, i, i^2, r, i*r, and the cyclic-prefix angles
-    double sn = 0, si = 0, sii = 0, sr = 0, sir = 0, sang = 0;
+    double sn = 0, si = 0, sii = 0, sr = 0, sir = 0, sang = 0, sang2 = 0;     // (dd: sang / sang2 = real / imaginary part)
     int last = -1;
     for (int i = tid; i < count; i += TU) {
         const AcquiredFrame f = fr[i];
@@ -397,20 +397,25 @@ __global__ __launch_bounds__(TU) void track_update_kernel(TrackUpdateArgs a) {
         const int i = k / NB_FRAME_SYMBOLS;
         if ((fr[i].flags & 3) != 3) continue;
         const float2 c = cyc[k];
-        sang += double(atan2f(c.y, c.x));
+        if (a.dd) {
+            if (k - i * NB_FRAME_SYMBOLS) { sang += double(c.x); sang2 += double(c.y); }     // entry 0 is never written
+        } else {
+            sang += double(atan2f(c.y, c.x));
+        }
     }
     red[0][tid] = sn; red[1][tid] = si; red[2][tid] = sii; red[3][tid] = sr; red[4][tid] = sir; red[5][tid] = sang;
+    red[6][tid] = sang2;
     red_last[tid] = last;
     __syncthreads();
     for (int off = TU / 2; off > 0; off >>= 1) {
         if (tid < off) {
 #pragma unroll
-            for (int q = 0; q < 6; q++) red[q][tid] += red[q][tid + off];
+            for (int q = 0; q < 7; q++) red[q][tid] += red[q][tid + off];
             red_last[tid] = max(red_last[tid], red_last[tid + off]);
         }
         __syncthreads();
     }
-    sn = red[0][0]; si = red[1][0]; sii = red[2][0]; sr = red[3][0]; sir = red[4][0]; sang = red[5][0];
+    sn = red[0][0]; si = red[1][0]; sii = red[2][0]; sr = red[3][0]; sir = red[4][0]; sang = red[5][0]; sang2 = red[6][0];
     last = red_last[0];
     __syncthreads();
     // level of the last locked frame: its first 4096 samples
@@ -431,7 +436,8 @@ __global__ __launch_bounds__(TU) void track_update_kernel(TrackUpdateArgs a) {
     int desync = (a.fixed_start ? 0 : pr.j0) + (count - n_locked);
     if (n_locked > 0) {
         // fine-frequency loop
-        const float err = float(sang / (sn * double(NB_FRAME_SYMBOLS))) * (1.0f / (6.283185307179586f * float(NB_FFT)));
+        float err = float(sang / (sn * double(NB_FRAME_SYMBOLS))) * (1.0f / (6.283185307179586f * float(NB_FFT)));
+        if (a.dd) err = float(atan2(-sang2, -sang) / (4.0 * 6.283185307179586 * double(NB_SYM_PERIOD)));
         constexpr float HALF = 0.5f / float(NB_FFT);
         float f = st.fine_freq_offset - a.fine_beta * err;
         if (f > HALF) f -= 2.f * HALF;

@@ -41,7 +41,7 @@ EXPORTS = [
     "dabgpu_decode_stream_reset", "dabgpu_alloc_frame_buffers", "dabgpu_free_frame_buffers",
     "dabgpu_device_alloc_apart", "dabgpu_device_free",
     "dabgpu_set_stream_loop", "dabgpu_track_default_cfg", "dabgpu_track_start_dev", "dabgpu_ofdm_demod_tracked_dev",
-    "dabgpu_ofdm_demod_stream_frame", "dabgpu_alloc_frame_buffers_placed",
+    "dabgpu_ofdm_demod_stream_frame", "dabgpu_alloc_frame_buffers_placed", "dabgpu_ofdm_demod_frames_dd_dev",
 ]
 
 ABI_VERSION = 4
@@ -107,7 +107,7 @@ class TrackCfg(C.Structure):
     _fields_ = [("fine_freq_update_beta", C.c_float), ("signal_update_beta", C.c_float), ("thr_null_start", C.c_float),
                 ("min_peak_to_mean", C.c_float), ("impulse_peak_distance_probability", C.c_float),
                 ("first_path_rel", C.c_float), ("drift_beta", C.c_float), ("coarse_freq_slow_beta", C.c_float),
-                ("timing_margin", C.c_int32), ("max_coarse_carriers", C.c_int32), ("auto_acquire", C.c_int32), ("reserved", C.c_int32)]
+                ("timing_margin", C.c_int32), ("max_coarse_carriers", C.c_int32), ("decision_directed", C.c_int32), ("auto_acquire", C.c_int32)]
 
 
 class PlacementReport(C.Structure):
@@ -184,6 +184,7 @@ def load_library(path):
     L.dabgpu_sync.argtypes = [vp]
     L.dabgpu_ofdm_demod_frames_dev.argtypes = [vp, vp, sz, i, vp, vp, vp, vp, vp]
     L.dabgpu_ofdm_demod_frames.argtypes = [vp, vp, sz, i, vp, vp, vp, vp]
+    L.dabgpu_ofdm_demod_frames_dd_dev.argtypes = [vp, vp, sz, i, vp, vp, vp, vp]
     L.dabgpu_fft_symbols_dev.argtypes = [vp, vp, sz, i, vp, vp, vp]
     L.dabgpu_fft_symbols.argtypes = [vp, vp, sz, i, vp, vp]
     L.dabgpu_fic_decode_dev.argtypes = [vp, vp, sz, i, vp, vp, vp]
@@ -229,7 +230,7 @@ def load_library(path):
     L.dabgpu_alloc_frame_buffers_placed.argtypes = [vp, i, sz, C.POINTER(vp), C.POINTER(vp), C.POINTER(PlacementReport)]
     L.dabgpu_device_alloc_apart.argtypes = [vp, sz, vp, sz, C.POINTER(vp), C.POINTER(C.c_float)]
     L.dabgpu_device_free.argtypes = [vp, vp]
-    L.dabgpu_set_stream_loop.argtypes = [vp, C.c_float, C.c_float]
+    L.dabgpu_set_stream_loop.argtypes = [vp, C.c_float, C.c_float, i]
     L.dabgpu_track_default_cfg.restype = None
     L.dabgpu_track_default_cfg.argtypes = [C.POINTER(TrackCfg)]
     L.dabgpu_track_start_dev.argtypes = [vp, vp, vp, i, i, C.c_int64, i, vp]
@@ -451,8 +452,9 @@ class Context:
         _check(self._lib.dabgpu_get_stats(self._h, stream, C.byref(st)), "dabgpu_get_stats")
         return st
 
-    def set_stream_loop(self, signal_update_beta=0.95, thr_null_start=0.35):
-        _check(self._lib.dabgpu_set_stream_loop(self._h, signal_update_beta, thr_null_start), "dabgpu_set_stream_loop")
+    def set_stream_loop(self, signal_update_beta=0.95, thr_null_start=0.35, decision_directed=False):
+        _check(self._lib.dabgpu_set_stream_loop(self._h, signal_update_beta, thr_null_start, int(bool(decision_directed))),
+               "dabgpu_set_stream_loop")
 
     def track_start_dev(self, d_frames, d_counts, n_streams, max_frames, advance, stream=None, only_lost=False):
         _check(self._lib.dabgpu_track_start_dev(self._h, d_frames, d_counts, n_streams, max_frames, advance, int(bool(only_lost)),
@@ -652,6 +654,10 @@ class Context:
                               stream=None):
         _check(self._lib.dabgpu_ofdm_demod_frames_dev(self._h, d_iq, frame_stride, n_frames, d_freq_offset, d_soft,
                                                   d_cyc, d_dqpsk, stream), "dabgpu_ofdm_demod_frames_dev")
+
+    def ofdm_demod_frames_dd_dev(self, d_iq, frame_stride, n_frames, d_freq_offset, d_soft, d_dd4, stream=None):
+        _check(self._lib.dabgpu_ofdm_demod_frames_dd_dev(self._h, d_iq, frame_stride, n_frames, d_freq_offset, d_soft, d_dd4,
+                                                     stream), "dabgpu_ofdm_demod_frames_dd_dev")
 
     def sync_prs_dev(self, d_iq, frame_stride, n_frames, d_freq_offset, max_coarse, d_out, stream=None):
         """d_out: [n_frames] dabgpu_sync_result (4 x 32 bit: coarse_carriers, time_offset, peak_to_mean, coarse ptm)."""

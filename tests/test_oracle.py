@@ -92,3 +92,29 @@ def test_time_interleaver_is_inverse_of_deinterleaver():
     for r in range(32):
         rows = np.stack([tx[(r + k) % 32] for k in range(16)])
         assert (O.time_deinterleave(rows) == coded[r]).all()
+
+
+def test_decision_directed_frequency_error_tracks_the_cyclic_prefix_estimate(built):
+    """oracle.dd_error (fourth power of the differential symbols over the 256 centre carriers of a symbol) against the
+    cyclic-prefix estimate and the injected residual, through noise and echoes; its range is +-0.1 carrier."""
+    import numpy as np
+    from dabgpu import synth
+    from oracle import oracle as O
+    e = synth.Ensemble(seed=21, n_frames=4)
+    for resid, snr, paths in ((0.05, 12.0, None), (-0.08, 8.0, None), (0.03, 15.0, [(0, 1.0), (120, 0.8j)]), (0.0, 10.0, None)):
+        rng = np.random.default_rng(int(1000 * abs(resid)) + 7)
+        rx = synth.channel(e.iq().ravel(), snr_db=snr, cfo=resid / 2048, rng=rng, paths=paths).reshape(4, -1)
+        fr = np.ascontiguousarray(rx[0, synth.NB_NULL - 8:synth.NB_NULL - 8 + 76 * 2552])
+        _, dd = O.ofdm_demod_frame_dd(fr, 0.0)
+        _, _, cyc, _ = O.ofdm_demod_frame(fr, 0.0, want_cyc=True)
+        e_dd = float(O.dd_error(dd)) * 2048
+        e_cp = float(np.angle(cyc.astype(np.complex128)).mean() / (2 * np.pi * 2048)) * 2048
+        assert abs(e_dd - resid) < 0.004 and abs(e_cp - resid) < 0.006, (resid, e_dd, e_cp)
+    # a sample clock 150 ppm off rotates carrier k by 2 pi k 1.5e-4 2552/2048 per symbol: the outer carriers' fourth
+    # powers would point the other way, the 256 centre carriers the estimator uses do not care
+    for ppm in (150.0, -150.0):
+        rx = synth.channel(e.iq().ravel(), snr_db=15.0, cfo=0.04 / 2048, rng=np.random.default_rng(3), sco_ppm=ppm).reshape(-1)
+        start = int(round((synth.NB_NULL + 12) / (1 + ppm * 1e-6))) - 8          # resample()'s group delay is 12 samples
+        fr = np.ascontiguousarray(rx[start:start + 76 * 2552])
+        _, dd = O.ofdm_demod_frame_dd(fr, 0.0)
+        assert abs(float(O.dd_error(dd)) * 2048 - 0.04) < 0.004, (ppm, float(O.dd_error(dd)) * 2048)

@@ -223,6 +223,62 @@ def test_alloc_frame_buffers_returns_a_usable_pair(built, ensemble, ensemble_iq)
     c.close()
 
 
+def test_decision_directed_front_end_and_loop(built, ensemble, ensemble_iq):
+    """dabgpu_ofdm_demod_frames_dd_dev: the front end without the cyclic prefixes (never read) -- the same soft bits as the
+    call that produces the correlations, and dd4 sums equal to the oracle's; the stream call with d_cyc == NULL runs its
+    fine loop on them: from 0 against an unknown 0.07-carrier offset it settles like the correlation loop does, its state
+    after every call equals oracle.stream_update(dd=True) on the oracle's own sums, and the frames decode."""
+    import torch
+    from oracle import oracle as O
+    L = dabgpu.NB_FRAME_SAMPLES
+    dev = torch.device("cuda", 0)
+    cfo = 0.07 / 2048
+    rx = synth.channel(ensemble_iq.ravel(), snr_db=14.0, cfo=cfo, rng=np.random.default_rng(8),
+                       paths=[(0, 1.0), (70, 0.5j)]).reshape(ensemble_iq.shape)
+    frames = np.ascontiguousarray(rx[:4, synth.NB_NULL - 16:synth.NB_NULL - 16 + 76 * 2552])
+    n = frames.shape[0]
+    c = make_ctx(None, 8)
+    d_iq = torch.from_numpy(frames).to(dev)
+    soft = torch.zeros((n, dabgpu.NB_FRAME_BITS), dtype=torch.int8, device=dev)
+    dd4 = torch.zeros((n, 76), dtype=torch.complex64, device=dev)
+    fo = torch.full((n,), -0.02 / 2048, dtype=torch.float32, device=dev)          # a residual of 0.05 carriers is left
+    torch.cuda.synchronize()
+    c.ofdm_demod_frames_dd_dev(d_iq.data_ptr(), frames.shape[1], n, fo.data_ptr(), soft.data_ptr(), dd4.data_ptr())
+    c.sync()
+    ref_soft, ref_cyc, _ = c.ofdm_demod_frames(frames, np.full(n, -0.02 / 2048, np.float32), want_cyc=True)
+    assert (soft.cpu().numpy() == ref_soft).all()
+    got = dd4.cpu().numpy()
+    for f in range(n):
+        osoft, odd = O.ofdm_demod_frame_dd(frames[f], -0.02 / 2048)
+        # a run's total sits in the entry of its last symbol, zeros in its others (four frames on an idle chip are
+        # cut into runs of one symbol): the frame's sum is the contract
+        assert abs(got[f, 1:].sum() - odd[1:].sum()) <= 1e-4 * abs(odd[1:].sum())
+        assert got[f, 75] != 0
+        assert np.abs(soft[f].cpu().numpy().astype(np.int32) - osoft.astype(np.int32)).max() <= 1
+    # both estimators see the residual 0.07 - 0.02 = 0.05 carriers
+    e_dd = float(O.dd_error(got)) * 2048
+    e_cp = float(np.angle(ref_cyc.astype(np.complex128)).mean() / (2 * np.pi * 2048)) * 2048
+    assert abs(e_dd - 0.05) < 0.004 and abs(e_cp - 0.05) < 0.004 and abs(e_dd - e_cp) < 0.004
+    # the closed loop on it
+    c.streams_reset(1)
+    c.set_stream_loop(decision_directed=True)
+    state = {"fine_freq_offset": np.float32(0), "coarse_freq_offset": np.float32(0), "signal_average": np.float32(0),
+             "total_frames_read": 0, "total_frames_desync": 0}
+    for k in range(4):
+        torch.cuda.synchronize()
+        c.ofdm_demod_streams_dev(d_iq.data_ptr(), frames.shape[1], 1, n, 0.9, soft.data_ptr(), None, None)
+        c.sync()
+        odd = np.stack([O.ofdm_demod_frame_dd(frames[f], float(state["fine_freq_offset"]))[1] for f in range(n)])
+        state = O.stream_update(state, odd, frames[n - 1], 0.9, dd=True)
+        st = c.get_stats(0)
+        assert abs(st.fine_freq_offset - state["fine_freq_offset"]) <= 2e-9, k
+        assert st.total_frames_read == state["total_frames_read"] and st.total_frames_desync == 0
+    assert abs(st.fine_freq_offset * 2048 + 0.07) < 0.003
+    fib, ok = c.fic_decode(soft.cpu().numpy())
+    assert ok.all() and (fib == ensemble.fibs[:n]).all()
+    c.close()
+
+
 def test_alloc_frame_buffers_placed(built, ensemble_iq):
     """dabgpu_alloc_frame_buffers_placed: a small request is a plain allocation; a 5 GiB one goes through the
     virtual-memory arena (1 GiB / 256 MiB chunks, domain classification, mapped ranges): the set-up holds at most 1.2 x

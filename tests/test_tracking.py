@@ -208,6 +208,46 @@ def test_gpu_tracked_call_equals_the_oracle(tctx):
 
 
 @pytest.mark.gpu
+def test_gpu_tracked_call_decision_directed_loop_equals_the_oracle(tctx):
+    """The tracked call's default fine loop (no correlation buffer passed): decision-directed, no cyclic prefix read.  The
+    state after the call equals oracle.track_update(dd=True) fed with the oracle's own dd4 sums of the frames the call
+    found; with cfg.decision_directed = 0 the same call runs on the cyclic-prefix correlations and lands within 1e-3
+    carriers of it."""
+    import torch
+    import dabgpu
+    dev = torch.device("cuda", 0)
+    x, pos, e = short_stream(66, 10, 30.0, 0.9, 15.0, 61000)
+    n_cap, adv, MF = 3 * L + 8192, 2 * L, 4
+    d_x = torch.from_numpy(x).to(dev)
+    frames = torch.zeros((1, MF, 32), dtype=torch.uint8, device=dev)
+    counts = torch.zeros(1, dtype=torch.int32, device=dev)
+    soft = torch.zeros((MF, dabgpu.NB_FRAME_BITS), dtype=torch.int8, device=dev)
+    fines = {}
+    for name, cfg in (("dd", None), ("cp", dabgpu.track_cfg(decision_directed=0))):
+        tctx.streams_reset(1)
+        torch.cuda.synchronize()
+        tctx.acquire_dev(d_x.data_ptr(), x.size, 1, n_cap, MF, frames.data_ptr(), counts.data_ptr())
+        tctx.track_start_dev(frames.data_ptr(), counts.data_ptr(), 1, MF, adv)
+        tctx.sync()
+        before = state_dict(read_states(torch, tctx, 1)[0])
+        tctx.ofdm_demod_tracked_dev(d_x.data_ptr() + adv * 8, x.size, 1, n_cap, MF, adv, soft.data_ptr(), frames.data_ptr(),
+                                    counts.data_ptr(), cfg=cfg)
+        tctx.sync()
+        after = read_states(torch, tctx, 1)[0]
+        fines[name] = float(after["fine_freq_offset"])
+        if name == "dd":
+            cap = x[adv:adv + n_cap]
+            of = O.track_sync(cap, before, MF)
+            assert counts.cpu().numpy()[0] == len(of) == 2
+            odd = np.stack([O.ofdm_demod_frame_dd(cap[f["start"]:f["start"] + SYMS], float(f["freq_offset"]))[1] for f in of])
+            want, _ = O.track_update(before, of, odd, cap, n_cap, MF, adv, dd=True)
+            check_state(after, want, "decision-directed")
+    assert abs(fines["dd"] - fines["cp"]) * 2048 < 5e-3
+    fib, ok = tctx.fic_decode(soft.cpu().numpy()[:2])
+    assert ok.all()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("ppms", [(100.0, -100.0)])
 def test_gpu_stream_off_by_100ppm_stays_locked_for_256_frames(tctx, ppms):
     """streams resampled by +100 and -100 ppm (frame period +-19.7 samples), acquired ONCE, then
