@@ -210,7 +210,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
     // run; the last symbol of a run always has a value: only a run's reference symbol l_first > 0 has none).
     float2 *const qout = a.cyc;
     const bool dd = !FFT_ONLY && a.cyc == nullptr && a.dd4 != nullptr;
-    float2 ddacc = make_float2(0.f, 0.f);                       // decision-directed frequency-error sum of this lane over the run
+    float2 ddacc = make_float2(0.f, 0.f);                       // decision-directed frequency-error sum of the run (wave-uniform: scalar registers)
     auto put_cyc = [&](const int l, const float2 c) {
         const int slot = (l - l_first) & 31;                    // wave-uniform
         if (lane == 0) sm.cyc[wave][slot] = c;
@@ -424,17 +424,19 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
         // 256 nearest the centre (bins lane, lane + 64, lane + 1920, lane + 1984 = carriers -128..127), because a sample
         // clock that is off by e rotates carrier k by 2 pi k e 2552/2048 per symbol on top of theta -- times four, 150 ppm
         // would turn the outer carriers' terms around (cos(4 x 0.9) < 0) while these lose 4 % and, being symmetric
-        // about the centre, stay unbiased.  Summed per lane over the whole run and reduced once at its end: what the
-        // loop needs, without a single cyclic-prefix sample being read.
-        if (dd && l > l_first) {
+        // about the centre, stay unbiased.  Reduced over the wave per symbol and summed over the run in scalar registers
+        // (two more live VGPRs would spill): what the loop needs, without a single cyclic-prefix sample being read.
+        if (SELECT && dd && l > l_first) {                      // (without a selection the epilogue below does it on the way)
+            float2 t = make_float2(0.f, 0.f);
 #pragma unroll
             for (int jj = 0; jj < 4; jj++) {
                 const int j = jj < 2 ? jj : 20 + jj;            // m = 0, 1, 30, 31
                 const float2 d = cmulc(cur[j], prev[j]);
                 const float2 z = make_float2(d.x * d.x - d.y * d.y, 2.0f * d.x * d.y);
-                ddacc.x += z.x * z.x - z.y * z.y;
-                ddacc.y += 2.0f * z.x * z.y;
+                t.x += z.x * z.x - z.y * z.y;
+                t.y += 2.0f * z.x * z.y;
             }
+            ddacc = uniform(make_float2(ddacc.x + wave_sum(t.x, lane), ddacc.y + wave_sum(t.y, lane)));
         }
         // soft-bit selection: bit k of the symbol's 192-bit word = its 16-byte chunk k is wanted.  A symbol nobody
         // wants skips the whole epilogue (its spectrum is still the next symbol's reference).
@@ -448,9 +450,15 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
         if (l > l_first && wanted) {
             uint8_t *stg = reinterpret_cast<uint8_t *>(ex);
             lds_stores_done();
+            float2 t = make_float2(0.f, 0.f);
 #pragma unroll
             for (int j = 0; j < 24; j++) {
                 const float2 d = cmulc(cur[j], prev[j]);
+                if (!SELECT && (j < 2 || j >= 22) && dd) {
+                    const float2 z = make_float2(d.x * d.x - d.y * d.y, 2.0f * d.x * d.y);
+                    t.x += z.x * z.x - z.y * z.y;
+                    t.y += 2.0f * z.x * z.y;
+                }
                 // A6: trunc(-127 * c / max(|re|,|im|)).  One v_rcp (1 ulp) instead of two IEEE divisions; the 2^-22
                 // head-room keeps the larger component's product in [127, 127.0001], which the truncating conversion
                 // turns into exactly +-127 as an exact division gives (no clamp needed: nothing exceeds 127.0001).
@@ -471,6 +479,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
                     st_stream(dq + (bin >= 1280 ? bin - 1280 : bin + 767), d);
                 }
             }
+            if (!SELECT && dd) ddacc = uniform(make_float2(ddacc.x + wave_sum(t.x, lane), ddacc.y + wave_sum(t.y, lane)));
             lds_stores_done();
             lds_loads_may_start();
             const uint4 *sv = reinterpret_cast<const uint4 *>(stg) + lane;
@@ -492,7 +501,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
     }
     if (dd) {
         // the run's sum goes to the entry of its last symbol, zeros to its other entries (one narrow store per lane)
-        const float sx = wave_sum(ddacc.x, lane), sy = wave_sum(ddacc.y, lane);
+        const float sx = ddacc.x, sy = ddacc.y;
         const int nrun = l_last - l_first;
         for (int i = lane; i < nrun; i += 64)
             st_stream(a.dd4 + size_t(frame) * NB_FRAME_SYMBOLS + l_first + 1 + i,

@@ -2,7 +2,8 @@
 """A/B between builds of libdabgpu.so INSIDE one process: same buffers, same physical pages, launches alternated --
 the process-to-process spread of the HBM-bound kernels (+-4 %) drops out and 0.3 % differences become visible.
 usage: tools/ab_inproc.py <mode> <n_frames> <rounds> <reps> lib1.so lib2.so ...   ("default" = the in-tree library)
-modes: ofdm (fused front end, NCO + cyc) | fft (FFT stage only) | select (front end with a soft-bit selection) |
+modes: ofdm (fused front end, NCO + cyc) | dd (the same with decision-directed sums, no cyclic prefix read) |
+       select_dd (dd with a soft-bit selection) | bare (no estimator output at all) | fft (FFT stage only) | select (front end with a soft-bit selection) |
        acquire (null search + PRS sync on unaligned captures) | decode (FIC + one sub-channel, grouped launch) |
        multiplex (FIC + 18 sub-channels)"""
 import os, sys
@@ -15,7 +16,7 @@ dev = torch.device("cuda", 0)
 L, NB = dabgpu.NB_FRAME_SAMPLES, dabgpu.NB_FRAME_BITS
 st = torch.cuda.Stream(); torch.cuda.set_stream(st); s = st.cuda_stream
 E = 64; F = max(1, n // E)
-if mode in ("ofdm", "fft", "select", "acquire"):
+if mode in ("ofdm", "fft", "select", "acquire", "dd", "select_dd", "bare"):
     iq = torch.empty((n, L, 2), dtype=torch.float32, device=dev).normal_()
     fo = torch.full((n,), 1.0e-4, dtype=torch.float32, device=dev)
 if mode in ("ofdm", "select"):
@@ -23,6 +24,14 @@ if mode in ("ofdm", "select"):
     outs = [soft, cyc]
     sel = dabgpu.soft_selection([dabgpu.subchannel(0, 64, level=3)], True) if mode == "select" else None
     def run(c): c.ofdm_demod_frames_dev(iq.data_ptr(), L, n, fo.data_ptr(), soft.data_ptr(), cyc.data_ptr(), None, s)
+elif mode in ("dd", "select_dd", "bare"):
+    soft = torch.zeros((n, NB), dtype=torch.int8, device=dev); dd4 = torch.zeros((n, 76, 2), dtype=torch.float32, device=dev)
+    outs = [soft, dd4]
+    sel = dabgpu.soft_selection([dabgpu.subchannel(0, 64, level=3)], True) if mode == "select_dd" else None
+    if mode == "bare":
+        def run(c): c.ofdm_demod_frames_dev(iq.data_ptr(), L, n, fo.data_ptr(), soft.data_ptr(), None, None, s)
+    else:
+        def run(c): c.ofdm_demod_frames_dd_dev(iq.data_ptr(), L, n, fo.data_ptr(), soft.data_ptr(), dd4.data_ptr(), s)
 elif mode == "fft":
     spec = torch.zeros((n, 76, 2048, 2), dtype=torch.float32, device=dev); outs = [spec]; sel = None
     def run(c): c.fft_symbols_dev(iq.data_ptr(), L, n, fo.data_ptr(), spec.data_ptr(), s)

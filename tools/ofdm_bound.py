@@ -56,10 +56,14 @@ rows.append(("same, without the cyclic-prefix correlation output",
              t(lambda: ctx.ofdm_demod_acquired_dev(d_iq, F * 196608, 1, n, tab_c.data_ptr(), soft.data_ptr(), None, None, s))))
 rows.append(("aligned frames from HBM, NCO, no cyc (-17 % bytes, -4 % instr.)",
              t(lambda: ctx.ofdm_demod_frames_dev(d_iq + 2656 * 8, 196608, n, fo.data_ptr(), soft.data_ptr(), None, None, s))))
+dd4 = torch.zeros((n, 76, 2), dtype=torch.float32, device=dev)
+rows.append(("aligned frames from HBM, NCO, decision-directed sums instead of cyc (no prefix read)",
+             t(lambda: ctx.ofdm_demod_frames_dd_dev(d_iq + 2656 * 8, 196608, n, fo.data_ptr(), soft.data_ptr(), dd4.data_ptr(), s))))
 rows.append(("aligned frames from HBM, no NCO, cyc (same bytes, -14 % instr.)",
              t(lambda: ctx.ofdm_demod_frames_dev(d_iq + 2656 * 8, 196608, n, None, soft.data_ptr(), cyc.data_ptr(), None, s))))
 rows.append(("aligned frames from HBM, no NCO, no cyc",
              t(lambda: ctx.ofdm_demod_frames_dev(d_iq + 2656 * 8, 196608, n, None, soft.data_ptr(), None, None, s))))
 print("# tools/ofdm_bound.py  %d frames per launch, lib %s" % (n, os.environ.get("DABGPU_LIB", "default")))
 for name, (mn, av) in rows:
-    print("%-62s min %.3f ms  mean %.3f ms  (%.0f GB/s algorithmic at min)" % (name, mn, av, A * n / mn / 1e6))
+    a = A if ("cyc" in name and "no cyc" not in name and "instead of cyc" not in name and "without" not in name) else A - 76 * 504 * 8
+    print("%-86s min %.3f ms  mean %.3f ms  (%.0f GB/s on the bytes this row moves)" % (name, mn, av, a * n / mn / 1e6))
