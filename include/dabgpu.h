@@ -216,14 +216,17 @@ int dabgpu_ofdm_demod_frames(dabgpu_ctx *ctx, const float *iq, size_t frame_stri
 /* The same front end WITHOUT reading a single cyclic-prefix sample (17 % of the bytes of an HBM-bound kernel), with the
  * decision-directed frequency-error sums a loop needs instead of the cyclic-prefix correlations:
  *   dd4  [n_frames][76] cf32; the SUM of entries 1..75 of a frame = sum over its 75 data symbols and 256 of each
- *        symbol's carriers (FFT bins v + 64 m, v < 64, m in {0, 1, 30, 31}, bin 0 replaced by 768) of (X_l conj X_{l-1})^4
+ *        symbol's carriers (FFT bins v + 64 m, v < 64, m in {0, 1, 30, 31}, bin 0 replaced by 768) of u^4, u = the
+ *        differential symbol X_l conj X_{l-1} divided by its magnitude (every term has magnitude 1 whatever the level of
+ *        the input; |sum| / 19200 is a lock quality between 0 and 1)
  *        (how the sum is spread over the entries depends on how the launch cut the frame into runs: a run's total sits
  *        in the entry of its last symbol, its other entries are 0).  Whatever two bits a differential
  *        symbol carries, its fourth power is -|d|^4 exp(j 4 theta) with theta = 2 pi * (residual offset, cycles per
  *        sample) * 2552: angle(-sum) / (4 * 2 pi * 2552) is the residual, unambiguous within +-0.1 carrier (the loop
  *        must have been brought that close first: acquisition's estimate from the PRS prefix is).  Entry 0 of a frame
  *        is not written.
- * The closed-loop calls below run on this when the caller does not ask for the correlations (d_cyc == NULL). */
+ * The tracked call below runs on this by default (dabgpu_track_cfg.decision_directed), the stream call after
+ * dabgpu_set_stream_loop(..., decision_directed = 1), whenever the caller does not ask for the correlations (d_cyc == NULL). */
 int dabgpu_ofdm_demod_frames_dd_dev(dabgpu_ctx *ctx, const void *d_iq, size_t frame_stride, int n_frames,
                                     const float *d_freq_offset, int8_t *d_soft, void *d_dd4, void *stream);
 

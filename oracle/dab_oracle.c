@@ -431,7 +431,14 @@ void oracle_ofdm_demod_frame_dd(const float *iq, float freq_offset, int8_t *soft
                     const float ar = Xc[2 * bin], ai = Xc[2 * bin + 1];
                     const float br = Xp[2 * bin], bi = Xp[2 * bin + 1];
                     const float dr = ar * br + ai * bi, di = ai * br - ar * bi;
-                    const float zr = dr * dr - di * di, zi = 2.0f * dr * di;
+                    /* its direction only: scaled as the quantiser scales it (A6: larger component = 127, not
+                       truncated), then to unit magnitude -- no input level overflows or vanishes */
+                    const float A = fmaxf(fabsf(dr), fabsf(di));
+                    if (A == 0.0f) continue;
+                    const float fr = -127.0f * (dr / A), fi = -127.0f * (di / A);
+                    const float g = 1.0f / sqrtf(fr * fr + fi * fi);
+                    const float ur = fr * g, ui = fi * g;
+                    const float zr = ur * ur - ui * ui, zi = 2.0f * ur * ui;
                     sr += (double)(zr * zr - zi * zi);
                     si += (double)(2.0f * zr * zi);
                 }

@@ -116,7 +116,8 @@ void oracle_fft2048(const float *in_cf32, float *out_cf32);  /* forward, unnorma
 void oracle_ofdm_demod_frame(const float *iq, float freq_offset, int8_t *soft,
                              float *spectra, float *cyc, float *dqpsk);
 /* ... and dd4 (may be NULL) 76 cf32: entry l >= 1 = sum over 256 carriers (bins v + 64 m, v < 64, m in {0, 1, 30, 31}, DC
-   replaced by bin 768) of (X_l conj X_{l-1})^4 -- the decision-directed frequency-error estimator: whatever
+   replaced by bin 768) of u^4, u = (X_l conj X_{l-1}) / |X_l conj X_{l-1}| (taken from A6's scaling:
+   no input level overflows the sum) -- the decision-directed frequency-error estimator: whatever
    two bits a differential symbol carries, its fourth power is -|d|^4 exp(j 4 theta), theta = 2 pi (residual offset)
    2552.  Entry 0 is not written.  No cyclic-prefix sample is needed for it. */
 void oracle_ofdm_demod_frame_dd(const float *iq, float freq_offset, int8_t *soft,

@@ -65,6 +65,12 @@ __device__ __forceinline__ float2 cmul_k(float2 a, float c, float s) {   // a * 
     return make_float2(a.x * c - a.y * s, a.x * s + a.y * c);
 }
 
+// (x, y) / |(x, y)| for a vector whose larger component has magnitude 127 (the quantiser's scaling); (0, 0) stays (0, 0)
+__device__ __forceinline__ float2 unit_of(float x, float y) {
+    const float g = __builtin_amdgcn_rsqf(fmaxf(x * x + y * y, 1.0f));
+    return make_float2(x * g, y * g);
+}
+
 // a wave-uniform value, kept in a scalar register
 __device__ __forceinline__ float uniform(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 __device__ __forceinline__ float2 uniform(float2 v) { return make_float2(uniform(v.x), uniform(v.y)); }
@@ -420,7 +426,9 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
         }
         if (lane == 0) cur[0] = X[0][3];
         // ---- decision-directed frequency error: the fourth power of a differential symbol is -|d|^4 exp(j 4 theta)
-        // whatever its two bits are, theta = 2 pi (residual offset) 2552.  Four of the lane's 24 carriers are used: the
+        // whatever its two bits are, theta = 2 pi (residual offset) 2552.  Each symbol enters with unit magnitude (its
+        // direction, taken from the soft-bit quantiser's scaling): every carrier weighs the same, the estimator's gain
+        // is 1, and no input level can overflow the sum.  Four of the lane's 24 carriers are used: the
         // 256 nearest the centre (bins lane, lane + 64, lane + 1920, lane + 1984 = carriers -128..127), because a sample
         // clock that is off by e rotates carrier k by 2 pi k e 2552/2048 per symbol on top of theta -- times four, 150 ppm
         // would turn the outer carriers' terms around (cos(4 x 0.9) < 0) while these lose 4 % and, being symmetric
@@ -432,7 +440,9 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
             for (int jj = 0; jj < 4; jj++) {
                 const int j = jj < 2 ? jj : 20 + jj;            // m = 0, 1, 30, 31
                 const float2 d = cmulc(cur[j], prev[j]);
-                const float2 z = make_float2(d.x * d.x - d.y * d.y, 2.0f * d.x * d.y);
+                const float sc = -127.00003f * __builtin_amdgcn_rcpf(fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), 1.0e-30f));
+                const float2 u = unit_of(d.x * sc, d.y * sc);
+                const float2 z = make_float2(u.x * u.x - u.y * u.y, 2.0f * u.x * u.y);
                 t.x += z.x * z.x - z.y * z.y;
                 t.y += 2.0f * z.x * z.y;
             }
@@ -454,18 +464,22 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
 #pragma unroll
             for (int j = 0; j < 24; j++) {
                 const float2 d = cmulc(cur[j], prev[j]);
-                if (!SELECT && (j < 2 || j >= 22) && dd) {
-                    const float2 z = make_float2(d.x * d.x - d.y * d.y, 2.0f * d.x * d.y);
-                    t.x += z.x * z.x - z.y * z.y;
-                    t.y += 2.0f * z.x * z.y;
-                }
                 // A6: trunc(-127 * c / max(|re|,|im|)).  One v_rcp (1 ulp) instead of two IEEE divisions; the 2^-22
                 // head-room keeps the larger component's product in [127, 127.0001], which the truncating conversion
                 // turns into exactly +-127 as an exact division gives (no clamp needed: nothing exceeds 127.0001).
                 // A == 0 (erased carrier) yields 0 because d == 0 and the floor keeps sc finite.
                 const float Amax = fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), 1.0e-30f);
                 const float sc = -127.00003f * __builtin_amdgcn_rcpf(Amax);
-                const int br = int(d.x * sc), bi = int(d.y * sc);
+                const float fx = d.x * sc, fy = d.y * sc;
+                const int br = int(fx), bi = int(fy);
+                if (!SELECT && (j < 2 || j >= 22) && dd) {
+                    // the decision-directed sum takes the differential symbol's direction only (from the quantiser's
+                    // scaling, larger component = 127: nothing can overflow or vanish whatever the level of the input)
+                    const float2 u = unit_of(fx, fy);
+                    const float2 z = make_float2(u.x * u.x - u.y * u.y, 2.0f * u.x * u.y);
+                    t.x += z.x * z.x - z.y * z.y;
+                    t.y += 2.0f * z.x * z.y;
+                }
                 const uint32_t nd = sm.nidx[(j >> 1) * 64 + lane];
                 const uint32_t ni = (j & 1) ? (nd >> 16) : (nd & 0xFFFFu);
                 stg[ni] = uint8_t(br);

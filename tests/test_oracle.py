@@ -118,3 +118,7 @@ def test_decision_directed_frequency_error_tracks_the_cyclic_prefix_estimate(bui
         fr = np.ascontiguousarray(rx[start:start + 76 * 2552])
         _, dd = O.ofdm_demod_frame_dd(fr, 0.0)
         assert abs(float(O.dd_error(dd)) * 2048 - 0.04) < 0.004, (ppm, float(O.dd_error(dd)) * 2048)
+    # the level of the input does not matter (every term is scaled as the quantiser scales it): 16-bit sample values
+    # would overflow a plain fourth power of X conj X in single precision
+    _, dd_big = O.ofdm_demod_frame_dd(fr * np.float32(30000.0), 0.0)
+    assert np.isfinite(dd_big).all() and abs(float(O.dd_error(dd_big)) - float(O.dd_error(dd))) * 2048 < 1e-5

@@ -255,6 +255,15 @@ def test_decision_directed_front_end_and_loop(built, ensemble, ensemble_iq):
         assert abs(got[f, 1:].sum() - odd[1:].sum()) <= 1e-4 * abs(odd[1:].sum())
         assert got[f, 75] != 0
         assert np.abs(soft[f].cpu().numpy().astype(np.int32) - osoft.astype(np.int32)).max() <= 1
+    # samples at 16-bit scale: same soft bits, finite sums, same estimate (a plain (X conj X)^4 would overflow)
+    d_big = d_iq * 30000.0
+    soft_b = torch.zeros_like(soft); dd4_b = torch.zeros_like(dd4)
+    torch.cuda.synchronize()
+    c.ofdm_demod_frames_dd_dev(d_big.data_ptr(), frames.shape[1], n, fo.data_ptr(), soft_b.data_ptr(), dd4_b.data_ptr())
+    c.sync()
+    big = dd4_b.cpu().numpy()
+    assert np.isfinite(big.view(np.float32)).all() and (np.abs(soft_b.cpu().numpy().astype(np.int32) - ref_soft) <= 1).all()
+    assert abs(float(O.dd_error(big)) - float(O.dd_error(got))) * 2048 < 1e-4
     # both estimators see the residual 0.07 - 0.02 = 0.05 carriers
     e_dd = float(O.dd_error(got)) * 2048
     e_cp = float(np.angle(ref_cyc.astype(np.complex128)).mean() / (2 * np.pi * 2048)) * 2048
