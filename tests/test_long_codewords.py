@@ -105,6 +105,19 @@ def test_every_entry_point_accepts_empty_batches():
     assert L.dabgpu_viterbi_dev(h, d, 0, mask, 102, d, None) == 0
     assert L.dabgpu_dabplus_superframes_dev(h, d, 960, 0, 64, d, d, None) == 0
     assert L.dabgpu_streams_reset(h, 0) == 0
+    # the ABI-v4 entry points: tracking, the decision-directed front end
+    assert L.dabgpu_ofdm_demod_frames_dd_dev(h, d, 196608, 0, None, d, d, None) == 0
+    assert L.dabgpu_track_start_dev(h, d, d, 0, 4, 196608, 0, None) == 0
+    assert L.dabgpu_track_start_dev(h, d, d, 0, 4, 196608, 1, None) == 0
+    assert L.dabgpu_ofdm_demod_tracked_dev(h, d, 0, 0, 400000, 4, 196608, None, d, None, None, d, d, None) == 0
+    cfg = dabgpu.track_cfg(auto_acquire=1)
+    assert L.dabgpu_ofdm_demod_tracked_dev(h, d, 0, 0, 400000, 4, 196608, C.byref(cfg), d, None, None, d, d, None) == 0
+    # ... and their argument checks: no frame table, no frame slots, more streams than states
+    assert L.dabgpu_ofdm_demod_tracked_dev(h, d, 0, 0, 400000, 4, 196608, None, d, None, None, None, d, None) == -1
+    assert L.dabgpu_ofdm_demod_tracked_dev(h, d, 0, 0, 400000, 0, 196608, None, d, None, None, d, d, None) == -1
+    assert L.dabgpu_ofdm_demod_tracked_dev(h, d, 400000, 3, 400000, 4, 196608, None, d, None, None, d, d, None) == -6
+    assert L.dabgpu_track_start_dev(h, d, d, 3, 4, 196608, 0, None) == -6
+    assert L.dabgpu_ofdm_demod_frames_dd_dev(h, d, 196608, 1, None, d, None, None) == -1      # no place for the sums
     c.sync()
     assert int(buf.sum().item()) == 0
     # the host-pointer variants
