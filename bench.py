@@ -632,13 +632,14 @@ def main():
             sel_ofdm = float(np.mean([a.elapsed_time(b) for a, b in ofdm_ev[n_before:]]))
             sel = dabgpu.soft_selection([sc])
             kept = sum(c for _, c in sel)
-            # symbols that are transformed: those carrying selected bits and their differential references; the
-            # others are read only for the cyclic-prefix correlation (prefix + last 512 samples)
+            # symbols that are transformed: those carrying selected bits and their differential references; with the
+            # decision-directed loop of the timed step the others are not read at all (a loop on the cyclic-prefix
+            # correlations would read their prefix + last 512 samples)
             wanted = np.zeros(76, bool)
             for first, count in sel:
                 wanted[1 + first // 3072: 1 + (first + count - 1) // 3072 + 1] = True
             need = wanted | np.append(wanted[1:], False)
-            a_sel = int(need.sum()) * 2552 * 8 + int((~need).sum()) * (504 + 512) * 8 + kept
+            a_sel = int(need.sum()) * 2048 * 8 + kept
             out["selective_soft_output"] = {
                 "value": n_frames * args.steps / sel_s, "unit": "frames/s", "ms_per_step": sel_s / args.steps * 1e3,
                 "ofdm_avg_launch_ms": sel_ofdm, "soft_bits_written_per_frame": kept,

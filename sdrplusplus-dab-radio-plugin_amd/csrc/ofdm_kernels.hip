@@ -428,26 +428,13 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
         // ---- decision-directed frequency error: the fourth power of a differential symbol is -|d|^4 exp(j 4 theta)
         // whatever its two bits are, theta = 2 pi (residual offset) 2552.  Each symbol enters with unit magnitude (its
         // direction, taken from the soft-bit quantiser's scaling): every carrier weighs the same, the estimator's gain
-        // is 1, and no input level can overflow the sum.  Four of the lane's 24 carriers are used: the
-        // 256 nearest the centre (bins lane, lane + 64, lane + 1920, lane + 1984 = carriers -128..127), because a sample
+        // is 1, and no input level can overflow the sum.  With a soft-bit selection only the symbols whose bits are wanted
+        // contribute (their differential reference is then a transformed symbol by construction).  Four of the lane's
+        // 24 carriers are used: the 256 nearest the centre (bins lane, lane + 64, lane + 1920, lane + 1984 = carriers -128..127), because a sample
         // clock that is off by e rotates carrier k by 2 pi k e 2552/2048 per symbol on top of theta -- times four, 150 ppm
         // would turn the outer carriers' terms around (cos(4 x 0.9) < 0) while these lose 4 % and, being symmetric
         // about the centre, stay unbiased.  Reduced over the wave per symbol and summed over the run in scalar registers
         // (two more live VGPRs would spill): what the loop needs, without a single cyclic-prefix sample being read.
-        if (SELECT && dd && l > l_first) {                      // (without a selection the epilogue below does it on the way)
-            float2 t = make_float2(0.f, 0.f);
-#pragma unroll
-            for (int jj = 0; jj < 4; jj++) {
-                const int j = jj < 2 ? jj : 20 + jj;            // m = 0, 1, 30, 31
-                const float2 d = cmulc(cur[j], prev[j]);
-                const float sc = -127.00003f * __builtin_amdgcn_rcpf(fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), 1.0e-30f));
-                const float2 u = unit_of(d.x * sc, d.y * sc);
-                const float2 z = make_float2(u.x * u.x - u.y * u.y, 2.0f * u.x * u.y);
-                t.x += z.x * z.x - z.y * z.y;
-                t.y += 2.0f * z.x * z.y;
-            }
-            ddacc = uniform(make_float2(ddacc.x + wave_sum(t.x, lane), ddacc.y + wave_sum(t.y, lane)));
-        }
         // soft-bit selection: bit k of the symbol's 192-bit word = its 16-byte chunk k is wanted.  A symbol nobody
         // wants skips the whole epilogue (its spectrum is still the next symbol's reference).
         bool wanted = true;
@@ -472,7 +459,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
                 const float sc = -127.00003f * __builtin_amdgcn_rcpf(Amax);
                 const float fx = d.x * sc, fy = d.y * sc;
                 const int br = int(fx), bi = int(fy);
-                if (!SELECT && (j < 2 || j >= 22) && dd) {
+                if ((j < 2 || j >= 22) && dd) {
                     // the decision-directed sum takes the differential symbol's direction only (from the quantiser's
                     // scaling, larger component = 127: nothing can overflow or vanish whatever the level of the input)
                     const float2 u = unit_of(fx, fy);
@@ -493,7 +480,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
                     st_stream(dq + (bin >= 1280 ? bin - 1280 : bin + 767), d);
                 }
             }
-            if (!SELECT && dd) ddacc = uniform(make_float2(ddacc.x + wave_sum(t.x, lane), ddacc.y + wave_sum(t.y, lane)));
+            if (dd) ddacc = uniform(make_float2(ddacc.x + wave_sum(t.x, lane), ddacc.y + wave_sum(t.y, lane)));
             lds_stores_done();
             lds_loads_may_start();
             const uint4 *sv = reinterpret_cast<const uint4 *>(stg) + lane;

@@ -53,6 +53,19 @@ def test_selected_output_equals_whole_frame_run(built, ensemble, ensemble_iq, pa
     for first, count in sel:
         want[:, first:first + count] = full[:, first:first + count]
     assert (got == want).all()
+    # the decision-directed sums under a selection: the symbols whose bits are wanted contribute, nothing else
+    from oracle import oracle as O
+    wanted = sorted({(b // 3072) + 1 for first, count in sel for b in range(first, first + count, 16)})
+    d_soft2 = torch.full((n, dabgpu.NB_FRAME_BITS), 99, dtype=torch.int8, device=dev)
+    d_dd = torch.zeros((n, 76), dtype=torch.complex64, device=dev)
+    torch.cuda.synchronize()
+    c.ofdm_demod_frames_dd_dev(d_iq.data_ptr(), frames.shape[1], n, d_fo.data_ptr(), d_soft2.data_ptr(), d_dd.data_ptr())
+    c.sync()
+    assert (d_soft2.cpu().numpy() == want).all()
+    dd = d_dd.cpu().numpy()
+    for f in range(2):
+        ref = O.ofdm_demod_frame_dd(frames[f], float(fo[f]))[1][wanted].astype(np.complex128).sum()
+        assert abs(dd[f, 1:].astype(np.complex128).sum() - ref) <= 1e-4 * abs(ref), (f, parts)
     # the host-pointer call copies back the selected runs only: the rest of the caller's buffer stays as it was
     host = np.full_like(full, 99)
     c.ofdm_demod_frames(frames, fo, soft=host)
