@@ -152,8 +152,12 @@ int dabgpu_free_frame_buffers(dabgpu_ctx *ctx, void *d_iq, int8_t *d_soft);
  * chunk's HBM domain is found with a small data mover (a launch that reads chunk a and writes chunk b is ~10 % slower
  * when they share a domain: two passes, ~40 ms), the IQ buffer is mapped over chunks of the most plentiful domain(s)
  * and every 256 MiB of the soft-bit buffer over a chunk whose domain differs from the ~1.7 GiB of samples that are
- * read WHILE it is written (the front end walks both buffers in frame order); the chunks left over are released.  Falls back to a plain allocation (method 0) for small buffers or when
- * the virtual-memory API is not available.  The report (may be NULL) says what was found and what one front-end
+ * read WHILE it is written (the front end walks both buffers in frame order); the chunks left over are released.
+ * One case needs more than 1.2 x for a moment: a fresh device hands out its memory in address order and a domain's
+ * address ranges are tens of GB long, so the whole budget can lie in ONE domain.  Then 1 GiB spacers are taken (and
+ * classified one by one) until enough of them lie elsewhere to carry the soft bits; the others go back before the call
+ * returns, setup_peak_bytes says what was held, and what the caller keeps is the two buffers as always.
+ * Falls back to a plain allocation (method 0) for small buffers or when the virtual-memory API is not available.  The report (may be NULL) says what was found and what one front-end
  * launch on the placed pair takes.  Release with dabgpu_free_frame_buffers. */
 typedef struct dabgpu_placement_report {
     int32_t method;             /* 0 = plain hipMalloc, 1 = domain-aware arena                                 */
@@ -166,7 +170,7 @@ typedef struct dabgpu_placement_report {
     float classify_ms;          /* time spent finding the domains                                              */
     float front_end_ms;         /* one timed front-end launch on the placed pair (noise input)                 */
     char domains[72];           /* one letter per chunk in allocation order: 'A' 'B' 'C' for the 1 GiB chunks, */
-                                /* 'a' 'b' 'c' for the 256 MiB ones; NUL-terminated                            */
+                                /* 'a' 'b' 'c' for the 256 MiB ones, then the spacers; NUL-terminated, cut at 71 */
     char iq_map[72];            /* the chunks of the IQ buffer in address order, same letters                  */
     char soft_map[24];          /* the chunks of the soft-bit buffer in address order                          */
 } dabgpu_placement_report;
@@ -213,18 +217,20 @@ int dabgpu_ofdm_demod_frames_dev(dabgpu_ctx *ctx, const void *d_iq, size_t frame
                                  void *stream);
 int dabgpu_ofdm_demod_frames(dabgpu_ctx *ctx, const float *iq, size_t frame_stride, int n_frames,
                              const float *freq_offset, int8_t *soft, float *cyc, float *dqpsk);
-/* The same front end WITHOUT reading a single cyclic-prefix sample (17 % of the bytes of an HBM-bound kernel), with the
- * decision-directed frequency-error sums a loop needs instead of the cyclic-prefix correlations:
+/* The same front end reading ONE cyclic prefix per frame instead of 76 (the prefixes are 20 % of the samples, and the
+ * kernel is bound by the bytes it moves), with the decision-directed frequency-error sums a loop needs instead of the
+ * cyclic-prefix correlations:
  *   dd4  [n_frames][76] cf32; the SUM of entries 1..75 of a frame = sum over its 75 data symbols and 256 of each
  *        symbol's carriers (FFT bins v + 64 m, v < 64, m in {0, 1, 30, 31}, bin 0 replaced by 768) of u^4, u = the
  *        differential symbol X_l conj X_{l-1} divided by its magnitude (every term has magnitude 1 whatever the level of
- *        the input; |sum| / 19200 is a lock quality between 0 and 1)
- *        (how the sum is spread over the entries depends on how the launch cut the frame into runs: a run's total sits
- *        in the entry of its last symbol, its other entries are 0).  Whatever two bits a differential
- *        symbol carries, its fourth power is -|d|^4 exp(j 4 theta) with theta = 2 pi * (residual offset, cycles per
- *        sample) * 2552: angle(-sum) / (4 * 2 pi * 2552) is the residual, unambiguous within +-0.1 carrier (the loop
- *        must have been brought that close first: acquisition's estimate from the PRS prefix is).  Entry 0 of a frame
- *        is not written.
+ *        the input; |sum| / 19200 is a lock quality between 0 and 1).  How the sum is spread over the entries depends on
+ *        how the launch cut the frame into runs: a run's total sits in the entry of its last symbol, its other entries
+ *        are 0.  Whatever two bits a differential symbol carries, its fourth power is -exp(j 4 theta) with theta =
+ *        2 pi * (residual offset, cycles per sample) * 2552: angle(-sum) / (4 * 2 pi * 2552) is the residual modulo
+ *        1 / (4 * 2552) (0.2 carriers).
+ *        Entry 0 of a frame = the cyclic-prefix correlation of its PRS (symbol 0; the one prefix that IS read, 0.3 % of
+ *        the frame): angle / (2 pi 2048) is the same residual, coarser but unambiguous within half a carrier -- it picks
+ *        the branch: residual = e_dd + k / (4 * 2552), k = round((e_cp - e_dd) * 4 * 2552).
  * The tracked call below runs on this by default (dabgpu_track_cfg.decision_directed), the stream call after
  * dabgpu_set_stream_loop(..., decision_directed = 1), whenever the caller does not ask for the correlations (d_cyc == NULL). */
 int dabgpu_ofdm_demod_frames_dd_dev(dabgpu_ctx *ctx, const void *d_iq, size_t frame_stride, int n_frames,

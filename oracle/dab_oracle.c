@@ -393,7 +393,7 @@ void oracle_ofdm_demod_frame_dd(const float *iq, float freq_offset, int8_t *soft
             y[2 * i + 1] = xr * wi + xi * wr;
         }
         /* cyclic-prefix correlation (fine frequency error estimator) */
-        if (cyc) {
+        if (cyc || (dd4 && l == 0)) {
             double cr = 0.0, ci = 0.0;
             for (int i = 0; i < DAB_NB_CP; i++) {
                 const float ar = y[2 * i], ai = y[2 * i + 1];
@@ -401,8 +401,14 @@ void oracle_ofdm_demod_frame_dd(const float *iq, float freq_offset, int8_t *soft
                 cr += (double)(ar * br + ai * bi);   /* conj(a)*b */
                 ci += (double)(ar * bi - ai * br);
             }
-            cyc[2 * l] = (float)cr;
-            cyc[2 * l + 1] = (float)ci;
+            if (cyc) {
+                cyc[2 * l] = (float)cr;
+                cyc[2 * l + 1] = (float)ci;
+            }
+            if (dd4 && l == 0) {               /* entry 0: the PRS's cyclic-prefix correlation (resolves the sums' ambiguity) */
+                dd4[0] = (float)cr;
+                dd4[1] = (float)ci;
+            }
         }
         /* A3: FFT of the useful part */
         float *Xc = X[l & 1], *Xp = X[(l & 1) ^ 1];

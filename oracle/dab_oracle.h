@@ -119,7 +119,8 @@ void oracle_ofdm_demod_frame(const float *iq, float freq_offset, int8_t *soft,
    replaced by bin 768) of u^4, u = (X_l conj X_{l-1}) / |X_l conj X_{l-1}| (taken from A6's scaling:
    no input level overflows the sum) -- the decision-directed frequency-error estimator: whatever
    two bits a differential symbol carries, its fourth power is -|d|^4 exp(j 4 theta), theta = 2 pi (residual offset)
-   2552.  Entry 0 is not written.  No cyclic-prefix sample is needed for it. */
+   2552, unambiguous within +-1/(8 2552).  Entry 0 = the cyclic-prefix correlation of the PRS (symbol 0), the only prefix read:
+   its angle / (2 pi 2048) is the same residual within +-1/4096 and picks the branch of the fourth-power estimate. */
 void oracle_ofdm_demod_frame_dd(const float *iq, float freq_offset, int8_t *soft,
                                 float *spectra, float *cyc, float *dqpsk, float *dd4);
 

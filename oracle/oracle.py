@@ -197,7 +197,8 @@ def ofdm_demod_frame(iq, freq_offset=0.0, want_spectra=False, want_cyc=False, wa
 
 
 def ofdm_demod_frame_dd(iq, freq_offset=0.0):
-    """-> (soft, dd4): dd4 complex64[76], the decision-directed frequency-error sums (entry 0 unused)."""
+    """-> (soft, dd4): dd4 complex64[76], the decision-directed frequency-error sums (entry 0: the PRS's cyclic-prefix
+    correlation)."""
     a = np.ascontiguousarray(iq, np.complex64)
     assert a.size == NB_SYMBOLS * NB_SYM
     soft = np.zeros(NB_FRAME_BITS, np.int8)
@@ -207,9 +208,15 @@ def ofdm_demod_frame_dd(iq, freq_offset=0.0):
 
 
 def dd_error(dd4):
-    """Residual frequency offset (cycles/sample) from dd4 sums of any shape [..., 76]: angle(-sum over l >= 1) / (4 2 pi 2552)."""
-    s = np.asarray(dd4, np.complex128)[..., 1:].sum()
-    return np.float32(np.arctan2(-s.imag, -s.real) / (4.0 * 2.0 * np.pi * 2552.0))
+    """Residual frequency offset (cycles/sample) from dd4 rows of any shape [..., 76]: the fourth-power estimate
+    angle(-sum over l >= 1) / (4 2 pi 2552), whose branch (it repeats every 1 / (4 2552)) is picked by the mean angle of the
+    PRS cyclic-prefix correlations in entry 0, / (2 pi 2048)."""
+    a = np.asarray(dd4, np.complex128)
+    s = a[..., 1:].sum()
+    e_dd = np.float32(np.arctan2(-s.imag, -s.real) / (4.0 * 2.0 * np.pi * 2552.0))
+    e_cp = np.float32(np.float32(np.angle(a[..., 0]).mean()) * np.float32(1.0 / (6.283185307179586 * 2048.0)))
+    k = np.rint(np.float32(e_cp - e_dd) * np.float32(4.0 * 2552.0))
+    return np.float32(e_dd + np.float32(k) * np.float32(1.0 / (4.0 * 2552.0)))
 
 
 def stream_update(state, cyc, iq_last_frame, beta, thr_null_start=0.35, signal_beta=0.95, dd=False):

@@ -644,8 +644,9 @@ int dabgpu_alloc_frame_buffers_placed(dabgpu_ctx *ctx, int n_frames, size_t fram
     while (n_big > n_iq && size_t(n_big) * CH + size_t(n_small) * CS > free_b - free_b / 16) n_big--;
     while (n_small > n_soft && size_t(n_big) * CH + size_t(n_small) * CS > free_b - free_b / 16) n_small--;
     if (size_t(n_big) * CH + size_t(n_small) * CS > free_b - free_b / 16) return plain();
-    const int n_total = n_big + n_small;
+    int n_total = n_big + n_small;
     if (n_total > 70) return plain();
+    const int n_budget = n_total;                            // chunks of the 1.2 x budget; spacers (below) come after them
     hipStream_t s = ctx->stream;
     HIP_TRY(hipStreamSynchronize(s));
 
@@ -656,8 +657,10 @@ int dabgpu_alloc_frame_buffers_placed(dabgpu_ctx *ctx, int n_frames, size_t fram
     hipMemAccessDesc acc = {};
     acc.location = prop.location;
     acc.flags = hipMemAccessFlagsProtReadWrite;
+    // (address space for the spacers of the one-domain case below is reserved with the rest: it costs nothing)
+    constexpr int MAX_SPACERS = 100;
     Chunks c;
-    c.reserved = size_t(n_big) * CH + size_t(n_small) * CS;
+    c.reserved = size_t(n_big) * CH + size_t(n_small) * CS + size_t(MAX_SPACERS) * CH;
     void *va = nullptr;
     if (hipMemAddressReserve(&va, c.reserved, 0, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); return plain(); }
     c.va = static_cast<char *>(va);
@@ -691,8 +694,62 @@ int dabgpu_alloc_frame_buffers_placed(dabgpu_ctx *ctx, int n_frames, size_t fram
         (void)hipEventSynchronize(ec1);
         (void)hipEventElapsedTime(&rep.classify_ms, ec0, ec1);
     }
+    // ---- the budget may not hold what a clean placement needs: one domain with room for all the samples AND enough
+    //      memory elsewhere for the soft bits (a fresh device hands out its memory in address order, and a domain's
+    //      address ranges are tens of GB long: the whole budget can lie in one of them).  Then 1 GiB spacers are taken and
+    //      classified one by one until it does; they take part in the selection below like any other chunk, and the ones
+    //      nobody takes go back at the end of this call (what is held at the peak is reported). ----
+    int iq_domain = -1;                                        // the domain that can carry the samples alone, if any
+    if (!rc) {
+        size_t bytes_in[3] = {0, 0, 0};
+        for (int i = 0; i < n_total; i++) bytes_in[dom[size_t(i)]] += c.items[size_t(i)].bytes;
+        auto clean = [&]() {
+            int best = -1;
+            const size_t all = bytes_in[0] + bytes_in[1] + bytes_in[2];
+            for (int d = 0; d < 3; d++)
+                if (bytes_in[d] >= iq_bytes && all - bytes_in[d] >= soft_bytes && (best < 0 || bytes_in[d] > bytes_in[best])) best = d;
+            return best;
+        };
+        iq_domain = clean();
+        int ref[3] = {-1, -1, -1};
+        float self[3] = {0.f, 0.f, 0.f};
+        for (int i = n_total - 1; i >= 0; i--) ref[dom[size_t(i)]] = i;          // a reference chunk per domain seen: its first one
+        for (int k = 0; k < MAX_SPACERS && iq_domain < 0; k++) {
+            size_t fb = 0, tb = 0;
+            if (hipMemGetInfo(&fb, &tb) != hipSuccess || fb < 2 * CH + tb / 16) break;          // leave the device some air
+            hipMemGenericAllocationHandle_t h;
+            if (hipMemCreate(&h, CH, &prop, 0) != hipSuccess) break;
+            if (hipMemMap(c.va + c.mapped, CH, 0, h, 0) != hipSuccess) { (void)hipMemRelease(h); break; }
+            c.items.push_back(Chunks::Item{h, CH, c.mapped});
+            c.mapped += CH;
+            const int x = n_total++;
+            dom.push_back(0);
+            if (hipMemSetAccess(c.at(x), CH, &acc, 1) != hipSuccess) { rc = DABGPU_ERR_HIP; break; }
+            // same domain as a known one?  (reading the reference and writing the spacer is ~10 % slower then)
+            int d = -1;
+            for (int q = 0; q < 3 && d < 0; q++) {
+                if (ref[q] < 0) continue;
+                if (self[q] == 0.f) self[q] = pair_ms(c, ref[q], ref[q], s, e0, e1);
+                const float t = pair_ms(c, ref[q], x, s, e0, e1);
+                if (t < 0.f || self[q] < 0.f) { rc = DABGPU_ERR_HIP; break; }
+                if (t >= 0.97f * self[q]) d = q;
+            }
+            if (rc) break;
+            if (d < 0) {                                           // a domain not seen before
+                d = ref[0] < 0 ? 0 : ref[1] < 0 ? 1 : ref[2] < 0 ? 2 : 0;   // (a fourth cannot happen; stay consistent)
+                if (ref[d] < 0) { ref[d] = x; n_dom++; }
+            }
+            dom[size_t(x)] = d;
+            bytes_in[d] += CH;
+            iq_domain = clean();
+        }
+        (void)hipGetLastError();
+        rep.setup_peak_bytes = c.mapped;
+        rep.n_chunks = n_total;
+    }
     rep.n_domains = n_dom;
-    for (int i = 0; i < n_total && i < 71; i++) rep.domains[i] = char((i < n_big ? 'A' : 'a') + dom[size_t(i)]);   // small chunks in lower case
+    // (small chunks in lower case; spacers, 1 GiB each, follow the budget's chunks)
+    for (int i = 0; i < n_total && i < 71; i++) rep.domains[i] = char((i < n_big || i >= n_budget ? 'A' : 'a') + dom[size_t(i)]);
 
     // ---- IQ: the domain with the most bytes first (1 GiB chunks, then 256 MiB ones); the soft bits, piece by piece:
     //      a chunk whose domain the samples read beside that piece are not in ----
@@ -703,16 +760,20 @@ int dabgpu_alloc_frame_buffers_placed(dabgpu_ctx *ctx, int n_frames, size_t fram
         size_t bytes_in[3] = {0, 0, 0};
         for (int i = 0; i < n_total; i++) bytes_in[dom[size_t(i)]] += c.items[size_t(i)].bytes;
         int order[3] = {0, 1, 2};
-        std::sort(order, order + 3, [&](int x, int y) { return bytes_in[x] != bytes_in[y] ? bytes_in[x] > bytes_in[y] : x < y; });
+        std::sort(order, order + 3, [&](int x, int y) {
+            if ((x == iq_domain) != (y == iq_domain)) return x == iq_domain;
+            return bytes_in[x] != bytes_in[y] ? bytes_in[x] > bytes_in[y] : x < y;
+        });
+        auto is_big = [&](int i) { return i < n_big || i >= n_budget; };
         // leave the other domains what the soft bits need of them whenever the first domain can carry the samples alone
         for (int k = 0; k < 3 && iq_mapped < iq_bytes; k++)
             for (int pass = 0; pass < 2 && iq_mapped < iq_bytes; pass++)          // pass 0: 1 GiB chunks, pass 1: 256 MiB ones
-                for (int i = (pass ? n_big : 0); i < (pass ? n_total : n_big) && iq_mapped < iq_bytes; i++) {
-                    if (used[size_t(i)] || dom[size_t(i)] != order[k]) continue;
+                for (int i = 0; i < n_total && iq_mapped < iq_bytes; i++) {
+                    if (is_big(i) != (pass == 0) || used[size_t(i)] || dom[size_t(i)] != order[k]) continue;
                     if (pass == 0 && iq_bytes - iq_mapped < CH && bytes_in[order[k]] > 0) {
                         // less than a whole big chunk is missing: small chunks of this domain first, if there are enough
                         size_t small_left = 0;
-                        for (int j = n_big; j < n_total; j++) if (!used[size_t(j)] && dom[size_t(j)] == order[k]) small_left += CS;
+                        for (int j = n_big; j < n_budget; j++) if (!used[size_t(j)] && dom[size_t(j)] == order[k]) small_left += CS;
                         if (small_left >= iq_bytes - iq_mapped) break;
                     }
                     iq_sel.push_back(i);
@@ -758,7 +819,8 @@ int dabgpu_alloc_frame_buffers_placed(dabgpu_ctx *ctx, int n_frames, size_t fram
         rep.iq_chunks = int(iq_sel.size());
         rep.soft_chunks = int(soft_sel.size());
         for (size_t k = 0; k < iq_sel.size() && k < 71; k++) rep.iq_map[k] = char((iq_sel[k] < n_big ? 'A' : 'a') + dom[size_t(iq_sel[k])]);
-        for (size_t k = 0; k < soft_sel.size() && k < 23; k++) rep.soft_map[k] = char((soft_sel[k] < n_big ? 'A' : 'a') + dom[size_t(soft_sel[k])]);
+        for (size_t k = 0; k < soft_sel.size() && k < 23; k++)
+            rep.soft_map[k] = char((soft_sel[k] < n_big || soft_sel[k] >= n_budget ? 'A' : 'a') + dom[size_t(soft_sel[k])]);
     }
     // ---- final mappings; the chunks nobody took go back ----
     dabgpu_ctx::Mapped m_iq{nullptr, iq_mapped, 0, {}}, m_soft{nullptr, soft_mapped, 0, {}};

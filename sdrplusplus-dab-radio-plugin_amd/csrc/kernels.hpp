@@ -191,6 +191,13 @@ hipError_t launch_track_sync(const SyncTables &t, const TrackArgs &a, hipStream_
 //               (signal_beta * average + (1 - signal_beta) * level); a level below thr_null_start * average counts one
 //               more desync and leaves the average alone
 //   counts[s]   = count
+// The fourth-power estimate e_dd of a residual frequency offset repeats every 1 / (4 * 2552) cycles per sample; the mean
+// angle of the PRS cyclic-prefix correlations, e_cp (+-1/4096, coarser), picks its branch.  Restated by oracle.dd_error.
+__host__ __device__ inline float dd_unwrap(float e_dd, float e_cp) {
+    const float k = rintf((e_cp - e_dd) * (4.0f * 2552.0f));
+    return e_dd + k * (1.0f / (4.0f * 2552.0f));
+}
+
 struct TrackUpdateArgs {
     StreamState *state;
     const AcquiredFrame *frames;

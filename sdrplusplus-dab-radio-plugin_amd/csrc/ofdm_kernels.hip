@@ -252,7 +252,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
             if (ls > l_first) { const unsigned long long *kw = a.keep + 3 * (ls - 1); need |= (kw[0] | kw[1] | kw[2]) != 0ull; }
             if (ls < l_last) { const unsigned long long *kw = a.keep + 3 * ls; need |= (kw[0] | kw[1] | kw[2]) != 0ull; }
             if (!need) {
-                if (a.cyc && emit) {
+                if ((a.cyc && emit) || (dd && l == 0)) {
                     float2 acc = make_float2(0.f, 0.f);
                     const float2 *cp = sym + 2 * (lane - 4);
                     const float2 *tail = sym + NB_CP + 128 * 12 + 2 * lane;
@@ -267,7 +267,8 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
                     }
                     acc.x = wave_sum(acc.x, lane);
                     acc.y = wave_sum(acc.y, lane);
-                    put_cyc(l, cmul(acc, rot2048));
+                    if (dd) { if (lane == 0) st_stream(a.dd4 + size_t(frame) * NB_FRAME_SYMBOLS, cmul(acc, rot2048)); }
+                    else put_cyc(l, cmul(acc, rot2048));
                 }
                 continue;
             }
@@ -298,7 +299,8 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
         }
         __builtin_amdgcn_sched_barrier(0);
         // ---- cyclic-prefix correlation on raw samples: CP pair c = lane-4+64*i <-> row 12+i of this lane ----
-        if (a.cyc && emit) {
+        // (decision-directed mode: of the PRS only -- its angle picks the branch of the fourth-power estimate, 4.1)
+        if ((a.cyc && emit) || (dd && l == 0)) {
             float2 acc = make_float2(0.f, 0.f);
             const float2 *cp = sym + 2 * (lane - 4);
 #pragma unroll
@@ -318,7 +320,8 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
             }
             acc.x = wave_sum(acc.x, lane);
             acc.y = wave_sum(acc.y, lane);
-            put_cyc(l, cmul(acc, rot2048));
+            if (dd) { if (lane == 0) st_stream(a.dd4 + size_t(frame) * NB_FRAME_SYMBOLS, cmul(acc, rot2048)); }
+            else put_cyc(l, cmul(acc, rot2048));
         }
         __builtin_amdgcn_sched_barrier(0);
         // ---- A2: NCO.  Even and odd sample of a load get the same phasor here; the odd one's missing sample
@@ -523,8 +526,10 @@ __global__ __launch_bounds__(SU_THREADS) void stream_update_kernel(StreamState *
     float acc = 0.f;
     double sx = 0.0, sy = 0.0;
     if (dd) {
-        for (int i = tid; i < n; i += SU_THREADS)
-            if (i % NB_FRAME_SYMBOLS) { sx += double(c[i].x); sy += double(c[i].y); }      // entry 0 of a frame is never written
+        for (int i = tid; i < n; i += SU_THREADS) {
+            if (i % NB_FRAME_SYMBOLS) { sx += double(c[i].x); sy += double(c[i].y); }
+            else acc += atan2f(c[i].y, c[i].x);                   // entry 0 of a frame: the PRS's cyclic-prefix correlation
+        }
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) { sx += __shfl_xor(sx, off); sy += __shfl_xor(sy, off); }
         if (lane == 0) { red_dd[0][wave] = sx; red_dd[1][wave] = sy; }
@@ -551,8 +556,9 @@ __global__ __launch_bounds__(SU_THREADS) void stream_update_kernel(StreamState *
         if (dd) {
             sx = 0.0; sy = 0.0;
             for (int w = 0; w < SU_THREADS / 64; w++) { sx += red_dd[0][w]; sy += red_dd[1][w]; }
-            // sum = -A exp(j 4 theta), theta = 2 pi r 2552
-            err = float(atan2(-sy, -sx) / (4.0 * 6.283185307179586 * double(NB_SYM_PERIOD)));
+            // sum = -A exp(j 4 theta), theta = 2 pi r 2552: r modulo 1 / (4 2552); the branch from the PRS prefixes
+            err = dd_unwrap(float(atan2(-sy, -sx) / (4.0 * 6.283185307179586 * double(NB_SYM_PERIOD))),
+                            acc / float(frames_per_stream) * (1.0f / (6.283185307179586f * float(NB_FFT))));
         }
         constexpr float HALF = 0.5f / float(NB_FFT);
         float f = st.fine_freq_offset - beta * err;

@@ -398,7 +398,7 @@ __global__ __launch_bounds__(TU) void track_update_kernel(TrackUpdateArgs a) {
         if ((fr[i].flags & 3) != 3) continue;
         const float2 c = cyc[k];
         if (a.dd) {
-            if (k - i * NB_FRAME_SYMBOLS) { sang += double(c.x); sang2 += double(c.y); }     // entry 0 is never written
+            if (k - i * NB_FRAME_SYMBOLS) { sang += double(c.x); sang2 += double(c.y); }     // (entry 0: second pass below)
         } else {
             sang += double(atan2f(c.y, c.x));
         }
@@ -424,20 +424,29 @@ __global__ __launch_bounds__(TU) void track_update_kernel(TrackUpdateArgs a) {
         const float2 *x = a.iq + size_t(s) * a.stream_stride + fr[last].start;
         for (int i = tid; i < 4096; i += TU) l1 += fabsf(x[i].x) + fabsf(x[i].y);
     }
+    // ... and, for the decision-directed loop, the angles of the locked frames' PRS cyclic-prefix correlations (entry 0)
+    double ang0 = 0.0;
+    if (a.dd)
+        for (int i = tid; i < count; i += TU)
+            if ((fr[i].flags & 3) == 3) ang0 += double(atan2f(cyc[size_t(i) * NB_FRAME_SYMBOLS].y, cyc[size_t(i) * NB_FRAME_SYMBOLS].x));
     red[0][tid] = double(l1);
+    red[1][tid] = ang0;
     __syncthreads();
     for (int off = TU / 2; off > 0; off >>= 1) {
-        if (tid < off) red[0][tid] += red[0][tid + off];
+        if (tid < off) { red[0][tid] += red[0][tid + off]; red[1][tid] += red[1][tid + off]; }
         __syncthreads();
     }
     if (tid != 0) return;
     l1 = float(red[0][0] * (1.0 / 4096.0));
+    ang0 = red[1][0];
     const int n_locked = int(sn);
     int desync = (a.fixed_start ? 0 : pr.j0) + (count - n_locked);
     if (n_locked > 0) {
         // fine-frequency loop
         float err = float(sang / (sn * double(NB_FRAME_SYMBOLS))) * (1.0f / (6.283185307179586f * float(NB_FFT)));
-        if (a.dd) err = float(atan2(-sang2, -sang) / (4.0 * 6.283185307179586 * double(NB_SYM_PERIOD)));
+        if (a.dd)
+            err = dd_unwrap(float(atan2(-sang2, -sang) / (4.0 * 6.283185307179586 * double(NB_SYM_PERIOD))),
+                            float(ang0 / sn) * (1.0f / (6.283185307179586f * float(NB_FFT))));
         constexpr float HALF = 0.5f / float(NB_FFT);
         float f = st.fine_freq_offset - a.fine_beta * err;
         if (f > HALF) f -= 2.f * HALF;

@@ -95,13 +95,15 @@ def test_time_interleaver_is_inverse_of_deinterleaver():
 
 
 def test_decision_directed_frequency_error_tracks_the_cyclic_prefix_estimate(built):
-    """oracle.dd_error (fourth power of the differential symbols over the 256 centre carriers of a symbol) against the
-    cyclic-prefix estimate and the injected residual, through noise and echoes; its range is +-0.1 carrier."""
+    """oracle.dd_error (fourth power of the differential symbols over the 256 centre carriers of a symbol, branch picked
+    by the PRS's cyclic-prefix correlation) against the all-symbol cyclic-prefix estimate and the injected residual,
+    through noise and echoes, over the whole +-0.5 carrier range."""
     import numpy as np
     from dabgpu import synth
     from oracle import oracle as O
     e = synth.Ensemble(seed=21, n_frames=4)
-    for resid, snr, paths in ((0.05, 12.0, None), (-0.08, 8.0, None), (0.03, 15.0, [(0, 1.0), (120, 0.8j)]), (0.0, 10.0, None)):
+    for resid, snr, paths in ((0.05, 12.0, None), (-0.08, 8.0, None), (0.03, 15.0, [(0, 1.0), (120, 0.8j)]), (0.0, 10.0, None),
+                              (0.31, 12.0, None), (-0.22, 10.0, [(0, 1.0), (60, 0.5)]), (0.45, 15.0, None), (-0.1, 9.0, None)):
         rng = np.random.default_rng(int(1000 * abs(resid)) + 7)
         rx = synth.channel(e.iq().ravel(), snr_db=snr, cfo=resid / 2048, rng=rng, paths=paths).reshape(4, -1)
         fr = np.ascontiguousarray(rx[0, synth.NB_NULL - 8:synth.NB_NULL - 8 + 76 * 2552])
@@ -109,7 +111,9 @@ def test_decision_directed_frequency_error_tracks_the_cyclic_prefix_estimate(bui
         _, _, cyc, _ = O.ofdm_demod_frame(fr, 0.0, want_cyc=True)
         e_dd = float(O.dd_error(dd)) * 2048
         e_cp = float(np.angle(cyc.astype(np.complex128)).mean() / (2 * np.pi * 2048)) * 2048
-        assert abs(e_dd - resid) < 0.004 and abs(e_cp - resid) < 0.006, (resid, e_dd, e_cp)
+        # (approaching half a carrier the carriers leak into each other: the decisions, and with them the fourth-power
+        # estimate, degrade -- a loop still lands inside the accurate region with its first step)
+        assert abs(e_dd - resid) < (0.004 if abs(resid) <= 0.35 else 0.05) and abs(e_cp - resid) < 0.006, (resid, e_dd, e_cp)
     # a sample clock 150 ppm off rotates carrier k by 2 pi k 1.5e-4 2552/2048 per symbol: the outer carriers' fourth
     # powers would point the other way, the 256 centre carriers the estimator uses do not care
     for ppm in (150.0, -150.0):
