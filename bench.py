@@ -12,9 +12,9 @@ device buffers, stream, events, and torch.distributed (RCCL) for the barrier / m
 Nothing on the GPU side is told the frequency offsets the synthetic channel applied: the front end runs closed
 loop.  Per ensemble the carrier offset is a whole number of carriers (|k| <= 3) plus a fraction (|f| <= 0.4); before
 the timed region the coarse part is found on the first frame's phase reference symbol (dabgpu_sync_prs_dev) and the
-fine loop settles over three untimed calls; during the timed steps every call corrects with the stream's state in
-HBM and updates it from the cyclic-prefix correlations (a small kernel after the demodulation launch, inside the
-timed region).  `closed_loop` repeats the step on the same samples presented as unaligned captures: null-symbol
+fine loop settles over four untimed calls; during the timed steps every call corrects with the stream's state in
+HBM and updates it from the decision-directed sums the demodulation launch leaves (a small kernel after it, inside the
+timed region; `with_cyclic_prefix_correlations` is the same step on the reference's estimator).  `closed_loop` repeats the step on the same samples presented as unaligned captures: null-symbol
 search, per-frame frequency and timing from the PRS, demodulation where the frames lie.
 
 Ensembles shard across GPUs with no data-path collective (weak scaling: 64 per rank; global ensemble ids
@@ -33,11 +33,11 @@ sys.path.insert(0, os.path.join(ROOT, "sdrplusplus-dab-radio-plugin_amd"))
 sys.path.insert(0, ROOT)
 
 # algorithmic HBM bytes per frame (DESIGN.md "Measurement").  Round 3: the closed-loop front end no longer reads the
-# cyclic prefixes at all (decision-directed fine-frequency loop): the useful 2048 samples of the 76 symbols in, 230400
-# int8 soft bits out.  A_OFDM_CP is what the kernel moves when the caller asks for the cyclic-prefix correlations
+# cyclic prefixes of the data symbols (decision-directed fine-frequency loop): the useful 2048 samples of the 76 symbols
+# and the prefix of the PRS in, 230400 int8 soft bits out.  A_OFDM_CP is what the kernel moves when the caller asks for the cyclic-prefix correlations
 # (rounds 1-2, and the `with_cyclic_prefix_correlations` leg below); SURVEY 8(d)'s A_ofdm = 1 803 264 B also counts the
 # null symbol, which no kernel here ever read.
-A_OFDM = 76 * 2048 * 8 + 230400            # 1 475 584 B
+A_OFDM = (76 * 2048 + 504) * 8 + 230400    # 1 479 616 B (the PRS keeps its prefix: it resolves the estimator's ambiguity)
 A_OFDM_CP = 76 * 2552 * 8 + 230400         # 1 782 016 B
 A_OFDM_SURVEY = 196608 * 8 + 230400        # 1 803 264 B
 A_FFT = 76 * 2552 * 8 + 76 * 2048 * 8      # 2 796 800 B (unfused FFT stage)
@@ -391,12 +391,12 @@ def main():
             ev[2].record()
             ofdm_ev.append((ev[0], ev[1])); dec_ev.append((ev[1], ev[2]))
 
-    # settle the fine-frequency loop (part of acquisition, untimed): first on the cyclic-prefix correlations, whose range
-    # is +-half a carrier, then decision-directed (range +-0.1 carrier), as the timed steps run
-    for k in range(3):
-        ctx.ofdm_demod_streams_dev(d_iq, synth.NB_FRAME_SAMPLES, E, F, BETA, soft.data_ptr(), cyc.data_ptr(), None, stream)
-    ctx.set_stream_loop(decision_directed=True)      # from here on calls without a correlation buffer skip the prefixes
-    ctx.ofdm_demod_streams_dev(d_iq, synth.NB_FRAME_SAMPLES, E, F, BETA, soft.data_ptr(), None, None, stream)
+    # settle the fine-frequency loop (part of acquisition, untimed), decision-directed from the first call as the timed
+    # steps run: the fourth-power estimate is exact to 1e-4 carriers but repeats every 0.2, the cyclic prefix of each
+    # frame's PRS (the one prefix that is read) picks its branch, so the loop pulls in from +-half a carrier
+    ctx.set_stream_loop(decision_directed=True)      # calls without a correlation buffer skip the other 75 prefixes
+    for k in range(4):
+        ctx.ofdm_demod_streams_dev(d_iq, synth.NB_FRAME_SAMPLES, E, F, BETA, soft.data_ptr(), None, None, stream)
     torch.cuda.synchronize()
     net = np.array([ctx.get_stats(s).net_freq_offset for s in range(E)])
     loop_residual = float(np.abs(net + cfo_true).max() * 2048.0)            # carriers; reported, not used
@@ -478,9 +478,9 @@ def main():
                        "ensembles_per_gpu": E, "frames_per_step_per_gpu": n_frames, "snr_db": args.snr,
                        "carrier_offset": "unknown to the receiver: k + f carriers per ensemble, |k| <= 3, |f| <= 0.4",
                        "frequency_correction": "closed loop on the device (dabgpu_ofdm_demod_streams_dev): coarse from the first PRS, "
-                                               "fine: settled on the cyclic-prefix correlations (untimed), then decision-directed "
-                                               "(fourth power of the differential symbols of the previous call; the cyclic prefixes "
-                                               "are never read in the timed steps)",
+                                               "fine: decision-directed from the first (untimed) call on -- fourth power of the "
+                                               "differential symbols of the previous call, its 0.2-carrier ambiguity resolved by the "
+                                               "cyclic prefix of each frame's PRS, the only prefix that is read",
                        "sharding": "independent ensembles per rank (global id % world == rank), no data-path collective",
                        "buffer_placement": placement if placement is not None else "first allocation taken"},
             "x_realtime": value / REALTIME_FPS,
@@ -491,8 +491,8 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_source, "avg_launch_ms": ofdm_ms, "launches_timed": ofdm_launches,
                          "front_end_call_ms": ofdm_call_ms, "frames_per_launch": n_frames,
                          "algorithmic_bytes_per_frame": A_OFDM,
-                         "algorithmic_bytes_note": "76 x 2048 cf32 in + 230400 int8 out: the cyclic prefixes (19.7 % of the samples) "
-                                                   "are not read any more; priced on SURVEY 8(d)'s A_ofdm (1 803 264 B, prefixes "
+                         "algorithmic_bytes_note": "76 x 2048 cf32 + the PRS's 504-sample prefix in, 230400 int8 out: the other 75 cyclic "
+                                                   "prefixes (19.5 % of the samples) are not read any more; priced on SURVEY 8(d)'s A_ofdm (1 803 264 B, prefixes "
                                                    "and null symbol included) the same launch would read achieved_on_survey_bytes",
                          "achieved_on_survey_bytes": A_OFDM_SURVEY * n_frames / (ofdm_ms * 1e-3) / 1e9,
                          "copy_ceiling": copy_ceiling(torch, dev)},

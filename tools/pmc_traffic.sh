@@ -25,7 +25,7 @@ rd_scale = GiB / (res["FETCH_SIZE"]["copy"] * 1024)
 wr_scale = GiB / (res["WRITE_SIZE"]["copy"] * 1024)
 rd = res["FETCH_SIZE"]["ofdm"] * 1024 * rd_scale
 wr = res["WRITE_SIZE"]["ofdm"] * 1024 * wr_scale
-alg = (76 * 2048 * 8 + 230400) if mode == "dd" else 1782016
+alg = ((76 * 2048 + 504) * 8 + 230400) if mode == "dd" else 1782016
 out = {"frames_per_launch": n, "mode": "decision-directed, no cyclic prefix read" if mode == "dd" else "with cyclic-prefix correlations", "raw_kib": res, "read_scale_from_1GiB_copy": rd_scale, "write_scale_from_1GiB_copy": wr_scale,
        "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
        "algorithmic_bytes_per_launch": alg * n, "ratio_to_algorithmic": (rd + wr) / (alg * n)}
