@@ -487,6 +487,70 @@ def test_gpu_auto_acquire_equals_the_explicit_sequence_and_heals_a_lost_stream(t
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dd", [1, 0])
+def test_gpu_tracking_through_a_deep_fade(tctx, dd):
+    """Stream 0 fades by 26 dB (to -8 dB SNR) for the length of three frames in the middle of its run while stream 1 does
+    not: whatever the loops do during the fade (frames lost, tracking dropped and re-acquired by cfg.auto_acquire), two
+    calls after the signal is back every frame of both streams decodes to the transmitted FIBs and the fine-frequency
+    state sits on the true offset -- not 0.2 carriers beside it, where a fourth-power loop without the PRS prefix could
+    settle.  Both estimators (cfg.decision_directed 1 / 0)."""
+    import torch
+    import dabgpu
+    dev = torch.device("cuda", 0)
+    specs = [(30.0, 1.3, 60000), (-45.0, -0.7, 99000)]            # ppm, carrier offset, cut
+    NF, S = 22, 2
+    xs, ens = [], []
+    for i, (ppm, cfo, cut) in enumerate(specs):
+        e = synth.Ensemble(seed=300 + i, n_frames=4)
+        tx = np.tile(e.iq().ravel(), (NF + 3) // 4)[:NF * L]
+        clean = synth.channel(tx, snr_db=None, cfo=cfo / 2048.0, rng=np.random.default_rng(40 + i), sco_ppm=ppm)[cut:]
+        g = np.ones(clean.size, np.float32)
+        if i == 0:
+            g[8 * L:11 * L] = 0.05
+        rng = np.random.default_rng(50 + i)
+        sigma = np.sqrt(0.5 * 10 ** (-18.0 / 10)) * np.sqrt(np.mean(np.abs(clean[:L]) ** 2))
+        noise = (rng.standard_normal(clean.size) + 1j * rng.standard_normal(clean.size)).astype(np.complex64) * np.float32(sigma)
+        xs.append((clean * g + noise).astype(np.complex64)); ens.append(e)
+    n_total = min(x.size for x in xs)
+    d_x = torch.from_numpy(np.stack([x[:n_total] for x in xs])).to(dev)
+    n_cap, adv, MF = 3 * L + 8192, 2 * L, 4
+    cfg = dabgpu.track_cfg(auto_acquire=1, decision_directed=dd)
+    tctx.streams_reset(S)
+    frames = torch.zeros((S, MF, 32), dtype=torch.uint8, device=dev)
+    counts = torch.zeros(S, dtype=torch.int32, device=dev)
+    soft = torch.zeros((S * MF, dabgpu.NB_FRAME_BITS), dtype=torch.int8, device=dev)
+    torch.cuda.synchronize()
+    base, call, good_after = 0, 0, [0, 0]
+    while base + n_cap <= n_total:
+        tctx.ofdm_demod_tracked_dev(d_x.data_ptr() + base * 8, n_total, S, n_cap, MF, adv, soft.data_ptr(), frames.data_ptr(),
+                                    counts.data_ptr(), cfg=cfg)
+        tctx.sync()
+        fr = frames.cpu().numpy().view(dabgpu.ACQUIRED_FRAME_DTYPE).reshape(S, MF)
+        cnt = counts.cpu().numpy()
+        fib, ok = tctx.fic_decode(soft.cpu().numpy())
+        st = read_states(torch, tctx, S)
+        for s in range(S):
+            ppm, cfo, cut = specs[s]
+            faded = s == 0 and base + n_cap > 8 * L and base < 11 * L + 2 * adv      # the fade, and two calls of grace
+            n_ok = 0
+            for j in range(cnt[s]):
+                if fr[s, j]["flags"] != 3:
+                    continue
+                k = int(round(((base + int(fr[s, j]["start"]) + 64 + HALF + cut) / (1 + ppm * 1e-6) - NULL) / L))
+                good = bool(ok[s * MF + j].all()) and bool((fib[s * MF + j] == ens[s].fibs[k % 4]).all())
+                n_ok += good
+                assert good or faded, (dd, call, s, j)
+            if not faded and call > 0:
+                assert n_ok == 2 and st[s]["tracking"] == 1, (dd, call, s, n_ok)
+                net = (float(st[s]["fine_freq_offset"]) + float(st[s]["coarse_freq_offset"])) * 2048
+                assert abs(net + cfo) < 0.01, (dd, call, s, net, cfo)
+                good_after[s] += base > 11 * L
+        base += adv
+        call += 1
+    assert good_after[0] >= 2 and good_after[1] >= 2                 # the run went on long enough after the fade to say so
+
+
+@pytest.mark.gpu
 def test_gpu_tracking_drops_out_on_noise_and_counts_missed_frames(tctx):
     """A tracked stream whose capture turns into noise loses every frame of the call: tracking stops (state 0), the
     frames count as desync, soft bits are erased.  A capture that begins late (frames before it) counts them missed."""
