@@ -66,6 +66,21 @@ def test_selected_output_equals_whole_frame_run(built, ensemble, ensemble_iq, pa
     for f in range(2):
         ref = O.ofdm_demod_frame_dd(frames[f], float(fo[f]))[1][wanted].astype(np.complex128).sum()
         assert abs(dd[f, 1:].astype(np.complex128).sum() - ref) <= 1e-4 * abs(ref), (f, parts)
+        assert abs(dd[f, 0] - O.ofdm_demod_frame_dd(frames[f], float(fo[f]))[1][0]) <= 1e-3 * abs(dd[f, 0])
+    # ... and with a selection that leaves the PRS untransformed (no FIC, nothing in symbol 1) its prefix correlation
+    # still arrives in entry 0 (it then comes from the prefix and the symbol's last 512 samples alone)
+    c.set_soft_selection([(100000 - 100000 % 16, 48)])
+    d_dd.zero_()
+    torch.cuda.synchronize()
+    c.ofdm_demod_frames_dd_dev(d_iq.data_ptr(), frames.shape[1], n, d_fo.data_ptr(), d_soft2.data_ptr(), d_dd.data_ptr())
+    c.sync()
+    dd = d_dd.cpu().numpy()
+    for f in range(2):
+        odd = O.ofdm_demod_frame_dd(frames[f], float(fo[f]))[1]
+        assert abs(dd[f, 0] - odd[0]) <= 1e-3 * abs(odd[0])
+        ref = odd[100000 // 3072 + 1].astype(np.complex128)
+        assert abs(dd[f, 1:].astype(np.complex128).sum() - ref) <= 1e-4 * abs(ref)
+    c.set_soft_selection(sel)
     # the host-pointer call copies back the selected runs only: the rest of the caller's buffer stays as it was
     host = np.full_like(full, 99)
     c.ofdm_demod_frames(frames, fo, soft=host)
