@@ -382,7 +382,7 @@ def main():
         if timed:
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
             ev[0].record()
-        # (no correlation buffer passed: the fine loop runs decision-directed and the cyclic prefixes are never read)
+        # (no correlation buffer passed: the fine loop runs decision-directed; of a frame's prefixes only the PRS's is read)
         ctx.ofdm_demod_streams_dev(d_iq, synth.NB_FRAME_SAMPLES, E, F, BETA, soft.data_ptr(), None, None, stream)
         if timed:
             ev[1].record()

@@ -253,7 +253,7 @@ int dabgpu_ofdm_demod_frames_dd_dev(dabgpu_ctx *ctx, const void *d_iq, size_t fr
 /* (s, f) starts at iq + (s*frames_per_stream + f)*frame_stride.               */
 /* cyc may be NULL: the library keeps what the loop needs in its own scratch --  */
 /* the correlations, or (dabgpu_set_stream_loop(.., decision_directed = 1)) the  */
-/* dd4 sums, in which case the cyclic prefixes are not read at all.              */
+/* dd4 sums, in which case only the PRS's cyclic prefix is read.                  */
 /* ------------------------------------------------------------------------ */
 typedef struct dabgpu_stream_state {      /* DEVICE memory, 64 bytes */
     float fine_freq_offset;               /* cycles/sample, within +-0.5/2048                     */
@@ -312,10 +312,11 @@ int dabgpu_get_stats(dabgpu_ctx *ctx, int stream_index, dabgpu_stats *out);
  * dabgpu_ofdm_demod_streams_dev runs on when the caller passes no correlation buffer (d_cyc == NULL):
  *   decision_directed == 0 (default)  the cyclic-prefix correlations, kept in the library's scratch: pulls in from
  *                                     +-half a carrier, as the reference's loop does
- *   decision_directed != 0            the dd4 sums of dabgpu_ofdm_demod_frames_dd_dev: the cyclic prefixes are not read
- *                                     (17 % fewer bytes).  Range +-0.1 carrier: switch it on once the loop has settled
- *                                     (a few calls on the correlations) -- beyond it the loop would lock a multiple of
- *                                     0.1 carrier off and the symbols would come out rotated. */
+ *   decision_directed != 0            the dd4 sums of dabgpu_ofdm_demod_frames_dd_dev: of the 76 cyclic prefixes of a frame
+ *                                     only the PRS's is read (17 % fewer bytes); it resolves the sums' 0.2-carrier
+ *                                     ambiguity, so this loop, too, pulls in from +-half a carrier and may run from
+ *                                     the first call on.  (Off by default only so that callers written against ABI v3
+ *                                     see the loop they know.) */
 int dabgpu_set_stream_loop(dabgpu_ctx *ctx, float signal_update_beta, float thr_null_start, int decision_directed);
 
 /* Soft-bit selection (batch receivers that decode the FIC and a few sub-channels and never look at the rest of the
@@ -491,8 +492,7 @@ typedef struct dabgpu_track_cfg {
     int32_t max_coarse_carriers;              /* frame call and auto-acquisition: whole-carrier search */
                                               /* range, 0 = off (204)                                  */
     int32_t decision_directed;                /* tracked call with d_cyc == NULL: fine loop on the dd4 */
-                                              /* sums, no cyclic prefix read (1; acquisition leaves    */
-                                              /* the fine offset well inside their +-0.1 carrier);     */
+                                              /* sums, only the PRS's cyclic prefix read (1);          */
                                               /* 0 = on the cyclic-prefix correlations                 */
     int32_t auto_acquire;                     /* tracked call: != 0 = streams that are not tracking    */
                                               /* (never acquired, or lost) are ACQUIRED inside the     */
