@@ -172,3 +172,40 @@ def test_bench_rccl_branch_executes_with_one_rank():
     assert r["n_gpus"] == 1 and r["fic_bit_exact"] is True and r["msc_bit_exact"] is True
     assert r["config"]["buffer_placement"] == "first allocation taken"
     assert abs(r["value"] * r["ms_per_step"] * 1e-3 - 64) < 1e-3
+
+
+@pytest.mark.gpu
+def test_bench_line_keeps_the_contract():
+    """The one JSON line of a (small) default-shaped run carries every field the driver and the judge read, with the
+    types and relations the contract states: whole-job value, roofline priced on the bytes the timed step moves, the CPU
+    baseline of a bounded sample, both fine-frequency loops compared, nothing decoded wrongly."""
+    env = dict(os.environ)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--ensembles", "4", "--frames", "16", "--steps", "3", "--warmup", "1",
+           "--cpu-seconds", "2", "--sustained-seconds", "0.2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["metric"].startswith("DAB Mode-I frames/sec") and j["unit"] == "frames/s" and j["higher_is_better"] is True
+    assert j["n_gpus"] == 1 and j["steps"] == 3 and j["warmup"] == 1 and j["scaling"] == "weak" and j["vs_baseline"] is None
+    assert j["dtype"] == "f32" and j["data"] == "synthetic" and "workload" in j["config"] and "model" not in j["config"]
+    assert abs(j["value"] * j["ms_per_step"] * 1e-3 - 64) < 1e-6 * 64                       # frames per step / time per step
+    assert j["fic_bit_exact"] is True and j["msc_bit_exact"] is True
+    ro = j["roofline"]
+    assert ro["bound"] == "hbm" and ro["unit"] == "GB/s" and ro["peak"] == 8000.0
+    assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-9 and 0 < ro["frac"] < 1
+    assert ro["algorithmic_bytes_per_frame"] == (76 * 2048 + 504) * 8 + 230400 and ro["frames_per_launch"] == 64
+    assert abs(ro["achieved"] - ro["algorithmic_bytes_per_frame"] * 64 / (ro["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * ro["achieved"]
+    assert ro["traffic"] is None and ro["avg_launch_ms"] < j["ms_per_step"]               # no PMC file for this launch size
+    cb = j["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["unit"] == "frames/s" and cb["value"] > 0 and cb["cores"] >= 1 and "frames" in cb["sample"]
+    assert cb["simd_port"]["kind"] == "simd_port" and cb["simd_port"]["decodes_bench_inputs_to_transmitted_fibs"] is True
+    cp = j["with_cyclic_prefix_correlations"]
+    assert cp["outputs_identical_to_timed_run"] is True and cp["max_abs_soft_bit_difference"] <= 1
+    assert cp["algorithmic_bytes_per_frame"] == 76 * 2552 * 8 + 230400
+    assert j["sustained"]["outputs_identical_to_timed_run"] is True and j["sustained"]["steps"] >= 1
+    assert j["selective_soft_output"]["outputs_identical_to_whole_frame_run"] is True
+    cl = j["closed_loop"]
+    assert cl["fic_bit_exact"] is True and cl["msc_bit_exact"] is True and cl["tracking"]["fic_bit_exact"] is True
+    assert cl["tracking"]["streams_tracking"] == 4 and cl["tracking"]["frames_desync_total"] == 0
