@@ -99,6 +99,22 @@ struct dabgpu_ctx {
         void *va;
         size_t bytes, chunk;             // reserved = mapped bytes; scratch while mapping
         std::vector<hipMemGenericAllocationHandle_t> handles;
+        std::vector<size_t> sizes;       // bytes of each handle's mapping, in address order
+        // every mapping is undone on its own extents (an unmap spanning several mappings is not something the
+        // virtual-memory API promises), then the physical memory and the address range go back
+        void release() {
+            size_t off = 0;
+            for (size_t k = 0; k < handles.size(); k++) {
+                (void)hipMemUnmap(static_cast<char *>(va) + off, sizes[k]);
+                (void)hipMemRelease(handles[k]);
+                off += sizes[k];
+            }
+            if (va) (void)hipMemAddressFree(va, bytes);
+            (void)hipGetLastError();
+            handles.clear();
+            sizes.clear();
+            va = nullptr;
+        }
     };
     std::vector<Mapped> mapped;
 };
@@ -501,9 +517,7 @@ static bool release_mapped(dabgpu_ctx *ctx, void *p) {
     for (size_t i = 0; i < ctx->mapped.size(); i++) {
         dabgpu_ctx::Mapped &m = ctx->mapped[i];
         if (m.va != p) continue;
-        (void)hipMemUnmap(m.va, m.bytes);
-        for (auto h : m.handles) (void)hipMemRelease(h);
-        (void)hipMemAddressFree(m.va, m.bytes);
+        m.release();
         ctx->mapped.erase(ctx->mapped.begin() + long(i));
         return true;
     }
@@ -525,19 +539,52 @@ struct Chunks {
     struct Item {
         hipMemGenericAllocationHandle_t h;
         size_t bytes, off;                                   // offset inside the probe mapping
+        bool in_probe = true;                                // still mapped for probing
+        char *own = nullptr;                                 // a spacer: its own little address range (the runtime books
+                                                             // reserved ADDRESS SPACE against free device memory, so the
+                                                             // probe range is never reserved larger than what fills it)
     };
     std::vector<Item> items;
     char *va = nullptr;                                      // probe mapping
-    size_t reserved = 0, mapped = 0;
-    ~Chunks() {
-        if (va) {
-            if (mapped) (void)hipMemUnmap(va, mapped);
-            (void)hipMemAddressFree(va, reserved);
+    size_t reserved = 0, mapped = 0;                         // mapped: bytes handed out of the range so far
+    // every chunk leaves its probe mapping on its own extents.  (The address ranges themselves are all given back
+    // together at the very end, after whatever the caller builds from the chunks has its own ranges: this runtime was
+    // seen to look a new range's addresses up in a range freed moments before.)
+    bool unmap_all() {
+        bool ok = true;
+        for (auto &x : items) {
+            if (!x.in_probe) continue;
+            ok = hipMemUnmap(x.own ? x.own : va + x.off, x.bytes) == hipSuccess && ok;
+            x.in_probe = false;
         }
-        for (auto &x : items) if (x.h) (void)hipMemRelease(x.h);
+        return ok;
+    }
+    // one more chunk of `bytes` outside the probe range, mapped and accessible; -1 when the device has no more to give
+    int add_spacer(size_t bytes, const hipMemAllocationProp &prop, const hipMemAccessDesc &acc) {
+        hipMemGenericAllocationHandle_t h;
+        if (hipMemCreate(&h, bytes, &prop, 0) != hipSuccess) { (void)hipGetLastError(); return -1; }
+        void *p = nullptr;
+        if (hipMemAddressReserve(&p, bytes, 0, nullptr, 0) != hipSuccess) { (void)hipMemRelease(h); (void)hipGetLastError(); return -1; }
+        if (hipMemMap(p, bytes, 0, h, 0) != hipSuccess || hipMemSetAccess(p, bytes, &acc, 1) != hipSuccess) {
+            (void)hipMemUnmap(p, bytes);
+            (void)hipMemAddressFree(p, bytes);
+            (void)hipMemRelease(h);
+            (void)hipGetLastError();
+            return -1;
+        }
+        Item it{h, bytes, 0};
+        it.own = static_cast<char *>(p);
+        items.push_back(it);
+        return int(items.size()) - 1;
+    }
+    ~Chunks() {
+        (void)unmap_all();
+        for (auto &x : items) if (x.h) (void)hipMemRelease(x.h);                  // the chunks nobody took
+        for (auto &x : items) if (x.own) (void)hipMemAddressFree(x.own, x.bytes);
+        if (va) (void)hipMemAddressFree(va, reserved);
         (void)hipGetLastError();
     }
-    char *at(int i) const { return va + items[size_t(i)].off; }
+    char *at(int i) const { const Item &x = items[size_t(i)]; return x.own ? x.own : va + x.off; }
 };
 
 // time of a mover launch that reads [in, in + in_b) and writes [out, out + out_b): min of two after a warm-up
@@ -657,10 +704,9 @@ int dabgpu_alloc_frame_buffers_placed(dabgpu_ctx *ctx, int n_frames, size_t fram
     hipMemAccessDesc acc = {};
     acc.location = prop.location;
     acc.flags = hipMemAccessFlagsProtReadWrite;
-    // (address space for the spacers of the one-domain case below is reserved with the rest: it costs nothing)
     constexpr int MAX_SPACERS = 100;
     Chunks c;
-    c.reserved = size_t(n_big) * CH + size_t(n_small) * CS + size_t(MAX_SPACERS) * CH;
+    c.reserved = size_t(n_big) * CH + size_t(n_small) * CS;
     void *va = nullptr;
     if (hipMemAddressReserve(&va, c.reserved, 0, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); return plain(); }
     c.va = static_cast<char *>(va);
@@ -713,18 +759,16 @@ int dabgpu_alloc_frame_buffers_placed(dabgpu_ctx *ctx, int n_frames, size_t fram
         iq_domain = clean();
         int ref[3] = {-1, -1, -1};
         float self[3] = {0.f, 0.f, 0.f};
+        size_t spacer_bytes = 0;
         for (int i = n_total - 1; i >= 0; i--) ref[dom[size_t(i)]] = i;          // a reference chunk per domain seen: its first one
         for (int k = 0; k < MAX_SPACERS && iq_domain < 0; k++) {
             size_t fb = 0, tb = 0;
             if (hipMemGetInfo(&fb, &tb) != hipSuccess || fb < 2 * CH + tb / 16) break;          // leave the device some air
-            hipMemGenericAllocationHandle_t h;
-            if (hipMemCreate(&h, CH, &prop, 0) != hipSuccess) break;
-            if (hipMemMap(c.va + c.mapped, CH, 0, h, 0) != hipSuccess) { (void)hipMemRelease(h); break; }
-            c.items.push_back(Chunks::Item{h, CH, c.mapped});
-            c.mapped += CH;
-            const int x = n_total++;
+            const int x = c.add_spacer(CH, prop, acc);
+            if (x < 0) break;
+            n_total++;
             dom.push_back(0);
-            if (hipMemSetAccess(c.at(x), CH, &acc, 1) != hipSuccess) { rc = DABGPU_ERR_HIP; break; }
+            spacer_bytes += CH;
             // same domain as a known one?  (reading the reference and writing the spacer is ~10 % slower then)
             int d = -1;
             for (int q = 0; q < 3 && d < 0; q++) {
@@ -744,7 +788,7 @@ int dabgpu_alloc_frame_buffers_placed(dabgpu_ctx *ctx, int n_frames, size_t fram
             iq_domain = clean();
         }
         (void)hipGetLastError();
-        rep.setup_peak_bytes = c.mapped;
+        rep.setup_peak_bytes = c.mapped + spacer_bytes;
         rep.n_chunks = n_total;
     }
     rep.n_domains = n_dom;
@@ -826,8 +870,7 @@ int dabgpu_alloc_frame_buffers_placed(dabgpu_ctx *ctx, int n_frames, size_t fram
     dabgpu_ctx::Mapped m_iq{nullptr, iq_mapped, 0, {}}, m_soft{nullptr, soft_mapped, 0, {}};
     if (!rc) {
         (void)hipStreamSynchronize(s);
-        if (hipMemUnmap(c.va, c.mapped) != hipSuccess) rc = DABGPU_ERR_HIP;
-        c.mapped = 0;
+        if (!c.unmap_all()) rc = DABGPU_ERR_HIP;
     }
     auto map_over = [&](dabgpu_ctx::Mapped &m, const std::vector<int> &sel) -> int {
         if (hipMemAddressReserve(&m.va, m.bytes, 0, nullptr, 0) != hipSuccess) return DABGPU_ERR_NOMEM;
@@ -836,6 +879,7 @@ int dabgpu_alloc_frame_buffers_placed(dabgpu_ctx *ctx, int n_frames, size_t fram
             Chunks::Item &it = c.items[size_t(sel[k])];
             if (hipMemMap(static_cast<char *>(m.va) + off, it.bytes, 0, it.h, 0) != hipSuccess) return DABGPU_ERR_HIP;
             m.handles.push_back(it.h);
+            m.sizes.push_back(it.bytes);
             it.h = nullptr;                                    // owned by the mapping from here on
             off += it.bytes;
             m.chunk = off;                                     // bytes mapped so far
@@ -845,13 +889,7 @@ int dabgpu_alloc_frame_buffers_placed(dabgpu_ctx *ctx, int n_frames, size_t fram
     if (!rc) rc = map_over(m_iq, iq_sel);
     if (!rc) rc = map_over(m_soft, soft_sel);
     if (rc) {
-        for (dabgpu_ctx::Mapped *m : {&m_iq, &m_soft}) {
-            if (!m->va) continue;
-            if (m->chunk) (void)hipMemUnmap(m->va, m->chunk);
-            for (auto h : m->handles) (void)hipMemRelease(h);
-            (void)hipMemAddressFree(m->va, m->bytes);
-        }
-        (void)hipGetLastError();
+        for (dabgpu_ctx::Mapped *m : {&m_iq, &m_soft}) m->release();
     } else {
         ctx->mapped.push_back(m_iq);
         ctx->mapped.push_back(m_soft);
@@ -915,6 +953,7 @@ static int alloc_apart(dabgpu_ctx *ctx, size_t bytes, const void *ref, size_t re
     hipMemAccessDesc acc = {};
     acc.location = prop.location;
     acc.flags = hipMemAccessFlagsProtReadWrite;
+    constexpr int MAX_SPACERS = 100;                        // (see dabgpu_alloc_frame_buffers_placed: the one-domain case)
     Chunks c;
     c.reserved = size_t(n_total) * CH;
     void *va = nullptr;
@@ -938,8 +977,8 @@ static int alloc_apart(dabgpu_ctx *ctx, size_t bytes, const void *ref, size_t re
         rc = DABGPU_ERR_HIP;
     if (!rc) {
         (void)hipEventRecord(ec0, s);
-        const int n_dom = classify_chunks(c, s, e0, e1, dom);
-        if (n_dom < 0) rc = DABGPU_ERR_HIP;
+        int n_dom = classify_chunks(c, s, e0, e1, dom);
+        if (n_dom < 0) { rc = DABGPU_ERR_HIP; n_dom = 1; }
         // the domain of every piece of ref: the representative it is slow against (none: a domain no chunk is in)
         const size_t RP = size_t(1) << 30;
         const int n_ref = int((ref_bytes + RP - 1) / RP);
@@ -965,9 +1004,17 @@ static int alloc_apart(dabgpu_ctx *ctx, size_t bytes, const void *ref, size_t re
                 if (t[0] > 0.97f * self) ref_dom[size_t(r)] = 0;
             }
         }
-        // every piece of the buffer: the chunk least beside its own domain
-        std::vector<char> used(size_t(n_total), 0);
+        // every piece of the buffer: the chunk least beside its own domain.  Where the 1.2 x budget leaves more than a
+        // twentieth of the buffer beside same-domain reads (all of it, when budget and reference lie in one domain),
+        // 1 GiB-class spacers are taken four at a time, placed among the known domains (or given a new one), and the
+        // selection is repeated; the ones nobody takes go back when this call returns.
         const double ratio = double(ref_bytes) / double(bytes);
+        float self_ms[3] = {0.f, 0.f, 0.f};
+        int spacers = 0;
+      select_again:
+        std::vector<char> used(size_t(n_total), 0);
+        sel.clear();
+        shared = 0.0;
         for (int m = 0; m < n_need && !rc; m++) {
             const double lo_b = double(m) * double(CH) * ratio - 1.5 * double(RP), hi_b = double(m + 1) * double(CH) * ratio + 1.5 * double(RP);
             double w[3] = {0.0, 0.0, 0.0}, tot = 0.0;
@@ -986,6 +1033,45 @@ static int alloc_apart(dabgpu_ctx *ctx, size_t bytes, const void *ref, size_t re
             used[size_t(best)] = 1;
             if (tot > 0.0) shared += w[dom[size_t(best)]] / tot;
         }
+        if (!rc && shared > 0.05 * double(n_need) && spacers < MAX_SPACERS) {
+            int added = 0;
+            for (int k = 0; k < 4 && spacers < MAX_SPACERS; k++) {
+                size_t fb = 0, tb = 0;
+                if (hipMemGetInfo(&fb, &tb) != hipSuccess || fb < 2 * CH + tb / 16) break;
+                const int x = c.add_spacer(CH, prop, acc);
+                if (x < 0) break;
+                n_total++;
+                dom.push_back(0);
+                spacers++;
+                added++;
+                int d = -1;
+                for (int q = 0; q < n_dom && d < 0; q++) {
+                    if (self_ms[q] == 0.f) self_ms[q] = pair_ms(c, repr[size_t(q)], repr[size_t(q)], s, e0, e1);
+                    const float t = pair_ms(c, repr[size_t(q)], x, s, e0, e1);
+                    if (t < 0.f || self_ms[q] < 0.f) { rc = DABGPU_ERR_HIP; break; }
+                    if (t >= 0.97f * self_ms[q]) d = q;
+                }
+                if (rc) break;
+                if (d < 0) {
+                    if (n_dom < 3) { d = n_dom++; repr[size_t(d)] = x; }
+                    else d = 0;
+                    // a domain no chunk was in before: are pieces of the reference in it?  (those that matched none)
+                    for (int r = 0; r < n_ref && d == n_dom - 1 && repr[size_t(d)] == x; r++) {
+                        if (ref_dom[size_t(r)] >= 0) continue;
+                        const size_t in_b = std::min(RP, ref_bytes - size_t(r) * RP);
+                        if (in_b < (size_t(64) << 20)) { ref_dom[size_t(r)] = r > 0 ? ref_dom[size_t(r) - 1] : -1; continue; }
+                        const char *in = static_cast<const char *>(ref) + size_t(r) * RP;
+                        const float tn = mover_ms(in, in_b, c.at(x), std::min(CH, in_b / 6), s, e0, e1);
+                        const float to = mover_ms(in, in_b, c.at(repr[0]), std::min(CH, in_b / 6), s, e0, e1);   // (not its domain: it matched none)
+                        if (tn < 0.f || to < 0.f) { rc = DABGPU_ERR_HIP; break; }
+                        if (tn > 1.04f * to) ref_dom[size_t(r)] = d;
+                    }
+                }
+                dom[size_t(x)] = d;
+            }
+            (void)hipGetLastError();
+            if (!rc && added > 0) goto select_again;
+        }
         (void)hipEventRecord(ec1, s);
         (void)hipEventSynchronize(ec1);
         float cms = 0.f;
@@ -995,25 +1081,20 @@ static int alloc_apart(dabgpu_ctx *ctx, size_t bytes, const void *ref, size_t re
     dabgpu_ctx::Mapped m{nullptr, CH * size_t(n_need), 0, {}};
     if (!rc) {
         (void)hipStreamSynchronize(s);
-        if (hipMemUnmap(c.va, c.mapped) != hipSuccess) rc = DABGPU_ERR_HIP;
-        c.mapped = 0;
+        if (!c.unmap_all()) rc = DABGPU_ERR_HIP;
     }
     if (!rc && hipMemAddressReserve(&m.va, m.bytes, 0, nullptr, 0) != hipSuccess) rc = DABGPU_ERR_NOMEM;
     for (size_t k = 0; k < sel.size() && !rc; k++) {
         Chunks::Item &it = c.items[size_t(sel[k])];
         if (hipMemMap(static_cast<char *>(m.va) + CH * k, CH, 0, it.h, 0) != hipSuccess) { rc = DABGPU_ERR_HIP; break; }
         m.handles.push_back(it.h);
+        m.sizes.push_back(CH);
         it.h = nullptr;
         m.chunk = CH * (k + 1);
     }
     if (!rc && hipMemSetAccess(m.va, m.bytes, &acc, 1) != hipSuccess) rc = DABGPU_ERR_HIP;
     if (rc) {
-        if (m.va) {
-            if (m.chunk) (void)hipMemUnmap(m.va, m.chunk);
-            for (auto h : m.handles) (void)hipMemRelease(h);
-            (void)hipMemAddressFree(m.va, m.bytes);
-        }
-        (void)hipGetLastError();
+        m.release();
     } else {
         ctx->mapped.push_back(m);
         *out = m.va;

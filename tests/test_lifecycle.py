@@ -83,3 +83,28 @@ def test_two_contexts_keep_their_own_stream_states(built, ensemble, ensemble_iq)
     assert abs(sa.fine_freq_offset * 2048 + 0.2) < 0.01 and sa.total_frames_read == 6
     assert sb.fine_freq_offset == 0 and sb.total_frames_read == 0
     a.close(); b.close()
+
+
+def test_placed_allocations_repeat(built):
+    """dabgpu_alloc_frame_buffers_placed / dabgpu_device_alloc_apart / free, ten times over in one context: every call
+    succeeds, the reports stay sane, and the device's free memory ends where it began (a runtime that books reserved
+    address space against free memory, or an unmap that spans several mappings, shows up here as a failure on the second
+    or third round)."""
+    import torch
+    c = make_ctx(None, 8)
+    L = dabgpu.NB_FRAME_SAMPLES
+    torch.cuda.synchronize()
+    d_iq, d_soft, rep = c.alloc_frame_buffers_placed(3000, L)        # once, so that pools are warm
+    c.free_frame_buffers(d_iq, d_soft)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for k in range(10):
+        d_iq, d_soft, rep = c.alloc_frame_buffers_placed(3000, L)
+        assert rep.method == 1 and d_iq and d_soft and 0 <= rep.conflicts <= 1000, k
+        d_other, ms = c.device_alloc_apart(1 << 30, d_iq, 3000 * L * 8)
+        assert d_other and 0.0 <= ms[1] <= 1000.0
+        c.device_free(d_other)
+        c.free_frame_buffers(d_iq, d_soft)
+    torch.cuda.synchronize()
+    assert abs(free0 - torch.cuda.mem_get_info()[0]) <= 64 << 20
+    c.close()
