@@ -71,6 +71,7 @@ def place_buffers(torch, dabgpu, ctx, dev, n_frames, mode, n_candidates):
                   "chunk_domains": rep.domains.decode(), "iq_chunk_domains": rep.iq_map.decode(),
                   "soft_chunk_domains": rep.soft_map.decode(), "domains_seen": rep.n_domains,
                   "soft_bits_written_beside_same_domain_reads_per_mille": rep.conflicts, "classify_ms": round(rep.classify_ms, 2),
+                  "mover_on_pair_over_mover_in_one_domain": round(float(rep.pair_over_same_domain), 3),
                   "setup_peak_bytes": int(rep.setup_peak_bytes),
                   "setup_peak_over_final_footprint": round(rep.setup_peak_bytes / (n_frames * (L * 8 + dabgpu.NB_FRAME_BITS)), 3),
                   "front_end_ms_on_placed_pair": round(rep.front_end_ms, 3)}

@@ -169,6 +169,11 @@ typedef struct dabgpu_placement_report {
     uint64_t setup_peak_bytes;  /* device memory held at the peak of the set-up                                */
     float classify_ms;          /* time spent finding the domains                                              */
     float front_end_ms;         /* one timed front-end launch on the placed pair (noise input)                 */
+    float pair_over_same_domain; /* check of the result: a mover reading the first GiB of the samples and writing  */
+                                /* the start of the soft-bit buffer, over the same mover writing into the samples' */
+                                /* own buffer instead (same domain by construction): ~0.9 when the two buffers     */
+                                /* lie apart, ~1.0 when they do not (0 = not measured)                             */
+    float reserved;
     char domains[72];           /* one letter per chunk in allocation order: 'A' 'B' 'C' for the 1 GiB chunks, */
                                 /* 'a' 'b' 'c' for the 256 MiB ones, then the spacers; NUL-terminated, cut at 71 */
     char iq_map[72];            /* the chunks of the IQ buffer in address order, same letters                  */

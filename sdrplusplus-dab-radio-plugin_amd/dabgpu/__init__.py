@@ -113,7 +113,8 @@ class TrackCfg(C.Structure):
 class PlacementReport(C.Structure):
     _fields_ = [("method", C.c_int32), ("n_chunks", C.c_int32), ("iq_chunks", C.c_int32), ("soft_chunks", C.c_int32),
                 ("n_domains", C.c_int32), ("conflicts", C.c_int32), ("chunk_bytes", C.c_uint64), ("setup_peak_bytes", C.c_uint64),
-                ("classify_ms", C.c_float), ("front_end_ms", C.c_float), ("domains", C.c_char * 72), ("iq_map", C.c_char * 72),
+                ("classify_ms", C.c_float), ("front_end_ms", C.c_float), ("pair_over_same_domain", C.c_float), ("reserved", C.c_float),
+                ("domains", C.c_char * 72), ("iq_map", C.c_char * 72),
                 ("soft_map", C.c_char * 24)]
 
 

@@ -348,6 +348,9 @@ def test_alloc_frame_buffers_placed(built, ensemble_iq):
     assert rep.front_end_ms > 0 and rep.classify_ms > 0 and 0 <= rep.conflicts <= 1000
     if rep.conflicts == 0 and rep.n_domains > 1:
         assert not set(rep.soft_map.decode().upper()) & set(rep.iq_map.decode().upper()[:2])
+        # ... and the mover agrees: writing the soft-bit buffer beside reads of the samples is faster than writing into
+        # the samples' own buffer beside the same reads
+        assert 0.5 < rep.pair_over_same_domain < 0.985, rep.pair_over_same_domain
     held = free0 - torch.cuda.mem_get_info()[0]
     assert held <= 1.2 * final + (64 << 20) and held >= final, held   # the chunks nobody took (and every spacer not taken) were released
     rx = synth.channel(ensemble_iq.ravel(), snr_db=18.0, cfo=0.0, rng=np.random.default_rng(6)).reshape(ensemble_iq.shape)
