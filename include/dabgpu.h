@@ -222,7 +222,9 @@ int dabgpu_ofdm_demod_frames_dev(dabgpu_ctx *ctx, const void *d_iq, size_t frame
                                  void *stream);
 int dabgpu_ofdm_demod_frames(dabgpu_ctx *ctx, const float *iq, size_t frame_stride, int n_frames,
                              const float *freq_offset, int8_t *soft, float *cyc, float *dqpsk);
-/* The same front end reading ONE cyclic prefix per frame instead of 76 (the prefixes are 20 % of the samples, and the
+/* (Serves the fine-frequency loop whose state the GUI reads -- GetFineFrequencyOffset, fine_freq_update_beta,
+ * /root/reference/src/render_radio_block.cpp:202, :216 -- with an estimator of this library's own.)
+ * The same front end reading ONE cyclic prefix per frame instead of 76 (the prefixes are 20 % of the samples, and the
  * kernel is bound by the bytes it moves), with the decision-directed frequency-error sums a loop needs instead of the
  * cyclic-prefix correlations:
  *   dd4  [n_frames][76] cf32; the SUM of entries 1..75 of a frame = sum over its 75 data symbols and 256 of each
@@ -467,7 +469,8 @@ int dabgpu_ofdm_demod_acquired_dev(dabgpu_ctx *ctx, const void *d_iq, size_t str
 /* predicts inside the capture (start_i = next_frame_start + i*(196608+drift)) */
 /* are synchronised on their own PRS (impulse response -> exact start, lock),   */
 /* demodulated where they lie with the stream's fine + coarse offset, and the   */
-/* state is moved on: fine-frequency loop from the cyclic-prefix correlations, */
+/* state is moved on: fine-frequency loop (decision-directed sums by default,    */
+/* cfg.decision_directed; the cyclic-prefix correlations when d_cyc is given),  */
 /* next_frame_start and drift from a line through the measured starts.         */
 /*   n_samples  samples per stream in this capture                             */
 /*   advance    the next capture of every stream will begin this many samples   */
