@@ -4,8 +4,11 @@ Plumbing only: argument marshalling and error translation.  There is no Python o
 CPU implementation behind these calls -- if the HIP library is missing or no gfx950
 device is visible they raise.  Used by tests/, bench.py and __graft_entry__.py.
 """
+import atexit
 import ctypes as C
 import os
+import sys
+import weakref
 
 import numpy as np
 
@@ -325,6 +328,8 @@ class PinnedArray:
             self._p = None
 
     def __del__(self):
+        if sys.is_finalizing():                  # the HIP runtime may be gone already: the process is about to return it all
+            return
         try:
             self.close()
         except Exception:
@@ -351,6 +356,23 @@ def uep_subchannel(table_index, start_address):
 
 
 # ------------------------------------------------------------------ context
+# Contexts still open when the interpreter ends are closed from an atexit handler -- registered when this module is
+# imported, i.e. after torch's own, so it runs BEFORE them -- while the HIP runtime is certainly still there; what the
+# garbage collector finds after that is left to the operating system.
+_LIVE_CONTEXTS = weakref.WeakSet()
+
+
+def _close_live_contexts():
+    for c in list(_LIVE_CONTEXTS):
+        try:
+            c.close()
+        except Exception:
+            pass
+
+
+atexit.register(_close_live_contexts)
+
+
 class Context:
     """Owns a dabgpu_ctx.  Host-array methods copy in/out and synchronise; *_dev methods take
     raw device addresses (e.g. torch.Tensor.data_ptr()) and a stream handle and only enqueue."""
@@ -360,13 +382,17 @@ class Context:
         self._lib = library if library is not None else lib()
         cfg = Cfg(device, max_frames, 1, flags, ofdm_symbol_runs)
         _check(self._lib.dabgpu_create(C.byref(cfg), C.byref(self._h)), "dabgpu_create")
+        _LIVE_CONTEXTS.add(self)
 
     def close(self):
         if self._h:
             self._lib.dabgpu_destroy(self._h)
             self._h = C.c_void_p()
+        _LIVE_CONTEXTS.discard(self)
 
     def __del__(self):
+        if sys.is_finalizing():                  # (see _close_live_contexts: contexts are closed before the interpreter goes)
+            return
         try:
             self.close()
         except Exception:
