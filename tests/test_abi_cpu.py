@@ -64,3 +64,32 @@ def test_product_path_never_imports_the_oracle():
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "dab_oracle" not in txt and "liboracle" not in txt, os.path.join(dirpath, f)
                 assert not re.search(r"^\s*(from|import)\s+oracle", txt, re.M), os.path.join(dirpath, f)
+
+
+def test_binding_structures_match_the_header(tmp_path):
+    """Every ctypes structure of the binding has the size the C compiler gives the header's struct, and its fields sit at
+    the header's offsets (a field added to one side only would shift everything behind it silently)."""
+    import ctypes as C
+    import subprocess
+    pairs = [("dabgpu_ofdm_params", dabgpu.OfdmParams), ("dabgpu_dab_params", dabgpu.DabParams), ("dabgpu_cfg", dabgpu.Cfg),
+             ("dabgpu_stats", dabgpu.Stats), ("dabgpu_sync_result", dabgpu.SyncResult), ("dabgpu_acquire_cfg", dabgpu.AcquireCfg),
+             ("dabgpu_track_cfg", dabgpu.TrackCfg), ("dabgpu_placement_report", dabgpu.PlacementReport),
+             ("dabgpu_frame_result", dabgpu.FrameResult), ("dabgpu_subchannel", dabgpu.Subchannel)]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "dabgpu.h"', 'int main(void) {']
+    for cname, cls in pairs:
+        lines.append('  printf("%s %%zu", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            lines.append('  printf(" %%zu", offsetof(%s, %s));' % (cname, fname))
+        lines.append('  printf("\\n");')
+    lines += ['  printf("dabgpu_stream_state %zu\\n", sizeof(dabgpu_stream_state));', '  return 0; }']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines) + "\n")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)], text=True).split("\n")
+    for (cname, cls), line in zip(pairs, out):
+        got = line.split()
+        assert got[0] == cname
+        want = [C.sizeof(cls)] + [getattr(cls, f).offset for f, _ in cls._fields_]
+        assert [int(x) for x in got[1:]] == want, (cname, got[1:], want)
+    assert out[len(pairs)].split() == ["dabgpu_stream_state", "64"] and dabgpu.STREAM_STATE_DTYPE.itemsize == 64
