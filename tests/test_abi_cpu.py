@@ -81,7 +81,14 @@ def test_binding_structures_match_the_header(tmp_path):
         for fname, _ in cls._fields_:
             lines.append('  printf(" %%zu", offsetof(%s, %s));' % (cname, fname))
         lines.append('  printf("\\n");')
-    lines += ['  printf("dabgpu_stream_state %zu\\n", sizeof(dabgpu_stream_state));', '  return 0; }']
+    # the two device-resident records the tests read through numpy dtypes
+    records = [("dabgpu_stream_state", dabgpu.STREAM_STATE_DTYPE), ("dabgpu_acquired_frame", dabgpu.ACQUIRED_FRAME_DTYPE)]
+    for cname, dt in records:
+        lines.append('  printf("%s %%zu", sizeof(%s));' % (cname, cname))
+        for fname in dt.names:
+            lines.append('  printf(" %%zu", offsetof(%s, %s));' % (cname, fname))
+        lines.append('  printf("\\n");')
+    lines += ['  return 0; }']
     src = tmp_path / "layout.c"
     src.write_text("\n".join(lines) + "\n")
     exe = tmp_path / "layout"
@@ -92,4 +99,8 @@ def test_binding_structures_match_the_header(tmp_path):
         assert got[0] == cname
         want = [C.sizeof(cls)] + [getattr(cls, f).offset for f, _ in cls._fields_]
         assert [int(x) for x in got[1:]] == want, (cname, got[1:], want)
-    assert out[len(pairs)].split() == ["dabgpu_stream_state", "64"] and dabgpu.STREAM_STATE_DTYPE.itemsize == 64
+    for (cname, dt), line in zip(records, out[len(pairs):]):
+        got = line.split()
+        assert got[0] == cname
+        assert [int(x) for x in got[1:]] == [dt.itemsize] + [dt.fields[f][1] for f in dt.names], (cname, got[1:])
+    assert dabgpu.STREAM_STATE_DTYPE.itemsize == 64 and dabgpu.ACQUIRED_FRAME_DTYPE.itemsize == 32
