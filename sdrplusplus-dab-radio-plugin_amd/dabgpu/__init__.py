@@ -327,10 +327,10 @@ class PinnedArray:
             lib().dabgpu_host_free(self._p)
             self._p = None
 
-    def __del__(self):
-        if sys.is_finalizing():                  # the HIP runtime may be gone already: the process is about to return it all
-            return
+    def __del__(self, _finalizing=sys.is_finalizing):   # (bound now: module globals are gone when the interpreter ends)
         try:
+            if _finalizing():                    # the HIP runtime may be gone already: the process is about to return it all
+                return
             self.close()
         except Exception:
             pass
@@ -390,10 +390,10 @@ class Context:
             self._h = C.c_void_p()
         _LIVE_CONTEXTS.discard(self)
 
-    def __del__(self):
-        if sys.is_finalizing():                  # (see _close_live_contexts: contexts are closed before the interpreter goes)
-            return
+    def __del__(self, _finalizing=sys.is_finalizing):
         try:
+            if _finalizing():                    # (see _close_live_contexts: contexts are closed before the interpreter goes)
+                return
             self.close()
         except Exception:
             pass
