@@ -684,34 +684,13 @@ bool same_domain_as(const Chunks &c, int ref, const std::vector<int> &idx, hipSt
 }
 }  // namespace
 
-static int alloc_frame_buffers_placed_once(dabgpu_ctx *ctx, int n_frames, size_t frame_stride, void **d_iq, int8_t **d_soft,
-                                           dabgpu_placement_report *report);
-
+// (A placement whose own check -- pair_over_same_domain -- says the two buffers do NOT lie apart is reported as such and
+// kept.  Throwing it away and placing again was tried: every free-then-reserve of address ranges gives this runtime
+// another chance to answer a look-up in the new range with the freed one ("Sub buffer memory end cannot be greater than
+// base_end", then a crash inside hipMemMap: once in ~40 allocations on a device another process also uses), and a
+// suboptimal placement costs 4 %, a crash the process.  Call these allocators once, at start-up.)
 int dabgpu_alloc_frame_buffers_placed(dabgpu_ctx *ctx, int n_frames, size_t frame_stride, void **d_iq, int8_t **d_soft,
                                       dabgpu_placement_report *report) {
-    // The classification rests on timings; its result is checked by a measurement of its own (pair_over_same_domain).
-    // A placement that claims to be clean but does not measure so (seen in 1 of 60 fresh processes) is thrown away and
-    // made again, twice at most.
-    dabgpu_placement_report rep;
-    int rc = DABGPU_OK;
-    for (int attempt = 0; attempt < 3; attempt++) {
-        std::memset(&rep, 0, sizeof(rep));
-        rc = alloc_frame_buffers_placed_once(ctx, n_frames, frame_stride, d_iq, d_soft, &rep);
-        const bool suspicious = !rc && rep.method == 1 && rep.conflicts < 100 && rep.pair_over_same_domain > 0.97f;
-        if (!suspicious || attempt == 2) break;
-        DeviceGuard guard(ctx);
-        (void)hipDeviceSynchronize();
-        (void)release_mapped(ctx, *d_iq);
-        (void)release_mapped(ctx, *d_soft);
-        *d_iq = nullptr;
-        *d_soft = nullptr;
-    }
-    if (report) *report = rep;
-    return rc;
-}
-
-static int alloc_frame_buffers_placed_once(dabgpu_ctx *ctx, int n_frames, size_t frame_stride, void **d_iq, int8_t **d_soft,
-                                           dabgpu_placement_report *report) {
     if (!ctx || !d_iq || !d_soft || n_frames <= 0) return DABGPU_ERR_ARG;
     if (frame_stride < size_t(NB_FRAME_SAMPLES) || (frame_stride & 1u)) return DABGPU_ERR_ARG;
     if (size_t(n_frames) > size_t(0x7fffffff) / NB_DATA_SYMBOLS) return DABGPU_ERR_ARG;
