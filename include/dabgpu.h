@@ -16,10 +16,12 @@
  *     without `_dev` take HOST pointers, copy, run and synchronise.
  *   - the caller owns every buffer; a context is thread-compatible (one caller
  *     at a time per context), contexts are independent.
- *   - work enqueued through ONE context must be stream-ordered: the decoder entry
- *     points share per-context work buffers, so two calls on different streams
- *     need an event between them (or two contexts, as the host mirror uses: one
- *     for OFDM_Demod, one for BasicRadio).
+ *   - work enqueued through ONE context must be stream-ordered: the entry points
+ *     share per-context work buffers (decoder scratch, the stream / tracked / frame
+ *     calls' loop input, the stream states), so AT MOST ONE caller stream may be in
+ *     flight per context -- two calls on different streams need an event between
+ *     them (or two contexts, as the host mirror uses: one for OFDM_Demod, one for
+ *     BasicRadio).
  *   - soft bits are int8: +127 = logical 1, -127 = logical 0, 0 = erased
  *     (`viterbi_bit_t`, /root/reference/src/radio_block.h:19).
  *   - the library REQUIRES a gfx950 device for everything except the table
@@ -35,7 +37,7 @@
 extern "C" {
 #endif
 
-#define DABGPU_ABI_VERSION 4   /* 4: + timing tracking (64-byte stream state, tracked / frame calls, peak rule in the acquire cfg) */
+#define DABGPU_ABI_VERSION 5   /* 5: one frame-buffer allocator (placement mode), host-fed ring (dabgpu_pipe_*), loop gate */
 
 typedef enum dabgpu_status {
     DABGPU_OK = 0,
@@ -134,65 +136,68 @@ void *dabgpu_host_alloc(size_t bytes);
 void dabgpu_host_free(void *p);
 
 /* Device buffers for a batch user's IQ samples ([n_frames][frame_stride] cf32, frame_stride >= 196608 samples) and
- * soft bits ([n_frames][230400] int8), placed for the front end: MI355X's HBM behaves as three domains of 96 GB, and
- * a launch that reads its samples from the domain it writes its soft bits to runs ~12 % slower than one whose two
- * streams are apart (profiles/r02_hbm_domains.txt).  Where hipMalloc puts a buffer is not visible, so
- * this call allocates `candidates` (1..8, clamped to what fits in free memory) buffers of each kind, times the
- * front-end launch on every (input, output) pair, keeps the fastest pair and frees the rest.  A set-up call: it
- * synchronises, takes a few hundred milliseconds and leaves noise in the IQ buffer.  probe_ms (may be NULL) receives
- * the candidates x candidates table of launch times, row = input candidate; kept (may be NULL) the chosen pair.
- * candidates == 1 is a plain allocation.  Any device buffer is accepted by the _dev entry points; this is an
- * optimisation for callers that own their buffers.  Release with dabgpu_free_frame_buffers (either may be NULL). */
-int dabgpu_alloc_frame_buffers(dabgpu_ctx *ctx, int n_frames, size_t frame_stride, int candidates, void **d_iq,
-                               int8_t **d_soft, float *probe_ms, int *kept);
-int dabgpu_free_frame_buffers(dabgpu_ctx *ctx, void *d_iq, int8_t *d_soft);
-
-/* The same pair of buffers, placed DETERMINISTICALLY and within 1.2 x their size: physical memory is taken in chunks
- * through the virtual-memory API (hipMemCreate; 1 GiB chunks for the samples, 256 MiB ones for the soft bits), every
- * chunk's HBM domain is found with a small data mover (a launch that reads chunk a and writes chunk b is ~10 % slower
- * when they share a domain: two passes, ~40 ms), the IQ buffer is mapped over chunks of the most plentiful domain(s)
- * and every 256 MiB of the soft-bit buffer over a chunk whose domain differs from the ~1.7 GiB of samples that are
- * read WHILE it is written (the front end walks both buffers in frame order); the chunks left over are released.
- * One case needs more than 1.2 x for a moment: a fresh device hands out its memory in address order and a domain's
- * address ranges are tens of GB long, so the whole budget can lie in ONE domain.  Then 1 GiB spacers are taken (and
- * classified one by one) until enough of them lie elsewhere to carry the soft bits; the others go back before the call
- * returns, setup_peak_bytes says what was held, and what the caller keeps is the two buffers as always.
- * Falls back to a plain allocation (method 0) for small buffers or when the virtual-memory API is not available.  The report (may be NULL) says what was found and what one front-end
- * launch on the placed pair takes.  Release with dabgpu_free_frame_buffers. */
+ * soft bits ([n_frames][230400] int8).  Any device buffer is accepted by the _dev entry points; this call exists for
+ * callers that own their buffers and want them placed for the front end.
+ *   placement  DABGPU_PLACE_PLAIN    two hipMallocs.
+ *              DABGPU_PLACE_DOMAINS  MI355X's HBM behaves as three domains of 96 GB, and a launch that reads its
+ *                samples from the domain it writes its soft bits to runs up to ~10 % slower than one whose two streams
+ *                lie apart (profiles/r02_hbm_domains.txt; on most boxes a plain pair already lies apart
+ *                and the gain is ~0).  Physical memory is taken in chunks through the virtual-memory API (1 GiB for the
+ *                samples, 256 MiB for the soft bits; never more than 1.5 x the pair's size held during set-up), every
+ *                chunk's domain is found with a small data mover (two passes, ~40 ms), the IQ buffer is mapped over
+ *                chunks of the most plentiful domain(s) and every 256 MiB of the soft-bit buffer over a chunk whose
+ *                domain differs from the ~1.7 GiB of samples read WHILE it is written; the chunks left over go back.
+ *                All of it happens inside ONE address range per context, reserved by the first such call and released
+ *                by dabgpu_destroy: one domain-aware pair per context at a time; a second request while the first is
+ *                alive, a request larger than the range was reserved for, buffers below ~4 GiB, a device without the
+ *                virtual-memory API or without room, and any failure on the way all end in a PLAIN pair
+ *                (report->method = 0, report->fallback_reason says why).  A set-up call: it synchronises, takes
+ *                ~0.1 s and leaves noise in both buffers.
+ * Returns an error only when the plain allocation fails too.  Release with dabgpu_free_frame_buffers (both pointers of
+ * a domain-aware pair together). */
+#define DABGPU_PLACE_PLAIN   0
+#define DABGPU_PLACE_DOMAINS 1
+/* report->fallback_reason */
+#define DABGPU_PLAIN_REQUESTED    0  /* DABGPU_PLACE_PLAIN was asked for                                   */
+#define DABGPU_PLAIN_SIZE         1  /* too small for the domains to matter, or more chunks than are handled */
+#define DABGPU_PLAIN_NO_VMM       2  /* the virtual-memory API refused (reserve / map / set access)          */
+#define DABGPU_PLAIN_NO_ROOM      3  /* free memory does not hold the chunks                                  */
+#define DABGPU_PLAIN_ARENA_BUSY   4  /* the context's domain-aware pair is still alive                        */
+#define DABGPU_PLAIN_ARENA_SMALL  5  /* larger than the address range the context reserved on its first call   */
+#define DABGPU_PLAIN_PROBE_FAILED 6  /* a probe launch or its timing failed                                    */
 typedef struct dabgpu_placement_report {
-    int32_t method;             /* 0 = plain hipMalloc, 1 = domain-aware arena                                 */
+    int32_t method;             /* 0 = plain hipMalloc pair, 1 = domain-aware pair                              */
+    int32_t fallback_reason;    /* method 0: DABGPU_PLAIN_*                                                     */
     int32_t n_chunks;           /* physical chunks taken during set-up                                         */
     int32_t iq_chunks, soft_chunks;   /* chunks (of either size) each buffer is mapped over                    */
     int32_t n_domains;          /* distinct HBM domains seen among the chunks (1..3)                           */
     int32_t conflicts;          /* per mille of the soft bits that are written beside reads from their own domain */
+    int32_t runtime_error;      /* fallback after a failed runtime call: stage * 1000 + hipError_t (stage 1 reserve, */
+                                /* 2 create, 3 map, 4 set access, 5 re-map, 6 memory info); else 0                  */
     uint64_t chunk_bytes;
-    uint64_t setup_peak_bytes;  /* device memory held at the peak of the set-up                                */
+    uint64_t setup_peak_bytes;  /* device memory held at the peak of the set-up (<= 1.5 x the pair)            */
     float classify_ms;          /* time spent finding the domains                                              */
-    float front_end_ms;         /* one timed front-end launch on the placed pair (noise input)                 */
     float pair_over_same_domain; /* check of the result: a mover reading the first GiB of the samples and writing  */
                                 /* the start of the soft-bit buffer, over the same mover writing into the samples' */
                                 /* own buffer instead (same domain by construction): ~0.9 when the two buffers     */
                                 /* lie apart, ~1.0 when they do not (0 = not measured)                             */
-    float reserved;
-    char domains[72];           /* one letter per chunk in allocation order: 'A' 'B' 'C' for the 1 GiB chunks, */
-                                /* 'a' 'b' 'c' for the 256 MiB ones, then the spacers; NUL-terminated, cut at 71 */
+    char domains[100];          /* one letter per chunk in allocation order: 'A' 'B' 'C' for the 1 GiB chunks, */
+                                /* 'a' 'b' 'c' for the 256 MiB ones; NUL-terminated, cut at 95                  */
     char iq_map[72];            /* the chunks of the IQ buffer in address order, same letters                  */
-    char soft_map[24];          /* the chunks of the soft-bit buffer in address order                          */
+    char soft_map[28];          /* the chunks of the soft-bit buffer in address order                          */
 } dabgpu_placement_report;
-int dabgpu_alloc_frame_buffers_placed(dabgpu_ctx *ctx, int n_frames, size_t frame_stride, void **d_iq, int8_t **d_soft,
-                                      dabgpu_placement_report *report);
+int dabgpu_alloc_frame_buffers(dabgpu_ctx *ctx, int n_frames, size_t frame_stride, int placement, void **d_iq,
+                               int8_t **d_soft, dabgpu_placement_report *report);
+int dabgpu_free_frame_buffers(dabgpu_ctx *ctx, void *d_iq, int8_t *d_soft);
 
-/* The same for any other buffer a launch WRITES while it reads `d_other`, both walked front to back in step (e.g. the
- * spectra of dabgpu_fft_symbols_dev beside the IQ samples): physical chunks (1 GiB, or 256 MiB below 8 GiB; at most
- * 1.2 x `bytes` held during set-up), their HBM domains among themselves, the domain of every GiB of d_other against one
- * representative chunk per domain, then every piece of the new buffer over a chunk whose domain the part of d_other
- * read beside it is not in; the chunks left over are released.  With d_other == NULL, or buffers too small for the
- * domains to matter (< 256 MB), a plain allocation.  probe_ms (may be NULL, 3 floats): [0] the time of a small mover
- * on the result (first GiB of d_other -> start of the buffer), [1] per mille of the buffer left beside same-domain
- * reads, [2] milliseconds spent classifying; all 0 for a plain allocation.  Release with dabgpu_device_free. */
-int dabgpu_device_alloc_apart(dabgpu_ctx *ctx, size_t bytes, const void *d_other, size_t other_bytes, void **d_out,
-                              float *probe_ms);
-int dabgpu_device_free(dabgpu_ctx *ctx, void *d_ptr);
+/* The ceiling the front end is measured against: a pure data mover of the front end's own geometry on the caller's
+ * buffers -- per frame the useful 2048 samples of each of the 76 symbols (+ the PRS's prefix; with_prefixes != 0: the
+ * whole 2552-sample periods, what a launch that produces the cyclic-prefix correlations reads) in, 230400 bytes out,
+ * one wavefront per run of symbols cut exactly as dabgpu_ofdm_demod_frames_dev cuts the same batch, streaming
+ * accesses, the same LDS footprint (occupancy) -- and no arithmetic.  Overwrites d_soft with meaningless bytes.
+ * Time it with events on `stream`; bench.py reports it as roofline.mover_same_geometry_ms. */
+int dabgpu_mover_frames_dev(dabgpu_ctx *ctx, const void *d_iq, size_t frame_stride, int n_frames, int8_t *d_soft,
+                            int with_prefixes, void *stream);
 
 /* ------------------------------------------------------------------------ */
 /* A2..A6: OFDM front end on time-aligned frames.                             */
@@ -277,7 +282,12 @@ typedef struct dabgpu_stream_state {      /* DEVICE memory, 64 bytes */
                                           /* relative to the first sample of the NEXT capture                      */
     float drift;                          /* samples per frame the frame period differs from 196608                */
     float last_peak_to_mean;              /* impulse-response peak / mean of the most recent frame                 */
-    int32_t reserved[4];
+    int32_t loop_gated;                   /* decision-directed loop: calls whose fourth-power estimate was gated    */
+                                          /* (quality below the gate: the PRS prefix alone was used; or a one-step  */
+                                          /* branch departure held back) -- see dabgpu_set_loop_gate                */
+    int32_t dd_branch;                    /* branch of the most recent accepted estimate, units of 0.2 carriers     */
+    int32_t dd_pending;                   /* a one-step departure from branch 0 seen once (0x7fffffff: none)        */
+    int32_t reserved;
 } dabgpu_stream_state;
 
 typedef struct dabgpu_stats {             /* HOST copy with the derived fields the GUI prints */
@@ -295,6 +305,8 @@ typedef struct dabgpu_stats {             /* HOST copy with the derived fields t
     double next_frame_start;
     float drift;
     float last_peak_to_mean;
+    int32_t loop_gated;                   /* see dabgpu_stream_state                                                */
+    int32_t reserved;
 } dabgpu_stats;
 
 /* (re)create the context's stream states, all zero */
@@ -325,6 +337,16 @@ int dabgpu_get_stats(dabgpu_ctx *ctx, int stream_index, dabgpu_stats *out);
  *                                     the first call on.  (Off by default only so that callers written against ABI v3
  *                                     see the loop they know.) */
 int dabgpu_set_stream_loop(dabgpu_ctx *ctx, float signal_update_beta, float thr_null_start, int decision_directed);
+/* The decision-directed loop checks its own estimate before it moves (stream call here; tracked and frame calls:
+ * dabgpu_track_cfg.dd_gate).  With S = the call's sum of unit fourth powers over n terms:
+ *   quality  |S| < dd_gate * sqrt(n) -- what n random phases add up to, times the gate (8 by default): the sum carries no
+ *            usable phase (3 dB SNR and less on single frames, an interferer, nothing selected) and the call takes the
+ *            cyclic-prefix estimate of its PRSs alone -- unbiased, coarser; 0 switches this gate off.
+ *   branch   a stream whose previous residual lay inside +-0.1 carriers and whose PRS prefix now asks for the branch one
+ *            step (0.2 carriers) away is believed only when the next call asks again; the first time the branch is held.
+ * Either event counts in loop_gated (dabgpu_get_stats).  The loop on the cyclic-prefix correlations -- the reference's
+ * estimator, fine_freq_update_beta at /root/reference/src/render_radio_block.cpp:216 -- has no such ambiguity and no gate. */
+int dabgpu_set_loop_gate(dabgpu_ctx *ctx, float dd_gate);
 
 /* Soft-bit selection (batch receivers that decode the FIC and a few sub-channels and never look at the rest of the
  * frame): from the next call on, dabgpu_ofdm_demod_frames[_dev], dabgpu_ofdm_demod_streams[_dev] and
@@ -509,6 +531,9 @@ typedef struct dabgpu_track_cfg {
                                               /* with the others', their tracking started; streams     */
                                               /* that are tracking cost nothing extra.  One call does  */
                                               /* everything from the first capture on (0)              */
+    float dd_gate;                            /* decision-directed loop: quality gate, see             */
+                                              /* dabgpu_set_loop_gate (8; 0 = off)                     */
+    int32_t reserved;                         /* must be 0                                             */
 } dabgpu_track_cfg;
 void dabgpu_track_default_cfg(dabgpu_track_cfg *cfg);
 /* only_lost != 0: streams that are tracking keep their state (re-acquisition of the lost ones beside them) */
@@ -632,6 +657,49 @@ int dabgpu_decode_frames(dabgpu_ctx *ctx, const int8_t *soft, size_t soft_stride
 int dabgpu_decode_stream_frames(dabgpu_ctx *ctx, const int8_t *soft, size_t soft_stride, int n_frames, uint8_t *fib,
                                 uint8_t *crc_ok, const dabgpu_subchannel *sc, int n_subchannels, uint8_t *const *out);
 int dabgpu_decode_stream_reset(dabgpu_ctx *ctx);
+
+/* ------------------------------------------------------------------------ */
+/* The host-fed ring: dabgpu_ofdm_demod_frames + dabgpu_decode_frames for a    */
+/* caller whose samples start in HOST memory (files, a network), pipelined.    */
+/* The reference runs these two stages on two threads with a 2-frame ring       */
+/* between them (/root/reference/src/radio_block.cpp:23-44: the On_OFDM_Frame   */
+/* callback writes, the radio thread reads and calls BasicRadio::Process); here  */
+/* the ring is `slots` device staging sets and three engines work at once: the   */
+/* upload of batch k+1, the kernels of batch k, the download of batch k-1.       */
+/*                                                                            */
+/* dabgpu_pipe_open   slots 2..8 (3 keeps all three engines busy); max_frames =   */
+/*            the largest n_streams * frames_per_stream a submit will carry;       */
+/*            frame_stride of the host IQ ([n][frame_stride] cf32, frame f's first  */
+/*            PRS sample at iq + f*frame_stride, 76*2552 samples read).  One ring    */
+/*            per context.                                                         */
+/* dabgpu_pipe_submit enqueues ONE batch and returns at once: the samples go up,    */
+/*            are demodulated -- with freq_offset[n_frames] as                       */
+/*            dabgpu_ofdm_demod_frames does, or (freq_offset == NULL) closed loop on   */
+/*            the context's stream states as dabgpu_ofdm_demod_streams does, cyclic-   */
+/*            prefix or decision-directed per dabgpu_set_stream_loop -- and decoded     */
+/*            as dabgpu_decode_frames does (FIC + the listed sub-channels); fib,         */
+/*            crc_ok, out[i] ([n_streams][frames_per_stream*4][bitrate*3]) and, when      */
+/*            soft != NULL, the soft bits come down.  Batches are processed in the        */
+/*            order submitted and CONTINUE their streams: the time de-interleaver of       */
+/*            every sub-channel stays on the device between submits (keyed by start         */
+/*            address, size and n_streams; a sub-channel seen for the first time, or left    */
+/*            out of the previous batch, starts from erasures; dabgpu_pipe_reset drops        */
+/*            them all).  Every host buffer must stay valid and untouched until                */
+/*            dabgpu_pipe_wait(ticket) returns; buffers from dabgpu_host_alloc move at          */
+/*            the link rate (pageable memory works, through the runtime's bounce buffers         */
+/*            and without overlap).  A submit that finds every slot busy first waits for           */
+/*            the oldest batch to leave the device.                                                */
+/* dabgpu_pipe_wait   blocks until that batch's results are in the caller's buffers.               */
+/* Kernels run on the context's own stream: the synchronous entry points of the same context         */
+/* stay ordered with the ring (and wait behind it).                                                   */
+/* ------------------------------------------------------------------------ */
+int dabgpu_pipe_open(dabgpu_ctx *ctx, int slots, int max_frames, size_t frame_stride);
+int dabgpu_pipe_submit(dabgpu_ctx *ctx, const float *iq, int n_streams, int frames_per_stream, const float *freq_offset,
+                       float fine_freq_update_beta, const dabgpu_subchannel *sc, int n_subchannels, int8_t *soft,
+                       uint8_t *fib, uint8_t *crc_ok, uint8_t *const *out, int64_t *ticket);
+int dabgpu_pipe_wait(dabgpu_ctx *ctx, int64_t ticket);
+int dabgpu_pipe_reset(dabgpu_ctx *ctx);
+int dabgpu_pipe_close(dabgpu_ctx *ctx);
 
 /* ------------------------------------------------------------------------ */
 /* DAB+ audio super-frame: Fire code, RS(120,110), AU CRC.    */

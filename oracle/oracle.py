@@ -219,30 +219,68 @@ def dd_error(dd4):
     return np.float32(e_dd + np.float32(k) * np.float32(1.0 / (4.0 * 2552.0)))
 
 
-def stream_update(state, cyc, iq_last_frame, beta, thr_null_start=0.35, signal_beta=0.95, dd=False):
+DD_NO_BRANCH = 0x7fffffff
+
+
+def dd_loop_error(dd4, state, gate=8.0, terms_per_frame=19200):
+    """The decision-directed fine-frequency error of a call WITH its two gates (TEST INFRASTRUCTURE; restates
+    dabk::dd_loop_error, csrc/kernels.hpp -- an estimator of this library's own: the reference shows only that a fine loop
+    exists, /root/reference/src/render_radio_block.cpp:202, :216).  dd4: rows [frames][76] (entry 0 = PRS cyclic-prefix
+    correlation, entries 1.. = fourth-power sums); state: dict with total_frames_read and (optionally) loop_gated,
+    dd_branch, dd_pending.  Returns (err float32, new {loop_gated, dd_branch, dd_pending}).
+      quality  |sum|^2 < gate^2 * n_terms: the cyclic-prefix estimate of the PRSs alone
+      branch   previous branch 0 and now +-1, not seen on the call before: held at 0 once"""
+    a = np.asarray(dd4, np.complex128)
+    frames = a.reshape(-1, a.shape[-1]).shape[0]
+    s = a[..., 1:].sum()
+    e_cp = np.float32(np.float32(np.angle(a[..., 0]).sum() / frames) * np.float32(1.0 / (6.283185307179586 * 2048.0)))
+    gated = int(state.get("loop_gated", 0))
+    branch = int(state.get("dd_branch", 0))
+    pending = int(state.get("dd_pending", 0))
+    n_terms = float(frames) * float(terms_per_frame)
+    g = float(np.float32(gate))
+    if not (n_terms > 0.0) or (s.real * s.real + s.imag * s.imag) < g * g * n_terms:
+        k = int(np.rint(np.float32(e_cp * np.float32(4.0 * 2552.0))))
+        return e_cp, {"loop_gated": gated + 1, "dd_branch": k, "dd_pending": DD_NO_BRANCH}
+    e_dd = np.float32(np.arctan2(-s.imag, -s.real) / (4.0 * 6.283185307179586 * 2552.0))
+    k = int(np.rint(np.float32(np.float32(e_cp - e_dd) * np.float32(4.0 * 2552.0))))
+    first = int(state.get("total_frames_read", 0)) == 0
+    if (not first) and branch == 0 and k in (1, -1) and pending != k:
+        pending, gated, k = k, gated + 1, 0
+    else:
+        pending = DD_NO_BRANCH
+    err = np.float32(e_dd + np.float32(np.float32(k) * np.float32(1.0 / (4.0 * 2552.0))))
+    return err, {"loop_gated": gated, "dd_branch": k, "dd_pending": pending}
+
+
+def stream_update(state, cyc, iq_last_frame, beta, thr_null_start=0.35, signal_beta=0.95, dd=False, dd_gate=8.0, terms_per_frame=19200):
     """Restatement of the fine-frequency loop and counters of the stream call (TEST INFRASTRUCTURE; parity unpinned:
     the loop runs inside the absent DAB-Radio OFDM_Demod, its existence and knobs are visible at
     /root/reference/src/render_radio_block.cpp:202-207, :216).  state: dict with fine_freq_offset,
-    coarse_freq_offset, signal_average, total_frames_read, total_frames_desync; cyc: complex [frames][76];
-    iq_last_frame: the stream's most recent frame from its first PRS sample.  Returns the new dict."""
+    coarse_freq_offset, signal_average, total_frames_read, total_frames_desync (decision-directed: + loop_gated, dd_branch,
+    dd_pending, 0 when absent); cyc: complex [frames][76]; iq_last_frame: the stream's most recent frame from its first PRS
+    sample.  Returns the new dict."""
     n = cyc.size
     frames = cyc.shape[0]
-    if dd:                                                       # `cyc` holds dd4 sums: the decision-directed loop
-        err = dd_error(cyc)
+    new = dict(state)
+    if dd:                                                       # `cyc` holds dd4 sums: the decision-directed loop, gated
+        err, gate_state = dd_loop_error(cyc, state, dd_gate, terms_per_frame)
+        new.update(gate_state)
     else:
         err = np.float32(np.angle(cyc.astype(np.complex128)).sum() / n / (2.0 * np.pi * 2048.0))
-    half = np.float32(0.5 / 2048.0)
-    f = np.float32(state["fine_freq_offset"]) - np.float32(beta) * err
-    if f > half:
-        f -= 2 * half
-    if f < -half:
-        f += 2 * half
     x = np.asarray(iq_last_frame[:4096])
     l1 = np.float32((np.abs(x.real).astype(np.float64) + np.abs(x.imag).astype(np.float64)).sum() / 4096.0)
-    new = dict(state)
-    new["fine_freq_offset"] = np.float32(f)
+    level_lost = bool(state["signal_average"] > 0 and l1 < np.float32(thr_null_start) * np.float32(state["signal_average"]))
+    if not (level_lost and frames == 1):                         # one frame whose level is gone steers nothing
+        half = np.float32(0.5 / 2048.0)
+        f = np.float32(state["fine_freq_offset"]) - np.float32(beta) * err
+        if f > half:
+            f -= 2 * half
+        if f < -half:
+            f += 2 * half
+        new["fine_freq_offset"] = np.float32(f)
     new["last_fine_error"] = err
-    if state["signal_average"] > 0 and l1 < thr_null_start * state["signal_average"]:
+    if level_lost:
         new["total_frames_desync"] = state["total_frames_desync"] + 1
         new["total_frames_read"] = state["total_frames_read"] + frames - 1
     else:
@@ -453,7 +491,7 @@ def track_sync(iq, state, max_frames, margin=64, min_peak_to_mean=100.0, distanc
 
 
 def track_update(state, frames, cyc, iq, n_samples, max_frames, advance, fine_beta=0.9, drift_beta=0.5, signal_beta=0.95,
-                 thr_null_start=0.35, dd=False):
+                 thr_null_start=0.35, dd=False, dd_gate=8.0, terms_per_frame=19200):
     """State after a tracked call: `frames` from track_sync, `cyc` complex [len(frames)][76] of the demodulated frames
     (rows of unlocked frames are ignored), `iq` the capture.  Returns (new state dict, count)."""
     st = dict(state)
@@ -466,26 +504,30 @@ def track_update(state, frames, cyc, iq, n_samples, max_frames, advance, fine_be
     locked = [i for i in range(count) if (frames[i]["flags"] & 3) == 3]
     n = len(locked)
     desync = j0 + (count - n)
+    level_lost = False
     if n > 0:
         if dd:
-            err = dd_error(np.asarray(cyc)[locked])
+            err, gate_state = dd_loop_error(np.asarray(cyc)[locked], state, dd_gate, terms_per_frame)
+            st.update(gate_state)
         else:
             ang = np.angle(np.asarray(cyc)[locked].astype(np.complex128)).sum()
             err = np.float32(np.float32(ang / (n * 76.0)) * np.float32(1.0 / (6.283185307179586 * 2048.0)))
-        half = np.float32(0.5 / 2048.0)
-        f = np.float32(state["fine_freq_offset"]) - np.float32(fine_beta) * err
-        if f > half:
-            f -= 2 * half
-        if f < -half:
-            f += 2 * half
-        st["fine_freq_offset"] = np.float32(f)
-        st["last_fine_error"] = err
         last = locked[-1]
-        st["last_time_offset"] = int(frames[last]["start"] - int(np.rint(nxt + float(j0 + last) * period)))
-        st["last_peak_to_mean"] = np.float32(frames[last]["peak_to_mean"])
         x = np.asarray(iq[frames[last]["start"]:frames[last]["start"] + 4096])
         l1 = np.float32((np.abs(x.real).astype(np.float64) + np.abs(x.imag).astype(np.float64)).sum() / 4096.0)
-        if state["signal_average"] > 0 and l1 < np.float32(thr_null_start) * np.float32(state["signal_average"]):
+        level_lost = bool(state["signal_average"] > 0 and l1 < np.float32(thr_null_start) * np.float32(state["signal_average"]))
+        if not (level_lost and n == 1):                          # one locked frame whose level is gone steers nothing
+            half = np.float32(0.5 / 2048.0)
+            f = np.float32(state["fine_freq_offset"]) - np.float32(fine_beta) * err
+            if f > half:
+                f -= 2 * half
+            if f < -half:
+                f += 2 * half
+            st["fine_freq_offset"] = np.float32(f)
+        st["last_fine_error"] = err
+        st["last_time_offset"] = int(frames[last]["start"] - int(np.rint(nxt + float(j0 + last) * period)))
+        st["last_peak_to_mean"] = np.float32(frames[last]["peak_to_mean"])
+        if level_lost:
             desync += 1
         else:
             sb = np.float32(signal_beta)
@@ -508,7 +550,7 @@ def track_update(state, frames, cyc, iq, n_samples, max_frames, advance, fine_be
         st["tracking"] = 0
     st["next_frame_start"] = nxt + float(j0 + count) * period + alpha + slope * count - float(advance)
     st["drift"] = np.float32(float(np.float32(state["drift"])) + gain * slope_hat)
-    st["total_frames_read"] = state["total_frames_read"] + n
+    st["total_frames_read"] = state["total_frames_read"] + n - (1 if level_lost else 0)   # (gone, not read)
     st["total_frames_desync"] = state["total_frames_desync"] + desync
     return st, count
 

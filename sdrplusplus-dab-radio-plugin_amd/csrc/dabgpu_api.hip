@@ -1,146 +1,20 @@
-// dabgpu_api.hip -- the C ABI of libdabgpu (include/dabgpu.h): context, tables,
-// argument checking and kernel launches.  No CPU fallback: without a gfx950 device
-// dabgpu_create fails with DABGPU_ERR_NODEVICE and every compute entry point needs a
-// context.
-#include "../../include/dabgpu.h"
-
-#include <hip/hip_runtime.h>
+// dabgpu_api.hip -- the C ABI of libdabgpu (include/dabgpu.h): context, tables, the OFDM front end, synchronisation,
+// acquisition and tracking entry points.  (Channel decoder: dabgpu_decode_api.hip; frame buffers: dabgpu_placement.hip;
+// host-fed ring: dabgpu_pipeline.hip.)  No CPU fallback: without a gfx950 device dabgpu_create fails with
+// DABGPU_ERR_NODEVICE and every compute entry point needs a context.
+#include "dabgpu_ctx.hpp"
 
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <map>
-#include <memory>
 #include <new>
-#include <vector>
-
-#include "dab_tables.hpp"
-#include "kernels.hpp"
 
 using namespace dab;
+using namespace dabapi;
 
 namespace {
-
-struct DeviceCode {
-    dab::PunctureProfile prof;
-    uint16_t *d_mother_pos = nullptr;
-    uint8_t *d_prbs = nullptr;
-    int32_t *d_punct_idx = nullptr;      // [4*nsteps] punctured index of each mother bit, -1 = erased (lane kernels)
-    int32_t *d_fused_desc = nullptr, *d_fused_tiles = nullptr;   // fused lane forward pass (build_lane_fused_tables)
-    dabk::LaneTables lane_tables() const { return dabk::LaneTables{d_punct_idx, d_fused_desc, d_fused_tiles}; }
-    dabk::CodeTables tables(bool descramble) const {
-        return dabk::CodeTables{d_mother_pos, prof.n_punct, prof.nsteps, descramble ? d_prbs : nullptr};
-    }
-};
-
-// hipEvent pairs around the most recent launches of one kernel family (a ring: the launches are asynchronous, so
-// the pairs can only be read back after the stream has caught up)
-constexpr int TIMER_RING = 32;
-struct Timer {
-    hipEvent_t start[TIMER_RING] = {}, stop[TIMER_RING] = {};
-    long recorded = 0;                   // launches timed since timing was switched on
-};
-
-}  // namespace
-
-struct dabgpu_ctx {
-    int device = 0;
-    int max_frames = 0;
-    hipStream_t stream = nullptr;
-    float2 *d_twiddle = nullptr;
-    uint16_t *d_bin_of_n = nullptr;
-    uint16_t *d_n_of_vj = nullptr;
-    int8_t *d_prs_qt = nullptr;
-    uint16_t *d_sync_pairs = nullptr;
-    int n_sync_pairs = 0;
-    float2 *d_sync_fs = nullptr;         // FFT of the PRS's adjacent-carrier differential (coarse search by FFT)
-    DeviceCode fic;
-    std::map<std::vector<uint8_t>, std::unique_ptr<DeviceCode>> codes;   // keyed by puncture mask
-    // staging for the host-pointer entry points
-    // slots 0..5: staging of the host-pointer entry points; slot 6: the stream call's own cyclic-prefix correlations
-    // (it runs on a caller's stream, so it must not share a slot with calls that run on the context stream)
-    void *d_stage[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t stage_bytes[7] = {0, 0, 0, 0, 0, 0, 0};
-    bool timing = false;
-    Timer timers[4];
-    int ofdm_parts_override = 0;
-    const unsigned long long *d_keep = nullptr;          // current soft-bit selection table ([75][3] words) or nullptr
-    std::vector<void *> keep_tables;                     // every table handed to a kernel so far (freed on destroy)
-    void *d_acq_scratch = nullptr;       // block norms + candidates of dabgpu_acquire
-    size_t acq_scratch_bytes = 0;
-    void *d_lane_scratch = nullptr;      // work buffers of the codeword-per-lane Viterbi
-    size_t lane_scratch_bytes = 0;
-    int lane_mode = -1;                  // 1 = DABGPU_FLAG_VITERBI_LANE, 0 = DABGPU_FLAG_VITERBI_WAVE, -1 by batch size
-    bool lane_unfused = false;           // DABGPU_FLAG_LANE_UNFUSED
-    int wave_slots = 3072;       // resident OFDM wavefronts: 12 per CU
-    std::vector<dabgpu_bit_range> keep_ranges;           // the current selection, merged, for the host-pointer copy-back
-    dabk::StreamState *d_states = nullptr;               // per-stream tracking state (dabgpu_streams_reset)
-    int n_states = 0;
-    hipEvent_t ev_states = nullptr;      // recorded behind the last launch that reads or writes d_states, on ITS stream
-    bool ev_states_pending = false;
-    float thr_null_start = 0.35f;        // desync threshold of the stream call (null_l1_search.thresh_null_start)
-    float signal_beta = 0.95f;           // signal_l1.update_beta of the stream call
-    bool loop_dd = false;                // stream call without a correlation buffer: decision-directed fine loop
-    // dabgpu_decode_stream_frames: de-interleaver rings of the stream's sub-channels, kept on the device between calls
-    struct SubHistory {
-        int start_address, length;
-        size_t bytes;
-        int8_t *ring[2];
-        int cur;
-        bool live;                       // decoded in the current call (a ring that misses a frame is stale: dropped)
-    };
-    std::vector<SubHistory> sub_history;
-    void *h_bounce = nullptr;            // page-locked landing area of that call's single download
-    size_t h_bounce_bytes = 0;
-    // buffers handed out by dabgpu_alloc_frame_buffers_placed: virtual ranges mapped over physical chunks
-    struct Mapped {
-        void *va;
-        size_t bytes, chunk;             // reserved = mapped bytes; scratch while mapping
-        std::vector<hipMemGenericAllocationHandle_t> handles;
-        std::vector<size_t> sizes;       // bytes of each handle's mapping, in address order
-        // every mapping is undone on its own extents (an unmap spanning several mappings is not something the
-        // virtual-memory API promises), then the physical memory and the address range go back
-        void release() {
-            size_t off = 0;
-            for (size_t k = 0; k < handles.size(); k++) {
-                (void)hipMemUnmap(static_cast<char *>(va) + off, sizes[k]);
-                (void)hipMemRelease(handles[k]);
-                off += sizes[k];
-            }
-            if (va) (void)hipMemAddressFree(va, bytes);
-            (void)hipGetLastError();
-            handles.clear();
-            sizes.clear();
-            va = nullptr;
-        }
-    };
-    std::vector<Mapped> mapped;
-};
-
-namespace {
-
-// Makes the context's device current for the duration of an entry point and restores the caller's afterwards:
-// allocations, copies and launches of a context must never land on whatever device the calling thread last used.
-struct DeviceGuard {
-    int prev = -1;
-    bool switched = false;
-    explicit DeviceGuard(const dabgpu_ctx *ctx) {
-        if (ctx && hipGetDevice(&prev) == hipSuccess && prev != ctx->device) switched = hipSetDevice(ctx->device) == hipSuccess;
-    }
-    ~DeviceGuard() {
-        if (switched) (void)hipSetDevice(prev);
-    }
-    DeviceGuard(const DeviceGuard &) = delete;
-    DeviceGuard &operator=(const DeviceGuard &) = delete;
-};
-
-#define HIP_TRY(expr)                               \
-    do {                                            \
-        hipError_t e_ = (expr);                     \
-        if (e_ != hipSuccess) return DABGPU_ERR_HIP; \
-    } while (0)
 
 template <class T>
 int upload(T **dst, const std::vector<T> &src) {
@@ -171,6 +45,9 @@ int build_device_code(DeviceCode &dc) {
     }
     return upload(&dc.d_prbs, dab::make_prbs_bytes((dc.prof.nsteps - 6 + 7) / 8));
 }
+}  // namespace
+
+namespace dabapi {
 
 void free_device_code(DeviceCode &dc) {
     if (dc.d_mother_pos) (void)hipFree(dc.d_mother_pos);
@@ -209,26 +86,9 @@ int stage(dabgpu_ctx *ctx, int slot, size_t bytes, void **out) {
     return DABGPU_OK;
 }
 
-struct ScopedTimer {
-    dabgpu_ctx *ctx;
-    int which;
-    hipStream_t s;
-    ScopedTimer(dabgpu_ctx *c, int w, hipStream_t st) : ctx(c), which(w), s(st) {
-        if (ctx->timing) {
-            Timer &t = ctx->timers[which];
-            const int i = int(t.recorded % TIMER_RING);
-            if (!t.start[i]) { (void)hipEventCreate(&t.start[i]); (void)hipEventCreate(&t.stop[i]); }
-            (void)hipEventRecord(t.start[i], s);
-        }
-    }
-    ~ScopedTimer() {
-        if (ctx->timing) {
-            Timer &t = ctx->timers[which];
-            (void)hipEventRecord(t.stop[int(t.recorded % TIMER_RING)], s);
-            t.recorded++;
-        }
-    }
-};
+}  // namespace dabapi
+
+namespace {
 
 // How a launch's frames are cut into runs of consecutive symbols (one run = one wavefront; 12 resident per CU).  A cut
 // costs one more transform and one more symbol read (the run's differential reference), so cuts are made only where they
@@ -257,43 +117,6 @@ RunPlan plan_runs(const dabgpu_ctx *ctx, int n_frames, int total_syms) {
     const long cost_mixed = whole / slots * (total_syms + 1) + uniform(long(n_frames) - whole, &p_tail);
     if (whole > 0 && cost_mixed < cost_all) return RunPlan{int(whole), p_tail};
     return RunPlan{0, p_all};
-}
-
-constexpr size_t PLACE_MIN_BYTES = size_t(256) << 20;      // below this the HBM domains do not matter
-
-// The codeword-per-lane Viterbi pays once a launch has enough codewords to give every SIMD a wave (one wave =
-// 64 codewords; its single-wave latency equals the wave-per-codeword kernels' time at ~24k codewords).
-constexpr int LANE_MIN_CODEWORDS = 24576;
-
-// returns true and a scratch descriptor when the lane kernels should take this launch
-// (`force`: the codeword is too long for the wave-per-codeword kernels' LDS slab -- the lane kernels keep their
-// survivors in HBM and take any length)
-bool use_lane(dabgpu_ctx *ctx, int nsteps, int n_codewords, hipStream_t s, dabk::LaneScratch *sc, int *rc, bool force = false) {
-    *rc = DABGPU_OK;
-    if (!dabk::lane_supported(nsteps)) return false;
-    if (!force && (ctx->lane_mode == 0 || (ctx->lane_mode < 0 && n_codewords < LANE_MIN_CODEWORDS))) return false;
-    const size_t need = dabk::lane_scratch_bytes(nsteps, n_codewords);
-    if (ctx->lane_scratch_bytes < need) {
-        // growing the buffer must not race with work still using the old one
-        if (hipStreamSynchronize(s) != hipSuccess) { *rc = DABGPU_ERR_HIP; return false; }
-        if (ctx->d_lane_scratch) (void)hipFree(ctx->d_lane_scratch);
-        ctx->d_lane_scratch = nullptr;
-        ctx->lane_scratch_bytes = 0;
-        if (hipMalloc(&ctx->d_lane_scratch, need) != hipSuccess) {
-            ctx->d_lane_scratch = nullptr;
-            if (ctx->lane_mode > 0 || force) *rc = DABGPU_ERR_NOMEM;
-            return false;                                     // fall back to the wave kernels
-        }
-        ctx->lane_scratch_bytes = need;
-    }
-    sc->base = ctx->d_lane_scratch;
-    sc->bytes = ctx->lane_scratch_bytes;
-    sc->unfused = ctx->lane_unfused;
-    return true;
-}
-
-hipStream_t pick_stream(dabgpu_ctx *ctx, void *stream) {
-    return stream ? reinterpret_cast<hipStream_t>(stream) : ctx->stream;
 }
 
 }  // namespace
@@ -468,8 +291,6 @@ int dabgpu_create(const dabgpu_cfg *cfg, dabgpu_ctx **out) {
     return DABGPU_OK;
 }
 
-static bool release_mapped(dabgpu_ctx *ctx, void *p);
-
 void dabgpu_destroy(dabgpu_ctx *ctx) {
     if (!ctx) return;
     {
@@ -495,7 +316,8 @@ void dabgpu_destroy(dabgpu_ctx *ctx) {
             if (t.start[i]) (void)hipEventDestroy(t.start[i]);
             if (t.stop[i]) (void)hipEventDestroy(t.stop[i]);
         }
-    while (!ctx->mapped.empty()) (void)release_mapped(ctx, ctx->mapped.back().va);
+    pipeline_destroy(ctx);
+    arena_destroy(ctx);
     if (ctx->ev_states) (void)hipEventDestroy(ctx->ev_states);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     }
@@ -511,747 +333,6 @@ void *dabgpu_host_alloc(size_t bytes) {
 void dabgpu_host_free(void *p) {
     if (p) (void)hipHostFree(p);
 }
-
-// releases a range handed out by the placed allocator; false when `p` is not one of them
-static bool release_mapped(dabgpu_ctx *ctx, void *p) {
-    for (size_t i = 0; i < ctx->mapped.size(); i++) {
-        dabgpu_ctx::Mapped &m = ctx->mapped[i];
-        if (m.va != p) continue;
-        m.release();
-        ctx->mapped.erase(ctx->mapped.begin() + long(i));
-        return true;
-    }
-    return false;
-}
-
-int dabgpu_free_frame_buffers(dabgpu_ctx *ctx, void *d_iq, int8_t *d_soft) {
-    if (!ctx) return DABGPU_ERR_ARG;
-    DeviceGuard guard(ctx);
-    HIP_TRY(hipDeviceSynchronize());
-    if (d_iq && !release_mapped(ctx, d_iq)) HIP_TRY(hipFree(d_iq));
-    if (d_soft && !release_mapped(ctx, d_soft)) HIP_TRY(hipFree(d_soft));
-    return DABGPU_OK;
-}
-
-// ---- domain-aware placement (dabgpu_alloc_frame_buffers_placed) ----
-namespace {
-struct Chunks {
-    struct Item {
-        hipMemGenericAllocationHandle_t h;
-        size_t bytes, off;                                   // offset inside the probe mapping
-        bool in_probe = true;                                // still mapped for probing
-        char *own = nullptr;                                 // a spacer: its own little address range (the runtime books
-                                                             // reserved ADDRESS SPACE against free device memory, so the
-                                                             // probe range is never reserved larger than what fills it)
-    };
-    std::vector<Item> items;
-    char *va = nullptr;                                      // probe mapping
-    size_t reserved = 0, mapped = 0;                         // mapped: bytes handed out of the range so far
-    // every chunk leaves its probe mapping on its own extents.  (The address ranges themselves are all given back
-    // together at the very end, after whatever the caller builds from the chunks has its own ranges: this runtime was
-    // seen to look a new range's addresses up in a range freed moments before.)
-    bool unmap_all() {
-        bool ok = true;
-        for (auto &x : items) {
-            if (!x.in_probe) continue;
-            ok = hipMemUnmap(x.own ? x.own : va + x.off, x.bytes) == hipSuccess && ok;
-            x.in_probe = false;
-        }
-        return ok;
-    }
-    // one more chunk of `bytes` outside the probe range, mapped and accessible; -1 when the device has no more to give
-    int add_spacer(size_t bytes, const hipMemAllocationProp &prop, const hipMemAccessDesc &acc) {
-        hipMemGenericAllocationHandle_t h;
-        if (hipMemCreate(&h, bytes, &prop, 0) != hipSuccess) { (void)hipGetLastError(); return -1; }
-        void *p = nullptr;
-        if (hipMemAddressReserve(&p, bytes, 0, nullptr, 0) != hipSuccess) { (void)hipMemRelease(h); (void)hipGetLastError(); return -1; }
-        if (hipMemMap(p, bytes, 0, h, 0) != hipSuccess || hipMemSetAccess(p, bytes, &acc, 1) != hipSuccess) {
-            (void)hipMemUnmap(p, bytes);
-            (void)hipMemAddressFree(p, bytes);
-            (void)hipMemRelease(h);
-            (void)hipGetLastError();
-            return -1;
-        }
-        Item it{h, bytes, 0};
-        it.own = static_cast<char *>(p);
-        items.push_back(it);
-        return int(items.size()) - 1;
-    }
-    ~Chunks() {
-        (void)unmap_all();
-        for (auto &x : items) if (x.h) (void)hipMemRelease(x.h);                  // the chunks nobody took
-        for (auto &x : items) if (x.own) (void)hipMemAddressFree(x.own, x.bytes);
-        if (va) (void)hipMemAddressFree(va, reserved);
-        (void)hipGetLastError();
-    }
-    char *at(int i) const { const Item &x = items[size_t(i)]; return x.own ? x.own : va + x.off; }
-};
-
-// time of a mover launch that reads [in, in + in_b) and writes [out, out + out_b): min of two after a warm-up
-float mover_ms(const void *in, size_t in_b, void *out, size_t out_b, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
-    float best = 1e30f;
-    for (int rep = 0; rep < 3; rep++) {
-        if (hipEventRecord(e0, s) != hipSuccess || dabk::launch_placement_probe(in, in_b, out, out_b, s) != hipSuccess ||
-            hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess)
-            return -1.f;
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return -1.f;
-        if (rep > 0) best = std::min(best, ms);
-    }
-    return best;
-}
-bool same_domain_as(const Chunks &c, int ref, const std::vector<int> &idx, hipStream_t s, hipEvent_t e0, hipEvent_t e1,
-                    std::vector<int> &same, std::vector<int> &other);
-// ... reading chunk a and writing (a sixth of its size of) chunk b
-float pair_ms(const Chunks &c, int a, int b, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
-    const size_t in_b = c.items[size_t(a)].bytes;
-    return mover_ms(c.at(a), in_b, c.at(b), std::min(c.items[size_t(b)].bytes, in_b / 6), s, e0, e1);
-}
-
-// Every chunk's domain (0, 1, 2 in order of first appearance) in two passes: against chunk 0, then against the first
-// chunk that differed.  Returns the number of domains seen, or -1.
-// Is chunk x in the HBM domain of chunk r?  Reading r and writing x against reading r and writing r itself (the
-// same-domain time by construction), the two taken side by side.  "Elsewhere" decides where a buffer goes, and a single
-// slow reference measurement is enough to fake it (seen in 3 of 40 fresh processes): it has to repeat twice more.
-// Returns 1 same, 0 elsewhere, -1 error.
-int in_domain_of(const Chunks &c, int r, int x, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
-    for (int round = 0; round < 3; round++) {
-        const float t = pair_ms(c, r, x, s, e0, e1), self = pair_ms(c, r, r, s, e0, e1);
-        if (t < 0.f || self < 0.f) return -1;
-        if (t >= 0.97f * self) return 1;
-    }
-    return 0;
-}
-
-// The mover's time moves with the memory side's clocks, which take tens of milliseconds to settle on a device that was
-// idle (a fresh process on a fresh box): chunk 0 against itself is timed until two consecutive rounds agree within 1 %
-// (at most ~60 ms) before any comparison is made.
-void settle_clocks(const Chunks &c, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
-    float last = 0.f;
-    for (int round = 0; round < 40; round++) {
-        float t = 0.f;
-        for (int k = 0; k < 2; k++) t = pair_ms(c, 0, 0, s, e0, e1);
-        if (t <= 0.f) return;
-        if (round >= 4 && fabsf(t - last) <= 0.01f * t) return;
-        last = t;
-    }
-}
-
-int classify_chunks(const Chunks &c, hipStream_t s, hipEvent_t e0, hipEvent_t e1, std::vector<int> &dom) {
-    const int n = int(c.items.size());
-    dom.assign(size_t(n), 0);
-    settle_clocks(c, s, e0, e1);
-    std::vector<int> rest, a_set, others;
-    for (int i = 1; i < n; i++) rest.push_back(i);
-    if (!same_domain_as(c, 0, rest, s, e0, e1, a_set, others)) return -1;
-    if (others.empty()) return 1;
-    const int r2 = others[0];
-    std::vector<int> rest2(others.begin() + 1, others.end()), b_set, c_set;
-    if (!same_domain_as(c, r2, rest2, s, e0, e1, b_set, c_set)) return -1;
-    b_set.push_back(r2);
-    for (int i : b_set) dom[size_t(i)] = 1;
-    for (int i : c_set) dom[size_t(i)] = 2;
-    return c_set.empty() ? 2 : 3;
-}
-
-// Chunks whose pairing with `ref` is slow share its domain.  The times of `idx` fall into two groups ~10 % apart; with
-// no gap, the pairing of ref with itself (the same-domain time by construction) says which group everything is in.
-bool same_domain_as(const Chunks &c, int ref, const std::vector<int> &idx, hipStream_t s, hipEvent_t e0, hipEvent_t e1,
-                    std::vector<int> &same, std::vector<int> &other) {
-    if (idx.empty()) return true;
-    std::vector<float> t(idx.size());
-    float lo = 1e30f, hi = 0.f;
-    for (size_t k = 0; k < idx.size(); k++) {
-        if ((t[k] = pair_ms(c, ref, idx[k], s, e0, e1)) < 0.f) return false;
-        lo = std::min(lo, t[k]);
-        hi = std::max(hi, t[k]);
-    }
-    if (hi > 1.04f * lo) {
-        const float thr = 0.5f * (lo + hi);
-        for (size_t k = 0; k < idx.size(); k++) (t[k] > thr ? same : other).push_back(idx[k]);
-        return true;
-    }
-    // (noise only ever makes a measurement slower: the reference time is the fastest of three, or everything would
-    // look "elsewhere" after one slow one)
-    float self = 1e30f;
-    for (int k = 0; k < 3; k++) {
-        const float t1 = pair_ms(c, ref, ref, s, e0, e1);
-        if (t1 < 0.f) return false;
-        self = std::min(self, t1);
-    }
-    (lo > 0.97f * self ? same : other) = idx;
-    return true;
-}
-}  // namespace
-
-// (A placement whose own check -- pair_over_same_domain -- says the two buffers do NOT lie apart is reported as such and
-// kept.  Throwing it away and placing again was tried: every free-then-reserve of address ranges gives this runtime
-// another chance to answer a look-up in the new range with the freed one ("Sub buffer memory end cannot be greater than
-// base_end", then a crash inside hipMemMap: once in ~40 allocations on a device another process also uses), and a
-// suboptimal placement costs 4 %, a crash the process.  Call these allocators once, at start-up.)
-int dabgpu_alloc_frame_buffers_placed(dabgpu_ctx *ctx, int n_frames, size_t frame_stride, void **d_iq, int8_t **d_soft,
-                                      dabgpu_placement_report *report) {
-    if (!ctx || !d_iq || !d_soft || n_frames <= 0) return DABGPU_ERR_ARG;
-    if (frame_stride < size_t(NB_FRAME_SAMPLES) || (frame_stride & 1u)) return DABGPU_ERR_ARG;
-    if (size_t(n_frames) > size_t(0x7fffffff) / NB_DATA_SYMBOLS) return DABGPU_ERR_ARG;
-    DeviceGuard guard(ctx);
-    *d_iq = nullptr;
-    *d_soft = nullptr;
-    dabgpu_placement_report rep;
-    std::memset(&rep, 0, sizeof(rep));
-    const size_t iq_bytes = size_t(n_frames) * frame_stride * sizeof(float2);
-    const size_t soft_bytes = size_t(n_frames) * NB_FRAME_BITS;
-    // IQ in 1 GiB chunks; the soft bits in 256 MiB chunks: each is written beside only ~1.7 GiB of samples, so where
-    // the IQ buffer has to change domain only one or two of them cannot avoid both of its neighbours' domains
-    const size_t CH = size_t(1) << 30, CS = size_t(256) << 20;
-    auto plain = [&]() -> int {
-        if (hipMalloc(d_iq, iq_bytes) != hipSuccess) return DABGPU_ERR_NOMEM;
-        if (hipMalloc(reinterpret_cast<void **>(d_soft), soft_bytes) != hipSuccess) {
-            (void)hipFree(*d_iq);
-            *d_iq = nullptr;
-            return DABGPU_ERR_NOMEM;
-        }
-        rep.method = 0;
-        rep.setup_peak_bytes = iq_bytes + soft_bytes;
-        if (report) *report = rep;
-        return DABGPU_OK;
-    };
-    const int n_iq = int((iq_bytes + CH - 1) / CH), n_soft = int((soft_bytes + CS - 1) / CS);
-    // (nothing is gained below a few GB, and rounding to whole chunks would cost too much)
-    if (iq_bytes < 4 * CH || n_iq > 60 || n_soft > 20) return plain();
-    // what may be held during set-up: 1.2 x the buffers; a third of the spare as whole IQ-size chunks, the rest small
-    const size_t budget = size_t(1.2 * double(iq_bytes + soft_bytes));
-    const size_t need = size_t(n_iq) * CH + size_t(n_soft) * CS;
-    const size_t spare = budget > need ? budget - need : 0;
-    int n_big = n_iq + int(spare / 3 / CH);
-    int n_small = n_soft + int((spare - size_t(n_big - n_iq) * CH) / CS);
-    size_t free_b = 0, total_b = 0;
-    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    while (n_big > n_iq && size_t(n_big) * CH + size_t(n_small) * CS > free_b - free_b / 16) n_big--;
-    while (n_small > n_soft && size_t(n_big) * CH + size_t(n_small) * CS > free_b - free_b / 16) n_small--;
-    if (size_t(n_big) * CH + size_t(n_small) * CS > free_b - free_b / 16) return plain();
-    int n_total = n_big + n_small;
-    if (n_total > 70) return plain();
-    const int n_budget = n_total;                            // chunks of the 1.2 x budget; spacers (below) come after them
-    hipStream_t s = ctx->stream;
-    HIP_TRY(hipStreamSynchronize(s));
-
-    hipMemAllocationProp prop = {};
-    prop.type = hipMemAllocationTypePinned;
-    prop.location.type = hipMemLocationTypeDevice;
-    prop.location.id = ctx->device;
-    hipMemAccessDesc acc = {};
-    acc.location = prop.location;
-    acc.flags = hipMemAccessFlagsProtReadWrite;
-    constexpr int MAX_SPACERS = 100;
-    Chunks c;
-    c.reserved = size_t(n_big) * CH + size_t(n_small) * CS;
-    void *va = nullptr;
-    if (hipMemAddressReserve(&va, c.reserved, 0, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); return plain(); }
-    c.va = static_cast<char *>(va);
-    bool ok = true;
-    for (int i = 0; i < n_total && ok; i++) {
-        const size_t bytes = i < n_big ? CH : CS;
-        hipMemGenericAllocationHandle_t h;
-        if (hipMemCreate(&h, bytes, &prop, 0) != hipSuccess) { ok = false; break; }
-        if (hipMemMap(c.va + c.mapped, bytes, 0, h, 0) != hipSuccess) { (void)hipMemRelease(h); ok = false; break; }
-        c.items.push_back(Chunks::Item{h, bytes, c.mapped});
-        c.mapped += bytes;
-    }
-    if (!ok || hipMemSetAccess(c.va, c.mapped, &acc, 1) != hipSuccess) { (void)hipGetLastError(); return plain(); }
-    rep.n_chunks = n_total;
-    rep.chunk_bytes = CH;
-    rep.setup_peak_bytes = c.mapped;
-
-    // ---- which domain is every chunk in? ----
-    hipEvent_t e0 = nullptr, e1 = nullptr, ec0 = nullptr, ec1 = nullptr;
-    int rc = DABGPU_OK;
-    std::vector<int> dom(size_t(n_total), 0);
-    int n_dom = 1;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventCreate(&ec0) != hipSuccess ||
-        hipEventCreate(&ec1) != hipSuccess || dabk::launch_fill_noise(c.va, c.mapped, s) != hipSuccess)
-        rc = DABGPU_ERR_HIP;
-    if (!rc) {
-        (void)hipEventRecord(ec0, s);
-        n_dom = classify_chunks(c, s, e0, e1, dom);
-        if (n_dom < 0) { rc = DABGPU_ERR_HIP; n_dom = 1; }
-        (void)hipEventRecord(ec1, s);
-        (void)hipEventSynchronize(ec1);
-        (void)hipEventElapsedTime(&rep.classify_ms, ec0, ec1);
-    }
-    // ---- the budget may not hold what a clean placement needs: one domain with room for all the samples AND enough
-    //      memory elsewhere for the soft bits (a fresh device hands out its memory in address order, and a domain's
-    //      address ranges are tens of GB long: the whole budget can lie in one of them).  Then 1 GiB spacers are taken and
-    //      classified one by one until it does; they take part in the selection below like any other chunk, and the ones
-    //      nobody takes go back at the end of this call (what is held at the peak is reported). ----
-    int iq_domain = -1;                                        // the domain that can carry the samples alone, if any
-    if (!rc) {
-        size_t bytes_in[3] = {0, 0, 0};
-        for (int i = 0; i < n_total; i++) bytes_in[dom[size_t(i)]] += c.items[size_t(i)].bytes;
-        auto clean = [&]() {
-            int best = -1;
-            const size_t all = bytes_in[0] + bytes_in[1] + bytes_in[2];
-            for (int d = 0; d < 3; d++)
-                if (bytes_in[d] >= iq_bytes && all - bytes_in[d] >= soft_bytes && (best < 0 || bytes_in[d] > bytes_in[best])) best = d;
-            return best;
-        };
-        iq_domain = clean();
-        int ref[3] = {-1, -1, -1};
-        size_t spacer_bytes = 0;
-        for (int i = n_total - 1; i >= 0; i--) ref[dom[size_t(i)]] = i;          // a reference chunk per domain seen: its first one
-        for (int k = 0; k < MAX_SPACERS && iq_domain < 0; k++) {
-            size_t fb = 0, tb = 0;
-            if (hipMemGetInfo(&fb, &tb) != hipSuccess || fb < 2 * CH + tb / 16) break;          // leave the device some air
-            const int x = c.add_spacer(CH, prop, acc);
-            if (x < 0) break;
-            n_total++;
-            dom.push_back(0);
-            spacer_bytes += CH;
-            // same domain as a known one?  (reading the reference and writing the spacer is ~10 % slower then)
-            int d = -1;
-            for (int q = 0; q < 3 && d < 0; q++) {
-                if (ref[q] < 0) continue;
-                const int same = in_domain_of(c, ref[q], x, s, e0, e1);
-                if (same < 0) { rc = DABGPU_ERR_HIP; break; }
-                if (same) d = q;
-            }
-            if (rc) break;
-            if (d < 0) {                                           // a domain not seen before
-                d = ref[0] < 0 ? 0 : ref[1] < 0 ? 1 : ref[2] < 0 ? 2 : 0;   // (a fourth cannot happen; stay consistent)
-                if (ref[d] < 0) { ref[d] = x; n_dom++; }
-            }
-            dom[size_t(x)] = d;
-            bytes_in[d] += CH;
-            iq_domain = clean();
-        }
-        (void)hipGetLastError();
-        rep.setup_peak_bytes = c.mapped + spacer_bytes;
-        rep.n_chunks = n_total;
-    }
-    rep.n_domains = n_dom;
-    // (small chunks in lower case; spacers, 1 GiB each, follow the budget's chunks)
-    for (int i = 0; i < n_total && i < 71; i++) rep.domains[i] = char((i < n_big || i >= n_budget ? 'A' : 'a') + dom[size_t(i)]);
-
-    // ---- IQ: the domain with the most bytes first (1 GiB chunks, then 256 MiB ones); the soft bits, piece by piece:
-    //      a chunk whose domain the samples read beside that piece are not in ----
-    std::vector<int> iq_sel, soft_sel;
-    std::vector<char> used(size_t(n_total), 0);
-    size_t iq_mapped = 0, soft_mapped = 0;
-    if (!rc) {
-        size_t bytes_in[3] = {0, 0, 0};
-        for (int i = 0; i < n_total; i++) bytes_in[dom[size_t(i)]] += c.items[size_t(i)].bytes;
-        int order[3] = {0, 1, 2};
-        std::sort(order, order + 3, [&](int x, int y) {
-            if ((x == iq_domain) != (y == iq_domain)) return x == iq_domain;
-            return bytes_in[x] != bytes_in[y] ? bytes_in[x] > bytes_in[y] : x < y;
-        });
-        auto is_big = [&](int i) { return i < n_big || i >= n_budget; };
-        // leave the other domains what the soft bits need of them whenever the first domain can carry the samples alone
-        for (int k = 0; k < 3 && iq_mapped < iq_bytes; k++)
-            for (int pass = 0; pass < 2 && iq_mapped < iq_bytes; pass++)          // pass 0: 1 GiB chunks, pass 1: 256 MiB ones
-                for (int i = 0; i < n_total && iq_mapped < iq_bytes; i++) {
-                    if (is_big(i) != (pass == 0) || used[size_t(i)] || dom[size_t(i)] != order[k]) continue;
-                    if (pass == 0 && iq_bytes - iq_mapped < CH && bytes_in[order[k]] > 0) {
-                        // less than a whole big chunk is missing: small chunks of this domain first, if there are enough
-                        size_t small_left = 0;
-                        for (int j = n_big; j < n_budget; j++) if (!used[size_t(j)] && dom[size_t(j)] == order[k]) small_left += CS;
-                        if (small_left >= iq_bytes - iq_mapped) break;
-                    }
-                    iq_sel.push_back(i);
-                    used[size_t(i)] = 1;
-                    iq_mapped += c.items[size_t(i)].bytes;
-                }
-        // domain of the samples at byte offset x of the IQ buffer
-        std::vector<size_t> iq_end;
-        { size_t e = 0; for (int i : iq_sel) { e += c.items[size_t(i)].bytes; iq_end.push_back(e); } }
-        auto iq_bytes_by_domain = [&](double lo, double hi, double w[3]) {
-            w[0] = w[1] = w[2] = 0.0;
-            size_t begin = 0;
-            for (size_t k = 0; k < iq_sel.size(); k++) {
-                const double a0 = std::max(lo, double(begin)), a1 = std::min(hi, double(iq_end[k]));
-                if (a1 > a0) w[dom[size_t(iq_sel[k])]] += a1 - a0;
-                begin = iq_end[k];
-            }
-        };
-        const double iq_per_soft = double(frame_stride * sizeof(float2)) / double(NB_FRAME_BITS);
-        const double slack = 1.5 * double(CH);                // samples of the ~1000 frames in flight
-        double shared = 0.0;
-        while (soft_mapped < soft_bytes) {
-            int best = -1;
-            double best_cost = 0.0;
-            for (int i = 0; i < n_total; i++) {
-                if (used[size_t(i)]) continue;
-                const size_t sz = c.items[size_t(i)].bytes;
-                double w[3];
-                iq_bytes_by_domain(double(soft_mapped) * iq_per_soft - slack, double(std::min(soft_bytes, soft_mapped + sz)) * iq_per_soft + slack, w);
-                const double tot = w[0] + w[1] + w[2];
-                const double cost = tot > 0.0 ? w[dom[size_t(i)]] / tot : 0.0;
-                // the least overlap wins; between equals a small chunk (a big one is kept for where it is needed)
-                if (best < 0 || cost < best_cost - 1e-9 || (cost < best_cost + 1e-9 && sz < c.items[size_t(best)].bytes)) { best = i; best_cost = cost; }
-            }
-            if (best < 0) { rc = DABGPU_ERR_NOMEM; break; }
-            soft_sel.push_back(best);
-            used[size_t(best)] = 1;
-            const size_t sz = std::min(c.items[size_t(best)].bytes, soft_bytes - soft_mapped);
-            shared += best_cost * double(sz);
-            soft_mapped += c.items[size_t(best)].bytes;
-        }
-        rep.conflicts = int(1000.0 * shared / double(soft_bytes) + 0.5);   // per mille of the soft bits written beside same-domain reads
-        rep.iq_chunks = int(iq_sel.size());
-        rep.soft_chunks = int(soft_sel.size());
-        for (size_t k = 0; k < iq_sel.size() && k < 71; k++) rep.iq_map[k] = char((iq_sel[k] < n_big ? 'A' : 'a') + dom[size_t(iq_sel[k])]);
-        for (size_t k = 0; k < soft_sel.size() && k < 23; k++)
-            rep.soft_map[k] = char((soft_sel[k] < n_big || soft_sel[k] >= n_budget ? 'A' : 'a') + dom[size_t(soft_sel[k])]);
-    }
-    // ---- final mappings; the chunks nobody took go back ----
-    dabgpu_ctx::Mapped m_iq{nullptr, iq_mapped, 0, {}}, m_soft{nullptr, soft_mapped, 0, {}};
-    if (!rc) {
-        (void)hipStreamSynchronize(s);
-        if (!c.unmap_all()) rc = DABGPU_ERR_HIP;
-    }
-    auto map_over = [&](dabgpu_ctx::Mapped &m, const std::vector<int> &sel) -> int {
-        if (hipMemAddressReserve(&m.va, m.bytes, 0, nullptr, 0) != hipSuccess) return DABGPU_ERR_NOMEM;
-        size_t off = 0;
-        for (size_t k = 0; k < sel.size(); k++) {
-            Chunks::Item &it = c.items[size_t(sel[k])];
-            if (hipMemMap(static_cast<char *>(m.va) + off, it.bytes, 0, it.h, 0) != hipSuccess) return DABGPU_ERR_HIP;
-            m.handles.push_back(it.h);
-            m.sizes.push_back(it.bytes);
-            it.h = nullptr;                                    // owned by the mapping from here on
-            off += it.bytes;
-            m.chunk = off;                                     // bytes mapped so far
-        }
-        return hipMemSetAccess(m.va, m.bytes, &acc, 1) == hipSuccess ? DABGPU_OK : DABGPU_ERR_HIP;
-    };
-    if (!rc) rc = map_over(m_iq, iq_sel);
-    if (!rc) rc = map_over(m_soft, soft_sel);
-    if (rc) {
-        for (dabgpu_ctx::Mapped *m : {&m_iq, &m_soft}) m->release();
-    } else {
-        ctx->mapped.push_back(m_iq);
-        ctx->mapped.push_back(m_soft);
-        *d_iq = m_iq.va;
-        *d_soft = static_cast<int8_t *>(m_soft.va);
-        rep.method = 1;
-        // one timed front-end launch on the pair (the IQ buffer still holds the classification's noise)
-        void *d_fo = nullptr, *d_cyc = nullptr;
-        const size_t fo_bytes = sizeof(float) * size_t(n_frames), cyc_bytes = size_t(n_frames) * NB_FRAME_SYMBOLS * sizeof(float2);
-        if (hipMalloc(&d_fo, fo_bytes) == hipSuccess && hipMalloc(&d_cyc, cyc_bytes) == hipSuccess &&
-            hipMemsetAsync(d_fo, 0, fo_bytes, s) == hipSuccess) {
-            const bool was_timing = ctx->timing;
-            ctx->timing = false;
-            const unsigned long long *keep = ctx->d_keep;
-            ctx->d_keep = nullptr;
-            int prc = DABGPU_OK;
-            for (int r = 0; r < 3 && !prc; r++) {
-                if (r == 1) (void)hipEventRecord(e0, s);
-                prc = dabgpu_ofdm_demod_frames_dev(ctx, static_cast<char *>(*d_iq) + size_t(NB_NULL_PERIOD) * sizeof(float2), frame_stride,
-                                                   n_frames, static_cast<const float *>(d_fo), *d_soft, d_cyc, nullptr, s);
-            }
-            float ms = 0.f;
-            if (!prc && hipEventRecord(e1, s) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
-                hipEventElapsedTime(&ms, e0, e1) == hipSuccess)
-                rep.front_end_ms = 0.5f * ms;
-            ctx->timing = was_timing;
-            ctx->d_keep = keep;
-        }
-        (void)hipStreamSynchronize(s);
-        if (d_fo) (void)hipFree(d_fo);
-        if (d_cyc) (void)hipFree(d_cyc);
-        (void)hipGetLastError();
-        // check of the result, independent of the classification: the mover reads the first GiB of the samples and
-        // writes (a) the start of the soft-bit buffer, (b) into the samples' own buffer two GiB further on
-        if (iq_mapped >= 4 * CH) {
-            const size_t out_b = std::min(soft_mapped, CH / 6);
-            char *iq0 = static_cast<char *>(*d_iq);
-            float ta = 1e30f, tb = 1e30f;
-            for (int r = 0; r < 3; r++) {                          // alternated: drift hits both alike
-                const float a = mover_ms(iq0, CH, *d_soft, out_b, s, e0, e1);
-                const float b = mover_ms(iq0, CH, iq0 + 2 * CH, out_b, s, e0, e1);
-                if (a > 0.f) ta = std::min(ta, a);
-                if (b > 0.f) tb = std::min(tb, b);
-            }
-            if (ta < 1e29f && tb < 1e29f) rep.pair_over_same_domain = ta / tb;
-            // (the mover left noise-like words at the start of the soft-bit buffer and in the samples: both are the
-            // caller's to fill; the classification's noise is what was there before)
-        }
-    }
-    for (hipEvent_t e : {e0, e1, ec0, ec1}) if (e) (void)hipEventDestroy(e);
-    if (report) *report = rep;
-    return rc;                                               // (~Chunks releases the chunks nobody took)
-}
-
-// A buffer that a launch WRITES while it reads [ref, ref + ref_bytes), both walked front to back in step: physical
-// chunks (1.2 x bytes at most), their domains among themselves, the domain of every GiB of `ref` against one
-// representative chunk per domain, then every piece of the new buffer over a chunk whose domain the part of `ref` read
-// beside it is not in.  probe_ms: [0] mover time on the result (first GiB of ref -> start of the buffer), [1] per mille of
-// the buffer left beside same-domain reads, [2] ms spent classifying.
-static int alloc_apart(dabgpu_ctx *ctx, size_t bytes, const void *ref, size_t ref_bytes, void **out, float *probe_ms) {
-    if (probe_ms) probe_ms[0] = probe_ms[1] = probe_ms[2] = 0.f;
-    *out = nullptr;
-    auto plain = [&]() { return hipMalloc(out, std::max<size_t>(bytes, 16)) == hipSuccess ? DABGPU_OK : DABGPU_ERR_NOMEM; };
-    if (!ref || ref_bytes < PLACE_MIN_BYTES || bytes < PLACE_MIN_BYTES) return plain();
-    const size_t CH = bytes >= (size_t(8) << 30) ? size_t(1) << 30 : size_t(256) << 20;
-    const int n_need = int((bytes + CH - 1) / CH);
-    int n_total = std::max(n_need + 1, int(1.2 * double(bytes) / double(CH)));
-    size_t free_b = 0, total_b = 0;
-    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    while (n_total > n_need && size_t(n_total) * CH > free_b - free_b / 16) n_total--;
-    if (n_total > 70 || size_t(n_total) * CH > free_b - free_b / 16) return plain();
-    hipStream_t s = ctx->stream;
-    hipMemAllocationProp prop = {};
-    prop.type = hipMemAllocationTypePinned;
-    prop.location.type = hipMemLocationTypeDevice;
-    prop.location.id = ctx->device;
-    hipMemAccessDesc acc = {};
-    acc.location = prop.location;
-    acc.flags = hipMemAccessFlagsProtReadWrite;
-    constexpr int MAX_SPACERS = 100;                        // (see dabgpu_alloc_frame_buffers_placed: the one-domain case)
-    Chunks c;
-    c.reserved = size_t(n_total) * CH;
-    void *va = nullptr;
-    if (hipMemAddressReserve(&va, c.reserved, 0, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); return plain(); }
-    c.va = static_cast<char *>(va);
-    bool ok = true;
-    for (int i = 0; i < n_total && ok; i++) {
-        hipMemGenericAllocationHandle_t h;
-        if (hipMemCreate(&h, CH, &prop, 0) != hipSuccess) { ok = false; break; }
-        if (hipMemMap(c.va + c.mapped, CH, 0, h, 0) != hipSuccess) { (void)hipMemRelease(h); ok = false; break; }
-        c.items.push_back(Chunks::Item{h, CH, c.mapped});
-        c.mapped += CH;
-    }
-    if (!ok || hipMemSetAccess(c.va, c.mapped, &acc, 1) != hipSuccess) { (void)hipGetLastError(); return plain(); }
-    hipEvent_t e0 = nullptr, e1 = nullptr, ec0 = nullptr, ec1 = nullptr;
-    int rc = DABGPU_OK;
-    std::vector<int> dom, sel;
-    double shared = 0.0;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventCreate(&ec0) != hipSuccess ||
-        hipEventCreate(&ec1) != hipSuccess || dabk::launch_fill_noise(c.va, c.mapped, s) != hipSuccess)
-        rc = DABGPU_ERR_HIP;
-    if (!rc) {
-        (void)hipEventRecord(ec0, s);
-        int n_dom = classify_chunks(c, s, e0, e1, dom);
-        if (n_dom < 0) { rc = DABGPU_ERR_HIP; n_dom = 1; }
-        // the domain of every piece of ref: the representative it is slow against (none: a domain no chunk is in)
-        const size_t RP = size_t(1) << 30;
-        const int n_ref = int((ref_bytes + RP - 1) / RP);
-        std::vector<int> ref_dom(size_t(n_ref), -1), repr(3, -1);
-        for (int i = n_total - 1; i >= 0 && !rc; i--) repr[size_t(dom[size_t(i)])] = i;
-        for (int r = 0; r < n_ref && !rc; r++) {
-            const char *in = static_cast<const char *>(ref) + size_t(r) * RP;
-            const size_t in_b = std::min(RP, ref_bytes - size_t(r) * RP);
-            if (in_b < (size_t(64) << 20)) { ref_dom[size_t(r)] = r > 0 ? ref_dom[size_t(r) - 1] : -1; continue; }
-            float t[3] = {0.f, 0.f, 0.f}, lo = 1e30f, hi = 0.f;
-            for (int d = 0; d < n_dom; d++) {
-                t[d] = mover_ms(in, in_b, c.at(repr[size_t(d)]), std::min(CH, in_b / 6), s, e0, e1);
-                if (t[d] < 0.f) { rc = DABGPU_ERR_HIP; break; }
-                lo = std::min(lo, t[d]);
-                hi = std::max(hi, t[d]);
-            }
-            if (rc) break;
-            if (n_dom > 1 && hi > 1.04f * lo) {
-                for (int d = 0; d < n_dom; d++) if (t[d] == hi) ref_dom[size_t(r)] = d;
-            } else if (n_dom == 1) {
-                // one domain among the chunks: is ref in it?  chunk 0 against itself is the same-domain time
-                const float self = pair_ms(c, 0, 0, s, e0, e1) * float(double(in_b) / double(CH));
-                if (t[0] > 0.97f * self) ref_dom[size_t(r)] = 0;
-            }
-        }
-        // every piece of the buffer: the chunk least beside its own domain.  Where the 1.2 x budget leaves more than a
-        // twentieth of the buffer beside same-domain reads (all of it, when budget and reference lie in one domain),
-        // 1 GiB-class spacers are taken four at a time, placed among the known domains (or given a new one), and the
-        // selection is repeated; the ones nobody takes go back when this call returns.
-        const double ratio = double(ref_bytes) / double(bytes);
-        int spacers = 0;
-      select_again:
-        std::vector<char> used(size_t(n_total), 0);
-        sel.clear();
-        shared = 0.0;
-        for (int m = 0; m < n_need && !rc; m++) {
-            const double lo_b = double(m) * double(CH) * ratio - 1.5 * double(RP), hi_b = double(m + 1) * double(CH) * ratio + 1.5 * double(RP);
-            double w[3] = {0.0, 0.0, 0.0}, tot = 0.0;
-            for (int r = 0; r < n_ref; r++) {
-                const double a0 = std::max(lo_b, double(r) * double(RP)), a1 = std::min(hi_b, std::min(double(ref_bytes), double(r + 1) * double(RP)));
-                if (a1 <= a0) continue;
-                tot += a1 - a0;
-                if (ref_dom[size_t(r)] >= 0) w[ref_dom[size_t(r)]] += a1 - a0;
-            }
-            int best = -1;
-            for (int i = 0; i < n_total; i++) {
-                if (used[size_t(i)]) continue;
-                if (best < 0 || w[dom[size_t(i)]] < w[dom[size_t(best)]] - 1e-9) best = i;
-            }
-            sel.push_back(best);
-            used[size_t(best)] = 1;
-            if (tot > 0.0) shared += w[dom[size_t(best)]] / tot;
-        }
-        if (!rc && shared > 0.05 * double(n_need) && spacers < MAX_SPACERS) {
-            int added = 0;
-            for (int k = 0; k < 4 && spacers < MAX_SPACERS; k++) {
-                size_t fb = 0, tb = 0;
-                if (hipMemGetInfo(&fb, &tb) != hipSuccess || fb < 2 * CH + tb / 16) break;
-                const int x = c.add_spacer(CH, prop, acc);
-                if (x < 0) break;
-                n_total++;
-                dom.push_back(0);
-                spacers++;
-                added++;
-                int d = -1;
-                for (int q = 0; q < n_dom && d < 0; q++) {
-                    const int same = in_domain_of(c, repr[size_t(q)], x, s, e0, e1);
-                    if (same < 0) { rc = DABGPU_ERR_HIP; break; }
-                    if (same) d = q;
-                }
-                if (rc) break;
-                if (d < 0) {
-                    if (n_dom < 3) { d = n_dom++; repr[size_t(d)] = x; }
-                    else d = 0;
-                    // a domain no chunk was in before: are pieces of the reference in it?  (those that matched none)
-                    for (int r = 0; r < n_ref && d == n_dom - 1 && repr[size_t(d)] == x; r++) {
-                        if (ref_dom[size_t(r)] >= 0) continue;
-                        const size_t in_b = std::min(RP, ref_bytes - size_t(r) * RP);
-                        if (in_b < (size_t(64) << 20)) { ref_dom[size_t(r)] = r > 0 ? ref_dom[size_t(r) - 1] : -1; continue; }
-                        const char *in = static_cast<const char *>(ref) + size_t(r) * RP;
-                        const float tn = mover_ms(in, in_b, c.at(x), std::min(CH, in_b / 6), s, e0, e1);
-                        const float to = mover_ms(in, in_b, c.at(repr[0]), std::min(CH, in_b / 6), s, e0, e1);   // (not its domain: it matched none)
-                        if (tn < 0.f || to < 0.f) { rc = DABGPU_ERR_HIP; break; }
-                        if (tn > 1.04f * to) ref_dom[size_t(r)] = d;
-                    }
-                }
-                dom[size_t(x)] = d;
-            }
-            (void)hipGetLastError();
-            if (!rc && added > 0) goto select_again;
-        }
-        (void)hipEventRecord(ec1, s);
-        (void)hipEventSynchronize(ec1);
-        float cms = 0.f;
-        (void)hipEventElapsedTime(&cms, ec0, ec1);
-        if (probe_ms) { probe_ms[1] = float(1000.0 * shared / double(n_need)); probe_ms[2] = cms; }
-    }
-    dabgpu_ctx::Mapped m{nullptr, CH * size_t(n_need), 0, {}};
-    if (!rc) {
-        (void)hipStreamSynchronize(s);
-        if (!c.unmap_all()) rc = DABGPU_ERR_HIP;
-    }
-    if (!rc && hipMemAddressReserve(&m.va, m.bytes, 0, nullptr, 0) != hipSuccess) rc = DABGPU_ERR_NOMEM;
-    for (size_t k = 0; k < sel.size() && !rc; k++) {
-        Chunks::Item &it = c.items[size_t(sel[k])];
-        if (hipMemMap(static_cast<char *>(m.va) + CH * k, CH, 0, it.h, 0) != hipSuccess) { rc = DABGPU_ERR_HIP; break; }
-        m.handles.push_back(it.h);
-        m.sizes.push_back(CH);
-        it.h = nullptr;
-        m.chunk = CH * (k + 1);
-    }
-    if (!rc && hipMemSetAccess(m.va, m.bytes, &acc, 1) != hipSuccess) rc = DABGPU_ERR_HIP;
-    if (rc) {
-        m.release();
-    } else {
-        ctx->mapped.push_back(m);
-        *out = m.va;
-        if (probe_ms) {
-            const size_t in_b = std::min(ref_bytes, size_t(1) << 30);
-            probe_ms[0] = mover_ms(ref, in_b, m.va, std::min(m.bytes, in_b / 6), s, e0, e1);
-        }
-    }
-    for (hipEvent_t e : {e0, e1, ec0, ec1}) if (e) (void)hipEventDestroy(e);
-    return rc;
-}
-
-int dabgpu_alloc_frame_buffers(dabgpu_ctx *ctx, int n_frames, size_t frame_stride, int candidates, void **d_iq,
-                               int8_t **d_soft, float *probe_ms, int *kept) {
-    if (!ctx || !d_iq || !d_soft || n_frames <= 0 || candidates < 1 || candidates > 8) return DABGPU_ERR_ARG;
-    if (frame_stride < size_t(NB_FRAME_SAMPLES) || (frame_stride & 1u)) return DABGPU_ERR_ARG;
-    if (size_t(n_frames) > size_t(0x7fffffff) / NB_DATA_SYMBOLS) return DABGPU_ERR_ARG;
-    DeviceGuard guard(ctx);
-    *d_iq = nullptr;
-    *d_soft = nullptr;
-    const size_t iq_bytes = size_t(n_frames) * frame_stride * sizeof(float2);
-    const size_t soft_bytes = size_t(n_frames) * NB_FRAME_BITS;
-    size_t free_b = 0, total_b = 0;
-    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    int K = candidates;
-    while (K > 1 && double(K) * double(iq_bytes + soft_bytes) > 0.6 * double(free_b)) K--;
-    hipStream_t s = ctx->stream;
-    std::vector<void *> iq(size_t(K), nullptr), soft(size_t(K), nullptr);
-    void *d_fo = nullptr, *d_cyc = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    std::vector<float> table(size_t(K) * K, 0.f);
-    int rc = DABGPU_OK, bi = 0, bj = 0;
-    do {
-        for (int k = 0; k < K && !rc; k++)
-            if (hipMalloc(&iq[k], iq_bytes) != hipSuccess || hipMalloc(&soft[k], soft_bytes) != hipSuccess) rc = DABGPU_ERR_NOMEM;
-        if (rc) break;
-        if (K == 1) break;
-        const size_t fo_bytes = sizeof(float) * size_t(n_frames), cyc_bytes = size_t(n_frames) * NB_FRAME_SYMBOLS * sizeof(float2);
-        if (hipMalloc(&d_fo, fo_bytes) != hipSuccess || hipMalloc(&d_cyc, cyc_bytes) != hipSuccess) { rc = DABGPU_ERR_NOMEM; break; }
-        if (hipMemsetAsync(d_fo, 0, fo_bytes, s) != hipSuccess || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
-            rc = DABGPU_ERR_HIP;
-            break;
-        }
-        for (int k = 0; k < K && !rc; k++)
-            if (dabk::launch_fill_noise(iq[k], iq_bytes, s) != hipSuccess) rc = DABGPU_ERR_HIP;
-        if (rc) break;
-        const bool was_timing = ctx->timing;
-        ctx->timing = false;                                   // the probe launches are not the caller's measurements
-        const unsigned long long *keep = ctx->d_keep;
-        ctx->d_keep = nullptr;                                 // whole frames, whatever selection is active
-        float best = -1.f;
-        for (int i = 0; i < K && !rc; i++)
-            for (int j = 0; j < K && !rc; j++) {
-                for (int rep = 0; rep < 3 && !rc; rep++) {
-                    if (rep == 1 && hipEventRecord(e0, s) != hipSuccess) rc = DABGPU_ERR_HIP;
-                    if (!rc)
-                        rc = dabgpu_ofdm_demod_frames_dev(ctx, static_cast<char *>(iq[i]) + size_t(NB_NULL_PERIOD) * sizeof(float2),
-                                                          frame_stride, n_frames, static_cast<const float *>(d_fo),
-                                                          static_cast<int8_t *>(soft[j]), d_cyc, nullptr, s);
-                }
-                float ms = 0.f;
-                if (!rc && (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
-                            hipEventElapsedTime(&ms, e0, e1) != hipSuccess))
-                    rc = DABGPU_ERR_HIP;
-                table[size_t(i) * K + j] = ms * 0.5f;
-                if (!rc && (best < 0.f || ms < best)) { best = ms; bi = i; bj = j; }
-            }
-        ctx->timing = was_timing;
-        ctx->d_keep = keep;
-    } while (0);
-    (void)hipStreamSynchronize(s);
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
-    if (d_fo) (void)hipFree(d_fo);
-    if (d_cyc) (void)hipFree(d_cyc);
-    for (int k = 0; k < K; k++) {
-        if (iq[k] && (rc || k != bi)) (void)hipFree(iq[k]);
-        if (soft[k] && (rc || k != bj)) (void)hipFree(soft[k]);
-    }
-    if (rc) return rc;
-    *d_iq = iq[bi];
-    *d_soft = static_cast<int8_t *>(soft[bj]);
-    if (probe_ms)
-        for (int i = 0; i < candidates; i++)
-            for (int j = 0; j < candidates; j++)
-                probe_ms[size_t(i) * candidates + j] = (i < K && j < K) ? table[size_t(i) * K + j] : 0.f;
-    if (kept) { kept[0] = bi; kept[1] = bj; }
-    return DABGPU_OK;
-}
-
-int dabgpu_device_alloc_apart(dabgpu_ctx *ctx, size_t bytes, const void *d_other, size_t other_bytes, void **d_out,
-                              float *probe_ms) {
-    if (!ctx || !d_out || bytes == 0) return DABGPU_ERR_ARG;
-    DeviceGuard guard(ctx);
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return alloc_apart(ctx, bytes, d_other, other_bytes, d_out, probe_ms);
-}
-
-int dabgpu_device_free(dabgpu_ctx *ctx, void *d_ptr) {
-    if (!ctx) return DABGPU_ERR_ARG;
-    DeviceGuard guard(ctx);
-    HIP_TRY(hipDeviceSynchronize());
-    if (d_ptr && !release_mapped(ctx, d_ptr)) HIP_TRY(hipFree(d_ptr));
-    return DABGPU_OK;
-}
-
 int dabgpu_sync(dabgpu_ctx *ctx) {
     if (!ctx) return DABGPU_ERR_ARG;
     DeviceGuard guard(ctx);
@@ -1358,10 +439,24 @@ int dabgpu_ofdm_demod_frames_dd_dev(dabgpu_ctx *ctx, const void *d_iq, size_t fr
     return DABGPU_OK;
 }
 
+int dabgpu_mover_frames_dev(dabgpu_ctx *ctx, const void *d_iq, size_t frame_stride, int n_frames, int8_t *d_soft,
+                            int with_prefixes, void *stream) {
+    if (!ctx || !d_soft) return DABGPU_ERR_ARG;
+    DeviceGuard guard(ctx);
+    int rc = check_iq(d_iq, frame_stride, n_frames);
+    if (rc) return rc;
+    if (reinterpret_cast<uintptr_t>(d_soft) & 15u) return DABGPU_ERR_ARG;
+    if (n_frames == 0) return DABGPU_OK;
+    const RunPlan plan = plan_runs(ctx, n_frames, NB_DATA_SYMBOLS);
+    HIP_TRY(dabk::launch_geometry_mover(static_cast<const float2 *>(d_iq), frame_stride, n_frames, d_soft, plan.uncut_frames,
+                                        plan.parts, with_prefixes != 0, pick_stream(ctx, stream)));
+    return DABGPU_OK;
+}
+
 int dabgpu_ofdm_set_soft_selection(dabgpu_ctx *ctx, const dabgpu_bit_range *ranges, int n_ranges) {
     if (!ctx || n_ranges < 0 || (n_ranges > 0 && !ranges)) return DABGPU_ERR_ARG;
     DeviceGuard guard(ctx);
-    if (n_ranges == 0) { ctx->d_keep = nullptr; ctx->keep_ranges.clear(); return DABGPU_OK; }
+    if (n_ranges == 0) { ctx->d_keep = nullptr; ctx->keep_ranges.clear(); ctx->keep_symbols = NB_DATA_SYMBOLS; return DABGPU_OK; }
     constexpr int CHUNKS_PER_SYMBOL = NB_SYM_BITS / 16;          // 192 = 3 words
     std::vector<unsigned long long> words(size_t(NB_DATA_SYMBOLS) * 3, 0ull);
     for (int r = 0; r < n_ranges; r++) {
@@ -1387,6 +482,9 @@ int dabgpu_ofdm_set_soft_selection(dabgpu_ctx *ctx, const dabgpu_bit_range *rang
     }
     ctx->keep_tables.push_back(d);
     ctx->d_keep = static_cast<const unsigned long long *>(d);
+    ctx->keep_symbols = 0;
+    for (int l = 0; l < NB_DATA_SYMBOLS; l++)
+        if (words[size_t(l) * 3] | words[size_t(l) * 3 + 1] | words[size_t(l) * 3 + 2]) ctx->keep_symbols++;
     // the same selection as merged byte runs, for the host-pointer call's copy-back
     ctx->keep_ranges.clear();
     for (int c = 0; c < NB_FRAME_BITS / 16; c++) {
@@ -1470,19 +568,23 @@ static_assert(offsetof(dabgpu_stream_state, next_frame_start) == offsetof(dabk::
 
 // The stream states are read and written by launches on whatever stream the caller passed: remember the most recent
 // one, so that the host-side accessors can wait for exactly that work.
-static int note_state_use(dabgpu_ctx *ctx, hipStream_t s) {
+}  // extern "C"
+namespace dabapi {
+int note_state_use(dabgpu_ctx *ctx, hipStream_t s) {
     if (!ctx->ev_states && hipEventCreateWithFlags(&ctx->ev_states, hipEventDisableTiming) != hipSuccess) return DABGPU_ERR_HIP;
     HIP_TRY(hipEventRecord(ctx->ev_states, s));
     ctx->ev_states_pending = true;
     return DABGPU_OK;
 }
-static int wait_state_use(dabgpu_ctx *ctx) {
+int wait_state_use(dabgpu_ctx *ctx) {
     if (ctx->ev_states_pending) {
         HIP_TRY(hipEventSynchronize(ctx->ev_states));
         ctx->ev_states_pending = false;
     }
     return DABGPU_OK;
 }
+}  // namespace dabapi
+extern "C" {
 
 int dabgpu_streams_reset(dabgpu_ctx *ctx, int n_streams) {
     if (!ctx || n_streams < 0) return DABGPU_ERR_ARG;
@@ -1518,7 +620,9 @@ int dabgpu_set_stream_offsets(dabgpu_ctx *ctx, int stream_index, const float *fi
     return DABGPU_OK;
 }
 
-static void stats_of(const dabk::StreamState &st, dabgpu_stats *out) {
+}  // extern "C"
+namespace dabapi {
+void stats_of(const dabk::StreamState &st, dabgpu_stats *out) {
     // READING_SYMBOLS / FINDING_NULL_POWER_DIP (a tracked stream that lost every frame of a call is searching again)
     out->state = (st.total_frames_read > 0 && !(st.tracking == 0 && st.next_frame_start != 0.0)) ? 4 : 0;
     out->fine_freq_offset = st.fine_freq_offset;
@@ -1533,7 +637,11 @@ static void stats_of(const dabk::StreamState &st, dabgpu_stats *out) {
     out->next_frame_start = st.next_frame_start;
     out->drift = st.drift;
     out->last_peak_to_mean = st.last_peak_to_mean;
+    out->loop_gated = st.loop_gated;
+    out->reserved = 0;
 }
+}  // namespace dabapi
+extern "C" {
 
 int dabgpu_get_stats(dabgpu_ctx *ctx, int stream_index, dabgpu_stats *out) {
     if (!ctx || !out || stream_index < 0 || stream_index >= ctx->n_states) return DABGPU_ERR_ARG;
@@ -1553,6 +661,12 @@ int dabgpu_set_stream_loop(dabgpu_ctx *ctx, float signal_update_beta, float thr_
     ctx->signal_beta = signal_update_beta;
     ctx->thr_null_start = thr_null_start;
     ctx->loop_dd = decision_directed != 0;
+    return DABGPU_OK;
+}
+
+int dabgpu_set_loop_gate(dabgpu_ctx *ctx, float dd_gate) {
+    if (!ctx || !(dd_gate >= 0.f && dd_gate <= 1000.f)) return DABGPU_ERR_ARG;
+    ctx->dd_gate = dd_gate;
     return DABGPU_OK;
 }
 
@@ -1596,7 +710,8 @@ int dabgpu_ofdm_demod_streams_dev(dabgpu_ctx *ctx, const void *d_iq, size_t fram
         HIP_TRY(dabk::launch_ofdm_demod(tab, a, plan.parts, s));
     }
     HIP_TRY(dabk::launch_stream_update(ctx->d_states, dd ? a.dd4 : a.cyc, a.iq, frame_stride, n_streams, frames_per_stream,
-                                       fine_freq_update_beta, ctx->thr_null_start, ctx->signal_beta, dd ? 1 : 0, s));
+                                       fine_freq_update_beta, ctx->thr_null_start, ctx->signal_beta, dd ? 1 : 0, ctx->dd_gate,
+                                       256 * ((a.keep && !a.dqpsk) ? ctx->keep_symbols : NB_DATA_SYMBOLS), s));
     return note_state_use(ctx, s);
 }
 
@@ -1855,6 +970,7 @@ void dabgpu_track_default_cfg(dabgpu_track_cfg *cfg) {
     cfg->max_coarse_carriers = 204;
     cfg->decision_directed = 1;
     cfg->auto_acquire = 0;
+    cfg->dd_gate = 8.0f;
 }
 
 static int track_cfg(const dabgpu_track_cfg *cfg, dabgpu_track_cfg &c) {
@@ -1863,7 +979,7 @@ static int track_cfg(const dabgpu_track_cfg *cfg, dabgpu_track_cfg &c) {
     if (!unit(c.fine_freq_update_beta) || !unit(c.signal_update_beta) || !unit(c.thr_null_start) || !unit(c.drift_beta) ||
         !unit(c.coarse_freq_slow_beta) || !peak_rule_ok(c.impulse_peak_distance_probability, c.first_path_rel) ||
         !(c.min_peak_to_mean >= 0.f) || c.timing_margin < 0 || c.timing_margin > NB_CP || c.max_coarse_carriers < 0 ||
-        c.max_coarse_carriers > 1023)
+        c.max_coarse_carriers > 1023 || !(c.dd_gate >= 0.f && c.dd_gate <= 1000.f) || c.reserved != 0)
         return DABGPU_ERR_ARG;
     return DABGPU_OK;
 }
@@ -1954,6 +1070,8 @@ static int tracked_launches(dabgpu_ctx *ctx, dabk::StreamState *states, const vo
     u.thr_null_start = c.thr_null_start;
     u.fixed_start = fixed_start;
     u.counts = d_counts;
+    u.dd_gate = c.dd_gate;
+    u.dd_terms_per_frame = 256 * ((a.keep && !a.dqpsk) ? ctx->keep_symbols : NB_DATA_SYMBOLS);
     // ... and their tracking starts from what the acquisition found (marked 2; the update launch makes it 1)
     if (auto_acq)
         HIP_TRY(dabk::launch_track_start(states, t.out, d_counts, n_streams, max_frames, advance, 1, s));
@@ -2047,619 +1165,6 @@ int dabgpu_ofdm_demod_stream_frame(dabgpu_ctx *ctx, int stream_index, const floa
     result->flags = fr.flags;
     result->reserved = 0;
     stats_of(hs, &result->stats);
-    return DABGPU_OK;
-}
-
-// ---------------------------------------------------------------------------- FIC
-int dabgpu_fic_decode_dev(dabgpu_ctx *ctx, const int8_t *d_soft, size_t soft_stride, int n_frames,
-                          uint8_t *d_fib, uint8_t *d_crc_ok, void *stream) {
-    if (!ctx || !d_soft || !d_fib || !d_crc_ok || n_frames < 0) return DABGPU_ERR_ARG;
-    DeviceGuard guard(ctx);
-    if (n_frames > 1 && soft_stride < size_t(NB_FIC_BITS)) return DABGPU_ERR_ARG;
-    if (n_frames == 0) return DABGPU_OK;
-    hipStream_t s = pick_stream(ctx, stream);
-    ScopedTimer tm(ctx, 1, s);
-    dabk::LaneScratch lsc{};
-    int lrc;
-    if (use_lane(ctx, ctx->fic.prof.nsteps, n_frames * NB_FIC_GROUPS, s, &lsc, &lrc)) {
-        HIP_TRY(dabk::launch_fic_decode_lane(ctx->fic.tables(true), ctx->fic.lane_tables(), d_soft, soft_stride, n_frames,
-                                             lsc, d_fib, d_crc_ok, s));
-        return DABGPU_OK;
-    }
-    if (lrc) return lrc;
-    HIP_TRY(dabk::launch_fic_decode(ctx->fic.tables(true), d_soft, soft_stride, n_frames, d_fib, d_crc_ok, s));
-    return DABGPU_OK;
-}
-
-int dabgpu_fic_decode(dabgpu_ctx *ctx, const int8_t *soft, size_t soft_stride, int n_frames, uint8_t *fib,
-                      uint8_t *crc_ok) {
-    if (!ctx || !soft || !fib || !crc_ok || n_frames < 0) return DABGPU_ERR_ARG;
-    DeviceGuard guard(ctx);
-    if (n_frames == 0) return DABGPU_OK;
-    void *d_soft, *d_fib, *d_ok;
-    int rc;
-    const size_t nb_soft = size_t(n_frames - 1) * soft_stride + NB_FIC_BITS;
-    if ((rc = stage(ctx, 1, nb_soft, &d_soft))) return rc;
-    if ((rc = stage(ctx, 3, size_t(n_frames) * NB_FIBS * 32, &d_fib))) return rc;
-    if ((rc = stage(ctx, 2, size_t(n_frames) * NB_FIBS, &d_ok))) return rc;
-    hipStream_t s = ctx->stream;
-    HIP_TRY(hipMemcpyAsync(d_soft, soft, nb_soft, hipMemcpyHostToDevice, s));
-    rc = dabgpu_fic_decode_dev(ctx, static_cast<const int8_t *>(d_soft), soft_stride, n_frames,
-                               static_cast<uint8_t *>(d_fib), static_cast<uint8_t *>(d_ok), s);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(fib, d_fib, size_t(n_frames) * NB_FIBS * 32, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(crc_ok, d_ok, size_t(n_frames) * NB_FIBS, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    return DABGPU_OK;
-}
-
-// ---------------------------------------------------------------------------- MSC
-static int subchannel_profile(const dabgpu_subchannel *sc, dab::PunctureProfile &prof) {
-    if (!sc) return DABGPU_ERR_ARG;
-    int size_cu = 0;
-    if (sc->is_uep) {
-        if (!make_uep_profile(uep_table_index(sc->bitrate_kbps, sc->protection_level), prof, size_cu)) return DABGPU_ERR_PROFILE;
-    } else if (!make_eep_profile(sc->eep_type, sc->protection_level, sc->bitrate_kbps, prof, size_cu)) {
-        return DABGPU_ERR_PROFILE;
-    }
-    if (size_cu != sc->length) return DABGPU_ERR_PROFILE;
-    if (sc->start_address < 0 || sc->start_address + sc->length > 864) return DABGPU_ERR_ARG;
-    return DABGPU_OK;
-}
-
-int dabgpu_soft_selection(const dabgpu_subchannel *subchannels, int n_subchannels, int with_fic,
-                          dabgpu_bit_range *out, int max_out) {
-    if (n_subchannels < 0 || (n_subchannels > 0 && !subchannels) || max_out < 0 || (max_out > 0 && !out)) return DABGPU_ERR_ARG;
-    int n = 0;
-    auto put = [&](int first, int count) {
-        if (n < max_out) { out[n].first = first; out[n].count = count; }
-        n++;
-    };
-    if (with_fic) put(0, NB_FIC_BITS);
-    for (int i = 0; i < n_subchannels; i++) {
-        dab::PunctureProfile prof;
-        const int rc = subchannel_profile(&subchannels[i], prof);
-        if (rc) return rc;
-        for (int c = 0; c < NB_CIFS; c++)
-            put(NB_FIC_BITS + c * NB_CIF_BITS + subchannels[i].start_address * 64, subchannels[i].length * 64);
-    }
-    return n;
-}
-
-int dabgpu_uep_subchannel(int table_index, int start_address, dabgpu_subchannel *out) {
-    if (!out) return DABGPU_ERR_ARG;
-    if (table_index < 0 || table_index >= 64) return DABGPU_ERR_PROFILE;
-    const UepProfileRow &r = UEP_TABLE[table_index];
-    if (start_address < 0 || start_address + r.size > 864) return DABGPU_ERR_ARG;
-    out->start_address = start_address;
-    out->length = r.size;
-    out->is_uep = 1;
-    out->eep_type = 0;
-    out->protection_level = r.level;
-    out->bitrate_kbps = r.bitrate;
-    return DABGPU_OK;
-}
-
-int dabgpu_subchannel_bytes(const dabgpu_subchannel *sc) {
-    dab::PunctureProfile prof;
-    int rc = subchannel_profile(sc, prof);
-    if (rc) return rc;
-    return (prof.nsteps - 6) / 8;
-}
-
-int dabgpu_msc_decode_dev(dabgpu_ctx *ctx, const dabgpu_subchannel *sc, const int8_t *d_soft, size_t soft_stride,
-                          int n_streams, int frames_per_stream, const int8_t *d_history_in,
-                          int8_t *d_history_out, uint8_t *d_out, void *stream) {
-    if (!ctx || !d_soft || !d_out || n_streams < 0 || frames_per_stream < 0) return DABGPU_ERR_ARG;
-    DeviceGuard guard(ctx);
-    if (d_history_in && d_history_in == d_history_out) return DABGPU_ERR_ARG;
-    if (soft_stride < size_t(NB_FRAME_BITS) && size_t(n_streams) * frames_per_stream > 1) return DABGPU_ERR_ARG;
-    dab::PunctureProfile prof;
-    int rc = subchannel_profile(sc, prof);
-    if (rc) return rc;
-    if (n_streams == 0 || frames_per_stream == 0) return DABGPU_OK;
-    const bool too_long = !dabk::viterbi_fits(prof.nsteps);   // above ~800 kbit/s: only the lane kernels hold it
-    if (too_long && !dabk::lane_supported(prof.nsteps)) return DABGPU_ERR_CAPACITY;
-    DeviceCode *dc = nullptr;
-    if ((rc = get_code(ctx, std::move(prof), &dc))) return rc;
-    hipStream_t s = pick_stream(ctx, stream);
-    dabk::MscArgs a{};
-    a.soft = d_soft;
-    a.soft_stride = soft_stride;
-    a.n_streams = n_streams;
-    a.frames_per_stream = frames_per_stream;
-    a.start_bit = sc->start_address * CU_BITS;
-    a.nbits = sc->length * CU_BITS;
-    a.hist_in = d_history_in;
-    a.hist_out = d_history_out;
-    a.out = d_out;
-    ScopedTimer tm(ctx, 2, s);
-    dabk::LaneScratch lsc{};
-    int lrc;
-    if (use_lane(ctx, dc->prof.nsteps, n_streams * frames_per_stream * NB_CIFS, s, &lsc, &lrc, too_long)) {
-        HIP_TRY(dabk::launch_msc_decode_lane(dc->tables(true), dc->lane_tables(), a, lsc, s));
-        HIP_TRY(dabk::launch_msc_history(a, s));
-        return DABGPU_OK;
-    }
-    if (lrc) return lrc;
-    if (too_long) return DABGPU_ERR_CAPACITY;
-    HIP_TRY(dabk::launch_msc_decode(dc->tables(true), a, s));
-    return DABGPU_OK;
-}
-
-int dabgpu_msc_decode(dabgpu_ctx *ctx, const dabgpu_subchannel *sc, const int8_t *soft, size_t soft_stride,
-                      int n_streams, int frames_per_stream, const int8_t *history_in, int8_t *history_out,
-                      uint8_t *out) {
-    if (!ctx || !soft || !out || n_streams < 0 || frames_per_stream < 0) return DABGPU_ERR_ARG;
-    DeviceGuard guard(ctx);
-    const int nbytes = dabgpu_subchannel_bytes(sc);
-    if (nbytes < 0) return nbytes;
-    const size_t nframes = size_t(n_streams) * frames_per_stream;
-    if (nframes == 0) return DABGPU_OK;
-    const size_t nb_soft = (nframes - 1) * soft_stride + NB_FRAME_BITS;
-    const size_t nb_hist = size_t(n_streams) * 15 * sc->length * CU_BITS;
-    const size_t nb_out = nframes * NB_CIFS * nbytes;
-    void *d_soft, *d_hi = nullptr, *d_ho = nullptr, *d_out;
-    int rc;
-    if ((rc = stage(ctx, 1, nb_soft, &d_soft))) return rc;
-    if ((rc = stage(ctx, 3, nb_out, &d_out))) return rc;
-    if (history_in && (rc = stage(ctx, 4, nb_hist, &d_hi))) return rc;
-    if (history_out && (rc = stage(ctx, 5, nb_hist, &d_ho))) return rc;
-    hipStream_t s = ctx->stream;
-    HIP_TRY(hipMemcpyAsync(d_soft, soft, nb_soft, hipMemcpyHostToDevice, s));
-    if (history_in) HIP_TRY(hipMemcpyAsync(d_hi, history_in, nb_hist, hipMemcpyHostToDevice, s));
-    rc = dabgpu_msc_decode_dev(ctx, sc, static_cast<const int8_t *>(d_soft), soft_stride, n_streams,
-                               frames_per_stream, static_cast<const int8_t *>(d_hi), static_cast<int8_t *>(d_ho),
-                               static_cast<uint8_t *>(d_out), s);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(out, d_out, nb_out, hipMemcpyDeviceToHost, s));
-    if (history_out) HIP_TRY(hipMemcpyAsync(history_out, d_ho, nb_hist, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    return DABGPU_OK;
-}
-
-// The FIC (d_fib != nullptr) and/or several sub-channels in one grouped lane launch.  Returns 0 when everything was
-// enqueued, 1 when the grouped path does not apply (caller falls back to one call per part), < 0 on errors.
-static int decode_grouped(dabgpu_ctx *ctx, uint8_t *d_fib, uint8_t *d_crc_ok, const dabgpu_subchannel *sc, int n_subchannels,
-                          const int8_t *d_soft, size_t soft_stride, int n_streams, int frames_per_stream,
-                          const int8_t *const *d_history_in, int8_t *const *d_history_out, uint8_t *const *d_out,
-                          void *stream) {
-    const int n_items = n_subchannels + (d_fib ? 1 : 0);
-    if (n_items < 2 || ctx->lane_mode == 0 || ctx->lane_unfused || !d_soft || n_streams <= 0 || frames_per_stream <= 0 ||
-        soft_stride < size_t(NB_FRAME_BITS))
-        return 1;
-    const long total_cw = long(n_items) * n_streams * frames_per_stream * NB_CIFS;
-    if (ctx->lane_mode < 0 && total_cw < LANE_MIN_CODEWORDS) return 1;
-    std::vector<dabk::LaneGroupItem> items;
-    if (d_fib) {
-        dabk::LaneGroupItem it{};
-        it.code = ctx->fic.tables(true);
-        it.tables = ctx->fic.lane_tables();
-        it.args.soft = d_soft;
-        it.args.soft_stride = soft_stride;
-        it.args.n_streams = n_streams;
-        it.args.frames_per_stream = frames_per_stream;
-        it.args.out = d_fib;
-        it.is_fic = true;
-        it.crc_ok = d_crc_ok;
-        if (((reinterpret_cast<uintptr_t>(d_soft) | soft_stride) & 15) || (reinterpret_cast<uintptr_t>(d_fib) & 3)) return 1;
-        items.push_back(it);
-    }
-    for (int i = 0; i < n_subchannels; i++) {
-        dab::PunctureProfile prof;
-        int rc = subchannel_profile(&sc[i], prof);
-        if (rc) return rc;
-        DeviceCode *dc = nullptr;
-        if ((rc = get_code(ctx, std::move(prof), &dc))) return rc;
-        dabk::LaneGroupItem it{};
-        it.code = dc->tables(true);
-        it.tables = dc->lane_tables();
-        it.args.soft = d_soft;
-        it.args.soft_stride = soft_stride;
-        it.args.n_streams = n_streams;
-        it.args.frames_per_stream = frames_per_stream;
-        it.args.start_bit = sc[i].start_address * CU_BITS;
-        it.args.nbits = sc[i].length * CU_BITS;
-        it.args.hist_in = d_history_in ? d_history_in[i] : nullptr;
-        it.args.hist_out = d_history_out ? d_history_out[i] : nullptr;
-        it.args.out = d_out[i];
-        if (it.args.hist_in && it.args.hist_in == it.args.hist_out) return DABGPU_ERR_ARG;
-        if (!dabk::lane_supported(dc->prof.nsteps) || !dabk::lane_group_fusable(it.args)) return 1;
-        items.push_back(it);
-    }
-    hipStream_t s = pick_stream(ctx, stream);
-    const size_t need = dabk::lane_group_scratch_bytes(items.data(), n_items);
-    if (ctx->lane_scratch_bytes < need) {
-        HIP_TRY(hipStreamSynchronize(s));
-        if (ctx->d_lane_scratch) (void)hipFree(ctx->d_lane_scratch);
-        ctx->d_lane_scratch = nullptr;
-        ctx->lane_scratch_bytes = 0;
-        if (hipMalloc(&ctx->d_lane_scratch, need) != hipSuccess) {
-            ctx->d_lane_scratch = nullptr;
-            return 1;
-        }
-        ctx->lane_scratch_bytes = need;
-    }
-    ScopedTimer tm(ctx, 2, s);
-    dabk::LaneScratch lsc{ctx->d_lane_scratch, ctx->lane_scratch_bytes};
-    HIP_TRY(dabk::launch_lane_group(items.data(), n_items, lsc, s));
-    for (const dabk::LaneGroupItem &it : items)
-        if (!it.is_fic) HIP_TRY(dabk::launch_msc_history(it.args, s));
-    return 0;
-}
-
-// Sub-channels that do not go through the grouped lane launch.  Small batches (each sub-channel below the lane
-// kernels' threshold: the plugin's one frame at a time) go through ONE launch of the wave-per-codeword kernel and one
-// for the history rings; anything else is decoded sub-channel by sub-channel.
-static int decode_subchannels(dabgpu_ctx *ctx, const dabgpu_subchannel *sc, int n_subchannels, const int8_t *d_soft,
-                              size_t soft_stride, int n_streams, int frames_per_stream, const int8_t *const *d_history_in,
-                              int8_t *const *d_history_out, uint8_t *const *d_out, void *stream, uint8_t *d_fib = nullptr,
-                              uint8_t *d_crc_ok = nullptr) {
-    const long cw_each = long(n_streams) * frames_per_stream * NB_CIFS;
-    bool group = n_subchannels >= 2 && ctx->lane_mode <= 0 && (ctx->lane_mode == 0 || cw_each < LANE_MIN_CODEWORDS) &&
-                 d_soft && n_streams > 0 && frames_per_stream > 0;
-    std::vector<dabk::WaveGroupItem> items;
-    for (int i = 0; group && i < n_subchannels; i++) {
-        dab::PunctureProfile prof;
-        int rc = subchannel_profile(&sc[i], prof);
-        if (rc) return rc;
-        if (!dabk::wave_group_supported(prof.nsteps)) { group = false; break; }
-        DeviceCode *dc = nullptr;
-        if ((rc = get_code(ctx, std::move(prof), &dc))) return rc;
-        dabk::WaveGroupItem it{};
-        it.code = dc->tables(true);
-        it.args.soft = d_soft;
-        it.args.soft_stride = soft_stride;
-        it.args.n_streams = n_streams;
-        it.args.frames_per_stream = frames_per_stream;
-        it.args.start_bit = sc[i].start_address * CU_BITS;
-        it.args.nbits = sc[i].length * CU_BITS;
-        it.args.hist_in = d_history_in ? d_history_in[i] : nullptr;
-        it.args.hist_out = d_history_out ? d_history_out[i] : nullptr;
-        it.args.out = d_out[i];
-        if (it.args.hist_in && it.args.hist_in == it.args.hist_out) return DABGPU_ERR_ARG;
-        items.push_back(it);
-    }
-    if (group) {
-        hipStream_t s = pick_stream(ctx, stream);
-        ScopedTimer tm(ctx, 2, s);
-        // a small batch's FIC rides along: its four codewords per frame are shorter than any sub-channel's, a launch
-        // of their own would only queue up in front
-        dabk::WaveFicItem fic{ctx->fic.tables(true), d_soft, soft_stride, n_streams * frames_per_stream, d_fib, d_crc_ok};
-        HIP_TRY(dabk::launch_msc_decode_group(items.data(), int(items.size()), s, d_fib ? &fic : nullptr));
-        return DABGPU_OK;
-    }
-    if (d_fib) {
-        const int rc = dabgpu_fic_decode_dev(ctx, d_soft, soft_stride, n_streams * frames_per_stream, d_fib, d_crc_ok, stream);
-        if (rc) return rc;
-    }
-    for (int i = 0; i < n_subchannels; i++) {
-        const int rc = dabgpu_msc_decode_dev(ctx, &sc[i], d_soft, soft_stride, n_streams, frames_per_stream,
-                                             d_history_in ? d_history_in[i] : nullptr,
-                                             d_history_out ? d_history_out[i] : nullptr, d_out[i], stream);
-        if (rc) return rc;
-    }
-    return DABGPU_OK;
-}
-
-int dabgpu_msc_decode_multi_dev(dabgpu_ctx *ctx, const dabgpu_subchannel *sc, int n_subchannels,
-                                const int8_t *d_soft, size_t soft_stride, int n_streams, int frames_per_stream,
-                                const int8_t *const *d_history_in, int8_t *const *d_history_out,
-                                uint8_t *const *d_out, void *stream) {
-    if (!ctx || !sc || !d_out || n_subchannels < 0) return DABGPU_ERR_ARG;
-    DeviceGuard guard(ctx);
-    // validate everything before enqueueing anything: profiles, bounds, no overlap inside the CIF
-    std::vector<char> used(864, 0);
-    for (int i = 0; i < n_subchannels; i++) {
-        dab::PunctureProfile prof;
-        const int rc = subchannel_profile(&sc[i], prof);
-        if (rc) return rc;
-        if (!d_out[i]) return DABGPU_ERR_ARG;
-        for (int cu = sc[i].start_address; cu < sc[i].start_address + sc[i].length; cu++) {
-            if (used[cu]) return DABGPU_ERR_ARG;
-            used[cu] = 1;
-        }
-    }
-    {
-        const int g = decode_grouped(ctx, nullptr, nullptr, sc, n_subchannels, d_soft, soft_stride, n_streams,
-                                     frames_per_stream, d_history_in, d_history_out, d_out, stream);
-        if (g <= 0) return g;                                  // done (0) or a real error (< 0); 1 = not applicable
-    }
-    return decode_subchannels(ctx, sc, n_subchannels, d_soft, soft_stride, n_streams, frames_per_stream, d_history_in,
-                              d_history_out, d_out, stream);
-}
-
-int dabgpu_decode_frames_dev(dabgpu_ctx *ctx, const int8_t *d_soft, size_t soft_stride, int n_streams,
-                             int frames_per_stream, uint8_t *d_fib, uint8_t *d_crc_ok, const dabgpu_subchannel *sc,
-                             int n_subchannels, const int8_t *const *d_history_in, int8_t *const *d_history_out,
-                             uint8_t *const *d_out, void *stream) {
-    if (!ctx || !d_soft || !d_fib || !d_crc_ok || n_streams < 0 || frames_per_stream < 0 || n_subchannels < 0) return DABGPU_ERR_ARG;
-    DeviceGuard guard(ctx);
-    if (n_subchannels > 0 && (!sc || !d_out)) return DABGPU_ERR_ARG;
-    if (soft_stride < size_t(NB_FRAME_BITS) && size_t(n_streams) * frames_per_stream > 1) return DABGPU_ERR_ARG;
-    std::vector<char> used(864, 0);
-    for (int i = 0; i < n_subchannels; i++) {
-        dab::PunctureProfile prof;
-        const int rc = subchannel_profile(&sc[i], prof);
-        if (rc) return rc;
-        if (!d_out[i]) return DABGPU_ERR_ARG;
-        for (int cu = sc[i].start_address; cu < sc[i].start_address + sc[i].length; cu++) {
-            if (used[cu]) return DABGPU_ERR_ARG;
-            used[cu] = 1;
-        }
-    }
-    if (n_streams == 0 || frames_per_stream == 0) return DABGPU_OK;
-    const int g = decode_grouped(ctx, d_fib, d_crc_ok, sc, n_subchannels, d_soft, soft_stride, n_streams, frames_per_stream,
-                                 d_history_in, d_history_out, d_out, stream);
-    if (g <= 0) return g;
-    // (the FIC goes into the sub-channels' grouped wave launch when there is one, else it gets its own)
-    return decode_subchannels(ctx, sc, n_subchannels, d_soft, soft_stride, n_streams, frames_per_stream, d_history_in,
-                              d_history_out, d_out, stream, d_fib, d_crc_ok);
-}
-
-int dabgpu_decode_frames(dabgpu_ctx *ctx, const int8_t *soft, size_t soft_stride, int n_streams, int frames_per_stream,
-                         uint8_t *fib, uint8_t *crc_ok, const dabgpu_subchannel *sc, int n_subchannels,
-                         const int8_t *const *history_in, int8_t *const *history_out, uint8_t *const *out) {
-    if (!ctx || !soft || !fib || !crc_ok || n_streams < 0 || frames_per_stream < 0 || n_subchannels < 0) return DABGPU_ERR_ARG;
-    DeviceGuard guard(ctx);
-    if (n_subchannels > 0 && (!sc || !out)) return DABGPU_ERR_ARG;
-    const size_t nframes = size_t(n_streams) * frames_per_stream;
-    if (nframes == 0) return DABGPU_OK;
-    if (soft_stride < size_t(NB_FRAME_BITS) && nframes > 1) return DABGPU_ERR_ARG;
-    // layout of the result and history staging buffers: [fib | crc | out_0 | out_1 ...], [hist_0 | hist_1 ...]
-    auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
-    std::vector<size_t> out_off(n_subchannels), out_bytes(n_subchannels), hist_off(n_subchannels), hist_bytes(n_subchannels);
-    const size_t nb_fib = nframes * NB_FIBS * 32, nb_crc = nframes * NB_FIBS;
-    size_t res_total = al(nb_fib) + al(nb_crc), hist_total = 0;
-    for (int i = 0; i < n_subchannels; i++) {
-        const int nbytes = dabgpu_subchannel_bytes(&sc[i]);
-        if (nbytes < 0) return nbytes;
-        if (!out[i]) return DABGPU_ERR_ARG;
-        out_off[i] = res_total;
-        out_bytes[i] = nframes * NB_CIFS * size_t(nbytes);
-        res_total += al(out_bytes[i]);
-        hist_off[i] = hist_total;
-        hist_bytes[i] = size_t(n_streams) * 15 * sc[i].length * CU_BITS;
-        hist_total += al(hist_bytes[i]);
-    }
-    const size_t nb_soft = (nframes - 1) * soft_stride + NB_FRAME_BITS;
-    void *d_soft, *d_res, *d_hi = nullptr, *d_ho = nullptr;
-    int rc;
-    if ((rc = stage(ctx, 1, nb_soft, &d_soft))) return rc;
-    if ((rc = stage(ctx, 3, res_total, &d_res))) return rc;
-    if (hist_total && history_in && (rc = stage(ctx, 4, hist_total, &d_hi))) return rc;
-    if (hist_total && history_out && (rc = stage(ctx, 5, hist_total, &d_ho))) return rc;
-    hipStream_t s = ctx->stream;
-    HIP_TRY(hipMemcpyAsync(d_soft, soft, nb_soft, hipMemcpyHostToDevice, s));            // the frames go up once
-    std::vector<const int8_t *> p_hi(n_subchannels, nullptr);
-    std::vector<int8_t *> p_ho(n_subchannels, nullptr);
-    std::vector<uint8_t *> p_out(n_subchannels, nullptr);
-    char *res = static_cast<char *>(d_res);
-    for (int i = 0; i < n_subchannels; i++) {
-        p_out[i] = reinterpret_cast<uint8_t *>(res + out_off[i]);
-        if (history_in && history_in[i]) {
-            p_hi[i] = reinterpret_cast<const int8_t *>(static_cast<char *>(d_hi) + hist_off[i]);
-            HIP_TRY(hipMemcpyAsync(const_cast<int8_t *>(p_hi[i]), history_in[i], hist_bytes[i], hipMemcpyHostToDevice, s));
-        }
-        if (history_out && history_out[i]) p_ho[i] = reinterpret_cast<int8_t *>(static_cast<char *>(d_ho) + hist_off[i]);
-    }
-    uint8_t *d_fib = reinterpret_cast<uint8_t *>(res), *d_crc = reinterpret_cast<uint8_t *>(res + al(nb_fib));
-    rc = dabgpu_decode_frames_dev(ctx, static_cast<const int8_t *>(d_soft), soft_stride, n_streams, frames_per_stream, d_fib,
-                                  d_crc, sc, n_subchannels, n_subchannels ? p_hi.data() : nullptr,
-                                  n_subchannels ? p_ho.data() : nullptr, n_subchannels ? p_out.data() : nullptr, s);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(fib, d_fib, nb_fib, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(crc_ok, d_crc, nb_crc, hipMemcpyDeviceToHost, s));
-    for (int i = 0; i < n_subchannels; i++) {
-        HIP_TRY(hipMemcpyAsync(out[i], p_out[i], out_bytes[i], hipMemcpyDeviceToHost, s));
-        if (p_ho[i]) HIP_TRY(hipMemcpyAsync(history_out[i], p_ho[i], hist_bytes[i], hipMemcpyDeviceToHost, s));
-    }
-    HIP_TRY(hipStreamSynchronize(s));                                                  // one synchronisation
-    return DABGPU_OK;
-}
-
-int dabgpu_decode_stream_reset(dabgpu_ctx *ctx) {
-    if (!ctx) return DABGPU_ERR_ARG;
-    DeviceGuard guard(ctx);
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    for (auto &h : ctx->sub_history) { (void)hipFree(h.ring[0]); (void)hipFree(h.ring[1]); }
-    ctx->sub_history.clear();
-    return DABGPU_OK;
-}
-
-static int decode_stream_frames_body(dabgpu_ctx *ctx, const int8_t *soft, size_t soft_stride, int n_frames, uint8_t *fib,
-                                     uint8_t *crc_ok, const dabgpu_subchannel *sc, int n_subchannels, uint8_t *const *out);
-
-int dabgpu_decode_stream_frames(dabgpu_ctx *ctx, const int8_t *soft, size_t soft_stride, int n_frames, uint8_t *fib,
-                                uint8_t *crc_ok, const dabgpu_subchannel *sc, int n_subchannels, uint8_t *const *out) {
-    if (!ctx || !soft || !fib || !crc_ok || n_frames < 0 || n_subchannels < 0) return DABGPU_ERR_ARG;
-    DeviceGuard guard(ctx);
-    if (n_subchannels > 0 && (!sc || !out)) return DABGPU_ERR_ARG;
-    if (n_frames == 0) return DABGPU_OK;
-    if (soft_stride < size_t(NB_FRAME_BITS) && n_frames > 1) return DABGPU_ERR_ARG;
-    const int rc = decode_stream_frames_body(ctx, soft, soft_stride, n_frames, fib, crc_ok, sc, n_subchannels, out);
-    if (rc != DABGPU_OK) {
-        // A call that failed part-way leaves rings that have missed this frame (and `live` marks on some of them): no
-        // ring continues the stream any more.  All of them go; the next call starts every sub-channel from erasures.
-        (void)hipStreamSynchronize(ctx->stream);
-        (void)hipGetLastError();
-        for (auto &h : ctx->sub_history) { (void)hipFree(h.ring[0]); (void)hipFree(h.ring[1]); }
-        ctx->sub_history.clear();
-    }
-    return rc;
-}
-
-static int decode_stream_frames_body(dabgpu_ctx *ctx, const int8_t *soft, size_t soft_stride, int n_frames, uint8_t *fib,
-                                     uint8_t *crc_ok, const dabgpu_subchannel *sc, int n_subchannels, uint8_t *const *out) {
-    auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
-    const size_t nb_fib = size_t(n_frames) * NB_FIBS * 32, nb_crc = size_t(n_frames) * NB_FIBS;
-    std::vector<size_t> out_off(n_subchannels), out_bytes(n_subchannels);
-    size_t res_total = al(nb_fib) + al(nb_crc);
-    std::vector<const int8_t *> p_hi(n_subchannels, nullptr);
-    std::vector<int8_t *> p_ho(n_subchannels, nullptr);
-    std::vector<int> hist_index(n_subchannels, -1);
-    hipStream_t s = ctx->stream;
-    for (int i = 0; i < n_subchannels; i++) {
-        const int nbytes = dabgpu_subchannel_bytes(&sc[i]);
-        if (nbytes < 0) return nbytes;
-        if (!out[i]) return DABGPU_ERR_ARG;
-        out_off[i] = res_total;
-        out_bytes[i] = size_t(n_frames) * NB_CIFS * size_t(nbytes);
-        res_total += al(out_bytes[i]);
-        // the sub-channel's ring from the call before, or a new (erased) one
-        for (size_t k = 0; k < ctx->sub_history.size(); k++)
-            if (ctx->sub_history[k].start_address == sc[i].start_address && ctx->sub_history[k].length == sc[i].length) hist_index[i] = int(k);
-        if (hist_index[i] < 0) {
-            dabgpu_ctx::SubHistory h{};
-            h.start_address = sc[i].start_address;
-            h.length = sc[i].length;
-            h.bytes = size_t(15) * sc[i].length * CU_BITS;
-            if (hipMalloc(reinterpret_cast<void **>(&h.ring[0]), h.bytes) != hipSuccess) return DABGPU_ERR_NOMEM;
-            if (hipMalloc(reinterpret_cast<void **>(&h.ring[1]), h.bytes) != hipSuccess) { (void)hipFree(h.ring[0]); return DABGPU_ERR_NOMEM; }
-            hist_index[i] = int(ctx->sub_history.size());
-            ctx->sub_history.push_back(h);
-            HIP_TRY(hipMemsetAsync(h.ring[0], 0, h.bytes, s));
-        }
-        dabgpu_ctx::SubHistory &h = ctx->sub_history[size_t(hist_index[i])];
-        h.live = true;
-        p_hi[i] = h.ring[h.cur];
-        p_ho[i] = h.ring[h.cur ^ 1];
-    }
-    const size_t nb_soft = size_t(n_frames - 1) * soft_stride + NB_FRAME_BITS;
-    void *d_soft, *d_res;
-    int rc;
-    if ((rc = stage(ctx, 1, nb_soft, &d_soft))) return rc;
-    if ((rc = stage(ctx, 3, res_total, &d_res))) return rc;
-    if (ctx->h_bounce_bytes < res_total) {
-        if (ctx->h_bounce) (void)hipHostFree(ctx->h_bounce);
-        ctx->h_bounce = nullptr;
-        ctx->h_bounce_bytes = 0;
-        if (hipHostMalloc(&ctx->h_bounce, res_total, hipHostMallocDefault) != hipSuccess) return DABGPU_ERR_NOMEM;
-        ctx->h_bounce_bytes = res_total;
-    }
-    HIP_TRY(hipMemcpyAsync(d_soft, soft, nb_soft, hipMemcpyHostToDevice, s));            // one upload
-    char *res = static_cast<char *>(d_res);
-    std::vector<uint8_t *> p_out(n_subchannels, nullptr);
-    for (int i = 0; i < n_subchannels; i++) p_out[i] = reinterpret_cast<uint8_t *>(res + out_off[i]);
-    rc = dabgpu_decode_frames_dev(ctx, static_cast<const int8_t *>(d_soft), soft_stride, 1, n_frames,
-                                  reinterpret_cast<uint8_t *>(res), reinterpret_cast<uint8_t *>(res + al(nb_fib)), sc, n_subchannels,
-                                  n_subchannels ? p_hi.data() : nullptr, n_subchannels ? p_ho.data() : nullptr,
-                                  n_subchannels ? p_out.data() : nullptr, s);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(ctx->h_bounce, d_res, res_total, hipMemcpyDeviceToHost, s));     // one download
-    HIP_TRY(hipStreamSynchronize(s));                                                   // one synchronisation
-    const char *hb = static_cast<const char *>(ctx->h_bounce);
-    std::memcpy(fib, hb, nb_fib);
-    std::memcpy(crc_ok, hb + al(nb_fib), nb_crc);
-    for (int i = 0; i < n_subchannels; i++) {
-        std::memcpy(out[i], hb + out_off[i], out_bytes[i]);
-        ctx->sub_history[size_t(hist_index[i])].cur ^= 1;
-    }
-    // a sub-channel left out of this call has missed a frame: its ring no longer continues the stream, and a later
-    // call starts it from erasures again (this also bounds the list over any number of reconfigurations)
-    size_t kept = 0;
-    for (auto &h : ctx->sub_history) {
-        if (h.live) { h.live = false; ctx->sub_history[kept++] = h; }
-        else { (void)hipFree(h.ring[0]); (void)hipFree(h.ring[1]); }
-    }
-    ctx->sub_history.resize(kept);
-    return DABGPU_OK;
-}
-
-// ---------------------------------------------------------------------------- DAB+ super-frame
-static_assert(sizeof(dabgpu_superframe_status) == sizeof(dabk::SuperframeStatus), "ABI struct mirrors the kernel's");
-
-int dabgpu_dabplus_superframes_dev(dabgpu_ctx *ctx, const uint8_t *d_in, size_t in_stride, int n_superframes,
-                                   int bitrate_kbps, uint8_t *d_out, dabgpu_superframe_status *d_status,
-                                   void *stream) {
-    if (!ctx || !d_in || !d_out || !d_status || n_superframes < 0) return DABGPU_ERR_ARG;
-    DeviceGuard guard(ctx);
-    if (bitrate_kbps < 8 || bitrate_kbps % 8 || bitrate_kbps > 512) return DABGPU_ERR_PROFILE;
-    const int s = bitrate_kbps / 8;
-    if (n_superframes > 1 && in_stride < size_t(120) * s) return DABGPU_ERR_ARG;
-    if (n_superframes == 0) return DABGPU_OK;
-    HIP_TRY(dabk::launch_dabplus_superframes(d_in, in_stride, n_superframes, s, d_out,
-                                             reinterpret_cast<dabk::SuperframeStatus *>(d_status),
-                                             pick_stream(ctx, stream)));
-    return DABGPU_OK;
-}
-
-int dabgpu_dabplus_superframes(dabgpu_ctx *ctx, const uint8_t *in, size_t in_stride, int n_superframes,
-                               int bitrate_kbps, uint8_t *out, dabgpu_superframe_status *status) {
-    if (!ctx || !in || !out || !status || n_superframes < 0) return DABGPU_ERR_ARG;
-    DeviceGuard guard(ctx);
-    if (bitrate_kbps < 8 || bitrate_kbps % 8 || bitrate_kbps > 512) return DABGPU_ERR_PROFILE;
-    if (n_superframes == 0) return DABGPU_OK;
-    const int s = bitrate_kbps / 8;
-    const size_t nb_in = size_t(n_superframes - 1) * in_stride + size_t(120) * s;
-    const size_t nb_out = size_t(n_superframes) * 110 * s;
-    void *d_in, *d_out, *d_st;
-    int rc;
-    if ((rc = stage(ctx, 1, nb_in, &d_in))) return rc;
-    if ((rc = stage(ctx, 3, nb_out, &d_out))) return rc;
-    if ((rc = stage(ctx, 2, sizeof(dabgpu_superframe_status) * n_superframes, &d_st))) return rc;
-    hipStream_t st = ctx->stream;
-    HIP_TRY(hipMemcpyAsync(d_in, in, nb_in, hipMemcpyHostToDevice, st));
-    rc = dabgpu_dabplus_superframes_dev(ctx, static_cast<const uint8_t *>(d_in), in_stride, n_superframes,
-                                        bitrate_kbps, static_cast<uint8_t *>(d_out),
-                                        static_cast<dabgpu_superframe_status *>(d_st), st);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(out, d_out, nb_out, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(status, d_st, sizeof(dabgpu_superframe_status) * n_superframes, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    return DABGPU_OK;
-}
-
-// ---------------------------------------------------------------------------- plain Viterbi
-int dabgpu_viterbi_dev(dabgpu_ctx *ctx, const int8_t *d_punct, int n_codewords, const uint8_t *mask, int nsteps,
-                       uint8_t *d_out_bytes, void *stream) {
-    if (!ctx || !d_punct || !mask || !d_out_bytes || n_codewords < 0) return DABGPU_ERR_ARG;
-    DeviceGuard guard(ctx);
-    if (nsteps < 14 || ((nsteps - 6) & 7)) return DABGPU_ERR_ARG;
-    const bool too_long = !dabk::viterbi_fits(nsteps);
-    if (too_long && !dabk::lane_supported(nsteps)) return DABGPU_ERR_CAPACITY;
-    dab::PunctureProfile prof;
-    prof.mask.assign(mask, mask + 4 * size_t(nsteps));
-    for (uint8_t &f : prof.mask) f = f ? 1 : 0;
-    finish_profile(prof);
-    if (n_codewords == 0) return DABGPU_OK;
-    DeviceCode *dc = nullptr;
-    int rc = get_code(ctx, std::move(prof), &dc);
-    if (rc) return rc;
-    hipStream_t s = pick_stream(ctx, stream);
-    dabk::LaneScratch lsc{};
-    int lrc;
-    if (use_lane(ctx, dc->prof.nsteps, n_codewords, s, &lsc, &lrc, too_long)) {
-        HIP_TRY(dabk::launch_viterbi_plain_lane(dc->tables(false), dc->lane_tables(), d_punct, n_codewords, lsc,
-                                                d_out_bytes, s));
-        return DABGPU_OK;
-    }
-    if (lrc) return lrc;
-    if (too_long) return DABGPU_ERR_CAPACITY;
-    HIP_TRY(dabk::launch_viterbi_plain(dc->tables(false), d_punct, n_codewords, d_out_bytes, s));
-    return DABGPU_OK;
-}
-
-int dabgpu_viterbi(dabgpu_ctx *ctx, const int8_t *punct, int n_codewords, const uint8_t *mask, int nsteps,
-                   uint8_t *out_bytes) {
-    if (!ctx || !punct || !mask || !out_bytes || n_codewords < 0) return DABGPU_ERR_ARG;
-    DeviceGuard guard(ctx);
-    if (nsteps < 14 || ((nsteps - 6) & 7)) return DABGPU_ERR_ARG;
-    if (n_codewords == 0) return DABGPU_OK;
-    size_t n_punct = 0;
-    for (int i = 0; i < 4 * nsteps; i++) n_punct += mask[i] ? 1 : 0;
-    const size_t nb_in = size_t(n_codewords) * n_punct, nb_out = size_t(n_codewords) * ((nsteps - 6) / 8);
-    void *d_in, *d_out;
-    int rc;
-    if ((rc = stage(ctx, 1, nb_in ? nb_in : 1, &d_in))) return rc;
-    if ((rc = stage(ctx, 3, nb_out, &d_out))) return rc;
-    hipStream_t s = ctx->stream;
-    if (nb_in) HIP_TRY(hipMemcpyAsync(d_in, punct, nb_in, hipMemcpyHostToDevice, s));
-    rc = dabgpu_viterbi_dev(ctx, static_cast<const int8_t *>(d_in), n_codewords, mask, nsteps,
-                            static_cast<uint8_t *>(d_out), s);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(out_bytes, d_out, nb_out, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
     return DABGPU_OK;
 }
 

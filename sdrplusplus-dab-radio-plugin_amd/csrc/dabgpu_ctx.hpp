@@ -1,0 +1,173 @@
+// dabgpu_ctx.hpp -- the context behind the opaque dabgpu_ctx handle and the helpers the translation units of the C ABI
+// share (dabgpu_api.hip: context + front end, dabgpu_decode_api.hip: channel decoder, dabgpu_placement.hip: frame
+// buffers, dabgpu_pipeline.hip: the host-fed ring).  Internal to libdabgpu.
+#pragma once
+#include "../../include/dabgpu.h"
+
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <memory>
+#include <vector>
+
+#include "dab_tables.hpp"
+#include "kernels.hpp"
+
+namespace dabapi {
+
+struct DeviceCode {
+    dab::PunctureProfile prof;
+    uint16_t *d_mother_pos = nullptr;
+    uint8_t *d_prbs = nullptr;
+    int32_t *d_punct_idx = nullptr;      // [4*nsteps] punctured index of each mother bit, -1 = erased (lane kernels)
+    int32_t *d_fused_desc = nullptr, *d_fused_tiles = nullptr;   // fused lane forward pass (build_lane_fused_tables)
+    dabk::LaneTables lane_tables() const { return dabk::LaneTables{d_punct_idx, d_fused_desc, d_fused_tiles}; }
+    dabk::CodeTables tables(bool descramble) const {
+        return dabk::CodeTables{d_mother_pos, prof.n_punct, prof.nsteps, descramble ? d_prbs : nullptr};
+    }
+};
+
+// hipEvent pairs around the most recent launches of one kernel family (a ring: the launches are asynchronous, so
+// the pairs can only be read back after the stream has caught up)
+constexpr int TIMER_RING = 32;
+struct Timer {
+    hipEvent_t start[TIMER_RING] = {}, stop[TIMER_RING] = {};
+    long recorded = 0;                   // launches timed since timing was switched on
+};
+
+struct Pipeline;                         // dabgpu_pipeline.hip
+
+// The domain-aware frame buffers of a context live inside ONE address range, reserved by the first such allocation and
+// given back by dabgpu_destroy only (dabgpu_placement.hip): [va, va + probe_bytes) is where physical chunks are mapped
+// while their HBM domains are found, [va + probe_bytes, va + reserved) is where the pair handed to the caller is mapped.
+struct Arena {
+    char *va = nullptr;
+    size_t reserved = 0, probe_bytes = 0;
+    struct Piece {
+        size_t off, bytes;               // offset inside the range, mapped bytes
+        hipMemGenericAllocationHandle_t h;
+    };
+    std::vector<Piece> pieces;           // live mappings of the pair handed out (empty: the arena is idle)
+    void *d_iq = nullptr, *d_soft = nullptr;
+};
+
+}  // namespace dabapi
+
+struct dabgpu_ctx {
+    int device = 0;
+    int max_frames = 0;
+    hipStream_t stream = nullptr;
+    float2 *d_twiddle = nullptr;
+    uint16_t *d_bin_of_n = nullptr;
+    uint16_t *d_n_of_vj = nullptr;
+    int8_t *d_prs_qt = nullptr;
+    uint16_t *d_sync_pairs = nullptr;
+    int n_sync_pairs = 0;
+    float2 *d_sync_fs = nullptr;         // FFT of the PRS's adjacent-carrier differential (coarse search by FFT)
+    dabapi::DeviceCode fic;
+    std::map<std::vector<uint8_t>, std::unique_ptr<dabapi::DeviceCode>> codes;   // keyed by puncture mask
+    // slots 0..5: staging of the host-pointer entry points; slot 6: the stream / tracked / frame calls' own loop input
+    // (correlations or decision-directed sums).  One caller stream at a time per context (dabgpu.h, conventions).
+    void *d_stage[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t stage_bytes[7] = {0, 0, 0, 0, 0, 0, 0};
+    bool timing = false;
+    dabapi::Timer timers[4];
+    int ofdm_parts_override = 0;
+    const unsigned long long *d_keep = nullptr;          // current soft-bit selection table ([75][3] words) or nullptr
+    std::vector<void *> keep_tables;                     // every table handed to a kernel so far (freed on destroy)
+    void *d_acq_scratch = nullptr;       // block norms + candidates of dabgpu_acquire
+    size_t acq_scratch_bytes = 0;
+    void *d_lane_scratch = nullptr;      // work buffers of the codeword-per-lane Viterbi
+    size_t lane_scratch_bytes = 0;
+    int lane_mode = -1;                  // 1 = DABGPU_FLAG_VITERBI_LANE, 0 = DABGPU_FLAG_VITERBI_WAVE, -1 by batch size
+    bool lane_unfused = false;           // DABGPU_FLAG_LANE_UNFUSED
+    int wave_slots = 3072;               // resident OFDM wavefronts: 12 per CU
+    std::vector<dabgpu_bit_range> keep_ranges;           // the current selection, merged, for the host-pointer copy-back
+    dabk::StreamState *d_states = nullptr;               // per-stream tracking state (dabgpu_streams_reset)
+    int n_states = 0;
+    hipEvent_t ev_states = nullptr;      // recorded behind the last launch that reads or writes d_states, on ITS stream
+    bool ev_states_pending = false;
+    float thr_null_start = 0.35f;        // desync threshold of the stream call (null_l1_search.thresh_null_start)
+    float signal_beta = 0.95f;           // signal_l1.update_beta of the stream call
+    bool loop_dd = false;                // stream call without a correlation buffer: decision-directed fine loop
+    float dd_gate = 8.0f;                // decision-directed loop: quality gate (dabgpu_set_loop_gate, dabk::dd_loop_error)
+    int keep_symbols = 75;               // data symbols per frame the current selection demodulates (75: no selection)
+    // dabgpu_decode_stream_frames: de-interleaver rings of the stream's sub-channels, kept on the device between calls
+    struct SubHistory {
+        int start_address, length;
+        size_t bytes;
+        int8_t *ring[2];
+        int cur;
+        bool live;                       // decoded in the current call (a ring that misses a frame is stale: dropped)
+    };
+    std::vector<SubHistory> sub_history;
+    void *h_bounce = nullptr;            // page-locked landing area of that call's single download
+    size_t h_bounce_bytes = 0;
+    dabapi::Arena arena;                 // dabgpu_alloc_frame_buffers(DABGPU_PLACE_DOMAINS)
+    dabapi::Pipeline *pipe = nullptr;    // dabgpu_pipe_open
+};
+
+namespace dabapi {
+
+// Makes the context's device current for the duration of an entry point and restores the caller's afterwards:
+// allocations, copies and launches of a context must never land on whatever device the calling thread last used.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(const dabgpu_ctx *ctx) {
+        if (ctx && hipGetDevice(&prev) == hipSuccess && prev != ctx->device) switched = hipSetDevice(ctx->device) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
+#define HIP_TRY(expr)                               \
+    do {                                            \
+        hipError_t e_ = (expr);                     \
+        if (e_ != hipSuccess) return DABGPU_ERR_HIP; \
+    } while (0)
+
+struct ScopedTimer {
+    dabgpu_ctx *ctx;
+    int which;
+    hipStream_t s;
+    ScopedTimer(dabgpu_ctx *c, int w, hipStream_t st) : ctx(c), which(w), s(st) {
+        if (ctx->timing) {
+            Timer &t = ctx->timers[which];
+            const int i = int(t.recorded % TIMER_RING);
+            if (!t.start[i]) { (void)hipEventCreate(&t.start[i]); (void)hipEventCreate(&t.stop[i]); }
+            (void)hipEventRecord(t.start[i], s);
+        }
+    }
+    ~ScopedTimer() {
+        if (ctx->timing) {
+            Timer &t = ctx->timers[which];
+            (void)hipEventRecord(t.stop[int(t.recorded % TIMER_RING)], s);
+            t.recorded++;
+        }
+    }
+};
+
+inline hipStream_t pick_stream(dabgpu_ctx *ctx, void *stream) {
+    return stream ? reinterpret_cast<hipStream_t>(stream) : ctx->stream;
+}
+
+// defined in dabgpu_api.hip
+int stage(dabgpu_ctx *ctx, int slot, size_t bytes, void **out);
+int get_code(dabgpu_ctx *ctx, dab::PunctureProfile &&prof, DeviceCode **out);
+void free_device_code(DeviceCode &dc);
+int note_state_use(dabgpu_ctx *ctx, hipStream_t s);
+int wait_state_use(dabgpu_ctx *ctx);
+void stats_of(const dabk::StreamState &st, dabgpu_stats *out);
+// defined in dabgpu_placement.hip / dabgpu_pipeline.hip: what dabgpu_destroy calls
+void arena_destroy(dabgpu_ctx *ctx);
+void pipeline_destroy(dabgpu_ctx *ctx);
+
+// The codeword-per-lane Viterbi pays once a launch has enough codewords to give every SIMD a wave (one wave =
+// 64 codewords; its single-wave latency equals the wave-per-codeword kernels' time at ~24k codewords).
+constexpr int LANE_MIN_CODEWORDS = 24576;
+
+}  // namespace dabapi

@@ -1,0 +1,417 @@
+// dabgpu_placement.hip -- device buffers for a batch user's IQ samples and soft bits (dabgpu_alloc_frame_buffers).
+//
+// MI355X's HBM behaves as three domains of 96 GB; a launch that reads its samples from the domain it writes its soft
+// bits to runs up to ~10 % slower than one whose two streams lie apart (profiles/r02_hbm_domains.txt).  Where hipMalloc
+// puts a buffer is not visible, so DABGPU_PLACE_DOMAINS takes physical memory in chunks through the virtual-memory API,
+// finds every chunk's domain with a small data mover, and maps the pair over chunks that lie apart.
+//
+// Rules this file keeps (round 3's version broke the first and could take the process down with it):
+//   * ONE address range per context, reserved by the first domain-aware allocation, freed by dabgpu_destroy only.
+//     Chunks are mapped and unmapped INSIDE it; no address range is ever freed and reserved again while the context
+//     lives (the runtime was seen to answer a look-up in a new range with one freed moments before).
+//   * never more than 1.5 x the pair's size held (no spacers beyond that budget); when the budget's chunks do not allow
+//     a clean placement, the pair is placed as well as they do and the report says so (conflicts): not chased.
+//   * every failure on the way -- no virtual-memory API, no room, a failed map, a failed probe launch -- ends in two
+//     plain hipMallocs (report.method = 0); an error is returned only when those fail too.
+#include "dabgpu_ctx.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+using namespace dab;
+using namespace dabapi;
+
+namespace {
+
+constexpr size_t CH = size_t(1) << 30;       // IQ chunks
+constexpr size_t CS = size_t(256) << 20;     // soft-bit chunks: each is written beside only ~1.7 GiB of samples
+
+struct Chunk {
+    hipMemGenericAllocationHandle_t h;
+    size_t bytes, off;                       // offset inside the arena's probe region
+    bool mapped;
+    int dom;
+};
+
+struct Probe {
+    dabgpu_ctx *ctx;
+    hipStream_t s;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    std::vector<Chunk> c;
+    char *at(int i) const { return ctx->arena.va + c[size_t(i)].off; }
+    // every chunk still in the probe region leaves it; the ones nobody took are released
+    void drop_all() {
+        for (Chunk &x : c) {
+            if (x.mapped) (void)hipMemUnmap(ctx->arena.va + x.off, x.bytes);
+            if (x.h) (void)hipMemRelease(x.h);
+            x.mapped = false;
+            x.h = nullptr;
+        }
+        (void)hipGetLastError();
+    }
+    ~Probe() {
+        drop_all();
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    }
+};
+
+// time of a mover launch that reads [in, in + in_b) and writes [out, out + out_b): min of two after a warm-up
+float mover_ms(const Probe &p, const void *in, size_t in_b, void *out, size_t out_b) {
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; rep++) {
+        if (hipEventRecord(p.e0, p.s) != hipSuccess || dabk::launch_placement_probe(in, in_b, out, out_b, p.s) != hipSuccess ||
+            hipEventRecord(p.e1, p.s) != hipSuccess || hipEventSynchronize(p.e1) != hipSuccess)
+            return -1.f;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.e0, p.e1) != hipSuccess) return -1.f;
+        if (rep > 0) best = std::min(best, ms);
+    }
+    return best;
+}
+// ... reading chunk a and writing (a sixth of its size of) chunk b
+float pair_ms(const Probe &p, int a, int b) {
+    const size_t in_b = p.c[size_t(a)].bytes;
+    return mover_ms(p, p.at(a), in_b, p.at(b), std::min(p.c[size_t(b)].bytes, in_b / 6));
+}
+
+// Chunks whose pairing with `ref` is slow share its domain.  The times of `idx` fall into two groups ~10 % apart; with
+// no gap, the pairing of ref with itself (the same-domain time by construction; the fastest of three, noise only ever
+// makes a measurement slower) says which group everything is in.
+bool same_domain_as(const Probe &p, int ref, const std::vector<int> &idx, std::vector<int> &same, std::vector<int> &other) {
+    if (idx.empty()) return true;
+    std::vector<float> t(idx.size());
+    float lo = 1e30f, hi = 0.f;
+    for (size_t k = 0; k < idx.size(); k++) {
+        if ((t[k] = pair_ms(p, ref, idx[k])) < 0.f) return false;
+        lo = std::min(lo, t[k]);
+        hi = std::max(hi, t[k]);
+    }
+    if (hi > 1.04f * lo) {
+        const float thr = 0.5f * (lo + hi);
+        for (size_t k = 0; k < idx.size(); k++) (t[k] > thr ? same : other).push_back(idx[k]);
+        return true;
+    }
+    float self = 1e30f;
+    for (int k = 0; k < 3; k++) {
+        const float t1 = pair_ms(p, ref, ref);
+        if (t1 < 0.f) return false;
+        self = std::min(self, t1);
+    }
+    (lo > 0.97f * self ? same : other) = idx;
+    return true;
+}
+
+// Every chunk's domain (0, 1, 2 in order of first appearance) in two passes: against chunk 0, then against the first
+// chunk that differed.  Returns the number of domains seen, or -1.
+int classify(Probe &p) {
+    const int n = int(p.c.size());
+    // the mover's time moves with the memory side's clocks, which take tens of milliseconds to settle on an idle device:
+    // chunk 0 against itself until two consecutive rounds agree within 1 % (at most ~60 ms)
+    float last = 0.f;
+    for (int round = 0; round < 40; round++) {
+        float t = 0.f;
+        for (int k = 0; k < 2; k++) t = pair_ms(p, 0, 0);
+        if (t <= 0.f) return -1;
+        if (round >= 4 && std::fabs(t - last) <= 0.01f * t) break;
+        last = t;
+    }
+    std::vector<int> rest, a_set, others;
+    for (int i = 1; i < n; i++) rest.push_back(i);
+    if (!same_domain_as(p, 0, rest, a_set, others)) return -1;
+    if (others.empty()) return 1;
+    const int r2 = others[0];
+    std::vector<int> rest2(others.begin() + 1, others.end()), b_set, c_set;
+    if (!same_domain_as(p, r2, rest2, b_set, c_set)) return -1;
+    b_set.push_back(r2);
+    for (int i : b_set) p.c[size_t(i)].dom = 1;
+    for (int i : c_set) p.c[size_t(i)].dom = 2;
+    return c_set.empty() ? 2 : 3;
+}
+
+void unmap_pieces(dabgpu_ctx *ctx) {
+    Arena &a = ctx->arena;
+    for (Arena::Piece &pc : a.pieces) {
+        (void)hipMemUnmap(a.va + pc.off, pc.bytes);
+        (void)hipMemRelease(pc.h);
+    }
+    (void)hipGetLastError();
+    a.pieces.clear();
+    a.d_iq = a.d_soft = nullptr;
+}
+
+int plain_pair(size_t iq_bytes, size_t soft_bytes, void **d_iq, int8_t **d_soft, dabgpu_placement_report &rep,
+               dabgpu_placement_report *report) {
+    if (hipMalloc(d_iq, iq_bytes) != hipSuccess) { (void)hipGetLastError(); *d_iq = nullptr; return DABGPU_ERR_NOMEM; }
+    if (hipMalloc(reinterpret_cast<void **>(d_soft), soft_bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(*d_iq);
+        *d_iq = nullptr;
+        *d_soft = nullptr;
+        return DABGPU_ERR_NOMEM;
+    }
+    rep.method = 0;
+    rep.setup_peak_bytes = std::max<uint64_t>(rep.setup_peak_bytes, iq_bytes + soft_bytes);   // (probe chunks, if any, went back first)
+    if (report) *report = rep;
+    return DABGPU_OK;
+}
+
+}  // namespace
+
+namespace dabapi {
+void arena_destroy(dabgpu_ctx *ctx) {
+    unmap_pieces(ctx);
+    Arena &a = ctx->arena;
+    if (a.va) (void)hipMemAddressFree(a.va, a.reserved);
+    (void)hipGetLastError();
+    a.va = nullptr;
+    a.reserved = a.probe_bytes = 0;
+}
+}  // namespace dabapi
+
+extern "C" {
+
+int dabgpu_alloc_frame_buffers(dabgpu_ctx *ctx, int n_frames, size_t frame_stride, int placement, void **d_iq, int8_t **d_soft,
+                               dabgpu_placement_report *report) {
+    if (!ctx || !d_iq || !d_soft || n_frames <= 0) return DABGPU_ERR_ARG;
+    if (placement != DABGPU_PLACE_PLAIN && placement != DABGPU_PLACE_DOMAINS) return DABGPU_ERR_ARG;
+    if (frame_stride < size_t(NB_FRAME_SAMPLES) || (frame_stride & 1u)) return DABGPU_ERR_ARG;
+    if (size_t(n_frames) > size_t(0x7fffffff) / NB_DATA_SYMBOLS) return DABGPU_ERR_ARG;
+    DeviceGuard guard(ctx);
+    *d_iq = nullptr;
+    *d_soft = nullptr;
+    dabgpu_placement_report rep;
+    std::memset(&rep, 0, sizeof(rep));
+    const size_t iq_bytes = size_t(n_frames) * frame_stride * sizeof(float2);
+    const size_t soft_bytes = size_t(n_frames) * NB_FRAME_BITS;
+    Probe p{ctx, ctx->stream};
+    hipError_t herr = hipSuccess;                              // the runtime call that sent the request to the plain path
+    int hstage = 0;                                            // 1 reserve, 2 create, 3 map, 4 set access, 5 re-map, 6 mem info
+    auto plain = [&](int why) {
+        p.drop_all();                                          // (what the probe still holds goes back first)
+        rep.fallback_reason = why;
+        rep.runtime_error = hstage * 1000 + int(herr);
+        return plain_pair(iq_bytes, soft_bytes, d_iq, d_soft, rep, report);
+    };
+    if (placement == DABGPU_PLACE_PLAIN) return plain(DABGPU_PLAIN_REQUESTED);
+    Arena &ar = ctx->arena;
+    if (!ar.pieces.empty()) return plain(DABGPU_PLAIN_ARENA_BUSY);
+    const int n_iq = int((iq_bytes + CH - 1) / CH), n_soft = int((soft_bytes + CS - 1) / CS);
+    // (nothing is gained below a few GB, and rounding to whole chunks would cost too much)
+    if (iq_bytes < 4 * CH || n_iq > 60 || n_soft > 20) return plain(DABGPU_PLAIN_SIZE);
+    // what may be held during set-up: 1.5 x the buffers; a third of the spare as 1 GiB chunks, the rest small
+    const size_t need = size_t(n_iq) * CH + size_t(n_soft) * CS;
+    const size_t budget = size_t(1.5 * double(iq_bytes + soft_bytes));
+    const size_t spare = budget > need ? budget - need : 0;
+    int n_big = n_iq + int(spare / 3 / CH);
+    int n_small = n_soft + int((spare - size_t(n_big - n_iq) * CH) / CS);
+    size_t free_b = 0, total_b = 0;
+    if ((herr = hipMemGetInfo(&free_b, &total_b)) != hipSuccess) { hstage = 6; return plain(DABGPU_PLAIN_NO_VMM); }
+    const size_t may_take = free_b - free_b / 16;
+    while (n_big > n_iq && size_t(n_big) * CH + size_t(n_small) * CS > may_take) n_big--;
+    while (n_small > n_soft && size_t(n_big) * CH + size_t(n_small) * CS > may_take) n_small--;
+    const size_t probe_bytes = size_t(n_big) * CH + size_t(n_small) * CS;
+    if (probe_bytes > may_take || n_big + n_small > 96) return plain(DABGPU_PLAIN_NO_ROOM);
+    // the context's one address range: probe region + the region the pair is mapped in
+    if (!ar.va) {
+        void *va = nullptr;
+        // (+ one chunk of addresses: the soft bits may end on a 1 GiB chunk)
+        if ((herr = hipMemAddressReserve(&va, probe_bytes + need + CH, 0, nullptr, 0)) != hipSuccess) { hstage = 1; (void)hipGetLastError(); return plain(DABGPU_PLAIN_NO_VMM); }
+        ar.va = static_cast<char *>(va);
+        ar.reserved = probe_bytes + need + CH;
+        ar.probe_bytes = probe_bytes;
+    } else if (ar.probe_bytes < probe_bytes || ar.reserved - ar.probe_bytes < need + CH) {
+        return plain(DABGPU_PLAIN_ARENA_SMALL);              // (a larger request than the range was reserved for)
+    }
+    hipStream_t s = ctx->stream;
+    if (hipStreamSynchronize(s) != hipSuccess) return DABGPU_ERR_HIP;
+
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = ctx->device;
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    size_t off = 0;
+    const int n_total = n_big + n_small;
+    for (int i = 0; i < n_total; i++) {
+        const size_t bytes = i < n_big ? CH : CS;
+        hipMemGenericAllocationHandle_t h;
+        if ((herr = hipMemCreate(&h, bytes, &prop, 0)) != hipSuccess) { hstage = 2; (void)hipGetLastError(); return plain(DABGPU_PLAIN_NO_ROOM); }
+        if ((herr = hipMemMap(ar.va + off, bytes, 0, h, 0)) != hipSuccess) {
+            hstage = 3;
+            (void)hipMemRelease(h);
+            (void)hipGetLastError();
+            return plain(DABGPU_PLAIN_NO_VMM);
+        }
+        p.c.push_back(Chunk{h, bytes, off, true, 0});
+        off += bytes;
+    }
+    if ((herr = hipMemSetAccess(ar.va, off, &acc, 1)) != hipSuccess) { hstage = 4; (void)hipGetLastError(); return plain(DABGPU_PLAIN_NO_VMM); }
+    rep.n_chunks = n_total;
+    rep.chunk_bytes = CH;
+    rep.setup_peak_bytes = off;
+
+    // ---- which domain is every chunk in? ----
+    hipEvent_t ec0 = nullptr, ec1 = nullptr;
+    bool ok = hipEventCreate(&p.e0) == hipSuccess && hipEventCreate(&p.e1) == hipSuccess && hipEventCreate(&ec0) == hipSuccess &&
+              hipEventCreate(&ec1) == hipSuccess && dabk::launch_fill_noise(ar.va, off, s) == hipSuccess;
+    int n_dom = 1;
+    if (ok) {
+        (void)hipEventRecord(ec0, s);
+        n_dom = classify(p);
+        ok = n_dom > 0 && hipEventRecord(ec1, s) == hipSuccess && hipEventSynchronize(ec1) == hipSuccess &&
+             hipEventElapsedTime(&rep.classify_ms, ec0, ec1) == hipSuccess;
+    }
+    if (ec0) (void)hipEventDestroy(ec0);
+    if (ec1) (void)hipEventDestroy(ec1);
+    if (!ok) { (void)hipGetLastError(); return plain(DABGPU_PLAIN_PROBE_FAILED); }
+    rep.n_domains = n_dom;
+    for (int i = 0; i < n_total && i < 95; i++) rep.domains[i] = char((i < n_big ? 'A' : 'a') + p.c[size_t(i)].dom);
+
+    // ---- IQ: the domain that can carry the samples alone and leaves enough elsewhere for the soft bits, else the one
+    //      with the most bytes first (1 GiB chunks, then 256 MiB ones); the soft bits, piece by piece: a chunk whose
+    //      domain the samples read beside that piece are not in ----
+    size_t bytes_in[3] = {0, 0, 0};
+    for (const Chunk &x : p.c) bytes_in[x.dom] += x.bytes;
+    int iq_domain = -1;
+    {
+        const size_t all = bytes_in[0] + bytes_in[1] + bytes_in[2];
+        for (int d = 0; d < 3; d++)
+            if (bytes_in[d] >= iq_bytes && all - bytes_in[d] >= soft_bytes && (iq_domain < 0 || bytes_in[d] > bytes_in[iq_domain])) iq_domain = d;
+    }
+    int order[3] = {0, 1, 2};
+    std::sort(order, order + 3, [&](int x, int y) {
+        if ((x == iq_domain) != (y == iq_domain)) return x == iq_domain;
+        return bytes_in[x] != bytes_in[y] ? bytes_in[x] > bytes_in[y] : x < y;
+    });
+    std::vector<int> iq_sel, soft_sel;
+    std::vector<char> used(size_t(n_total), 0);
+    size_t iq_mapped = 0, soft_mapped = 0;
+    for (int k = 0; k < 3 && iq_mapped < iq_bytes; k++)
+        for (int pass = 0; pass < 2 && iq_mapped < iq_bytes; pass++)          // pass 0: 1 GiB chunks, pass 1: 256 MiB ones
+            for (int i = 0; i < n_total && iq_mapped < iq_bytes; i++) {
+                if ((i < n_big) != (pass == 0) || used[size_t(i)] || p.c[size_t(i)].dom != order[k]) continue;
+                if (pass == 0 && iq_bytes - iq_mapped < CH) {
+                    // less than a whole big chunk is missing: small chunks of this domain first, if there are enough
+                    size_t small_left = 0;
+                    for (int j = n_big; j < n_total; j++) if (!used[size_t(j)] && p.c[size_t(j)].dom == order[k]) small_left += CS;
+                    if (small_left >= iq_bytes - iq_mapped) break;
+                }
+                iq_sel.push_back(i);
+                used[size_t(i)] = 1;
+                iq_mapped += p.c[size_t(i)].bytes;
+            }
+    std::vector<size_t> iq_end;
+    { size_t e = 0; for (int i : iq_sel) { e += p.c[size_t(i)].bytes; iq_end.push_back(e); } }
+    auto iq_bytes_by_domain = [&](double lo, double hi, double w[3]) {
+        w[0] = w[1] = w[2] = 0.0;
+        size_t begin = 0;
+        for (size_t k = 0; k < iq_sel.size(); k++) {
+            const double a0 = std::max(lo, double(begin)), a1 = std::min(hi, double(iq_end[k]));
+            if (a1 > a0) w[p.c[size_t(iq_sel[k])].dom] += a1 - a0;
+            begin = iq_end[k];
+        }
+    };
+    const double iq_per_soft = double(frame_stride * sizeof(float2)) / double(NB_FRAME_BITS);
+    const double slack = 1.5 * double(CH);                    // samples of the ~1000 frames in flight
+    double shared = 0.0;
+    while (soft_mapped < soft_bytes) {
+        int best = -1;
+        double best_cost = 0.0;
+        for (int i = 0; i < n_total; i++) {
+            if (used[size_t(i)]) continue;
+            const size_t sz = p.c[size_t(i)].bytes;
+            if (iq_mapped + soft_mapped + sz > ar.reserved - ar.probe_bytes) continue;      // would not fit the pair's region
+            double w[3];
+            iq_bytes_by_domain(double(soft_mapped) * iq_per_soft - slack, double(std::min(soft_bytes, soft_mapped + sz)) * iq_per_soft + slack, w);
+            const double tot = w[0] + w[1] + w[2];
+            const double cost = tot > 0.0 ? w[p.c[size_t(i)].dom] / tot : 0.0;
+            // the least overlap wins; between equals a small chunk (a big one is kept for where it is needed)
+            if (best < 0 || cost < best_cost - 1e-9 || (cost < best_cost + 1e-9 && sz < p.c[size_t(best)].bytes)) { best = i; best_cost = cost; }
+        }
+        if (best < 0) break;
+        soft_sel.push_back(best);
+        used[size_t(best)] = 1;
+        shared += best_cost * double(std::min(p.c[size_t(best)].bytes, soft_bytes - soft_mapped));
+        soft_mapped += p.c[size_t(best)].bytes;
+    }
+    if (iq_mapped < iq_bytes || soft_mapped < soft_bytes || iq_mapped + soft_mapped > ar.reserved - ar.probe_bytes)
+        return plain(DABGPU_PLAIN_NO_ROOM);                    // (~Probe releases every chunk)
+    rep.conflicts = int(1000.0 * shared / double(soft_bytes) + 0.5);
+    rep.iq_chunks = int(iq_sel.size());
+    rep.soft_chunks = int(soft_sel.size());
+    for (size_t k = 0; k < iq_sel.size() && k < 71; k++) rep.iq_map[k] = char((iq_sel[k] < n_big ? 'A' : 'a') + p.c[size_t(iq_sel[k])].dom);
+    for (size_t k = 0; k < soft_sel.size() && k < 23; k++) rep.soft_map[k] = char((soft_sel[k] < n_big ? 'A' : 'a') + p.c[size_t(soft_sel[k])].dom);
+
+    // ---- the chosen chunks move from the probe region to the pair's region of the same range; the others go back ----
+    if (hipStreamSynchronize(s) != hipSuccess) return plain(DABGPU_PLAIN_PROBE_FAILED);
+    size_t dst = ar.probe_bytes;
+    bool mapped_ok = true;
+    auto move = [&](const std::vector<int> &sel) {
+        for (int i : sel) {
+            Chunk &x = p.c[size_t(i)];
+            if (!mapped_ok) break;
+            if (hipMemUnmap(ar.va + x.off, x.bytes) != hipSuccess) { mapped_ok = false; break; }
+            x.mapped = false;
+            if (hipMemMap(ar.va + dst, x.bytes, 0, x.h, 0) != hipSuccess) { mapped_ok = false; break; }
+            ar.pieces.push_back(Arena::Piece{dst, x.bytes, x.h});
+            x.h = nullptr;                                    // owned by the arena from here on
+            dst += x.bytes;
+        }
+    };
+    move(iq_sel);
+    const size_t soft_off = dst;
+    move(soft_sel);
+    if (!mapped_ok || hipMemSetAccess(ar.va + ar.probe_bytes, dst - ar.probe_bytes, &acc, 1) != hipSuccess) {
+        herr = hipGetLastError();
+        hstage = 5;
+        unmap_pieces(ctx);
+        return plain(DABGPU_PLAIN_NO_VMM);
+    }
+    p.drop_all();
+    ar.d_iq = ar.va + ar.probe_bytes;
+    ar.d_soft = ar.va + soft_off;
+    *d_iq = ar.d_iq;
+    *d_soft = static_cast<int8_t *>(ar.d_soft);
+    rep.method = 1;
+    // check of the result, independent of the classification: the mover reads the first GiB of the samples and writes
+    // (a) the start of the soft-bit buffer, (b) into the samples' own buffer two GiB further on (same domain by
+    // construction); alternated, so that drift hits both alike.  Leaves noise-like words in both buffers.
+    {
+        const size_t out_b = std::min(soft_mapped, CH / 6);
+        char *iq0 = static_cast<char *>(*d_iq);
+        float ta = 1e30f, tb = 1e30f;
+        for (int r = 0; r < 3; r++) {
+            const float a = mover_ms(p, iq0, CH, *d_soft, out_b);
+            const float b = mover_ms(p, iq0, CH, iq0 + 2 * CH, out_b);
+            if (a > 0.f) ta = std::min(ta, a);
+            if (b > 0.f) tb = std::min(tb, b);
+        }
+        if (ta < 1e29f && tb < 1e29f) rep.pair_over_same_domain = ta / tb;
+        (void)hipGetLastError();
+    }
+    if (report) *report = rep;
+    return DABGPU_OK;
+}
+
+int dabgpu_free_frame_buffers(dabgpu_ctx *ctx, void *d_iq, int8_t *d_soft) {
+    if (!ctx) return DABGPU_ERR_ARG;
+    DeviceGuard guard(ctx);
+    HIP_TRY(hipDeviceSynchronize());
+    Arena &a = ctx->arena;
+    const bool iq_mapped = d_iq && d_iq == a.d_iq, soft_mapped = d_soft && d_soft == a.d_soft;
+    // the mapped pair goes back together (its two buffers share the arena)
+    if (iq_mapped || soft_mapped) {
+        if ((d_iq && !iq_mapped) || (d_soft && !soft_mapped) || !d_iq || !d_soft) return DABGPU_ERR_ARG;
+        unmap_pieces(ctx);
+        return DABGPU_OK;
+    }
+    if (d_iq) HIP_TRY(hipFree(d_iq));
+    if (d_soft) HIP_TRY(hipFree(d_soft));
+    return DABGPU_OK;
+}
+
+}  // extern "C"

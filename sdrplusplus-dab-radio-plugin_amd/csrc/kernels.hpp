@@ -31,7 +31,11 @@ struct StreamState {
     double next_frame_start;   // first sample (PRS prefix minus margin) of the next frame, relative to the NEXT capture
     float drift;               // samples per frame by which the frame period differs from 196608
     float last_peak_to_mean;
-    int32_t reserved[4];
+    // decision-directed fine loop (dd_loop_error below)
+    int32_t loop_gated;        // calls whose fourth-power estimate was not used as it came (quality gate, branch hold)
+    int32_t dd_branch;         // branch k of the most recent accepted estimate (residual = e_dd + k / (4 2552))
+    int32_t dd_pending;        // a one-step departure from branch 0 seen once (DD_NO_BRANCH: none)
+    int32_t reserved;
 };
 
 struct OfdmArgs {
@@ -78,10 +82,14 @@ hipError_t launch_fill_noise(void *p, size_t bytes, hipStream_t s);
 // reads `in` and writes `out` at the same time (streaming, both whole): the launch is slower when the two buffers
 // share an HBM domain -- what the placement helpers time
 hipError_t launch_placement_probe(const void *in, size_t in_bytes, void *out, size_t out_bytes, hipStream_t s);
+// the fused front end's loads and stores without its arithmetic, same run structure and occupancy (dabgpu_mover_frames_dev)
+hipError_t launch_geometry_mover(const float2 *iq, size_t frame_stride, int n_frames, int8_t *soft, int uncut_frames, int parts,
+                                 bool prefixes, hipStream_t s);
 // dd != 0: `cyc` holds the front end's dd4 output instead; the error is angle(-sum of all entries l >= 1) / (4 * 2 pi * 2552)
+// (dd_gate, dd_terms_per_frame: see dd_loop_error / TrackUpdateArgs)
 hipError_t launch_stream_update(StreamState *state, const float2 *cyc, const float2 *iq, size_t frame_stride,
                                 int n_streams, int frames_per_stream, float beta, float thr_null_start, float signal_beta,
-                                int dd, hipStream_t s);
+                                int dd, float dd_gate, int dd_terms_per_frame, hipStream_t s);
 
 // ---- synchronisation on the PRS (sync_kernels.hip) -----------------------------
 struct SyncTables {
@@ -191,11 +199,41 @@ hipError_t launch_track_sync(const SyncTables &t, const TrackArgs &a, hipStream_
 //               (signal_beta * average + (1 - signal_beta) * level); a level below thr_null_start * average counts one
 //               more desync and leaves the average alone
 //   counts[s]   = count
-// The fourth-power estimate e_dd of a residual frequency offset repeats every 1 / (4 * 2552) cycles per sample; the mean
-// angle of the PRS cyclic-prefix correlations, e_cp (+-1/4096, coarser), picks its branch.  Restated by oracle.dd_error.
-__host__ __device__ inline float dd_unwrap(float e_dd, float e_cp) {
-    const float k = rintf((e_cp - e_dd) * (4.0f * 2552.0f));
-    return e_dd + k * (1.0f / (4.0f * 2552.0f));
+// The decision-directed fine-frequency error of a call (restated by oracle.dd_loop_error).
+//   (sx, sy)  sum of u^4 over the call's differential symbols (unit magnitude each), n_terms of them
+//   e_cp      mean angle of the call's PRS cyclic-prefix correlations / (2 pi 2048): the same residual, coarser, but
+//             unambiguous within half a carrier
+// The fourth-power estimate e_dd = angle(-sum) / (4 2 pi 2552) repeats every 1 / (4 2552) cycles per sample (0.2 carriers);
+// e_cp picks its branch k.  Two things can make that wrong, and both are gated:
+//   quality   |sum| is compared with what n_terms random unit phasors add up to (sqrt(n_terms)): below `gate` times that
+//             (gate > 0; 8 by default) the sum carries no usable phase -- 3 dB SNR and less on single frames, an
+//             interferer, an empty selection -- and the call takes e_cp alone: unbiased, coarser.
+//   branch    a stream that was locked (previous branch 0: residual inside +-0.1 carriers) and now asks for branch +-1
+//             has, far more often than a real 200 Hz jump between two calls, a PRS prefix hit by a fade or an impulse:
+//             the departure must be seen on two consecutive calls before it is believed; the first time the branch is
+//             held at 0.  (While a stream pulls in -- previous branch not 0, or its first call -- everything is believed.)
+// Either gate counts in state.loop_gated.
+constexpr int32_t DD_NO_BRANCH = 0x7fffffff;
+__host__ __device__ inline float dd_loop_error(double sx, double sy, float e_cp, double n_terms, float gate, bool first_call,
+                                               StreamState &st) {
+    const double mag2 = sx * sx + sy * sy;
+    if (!(n_terms > 0.0) || mag2 < double(gate) * double(gate) * n_terms) {
+        st.loop_gated += 1;
+        st.dd_pending = DD_NO_BRANCH;
+        st.dd_branch = int32_t(rintf(e_cp * (4.0f * 2552.0f)));
+        return e_cp;
+    }
+    const float e_dd = float(atan2(-sy, -sx) / (4.0 * 6.283185307179586 * 2552.0));
+    int32_t k = int32_t(rintf((e_cp - e_dd) * (4.0f * 2552.0f)));
+    if (!first_call && st.dd_branch == 0 && (k == 1 || k == -1) && st.dd_pending != k) {
+        st.dd_pending = k;
+        st.loop_gated += 1;
+        k = 0;
+    } else {
+        st.dd_pending = DD_NO_BRANCH;
+    }
+    st.dd_branch = k;
+    return e_dd + float(k) * (1.0f / (4.0f * 2552.0f));
 }
 
 struct TrackUpdateArgs {
@@ -213,6 +251,8 @@ struct TrackUpdateArgs {
     int fixed_start;
     int32_t *counts;           // [n_streams] or nullptr
     int settle_only = 0;       // only turn "started in this call" marks (tracking == 2) into 1
+    float dd_gate = 8.0f;      // dd_loop_error's quality gate
+    int dd_terms_per_frame = 19200;   // unit terms one frame adds to the sums (256 carriers x the symbols that are demodulated)
 };
 hipError_t launch_track_update(const TrackUpdateArgs &a, hipStream_t s);
 // Start tracking from an acquisition result (dabgpu_acquire_dev on the same capture): per stream, a least-squares line

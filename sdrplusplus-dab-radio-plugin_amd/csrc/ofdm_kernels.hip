@@ -517,7 +517,8 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
 constexpr int SU_THREADS = 1024;
 __global__ __launch_bounds__(SU_THREADS) void stream_update_kernel(StreamState *state, const float2 *cyc, const float2 *iq,
                                                                    size_t frame_stride, int frames_per_stream, float beta,
-                                                                   float thr_null_start, float signal_beta, int dd) {
+                                                                   float thr_null_start, float signal_beta, int dd, float dd_gate,
+                                                                   int dd_terms_per_frame) {
     __shared__ float red[2][SU_THREADS / 64];
     __shared__ double red_dd[2][SU_THREADS / 64];
     const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -556,17 +557,21 @@ __global__ __launch_bounds__(SU_THREADS) void stream_update_kernel(StreamState *
         if (dd) {
             sx = 0.0; sy = 0.0;
             for (int w = 0; w < SU_THREADS / 64; w++) { sx += red_dd[0][w]; sy += red_dd[1][w]; }
-            // sum = -A exp(j 4 theta), theta = 2 pi r 2552: r modulo 1 / (4 2552); the branch from the PRS prefixes
-            err = dd_unwrap(float(atan2(-sy, -sx) / (4.0 * 6.283185307179586 * double(NB_SYM_PERIOD))),
-                            acc / float(frames_per_stream) * (1.0f / (6.283185307179586f * float(NB_FFT))));
+            // sum = -A exp(j 4 theta), theta = 2 pi r 2552: r modulo 1 / (4 2552); the branch from the PRS prefixes; gated
+            err = dd_loop_error(sx, sy, acc / float(frames_per_stream) * (1.0f / (6.283185307179586f * float(NB_FFT))),
+                                double(frames_per_stream) * double(dd_terms_per_frame), dd_gate, st.total_frames_read == 0, st);
         }
-        constexpr float HALF = 0.5f / float(NB_FFT);
-        float f = st.fine_freq_offset - beta * err;
-        if (f > HALF) f -= 2.f * HALF;
-        if (f < -HALF) f += 2.f * HALF;
-        st.fine_freq_offset = f;
+        const bool level_lost = st.signal_average > 0.f && l1 < thr_null_start * st.signal_average;
+        // (a call of ONE frame whose level is gone -- a null symbol, a dropout -- has nothing to steer the loop with)
+        if (!(level_lost && frames_per_stream == 1)) {
+            constexpr float HALF = 0.5f / float(NB_FFT);
+            float f = st.fine_freq_offset - beta * err;
+            if (f > HALF) f -= 2.f * HALF;
+            if (f < -HALF) f += 2.f * HALF;
+            st.fine_freq_offset = f;
+        }
         st.last_fine_error = err;
-        if (st.signal_average > 0.f && l1 < thr_null_start * st.signal_average) {
+        if (level_lost) {
             st.total_frames_desync += 1;
             st.total_frames_read += frames_per_stream - 1;
         } else {
@@ -614,6 +619,63 @@ __global__ __launch_bounds__(256) void placement_probe_kernel(const char *in, ch
 }
 }  // namespace
 
+namespace {
+// The fused front end's memory geometry without its arithmetic (dabgpu_mover_frames_dev): the same items (whole frames
+// first, then frames cut into `parts` runs), one wavefront per item, per symbol of the run sixteen 16-byte loads per lane
+// from the useful part (PREFIXES: four more covering the cyclic prefix; else the prefix of symbol 0 only), per data symbol
+// three 16-byte stores per lane; streaming accesses, the same 52 KB of LDS per 4-wave workgroup.
+template <bool PREFIXES>
+__global__ __launch_bounds__(64 * WAVES, 3) void geometry_mover_kernel(const float2 *iq, size_t frame_stride, int8_t *soft,
+                                                                        int uncut_frames, int parts, int n_items) {
+    __shared__ char occupancy[sizeof(WaveLds)];
+    const int lane = threadIdx.x & 63;
+    if (n_items < 0) occupancy[threadIdx.x] = 1;               // (never: keeps the array)
+    const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES + (threadIdx.x >> 6));
+    if (item >= n_items) return;
+    int frame = item, part = 0;
+    if (item >= uncut_frames) {
+        const int j = item - uncut_frames;
+        frame = uncut_frames + j / parts;
+        part = j - (frame - uncut_frames) * parts;
+    } else {
+        parts = 1;
+    }
+    const float2 *fiq = iq + size_t(frame) * frame_stride;
+    const int l_first = (NB_DATA_SYMBOLS * part) / parts, l_last = (NB_DATA_SYMBOLS * (part + 1)) / parts;
+    uint4 acc = make_uint4(1u, 2u, 3u, 4u);
+    for (int l = l_first; l <= l_last; l++) {
+        const float2 *sym = fiq + size_t(l) * NB_SYM_PERIOD;
+        const uint4 *rows = reinterpret_cast<const uint4 *>(sym + NB_CP) + lane;
+        uint4 v[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) v[i] = ld_stream(rows + 64 * i);
+        if (PREFIXES ? (l > l_first || l == 0) : l == 0) {
+            const uint4 *cp = reinterpret_cast<const uint4 *>(sym + 2 * (lane - 4));
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (i > 0 || lane >= 4) { const uint4 c = ld_stream(cp + 64 * i); acc.x += c.x; acc.y ^= c.y; acc.z += c.z; acc.w ^= c.w; }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) { acc.x += v[i].x; acc.y ^= v[i].y; acc.z += v[i].z; acc.w ^= v[i].w; }
+        if (l > l_first) {
+            uint4 *o = reinterpret_cast<uint4 *>(soft + size_t(frame) * NB_FRAME_BITS + size_t(l - 1) * NB_SYM_BITS) + lane;
+            st_stream(o, acc); st_stream(o + 64, acc); st_stream(o + 128, acc);
+        }
+    }
+}
+}  // namespace
+
+hipError_t launch_geometry_mover(const float2 *iq, size_t frame_stride, int n_frames, int8_t *soft, int uncut_frames, int parts,
+                                 bool prefixes, hipStream_t s) {
+    if (n_frames <= 0) return hipSuccess;
+    if (parts <= 0 || parts > NB_DATA_SYMBOLS || uncut_frames < 0 || uncut_frames > n_frames) return hipErrorInvalidValue;
+    const int items = uncut_frames + (n_frames - uncut_frames) * parts;
+    const dim3 grid(unsigned((items + WAVES - 1) / WAVES)), block(64 * WAVES);
+    if (prefixes) hipLaunchKernelGGL(geometry_mover_kernel<true>, grid, block, 0, s, iq, frame_stride, soft, uncut_frames, parts, items);
+    else hipLaunchKernelGGL(geometry_mover_kernel<false>, grid, block, 0, s, iq, frame_stride, soft, uncut_frames, parts, items);
+    return hipGetLastError();
+}
+
 hipError_t launch_placement_probe(const void *in, size_t in_bytes, void *out, size_t out_bytes, hipStream_t s) {
     const size_t n_chunks = std::min<size_t>(std::min(in_bytes / 20480, out_bytes / 3072), size_t(1) << 20);
     if (n_chunks == 0) return hipSuccess;
@@ -632,10 +694,10 @@ hipError_t launch_fill_noise(void *p, size_t bytes, hipStream_t s) {
 
 hipError_t launch_stream_update(StreamState *state, const float2 *cyc, const float2 *iq, size_t frame_stride,
                                 int n_streams, int frames_per_stream, float beta, float thr_null_start, float signal_beta,
-                                int dd, hipStream_t s) {
+                                int dd, float dd_gate, int dd_terms_per_frame, hipStream_t s) {
     if (n_streams <= 0 || frames_per_stream <= 0) return hipSuccess;
     hipLaunchKernelGGL(stream_update_kernel, dim3(unsigned(n_streams)), dim3(SU_THREADS), 0, s, state, cyc, iq, frame_stride,
-                       frames_per_stream, beta, thr_null_start, signal_beta, dd);
+                       frames_per_stream, beta, thr_null_start, signal_beta, dd, dd_gate, dd_terms_per_frame);
     return hipGetLastError();
 }
 

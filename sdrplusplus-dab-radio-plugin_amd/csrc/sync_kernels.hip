@@ -363,8 +363,13 @@ constexpr int TU = 1024;          // threads per stream: the kernel is one workg
 __global__ __launch_bounds__(TU) void track_update_kernel(TrackUpdateArgs a) {
     __shared__ double red[7][TU];
     __shared__ int red_last[TU];
+    __shared__ StreamState st_in;
     const int s = blockIdx.x, tid = threadIdx.x;
-    StreamState st = a.state[s];
+    // one thread reads the state for everybody: thread 0 writes it back further down (and at once in the branch below),
+    // and a wavefront scheduled late must not see that write
+    if (tid == 0) st_in = a.state[s];
+    __syncthreads();
+    StreamState st = st_in;
     if (!a.fixed_start && st.tracking == 2) {                  // started in this very call (auto-acquisition): nothing to update
         if (tid == 0) a.state[s].tracking = 1;
         return;
@@ -441,21 +446,26 @@ __global__ __launch_bounds__(TU) void track_update_kernel(TrackUpdateArgs a) {
     ang0 = red[1][0];
     const int n_locked = int(sn);
     int desync = (a.fixed_start ? 0 : pr.j0) + (count - n_locked);
+    bool level_lost = false;
     if (n_locked > 0) {
         // fine-frequency loop
         float err = float(sang / (sn * double(NB_FRAME_SYMBOLS))) * (1.0f / (6.283185307179586f * float(NB_FFT)));
         if (a.dd)
-            err = dd_unwrap(float(atan2(-sang2, -sang) / (4.0 * 6.283185307179586 * double(NB_SYM_PERIOD))),
-                            float(ang0 / sn) * (1.0f / (6.283185307179586f * float(NB_FFT))));
-        constexpr float HALF = 0.5f / float(NB_FFT);
-        float f = st.fine_freq_offset - a.fine_beta * err;
-        if (f > HALF) f -= 2.f * HALF;
-        if (f < -HALF) f += 2.f * HALF;
-        st.fine_freq_offset = f;
+            err = dd_loop_error(sang, sang2, float(ang0 / sn) * (1.0f / (6.283185307179586f * float(NB_FFT))),
+                                sn * double(a.dd_terms_per_frame), a.dd_gate, st.total_frames_read == 0, st);
+        level_lost = st.signal_average > 0.f && l1 < a.thr_null_start * st.signal_average;
+        // (ONE locked frame whose level is gone has nothing to steer the loop with)
+        if (!(level_lost && n_locked == 1)) {
+            constexpr float HALF = 0.5f / float(NB_FFT);
+            float f = st.fine_freq_offset - a.fine_beta * err;
+            if (f > HALF) f -= 2.f * HALF;
+            if (f < -HALF) f += 2.f * HALF;
+            st.fine_freq_offset = f;
+        }
         st.last_fine_error = err;
         if (!a.fixed_start) st.last_time_offset = int32_t(fr[last].start - __double2ll_rn(pr.at(last)));
         st.last_peak_to_mean = fr[last].peak_to_mean;
-        if (st.signal_average > 0.f && l1 < a.thr_null_start * st.signal_average) desync++;
+        if (level_lost) desync++;
         else st.signal_average = st.signal_average > 0.f ? a.signal_beta * st.signal_average + (1.0f - a.signal_beta) * l1 : l1;
     }
     if (!a.fixed_start) {
@@ -477,7 +487,7 @@ __global__ __launch_bounds__(TU) void track_update_kernel(TrackUpdateArgs a) {
         st.next_frame_start = pr.at(count) + alpha + slope * double(count) - double(a.advance);
         st.drift = float(double(st.drift) + gain * slope_hat);
     }
-    st.total_frames_read += n_locked;
+    st.total_frames_read += n_locked - (level_lost ? 1 : 0);      // (a frame whose level is gone counts as lost, not as read)
     st.total_frames_desync += desync;
     a.state[s] = st;
     if (a.counts) a.counts[s] = count;

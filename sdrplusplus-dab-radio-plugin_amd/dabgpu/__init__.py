@@ -42,12 +42,16 @@ EXPORTS = [
     "dabgpu_streams_reset", "dabgpu_stream_states", "dabgpu_set_stream_offsets", "dabgpu_ofdm_demod_streams_dev",
     "dabgpu_ofdm_demod_streams", "dabgpu_get_stats", "dabgpu_mean_kernel_ms", "dabgpu_decode_stream_frames",
     "dabgpu_decode_stream_reset", "dabgpu_alloc_frame_buffers", "dabgpu_free_frame_buffers",
-    "dabgpu_device_alloc_apart", "dabgpu_device_free",
-    "dabgpu_set_stream_loop", "dabgpu_track_default_cfg", "dabgpu_track_start_dev", "dabgpu_ofdm_demod_tracked_dev",
-    "dabgpu_ofdm_demod_stream_frame", "dabgpu_alloc_frame_buffers_placed", "dabgpu_ofdm_demod_frames_dd_dev",
+    "dabgpu_mover_frames_dev", "dabgpu_pipe_open", "dabgpu_pipe_submit", "dabgpu_pipe_wait", "dabgpu_pipe_reset", "dabgpu_pipe_close",
+    "dabgpu_set_stream_loop", "dabgpu_set_loop_gate", "dabgpu_track_default_cfg", "dabgpu_track_start_dev", "dabgpu_ofdm_demod_tracked_dev",
+    "dabgpu_ofdm_demod_stream_frame", "dabgpu_ofdm_demod_frames_dd_dev",
 ]
 
-ABI_VERSION = 4
+ABI_VERSION = 5
+PLACE_PLAIN, PLACE_DOMAINS = 0, 1
+PLAIN_REASONS = {0: "plain requested", 1: "buffers too small (or too many chunks) for placement", 2: "virtual-memory API refused",
+                 3: "no room for the chunks", 4: "the context's domain-aware pair is still alive",
+                 5: "larger than the context's reserved address range", 6: "probe launch failed"}
 FLAG_VITERBI_WAVE = 1 << 0
 FLAG_VITERBI_LANE = 1 << 1
 FLAG_LANE_UNFUSED = 1 << 2
@@ -82,7 +86,7 @@ class Stats(C.Structure):
                 ("net_freq_offset", C.c_float), ("signal_average", C.c_float), ("total_frames_read", C.c_int32),
                 ("total_frames_desync", C.c_int32), ("last_fine_error", C.c_float), ("tracking", C.c_int32),
                 ("last_time_offset", C.c_int32), ("next_frame_start", C.c_double), ("drift", C.c_float),
-                ("last_peak_to_mean", C.c_float)]
+                ("last_peak_to_mean", C.c_float), ("loop_gated", C.c_int32), ("reserved", C.c_int32)]
 
 
 STREAM_STATE_DTYPE = np.dtype([("fine_freq_offset", np.float32), ("coarse_freq_offset", np.float32),
@@ -90,7 +94,8 @@ STREAM_STATE_DTYPE = np.dtype([("fine_freq_offset", np.float32), ("coarse_freq_o
                                ("total_frames_read", np.int32), ("total_frames_desync", np.int32),
                                ("tracking", np.int32), ("last_time_offset", np.int32),
                                ("next_frame_start", np.float64), ("drift", np.float32), ("last_peak_to_mean", np.float32),
-                               ("reserved", np.int32, (4,))])     # 64 bytes, device-resident
+                               ("loop_gated", np.int32), ("dd_branch", np.int32), ("dd_pending", np.int32),
+                               ("reserved", np.int32)])     # 64 bytes, device-resident
 assert STREAM_STATE_DTYPE.itemsize == 64
 
 
@@ -110,15 +115,16 @@ class TrackCfg(C.Structure):
     _fields_ = [("fine_freq_update_beta", C.c_float), ("signal_update_beta", C.c_float), ("thr_null_start", C.c_float),
                 ("min_peak_to_mean", C.c_float), ("impulse_peak_distance_probability", C.c_float),
                 ("first_path_rel", C.c_float), ("drift_beta", C.c_float), ("coarse_freq_slow_beta", C.c_float),
-                ("timing_margin", C.c_int32), ("max_coarse_carriers", C.c_int32), ("decision_directed", C.c_int32), ("auto_acquire", C.c_int32)]
+                ("timing_margin", C.c_int32), ("max_coarse_carriers", C.c_int32), ("decision_directed", C.c_int32), ("auto_acquire", C.c_int32),
+                ("dd_gate", C.c_float), ("reserved", C.c_int32)]
 
 
 class PlacementReport(C.Structure):
-    _fields_ = [("method", C.c_int32), ("n_chunks", C.c_int32), ("iq_chunks", C.c_int32), ("soft_chunks", C.c_int32),
-                ("n_domains", C.c_int32), ("conflicts", C.c_int32), ("chunk_bytes", C.c_uint64), ("setup_peak_bytes", C.c_uint64),
-                ("classify_ms", C.c_float), ("front_end_ms", C.c_float), ("pair_over_same_domain", C.c_float), ("reserved", C.c_float),
-                ("domains", C.c_char * 72), ("iq_map", C.c_char * 72),
-                ("soft_map", C.c_char * 24)]
+    _fields_ = [("method", C.c_int32), ("fallback_reason", C.c_int32), ("n_chunks", C.c_int32), ("iq_chunks", C.c_int32),
+                ("soft_chunks", C.c_int32), ("n_domains", C.c_int32), ("conflicts", C.c_int32), ("runtime_error", C.c_int32),
+                ("chunk_bytes", C.c_uint64), ("setup_peak_bytes", C.c_uint64),
+                ("classify_ms", C.c_float), ("pair_over_same_domain", C.c_float),
+                ("domains", C.c_char * 100), ("iq_map", C.c_char * 72), ("soft_map", C.c_char * 28)]
 
 
 class FrameResult(C.Structure):
@@ -229,12 +235,16 @@ def load_library(path):
     L.dabgpu_ofdm_demod_acquired_dev.argtypes = [vp, vp, sz, i, i, vp, vp, vp, vp, vp]
     L.dabgpu_last_kernel_ms.argtypes = [vp, i, C.POINTER(C.c_float)]
     L.dabgpu_mean_kernel_ms.argtypes = [vp, i, C.POINTER(C.c_float), C.POINTER(C.c_int)]
-    L.dabgpu_alloc_frame_buffers.argtypes = [vp, i, sz, i, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_float), C.POINTER(i)]
+    L.dabgpu_alloc_frame_buffers.argtypes = [vp, i, sz, i, C.POINTER(vp), C.POINTER(vp), C.POINTER(PlacementReport)]
     L.dabgpu_free_frame_buffers.argtypes = [vp, vp, vp]
-    L.dabgpu_alloc_frame_buffers_placed.argtypes = [vp, i, sz, C.POINTER(vp), C.POINTER(vp), C.POINTER(PlacementReport)]
-    L.dabgpu_device_alloc_apart.argtypes = [vp, sz, vp, sz, C.POINTER(vp), C.POINTER(C.c_float)]
-    L.dabgpu_device_free.argtypes = [vp, vp]
+    L.dabgpu_mover_frames_dev.argtypes = [vp, vp, sz, i, vp, i, vp]
+    L.dabgpu_pipe_open.argtypes = [vp, i, i, sz]
+    L.dabgpu_pipe_submit.argtypes = [vp, vp, i, i, vp, C.c_float, vp, i, vp, vp, vp, vp, C.POINTER(C.c_int64)]
+    L.dabgpu_pipe_wait.argtypes = [vp, C.c_int64]
+    L.dabgpu_pipe_reset.argtypes = [vp]
+    L.dabgpu_pipe_close.argtypes = [vp]
     L.dabgpu_set_stream_loop.argtypes = [vp, C.c_float, C.c_float, i]
+    L.dabgpu_set_loop_gate.argtypes = [vp, C.c_float]
     L.dabgpu_track_default_cfg.restype = None
     L.dabgpu_track_default_cfg.argtypes = [C.POINTER(TrackCfg)]
     L.dabgpu_track_start_dev.argtypes = [vp, vp, vp, i, i, C.c_int64, i, vp]
@@ -426,38 +436,47 @@ class Context:
         return ms.value, n.value
 
     # ---- closed-loop stream call
-    def alloc_frame_buffers(self, n_frames, frame_stride=NB_FRAME_SAMPLES, candidates=3):
-        """Device buffers for [n_frames][frame_stride] cf32 samples and [n_frames][230400] soft bits whose HBM
-        placement suits the front end (dabgpu_alloc_frame_buffers).  Returns (d_iq, d_soft, probe table or None, kept
-        pair): raw device addresses; release with free_frame_buffers."""
-        d_iq, d_soft = C.c_void_p(), C.c_void_p()
-        table = (C.c_float * (candidates * candidates))()
-        kept = (C.c_int * 2)()
-        _check(self._lib.dabgpu_alloc_frame_buffers(self._h, n_frames, frame_stride, candidates, C.byref(d_iq), C.byref(d_soft),
-                                                    table, kept), "dabgpu_alloc_frame_buffers")
-        t = np.array(table, dtype=np.float32).reshape(candidates, candidates)
-        return d_iq.value, d_soft.value, (t if candidates > 1 else None), (int(kept[0]), int(kept[1]))
-
-    def alloc_frame_buffers_placed(self, n_frames, frame_stride=NB_FRAME_SAMPLES):
-        """The same pair of buffers placed by HBM domain inside 1.2 x their size (dabgpu_alloc_frame_buffers_placed).
-        -> (d_iq, d_soft, PlacementReport); release with free_frame_buffers."""
+    def alloc_frame_buffers(self, n_frames, frame_stride=NB_FRAME_SAMPLES, placement=PLACE_PLAIN):
+        """Device buffers for [n_frames][frame_stride] cf32 samples and [n_frames][230400] soft bits
+        (dabgpu_alloc_frame_buffers): two hipMallocs, or (PLACE_DOMAINS) placed by HBM domain inside 1.5 x their size.
+        -> (d_iq, d_soft, PlacementReport): raw device addresses; release with free_frame_buffers."""
         d_iq, d_soft = C.c_void_p(), C.c_void_p()
         rep = PlacementReport()
-        _check(self._lib.dabgpu_alloc_frame_buffers_placed(self._h, n_frames, frame_stride, C.byref(d_iq), C.byref(d_soft),
-                                                       C.byref(rep)), "dabgpu_alloc_frame_buffers_placed")
+        _check(self._lib.dabgpu_alloc_frame_buffers(self._h, n_frames, frame_stride, placement, C.byref(d_iq), C.byref(d_soft),
+                                                    C.byref(rep)), "dabgpu_alloc_frame_buffers")
         return d_iq.value, d_soft.value, rep
 
-    def device_alloc_apart(self, nbytes, d_other=None, other_bytes=0):
-        """A device buffer that a launch can write while it reads `d_other` without the two sharing an HBM domain
-        (dabgpu_device_alloc_apart).  Returns (address, [three probe times in ms]); release with device_free."""
-        out = C.c_void_p()
-        ms = (C.c_float * 3)()
-        _check(self._lib.dabgpu_device_alloc_apart(self._h, nbytes, d_other, other_bytes, C.byref(out), ms),
-               "dabgpu_device_alloc_apart")
-        return out.value, [float(x) for x in ms]
+    def mover_frames_dev(self, d_iq, frame_stride, n_frames, d_soft, with_prefixes=False, stream=None):
+        """The front end's loads and stores without its arithmetic (dabgpu_mover_frames_dev); overwrites d_soft."""
+        _check(self._lib.dabgpu_mover_frames_dev(self._h, d_iq, frame_stride, n_frames, d_soft, 1 if with_prefixes else 0, stream),
+               "dabgpu_mover_frames_dev")
 
-    def device_free(self, d_ptr):
-        _check(self._lib.dabgpu_device_free(self._h, d_ptr), "dabgpu_device_free")
+    # ---- host-fed ring
+    def pipe_open(self, slots, max_frames, frame_stride=FRAME_USED_SAMPLES):
+        _check(self._lib.dabgpu_pipe_open(self._h, slots, max_frames, frame_stride), "dabgpu_pipe_open")
+
+    def pipe_submit(self, iq, n_streams, frames_per_stream, freq_offset, scs, soft, fib, crc_ok, outs, beta=0.9):
+        """Enqueue one batch (dabgpu_pipe_submit).  Every array argument is a numpy array (or None for freq_offset / soft)
+        that the CALLER keeps alive and untouched until pipe_wait(ticket); page-locked ones (PinnedArray.array) move at the
+        link rate.  -> ticket"""
+        n = len(scs)
+        arr = (Subchannel * max(n, 1))(*scs)
+        ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in outs]) if n else None
+        t = C.c_int64(-1)
+        _check(self._lib.dabgpu_pipe_submit(self._h, iq.ctypes.data, n_streams, frames_per_stream,
+                                            None if freq_offset is None else freq_offset.ctypes.data, beta, arr, n,
+                                            None if soft is None else soft.ctypes.data, fib.ctypes.data, crc_ok.ctypes.data, ptrs,
+                                            C.byref(t)), "dabgpu_pipe_submit")
+        return t.value
+
+    def pipe_wait(self, ticket):
+        _check(self._lib.dabgpu_pipe_wait(self._h, ticket), "dabgpu_pipe_wait")
+
+    def pipe_reset(self):
+        _check(self._lib.dabgpu_pipe_reset(self._h), "dabgpu_pipe_reset")
+
+    def pipe_close(self):
+        _check(self._lib.dabgpu_pipe_close(self._h), "dabgpu_pipe_close")
 
     def free_frame_buffers(self, d_iq, d_soft):
         _check(self._lib.dabgpu_free_frame_buffers(self._h, d_iq, d_soft), "dabgpu_free_frame_buffers")
@@ -482,6 +501,18 @@ class Context:
     def set_stream_loop(self, signal_update_beta=0.95, thr_null_start=0.35, decision_directed=False):
         _check(self._lib.dabgpu_set_stream_loop(self._h, signal_update_beta, thr_null_start, int(bool(decision_directed))),
                "dabgpu_set_stream_loop")
+
+    def stream_states_host(self, n_streams):
+        """The first n_streams stream states as a numpy record array (STREAM_STATE_DTYPE), read back after waiting for the
+        context stream.  The caller syncs whatever other stream the last stream call ran on."""
+        import torch
+        self.sync()
+        t = device_tensor(torch, self.stream_states_ptr, (n_streams * 64,), torch.uint8, torch.device("cuda", self._device))
+        torch.cuda.synchronize()
+        return t.cpu().numpy().view(STREAM_STATE_DTYPE).copy()
+
+    def set_loop_gate(self, dd_gate):
+        _check(self._lib.dabgpu_set_loop_gate(self._h, dd_gate), "dabgpu_set_loop_gate")
 
     def track_start_dev(self, d_frames, d_counts, n_streams, max_frames, advance, stream=None, only_lost=False):
         _check(self._lib.dabgpu_track_start_dev(self._h, d_frames, d_counts, n_streams, max_frames, advance, int(bool(only_lost)),

@@ -16,7 +16,7 @@ def test_header_symbols_are_all_exported(built):
     L = dabgpu.lib()
     for sym in declared:
         assert hasattr(L, sym), sym
-    assert L.dabgpu_abi_version() == dabgpu.ABI_VERSION == 4
+    assert L.dabgpu_abi_version() == dabgpu.ABI_VERSION == 5
     # the binding declares every entry point's argument types (an undeclared pointer argument would be passed as a C int)
     assert [n for n in dabgpu.EXPORTS if getattr(L, n).argtypes is None] == []
 

@@ -1,0 +1,183 @@
+"""The decision-directed fine-frequency loop where fourth-power estimators fail -- low SNR, Doppler, a CW interferer -- and
+its two gates (quality, branch hold; dabk::dd_loop_error restated by oracle.dd_loop_error).
+
+not gpu: the restatement's own logic on constructed sums.
+gpu:     per scenario, one frame per call (the plugin's use, the hardest case for the gate: 19200 terms) and four frames
+         per call: the device state after EVERY call equals the oracle's (fine offset to 2e-9, gate counter and branch
+         exactly); the loop stays as close to the true offset as the loop on the cyclic-prefix correlations (the
+         reference's estimator) does on the same samples, within the stated margin; every frame the cyclic-prefix loop
+         decodes to the transmitted FIBs, the gated loop decodes too."""
+import numpy as np
+import pytest
+
+import dabgpu
+from dabgpu import synth
+from oracle import oracle as O
+from conftest import make_ctx
+
+USED = 76 * 2552
+STEP = 2048.0 / (4 * 2552.0)      # the fourth-power estimate's ambiguity, carriers (0.2006)
+
+
+def _rows(sum4, e_cp_carriers, frames=1):
+    """dd4 rows whose fourth-power sum is `sum4` (complex, split evenly) and whose PRS correlations point at e_cp"""
+    rows = np.zeros((frames, 76), np.complex128)
+    rows[:, 0] = np.exp(2j * np.pi * 2048.0 * (e_cp_carriers / 2048.0))
+    rows[:, 75] = sum4 / frames
+    return rows
+
+
+def test_quality_gate_and_branch_hold_logic():
+    st = {"total_frames_read": 10, "loop_gated": 0, "dd_branch": 0, "dd_pending": 0}
+    n = 19200.0
+    theta = lambda carriers: 2 * np.pi * (carriers / 2048.0) * 2552.0            # noqa: E731
+    strong = lambda c: -0.5 * n * np.exp(4j * theta(c))                          # noqa: E731  quality 0.5
+    # a good sum: e_dd itself, branch 0, nothing gated
+    err, g = O.dd_loop_error(_rows(strong(0.03), 0.03), st)
+    assert abs(float(err) * 2048 - 0.03) < 1e-4 and g == {"loop_gated": 0, "dd_branch": 0, "dd_pending": O.DD_NO_BRANCH}
+    # below 8 sigma of what 19200 random phases add up to: the PRS prefix alone, counted
+    weak = -7.9 * np.sqrt(n) * np.exp(4j * theta(0.03))
+    err, g = O.dd_loop_error(_rows(weak, 0.05), st)
+    assert abs(float(err) * 2048 - 0.05) < 1e-6 and g["loop_gated"] == 1 and g["dd_pending"] == O.DD_NO_BRANCH
+    ok = -8.1 * np.sqrt(n) * np.exp(4j * theta(0.03))
+    err, g = O.dd_loop_error(_rows(ok, 0.05), st)
+    assert abs(float(err) * 2048 - 0.03) < 1e-4 and g["loop_gated"] == 0
+    # four frames: four times the terms, twice the threshold
+    err, g = O.dd_loop_error(_rows(2 * ok * 0.98, 0.05, frames=4), st)
+    assert g["loop_gated"] == 1
+    err, g = O.dd_loop_error(_rows(2 * ok * 1.0, 0.05, frames=4), st)
+    assert g["loop_gated"] == 0
+    # an empty sum (nothing selected, every carrier erased): never an angle of (-0, -0)
+    err, g = O.dd_loop_error(_rows(0.0, -0.02), st)
+    assert abs(float(err) * 2048 + 0.02) < 1e-6 and g["loop_gated"] == 1
+    err, g = O.dd_loop_error(_rows(0.0, -0.02), st, gate=0.0, terms_per_frame=0)
+    assert abs(float(err) * 2048 + 0.02) < 1e-6 and g["loop_gated"] == 1
+    # gate 0: the quality gate is off
+    err, g = O.dd_loop_error(_rows(weak, 0.05), st, gate=0.0)
+    assert abs(float(err) * 2048 - 0.03) < 1e-4 and g["loop_gated"] == 0
+    # branch hold: locked (branch 0), the prefix suddenly says +0.21 carriers while the fourth power says +0.01 (mod 0.2)
+    err, g = O.dd_loop_error(_rows(strong(0.01), 0.21), st)
+    assert abs(float(err) * 2048 - 0.01) < 1e-4 and g == {"loop_gated": 1, "dd_branch": 0, "dd_pending": 1}
+    # ... the next call says so again: believed
+    st2 = dict(st, **g)
+    err, g2 = O.dd_loop_error(_rows(strong(0.01), 0.21), st2)
+    assert abs(float(err) * 2048 - 0.01 - STEP) < 1e-4 and g2 == {"loop_gated": 1, "dd_branch": 1, "dd_pending": O.DD_NO_BRANCH}
+    # ... or it does not: the hold was right, nothing pending any more
+    err, g3 = O.dd_loop_error(_rows(strong(0.01), 0.01), st2)
+    assert abs(float(err) * 2048 - 0.01) < 1e-4 and g3 == {"loop_gated": 1, "dd_branch": 0, "dd_pending": O.DD_NO_BRANCH}
+    # the other side is a new departure, not a confirmation
+    err, g4 = O.dd_loop_error(_rows(strong(0.01), -0.19), st2)
+    assert abs(float(err) * 2048 - 0.01) < 1e-4 and g4 == {"loop_gated": 2, "dd_branch": 0, "dd_pending": -1}
+    # pulling in: a stream's first call, or a previous branch that was not 0, believes everything
+    first = dict(st, total_frames_read=0)
+    err, g = O.dd_loop_error(_rows(strong(0.01), 0.21), first)
+    assert abs(float(err) * 2048 - 0.01 - STEP) < 1e-4 and g["loop_gated"] == 0 and g["dd_branch"] == 1
+    err, g = O.dd_loop_error(_rows(strong(0.01), 0.21), dict(st, dd_branch=2))
+    assert abs(float(err) * 2048 - 0.01 - STEP) < 1e-4 and g["loop_gated"] == 0
+    # two steps at once are not the one-step event the hold is for
+    err, g = O.dd_loop_error(_rows(strong(0.01), 0.41), st)
+    assert abs(float(err) * 2048 - 0.01 - 2 * STEP) < 1e-4 and g["loop_gated"] == 0 and g["dd_branch"] == 2
+
+
+def test_single_frame_without_level_steers_nothing():
+    """A call of ONE frame whose level has dropped below thresh_null_start x the running average (a dropout) counts as a
+    lost frame and leaves the fine offset where it was."""
+    rng = np.random.default_rng(3)
+    quiet = (0.01 * (rng.standard_normal(USED) + 1j * rng.standard_normal(USED))).astype(np.complex64)
+    st = {"fine_freq_offset": np.float32(1e-5), "coarse_freq_offset": np.float32(0), "signal_average": np.float32(1.0),
+          "total_frames_read": 7, "total_frames_desync": 0}
+    rows = _rows(-0.5 * 19200 * np.exp(4j * 2 * np.pi * (0.05 / 2048) * 2552), 0.05)
+    new = O.stream_update(st, rows, quiet, 0.9, dd=True)
+    assert new["fine_freq_offset"] == st["fine_freq_offset"] and new["total_frames_desync"] == 1 and new["total_frames_read"] == 7
+    assert new["signal_average"] == st["signal_average"]
+    # among several frames the (last) quiet one is counted, and the loop moves on the others
+    new = O.stream_update(st, np.concatenate([rows, rows]), quiet, 0.9, dd=True)
+    assert new["fine_freq_offset"] != st["fine_freq_offset"] and new["total_frames_desync"] == 1 and new["total_frames_read"] == 8
+
+
+# ------------------------------------------------------------------------------------------------------------ GPU
+SCENARIOS = {
+    # name: (snr_db, fading_hz, cw_dbc)
+    "awgn_5dB": (5.0, 0.0, None),
+    "awgn_3dB": (3.0, 0.0, None),
+    "awgn_0dB": (0.0, 0.0, None),
+    "rayleigh_25Hz": (15.0, 25.0, None),
+    "rayleigh_60Hz": (15.0, 60.0, None),
+    "cw_minus10dBc": (15.0, 0.0, -10.0),
+}
+CFO = 0.07          # carriers, unknown to the receiver
+N_FRAMES = 16
+
+
+def _scenario(ensemble, ensemble_iq, name):
+    snr, fading, cw = SCENARIOS[name]
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    reps = (N_FRAMES + ensemble.n_frames - 1) // ensemble.n_frames
+    tx = np.tile(ensemble_iq, (reps, 1))[:N_FRAMES].ravel()
+    if cw is not None:                    # a carrier 37.3 carriers above the centre, inside the 256 the estimator looks at
+        n = np.arange(tx.size)
+        tx = tx + np.sqrt(10 ** (cw / 10)) * np.exp(2j * np.pi * (37.3 / 2048.0) * n + 1.0j)
+    rx = synth.channel(tx, snr_db=snr, cfo=CFO / 2048.0, rng=rng, fading_hz=fading, rice_k=0.0).reshape(N_FRAMES, -1)
+    return np.ascontiguousarray(rx[:, synth.NB_NULL - 16:synth.NB_NULL - 16 + USED])
+
+
+def _state0():
+    return {"fine_freq_offset": np.float32(0), "coarse_freq_offset": np.float32(0), "signal_average": np.float32(0),
+            "total_frames_read": 0, "total_frames_desync": 0, "loop_gated": 0, "dd_branch": 0, "dd_pending": 0}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("per_call", [1, 4])
+@pytest.mark.parametrize("name", list(SCENARIOS))
+def test_gated_loop_equals_the_oracle_and_keeps_up_with_the_prefix_loop(built, ensemble, ensemble_iq, name, per_call):
+    import torch
+    dev = torch.device("cuda", 0)
+    frames = _scenario(ensemble, ensemble_iq, name)
+    d_iq = torch.from_numpy(frames).to(dev)
+    soft = torch.zeros((per_call, dabgpu.NB_FRAME_BITS), dtype=torch.int8, device=dev)
+    soft_cp = torch.zeros_like(soft)
+    cyc = torch.zeros((per_call, 76), dtype=torch.complex64, device=dev)
+    dd, cp = make_ctx(None, 8), make_ctx(None, 8)
+    for c in (dd, cp):
+        c.streams_reset(1)
+    dd.set_stream_loop(decision_directed=True)
+    state = _state0()
+    dev_dd, dev_cp, ok_dd, ok_cp = [], [], [], []
+    for k in range(N_FRAMES // per_call):
+        lo = k * per_call
+        base = d_iq.data_ptr() + lo * USED * 8
+        torch.cuda.synchronize()
+        dd.ofdm_demod_streams_dev(base, USED, 1, per_call, 0.9, soft.data_ptr(), None, None)
+        cp.ofdm_demod_streams_dev(base, USED, 1, per_call, 0.9, soft_cp.data_ptr(), cyc.data_ptr(), None)
+        dd.sync(); cp.sync()
+        odd = np.stack([O.ofdm_demod_frame_dd(frames[lo + f], float(state["fine_freq_offset"]))[1] for f in range(per_call)])
+        state = O.stream_update(state, odd, frames[lo + per_call - 1], 0.9, dd=True)
+        rec = dd.stream_states_host(1)[0]
+        assert abs(float(rec["fine_freq_offset"]) - float(state["fine_freq_offset"])) <= 2e-9, (name, k)
+        assert int(rec["loop_gated"]) == state["loop_gated"] and int(rec["dd_branch"]) == state["dd_branch"], (name, k)
+        assert int(rec["dd_pending"]) == state["dd_pending"], (name, k)
+        assert int(rec["total_frames_read"]) == state["total_frames_read"] and int(rec["total_frames_desync"]) == state["total_frames_desync"]
+        dev_dd.append(float(rec["fine_freq_offset"]) * 2048 + CFO)
+        dev_cp.append(cp.get_stats(0).fine_freq_offset * 2048 + CFO)
+        for ctx_, s_, okl in ((dd, soft, ok_dd), (cp, soft_cp, ok_cp)):
+            fib, ok = ctx_.fic_decode(s_.cpu().numpy())
+            for f in range(per_call):
+                okl.append(bool(ok[f].all()) and bool((fib[f] == ensemble.fibs[(lo + f) % ensemble.n_frames]).all()))
+    settle = 3 if per_call == 1 else 1                       # calls the loops get to pull in from 0.07 carriers
+    worst_dd = max(abs(v) for v in dev_dd[settle:])
+    worst_cp = max(abs(v) for v in dev_cp[settle:])
+    print("%-15s %d/call: |offset - truth| after settling: gated loop %.4f, prefix loop %.4f carriers; gated %d of %d calls; "
+          "frames decoded %d (prefix loop %d) of %d" % (name, per_call, worst_dd, worst_cp, state["loop_gated"], len(dev_dd),
+                                                       sum(ok_dd), sum(ok_cp), N_FRAMES))
+    # never further from the truth than the reference-shaped loop is on the same samples, give or take 0.02 carriers
+    # (20 Hz: 2 % of the carrier spacing, far inside what the demodulator tolerates)
+    assert worst_dd <= worst_cp + 0.02, (name, worst_dd, worst_cp)
+    # every frame the prefix loop decodes to the transmitted FIBs, the gated loop decodes too
+    for i, (a, b) in enumerate(zip(ok_dd, ok_cp)):
+        assert a or not b, (name, i)
+    if name == "awgn_0dB" and per_call == 1:
+        assert state["loop_gated"] >= len(dev_dd) - 2         # single frames at 0 dB: the fourth power has nothing to say
+    if name in ("awgn_5dB", "cw_minus10dBc") and per_call == 4:
+        assert state["loop_gated"] == 0
+    dd.close(); cp.close()

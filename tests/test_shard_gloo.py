@@ -68,8 +68,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _run_bench(nproc, extra_env=None, ensembles=4, frames=16, more=()):
     env = dict(os.environ)
     env.update(extra_env or {})
-    args = ["--ensembles", str(ensembles), "--frames", str(frames), "--steps", "2", "--warmup", "1", "--cpu-seconds", "0",
-            "--no-fft-stage", "--no-selective", "--no-closed-loop", "--no-sustained"] + list(more)
+    args = ["--ensembles", str(ensembles), "--frames", str(frames), "--steps", "2", "--warmup", "1", "--legs", "none"] + list(more)
     if nproc == 1 and not (extra_env or {}).get("DABGPU_DIST_FORCE"):
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + args
     else:
@@ -87,7 +86,7 @@ def _plain_bench(gpus, env_extra, timeout=900):
     env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
     env.update(env_extra)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--ensembles", "4", "--frames", "16", "--steps", "2",
-           "--warmup", "1", "--cpu-seconds", "0", "--no-fft-stage", "--no-selective", "--no-closed-loop", "--no-sustained"]
+           "--warmup", "1"]            # (default --legs auto: none of the post-timing legs run when world > 1)
     return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
 
 
@@ -118,8 +117,11 @@ def test_plain_bench_gpus_2_reports_two_ranks():
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     j = json.loads(lines[0])
-    assert j["n_gpus"] == 2 and j["rccl_world"] == 2 and len(j["per_rank"]) == 2
+    assert j["n_gpus"] == 2 and j["world"] == 2 and len(j["per_rank"]) == 2
+    assert "gloo" in j["collective_backend"] and "NOT RCCL" in j["collective_backend"]      # the line says what carried the reductions
     assert [p["rank"] for p in j["per_rank"]] == [0, 1] and all(p["frames_per_s"] > 0 for p in j["per_rank"])
+    assert all(0 < p["roofline_frac"] < 1 and p["mover_same_geometry_ms"] > 0 for p in j["per_rank"])
+    assert j["cpu_baseline"] is None and j["legs"].startswith("skipped")                     # world > 1: the timed step only
     assert j["fic_bit_exact"] is True and j["msc_bit_exact"] is True
     assert abs(j["value"] * j["ms_per_step"] * 1e-3 - 128) < 1e-3
 
@@ -157,8 +159,11 @@ def test_bench_config5_shape_512_ensembles_over_8_ranks():
     """BASELINE config 5's sharding -- 512 ensembles, 64 per rank, 8 ranks -- executed with the eight ranks sharing the
     test box's one GPU (16 frames per ensemble instead of 256 so that eight copies fit comfortably): every rank owns
     the global ids `id % 8 == rank`, decodes its 64 streams bit-exactly, and rank 0 reports the whole job."""
+    import time
+    t0 = time.time()
     r = _run_bench(8, {"DABGPU_DIST_BACKEND": "gloo"}, ensembles=64, frames=16)
-    assert r["n_gpus"] == 8 and r["fic_bit_exact"] is True and r["msc_bit_exact"] is True
+    assert time.time() - t0 < 60.0                           # eight ranks sharing one GPU: the run stays boring
+    assert r["n_gpus"] == 8 and len(r["per_rank"]) == 8 and r["fic_bit_exact"] is True and r["msc_bit_exact"] is True
     assert r["config"]["ensembles_per_gpu"] == 64 and r["config"]["frames_per_step_per_gpu"] == 1024
     assert abs(r["value"] * r["ms_per_step"] * 1e-3 - 8 * 1024) < 1e-3
 
@@ -168,9 +173,11 @@ def test_bench_rccl_branch_executes_with_one_rank():
     """The `nccl` (= RCCL) branch of bench.py -- process group on the GPU, barrier, the three all-reduces of the report
     on device tensors -- launched through torch.distributed.run with a single rank, which is all a one-GPU box can give
     RCCL (two ranks on one device are refused); the multi-rank logic is covered by the gloo runs above."""
-    r = _run_bench(1, {"DABGPU_DIST_FORCE": "1", "DABGPU_DIST_BACKEND": "nccl"}, more=["--placement", "plain"])
+    r = _run_bench(1, {"DABGPU_DIST_FORCE": "1", "DABGPU_DIST_BACKEND": "nccl"})
     assert r["n_gpus"] == 1 and r["fic_bit_exact"] is True and r["msc_bit_exact"] is True
-    assert r["config"]["buffer_placement"] == "first allocation taken"
+    assert r["collective_backend"] == "nccl (RCCL)" and r["world"] == 1
+    assert r["config"]["buffer_placement"]["method"] == "plain hipMalloc pair"
+    assert r["config"]["buffer_placement"]["setup_peak_over_final_footprint"] == 1.0
     assert abs(r["value"] * r["ms_per_step"] * 1e-3 - 64) < 1e-3
 
 
@@ -198,6 +205,24 @@ def test_bench_line_keeps_the_contract():
     assert ro["algorithmic_bytes_per_frame"] == (76 * 2048 + 504) * 8 + 230400 and ro["frames_per_launch"] == 64
     assert abs(ro["achieved"] - ro["algorithmic_bytes_per_frame"] * 64 / (ro["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * ro["achieved"]
     assert ro["traffic"] is None and ro["avg_launch_ms"] < j["ms_per_step"]               # no PMC file for this launch size
+    # the stated ceiling: a mover of the kernel's own geometry on the timed buffers (the kernel cannot beat its own bytes)
+    assert ro["mover_same_geometry_ms"] > 0 and "copy_ceiling" not in ro
+    assert abs(ro["kernel_over_mover"] - ro["avg_launch_ms"] / ro["mover_same_geometry_ms"]) < 1e-9
+    bp = j["config"]["buffer_placement"]
+    assert bp["requested"] == "plain" and bp["setup_peak_over_final_footprint"] == 1.0      # the default: two hipMallocs
+    # BASELINE configs 2 and 3 (one ensemble) and the plugin's one-frame-at-a-time use
+    se = j["single_ensemble"]
+    assert se["ofdm_fic"]["fic_bit_exact"] is True and se["ofdm_fic"]["value"] > 0 and se["ofdm_fic"]["frames_per_step"] == 16
+    assert se["ofdm_fic_msc64"]["fic_bit_exact"] is True and se["ofdm_fic_msc64"]["msc_bit_exact"] is True
+    hf = se["host_fed_per_frame"]
+    assert hf["every_frame_locked"] is True and hf["fic_bit_exact"] is True and hf["msc_bit_exact"] is True
+    assert hf["frame_ms"] > 0 and abs(hf["frame_ms"] - hf["ofdm_demod_stream_frame_ms"] - hf["decode_stream_frames_ms"]) < 1e-9
+    # the host-fed figure BASELINE.md section 4 item 5 promises: synchronous calls and the ring
+    hfed = j["host_fed"]
+    assert hfed["frames_per_call"] == 16 and hfed["h2d_copy_GBps"] > 0
+    assert hfed["synchronous_calls"]["fic_bit_exact"] is True and hfed["ring"]["fic_bit_exact"] is True
+    assert hfed["ring"]["msc_bit_exact"] is True and hfed["ring"]["outputs_identical_to_synchronous_calls"] is True
+    assert hfed["ring"]["value"] > 0 and hfed["ring_without_soft_bit_download"]["value"] > 0
     cb = j["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "frames/s" and cb["value"] > 0 and cb["cores"] >= 1 and "frames" in cb["sample"]
     assert cb["simd_port"]["kind"] == "simd_port" and cb["simd_port"]["decodes_bench_inputs_to_transmitted_fibs"] is True
@@ -209,3 +234,40 @@ def test_bench_line_keeps_the_contract():
     cl = j["closed_loop"]
     assert cl["fic_bit_exact"] is True and cl["msc_bit_exact"] is True and cl["tracking"]["fic_bit_exact"] is True
     assert cl["tracking"]["streams_tracking"] == 4 and cl["tracking"]["frames_desync_total"] == 0
+
+
+def test_self_launch_parent_never_loads_torch():
+    """`python bench.py --gpus N` without a launcher: the parent starts the N ranks as a fresh `torch.distributed.run` child
+    and relays its line.  It must reach that point -- and end -- without torch (let alone torch.cuda) in the process: a
+    parent that had initialised the GPU runtime would hand its state to every rank (and on this pool an exec / fork from
+    such a process takes the machine down).  The child is replaced by a stand-in that prints one line."""
+    code = r"""
+import json, subprocess, sys
+sys.argv = ['bench.py', '--gpus', '2', '--steps', '1']
+sys.path.insert(0, %r)
+import bench
+seen = {}
+class FakePopen:
+    def __init__(self, cmd, **kw):
+        seen['cmd'] = cmd; seen['env'] = kw.get('env', {})
+        self.returncode = 0
+    def communicate(self):
+        return json.dumps({'n_gpus': 2, 'value': 1.0}) + '\n', None
+subprocess.Popen = FakePopen
+try:
+    bench.main()
+    raise AssertionError('self_launch returned')
+except SystemExit as e:
+    assert e.code == 0, e.code
+assert 'torch' not in sys.modules and 'torch.cuda' not in sys.modules, 'the launcher process imported torch'
+assert 'dabgpu' not in sys.modules
+cmd = seen['cmd']
+assert cmd[1:3] == ['-m', 'torch.distributed.run'] and '--nproc-per-node' in cmd and cmd[cmd.index('--nproc-per-node') + 1] == '2'
+assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and seen['env'].get('HSA_ENABLE_IPC_MODE_LEGACY') == '0'
+print('ok')
+""" % ROOT
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env, cwd=ROOT)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout + r.stderr)[-2000:]

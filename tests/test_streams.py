@@ -191,16 +191,17 @@ def test_stream_decoder_drops_a_ring_that_missed_a_frame(built, ensemble, ensemb
 
 
 def test_alloc_frame_buffers_returns_a_usable_pair(built, ensemble, ensemble_iq):
-    """dabgpu_alloc_frame_buffers: candidates are timed, one (IQ, soft) pair is kept; the buffers hold whole frames
-    (null symbol included) and the front end run on them gives the soft bits of the host-pointer call."""
+    """dabgpu_alloc_frame_buffers(PLACE_PLAIN): the buffers hold whole frames (null symbol included) and the front end
+    run on them gives the soft bits of the host-pointer call; bad arguments are refused."""
     import torch
     L = dabgpu.NB_FRAME_SAMPLES
     rx = synth.channel(ensemble_iq.ravel(), snr_db=18.0, cfo=0.0, rng=np.random.default_rng(5)).reshape(ensemble_iq.shape)
     n = rx.shape[0]
     c = make_ctx(None, 8)
     ref, _, _ = c.ofdm_demod_frames(np.ascontiguousarray(rx[:, synth.NB_NULL:]))
-    d_iq, d_soft, table, kept = c.alloc_frame_buffers(n, L, 2)
-    assert d_iq and d_soft and table.shape == (2, 2) and (table > 0).all() and kept[0] in (0, 1) and kept[1] in (0, 1)
+    d_iq, d_soft, rep = c.alloc_frame_buffers(n, L, dabgpu.PLACE_PLAIN)
+    assert d_iq and d_soft and rep.method == 0 and rep.fallback_reason == 0
+    assert rep.setup_peak_bytes == n * (L * 8 + dabgpu.NB_FRAME_BITS)
     dev = torch.device("cuda", 0)
     iq = dabgpu.device_tensor(torch, d_iq, (n, L), torch.complex64, dev)
     soft = dabgpu.device_tensor(torch, d_soft, (n, dabgpu.NB_FRAME_BITS), torch.int8, dev)
@@ -210,16 +211,21 @@ def test_alloc_frame_buffers_returns_a_usable_pair(built, ensemble, ensemble_iq)
     c.ofdm_demod_frames_dev(d_iq + synth.NB_NULL * 8, L, n, None, d_soft)
     c.sync()
     assert (soft.cpu().numpy() == ref).all()
+    # the geometry mover runs on the same pair (and leaves meaningless bytes in the soft-bit buffer)
+    c.mover_frames_dev(d_iq + synth.NB_NULL * 8, L, n, d_soft)
+    c.mover_frames_dev(d_iq + synth.NB_NULL * 8, L, n, d_soft, with_prefixes=True)
+    c.sync()
     del iq, soft
     c.free_frame_buffers(d_iq, d_soft)
-    one = c.alloc_frame_buffers(n, L, 1)
-    assert one[2] is None and one[3] == (0, 0)
-    c.free_frame_buffers(one[0], one[1])
-    for bad in (dict(n_frames=0), dict(candidates=0), dict(candidates=9), dict(frame_stride=L - 2), dict(frame_stride=L + 1)):
-        kw = dict(n_frames=n, frame_stride=L, candidates=2)
+    # a request too small for the domains to matter is a plain pair whatever was asked for, and says why
+    d_iq, d_soft, rep = c.alloc_frame_buffers(n, L, dabgpu.PLACE_DOMAINS)
+    assert rep.method == 0 and rep.fallback_reason == 1
+    c.free_frame_buffers(d_iq, d_soft)
+    for bad in (dict(n_frames=0), dict(placement=2), dict(placement=-1), dict(frame_stride=L - 2), dict(frame_stride=L + 1)):
+        kw = dict(n_frames=n, frame_stride=L, placement=0)
         kw.update(bad)
         with pytest.raises(dabgpu.DabGpuError):
-            c.alloc_frame_buffers(kw["n_frames"], kw["frame_stride"], kw["candidates"])
+            c.alloc_frame_buffers(kw["n_frames"], kw["frame_stride"], kw["placement"])
     c.close()
 
 
@@ -307,52 +313,41 @@ def test_decision_directed_front_end_and_loop(built, ensemble, ensemble_iq):
     c.close()
 
 
-def test_alloc_frame_buffers_placed(built, ensemble_iq):
-    """dabgpu_alloc_frame_buffers_placed: a small request is a plain allocation; a 5 GiB one goes through the
-    virtual-memory arena (1 GiB / 256 MiB chunks, domain classification, mapped ranges): the set-up holds at most 1.2 x
-    the footprint, the buffers behave like any device memory (torch tensors over them, the
-    front end run on them gives the host-pointer call's soft bits), and releasing them gives the memory back."""
+def test_alloc_frame_buffers_by_domain(built, ensemble_iq):
+    """dabgpu_alloc_frame_buffers(PLACE_DOMAINS) on a 5 GiB pair: chunks through the virtual-memory API inside the
+    context's ONE address range, never more than 1.5 x the pair held, the buffers behave like any device memory (torch
+    tensors over them, the front end run on them gives the host-pointer call's soft bits), a second request while the
+    pair is alive is a plain pair, releasing gives the memory back, and the same range serves the next request."""
     import torch
     L = dabgpu.NB_FRAME_SAMPLES
     dev = torch.device("cuda", 0)
     c = make_ctx(None, 8)
-    d_iq, d_soft, rep = c.alloc_frame_buffers_placed(8, L)
-    assert rep.method == 0 and d_iq and d_soft
-    c.free_frame_buffers(d_iq, d_soft)
     torch.cuda.synchronize()
     free0 = torch.cuda.mem_get_info()[0]
     n = 3000                                                   # 4.4 GiB of samples, 0.64 GiB of soft bits
-    d_iq, d_soft, rep = c.alloc_frame_buffers_placed(n, L)
-    assert rep.method == 1, rep.method
     final = n * (L * 8 + dabgpu.NB_FRAME_BITS)
-    assert 5 <= rep.iq_chunks <= 8 and 1 <= rep.soft_chunks <= 3 and rep.n_chunks >= 8 and rep.chunk_bytes == 1 << 30
+    d_iq, d_soft, rep = c.alloc_frame_buffers(n, L, dabgpu.PLACE_DOMAINS)
+    assert rep.method == 1, (rep.method, rep.fallback_reason)
+    assert 5 <= rep.iq_chunks <= rep.n_chunks - 1 and 1 <= rep.soft_chunks <= 3 and rep.n_chunks >= 8 and rep.chunk_bytes == 1 << 30
     doms = rep.domains.decode()
-    assert len(doms) == min(71, rep.n_chunks) and set(doms.upper()) <= set("ABC") and 1 <= rep.n_domains <= 3
-    # IQ-size chunks first, then the 256 MiB ones (the 1.2 x budget), then -- only when the budget lay in one domain --
-    # 1 GiB spacers, which are gone again when the call returns
+    assert len(doms) == min(95, rep.n_chunks) and set(doms.upper()) <= set("ABC") and 1 <= rep.n_domains <= 3
     n_big = len(doms) - len(doms.lstrip("ABC"))
-    n_small = len(doms[n_big:]) - len(doms[n_big:].lstrip("abc"))
-    spacers = doms[n_big + n_small:]
-    assert n_big >= 5 and n_small >= 3 and (not spacers or spacers.isupper())
-    budget_bytes = (n_big << 30) + (n_small << 28)
-    assert budget_bytes <= 1.2 * final
-    if spacers:
-        # ... which means that no domain of the budget could carry the samples alone with room elsewhere for the soft bits
-        for d in "ABC":
-            mine = (doms[:n_big].count(d) << 30) + (doms[n_big:n_big + n_small].count(d.lower()) << 28)
-            assert not (mine >= n * L * 8 and budget_bytes - mine >= n * dabgpu.NB_FRAME_BITS), (d, doms)
-        assert rep.setup_peak_bytes == budget_bytes + (len(spacers) << 30) or rep.n_chunks > 71
-    else:
-        assert rep.setup_peak_bytes <= 1.2 * final                    # never more than 1.2 x the buffers during set-up
+    assert n_big >= 5 and doms[n_big:].islower() and len(doms) - n_big >= 3
+    assert rep.setup_peak_bytes == (n_big << 30) + ((len(doms) - n_big) << 28)
+    assert rep.setup_peak_bytes <= 1.5 * final                       # never more than 1.5 x the buffers during set-up
     assert len(rep.iq_map.decode()) == rep.iq_chunks and len(rep.soft_map.decode()) == rep.soft_chunks
-    assert rep.front_end_ms > 0 and rep.classify_ms > 0 and 0 <= rep.conflicts <= 1000
+    assert rep.classify_ms > 0 and 0 <= rep.conflicts <= 1000
     if rep.conflicts == 0 and rep.n_domains > 1:
         assert not set(rep.soft_map.decode().upper()) & set(rep.iq_map.decode().upper()[:2])
         # ... and the mover agrees: writing the soft-bit buffer beside reads of the samples is faster than writing into
         # the samples' own buffer beside the same reads
         assert 0.5 < rep.pair_over_same_domain < 0.985, rep.pair_over_same_domain
     held = free0 - torch.cuda.mem_get_info()[0]
-    assert held <= 1.2 * final + (64 << 20) and held >= final, held   # the chunks nobody took (and every spacer not taken) were released
+    assert final <= held <= final + (2 << 30) + (64 << 20), held   # the chunks nobody took were released (whole chunks are kept)
+    # one domain-aware pair per context at a time: the second request is a plain pair and says why
+    e_iq, e_soft, rep2 = c.alloc_frame_buffers(16, L, dabgpu.PLACE_DOMAINS)
+    assert rep2.method == 0 and rep2.fallback_reason in (1, 4)
+    c.free_frame_buffers(e_iq, e_soft)
     rx = synth.channel(ensemble_iq.ravel(), snr_db=18.0, cfo=0.0, rng=np.random.default_rng(6)).reshape(ensemble_iq.shape)
     k = rx.shape[0]
     ref, _, _ = c.ofdm_demod_frames(np.ascontiguousarray(rx[:, synth.NB_NULL:]))
@@ -367,37 +362,23 @@ def test_alloc_frame_buffers_placed(built, ensemble_iq):
     for base in (0, 680, n - k):
         assert (soft[base:base + k].cpu().numpy() == ref).all(), base
     del iq, soft
+    with pytest.raises(dabgpu.DabGpuError):                   # the two buffers of a mapped pair go back together
+        c.free_frame_buffers(d_iq, None)
     c.free_frame_buffers(d_iq, d_soft)
     torch.cuda.synchronize()
     assert free0 - torch.cuda.mem_get_info()[0] <= 64 << 20
+    # the same range serves the next pair (same addresses); a larger one than it was reserved for is a plain pair
+    f_iq, f_soft, rep3 = c.alloc_frame_buffers(n, L, dabgpu.PLACE_DOMAINS)
+    assert rep3.method == 1 and f_iq == d_iq
+    g_iq, g_soft, rep4 = c.alloc_frame_buffers(2 * n, L, dabgpu.PLACE_DOMAINS)
+    assert rep4.method == 0 and rep4.fallback_reason == 4
+    c.free_frame_buffers(g_iq, g_soft)
+    c.free_frame_buffers(f_iq, f_soft)
+    g_iq, g_soft, rep4 = c.alloc_frame_buffers(2 * n, L, dabgpu.PLACE_DOMAINS)
+    assert rep4.method == 0 and rep4.fallback_reason == 5
+    c.free_frame_buffers(g_iq, g_soft)
     with pytest.raises(dabgpu.DabGpuError):
-        c.alloc_frame_buffers_placed(0, L)
+        c.alloc_frame_buffers(0, L, dabgpu.PLACE_DOMAINS)
     c.close()
-
-
-def test_device_alloc_apart(built):
-    """dabgpu_device_alloc_apart: small requests are plain allocations; a large one next to a large reference goes through
-    the chunk arena (never more than 1.2 x its size + one chunk held), is usable like any device memory and goes back
-    on free; bad arguments are refused."""
-    import torch
-    c = make_ctx(None, 8)
-    p, ms = c.device_alloc_apart(4096)
-    assert p and ms == [0.0, 0.0, 0.0]
-    c.device_free(p)
-    dev = torch.device("cuda", 0)
-    ref = torch.zeros((1 << 30,), dtype=torch.uint8, device=dev)
-    torch.cuda.synchronize()
-    free0 = torch.cuda.mem_get_info()[0]
-    p, ms = c.device_alloc_apart(512 << 20, ref.data_ptr(), ref.numel())
-    assert p and ms[0] > 0 and 0 <= ms[1] <= 1000 and ms[2] > 0
-    assert free0 - torch.cuda.mem_get_info()[0] <= (512 << 20) + (64 << 20)      # two 256 MiB chunks, the spare released
-    t = dabgpu.device_tensor(torch, p, (512 << 20,), torch.uint8, dev)
-    t.fill_(7)
-    assert int(t[-1].item()) == 7 and int(t[(256 << 20) - 1].item()) == 7
-    del t
-    c.device_free(p)
     torch.cuda.synchronize()
     assert free0 - torch.cuda.mem_get_info()[0] <= 64 << 20
-    with pytest.raises(dabgpu.DabGpuError):
-        c.device_alloc_apart(0)
-    c.close()

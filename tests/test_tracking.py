@@ -131,6 +131,9 @@ def check_state(got, want, what):
     assert float(got["coarse_freq_offset"]) == float(want["coarse_freq_offset"]), what
     assert abs(float(got["signal_average"]) - float(want["signal_average"])) <= 1e-5 * float(want["signal_average"]) + 1e-12, what
     assert abs(float(got["last_peak_to_mean"]) - float(want["last_peak_to_mean"])) <= 2e-3 * float(want["last_peak_to_mean"]) + 1e-12, what
+    for k in ("loop_gated", "dd_branch"):                      # the decision-directed loop's gate (0 where it never ran)
+        if k in want and k in got:
+            assert int(got[k]) == int(want[k]), (what, k, got[k], want[k])
 
 
 @pytest.mark.gpu
