@@ -203,7 +203,7 @@ def main():
                                                           else dabgpu.PLACE_PLAIN)
     final_bytes = n_frames * (L * 8 + dabgpu.NB_FRAME_BITS)
     placement = {"requested": args.placement,
-                 "method": "domain-aware pair (one address range per context)" if rep.method == 1 else "plain hipMalloc pair",
+                 "method": "domain-aware pair (address ranges reserved once per context)" if rep.method == 1 else "plain hipMalloc pair",
                  "setup_peak_bytes": int(rep.setup_peak_bytes),
                  "setup_peak_over_final_footprint": round(rep.setup_peak_bytes / final_bytes, 3)}
     if rep.method == 1:

@@ -114,6 +114,11 @@ typedef struct dabgpu_cfg {
                                            /* above ~680 kbit/s do not fit its LDS slab: those go per lane)      */
 #define DABGPU_FLAG_VITERBI_LANE  (1 << 1) /* one codeword per lane wherever the length allows, any batch size */
 #define DABGPU_FLAG_LANE_UNFUSED  (1 << 2) /* lane decoder: separate depuncture pass before the forward pass   */
+/* front end, plain data flow (no constellation output, no selection): the structural variants round 4 measured and
+ * rejected (profiles/r04_front_end_variants.txt) -- same results bit for bit; kept for the A/B */
+#define DABGPU_FLAG_OFDM_PREFETCH (1 << 3) /* two waves per SIMD, the next symbol's loads in a second register set */
+#define DABGPU_FLAG_OFDM_EARLY8   (1 << 4) /* eight rows of the next symbol requested before the epilogue          */
+#define DABGPU_FLAG_OFDM_EARLY4   (1 << 5) /* four rows                                                             */
 
 /* Replaces the construction in Radio_Block::Radio_Block
  * (/root/reference/src/radio_block.cpp:11-22: params + PRS + mapper + OFDM_Demod). */
@@ -147,8 +152,8 @@ void dabgpu_host_free(void *p);
  *                chunk's domain is found with a small data mover (two passes, ~40 ms), the IQ buffer is mapped over
  *                chunks of the most plentiful domain(s) and every 256 MiB of the soft-bit buffer over a chunk whose
  *                domain differs from the ~1.7 GiB of samples read WHILE it is written; the chunks left over go back.
- *                All of it happens inside ONE address range per context, reserved by the first such call and released
- *                by dabgpu_destroy: one domain-aware pair per context at a time; a second request while the first is
+ *                All of it happens inside two address ranges per context (one to probe in, one for the pair), reserved by
+ *                the first such call and released by dabgpu_destroy: one domain-aware pair per context at a time; a second request while the first is
  *                alive, a request larger than the range was reserved for, buffers below ~4 GiB, a device without the
  *                virtual-memory API or without room, and any failure on the way all end in a PLAIN pair
  *                (report->method = 0, report->fallback_reason says why).  A set-up call: it synchronises, takes
@@ -173,7 +178,8 @@ typedef struct dabgpu_placement_report {
     int32_t n_domains;          /* distinct HBM domains seen among the chunks (1..3)                           */
     int32_t conflicts;          /* per mille of the soft bits that are written beside reads from their own domain */
     int32_t runtime_error;      /* fallback after a failed runtime call: stage * 1000 + hipError_t (stage 1 reserve, */
-                                /* 2 create, 3 map, 4 set access, 5 re-map, 6 memory info); else 0                  */
+                                /* 2 create, 3 map, 4 set access, 5 unmap, 6 memory info, 7 / 8 map / set access   */
+                                /* of the pair); else 0                                                             */
     uint64_t chunk_bytes;
     uint64_t setup_peak_bytes;  /* device memory held at the peak of the set-up (<= 1.5 x the pair)            */
     float classify_ms;          /* time spent finding the domains                                              */

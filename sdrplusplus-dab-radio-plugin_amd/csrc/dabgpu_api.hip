@@ -195,7 +195,8 @@ int dabgpu_create(const dabgpu_cfg *cfg, dabgpu_ctx **out) {
     if (!cfg || !out) return DABGPU_ERR_ARG;
     *out = nullptr;
     if (cfg->transmission_mode != 1) return DABGPU_ERR_PROFILE;
-    constexpr int KNOWN_FLAGS = DABGPU_FLAG_VITERBI_WAVE | DABGPU_FLAG_VITERBI_LANE | DABGPU_FLAG_LANE_UNFUSED;
+    constexpr int OFDM_FLAGS = DABGPU_FLAG_OFDM_PREFETCH | DABGPU_FLAG_OFDM_EARLY8 | DABGPU_FLAG_OFDM_EARLY4;
+    constexpr int KNOWN_FLAGS = DABGPU_FLAG_VITERBI_WAVE | DABGPU_FLAG_VITERBI_LANE | DABGPU_FLAG_LANE_UNFUSED | OFDM_FLAGS;
     if ((cfg->flags & ~KNOWN_FLAGS) || ((cfg->flags & DABGPU_FLAG_VITERBI_WAVE) && (cfg->flags & DABGPU_FLAG_VITERBI_LANE)))
         return DABGPU_ERR_ARG;
     if (cfg->ofdm_symbol_runs < 0 || cfg->ofdm_symbol_runs > NB_DATA_SYMBOLS) return DABGPU_ERR_ARG;
@@ -214,6 +215,7 @@ int dabgpu_create(const dabgpu_cfg *cfg, dabgpu_ctx **out) {
     ctx->ofdm_parts_override = cfg->ofdm_symbol_runs;
     ctx->lane_mode = (cfg->flags & DABGPU_FLAG_VITERBI_LANE) ? 1 : (cfg->flags & DABGPU_FLAG_VITERBI_WAVE) ? 0 : -1;
     ctx->lane_unfused = (cfg->flags & DABGPU_FLAG_LANE_UNFUSED) != 0;
+    ctx->ofdm_variant = (cfg->flags & DABGPU_FLAG_OFDM_PREFETCH) ? 1 : (cfg->flags & DABGPU_FLAG_OFDM_EARLY8) ? 2 : (cfg->flags & DABGPU_FLAG_OFDM_EARLY4) ? 3 : 0;
     ctx->wave_slots = prop.multiProcessorCount > 0 ? prop.multiProcessorCount * 12 : 3072;   // 3 workgroups x 4 waves per CU
     int rc = DABGPU_OK;
     do {
@@ -410,7 +412,7 @@ int dabgpu_ofdm_demod_frames_dev(dabgpu_ctx *ctx, const void *d_iq, size_t frame
     ScopedTimer tm(ctx, 0, s);
     const RunPlan plan = plan_runs(ctx, n_frames, NB_DATA_SYMBOLS);
     a.uncut_frames = plan.uncut_frames;
-    HIP_TRY(dabk::launch_ofdm_demod(tab, a, plan.parts, s));
+    HIP_TRY(dabk::launch_ofdm_demod(tab, a, plan.parts, s, ctx->ofdm_variant));
     return DABGPU_OK;
 }
 
@@ -435,7 +437,7 @@ int dabgpu_ofdm_demod_frames_dd_dev(dabgpu_ctx *ctx, const void *d_iq, size_t fr
     ScopedTimer tm(ctx, 0, s);
     const RunPlan plan = plan_runs(ctx, n_frames, NB_DATA_SYMBOLS);
     a.uncut_frames = plan.uncut_frames;
-    HIP_TRY(dabk::launch_ofdm_demod(tab, a, plan.parts, s));
+    HIP_TRY(dabk::launch_ofdm_demod(tab, a, plan.parts, s, ctx->ofdm_variant));
     return DABGPU_OK;
 }
 
@@ -707,7 +709,7 @@ int dabgpu_ofdm_demod_streams_dev(dabgpu_ctx *ctx, const void *d_iq, size_t fram
         ScopedTimer tm(ctx, 0, s);
         const RunPlan plan = plan_runs(ctx, n_frames, NB_DATA_SYMBOLS);
         a.uncut_frames = plan.uncut_frames;
-        HIP_TRY(dabk::launch_ofdm_demod(tab, a, plan.parts, s));
+        HIP_TRY(dabk::launch_ofdm_demod(tab, a, plan.parts, s, ctx->ofdm_variant));
     }
     HIP_TRY(dabk::launch_stream_update(ctx->d_states, dd ? a.dd4 : a.cyc, a.iq, frame_stride, n_streams, frames_per_stream,
                                        fine_freq_update_beta, ctx->thr_null_start, ctx->signal_beta, dd ? 1 : 0, ctx->dd_gate,
@@ -950,7 +952,7 @@ int dabgpu_ofdm_demod_acquired_dev(dabgpu_ctx *ctx, const void *d_iq, size_t str
     ScopedTimer tm(ctx, 0, s);
     const RunPlan plan = plan_runs(ctx, a.n_frames, NB_DATA_SYMBOLS);
     a.uncut_frames = plan.uncut_frames;
-    HIP_TRY(dabk::launch_ofdm_demod(tab, a, plan.parts, s));
+    HIP_TRY(dabk::launch_ofdm_demod(tab, a, plan.parts, s, ctx->ofdm_variant));
     return DABGPU_OK;
 }
 
@@ -1051,7 +1053,7 @@ static int tracked_launches(dabgpu_ctx *ctx, dabk::StreamState *states, const vo
         ScopedTimer tm(ctx, 0, s);
         const RunPlan plan = plan_runs(ctx, a.n_frames, NB_DATA_SYMBOLS);
         a.uncut_frames = plan.uncut_frames;
-        HIP_TRY(dabk::launch_ofdm_demod(tab, a, plan.parts, s));
+        HIP_TRY(dabk::launch_ofdm_demod(tab, a, plan.parts, s, ctx->ofdm_variant));
     }
     dabk::TrackUpdateArgs u{};
     u.state = states;

@@ -37,14 +37,16 @@ struct Timer {
 
 struct Pipeline;                         // dabgpu_pipeline.hip
 
-// The domain-aware frame buffers of a context live inside ONE address range, reserved by the first such allocation and
-// given back by dabgpu_destroy only (dabgpu_placement.hip): [va, va + probe_bytes) is where physical chunks are mapped
-// while their HBM domains are found, [va + probe_bytes, va + reserved) is where the pair handed to the caller is mapped.
+// The domain-aware frame buffers of a context live inside TWO address ranges, both reserved by the first such allocation
+// and given back by dabgpu_destroy only (dabgpu_placement.hip): `probe` is where physical chunks are mapped while their
+// HBM domains are found, `pair` is where the pair handed to the caller is mapped.  (Two, not one: access rights are only
+// ever set on a span that begins at the base of a reservation -- the one use of the virtual-memory API that was never
+// seen to fail on this runtime.)
 struct Arena {
-    char *va = nullptr;
-    size_t reserved = 0, probe_bytes = 0;
+    char *probe = nullptr, *pair = nullptr;
+    size_t probe_bytes = 0, pair_bytes = 0;
     struct Piece {
-        size_t off, bytes;               // offset inside the range, mapped bytes
+        size_t off, bytes;               // offset inside `pair`, mapped bytes
         hipMemGenericAllocationHandle_t h;
     };
     std::vector<Piece> pieces;           // live mappings of the pair handed out (empty: the arena is idle)
@@ -82,6 +84,7 @@ struct dabgpu_ctx {
     int lane_mode = -1;                  // 1 = DABGPU_FLAG_VITERBI_LANE, 0 = DABGPU_FLAG_VITERBI_WAVE, -1 by batch size
     bool lane_unfused = false;           // DABGPU_FLAG_LANE_UNFUSED
     int wave_slots = 3072;               // resident OFDM wavefronts: 12 per CU
+    int ofdm_variant = 0;                // DABGPU_FLAG_OFDM_*: 0 = ofdm_wave_kernel
     std::vector<dabgpu_bit_range> keep_ranges;           // the current selection, merged, for the host-pointer copy-back
     dabk::StreamState *d_states = nullptr;               // per-stream tracking state (dabgpu_streams_reset)
     int n_states = 0;

@@ -6,9 +6,11 @@
 // finds every chunk's domain with a small data mover, and maps the pair over chunks that lie apart.
 //
 // Rules this file keeps (round 3's version broke the first and could take the process down with it):
-//   * ONE address range per context, reserved by the first domain-aware allocation, freed by dabgpu_destroy only.
-//     Chunks are mapped and unmapped INSIDE it; no address range is ever freed and reserved again while the context
-//     lives (the runtime was seen to answer a look-up in a new range with one freed moments before).
+//   * TWO address ranges per context (one for probing, one for the pair), reserved by the first domain-aware allocation,
+//     freed by dabgpu_destroy only.  Chunks are mapped and unmapped INSIDE them; no address range is ever freed and reserved
+//     again while the context lives (the runtime was seen to answer a look-up in a new range with one freed moments
+//     before), and access rights are only ever set on a span that starts at the base of a range (set on a span in the
+//     middle of one, the call failed about every second time).
 //   * never more than 1.5 x the pair's size held (no spacers beyond that budget); when the budget's chunks do not allow
 //     a clean placement, the pair is placed as well as they do and the report says so (conflicts): not chased.
 //   * every failure on the way -- no virtual-memory API, no room, a failed map, a failed probe launch -- ends in two
@@ -39,11 +41,11 @@ struct Probe {
     hipStream_t s;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     std::vector<Chunk> c;
-    char *at(int i) const { return ctx->arena.va + c[size_t(i)].off; }
+    char *at(int i) const { return ctx->arena.probe + c[size_t(i)].off; }
     // every chunk still in the probe region leaves it; the ones nobody took are released
     void drop_all() {
         for (Chunk &x : c) {
-            if (x.mapped) (void)hipMemUnmap(ctx->arena.va + x.off, x.bytes);
+            if (x.mapped) (void)hipMemUnmap(ctx->arena.probe + x.off, x.bytes);
             if (x.h) (void)hipMemRelease(x.h);
             x.mapped = false;
             x.h = nullptr;
@@ -133,7 +135,7 @@ int classify(Probe &p) {
 void unmap_pieces(dabgpu_ctx *ctx) {
     Arena &a = ctx->arena;
     for (Arena::Piece &pc : a.pieces) {
-        (void)hipMemUnmap(a.va + pc.off, pc.bytes);
+        (void)hipMemUnmap(a.pair + pc.off, pc.bytes);
         (void)hipMemRelease(pc.h);
     }
     (void)hipGetLastError();
@@ -163,10 +165,11 @@ namespace dabapi {
 void arena_destroy(dabgpu_ctx *ctx) {
     unmap_pieces(ctx);
     Arena &a = ctx->arena;
-    if (a.va) (void)hipMemAddressFree(a.va, a.reserved);
+    if (a.probe) (void)hipMemAddressFree(a.probe, a.probe_bytes);
+    if (a.pair) (void)hipMemAddressFree(a.pair, a.pair_bytes);
     (void)hipGetLastError();
-    a.va = nullptr;
-    a.reserved = a.probe_bytes = 0;
+    a.probe = a.pair = nullptr;
+    a.probe_bytes = a.pair_bytes = 0;
 }
 }  // namespace dabapi
 
@@ -187,7 +190,7 @@ int dabgpu_alloc_frame_buffers(dabgpu_ctx *ctx, int n_frames, size_t frame_strid
     const size_t soft_bytes = size_t(n_frames) * NB_FRAME_BITS;
     Probe p{ctx, ctx->stream};
     hipError_t herr = hipSuccess;                              // the runtime call that sent the request to the plain path
-    int hstage = 0;                                            // 1 reserve, 2 create, 3 map, 4 set access, 5 re-map, 6 mem info
+    int hstage = 0;                                            // 1 reserve, 2 create, 3 map, 4 set access, 5 unmap, 6 mem info, 7 map (pair), 8 set access (pair)
     auto plain = [&](int why) {
         p.drop_all();                                          // (what the probe still holds goes back first)
         rep.fallback_reason = why;
@@ -213,16 +216,23 @@ int dabgpu_alloc_frame_buffers(dabgpu_ctx *ctx, int n_frames, size_t frame_strid
     while (n_small > n_soft && size_t(n_big) * CH + size_t(n_small) * CS > may_take) n_small--;
     const size_t probe_bytes = size_t(n_big) * CH + size_t(n_small) * CS;
     if (probe_bytes > may_take || n_big + n_small > 96) return plain(DABGPU_PLAIN_NO_ROOM);
-    // the context's one address range: probe region + the region the pair is mapped in
-    if (!ar.va) {
-        void *va = nullptr;
-        // (+ one chunk of addresses: the soft bits may end on a 1 GiB chunk)
-        if ((herr = hipMemAddressReserve(&va, probe_bytes + need + CH, 0, nullptr, 0)) != hipSuccess) { hstage = 1; (void)hipGetLastError(); return plain(DABGPU_PLAIN_NO_VMM); }
-        ar.va = static_cast<char *>(va);
-        ar.reserved = probe_bytes + need + CH;
+    // the context's two address ranges: where chunks are probed, and where the pair is mapped (+ one chunk of addresses:
+    // the soft bits may end on a 1 GiB chunk)
+    if (!ar.probe) {
+        void *va = nullptr, *vb = nullptr;
+        if ((herr = hipMemAddressReserve(&va, probe_bytes, 0, nullptr, 0)) != hipSuccess) { hstage = 1; (void)hipGetLastError(); return plain(DABGPU_PLAIN_NO_VMM); }
+        if ((herr = hipMemAddressReserve(&vb, need + CH, 0, nullptr, 0)) != hipSuccess) {
+            hstage = 1;
+            (void)hipMemAddressFree(va, probe_bytes);          // (nothing was ever mapped in it)
+            (void)hipGetLastError();
+            return plain(DABGPU_PLAIN_NO_VMM);
+        }
+        ar.probe = static_cast<char *>(va);
+        ar.pair = static_cast<char *>(vb);
         ar.probe_bytes = probe_bytes;
-    } else if (ar.probe_bytes < probe_bytes || ar.reserved - ar.probe_bytes < need + CH) {
-        return plain(DABGPU_PLAIN_ARENA_SMALL);              // (a larger request than the range was reserved for)
+        ar.pair_bytes = need + CH;
+    } else if (ar.probe_bytes < probe_bytes || ar.pair_bytes < need + CH) {
+        return plain(DABGPU_PLAIN_ARENA_SMALL);              // (a larger request than the ranges were reserved for)
     }
     hipStream_t s = ctx->stream;
     if (hipStreamSynchronize(s) != hipSuccess) return DABGPU_ERR_HIP;
@@ -240,7 +250,7 @@ int dabgpu_alloc_frame_buffers(dabgpu_ctx *ctx, int n_frames, size_t frame_strid
         const size_t bytes = i < n_big ? CH : CS;
         hipMemGenericAllocationHandle_t h;
         if ((herr = hipMemCreate(&h, bytes, &prop, 0)) != hipSuccess) { hstage = 2; (void)hipGetLastError(); return plain(DABGPU_PLAIN_NO_ROOM); }
-        if ((herr = hipMemMap(ar.va + off, bytes, 0, h, 0)) != hipSuccess) {
+        if ((herr = hipMemMap(ar.probe + off, bytes, 0, h, 0)) != hipSuccess) {
             hstage = 3;
             (void)hipMemRelease(h);
             (void)hipGetLastError();
@@ -249,7 +259,7 @@ int dabgpu_alloc_frame_buffers(dabgpu_ctx *ctx, int n_frames, size_t frame_strid
         p.c.push_back(Chunk{h, bytes, off, true, 0});
         off += bytes;
     }
-    if ((herr = hipMemSetAccess(ar.va, off, &acc, 1)) != hipSuccess) { hstage = 4; (void)hipGetLastError(); return plain(DABGPU_PLAIN_NO_VMM); }
+    if ((herr = hipMemSetAccess(ar.probe, off, &acc, 1)) != hipSuccess) { hstage = 4; (void)hipGetLastError(); return plain(DABGPU_PLAIN_NO_VMM); }
     rep.n_chunks = n_total;
     rep.chunk_bytes = CH;
     rep.setup_peak_bytes = off;
@@ -257,7 +267,7 @@ int dabgpu_alloc_frame_buffers(dabgpu_ctx *ctx, int n_frames, size_t frame_strid
     // ---- which domain is every chunk in? ----
     hipEvent_t ec0 = nullptr, ec1 = nullptr;
     bool ok = hipEventCreate(&p.e0) == hipSuccess && hipEventCreate(&p.e1) == hipSuccess && hipEventCreate(&ec0) == hipSuccess &&
-              hipEventCreate(&ec1) == hipSuccess && dabk::launch_fill_noise(ar.va, off, s) == hipSuccess;
+              hipEventCreate(&ec1) == hipSuccess && dabk::launch_fill_noise(ar.probe, off, s) == hipSuccess;
     int n_dom = 1;
     if (ok) {
         (void)hipEventRecord(ec0, s);
@@ -324,7 +334,7 @@ int dabgpu_alloc_frame_buffers(dabgpu_ctx *ctx, int n_frames, size_t frame_strid
         for (int i = 0; i < n_total; i++) {
             if (used[size_t(i)]) continue;
             const size_t sz = p.c[size_t(i)].bytes;
-            if (iq_mapped + soft_mapped + sz > ar.reserved - ar.probe_bytes) continue;      // would not fit the pair's region
+            if (iq_mapped + soft_mapped + sz > ar.pair_bytes) continue;      // would not fit the pair's range
             double w[3];
             iq_bytes_by_domain(double(soft_mapped) * iq_per_soft - slack, double(std::min(soft_bytes, soft_mapped + sz)) * iq_per_soft + slack, w);
             const double tot = w[0] + w[1] + w[2];
@@ -338,7 +348,7 @@ int dabgpu_alloc_frame_buffers(dabgpu_ctx *ctx, int n_frames, size_t frame_strid
         shared += best_cost * double(std::min(p.c[size_t(best)].bytes, soft_bytes - soft_mapped));
         soft_mapped += p.c[size_t(best)].bytes;
     }
-    if (iq_mapped < iq_bytes || soft_mapped < soft_bytes || iq_mapped + soft_mapped > ar.reserved - ar.probe_bytes)
+    if (iq_mapped < iq_bytes || soft_mapped < soft_bytes || iq_mapped + soft_mapped > ar.pair_bytes)
         return plain(DABGPU_PLAIN_NO_ROOM);                    // (~Probe releases every chunk)
     rep.conflicts = int(1000.0 * shared / double(soft_bytes) + 0.5);
     rep.iq_chunks = int(iq_sel.size());
@@ -346,34 +356,36 @@ int dabgpu_alloc_frame_buffers(dabgpu_ctx *ctx, int n_frames, size_t frame_strid
     for (size_t k = 0; k < iq_sel.size() && k < 71; k++) rep.iq_map[k] = char((iq_sel[k] < n_big ? 'A' : 'a') + p.c[size_t(iq_sel[k])].dom);
     for (size_t k = 0; k < soft_sel.size() && k < 23; k++) rep.soft_map[k] = char((soft_sel[k] < n_big ? 'A' : 'a') + p.c[size_t(soft_sel[k])].dom);
 
-    // ---- the chosen chunks move from the probe region to the pair's region of the same range; the others go back ----
+    // ---- the chosen chunks leave the probe range, then are mapped side by side in the pair's range; the others go back ----
     if (hipStreamSynchronize(s) != hipSuccess) return plain(DABGPU_PLAIN_PROBE_FAILED);
-    size_t dst = ar.probe_bytes;
     bool mapped_ok = true;
-    auto move = [&](const std::vector<int> &sel) {
-        for (int i : sel) {
+    for (const std::vector<int> *sel : {&iq_sel, &soft_sel})
+        for (int i : *sel) {
+            Chunk &x = p.c[size_t(i)];
+            if ((herr = hipMemUnmap(ar.probe + x.off, x.bytes)) != hipSuccess) { hstage = 5; mapped_ok = false; }
+            x.mapped = false;
+        }
+    size_t dst = 0, soft_off = 0;
+    for (const std::vector<int> *sel : {&iq_sel, &soft_sel}) {
+        if (sel == &soft_sel) soft_off = dst;
+        for (int i : *sel) {
             Chunk &x = p.c[size_t(i)];
             if (!mapped_ok) break;
-            if (hipMemUnmap(ar.va + x.off, x.bytes) != hipSuccess) { mapped_ok = false; break; }
-            x.mapped = false;
-            if (hipMemMap(ar.va + dst, x.bytes, 0, x.h, 0) != hipSuccess) { mapped_ok = false; break; }
+            if ((herr = hipMemMap(ar.pair + dst, x.bytes, 0, x.h, 0)) != hipSuccess) { hstage = 7; mapped_ok = false; break; }
             ar.pieces.push_back(Arena::Piece{dst, x.bytes, x.h});
             x.h = nullptr;                                    // owned by the arena from here on
             dst += x.bytes;
         }
-    };
-    move(iq_sel);
-    const size_t soft_off = dst;
-    move(soft_sel);
-    if (!mapped_ok || hipMemSetAccess(ar.va + ar.probe_bytes, dst - ar.probe_bytes, &acc, 1) != hipSuccess) {
-        herr = hipGetLastError();
-        hstage = 5;
+    }
+    if (mapped_ok && (herr = hipMemSetAccess(ar.pair, dst, &acc, 1)) != hipSuccess) { hstage = 8; mapped_ok = false; }
+    if (!mapped_ok) {
+        (void)hipGetLastError();
         unmap_pieces(ctx);
         return plain(DABGPU_PLAIN_NO_VMM);
     }
     p.drop_all();
-    ar.d_iq = ar.va + ar.probe_bytes;
-    ar.d_soft = ar.va + soft_off;
+    ar.d_iq = ar.pair;
+    ar.d_soft = ar.pair + soft_off;
     *d_iq = ar.d_iq;
     *d_soft = static_cast<int8_t *>(ar.d_soft);
     rep.method = 1;

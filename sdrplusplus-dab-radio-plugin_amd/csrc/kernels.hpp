@@ -70,7 +70,9 @@ struct OfdmArgs {
 
 // fused A2..A6.  Frames behind the first a.uncut_frames are cut into `parts` contiguous runs of data symbols (1..75);
 // a run re-reads the symbol before it as differential reference.
-hipError_t launch_ofdm_demod(const OfdmTables &t, const OfdmArgs &a, int parts, hipStream_t s);
+// variant (plain data flow only): 1 = two waves per SIMD with the next symbol's loads in flight in a second register set
+// (ofdm_wave_pf_kernel), 2 / 3 = eight / four rows of the next symbol requested before the epilogue (ofdm_wave_early_kernel); 0 = ofdm_wave_kernel
+hipError_t launch_ofdm_demod(const OfdmTables &t, const OfdmArgs &a, int parts, hipStream_t s, int variant = 0);
 // A2+A3 only; parts in 1..76.
 hipError_t launch_fft_symbols(const OfdmTables &t, const OfdmArgs &a, int parts, hipStream_t s);
 // Fine-frequency loop and counters of the stream call, after the demodulation launch on the same stream:

@@ -53,7 +53,24 @@ __device__ __forceinline__ unsigned pk_max(unsigned a, unsigned b) {
 }
 // (lo16(lo), lo16(hi))
 __device__ __forceinline__ unsigned pack16(int lo, int hi) { return __builtin_amdgcn_perm(unsigned(hi), unsigned(lo), 0x05040100u); }
-__device__ __forceinline__ unsigned swap16(unsigned a) { return __builtin_amdgcn_perm(a, a, 0x01000302u); }
+// a packed add / subtract whose FIRST operand has its halves swapped: (hi(a) +- lo(k), lo(a) +- hi(k)).  The swap rides on the
+// instruction's op_sel bits (the compiler does not fold a shuffle or a byte permute into them: it emits a second instruction)
+__device__ __forceinline__ unsigned pk_add_swapped(unsigned a, unsigned k) {
+    unsigned d;
+    asm("v_pk_add_u16 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]" : "=v"(d) : "v"(a), "v"(k));
+    return d;
+}
+__device__ __forceinline__ unsigned pk_sub_swapped(unsigned a, unsigned k) {
+    unsigned d;
+    asm("v_pk_sub_i16 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]" : "=v"(d) : "v"(a), "v"(k));
+    return d;
+}
+// (m & mask) | 1 in one instruction (a VOP3 cannot carry a 32-bit literal on this target: the mask travels in a scalar register)
+__device__ __forceinline__ unsigned and_or1(unsigned m, unsigned mask) {
+    unsigned d;
+    asm("v_and_or_b32 %0, %1, %2, 1" : "=v"(d) : "v"(m), "s"(mask));
+    return d;
+}
 
 __host__ __device__ constexpr int par7(int x) { x ^= x >> 4; x ^= x >> 2; x ^= x >> 1; return x & 1; }
 __host__ __device__ constexpr int rotl6c(int v, int r) { return r == 0 ? v : (((v << r) | (v >> (6 - r))) & 63); }
@@ -198,24 +215,33 @@ __global__ __launch_bounds__(256) void lane_prep_kernel(Src src, const int32_t *
 // ---------------------------------------------------------------------------------------------------------
 // K2: forward pass.  One wave = 64 codewords.
 // ---------------------------------------------------------------------------------------------------------
-// doubled branch correlations for the 8 sign patterns, low 16 bits valid
-struct Bm {
-    int c2[8];
+// The four soft bits of a trellis step (sign-extended) and the packed branch constants a phase needs.
+// A state's doubled branch correlation is 2c[S] = +-a +-b +-c with a = 2(s0 + s3), b = 2 s1, c = 2 s2 and the signs given
+// by the bits of its sign pattern S = sig_of(state) (bit set = plus), so c[S ^ 7] = -c[S].  The two states of a register
+// (its two 16-bit halves) differ in ONE state bit, i.e. their patterns differ by a constant D of the phase: the packed
+// constant of a register is (c[S], c[S ^ D]), and only the four odd S are formed -- with packed arithmetic, from a, b, c
+// packed with their second half negated where D says so; an even S uses the negative of its odd partner by swapping
+// the roles of add and subtract (lane_pair / lane_self1).
+struct Soft4 {
+    int s0, s1, s2, s3;
 };
-__device__ __forceinline__ Bm branch_metrics(uint32_t w) {
-    const int s0 = int(int8_t(w)), s1 = int(int8_t(w >> 8)), s2 = int(int8_t(w >> 16)), s3 = int(w) >> 24;
-    const int a = 2 * (s0 + s3), b = 2 * s1, c = 2 * s2;
-    const int e1 = a + b, e2 = a - b;
-    Bm m;
-    m.c2[7] = e1 + c;          // (+,+,+)
-    m.c2[3] = e1 - c;          // (+,+,-)
-    m.c2[5] = e2 + c;          // (+,-,+)
-    m.c2[1] = e2 - c;          // (+,-,-)
-    m.c2[0] = -m.c2[7];
-    m.c2[4] = -m.c2[3];
-    m.c2[2] = -m.c2[5];
-    m.c2[6] = -m.c2[1];
-    return m;
+__device__ __forceinline__ Soft4 unpack_soft(uint32_t w) {
+    return Soft4{int(int8_t(w)), int(int8_t(w >> 8)), int(int8_t(w >> 16)), int(w) >> 24};
+}
+struct KC {
+    unsigned k[4];             // index S >> 1 for S = 1, 3, 5, 7
+};
+template <int D>
+__device__ __forceinline__ KC branch_consts(const Soft4 &q) {
+    const int a = 2 * (q.s0 + q.s3), b = 2 * q.s1, c = 2 * q.s2;
+    const unsigned A2 = pack16(a, (D & 1) ? -a : a), B2 = pack16(b, (D & 2) ? -b : b), C2 = pack16(c, (D & 4) ? -c : c);
+    const unsigned e1 = pk_add(A2, B2), e2 = pk_sub(A2, B2);
+    KC k;
+    k.k[3] = pk_add(e1, C2);   // S = 7 (+,+,+)
+    k.k[1] = pk_sub(e1, C2);   // S = 3 (+,+,-)
+    k.k[2] = pk_add(e2, C2);   // S = 5 (+,-,+)
+    k.k[0] = pk_sub(e2, C2);   // S = 1 (+,-,-)
+    return k;
 }
 
 // Record the survivor tags (bits 0 and 16 of the max results) of a pair of registers: one byte gather, one mask,
@@ -230,67 +256,74 @@ __device__ __forceinline__ void take_tags(unsigned first, unsigned second, unsig
 }
 
 template <int PH, int I>
-__device__ __forceinline__ void lane_pair(unsigned (&M)[32], const Bm &bm, unsigned &acc0, unsigned &acc1) {
+__device__ __forceinline__ void lane_pair(unsigned (&M)[32], const KC &kc, unsigned &acc0, unsigned &acc1) {
     constexpr int Q = 5 - PH;                 // slot bit replaced in this step, 1..5 here
     constexpr int RB = Q - 1;                 // the same bit in register-index space
     constexpr int RA = ((I >> RB) << (RB + 1)) | (I & ((1 << RB) - 1));
     constexpr int RBI = RA | (1 << RB);
     constexpr int ROT = (PH + 1) % 6;         // layout after the step
-    constexpr int SLO = sig_of(rotl6c(2 * RA, ROT)), SHI = sig_of(rotl6c(2 * RA + 1, ROT));
-    const unsigned k2 = pack16(bm.c2[SLO], bm.c2[SHI]);        // 2c of the two new states of register RA
+    constexpr int SLO = sig_of(rotl6c(2 * RA, ROT));           // pattern of the register's low half; the high half's is SLO ^ D
+    static_assert(sig_of(rotl6c(2 * RA + 1, ROT)) == (SLO ^ sig_of(rotl6c(1, ROT))), "the halves differ by the phase's constant");
+    constexpr bool NEG = (SLO & 1) == 0;      // even pattern: minus the constant of its odd partner SLO ^ 7
+    const unsigned k2 = kc.k[(NEG ? (SLO ^ 7) : SLO) >> 1];
     const unsigned a1 = M[RA] | 0x00010001u;                   // older-bit-0 candidates are odd (metric + 1)
     const unsigned b = M[RBI] & 0xFFFEFFFEu;                   // older-bit-1 candidates even (metric)
-    const unsigned x = pk_add(a1, k2), y = pk_sub(b, k2);      // new states with newest bit 0 (register RA)
-    const unsigned u = pk_sub(a1, k2), v = pk_add(b, k2);      // newest bit 1 (register RB): c flips sign
+    // new states with newest bit 0 (register RA): a1 + 2c, b - 2c; newest bit 1 (register RB): c flips sign
+    const unsigned x = NEG ? pk_sub(a1, k2) : pk_add(a1, k2), y = NEG ? pk_add(b, k2) : pk_sub(b, k2);
+    const unsigned u = NEG ? pk_add(a1, k2) : pk_sub(a1, k2), v = NEG ? pk_sub(b, k2) : pk_add(b, k2);
     M[RA] = pk_max(x, y);
     M[RBI] = pk_max(u, v);
     take_tags<I>(M[RA], M[RBI], acc0, acc1);
 }
 
 template <int R>
-__device__ __forceinline__ unsigned lane_self1(unsigned m, const unsigned (&kk)[8]) {
+__device__ __forceinline__ unsigned lane_self1(unsigned m, const KC &kc) {
     // phase 5: the replaced bit is the half bit; both predecessors live in this register.  After the step the
-    // layout rotation is 0, so the new state of slot 2R is 2R itself.
+    // layout rotation is 0, so the new state of slot 2R is 2R itself, and both halves share one pattern (D = 0).
     constexpr int S = sig_of(2 * R);
-    const unsigned a = (m & 0xFFFEFFFFu) | 1u;           // (lo + 1, hi): odd older-bit-0, even older-bit-1 operand
-    const unsigned p = pk_add(a, kk[S]);                 // (lo + 1 + 2c, hi + 2c)
-    const unsigned q = pk_sub(swap16(a), kk[S]);         // (hi - 2c, lo + 1 - 2c)
+    constexpr bool NEG = (S & 1) == 0;
+    const unsigned k = kc.k[(NEG ? (S ^ 7) : S) >> 1];
+    const unsigned a = and_or1(m, 0xFFFEFFFFu);          // (lo + 1, hi): odd older-bit-0, even older-bit-1 operand
+    const unsigned p = NEG ? pk_sub(a, k) : pk_add(a, k);                 // (lo + 1 + 2c, hi + 2c)
+    const unsigned q = NEG ? pk_add_swapped(a, k) : pk_sub_swapped(a, k); // (hi - 2c, lo + 1 - 2c)
     return pk_max(p, q);
 }
 template <int I>
-__device__ __forceinline__ void lane_self(unsigned (&M)[32], const unsigned (&kk)[8], unsigned &acc0, unsigned &acc1) {
-    M[2 * I] = lane_self1<2 * I>(M[2 * I], kk);
-    M[2 * I + 1] = lane_self1<2 * I + 1>(M[2 * I + 1], kk);
+__device__ __forceinline__ void lane_self(unsigned (&M)[32], const KC &kc, unsigned &acc0, unsigned &acc1) {
+    M[2 * I] = lane_self1<2 * I>(M[2 * I], kc);
+    M[2 * I + 1] = lane_self1<2 * I + 1>(M[2 * I + 1], kc);
     take_tags<I>(M[2 * I], M[2 * I + 1], acc0, acc1);
 }
 
 template <int PH>
-__device__ __forceinline__ void lane_step(unsigned (&M)[32], uint32_t w, uint2 *dec_out) {
-    const Bm bm = branch_metrics(w);
+__device__ __forceinline__ void lane_step(unsigned (&M)[32], const Soft4 &q, uint2 *dec_out) {
     unsigned acc0 = 0, acc1 = 0;
     if constexpr (PH < 5) {
-        lane_pair<PH, 0>(M, bm, acc0, acc1);  lane_pair<PH, 1>(M, bm, acc0, acc1);
-        lane_pair<PH, 2>(M, bm, acc0, acc1);  lane_pair<PH, 3>(M, bm, acc0, acc1);
-        lane_pair<PH, 4>(M, bm, acc0, acc1);  lane_pair<PH, 5>(M, bm, acc0, acc1);
-        lane_pair<PH, 6>(M, bm, acc0, acc1);  lane_pair<PH, 7>(M, bm, acc0, acc1);
-        lane_pair<PH, 8>(M, bm, acc0, acc1);  lane_pair<PH, 9>(M, bm, acc0, acc1);
-        lane_pair<PH, 10>(M, bm, acc0, acc1); lane_pair<PH, 11>(M, bm, acc0, acc1);
-        lane_pair<PH, 12>(M, bm, acc0, acc1); lane_pair<PH, 13>(M, bm, acc0, acc1);
-        lane_pair<PH, 14>(M, bm, acc0, acc1); lane_pair<PH, 15>(M, bm, acc0, acc1);
+        const KC kc = branch_consts<sig_of(rotl6c(1, (PH + 1) % 6))>(q);
+        lane_pair<PH, 0>(M, kc, acc0, acc1);  lane_pair<PH, 1>(M, kc, acc0, acc1);
+        lane_pair<PH, 2>(M, kc, acc0, acc1);  lane_pair<PH, 3>(M, kc, acc0, acc1);
+        lane_pair<PH, 4>(M, kc, acc0, acc1);  lane_pair<PH, 5>(M, kc, acc0, acc1);
+        lane_pair<PH, 6>(M, kc, acc0, acc1);  lane_pair<PH, 7>(M, kc, acc0, acc1);
+        lane_pair<PH, 8>(M, kc, acc0, acc1);  lane_pair<PH, 9>(M, kc, acc0, acc1);
+        lane_pair<PH, 10>(M, kc, acc0, acc1); lane_pair<PH, 11>(M, kc, acc0, acc1);
+        lane_pair<PH, 12>(M, kc, acc0, acc1); lane_pair<PH, 13>(M, kc, acc0, acc1);
+        lane_pair<PH, 14>(M, kc, acc0, acc1); lane_pair<PH, 15>(M, kc, acc0, acc1);
     } else {
-        unsigned kk[8];
-#pragma unroll
-        for (int s = 0; s < 8; s++) kk[s] = pack16(bm.c2[s], bm.c2[s]);
-        lane_self<0>(M, kk, acc0, acc1);          lane_self<1>(M, kk, acc0, acc1);
-        lane_self<2>(M, kk, acc0, acc1);          lane_self<3>(M, kk, acc0, acc1);
-        lane_self<4>(M, kk, acc0, acc1);          lane_self<5>(M, kk, acc0, acc1);
-        lane_self<6>(M, kk, acc0, acc1);          lane_self<7>(M, kk, acc0, acc1);
-        lane_self<8>(M, kk, acc0, acc1);          lane_self<9>(M, kk, acc0, acc1);
-        lane_self<10>(M, kk, acc0, acc1);          lane_self<11>(M, kk, acc0, acc1);
-        lane_self<12>(M, kk, acc0, acc1);          lane_self<13>(M, kk, acc0, acc1);
-        lane_self<14>(M, kk, acc0, acc1);          lane_self<15>(M, kk, acc0, acc1);
+        const KC kc = branch_consts<0>(q);
+        lane_self<0>(M, kc, acc0, acc1);          lane_self<1>(M, kc, acc0, acc1);
+        lane_self<2>(M, kc, acc0, acc1);          lane_self<3>(M, kc, acc0, acc1);
+        lane_self<4>(M, kc, acc0, acc1);          lane_self<5>(M, kc, acc0, acc1);
+        lane_self<6>(M, kc, acc0, acc1);          lane_self<7>(M, kc, acc0, acc1);
+        lane_self<8>(M, kc, acc0, acc1);          lane_self<9>(M, kc, acc0, acc1);
+        lane_self<10>(M, kc, acc0, acc1);          lane_self<11>(M, kc, acc0, acc1);
+        lane_self<12>(M, kc, acc0, acc1);          lane_self<13>(M, kc, acc0, acc1);
+        lane_self<14>(M, kc, acc0, acc1);          lane_self<15>(M, kc, acc0, acc1);
     }
     st_stream(dec_out, make_uint2(acc0, acc1));
+}
+template <int PH>
+__device__ __forceinline__ void lane_step(unsigned (&M)[32], uint32_t w, uint2 *dec_out) {
+    lane_step<PH>(M, unpack_soft(w), dec_out);
 }
 
 // Four groups per workgroup (one per SIMD); the launcher pads the LDS request so that every CU gets the same
@@ -426,17 +459,19 @@ __device__ __forceinline__ void lane_forward_fused_body(const Src &src, const in
             const int32_t *dp = desc + 4 * min(t + 6, nsteps - 6);
 #pragma unroll
             for (int j = 0; j < 24; j++) dnxt[j] = dp[j];
-            uint32_t w[6];
+            // (signed byte reads straight into the four values a step works with: nothing is packed and unpacked again)
+            Soft4 w[6];
+            const int8_t *mys = reinterpret_cast<const int8_t *>(my);
 #pragma unroll
             for (int i = 0; i < 6; i++) {
-                uint32_t v = 0;
+                int v[4];
 #pragma unroll
                 for (int m = 0; m < 4; m++) {
                     const int dsc = dcur[4 * i + m];                            // wave-uniform: column | delay << 8
                     const int off = int((unsigned(dsc) >> dsh) & 0xFFFFu) + dex;
-                    v |= uint32_t(my[off]) << (8 * m);
+                    v[m] = int(mys[off]);
                 }
-                w[i] = v;
+                w[i] = Soft4{v[0], v[1], v[2], v[3]};
             }
 #pragma unroll
             for (int j = 0; j < 24; j++) dcur[j] = dnxt[j];

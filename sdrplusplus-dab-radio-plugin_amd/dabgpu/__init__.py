@@ -55,6 +55,7 @@ PLAIN_REASONS = {0: "plain requested", 1: "buffers too small (or too many chunks
 FLAG_VITERBI_WAVE = 1 << 0
 FLAG_VITERBI_LANE = 1 << 1
 FLAG_LANE_UNFUSED = 1 << 2
+FLAG_OFDM_PREFETCH, FLAG_OFDM_EARLY8, FLAG_OFDM_EARLY4 = 1 << 3, 1 << 4, 1 << 5
 
 
 class DabGpuError(RuntimeError):
@@ -389,6 +390,7 @@ class Context:
 
     def __init__(self, device=0, max_frames=64, flags=0, ofdm_symbol_runs=0, library=None):
         self._h = C.c_void_p()
+        self._device = int(device)
         self._lib = library if library is not None else lib()
         cfg = Cfg(device, max_frames, 1, flags, ofdm_symbol_runs)
         _check(self._lib.dabgpu_create(C.byref(cfg), C.byref(self._h)), "dabgpu_create")

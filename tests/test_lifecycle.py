@@ -89,7 +89,7 @@ def test_two_contexts_keep_their_own_stream_states(built, ensemble, ensemble_iq)
 
 def test_placed_allocations_repeat(built):
     """dabgpu_alloc_frame_buffers(PLACE_DOMAINS) / free, twenty times over IN THIS PROCESS: every call succeeds through
-    the context's one address range (same addresses every round), the reports stay sane, and the device's free memory
+    the context's address ranges, reserved once (same addresses every round), the reports stay sane, and the device's free memory
     ends where it began.  (Round 3 ran this in a process of its own and excused a crash of the runtime's virtual-memory
     API; the allocator no longer frees and re-reserves address ranges, which is what provoked it.  tools/alloc_stress.py
     is the long version: hundreds of rounds beside a process that holds 100 GB.)"""

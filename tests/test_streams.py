@@ -315,9 +315,9 @@ def test_decision_directed_front_end_and_loop(built, ensemble, ensemble_iq):
 
 def test_alloc_frame_buffers_by_domain(built, ensemble_iq):
     """dabgpu_alloc_frame_buffers(PLACE_DOMAINS) on a 5 GiB pair: chunks through the virtual-memory API inside the
-    context's ONE address range, never more than 1.5 x the pair held, the buffers behave like any device memory (torch
+    context's own address ranges (reserved once), never more than 1.5 x the pair held, the buffers behave like any device memory (torch
     tensors over them, the front end run on them gives the host-pointer call's soft bits), a second request while the
-    pair is alive is a plain pair, releasing gives the memory back, and the same range serves the next request."""
+    pair is alive is a plain pair, releasing gives the memory back, and the same ranges serve the next request."""
     import torch
     L = dabgpu.NB_FRAME_SAMPLES
     dev = torch.device("cuda", 0)
@@ -367,7 +367,7 @@ def test_alloc_frame_buffers_by_domain(built, ensemble_iq):
     c.free_frame_buffers(d_iq, d_soft)
     torch.cuda.synchronize()
     assert free0 - torch.cuda.mem_get_info()[0] <= 64 << 20
-    # the same range serves the next pair (same addresses); a larger one than it was reserved for is a plain pair
+    # the same ranges serve the next pair (same addresses); a larger one than they were reserved for is a plain pair
     f_iq, f_soft, rep3 = c.alloc_frame_buffers(n, L, dabgpu.PLACE_DOMAINS)
     assert rep3.method == 1 and f_iq == d_iq
     g_iq, g_soft, rep4 = c.alloc_frame_buffers(2 * n, L, dabgpu.PLACE_DOMAINS)
