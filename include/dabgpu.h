@@ -114,11 +114,6 @@ typedef struct dabgpu_cfg {
                                            /* above ~680 kbit/s do not fit its LDS slab: those go per lane)      */
 #define DABGPU_FLAG_VITERBI_LANE  (1 << 1) /* one codeword per lane wherever the length allows, any batch size */
 #define DABGPU_FLAG_LANE_UNFUSED  (1 << 2) /* lane decoder: separate depuncture pass before the forward pass   */
-/* front end, plain data flow (no constellation output, no selection): the structural variants round 4 measured and
- * rejected (profiles/r04_front_end_variants.txt) -- same results bit for bit; kept for the A/B */
-#define DABGPU_FLAG_OFDM_PREFETCH (1 << 3) /* two waves per SIMD, the next symbol's loads in a second register set */
-#define DABGPU_FLAG_OFDM_EARLY8   (1 << 4) /* eight rows of the next symbol requested before the epilogue          */
-#define DABGPU_FLAG_OFDM_EARLY4   (1 << 5) /* four rows                                                             */
 
 /* Replaces the construction in Radio_Block::Radio_Block
  * (/root/reference/src/radio_block.cpp:11-22: params + PRS + mapper + OFDM_Demod). */
@@ -345,9 +340,9 @@ int dabgpu_get_stats(dabgpu_ctx *ctx, int stream_index, dabgpu_stats *out);
 int dabgpu_set_stream_loop(dabgpu_ctx *ctx, float signal_update_beta, float thr_null_start, int decision_directed);
 /* The decision-directed loop checks its own estimate before it moves (stream call here; tracked and frame calls:
  * dabgpu_track_cfg.dd_gate).  With S = the call's sum of unit fourth powers over n terms:
- *   quality  |S| < dd_gate * sqrt(n) -- what n random phases add up to, times the gate (8 by default): the sum carries no
- *            usable phase (3 dB SNR and less on single frames, an interferer, nothing selected) and the call takes the
- *            cyclic-prefix estimate of its PRSs alone -- unbiased, coarser; 0 switches this gate off.
+ *   quality  |S| < dd_gate * sqrt(n) -- what n random phases add up to, times the gate (2.5 by default): the sum carries no
+ *            usable phase (single frames below ~3 dB SNR, nothing selected) and the call takes the cyclic-prefix
+ *            estimate of its PRSs alone -- unbiased, coarser; 0 switches this gate off.
  *   branch   a stream whose previous residual lay inside +-0.1 carriers and whose PRS prefix now asks for the branch one
  *            step (0.2 carriers) away is believed only when the next call asks again; the first time the branch is held.
  * Either event counts in loop_gated (dabgpu_get_stats).  The loop on the cyclic-prefix correlations -- the reference's
@@ -538,7 +533,7 @@ typedef struct dabgpu_track_cfg {
                                               /* that are tracking cost nothing extra.  One call does  */
                                               /* everything from the first capture on (0)              */
     float dd_gate;                            /* decision-directed loop: quality gate, see             */
-                                              /* dabgpu_set_loop_gate (8; 0 = off)                     */
+                                              /* dabgpu_set_loop_gate (2.5; 0 = off)                   */
     int32_t reserved;                         /* must be 0                                             */
 } dabgpu_track_cfg;
 void dabgpu_track_default_cfg(dabgpu_track_cfg *cfg);

@@ -222,7 +222,7 @@ def dd_error(dd4):
 DD_NO_BRANCH = 0x7fffffff
 
 
-def dd_loop_error(dd4, state, gate=8.0, terms_per_frame=19200):
+def dd_loop_error(dd4, state, gate=2.5, terms_per_frame=19200):
     """The decision-directed fine-frequency error of a call WITH its two gates (TEST INFRASTRUCTURE; restates
     dabk::dd_loop_error, csrc/kernels.hpp -- an estimator of this library's own: the reference shows only that a fine loop
     exists, /root/reference/src/render_radio_block.cpp:202, :216).  dd4: rows [frames][76] (entry 0 = PRS cyclic-prefix
@@ -253,7 +253,7 @@ def dd_loop_error(dd4, state, gate=8.0, terms_per_frame=19200):
     return err, {"loop_gated": gated, "dd_branch": k, "dd_pending": pending}
 
 
-def stream_update(state, cyc, iq_last_frame, beta, thr_null_start=0.35, signal_beta=0.95, dd=False, dd_gate=8.0, terms_per_frame=19200):
+def stream_update(state, cyc, iq_last_frame, beta, thr_null_start=0.35, signal_beta=0.95, dd=False, dd_gate=2.5, terms_per_frame=19200):
     """Restatement of the fine-frequency loop and counters of the stream call (TEST INFRASTRUCTURE; parity unpinned:
     the loop runs inside the absent DAB-Radio OFDM_Demod, its existence and knobs are visible at
     /root/reference/src/render_radio_block.cpp:202-207, :216).  state: dict with fine_freq_offset,
@@ -491,7 +491,7 @@ def track_sync(iq, state, max_frames, margin=64, min_peak_to_mean=100.0, distanc
 
 
 def track_update(state, frames, cyc, iq, n_samples, max_frames, advance, fine_beta=0.9, drift_beta=0.5, signal_beta=0.95,
-                 thr_null_start=0.35, dd=False, dd_gate=8.0, terms_per_frame=19200):
+                 thr_null_start=0.35, dd=False, dd_gate=2.5, terms_per_frame=19200):
     """State after a tracked call: `frames` from track_sync, `cyc` complex [len(frames)][76] of the demodulated frames
     (rows of unlocked frames are ignored), `iq` the capture.  Returns (new state dict, count)."""
     st = dict(state)

@@ -195,8 +195,7 @@ int dabgpu_create(const dabgpu_cfg *cfg, dabgpu_ctx **out) {
     if (!cfg || !out) return DABGPU_ERR_ARG;
     *out = nullptr;
     if (cfg->transmission_mode != 1) return DABGPU_ERR_PROFILE;
-    constexpr int OFDM_FLAGS = DABGPU_FLAG_OFDM_PREFETCH | DABGPU_FLAG_OFDM_EARLY8 | DABGPU_FLAG_OFDM_EARLY4;
-    constexpr int KNOWN_FLAGS = DABGPU_FLAG_VITERBI_WAVE | DABGPU_FLAG_VITERBI_LANE | DABGPU_FLAG_LANE_UNFUSED | OFDM_FLAGS;
+    constexpr int KNOWN_FLAGS = DABGPU_FLAG_VITERBI_WAVE | DABGPU_FLAG_VITERBI_LANE | DABGPU_FLAG_LANE_UNFUSED;
     if ((cfg->flags & ~KNOWN_FLAGS) || ((cfg->flags & DABGPU_FLAG_VITERBI_WAVE) && (cfg->flags & DABGPU_FLAG_VITERBI_LANE)))
         return DABGPU_ERR_ARG;
     if (cfg->ofdm_symbol_runs < 0 || cfg->ofdm_symbol_runs > NB_DATA_SYMBOLS) return DABGPU_ERR_ARG;
@@ -215,7 +214,6 @@ int dabgpu_create(const dabgpu_cfg *cfg, dabgpu_ctx **out) {
     ctx->ofdm_parts_override = cfg->ofdm_symbol_runs;
     ctx->lane_mode = (cfg->flags & DABGPU_FLAG_VITERBI_LANE) ? 1 : (cfg->flags & DABGPU_FLAG_VITERBI_WAVE) ? 0 : -1;
     ctx->lane_unfused = (cfg->flags & DABGPU_FLAG_LANE_UNFUSED) != 0;
-    ctx->ofdm_variant = (cfg->flags & DABGPU_FLAG_OFDM_PREFETCH) ? 1 : (cfg->flags & DABGPU_FLAG_OFDM_EARLY8) ? 2 : (cfg->flags & DABGPU_FLAG_OFDM_EARLY4) ? 3 : 0;
     ctx->wave_slots = prop.multiProcessorCount > 0 ? prop.multiProcessorCount * 12 : 3072;   // 3 workgroups x 4 waves per CU
     int rc = DABGPU_OK;
     do {
@@ -412,7 +410,7 @@ int dabgpu_ofdm_demod_frames_dev(dabgpu_ctx *ctx, const void *d_iq, size_t frame
     ScopedTimer tm(ctx, 0, s);
     const RunPlan plan = plan_runs(ctx, n_frames, NB_DATA_SYMBOLS);
     a.uncut_frames = plan.uncut_frames;
-    HIP_TRY(dabk::launch_ofdm_demod(tab, a, plan.parts, s, ctx->ofdm_variant));
+    HIP_TRY(dabk::launch_ofdm_demod(tab, a, plan.parts, s));
     return DABGPU_OK;
 }
 
@@ -437,7 +435,7 @@ int dabgpu_ofdm_demod_frames_dd_dev(dabgpu_ctx *ctx, const void *d_iq, size_t fr
     ScopedTimer tm(ctx, 0, s);
     const RunPlan plan = plan_runs(ctx, n_frames, NB_DATA_SYMBOLS);
     a.uncut_frames = plan.uncut_frames;
-    HIP_TRY(dabk::launch_ofdm_demod(tab, a, plan.parts, s, ctx->ofdm_variant));
+    HIP_TRY(dabk::launch_ofdm_demod(tab, a, plan.parts, s));
     return DABGPU_OK;
 }
 
@@ -709,7 +707,7 @@ int dabgpu_ofdm_demod_streams_dev(dabgpu_ctx *ctx, const void *d_iq, size_t fram
         ScopedTimer tm(ctx, 0, s);
         const RunPlan plan = plan_runs(ctx, n_frames, NB_DATA_SYMBOLS);
         a.uncut_frames = plan.uncut_frames;
-        HIP_TRY(dabk::launch_ofdm_demod(tab, a, plan.parts, s, ctx->ofdm_variant));
+        HIP_TRY(dabk::launch_ofdm_demod(tab, a, plan.parts, s));
     }
     HIP_TRY(dabk::launch_stream_update(ctx->d_states, dd ? a.dd4 : a.cyc, a.iq, frame_stride, n_streams, frames_per_stream,
                                        fine_freq_update_beta, ctx->thr_null_start, ctx->signal_beta, dd ? 1 : 0, ctx->dd_gate,
@@ -952,7 +950,7 @@ int dabgpu_ofdm_demod_acquired_dev(dabgpu_ctx *ctx, const void *d_iq, size_t str
     ScopedTimer tm(ctx, 0, s);
     const RunPlan plan = plan_runs(ctx, a.n_frames, NB_DATA_SYMBOLS);
     a.uncut_frames = plan.uncut_frames;
-    HIP_TRY(dabk::launch_ofdm_demod(tab, a, plan.parts, s, ctx->ofdm_variant));
+    HIP_TRY(dabk::launch_ofdm_demod(tab, a, plan.parts, s));
     return DABGPU_OK;
 }
 
@@ -972,7 +970,7 @@ void dabgpu_track_default_cfg(dabgpu_track_cfg *cfg) {
     cfg->max_coarse_carriers = 204;
     cfg->decision_directed = 1;
     cfg->auto_acquire = 0;
-    cfg->dd_gate = 8.0f;
+    cfg->dd_gate = 2.5f;
 }
 
 static int track_cfg(const dabgpu_track_cfg *cfg, dabgpu_track_cfg &c) {
@@ -1053,7 +1051,7 @@ static int tracked_launches(dabgpu_ctx *ctx, dabk::StreamState *states, const vo
         ScopedTimer tm(ctx, 0, s);
         const RunPlan plan = plan_runs(ctx, a.n_frames, NB_DATA_SYMBOLS);
         a.uncut_frames = plan.uncut_frames;
-        HIP_TRY(dabk::launch_ofdm_demod(tab, a, plan.parts, s, ctx->ofdm_variant));
+        HIP_TRY(dabk::launch_ofdm_demod(tab, a, plan.parts, s));
     }
     dabk::TrackUpdateArgs u{};
     u.state = states;

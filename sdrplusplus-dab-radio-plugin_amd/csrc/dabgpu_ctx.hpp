@@ -84,7 +84,6 @@ struct dabgpu_ctx {
     int lane_mode = -1;                  // 1 = DABGPU_FLAG_VITERBI_LANE, 0 = DABGPU_FLAG_VITERBI_WAVE, -1 by batch size
     bool lane_unfused = false;           // DABGPU_FLAG_LANE_UNFUSED
     int wave_slots = 3072;               // resident OFDM wavefronts: 12 per CU
-    int ofdm_variant = 0;                // DABGPU_FLAG_OFDM_*: 0 = ofdm_wave_kernel
     std::vector<dabgpu_bit_range> keep_ranges;           // the current selection, merged, for the host-pointer copy-back
     dabk::StreamState *d_states = nullptr;               // per-stream tracking state (dabgpu_streams_reset)
     int n_states = 0;
@@ -93,7 +92,7 @@ struct dabgpu_ctx {
     float thr_null_start = 0.35f;        // desync threshold of the stream call (null_l1_search.thresh_null_start)
     float signal_beta = 0.95f;           // signal_l1.update_beta of the stream call
     bool loop_dd = false;                // stream call without a correlation buffer: decision-directed fine loop
-    float dd_gate = 8.0f;                // decision-directed loop: quality gate (dabgpu_set_loop_gate, dabk::dd_loop_error)
+    float dd_gate = 2.5f;                // decision-directed loop: quality gate (dabgpu_set_loop_gate, dabk::dd_loop_error)
     int keep_symbols = 75;               // data symbols per frame the current selection demodulates (75: no selection)
     // dabgpu_decode_stream_frames: de-interleaver rings of the stream's sub-channels, kept on the device between calls
     struct SubHistory {

@@ -70,9 +70,7 @@ struct OfdmArgs {
 
 // fused A2..A6.  Frames behind the first a.uncut_frames are cut into `parts` contiguous runs of data symbols (1..75);
 // a run re-reads the symbol before it as differential reference.
-// variant (plain data flow only): 1 = two waves per SIMD with the next symbol's loads in flight in a second register set
-// (ofdm_wave_pf_kernel), 2 / 3 = eight / four rows of the next symbol requested before the epilogue (ofdm_wave_early_kernel); 0 = ofdm_wave_kernel
-hipError_t launch_ofdm_demod(const OfdmTables &t, const OfdmArgs &a, int parts, hipStream_t s, int variant = 0);
+hipError_t launch_ofdm_demod(const OfdmTables &t, const OfdmArgs &a, int parts, hipStream_t s);
 // A2+A3 only; parts in 1..76.
 hipError_t launch_fft_symbols(const OfdmTables &t, const OfdmArgs &a, int parts, hipStream_t s);
 // Fine-frequency loop and counters of the stream call, after the demodulation launch on the same stream:
@@ -208,8 +206,11 @@ hipError_t launch_track_sync(const SyncTables &t, const TrackArgs &a, hipStream_
 // The fourth-power estimate e_dd = angle(-sum) / (4 2 pi 2552) repeats every 1 / (4 2552) cycles per sample (0.2 carriers);
 // e_cp picks its branch k.  Two things can make that wrong, and both are gated:
 //   quality   |sum| is compared with what n_terms random unit phasors add up to (sqrt(n_terms)): below `gate` times that
-//             (gate > 0; 8 by default) the sum carries no usable phase -- 3 dB SNR and less on single frames, an
-//             interferer, an empty selection -- and the call takes e_cp alone: unbiased, coarser.
+//             (2.5 by default; 0 = off) the sum carries no usable phase -- single frames below ~3 dB SNR, an empty selection
+//             -- and the call takes e_cp alone: unbiased, coarser.  (At s = |sum| / sqrt(n_terms) the estimate's spread
+//             is 0.0225 / s carriers; a single PRS prefix has ~0.008-0.012 at 3-0 dB: the two cross near s = 2-3, and a
+//             pure-noise sum exceeds 2.5 once in 500 calls.  profiles/r04_loop_gate.txt has the table: 8 was too
+//             cautious -- at 3 dB it threw away an estimate twice as good as the prefix's.)
 //   branch    a stream that was locked (previous branch 0: residual inside +-0.1 carriers) and now asks for branch +-1
 //             has, far more often than a real 200 Hz jump between two calls, a PRS prefix hit by a fade or an impulse:
 //             the departure must be seen on two consecutive calls before it is believed; the first time the branch is
@@ -253,7 +254,7 @@ struct TrackUpdateArgs {
     int fixed_start;
     int32_t *counts;           // [n_streams] or nullptr
     int settle_only = 0;       // only turn "started in this call" marks (tracking == 2) into 1
-    float dd_gate = 8.0f;      // dd_loop_error's quality gate
+    float dd_gate = 2.5f;      // dd_loop_error's quality gate
     int dd_terms_per_frame = 19200;   // unit terms one frame adds to the sums (256 carriers x the symbols that are demodulated)
 };
 hipError_t launch_track_update(const TrackUpdateArgs &a, hipStream_t s);

@@ -513,561 +513,6 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// The structural variant of round 4 ("one more attempt"; DABGPU_FLAG_OFDM_PREFETCH): the same arithmetic,
-// bit for bit, with the NEXT symbol's sixteen loads in flight while the current symbol is transformed.  That takes a
-// second set of 64 data registers, so a SIMD holds two wavefronts instead of three (launch bounds 256 x 2: 256 VGPRs
-// each); the symbol loop is unrolled by two so that the two sets swap roles without a copy.  Whole frames only in the
-// plain data flow (no constellation output, no soft-bit selection): everything else takes ofdm_wave_kernel.
-// (The variant the round-3 review named -- previous spectrum in LDS -- does not fit: 12 KB per wave x 12 waves = 144 KB
-// beside 12 x 8 KB of exchange buffers and 19 KB of tables is 259 KB of a CU's 160 KB.)
-// ---------------------------------------------------------------------------------------------------------
-template <bool NCO>
-__global__ __launch_bounds__(64 * WAVES, 2) void ofdm_wave_pf_kernel(OfdmTables tab, OfdmArgs a, int parts, int n_items) {
-    __shared__ WaveLds sm;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    for (int i = tid; i < NB_FFT; i += 64 * WAVES) {
-        int m;
-        if (i < TW_E1) {
-            const int k2 = i / 49, r = i - 49 * k2;
-            const int hi = r / 24, s = r - 24 * hi, kq = s / 12, s2 = s - 12 * kq;
-            m = r == 48 ? 0 : 2 * ((s2 >> 2) + 1) * (hi * 8 + kq * 4 + (s2 & 3) + 16 * k2);
-        } else if (i < TW_T1) {
-            const int j = i - TW_E1, k2 = j >> 6, r = j & 63;
-            m = (2 * ((r >> 2) & 3) + 1) * ((r >> 5) * 8 + ((r >> 4) & 1) * 4 + (r & 3) + 16 * k2);
-        } else {
-            const int j = i - TW_T1;
-            m = 8 * (j & 15) * ((j >> 4) + 1);
-        }
-        sm.tw[i] = tab.twiddle[m];
-    }
-    for (int i = tid; i < 12 * 64; i += 64 * WAVES) sm.nidx[i] = reinterpret_cast<const uint32_t *>(tab.n_of_vj)[i];
-    __syncthreads();
-    const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES + wave);
-    if (item >= n_items) return;
-    int frame = item, part = 0;
-    if (item >= a.uncut_frames) {
-        const int j = item - a.uncut_frames;
-        frame = a.uncut_frames + j / parts;
-        part = j - (frame - a.uncut_frames) * parts;
-    } else {
-        parts = 1;
-    }
-    const float2 *fiq = a.iq + size_t(frame) * a.frame_stride;
-    const int l_first = (NB_DATA_SYMBOLS * part) / parts;
-    const int l_last = (NB_DATA_SYMBOLS * (part + 1)) / parts;
-    uint32_t dphi_acq = 0u;
-    if (a.acq) {
-        const AcquiredFrame m = a.acq[frame];
-        if ((m.flags & 3) != 3) {
-            uint4 *o = reinterpret_cast<uint4 *>(a.soft + size_t(frame) * NB_FRAME_BITS + size_t(l_first) * NB_SYM_BITS);
-            const int n16 = (l_last - l_first) * NB_SYM_BITS / 16;
-            for (int i = lane; i < n16; i += 64) st_stream(o + i, make_uint4(0u, 0u, 0u, 0u));
-            return;
-        }
-        fiq = a.iq + size_t(frame / a.acq_per_stream) * a.frame_stride + m.start;
-        dphi_acq = uint32_t(__double2ll_rn(double(m.freq_offset) * 4294967296.0));
-    }
-    const bool aligned16 = (reinterpret_cast<uintptr_t>(fiq) & 15u) == 0;
-    const uint32_t dphi = a.acq ? dphi_acq : frame_dphi(a, frame);
-    float2 *ex = sm.ex[wave];
-    const float2 *tw = sm.tw;
-    float2 prev[24];
-#pragma unroll
-    for (int j = 0; j < 24; j++) prev[j] = make_float2(0.f, 0.f);
-    const float2 r128 = uniform(nco(128u, dphi)), rot2048 = uniform(nco(uint32_t(NB_FFT), dphi));
-    float2 codd[4];
-    {
-        const float2 r1 = nco(1u, dphi);
-        codd[0] = uniform(r1);
-        codd[1] = uniform(cmul_k(r1, SQRT1_2, -SQRT1_2));
-        codd[2] = uniform(mul_mj(r1));
-        codd[3] = uniform(cmul_k(r1, -SQRT1_2, -SQRT1_2));
-    }
-    float2 *const qout = a.cyc;
-    const bool dd = a.cyc == nullptr && a.dd4 != nullptr;
-    float2 ddacc = make_float2(0.f, 0.f);
-    auto put_cyc = [&](const int l, const float2 c) {
-        const int slot = (l - l_first) & 31;
-        if (lane == 0) sm.cyc[wave][slot] = c;
-        if (slot == 31 || l == l_last) {
-            lds_stores_done();
-            lds_loads_may_start();
-            const int li = l - slot + lane;
-            if (lane <= slot && (li > l_first || li == 0)) st_stream(qout + size_t(frame) * NB_FRAME_SYMBOLS + li, sm.cyc[wave][lane]);
-        }
-    };
-    // the sixteen loads of symbol l into one of the two register sets
-    auto fetch = [&](const int l, float2 (&d0)[16], float2 (&d1)[16]) {
-        const float2 *sym = fiq + size_t(l) * NB_SYM_PERIOD;
-        if (aligned16) {
-            const float4 *rows = reinterpret_cast<const float4 *>(sym + NB_CP) + lane;
-#pragma unroll
-            for (int n1 = 0; n1 < 16; n1++) {
-                const float4 v = ld_stream(rows + 64 * n1);
-                d0[n1] = make_float2(v.x, v.y);
-                d1[n1] = make_float2(v.z, v.w);
-            }
-        } else {
-            const float2 *rows = sym + NB_CP + 2 * lane;
-#pragma unroll
-            for (int n1 = 0; n1 < 16; n1++) {
-                d0[n1] = ld_stream(rows + 128 * n1);
-                d1[n1] = ld_stream(rows + 128 * n1 + 1);
-            }
-        }
-    };
-    // one symbol: x0 / x1 hold its samples (requested one symbol ago); y0 / y1 receive the next symbol's
-    auto symbol = [&](const int l, float2 (&x0)[16], float2 (&x1)[16], float2 (&y0)[16], float2 (&y1)[16]) {
-        const float2 *sym = fiq + size_t(l) * NB_SYM_PERIOD;
-        const bool emit = (l > l_first) || (l == 0);
-        int li = lane;
-        asm volatile("" : "+v"(li));
-        const int n2i = li >> 2, pi = li & 3;
-        const int k1v = li & 15, kk = li >> 4;
-        const int w1_base = pi * 256, w1_r = n2i ^ (pi << 2);
-        const int w2_base = pi * 256 + (n2i ^ (pi << 2));
-        const int r2_base = kk * 16;
-        float2 w = make_float2(1.f, 0.f);
-        if constexpr (NCO) w = nco(uint32_t(l * NB_SYM_PERIOD + NB_CP + 2 * lane), dphi);
-        __builtin_amdgcn_sched_barrier(0);
-        if (l < l_last) fetch(l + 1, y0, y1);                  // in flight for the whole of this symbol's arithmetic
-        __builtin_amdgcn_sched_barrier(0);
-        if ((a.cyc && emit) || (dd && l == 0)) {
-            float2 acc = make_float2(0.f, 0.f);
-            const float2 *cp = sym + 2 * (lane - 4);
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                if (i > 0 || lane >= 4) {
-                    float4 c;
-                    if (aligned16) {
-                        c = ld_stream(reinterpret_cast<const float4 *>(cp + 128 * i));
-                    } else {
-                        const float2 c0 = ld_stream(cp + 128 * i), c1 = ld_stream(cp + 128 * i + 1);
-                        c = make_float4(c0.x, c0.y, c1.x, c1.y);
-                    }
-                    const float2 u0 = x0[12 + i], u1 = x1[12 + i];
-                    acc.x += c.x * u0.x + c.y * u0.y + c.z * u1.x + c.w * u1.y;
-                    acc.y += c.x * u0.y - c.y * u0.x + c.z * u1.y - c.w * u1.x;
-                }
-            }
-            acc.x = wave_sum(acc.x, lane);
-            acc.y = wave_sum(acc.y, lane);
-            if (dd) { if (lane == 0) st_stream(a.dd4 + size_t(frame) * NB_FRAME_SYMBOLS, cmul(acc, rot2048)); }
-            else put_cyc(l, cmul(acc, rot2048));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (NCO) {
-#pragma unroll
-            for (int n1 = 0; n1 < 16; n1++) {
-                x0[n1] = cmul(x0[n1], w);
-                x1[n1] = cmul(x1[n1], w);
-                asm volatile("" : "+v"(x0[n1].x), "+v"(x0[n1].y), "+v"(x1[n1].x), "+v"(x1[n1].y));
-                w = cmul(w, r128);
-                asm volatile("" : "+v"(w.x), "+v"(w.y));
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        fft16(x0);
-        __builtin_amdgcn_sched_barrier(0);
-        fft16(x1);
-        __builtin_amdgcn_sched_barrier(0);
-        {
-            const float2 *t1 = tw + TW_T1 + n2i;
-#pragma unroll
-            for (int k1 = 1; k1 < 16; k1++) {
-                const float2 t = t1[(k1 - 1) * 16];
-                x0[k1] = cmul(x0[k1], t);
-                x1[k1] = cmul(x1[k1], t);
-            }
-        }
-        const int r1b = pi * 256 + n2i * 16, r1x = (pi << 2) ^ ((n2i >> 1) & 3);
-#pragma unroll
-        for (int k1 = 0; k1 < 16; k1++) ex[w1_base + k1 * 16 + (w1_r ^ ((k1 >> 1) & 3))] = x0[k1];
-        lds_stores_done();
-        lds_loads_may_start();
-#pragma unroll
-        for (int m = 0; m < 16; m++) x0[m] = ex[r1b + (m ^ r1x)];
-        lds_stores_done();
-#pragma unroll
-        for (int k1 = 0; k1 < 16; k1++) ex[w1_base + k1 * 16 + (w1_r ^ ((k1 >> 1) & 3))] = x1[k1];
-        lds_stores_done();
-        lds_loads_may_start();
-#pragma unroll
-        for (int m = 0; m < 16; m++) x1[m] = ex[r1b + (m ^ r1x)];
-        __builtin_amdgcn_sched_barrier(0);
-        fft16(x0);
-        __builtin_amdgcn_sched_barrier(0);
-        fft16(x1);
-        __builtin_amdgcn_sched_barrier(0);
-        {
-            const int hi = n2i >> 3, kq = (n2i >> 2) & 1, klo = n2i & 3;
-            const float2 *t0 = tw + (pi ? hi * 24 + kq * 12 + (pi - 1) * 4 + klo : 48);
-            const float2 *t1 = tw + TW_E1 + hi * 32 + kq * 16 + pi * 4 + klo;
-#pragma unroll
-            for (int k2 = 0; k2 < 16; k2++) {
-                x0[k2] = cmul(x0[k2], t0[49 * k2]);
-                x1[k2] = cmul(x1[k2], t1[64 * k2]);
-            }
-        }
-        float2 X[4][8];
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            lds_stores_done();
-#pragma unroll
-            for (int k2 = 0; k2 < 8; k2++) {
-                ex[w2_base + k2 * 16] = x0[8 * h + k2];
-                ex[w2_base + k2 * 16 + 128] = x1[8 * h + k2];
-            }
-            lds_stores_done();
-            lds_loads_may_start();
-#pragma unroll
-            for (int cc = 0; cc < 2; cc++) {
-#pragma unroll
-                for (int n3 = 0; n3 < 8; n3++)
-                    X[2 * h + cc][n3] = ex[n3 * 128 + cc * 64 + r2_base + (k1v ^ ((n3 >> 1) << 2))];
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            if constexpr (NCO) fft8_odd_scaled(X[c], codd);
-            else fft8(X[c]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        float2 cur[24];
-#pragma unroll
-        for (int j = 0; j < 24; j++) {
-            const int m = j < 12 ? j : j + 8;
-            cur[j] = X[m & 3][m >> 2];
-        }
-        if (lane == 0) cur[0] = X[0][3];
-        if (l > l_first) {
-            uint8_t *stg = reinterpret_cast<uint8_t *>(ex);
-            lds_stores_done();
-            float2 t = make_float2(0.f, 0.f);
-#pragma unroll
-            for (int j = 0; j < 24; j++) {
-                const float2 d = cmulc(cur[j], prev[j]);
-                const float Amax = fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), 1.0e-30f);
-                const float sc = -127.00003f * __builtin_amdgcn_rcpf(Amax);
-                const float fx = d.x * sc, fy = d.y * sc;
-                const int br = int(fx), bi = int(fy);
-                if ((j < 2 || j >= 22) && dd) {
-                    const float2 u = unit_of(fx, fy);
-                    const float2 z = make_float2(u.x * u.x - u.y * u.y, 2.0f * u.x * u.y);
-                    t.x += z.x * z.x - z.y * z.y;
-                    t.y += 2.0f * z.x * z.y;
-                }
-                const uint32_t nd = sm.nidx[(j >> 1) * 64 + lane];
-                const uint32_t ni = (j & 1) ? (nd >> 16) : (nd & 0xFFFFu);
-                stg[ni] = uint8_t(br);
-                stg[NB_CARRIERS + ni] = uint8_t(bi);
-            }
-            if (dd) ddacc = uniform(make_float2(ddacc.x + wave_sum(t.x, lane), ddacc.y + wave_sum(t.y, lane)));
-            lds_stores_done();
-            lds_loads_may_start();
-            const uint4 *sv = reinterpret_cast<const uint4 *>(stg) + lane;
-            uint4 *o = reinterpret_cast<uint4 *>(a.soft + size_t(frame) * NB_FRAME_BITS + size_t(l - 1) * NB_SYM_BITS) + lane;
-            const uint4 s0 = sv[0], s1 = sv[64], s2 = sv[128];
-            st_stream(o, s0); st_stream(o + 64, s1); st_stream(o + 128, s2);
-        }
-#pragma unroll
-        for (int j = 0; j < 24; j++) prev[j] = cur[j];
-    };
-    float2 A0[16], A1[16], B0[16], B1[16];
-    fetch(l_first, A0, A1);
-    for (int l = l_first; l <= l_last; l += 2) {
-        symbol(l, A0, A1, B0, B1);
-        if (l + 1 <= l_last) symbol(l + 1, B0, B1, A0, A1);
-    }
-    if (dd) {
-        const float sx = ddacc.x, sy = ddacc.y;
-        const int nrun = l_last - l_first;
-        for (int i = lane; i < nrun; i += 64)
-            st_stream(a.dd4 + size_t(frame) * NB_FRAME_SYMBOLS + l_first + 1 + i,
-                      i == nrun - 1 ? make_float2(sx, sy) : make_float2(0.f, 0.f));
-    }
-}
-
-// The same idea without the second register set (DABGPU_FLAG_OFDM_EARLY_LOADS).
-// OFDM_EARLY_ROWS of the sixteen rows are requested early (all sixteen at once spill 52 registers at three waves per SIMD,
-// twelve spill 20, eight spill one, four none)
-template <bool NCO, int OFDM_EARLY_ROWS>
-__global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_early_kernel(OfdmTables tab, OfdmArgs a, int parts, int n_items) {
-    __shared__ WaveLds sm;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    for (int i = tid; i < NB_FFT; i += 64 * WAVES) {
-        int m;
-        if (i < TW_E1) {
-            const int k2 = i / 49, r = i - 49 * k2;
-            const int hi = r / 24, s = r - 24 * hi, kq = s / 12, s2 = s - 12 * kq;
-            m = r == 48 ? 0 : 2 * ((s2 >> 2) + 1) * (hi * 8 + kq * 4 + (s2 & 3) + 16 * k2);
-        } else if (i < TW_T1) {
-            const int j = i - TW_E1, k2 = j >> 6, r = j & 63;
-            m = (2 * ((r >> 2) & 3) + 1) * ((r >> 5) * 8 + ((r >> 4) & 1) * 4 + (r & 3) + 16 * k2);
-        } else {
-            const int j = i - TW_T1;
-            m = 8 * (j & 15) * ((j >> 4) + 1);
-        }
-        sm.tw[i] = tab.twiddle[m];
-    }
-    for (int i = tid; i < 12 * 64; i += 64 * WAVES) sm.nidx[i] = reinterpret_cast<const uint32_t *>(tab.n_of_vj)[i];
-    __syncthreads();
-    const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES + wave);
-    if (item >= n_items) return;
-    int frame = item, part = 0;
-    if (item >= a.uncut_frames) {
-        const int j = item - a.uncut_frames;
-        frame = a.uncut_frames + j / parts;
-        part = j - (frame - a.uncut_frames) * parts;
-    } else {
-        parts = 1;
-    }
-    const float2 *fiq = a.iq + size_t(frame) * a.frame_stride;
-    const int l_first = (NB_DATA_SYMBOLS * part) / parts;
-    const int l_last = (NB_DATA_SYMBOLS * (part + 1)) / parts;
-    uint32_t dphi_acq = 0u;
-    if (a.acq) {
-        const AcquiredFrame m = a.acq[frame];
-        if ((m.flags & 3) != 3) {
-            uint4 *o = reinterpret_cast<uint4 *>(a.soft + size_t(frame) * NB_FRAME_BITS + size_t(l_first) * NB_SYM_BITS);
-            const int n16 = (l_last - l_first) * NB_SYM_BITS / 16;
-            for (int i = lane; i < n16; i += 64) st_stream(o + i, make_uint4(0u, 0u, 0u, 0u));
-            return;
-        }
-        fiq = a.iq + size_t(frame / a.acq_per_stream) * a.frame_stride + m.start;
-        dphi_acq = uint32_t(__double2ll_rn(double(m.freq_offset) * 4294967296.0));
-    }
-    const bool aligned16 = (reinterpret_cast<uintptr_t>(fiq) & 15u) == 0;
-    const uint32_t dphi = a.acq ? dphi_acq : frame_dphi(a, frame);
-    float2 *ex = sm.ex[wave];
-    const float2 *tw = sm.tw;
-    float2 prev[24];
-#pragma unroll
-    for (int j = 0; j < 24; j++) prev[j] = make_float2(0.f, 0.f);
-    const float2 r128 = uniform(nco(128u, dphi)), rot2048 = uniform(nco(uint32_t(NB_FFT), dphi));
-    float2 codd[4];
-    {
-        const float2 r1 = nco(1u, dphi);
-        codd[0] = uniform(r1);
-        codd[1] = uniform(cmul_k(r1, SQRT1_2, -SQRT1_2));
-        codd[2] = uniform(mul_mj(r1));
-        codd[3] = uniform(cmul_k(r1, -SQRT1_2, -SQRT1_2));
-    }
-    float2 *const qout = a.cyc;
-    const bool dd = a.cyc == nullptr && a.dd4 != nullptr;
-    float2 ddacc = make_float2(0.f, 0.f);
-    auto put_cyc = [&](const int l, const float2 c) {
-        const int slot = (l - l_first) & 31;
-        if (lane == 0) sm.cyc[wave][slot] = c;
-        if (slot == 31 || l == l_last) {
-            lds_stores_done();
-            lds_loads_may_start();
-            const int li = l - slot + lane;
-            if (lane <= slot && (li > l_first || li == 0)) st_stream(qout + size_t(frame) * NB_FRAME_SYMBOLS + li, sm.cyc[wave][lane]);
-        }
-    };
-    // the sixteen loads of symbol l into one of the two register sets
-    auto fetch = [&](const int l, float2 (&d0)[16], float2 (&d1)[16], const int row_lo, const int row_hi) {
-        const float2 *sym = fiq + size_t(l) * NB_SYM_PERIOD;
-        if (aligned16) {
-            const float4 *rows = reinterpret_cast<const float4 *>(sym + NB_CP) + lane;
-#pragma unroll
-            for (int n1 = 0; n1 < 16; n1++) {
-                if (n1 < row_lo || n1 >= row_hi) continue;
-                const float4 v = ld_stream(rows + 64 * n1);
-                d0[n1] = make_float2(v.x, v.y);
-                d1[n1] = make_float2(v.z, v.w);
-            }
-        } else {
-            const float2 *rows = sym + NB_CP + 2 * lane;
-#pragma unroll
-            for (int n1 = 0; n1 < 16; n1++) {
-                if (n1 < row_lo || n1 >= row_hi) continue;
-                d0[n1] = ld_stream(rows + 128 * n1);
-                d1[n1] = ld_stream(rows + 128 * n1 + 1);
-            }
-        }
-    };
-    // one symbol: x0 / x1 hold its samples, requested before the previous symbol's epilogue (quantiser + scatter + store,
-    // a third of a symbol's instructions), when those registers had just gone dead: no second register set, three waves per SIMD
-    auto symbol = [&](const int l, float2 (&x0)[16], float2 (&x1)[16]) {
-        const float2 *sym = fiq + size_t(l) * NB_SYM_PERIOD;
-        const bool emit = (l > l_first) || (l == 0);
-        int li = lane;
-        asm volatile("" : "+v"(li));
-        const int n2i = li >> 2, pi = li & 3;
-        const int k1v = li & 15, kk = li >> 4;
-        const int w1_base = pi * 256, w1_r = n2i ^ (pi << 2);
-        const int w2_base = pi * 256 + (n2i ^ (pi << 2));
-        const int r2_base = kk * 16;
-        float2 w = make_float2(1.f, 0.f);
-        if constexpr (NCO) w = nco(uint32_t(l * NB_SYM_PERIOD + NB_CP + 2 * lane), dphi);
-        __builtin_amdgcn_sched_barrier(0);
-        fetch(l, x0, x1, OFDM_EARLY_ROWS, 16);                  // the rows that were not requested early
-        __builtin_amdgcn_sched_barrier(0);
-        if ((a.cyc && emit) || (dd && l == 0)) {
-            float2 acc = make_float2(0.f, 0.f);
-            const float2 *cp = sym + 2 * (lane - 4);
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                if (i > 0 || lane >= 4) {
-                    float4 c;
-                    if (aligned16) {
-                        c = ld_stream(reinterpret_cast<const float4 *>(cp + 128 * i));
-                    } else {
-                        const float2 c0 = ld_stream(cp + 128 * i), c1 = ld_stream(cp + 128 * i + 1);
-                        c = make_float4(c0.x, c0.y, c1.x, c1.y);
-                    }
-                    const float2 u0 = x0[12 + i], u1 = x1[12 + i];
-                    acc.x += c.x * u0.x + c.y * u0.y + c.z * u1.x + c.w * u1.y;
-                    acc.y += c.x * u0.y - c.y * u0.x + c.z * u1.y - c.w * u1.x;
-                }
-            }
-            acc.x = wave_sum(acc.x, lane);
-            acc.y = wave_sum(acc.y, lane);
-            if (dd) { if (lane == 0) st_stream(a.dd4 + size_t(frame) * NB_FRAME_SYMBOLS, cmul(acc, rot2048)); }
-            else put_cyc(l, cmul(acc, rot2048));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (NCO) {
-#pragma unroll
-            for (int n1 = 0; n1 < 16; n1++) {
-                x0[n1] = cmul(x0[n1], w);
-                x1[n1] = cmul(x1[n1], w);
-                asm volatile("" : "+v"(x0[n1].x), "+v"(x0[n1].y), "+v"(x1[n1].x), "+v"(x1[n1].y));
-                w = cmul(w, r128);
-                asm volatile("" : "+v"(w.x), "+v"(w.y));
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        fft16(x0);
-        __builtin_amdgcn_sched_barrier(0);
-        fft16(x1);
-        __builtin_amdgcn_sched_barrier(0);
-        {
-            const float2 *t1 = tw + TW_T1 + n2i;
-#pragma unroll
-            for (int k1 = 1; k1 < 16; k1++) {
-                const float2 t = t1[(k1 - 1) * 16];
-                x0[k1] = cmul(x0[k1], t);
-                x1[k1] = cmul(x1[k1], t);
-            }
-        }
-        const int r1b = pi * 256 + n2i * 16, r1x = (pi << 2) ^ ((n2i >> 1) & 3);
-#pragma unroll
-        for (int k1 = 0; k1 < 16; k1++) ex[w1_base + k1 * 16 + (w1_r ^ ((k1 >> 1) & 3))] = x0[k1];
-        lds_stores_done();
-        lds_loads_may_start();
-#pragma unroll
-        for (int m = 0; m < 16; m++) x0[m] = ex[r1b + (m ^ r1x)];
-        lds_stores_done();
-#pragma unroll
-        for (int k1 = 0; k1 < 16; k1++) ex[w1_base + k1 * 16 + (w1_r ^ ((k1 >> 1) & 3))] = x1[k1];
-        lds_stores_done();
-        lds_loads_may_start();
-#pragma unroll
-        for (int m = 0; m < 16; m++) x1[m] = ex[r1b + (m ^ r1x)];
-        __builtin_amdgcn_sched_barrier(0);
-        fft16(x0);
-        __builtin_amdgcn_sched_barrier(0);
-        fft16(x1);
-        __builtin_amdgcn_sched_barrier(0);
-        {
-            const int hi = n2i >> 3, kq = (n2i >> 2) & 1, klo = n2i & 3;
-            const float2 *t0 = tw + (pi ? hi * 24 + kq * 12 + (pi - 1) * 4 + klo : 48);
-            const float2 *t1 = tw + TW_E1 + hi * 32 + kq * 16 + pi * 4 + klo;
-#pragma unroll
-            for (int k2 = 0; k2 < 16; k2++) {
-                x0[k2] = cmul(x0[k2], t0[49 * k2]);
-                x1[k2] = cmul(x1[k2], t1[64 * k2]);
-            }
-        }
-        float2 X[4][8];
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            lds_stores_done();
-#pragma unroll
-            for (int k2 = 0; k2 < 8; k2++) {
-                ex[w2_base + k2 * 16] = x0[8 * h + k2];
-                ex[w2_base + k2 * 16 + 128] = x1[8 * h + k2];
-            }
-            lds_stores_done();
-            lds_loads_may_start();
-#pragma unroll
-            for (int cc = 0; cc < 2; cc++) {
-#pragma unroll
-                for (int n3 = 0; n3 < 8; n3++)
-                    X[2 * h + cc][n3] = ex[n3 * 128 + cc * 64 + r2_base + (k1v ^ ((n3 >> 1) << 2))];
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            if constexpr (NCO) fft8_odd_scaled(X[c], codd);
-            else fft8(X[c]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        float2 cur[24];
-#pragma unroll
-        for (int j = 0; j < 24; j++) {
-            const int m = j < 12 ? j : j + 8;
-            cur[j] = X[m & 3][m >> 2];
-        }
-        if (lane == 0) cur[0] = X[0][3];
-        __builtin_amdgcn_sched_barrier(0);
-        if (l < l_last) fetch(l + 1, x0, x1, 0, OFDM_EARLY_ROWS);   // in flight during the epilogue below
-        __builtin_amdgcn_sched_barrier(0);
-        if (l > l_first) {
-            uint8_t *stg = reinterpret_cast<uint8_t *>(ex);
-            lds_stores_done();
-            float2 t = make_float2(0.f, 0.f);
-#pragma unroll
-            for (int j = 0; j < 24; j++) {
-                const float2 d = cmulc(cur[j], prev[j]);
-                const float Amax = fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), 1.0e-30f);
-                const float sc = -127.00003f * __builtin_amdgcn_rcpf(Amax);
-                const float fx = d.x * sc, fy = d.y * sc;
-                const int br = int(fx), bi = int(fy);
-                if ((j < 2 || j >= 22) && dd) {
-                    const float2 u = unit_of(fx, fy);
-                    const float2 z = make_float2(u.x * u.x - u.y * u.y, 2.0f * u.x * u.y);
-                    t.x += z.x * z.x - z.y * z.y;
-                    t.y += 2.0f * z.x * z.y;
-                }
-                const uint32_t nd = sm.nidx[(j >> 1) * 64 + lane];
-                const uint32_t ni = (j & 1) ? (nd >> 16) : (nd & 0xFFFFu);
-                stg[ni] = uint8_t(br);
-                stg[NB_CARRIERS + ni] = uint8_t(bi);
-            }
-            if (dd) ddacc = uniform(make_float2(ddacc.x + wave_sum(t.x, lane), ddacc.y + wave_sum(t.y, lane)));
-            lds_stores_done();
-            lds_loads_may_start();
-            const uint4 *sv = reinterpret_cast<const uint4 *>(stg) + lane;
-            uint4 *o = reinterpret_cast<uint4 *>(a.soft + size_t(frame) * NB_FRAME_BITS + size_t(l - 1) * NB_SYM_BITS) + lane;
-            const uint4 s0 = sv[0], s1 = sv[64], s2 = sv[128];
-            st_stream(o, s0); st_stream(o + 64, s1); st_stream(o + 128, s2);
-        }
-#pragma unroll
-        for (int j = 0; j < 24; j++) prev[j] = cur[j];
-    };
-    float2 A0[16], A1[16];
-    fetch(l_first, A0, A1, 0, OFDM_EARLY_ROWS);
-    for (int l = l_first; l <= l_last; l++) symbol(l, A0, A1);
-    if (dd) {
-        const float sx = ddacc.x, sy = ddacc.y;
-        const int nrun = l_last - l_first;
-        for (int i = lane; i < nrun; i += 64)
-            st_stream(a.dd4 + size_t(frame) * NB_FRAME_SYMBOLS + l_first + 1 + i,
-                      i == nrun - 1 ? make_float2(sx, sy) : make_float2(0.f, 0.f));
-    }
-}
-
 // One 1024-thread workgroup per stream.  Restated by oracle.py stream_update() for the parity test.
 constexpr int SU_THREADS = 1024;
 __global__ __launch_bounds__(SU_THREADS) void stream_update_kernel(StreamState *state, const float2 *cyc, const float2 *iq,
@@ -1256,7 +701,7 @@ hipError_t launch_stream_update(StreamState *state, const float2 *cyc, const flo
     return hipGetLastError();
 }
 
-hipError_t launch_ofdm_demod(const OfdmTables &t, const OfdmArgs &a, int parts, hipStream_t s, int variant) {
+hipError_t launch_ofdm_demod(const OfdmTables &t, const OfdmArgs &a, int parts, hipStream_t s) {
     if (a.n_frames <= 0) return hipSuccess;
     if (parts <= 0 || parts > NB_DATA_SYMBOLS) return hipErrorInvalidValue;
     if (a.state && a.frames_per_stream <= 0) return hipErrorInvalidValue;
@@ -1272,15 +717,6 @@ hipError_t launch_ofdm_demod(const OfdmTables &t, const OfdmArgs &a, int parts, 
     } else if (b.keep) {
         if (nco) hipLaunchKernelGGL((ofdm_wave_kernel<false, false, true, true>), grid, block, 0, s, t, b, parts, items);
         else hipLaunchKernelGGL((ofdm_wave_kernel<false, false, true, false>), grid, block, 0, s, t, b, parts, items);
-    } else if (variant == 1) {
-        if (nco) hipLaunchKernelGGL((ofdm_wave_pf_kernel<true>), grid, block, 0, s, t, b, parts, items);
-        else hipLaunchKernelGGL((ofdm_wave_pf_kernel<false>), grid, block, 0, s, t, b, parts, items);
-    } else if (variant == 2) {
-        if (nco) hipLaunchKernelGGL((ofdm_wave_early_kernel<true, 8>), grid, block, 0, s, t, b, parts, items);
-        else hipLaunchKernelGGL((ofdm_wave_early_kernel<false, 8>), grid, block, 0, s, t, b, parts, items);
-    } else if (variant == 3) {
-        if (nco) hipLaunchKernelGGL((ofdm_wave_early_kernel<true, 4>), grid, block, 0, s, t, b, parts, items);
-        else hipLaunchKernelGGL((ofdm_wave_early_kernel<false, 4>), grid, block, 0, s, t, b, parts, items);
     } else {
         if (nco) hipLaunchKernelGGL((ofdm_wave_kernel<false, false, false, true>), grid, block, 0, s, t, b, parts, items);
         else hipLaunchKernelGGL((ofdm_wave_kernel<false, false, false, false>), grid, block, 0, s, t, b, parts, items);

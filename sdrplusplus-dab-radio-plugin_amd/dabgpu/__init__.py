@@ -55,7 +55,6 @@ PLAIN_REASONS = {0: "plain requested", 1: "buffers too small (or too many chunks
 FLAG_VITERBI_WAVE = 1 << 0
 FLAG_VITERBI_LANE = 1 << 1
 FLAG_LANE_UNFUSED = 1 << 2
-FLAG_OFDM_PREFETCH, FLAG_OFDM_EARLY8, FLAG_OFDM_EARLY4 = 1 << 3, 1 << 4, 1 << 5
 
 
 class DabGpuError(RuntimeError):

@@ -15,7 +15,7 @@ groups=(
 i=0
 for g in "${groups[@]}"; do
   i=$((i+1))
-  rocprofv3 --pmc $g --kernel-trace --output-format csv -d $out/g$i -o g$i -- python3 $root/bench.py --cpu-seconds 0 --no-fft-stage --no-selective --no-closed-loop --no-sustained --no-cp-leg --no-plain-compare --steps 4 --warmup 1 "$@" > $out/g$i.log 2>&1
+  rocprofv3 --pmc $g --kernel-trace --output-format csv -d $out/g$i -o g$i -- python3 $root/bench.py --legs none --steps 4 --warmup 1 "$@" > $out/g$i.log 2>&1
   echo "group $i rc $?"
 done
 python3 $root/tools/pmc_ofdm_summary.py $out > $out/summary.md
