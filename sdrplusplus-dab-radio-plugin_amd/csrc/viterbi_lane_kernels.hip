@@ -456,9 +456,14 @@ __device__ __forceinline__ void lane_forward_fused_body(const Src &src, const in
         if (more) fetch(tile + 1);
         const int t_end = min(t0 + FT, nsteps);
         for (int t = t0; t < t_end; t += 6) {
+            // The descriptors of the NEXT six steps: six 16-byte loads that stay here, in flight under the six steps below, and
+            // stay in vector registers until the bottom of the iteration.  (Left to itself the compiler turns each load into
+            // load + wait + v_readfirstlane through ONE register quad, six serial round trips per iteration: that cost more
+            // than this round's instruction diet saved, profiles/r04_pmc_ofdm_summary.md.)
             const int32_t *dp = desc + 4 * min(t + 6, nsteps - 6);
 #pragma unroll
             for (int j = 0; j < 24; j++) dnxt[j] = dp[j];
+            __builtin_amdgcn_sched_barrier(0);
             // (signed byte reads straight into the four values a step works with: nothing is packed and unpacked again)
             Soft4 w[6];
             const int8_t *mys = reinterpret_cast<const int8_t *>(my);
@@ -473,8 +478,6 @@ __device__ __forceinline__ void lane_forward_fused_body(const Src &src, const in
                 }
                 w[i] = Soft4{v[0], v[1], v[2], v[3]};
             }
-#pragma unroll
-            for (int j = 0; j < 24; j++) dcur[j] = dnxt[j];
             lane_step<0>(M, w[0], dst + size_t(t + 0) * 64);
             lane_step<1>(M, w[1], dst + size_t(t + 1) * 64);
             lane_step<2>(M, w[2], dst + size_t(t + 2) * 64);
@@ -486,6 +489,12 @@ __device__ __forceinline__ void lane_forward_fused_body(const Src &src, const in
 #pragma unroll
                 for (int r = 0; r < 32; r++) M[r] = pk_sub(M[r], ref);
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 24; j++) {                     // now they are wanted: wave-uniform values into scalar registers
+                asm volatile("" : "+v"(dnxt[j]));
+                dcur[j] = __builtin_amdgcn_readfirstlane(dnxt[j]);
+            }
         }
         if (more) {                                            // the wave's own LDS reads above are already issued
             window_fence();
@@ -496,7 +505,7 @@ __device__ __forceinline__ void lane_forward_fused_body(const Src &src, const in
 }
 
 template <class Src>
-__global__ __launch_bounds__(256) void lane_forward_fused_kernel(Src src, const int32_t *desc, const int32_t *tiles,
+__global__ __attribute__((amdgpu_waves_per_eu(2, 2))) __launch_bounds__(256) void lane_forward_fused_kernel(Src src, const int32_t *desc, const int32_t *tiles,
                                                                  int nsteps, int groups, int n_codewords, uint2 *dec) {
     extern __shared__ __attribute__((aligned(16))) uint8_t fused_lds[];
     const int lane = threadIdx.x & 63;
@@ -535,7 +544,7 @@ __device__ __forceinline__ int find_entry(const LaneEntryPack &pack, int group) 
     return e;
 }
 
-__global__ __launch_bounds__(256) void lane_forward_grouped_kernel(const LaneEntryPack pack) {
+__global__ __attribute__((amdgpu_waves_per_eu(2, 2))) __launch_bounds__(256) void lane_forward_grouped_kernel(const LaneEntryPack pack) {
     extern __shared__ __attribute__((aligned(16))) uint8_t fused_lds[];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
