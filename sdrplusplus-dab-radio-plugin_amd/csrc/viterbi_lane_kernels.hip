@@ -35,6 +35,10 @@ using namespace dab;
 
 namespace {
 
+#ifndef LANE_FWD_ATTR
+#define LANE_FWD_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
+#endif
+
 constexpr int LANE_INIT2 = 2 * 6144;      // doubled start penalty of states != 0
 // staging window of the fused forward pass (K2')
 constexpr int FT = 24;                          // steps per tile (four phase cycles)
@@ -505,7 +509,7 @@ __device__ __forceinline__ void lane_forward_fused_body(const Src &src, const in
 }
 
 template <class Src>
-__global__ __attribute__((amdgpu_waves_per_eu(2, 2))) __launch_bounds__(256) void lane_forward_fused_kernel(Src src, const int32_t *desc, const int32_t *tiles,
+__global__ LANE_FWD_ATTR __launch_bounds__(256) void lane_forward_fused_kernel(Src src, const int32_t *desc, const int32_t *tiles,
                                                                  int nsteps, int groups, int n_codewords, uint2 *dec) {
     extern __shared__ __attribute__((aligned(16))) uint8_t fused_lds[];
     const int lane = threadIdx.x & 63;
@@ -544,7 +548,7 @@ __device__ __forceinline__ int find_entry(const LaneEntryPack &pack, int group) 
     return e;
 }
 
-__global__ __attribute__((amdgpu_waves_per_eu(2, 2))) __launch_bounds__(256) void lane_forward_grouped_kernel(const LaneEntryPack pack) {
+__global__ LANE_FWD_ATTR __launch_bounds__(256) void lane_forward_grouped_kernel(const LaneEntryPack pack) {
     extern __shared__ __attribute__((aligned(16))) uint8_t fused_lds[];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
