@@ -125,7 +125,9 @@ def parse_args(argv=None):
                       ("closed-loop", "the unaligned-capture / tracking measurement"), ("sustained", "the sustained leg"),
                       ("cp-leg", "the step on the cyclic-prefix correlations (the reference's estimator)"),
                       ("single-ensemble", "BASELINE configs 2 and 3 (one ensemble) and the one-frame host path"),
-                      ("host-fed", "the host-fed ring (64 frames per call from page-locked memory)")):
+                      ("host-fed", "the host-fed ring (64 frames per call from page-locked memory)"),
+                      ("traffic", "measuring roofline.traffic now (two rocprofv3 --pmc child processes, ~20 s); the tracked figure "
+                                  "of profiles/pmc_traffic.json is reported instead")):
         ap.add_argument("--no-" + leg, action="store_true", help="skip " + what)
     ap.add_argument("--placement", choices=["plain", "domains"], default="plain",
                     help="how the IQ / soft-bit buffers are allocated (dabgpu_alloc_frame_buffers): two hipMallocs, or placed by "
@@ -141,10 +143,17 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args.gpus)                # never returns; nothing above this line has touched the GPU (or torch)
 
+    import gc
     import torch
     import dabgpu
     from dabgpu import synth
     from dabgpu.shard import ensembles_of_rank, reduce_report, gather_per_rank
+    # The cyclic collector stays off for the life of this short process: a generation-2 pass over the interpreter's few
+    # hundred thousand objects takes ~20 ms, and one that lands at the head of a leg whose ten steps are 22 ms of GPU work
+    # doubles that leg's wall clock (seen in `selective_soft_output`: 2.2 -> 3.9 ms per step in two runs of three).  Nothing
+    # here builds reference cycles of any size.
+    gc.collect()
+    gc.disable()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -381,7 +390,7 @@ def main():
             import bench_legs
             B = SimpleNamespace(torch=torch, dabgpu=dabgpu, synth=synth, ctx=ctx, dev=dev, stream=stream, args=args, E=E, F=F, L=L,
                                 n_frames=n_frames, iq=iq, soft=soft, fib=fib, crc=crc, msc=msc, hist=hist, sc=sc, ens=ens,
-                                d_iq=d_iq, BETA=BETA, step=step, decode_into=decode_into, ofdm_ev=ofdm_ev, net=net,
+                                d_iq=d_iq, BETA=BETA, step=step, decode_into=decode_into, ofdm_ev=ofdm_ev, dec_ev=dec_ev, net=net,
                                 cfo_true=cfo_true, fib_h=fib_h, crc_h=crc_h, msc_h=msc_h, ms_per_step=elapsed / args.steps * 1e3,
                                 dev_index=dev_index)
             bench_legs.run(B, out)

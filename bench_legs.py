@@ -11,6 +11,7 @@
                                    calls and the pipelined ring (dabgpu_pipe_*)
   closed_loop                      the same samples as unaligned captures: acquisition every step, and tracking
   cpu_baseline                     the oracle and the SIMD port on the box's host cores (a bounded sample)
+and `measure_traffic` replaces roofline.traffic (a figure from a tracked file) by one measured while the bench runs.
 """
 import ctypes as C
 import os
@@ -28,6 +29,15 @@ REALTIME_FPS = 1.0 / 0.096
 
 def run(B, out):
     a = B.args
+    if not a.no_traffic:
+        t = measure_traffic(B.n_frames, os.path.dirname(os.path.abspath(__file__)))
+        if t is not None:
+            out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
+            out["roofline"]["traffic_over_algorithmic"] = t["ratio_to_algorithmic"]
+            out["roofline"]["traffic_source"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (one child process per "
+                                                 "counter) around tools/pmc_traffic.py at this launch shape, counters calibrated on "
+                                                 "that process's 1 GiB device copy (read scale %.4f, write scale %.4f)"
+                                                 % (t["read_scale_from_1GiB_copy"], t["write_scale_from_1GiB_copy"]))
     if not a.no_cp_leg:
         out["with_cyclic_prefix_correlations"] = cp_leg(B)
     if not a.no_sustained and a.sustained_seconds > 0:
@@ -49,6 +59,56 @@ def run(B, out):
         out["cpu_baseline"] = cpu_baseline(iq_h, fo_h, B.sc.length * 64, B.ens[0].mask, 64 * 24 + 6, a.cpu_seconds,
                                            len(os.sched_getaffinity(0)) or 1,
                                            truth_fibs=[B.ens[0].fibs[f % 4] for f in range(4)])
+
+
+def measure_traffic(n_frames, root, timeout_s=240):
+    """HBM bytes per launch of the fused front end (decision-directed data flow) from the TCC counters, measured NOW: two child
+    processes `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 tools/pmc_traffic.py n dd` (counters cannot be
+    read from inside a running process; one pass per counter, as MI355X_MICROARCH.md prescribes; the child does a 1 GiB
+    device copy first, which calibrates the counters' unit).  Returns a dict, or None when the profiler is not there or a
+    pass fails -- the caller then falls back to the tracked figure."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None
+    out_dir = tempfile.mkdtemp(prefix="dabgpu_pmc_")
+    env = dict(os.environ, TMPDIR="/tmp")
+    res = {}
+    try:
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(out_dir, c)
+            r = subprocess.run([prof, "--pmc", c, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "t", "--",
+                                "python3", os.path.join(root, "tools", "pmc_traffic.py"), str(n_frames), "dd"],
+                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            path = os.path.join(d, "t_counter_collection.csv")
+            if r.returncode != 0 or not os.path.exists(path):
+                return None
+            acc = {"ofdm": [], "copy": []}
+            for row in csv.DictReader(open(path)):
+                if row["Counter_Name"] != c:
+                    continue
+                k = row["Kernel_Name"]
+                v = float(row["Counter_Value"])
+                if "ofdm_wave_kernel" in k:
+                    acc["ofdm"].append(v)
+                elif ("copy" in k.lower() or "clone" in k.lower()) and v > 1e5:
+                    acc["copy"].append(v)
+            if not acc["ofdm"] or not acc["copy"]:
+                return None
+            res[c] = {k: sum(v[-3:]) / len(v[-3:]) for k, v in acc.items()}
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(out_dir, ignore_errors=True)
+    gib = 1024 ** 3
+    rd = res["FETCH_SIZE"]["ofdm"] * gib / res["FETCH_SIZE"]["copy"]          # the copy read 1 GiB and wrote 1 GiB
+    wr = res["WRITE_SIZE"]["ofdm"] * gib / res["WRITE_SIZE"]["copy"]
+    return {"hbm_bytes_per_launch": rd + wr, "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr,
+            "ratio_to_algorithmic": (rd + wr) / (A_OFDM * n_frames),
+            "read_scale_from_1GiB_copy": gib / (res["FETCH_SIZE"]["copy"] * 1024), "write_scale_from_1GiB_copy": gib / (res["WRITE_SIZE"]["copy"] * 1024)}
 
 
 def _events(torch):
@@ -167,6 +227,7 @@ def selective_leg(B):
     fib_s, crc_s, msc_s = B.fib.cpu().numpy(), B.crc.cpu().numpy(), B.msc.cpu().numpy()
     sel_ok = bool(crc_s.all()) and bool((fib_s == B.fib_h).all()) and bool((msc_s == B.msc_h).all())
     sel_ofdm = float(np.mean([x.elapsed_time(y) for x, y in B.ofdm_ev[n_before:]]))
+    sel_dec = [x.elapsed_time(y) for x, y in B.dec_ev[n_before:]]
     kept = sum(c for _, c in sel)
     # symbols that are transformed: those carrying selected bits and their differential references; with the
     # decision-directed loop of the timed step the others are not read at all
@@ -176,7 +237,8 @@ def selective_leg(B):
     need = wanted | np.append(wanted[1:], False)
     a_sel = int(need.sum()) * 2048 * 8 + kept
     return {"value": B.n_frames * a.steps / sel_s, "unit": "frames/s", "ms_per_step": sel_s / a.steps * 1e3,
-            "ofdm_avg_launch_ms": sel_ofdm, "soft_bits_written_per_frame": kept,
+            "ofdm_avg_launch_ms": sel_ofdm, "decoder_ms": float(np.mean(sel_dec)), "decoder_ms_max": float(np.max(sel_dec)),
+            "soft_bits_written_per_frame": kept,
             "symbols_transformed_per_frame": int(need.sum()), "algorithmic_bytes_per_frame": a_sel,
             "ofdm_achieved_GBps": a_sel * B.n_frames / (sel_ofdm * 1e-3) / 1e9,
             "outputs_identical_to_whole_frame_run": sel_ok}

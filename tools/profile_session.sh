@@ -9,7 +9,7 @@ python3 bench.py > $o/bench.json 2> $o/bench.err                                
 tail -c 1500 $o/bench.json
 # per-kernel durations of the timed steps alone (no leg after the timed region launches the same kernels)
 tools/prof.sh $tag --legs none > $o/prof.log 2>&1
-cp gpurun_out/${tag}_kernel_stats.csv $o/kernel_stats.csv; tail -n 1 gpurun_out/prof_${tag}_bench.log > $o/kernel_stats_bench_line.json
+cp gpurun_out/${tag}_kernel_stats.csv $o/kernel_stats.csv; grep "^{" gpurun_out/prof_${tag}_bench.log | tail -n 1 > $o/kernel_stats_bench_line.json
 cat $o/kernel_stats.csv
 # HBM bytes of the fused front end from the TCC counters (two --pmc passes, calibrated on a 1 GiB copy)
 tools/pmc_traffic.sh 16384 dd > $o/pmc_traffic.log 2>&1; cp gpurun_out/pmc_traffic.json $o/pmc_traffic.json; tail -n 8 $o/pmc_traffic.json
@@ -20,3 +20,4 @@ python3 tools/vit_time.py 16384 > $o/vit_time.txt 2>&1; cat $o/vit_time.txt
 ./tools/ubench/gap_read > $o/gap_read.txt 2>&1; cat $o/gap_read.txt
 timeout 900 python3 tools/alloc_stress.py 300 100 > $o/alloc_stress.txt 2>&1; tail -n 2 $o/alloc_stress.txt
 python3 tools/frame_latency.py > $o/frame_latency.txt 2>&1; tail -n 3 $o/frame_latency.txt
+python3 tools/loop_gate_table.py 4 > $o/loop_gate.txt 2>&1; tail -n 8 $o/loop_gate.txt
