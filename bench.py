@@ -129,9 +129,10 @@ def parse_args(argv=None):
                       ("traffic", "measuring roofline.traffic now (two rocprofv3 --pmc child processes, ~20 s); the tracked figure "
                                   "of profiles/pmc_traffic.json is reported instead")):
         ap.add_argument("--no-" + leg, action="store_true", help="skip " + what)
-    ap.add_argument("--placement", choices=["plain", "domains"], default="plain",
+    ap.add_argument("--placement", choices=["plain", "domains"], default="domains",
                     help="how the IQ / soft-bit buffers are allocated (dabgpu_alloc_frame_buffers): two hipMallocs, or placed by "
-                         "HBM domain (measured gain on the pool's boxes: 0-7 %%, 0.5 %% on the driver's in round 3)")
+                         "HBM domain (six plain / domains pairs on three boxes, profiles/r04_placement_ab.txt: front end 0.8-3.9 %% "
+                         "faster, never slower; <= 1.5 x the pair held for ~0.1 s at set-up; any failure ends in a plain pair)")
     args = ap.parse_args(argv)
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")

@@ -451,9 +451,18 @@ __device__ __forceinline__ void lane_forward_fused_body(const Src &src, const in
     // nothing else would hide their latency.  They are deliberately NOT restrict-qualified: as scalar loads they
     // share the LDS counter (lgkmcnt) and every wait for them also drains the window reads (measured slower).
     const int dsh = desc_shift(src), dex = desc_extra(src);
-    int32_t dcur[24], dnxt[24];
+    // where this lane's 24 soft bytes of the coming six steps sit in the window: descriptor -> offset -> address once, in
+    // vector registers (two VALU per byte; as scalars they cost a v_readfirstlane, two SALU and a v_add per byte, and a
+    // lone wave pays an issue turn for every one of them)
+    const int8_t *mys = reinterpret_cast<const int8_t *>(my);
+    const int8_t *pcur[24];
+    int32_t dnxt[24];
+    auto soft_address = [&](int32_t d) {
+        asm volatile("" : "+v"(d));
+        return mys + (int((unsigned(d) >> dsh) & 0xFFFFu) + dex);
+    };
 #pragma unroll
-    for (int j = 0; j < 24; j++) dcur[j] = desc[j];
+    for (int j = 0; j < 24; j++) pcur[j] = soft_address(desc[j]);
     int tile = 0;
     for (int t0 = 0; t0 < nsteps; t0 += FT, tile++) {
         const bool more = t0 + FT < nsteps;
@@ -461,7 +470,7 @@ __device__ __forceinline__ void lane_forward_fused_body(const Src &src, const in
         const int t_end = min(t0 + FT, nsteps);
         for (int t = t0; t < t_end; t += 6) {
             // The descriptors of the NEXT six steps: six 16-byte loads that stay here, in flight under the six steps below, and
-            // stay in vector registers until the bottom of the iteration.  (Left to itself the compiler turns each load into
+            // stay in vector registers until the bottom of the iteration, where they become the next six steps' addresses.  (Left to itself the compiler turns each load into
             // load + wait + v_readfirstlane through ONE register quad, six serial round trips per iteration: that cost more
             // than this round's instruction diet saved, profiles/r04_pmc_ofdm_summary.md.)
             const int32_t *dp = desc + 4 * min(t + 6, nsteps - 6);
@@ -470,18 +479,8 @@ __device__ __forceinline__ void lane_forward_fused_body(const Src &src, const in
             __builtin_amdgcn_sched_barrier(0);
             // (signed byte reads straight into the four values a step works with: nothing is packed and unpacked again)
             Soft4 w[6];
-            const int8_t *mys = reinterpret_cast<const int8_t *>(my);
 #pragma unroll
-            for (int i = 0; i < 6; i++) {
-                int v[4];
-#pragma unroll
-                for (int m = 0; m < 4; m++) {
-                    const int dsc = dcur[4 * i + m];                            // wave-uniform: column | delay << 8
-                    const int off = int((unsigned(dsc) >> dsh) & 0xFFFFu) + dex;
-                    v[m] = int(mys[off]);
-                }
-                w[i] = Soft4{v[0], v[1], v[2], v[3]};
-            }
+            for (int i = 0; i < 6; i++) w[i] = Soft4{int(*pcur[4 * i]), int(*pcur[4 * i + 1]), int(*pcur[4 * i + 2]), int(*pcur[4 * i + 3])};
             lane_step<0>(M, w[0], dst + size_t(t + 0) * 64);
             lane_step<1>(M, w[1], dst + size_t(t + 1) * 64);
             lane_step<2>(M, w[2], dst + size_t(t + 2) * 64);
@@ -495,10 +494,7 @@ __device__ __forceinline__ void lane_forward_fused_body(const Src &src, const in
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < 24; j++) {                     // now they are wanted: wave-uniform values into scalar registers
-                asm volatile("" : "+v"(dnxt[j]));
-                dcur[j] = __builtin_amdgcn_readfirstlane(dnxt[j]);
-            }
+            for (int j = 0; j < 24; j++) pcur[j] = soft_address(dnxt[j]);   // now they are wanted
         }
         if (more) {                                            // the wave's own LDS reads above are already issued
             window_fence();
@@ -539,6 +535,7 @@ struct LaneEntry {
 struct LaneEntryPack {
     int n;
     int total_groups;
+    int prio_nsteps;          // waves of entries at least this long get the issue slots first (0: nobody); see the forward kernel
     LaneEntry e[LANE_GROUP_MAX];
 };
 
@@ -556,6 +553,13 @@ __global__ LANE_FWD_ATTR __launch_bounds__(256) void lane_forward_grouped_kernel
     if (group >= pack.total_groups) return;
     const LaneEntry &en = pack.e[find_entry(pack, group)];
     const LSrcMsc src = en.src;
+    // Codeword lengths differ between entries (FIC 774 steps, a 64 kbit/s sub-channel 1542).  When the whole launch is
+    // resident at once -- two waves per SIMD, one of each -- the longer wave would run alone, at a single wave's issue rate,
+    // for the last third of the launch.  The longest entry's waves therefore get the issue slots first; the shorter ones
+    // fill in and are still around when the long ones end: 1.17 -> 1.10 ms for the bench's pair of launches
+    // (profiles/r04_lane_forward.txt).  Launches with more waves than the chip holds balance themselves by dispatch order, and
+    // there a priority only hurt (whole multiplex +2.7 %): the launcher sets prio_nsteps to 0 for them.
+    if (pack.prio_nsteps > 0 && en.nsteps >= pack.prio_nsteps) __builtin_amdgcn_s_setprio(1);
     lane_forward_fused_body(src, en.desc, en.tiles, en.nsteps, group - en.first_group, en.n_codewords, en.dec,
                             fused_lds + wv * ((64 + LSrcMsc::PRE) * FPITCH), lane);
 }
@@ -810,6 +814,16 @@ size_t lane_group_scratch_bytes(const LaneGroupItem *items, int n) {
     return total + 512;
 }
 
+static int resident_cus() {
+    static const int n = [] {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                   ? prop.multiProcessorCount : 256;
+    }();
+    return n;
+}
+
 hipError_t launch_lane_group(const LaneGroupItem *items, int n, const LaneScratch &sc, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     if (!sc.base || sc.bytes < lane_group_scratch_bytes(items, n)) return hipErrorInvalidValue;
@@ -848,6 +862,11 @@ hipError_t launch_lane_group(const LaneGroupItem *items, int n, const LaneScratc
         }
         const unsigned fgrid = unsigned((pack.total_groups + 3) / 4);
         const size_t lds = balanced_lds_bytes(fgrid, size_t(4) * (64 + LSrcMsc::PRE) * FPITCH, 3);
+        {   // every wave resident at once (<= 2 per SIMD) and entries of different lengths: the longest go first
+            int longest = 0, shortest = 0x7fffffff;
+            for (int i = 0; i < pack.n; i++) { longest = std::max(longest, pack.e[i].nsteps); shortest = std::min(shortest, pack.e[i].nsteps); }
+            pack.prio_nsteps = (pack.total_groups <= 2 * 4 * resident_cus() && longest > shortest) ? longest : 0;
+        }
         hipLaunchKernelGGL(lane_forward_grouped_kernel, dim3(fgrid), dim3(256), lds, s, pack);
         const size_t tb_lds = size_t(64) * (max_nwords | 1) * 4;
         hipLaunchKernelGGL(lane_traceback_grouped_kernel, dim3(unsigned(pack.total_groups)), dim3(64), tb_lds, s, pack);
