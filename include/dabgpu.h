@@ -141,8 +141,8 @@ void dabgpu_host_free(void *p);
  *   placement  DABGPU_PLACE_PLAIN    two hipMallocs.
  *              DABGPU_PLACE_DOMAINS  MI355X's HBM behaves as three domains of 96 GB, and a launch that reads its
  *                samples from the domain it writes its soft bits to runs up to ~10 % slower than one whose two streams
- *                lie apart (profiles/r02_hbm_domains.txt; on most boxes a plain pair already lies apart
- *                and the gain is ~0).  Physical memory is taken in chunks through the virtual-memory API (1 GiB for the
+ *                lie apart (profiles/r02_hbm_domains.txt; against a plain pair the front end
+ *                gained 0.8-3.9 % in six of six trials, profiles/r04_placement_ab.txt).  Physical memory is taken in chunks through the virtual-memory API (1 GiB for the
  *                samples, 256 MiB for the soft bits; never more than 1.5 x the pair's size held during set-up), every
  *                chunk's domain is found with a small data mover (two passes, ~40 ms), the IQ buffer is mapped over
  *                chunks of the most plentiful domain(s) and every 256 MiB of the soft-bit buffer over a chunk whose
