@@ -226,7 +226,8 @@ def test_gpu_tracked_call_decision_directed_loop_equals_the_oracle(tctx):
     counts = torch.zeros(1, dtype=torch.int32, device=dev)
     soft = torch.zeros((MF, dabgpu.NB_FRAME_BITS), dtype=torch.int8, device=dev)
     fines = {}
-    for name, cfg in (("dd", None), ("cp", dabgpu.track_cfg(decision_directed=0))):
+    # ("gated": a quality gate nobody's sum can pass forces track_update_kernel's fall-back branch -- the PRS prefixes alone)
+    for name, cfg in (("dd", None), ("gated", dabgpu.track_cfg(dd_gate=500.0)), ("cp", dabgpu.track_cfg(decision_directed=0))):
         tctx.streams_reset(1)
         torch.cuda.synchronize()
         tctx.acquire_dev(d_x.data_ptr(), x.size, 1, n_cap, MF, frames.data_ptr(), counts.data_ptr())
@@ -238,14 +239,15 @@ def test_gpu_tracked_call_decision_directed_loop_equals_the_oracle(tctx):
         tctx.sync()
         after = read_states(torch, tctx, 1)[0]
         fines[name] = float(after["fine_freq_offset"])
-        if name == "dd":
+        if name in ("dd", "gated"):
             cap = x[adv:adv + n_cap]
             of = O.track_sync(cap, before, MF)
             assert counts.cpu().numpy()[0] == len(of) == 2
             odd = np.stack([O.ofdm_demod_frame_dd(cap[f["start"]:f["start"] + SYMS], float(f["freq_offset"]))[1] for f in of])
-            want, _ = O.track_update(before, of, odd, cap, n_cap, MF, adv, dd=True)
-            check_state(after, want, "decision-directed")
-    assert abs(fines["dd"] - fines["cp"]) * 2048 < 5e-3
+            want, _ = O.track_update(before, of, odd, cap, n_cap, MF, adv, dd=True, dd_gate=2.5 if name == "dd" else 500.0)
+            check_state(after, want, name)
+            assert int(after["loop_gated"]) == (0 if name == "dd" else 1)
+    assert abs(fines["dd"] - fines["cp"]) * 2048 < 5e-3 and abs(fines["gated"] - fines["cp"]) * 2048 < 2e-2
     fib, ok = tctx.fic_decode(soft.cpu().numpy()[:2])
     assert ok.all()
 
