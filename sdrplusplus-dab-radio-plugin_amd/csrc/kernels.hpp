@@ -323,6 +323,9 @@ struct WaveFicItem {
     uint8_t *fib, *crc_ok;
 };
 bool wave_group_supported(int nsteps);
+// true when `n_waves` codewords whose longest takes `max_nsteps` trellis steps are all resident at once (LDS per wave x
+// waves <= the chip's LDS): a grouped launch then finishes with its longest codeword instead of queueing kinds up
+bool wave_group_one_round(int max_nsteps, long n_waves);
 hipError_t launch_msc_decode_group(const WaveGroupItem *items, int n, hipStream_t s, const WaveFicItem *fic = nullptr);
 
 // ---- large-batch variant: one codeword per lane (viterbi_lane_kernels.hip) ----

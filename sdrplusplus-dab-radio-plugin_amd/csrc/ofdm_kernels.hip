@@ -526,24 +526,48 @@ __global__ __launch_bounds__(SU_THREADS) void stream_update_kernel(StreamState *
     const int n = frames_per_stream * NB_FRAME_SYMBOLS;
     float acc = 0.f;
     double sx = 0.0, sy = 0.0;
+    // level of the stream's most recent frame: first 4096 samples (PRS and the start of the first data symbol); read first
+    const float4 *x = reinterpret_cast<const float4 *>(iq + (size_t(s) * frames_per_stream + (frames_per_stream - 1)) * frame_stride);
+    float4 lv[2048 / SU_THREADS];
+#pragma unroll
+    for (int k = 0; k < 2048 / SU_THREADS; k++) lv[k] = x[tid + k * SU_THREADS];
+    // (eight entries in flight per thread; each thread still adds its entries in ascending order)
+    constexpr int SU_BATCH = 8;
     if (dd) {
-        for (int i = tid; i < n; i += SU_THREADS) {
-            if (i % NB_FRAME_SYMBOLS) { sx += double(c[i].x); sy += double(c[i].y); }
-            else acc += atan2f(c[i].y, c[i].x);                   // entry 0 of a frame: the PRS's cyclic-prefix correlation
+        for (int i0 = tid; i0 < n; i0 += SU_THREADS * SU_BATCH) {
+            float2 v[SU_BATCH];
+#pragma unroll
+            for (int u = 0; u < SU_BATCH; u++) {
+                const int i = i0 + u * SU_THREADS;
+                v[u] = i < n ? c[i] : make_float2(0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < SU_BATCH; u++) {
+                const int i = i0 + u * SU_THREADS;
+                if (i >= n) break;
+                if (i % NB_FRAME_SYMBOLS) { sx += double(v[u].x); sy += double(v[u].y); }
+                else acc += atan2f(v[u].y, v[u].x);               // entry 0 of a frame: the PRS's cyclic-prefix correlation
+            }
         }
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) { sx += __shfl_xor(sx, off); sy += __shfl_xor(sy, off); }
         if (lane == 0) { red_dd[0][wave] = sx; red_dd[1][wave] = sy; }
     } else {
-        for (int i = tid; i < n; i += SU_THREADS) acc += atan2f(c[i].y, c[i].x);
+        for (int i0 = tid; i0 < n; i0 += SU_THREADS * SU_BATCH) {
+            float2 v[SU_BATCH];
+#pragma unroll
+            for (int u = 0; u < SU_BATCH; u++) {
+                const int i = i0 + u * SU_THREADS;
+                v[u] = i < n ? c[i] : make_float2(1.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < SU_BATCH; u++)
+                if (i0 + u * SU_THREADS < n) acc += atan2f(v[u].y, v[u].x);
+        }
     }
-    // level of the stream's most recent frame: first 4096 samples (PRS and the start of the first data symbol)
-    const float4 *x = reinterpret_cast<const float4 *>(iq + (size_t(s) * frames_per_stream + (frames_per_stream - 1)) * frame_stride);
     float l1 = 0.f;
-    for (int i = tid; i < 2048; i += SU_THREADS) {
-        const float4 v = x[i];
-        l1 += fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w);
-    }
+#pragma unroll
+    for (int k = 0; k < 2048 / SU_THREADS; k++) l1 += fabsf(lv[k].x) + fabsf(lv[k].y) + fabsf(lv[k].z) + fabsf(lv[k].w);
     acc = wave_sum(acc, lane);
     l1 = wave_sum(l1, lane);
     if (lane == 0) { red[0][wave] = acc; red[1][wave] = l1; }

@@ -489,6 +489,23 @@ bool wave_group_supported(int nsteps) {
     return nsteps >= 102 && (nsteps - 6) % 96 == 0 && viterbi_fits(nsteps) && viterbi_rot_lds_bytes(nsteps) <= 160 * 1024;
 }
 
+static unsigned cu_count() {
+    static const unsigned n_cu = [] {
+        int dev = 0;
+        unsigned n = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            n = unsigned(prop.multiProcessorCount);
+        return n;
+    }();
+    return n_cu;
+}
+
+bool wave_group_one_round(int max_nsteps, long n_waves) {
+    const size_t lds = (viterbi_rot_lds_bytes(max_nsteps) + 255) & ~size_t(255);
+    return n_waves >= 0 && size_t(n_waves) <= size_t(cu_count()) * (size_t(160 * 1024) / lds);
+}
+
 hipError_t launch_msc_decode_group(const WaveGroupItem *items, int n, hipStream_t s, const WaveFicItem *fic) {
     for (int i0 = 0; i0 < n; i0 += WAVE_GROUP_MAX) {
         const int m = std::min(WAVE_GROUP_MAX, n - i0);
@@ -561,14 +578,7 @@ hipError_t launch_msc_decode(const CodeTables &c, const MscArgs &a, hipStream_t 
 // that is not a multiple of o_max * CUs leaves some CUs with more co-resident (slower) waves than others.  Ask for
 // just enough LDS that every CU holds the same number of workgroups per round.
 size_t balanced_lds_bytes(unsigned grid, size_t lds, unsigned o_cap) {
-    static const unsigned n_cu = [] {
-        int dev = 0;
-        unsigned n = 256;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-            n = unsigned(prop.multiProcessorCount);
-        return n;
-    }();
+    const unsigned n_cu = cu_count();
     const size_t cu_lds = 160 * 1024;
     const unsigned o_max = unsigned(std::min<size_t>(lds ? cu_lds / lds : o_cap, o_cap));
     if (o_max == 0 || grid == 0) return lds;

@@ -189,6 +189,39 @@ def test_decode_frames_equals_separate_calls(mode, fps):
     ref.close(); c.close()
 
 
+@pytest.mark.parametrize("n_streams,fps", [(1, 1), (1, 256), (3, 128), (1, 388), (2, 500)])
+def test_fic_with_one_sub_channel_equals_separate_calls(n_streams, fps):
+    """One ensemble's shape (BASELINE configs 2-3, the plugin's one frame per call): the FIC and ONE sub-channel share a
+    launch of the wave-per-codeword kernel while all their codewords are resident at once (<= 384 frames for 64 kbit/s),
+    above that they are two launches; on noise, with carried history, always the bytes of the separate calls."""
+    sc = dabgpu.subchannel(5, 64, level=3)
+    n = n_streams * fps
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev); g.manual_seed(1000 + n)
+    soft = torch.randint(-127, 128, (n, dabgpu.NB_FRAME_BITS), dtype=torch.int8, device=dev, generator=g)
+    hin = torch.randint(-127, 128, (n_streams, 15, sc.length * 64), dtype=torch.int8, device=dev, generator=g)
+    def buffers():
+        return (torch.zeros((n, 12, 32), dtype=torch.uint8, device=dev), torch.zeros((n, 12), dtype=torch.uint8, device=dev),
+                torch.zeros((n_streams, fps * 4, 192), dtype=torch.uint8, device=dev), torch.zeros_like(hin))
+    c = make_ctx(None, max_frames=8)
+    fib0, ok0, out0, hout0 = buffers()
+    c.fic_decode_dev(soft.data_ptr(), dabgpu.NB_FRAME_BITS, n, fib0.data_ptr(), ok0.data_ptr(), None)
+    c.msc_decode_dev(sc, soft.data_ptr(), dabgpu.NB_FRAME_BITS, n_streams, fps, hin.data_ptr(), hout0.data_ptr(), out0.data_ptr(), None)
+    fib1, ok1, out1, hout1 = buffers()
+    c.decode_frames_dev(soft.data_ptr(), dabgpu.NB_FRAME_BITS, n_streams, fps, fib1.data_ptr(), ok1.data_ptr(), [sc],
+                        [hin.data_ptr()], [hout1.data_ptr()], [out1.data_ptr()], None)
+    c.sync()
+    assert (fib0 == fib1).all() and (ok0 == ok1).all() and (out0 == out1).all() and (hout0 == hout1).all()
+    # and the oracle on a few codewords of the first stream
+    mask, kept, nsteps = O.eep_puncture_mask(0, 3, 64)[:3]
+    cifs = soft[:fps, dabgpu.NB_FIC_BITS:].reshape(fps * 4, 55296)[:, sc.start_address * 64:(sc.start_address + sc.length) * 64].cpu().numpy()
+    padded = np.concatenate([hin[0].cpu().numpy(), cifs])
+    for t in sorted({0, min(3, fps * 4 - 1), fps * 4 - 1}):
+        want = O.msc_decode_lf(O.time_deinterleave(padded[t:t + 16])[:kept], mask, nsteps)
+        assert (out1[0, t].cpu().numpy() == want).all(), t
+    c.close()
+
+
 def test_bench_shape_grouped_launch_equals_the_oracle_on_noise():
     """The shape bench.py runs -- 64 streams x 256 frames, FIC + one 64 kbit/s EEP 3-A sub-channel in ONE grouped
     lane launch (65 536 + 65 536 codewords) -- on pure noise, with carried de-interleaver history, against the oracle
