@@ -196,8 +196,7 @@ __device__ __forceinline__ int lane_xchg(int m, int lane) {
 }
 
 struct RotTables {
-    int tab_cs[6];    // int8x4 signs giving  +sigma * c  (sigma = -1 where the lane itself is the older-bit-1 predecessor)
-    int tab_ncs[6];   // int8x4 signs giving  -sigma * c
+    int tab_cs[6];    // int8x4 signs giving  sigma * c  (sigma = -1 where the lane itself is the older-bit-1 predecessor)
     int thr[6];       // 0 where bit q of the lane is 0, -1 where it is 1 (strict-compare threshold, see rot_step)
 };
 
@@ -211,24 +210,58 @@ __device__ __forceinline__ int pack_i8x4(int a, int b, int c, int d) {
     return (a & 0xFF) | ((b & 0xFF) << 8) | ((c & 0xFF) << 16) | ((d & 0xFF) << 24);
 }
 
-// one trellis step at phase PH (= t mod 6); w = the step's four soft bits (wave-uniform)
-//   x = M_self + sigma*c, y = M_other - sigma*c are the two candidates of the state this lane holds next.
+// one trellis step at phase PH (= t mod 6); c = sigma * (the step's branch metric), ct = c + the lane's threshold -- both
+// depend on the soft bits alone and are computed ahead of the chain metric -> exchange -> subtract -> max
+//   x = M_self + c, y = M_other - c are the two candidates of the state this lane holds next.
 //   Lanes with bit q clear are the older-bit-0 predecessor themselves: survivor bit = (y > x).
-//   Lanes with bit q set are the older-bit-1 predecessor:               survivor bit = (x > y) = !(y - x > -1).
-//   So one compare against a per-lane threshold (0 / -1) and an XOR with a constant lane mask gives the
-//   strict-greater rule for both; the bit is shifted into `dec` by an add-with-carry.
+//   Lanes with bit q set are the older-bit-1 predecessor:               survivor bit = (x > y) = !(y > x - 1).
+//   So one compare against x + threshold (0 / -1) and an XOR with a constant lane mask gives the strict-greater rule
+//   for both.  Returns the 64 survivor bits of the step.
 template <int PH>
-__device__ __forceinline__ void rot_step(const RotTables &T, int lane, int w, int &metric, unsigned &dec) {
+__device__ __forceinline__ unsigned long long rot_step(int lane, int c, int ct, int &metric) {
     constexpr int Q = 5 - PH;
-    const int x = __builtin_amdgcn_sdot4(T.tab_cs[PH], w, metric, false);
     const int other = lane_xchg<(1 << Q)>(metric, lane);
-    const int y = __builtin_amdgcn_sdot4(T.tab_ncs[PH], w, other, false);
-    const int d = y - x;
+    const int x = metric + c, xt = metric + ct;
+    const int y = other - c;
     metric = max(x, y);
-    const unsigned long long m = __ballot(d > T.thr[PH]) ^ qmask(Q);
-    unsigned long long carry_out;
-    asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(dec), "=s"(carry_out) : "v"(dec), "s"(m));
+    return __ballot(y > xt) ^ qmask(Q);
 }
+
+// lane LANE of v = the wave-uniform word s
+template <int LANE>
+__device__ __forceinline__ void write_lane(int &v, int s) {
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(s), "n"(LANE));
+}
+
+// The per-wave LDS slab of the rot kernel (host and device agree through this one function).
+//   survivors: one 8-byte slot per trellis step t (bit l = the survivor bit of lane l), at slot t + (t - 6) / seg_steps
+//              for t >= 6 -- one slot of skew per traceback segment, so that the lanes of the traceback, each reading
+//              its own segment, spread over the LDS banks (segments are 12..48 slots long: unskewed, 8- to 16-way conflicts)
+//   mother:    the depunctured codeword, consumed from a region that starts half-way up the survivors' final extent: a
+//              survivor row is only written after the codeword bytes it overlaps have been read (4 B/step consumed vs
+//              8 B/step produced); the skew slots are added to the offset
+//   out6:      the decoded bits, six per byte;  zero: six all-zero slots (what the traceback reads above the last step)
+struct RotLayout {
+    int seg_cycles;       // six-step phase cycles per traceback lane
+    int seg_steps;        // = 6 * seg_cycles
+    int n_lanes;          // lanes that own a segment
+    int mother_off, mother_bytes, out6_off, zero_off, total;
+};
+__host__ __device__ inline RotLayout rot_layout(int nsteps) {
+    RotLayout L;
+    const int groups = (nsteps - 6) / 6;
+    L.seg_cycles = (groups + 63) / 64;
+    L.seg_steps = 6 * L.seg_cycles;
+    L.n_lanes = (groups + L.seg_cycles - 1) / L.seg_cycles;
+    const int skew_slots = (nsteps - 6) / L.seg_steps + 2;
+    L.mother_off = 128 * ((nsteps - 6) / 32 + 1) + ((8 * skew_slots + 255) & ~255);
+    L.mother_bytes = (4 * nsteps + 255) & ~255;
+    L.out6_off = L.mother_off + L.mother_bytes;
+    L.zero_off = L.out6_off + ((groups + 255) & ~255);
+    L.total = L.zero_off + 256;                                   // (the survivors end below out6_off)
+    return L;
+}
+constexpr int ROT_WARM_CYCLES = 16;                                // 96 steps run in before a lane's own segment
 
 // One wavefront decodes codeword `cw` in its LDS slab (every wave of the workgroup must call it: it contains
 // workgroup barriers, none of them inside a loop whose trip count depends on the codeword).
@@ -238,19 +271,15 @@ __device__ __forceinline__ void rot_decode(const Fetch &fetch, const CodeTables 
     const int nsteps = code.nsteps;
     const int nchunks = (nsteps - 6) / 96;
 
-    // Per-wave LDS slab.  The survivor words W grow from the bottom (256 B per 32 steps) while the depunctured
-    // codeword is consumed from a region that starts half-way up W's final extent: a W row is only written after
-    // the codeword bytes it overlaps have been read (4 B/step consumed vs 8 B/step produced, offset = |W|/2).
-    const int ngroups = (nsteps - 6) / 32 + 1;
-    const int mother_off = ngroups * 128;
-    const int mother_bytes = (4 * nsteps + 255) & ~255;
-    unsigned *W = reinterpret_cast<unsigned *>(slab);                        // [ngroups][64]
-    int8_t *mother = reinterpret_cast<int8_t *>(slab + mother_off);
+    const RotLayout L = rot_layout(nsteps);
+    const int mother_bytes = L.mother_bytes;
+    int8_t *mother = reinterpret_cast<int8_t *>(slab + L.mother_off);
     int *m4 = reinterpret_cast<int *>(mother);
-    uint8_t *out6 = slab + mother_off + mother_bytes;                        // [16*nchunks] six-bit groups
+    uint8_t *out6 = slab + L.out6_off;                                       // [16*nchunks] six-bit groups
 
     // ---- A8: depuncture into LDS ----
     for (int i = lane; i < mother_bytes / 4; i += 64) m4[i] = 0;
+    if (lane < 16) reinterpret_cast<int *>(slab + L.zero_off)[lane] = 0;
     __syncthreads();
     for (int i = lane; i < code.n_punct; i += 64) mother[code.mother_pos[i]] = fetch(cw, i);
     __syncthreads();
@@ -266,83 +295,113 @@ __device__ __forceinline__ void rot_decode(const Fetch &fetch, const CodeTables 
         const int sg = qb ? -1 : 1;
         T.thr[ph] = -qb;
         T.tab_cs[ph] = pack_i8x4(sg * s0, sg * s1, sg * s2, sg * s0);
-        T.tab_ncs[ph] = pack_i8x4(-sg * s0, -sg * s1, -sg * s2, -sg * s0);
     }
 
     // ---- A9 forward pass ----
+    // The 64 survivor bits of a step are one ballot word; lane j & 31 of `vm` keeps its low half and lane 32 + (j & 31)
+    // its high half until a row of 32 steps goes to the survivor slots.
+    const unsigned seg_magic = unsigned((0x100000000ull + unsigned(L.seg_steps) - 1) / unsigned(L.seg_steps));
+    auto flush = [&](int row_t0, int vm) {
+        const int t = row_t0 + (lane & 31);
+        const int skew = t >= 6 ? int(__umulhi(unsigned(t - 6), seg_magic)) : 0;    // (t - 6) / seg_steps, exact below 2^16
+        if (t < nsteps) *reinterpret_cast<int *>(slab + 8 * (t + skew) + 4 * (lane >> 5)) = vm;
+    };
     int metric = (lane == 0) ? 0 : -VITERBI_INIT_PENALTY;
-    unsigned dec = 0;
+    int vm = 0;
     int cw0 = m4[lane], cw1 = m4[64 + (lane & 31)];
     for (int c = 0; c < nchunks; c++) {
         const int a0 = cw0, a1 = cw1;
         const int tn = (c + 1) * 96;
         cw0 = m4[min(tn + lane, nsteps - 1)];              // prefetch; clamped so it never leaves the codeword
         cw1 = m4[min(tn + 64 + (lane & 31), nsteps - 1)];
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
+#define DAB_ROT_METRIC(I, PH)                                                                    \
+        constexpr int j##PH = 6 * (I) + (PH);                                                    \
+        const int c##PH = __builtin_amdgcn_sdot4(T.tab_cs[PH], __builtin_amdgcn_readlane(j##PH < 64 ? a0 : a1, j##PH & 63), 0, false); \
+        const int ct##PH = c##PH + T.thr[PH];
 #define DAB_ROT_STEP(PH)                                                                         \
     {                                                                                            \
-        const int j = 6 * i + PH;                                                                \
-        const int w = __builtin_amdgcn_readlane(j < 64 ? a0 : a1, j & 63);                       \
-        rot_step<PH>(T, lane, w, metric, dec);                                                   \
-        if ((j & 31) == 31) W[(c * 3 + (j >> 5)) * 64 + lane] = dec;                             \
+        const unsigned long long m = rot_step<PH>(lane, c##PH, ct##PH, metric);                  \
+        write_lane<(j##PH & 31)>(vm, int(unsigned(m)));                                          \
+        write_lane<32 + (j##PH & 31)>(vm, int(unsigned(m >> 32)));                               \
+        if ((j##PH & 31) == 31) flush(c * 96 + j##PH - 31, vm);                                  \
     }
-            DAB_ROT_STEP(0) DAB_ROT_STEP(1) DAB_ROT_STEP(2) DAB_ROT_STEP(3) DAB_ROT_STEP(4) DAB_ROT_STEP(5)
+#define DAB_ROT_CYCLE(I)                                                                         \
+    {                                                                                            \
+        DAB_ROT_METRIC(I, 0) DAB_ROT_METRIC(I, 1) DAB_ROT_METRIC(I, 2) DAB_ROT_METRIC(I, 3) DAB_ROT_METRIC(I, 4) DAB_ROT_METRIC(I, 5) \
+        DAB_ROT_STEP(0) DAB_ROT_STEP(1) DAB_ROT_STEP(2) DAB_ROT_STEP(3) DAB_ROT_STEP(4) DAB_ROT_STEP(5) \
+    }
+        DAB_ROT_CYCLE(0) DAB_ROT_CYCLE(1) DAB_ROT_CYCLE(2) DAB_ROT_CYCLE(3) DAB_ROT_CYCLE(4) DAB_ROT_CYCLE(5) DAB_ROT_CYCLE(6) DAB_ROT_CYCLE(7)
+        DAB_ROT_CYCLE(8) DAB_ROT_CYCLE(9) DAB_ROT_CYCLE(10) DAB_ROT_CYCLE(11) DAB_ROT_CYCLE(12) DAB_ROT_CYCLE(13) DAB_ROT_CYCLE(14) DAB_ROT_CYCLE(15)
+#undef DAB_ROT_CYCLE
 #undef DAB_ROT_STEP
-        }
+#undef DAB_ROT_METRIC
     }
     {   // the six tail steps (zero tail bits): one more phase cycle
-        dec = 0;
         const int a0 = cw0;
-        rot_step<0>(T, lane, __builtin_amdgcn_readlane(a0, 0), metric, dec);
-        rot_step<1>(T, lane, __builtin_amdgcn_readlane(a0, 1), metric, dec);
-        rot_step<2>(T, lane, __builtin_amdgcn_readlane(a0, 2), metric, dec);
-        rot_step<3>(T, lane, __builtin_amdgcn_readlane(a0, 3), metric, dec);
-        rot_step<4>(T, lane, __builtin_amdgcn_readlane(a0, 4), metric, dec);
-        rot_step<5>(T, lane, __builtin_amdgcn_readlane(a0, 5), metric, dec);
-        W[nchunks * 3 * 64 + lane] = dec;    // bit 5 = first tail step ... bit 0 = last
+#define DAB_ROT_TAIL(PH)                                                                         \
+    {                                                                                            \
+        const int cb = __builtin_amdgcn_sdot4(T.tab_cs[PH], __builtin_amdgcn_readlane(a0, PH), 0, false); \
+        const unsigned long long m = rot_step<PH>(lane, cb, cb + T.thr[PH], metric);             \
+        write_lane<PH>(vm, int(unsigned(m)));                                                    \
+        write_lane<32 + PH>(vm, int(unsigned(m >> 32)));                                         \
+    }
+        DAB_ROT_TAIL(0) DAB_ROT_TAIL(1) DAB_ROT_TAIL(2) DAB_ROT_TAIL(3) DAB_ROT_TAIL(4) DAB_ROT_TAIL(5)
+#undef DAB_ROT_TAIL
+        flush(nchunks * 96, vm);                               // (only the six steps below nsteps are written)
     }
     __syncthreads();
 
-    // ---- traceback in the lane domain, on the scalar unit ----
-    // End state 0 sits in lane 0 in every layout.  Going back over step t replaces bit q_t of the lane index by
-    // the survivor bit h_t, and h_t is the input bit of step t-6 (it becomes the oldest bit of the earlier
-    // state).  After the six steps of one phase cycle (q = 0,1,..,5 going backwards) the lane index therefore
-    // IS six consecutive decoded bits, earliest in bit 5: they are appended to the output six at a time.
-    int l = 0;
+    // ---- traceback in the lane domain, all segments at once ----
+    // End state 0 sits in lane 0 in every layout.  Going back over step t replaces bit q_t of the lane index by the
+    // survivor bit h_t, and h_t is the input bit of step t-6 (it becomes the oldest bit of the earlier state).  After
+    // the six steps of one phase cycle (q = 0,1,..,5 going backwards) the lane index therefore IS six consecutive
+    // decoded bits, earliest in bit 5: out6[g] = the index after the cycle of steps [6g+6, 6g+12).
+    // Lane c owns the cycles of steps [6 + S c, 6 + S (c+1)) (S = seg_steps).  It starts ROT_WARM_CYCLES cycles above
+    // them from index 0 -- above the last step the slots read as zero, which keeps index 0 down to the true end state --
+    // and has, with all but negligible probability, merged with the survivor path when it reaches its own segment.
+    // That is then CHECKED, not assumed: the index a lane entered its segment with must be the one the lane above left
+    // its segment with; while any pair disagrees, the lanes re-enter with their neighbour's exit index and trace their
+    // segments again.  The top lane's entry is exact, so is, by induction, everything below once all pairs agree:
+    // the bits are those of the serial traceback, on any input (at most n_lanes passes, one on ordinary ones).
     {
-        const unsigned wv = W[nchunks * 3 * 64 + lane];
+        const int S = L.seg_steps;
+        const int t_above = 6 + S * (lane + 1);                   // first step above the lane's segment
+        const int slot_above = t_above + (lane + 1);              // ... and its slot (skew = lane + 1 segments)
+        int l = 0;
+        // one phase cycle of steps [t_above + wi, +6), wi a multiple of 6 in [-S, 6 * ROT_WARM_CYCLES)
+        auto cycle = [&](int wi, bool emit) {
+            const int fl = wi >= 0 ? wi / S : -1;                  // floor(wi / S): wave-uniform
+            const int tb = t_above + wi;
+            const bool real = tb < nsteps;
+            const unsigned long long *p = reinterpret_cast<const unsigned long long *>(slab + (real ? 8 * (slot_above + wi + fl) : L.zero_off));
+            unsigned long long M[6];
 #pragma unroll
-        for (int r = 5; r >= 0; r--) {
-            const int q = 5 - r;                                             // phase of tail step r is r
-            const unsigned sw = unsigned(__builtin_amdgcn_readlane(int(wv), l));
-            const unsigned h = (sw >> (5 - r)) & 1u;
-            l = (l & ~(1 << q)) | int(h << q);
-        }
-        // l now holds the last six INFO bits (inputs of steps 96k-6 .. 96k-1), earliest in bit 5
-    }
-    for (int c = nchunks - 1; c >= 0; c--) {
-        unsigned wv = 0;
-#pragma unroll
-        for (int cyc = 15; cyc >= 0; cyc--) {
-            // entering: l = info bits [96c + 6*cyc, +6)
-            if (lane == 0) out6[c * 16 + cyc] = uint8_t(l);
+            for (int ph = 0; ph < 6; ph++) M[ph] = p[ph];
 #pragma unroll
             for (int ph = 5; ph >= 0; ph--) {
-                const int j = 6 * cyc + ph;                                    // step index inside the chunk
-                if ((j & 31) == 31 || j == 95) wv = W[(c * 3 + (j >> 5)) * 64 + lane];
                 const int q = 5 - ph;
-                const unsigned sw = unsigned(__builtin_amdgcn_readlane(int(wv), l));
-                const unsigned h = (sw >> (31 - (j & 31))) & 1u;
+                const unsigned h = unsigned(M[ph] >> l) & 1u;
                 l = (l & ~(1 << q)) | int(h << q);
             }
+            if (emit && real) out6[(tb - 6) / 6] = uint8_t(l);
+        };
+        for (int i = ROT_WARM_CYCLES - 1; i >= 0; i--) cycle(6 * i, false);
+        int entry = l;
+        for (int i = 1; i <= L.seg_cycles; i++) cycle(-6 * i, true);
+        const bool chained = lane < L.n_lanes - 1;
+        int above = __shfl_down(l, 1);
+        while (__ballot(chained && entry != above)) {
+            if (chained) entry = above;
+            l = entry;
+            for (int i = 1; i <= L.seg_cycles; i++) cycle(-6 * i, true);
+            above = __shfl_down(l, 1);
         }
     }
     __syncthreads();
 
     // ---- A10: bytes out (big-endian within each word) + energy dispersal ----
     const int nbytes = (nsteps - 6) >> 3;
-    uint8_t *bytes = reinterpret_cast<uint8_t *>(W);
+    uint8_t *bytes = slab;                                                 // (the survivors are done with)
     uint8_t *o = out + size_t(cw) * nbytes;
     for (int k = lane; k < nbytes; k += 64) {
         // byte k = bits 8k..8k+7 = tail of six-bit group g and head of group g+1
@@ -415,12 +474,7 @@ struct HistoryPack {
     MscArgs a[WAVE_GROUP_MAX];
 };
 
-inline size_t viterbi_rot_lds_bytes(int nsteps) {
-    const size_t mother = (size_t(4) * nsteps + 255) & ~size_t(255);
-    const size_t groups = size_t((nsteps - 6) / 32 + 1);
-    const size_t out6 = (size_t((nsteps - 6) / 6) + 255) & ~size_t(255);
-    return std::max(groups * 256, groups * 128 + mother + out6);
-}
+inline size_t viterbi_rot_lds_bytes(int nsteps) { return size_t(rot_layout(nsteps).total); }
 
 // history ring update: hist_out[s][h] = CIF (4F - 15 + h), h = 0..14
 __device__ __forceinline__ void msc_history_body(const MscArgs &a, size_t first, size_t step) {

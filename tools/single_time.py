@@ -15,7 +15,8 @@ soft = torch.zeros((Fmax, dabgpu.NB_FRAME_BITS), dtype=torch.int8, device=dev)
 fib = torch.zeros((Fmax, 12, 32), dtype=torch.uint8, device=dev); ok = torch.zeros((Fmax, 12), dtype=torch.uint8, device=dev)
 sc = dabgpu.subchannel(0, 64, level=3)
 msc = torch.zeros((1, Fmax * 4, 192), dtype=torch.uint8, device=dev)
-hin = torch.zeros((1, 15, sc.length * 64), dtype=torch.int8, device=dev); hout = torch.zeros_like(hin)
+# (a de-interleaver history of noise, as the soft bits: an all-erasure history is the traceback's worst case, not its usual one)
+hin = torch.randint(-127, 128, (1, 15, sc.length * 64), dtype=torch.int8, device=dev); hout = torch.zeros_like(hin)
 st = torch.cuda.Stream(); torch.cuda.set_stream(st); s = st.cuda_stream
 def timed(fn, reps=20):
     for _ in range(3): fn()
