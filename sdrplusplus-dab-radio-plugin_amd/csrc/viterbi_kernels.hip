@@ -39,6 +39,7 @@ __device__ __forceinline__ unsigned crc16_byte(unsigned crc, unsigned byte) {
 
 // ---- where a codeword's punctured soft bits come from -----------------------
 struct FetchFic {
+    static constexpr int kBatch = 1;     // loads the rot kernel keeps in flight per lane while depuncturing
     const int8_t *soft;
     size_t stride;
     __device__ __forceinline__ int8_t operator()(int cw, int i) const {
@@ -46,6 +47,7 @@ struct FetchFic {
     }
 };
 struct FetchPlain {
+    static constexpr int kBatch = 1;
     const int8_t *punct;
     int n_punct;
     __device__ __forceinline__ int8_t operator()(int cw, int i) const { return punct[size_t(cw) * n_punct + i]; }
@@ -53,6 +55,7 @@ struct FetchPlain {
 // A12 time de-interleave: logical frame completed by CIF t takes bit i from CIF
 // t - 15 + d(i % 16); CIFs before the call come from the history ring.
 struct FetchMsc {
+    static constexpr int kBatch = 8;
     const int8_t *soft;
     size_t stride;
     const int8_t *hist;
@@ -281,7 +284,23 @@ __device__ __forceinline__ void rot_decode(const Fetch &fetch, const CodeTables 
     for (int i = lane; i < mother_bytes / 4; i += 64) m4[i] = 0;
     if (lane < 16) reinterpret_cast<int *>(slab + L.zero_off)[lane] = 0;
     __syncthreads();
-    for (int i = lane; i < code.n_punct; i += 64) mother[code.mother_pos[i]] = fetch(cw, i);
+    if constexpr (Fetch::kBatch > 1) {
+        // the de-interleaver's bytes come from sixteen CIFs at once: eight of them (and their positions) in flight per lane
+        for (int i0 = lane; i0 < code.n_punct; i0 += 64 * Fetch::kBatch) {
+            int8_t v[Fetch::kBatch];
+            uint16_t pos[Fetch::kBatch];
+#pragma unroll
+            for (int u = 0; u < Fetch::kBatch; u++) {
+                const int i = i0 + 64 * u;
+                if (i < code.n_punct) { v[u] = fetch(cw, i); pos[u] = code.mother_pos[i]; }
+            }
+#pragma unroll
+            for (int u = 0; u < Fetch::kBatch; u++)
+                if (i0 + 64 * u < code.n_punct) mother[pos[u]] = v[u];
+        }
+    } else {
+        for (int i = lane; i < code.n_punct; i += 64) mother[code.mother_pos[i]] = fetch(cw, i);
+    }
     __syncthreads();
 
     // ---- per-lane sign tables for the six layout phases ----
@@ -457,12 +476,21 @@ struct WaveEntryPack {
 };
 __global__ __launch_bounds__(64) void viterbi_rot_grouped_kernel(const WaveEntryPack pack) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // consecutive codewords to the same XCD (workgroup b runs on XCD b % 8): the sixteen CIFs a sub-channel codeword is
+    // gathered from are the next codeword's too, and each XCD has an L2 of its own.  The FIC's (shorter) codewords and
+    // the sub-channels' are spread separately, so that every XCD gets its share of both.
+    auto same_xcd = [](int b, int total) {
+        const int per = (total + 7) >> 3, x = b & 7, r = b >> 3;
+        const int full = total - (per - 1) * 8;               // XCDs that take `per` codewords (the others per - 1)
+        return x < full ? x * per + r : full * per + (x - full) * (per - 1) + r;
+    };
     int cw = blockIdx.x;
     if (cw < pack.n_fic) {            // one frame at a time the FIC's four codewords ride along with the sub-channels'
-        rot_decode<FetchFic, Tail::kFic>(pack.fic_fetch, pack.fic_code, cw, true, pack.fib, pack.crc_ok, smem, int(threadIdx.x));
+        rot_decode<FetchFic, Tail::kFic>(pack.fic_fetch, pack.fic_code, same_xcd(cw, pack.n_fic), true, pack.fib, pack.crc_ok, smem,
+                                         int(threadIdx.x));
         return;
     }
-    cw -= pack.n_fic;
+    cw = same_xcd(cw - pack.n_fic, int(gridDim.x) - pack.n_fic);
     int k = 0;
     while (k + 1 < pack.n && cw >= pack.e[k + 1].first_cw) k++;
     const WaveEntry &en = pack.e[k];

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "sdrplusplus-dab-radio-plugin_amd")); sys.path.insert(0, ROOT)
 import numpy as np, torch, dabgpu
 from dabgpu import synth
-dev = torch.device("cuda", 0)
+dev = torch.device("cuda", 0); torch.manual_seed(7)
 sizes = [int(a) for a in sys.argv[1:]] or [4, 16, 64, 256, 1024]
 Fmax = max(sizes)
 L = synth.NB_FRAME_SAMPLES if hasattr(synth, "NB_FRAME_SAMPLES") else 196608
