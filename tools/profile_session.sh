@@ -21,3 +21,4 @@ python3 tools/vit_time.py 16384 > $o/vit_time.txt 2>&1; cat $o/vit_time.txt
 timeout 900 python3 tools/alloc_stress.py 300 100 > $o/alloc_stress.txt 2>&1; tail -n 2 $o/alloc_stress.txt
 python3 tools/frame_latency.py > $o/frame_latency.txt 2>&1; tail -n 3 $o/frame_latency.txt
 python3 tools/loop_gate_table.py 4 > $o/loop_gate.txt 2>&1; tail -n 8 $o/loop_gate.txt
+python3 tools/single_time.py 1 4 64 256 1024 > $o/single_time.txt 2>&1; cat $o/single_time.txt     # one ensemble: each call of the step, per batch size
