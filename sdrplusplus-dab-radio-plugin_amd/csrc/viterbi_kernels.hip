@@ -327,15 +327,16 @@ __device__ __forceinline__ void rot_decode(const Fetch &fetch, const CodeTables 
     };
     int metric = (lane == 0) ? 0 : -VITERBI_INIT_PENALTY;
     int vm = 0;
-    int cw0 = m4[lane], cw1 = m4[64 + (lane & 31)];
+    // the step's four soft bits: one LDS word, the same address in every lane (a broadcast read), fetched one phase
+    // cycle ahead of its use
+    int wc[6];
+#pragma unroll
+    for (int ph = 0; ph < 6; ph++) wc[ph] = m4[ph];
     for (int c = 0; c < nchunks; c++) {
-        const int a0 = cw0, a1 = cw1;
-        const int tn = (c + 1) * 96;
-        cw0 = m4[min(tn + lane, nsteps - 1)];              // prefetch; clamped so it never leaves the codeword
-        cw1 = m4[min(tn + 64 + (lane & 31), nsteps - 1)];
+        const int *mw = m4 + 96 * c;
 #define DAB_ROT_METRIC(I, PH)                                                                    \
         constexpr int j##PH = 6 * (I) + (PH);                                                    \
-        const int c##PH = __builtin_amdgcn_sdot4(T.tab_cs[PH], __builtin_amdgcn_readlane(j##PH < 64 ? a0 : a1, j##PH & 63), 0, false); \
+        const int c##PH = __builtin_amdgcn_sdot4(T.tab_cs[PH], wc[PH], 0, false);                \
         const int ct##PH = c##PH + T.thr[PH];
 #define DAB_ROT_STEP(PH)                                                                         \
     {                                                                                            \
@@ -346,8 +347,11 @@ __device__ __forceinline__ void rot_decode(const Fetch &fetch, const CodeTables 
     }
 #define DAB_ROT_CYCLE(I)                                                                         \
     {                                                                                            \
+        int wn[6];                                                                               \
+        _Pragma("unroll") for (int ph = 0; ph < 6; ph++) wn[ph] = mw[6 * ((I) + 1) + ph];        \
         DAB_ROT_METRIC(I, 0) DAB_ROT_METRIC(I, 1) DAB_ROT_METRIC(I, 2) DAB_ROT_METRIC(I, 3) DAB_ROT_METRIC(I, 4) DAB_ROT_METRIC(I, 5) \
         DAB_ROT_STEP(0) DAB_ROT_STEP(1) DAB_ROT_STEP(2) DAB_ROT_STEP(3) DAB_ROT_STEP(4) DAB_ROT_STEP(5) \
+        _Pragma("unroll") for (int ph = 0; ph < 6; ph++) wc[ph] = wn[ph];                        \
     }
         DAB_ROT_CYCLE(0) DAB_ROT_CYCLE(1) DAB_ROT_CYCLE(2) DAB_ROT_CYCLE(3) DAB_ROT_CYCLE(4) DAB_ROT_CYCLE(5) DAB_ROT_CYCLE(6) DAB_ROT_CYCLE(7)
         DAB_ROT_CYCLE(8) DAB_ROT_CYCLE(9) DAB_ROT_CYCLE(10) DAB_ROT_CYCLE(11) DAB_ROT_CYCLE(12) DAB_ROT_CYCLE(13) DAB_ROT_CYCLE(14) DAB_ROT_CYCLE(15)
@@ -355,11 +359,10 @@ __device__ __forceinline__ void rot_decode(const Fetch &fetch, const CodeTables 
 #undef DAB_ROT_STEP
 #undef DAB_ROT_METRIC
     }
-    {   // the six tail steps (zero tail bits): one more phase cycle
-        const int a0 = cw0;
+    {   // the six tail steps (zero tail bits): one more phase cycle (its words came with the last cycle above)
 #define DAB_ROT_TAIL(PH)                                                                         \
     {                                                                                            \
-        const int cb = __builtin_amdgcn_sdot4(T.tab_cs[PH], __builtin_amdgcn_readlane(a0, PH), 0, false); \
+        const int cb = __builtin_amdgcn_sdot4(T.tab_cs[PH], wc[PH], 0, false);                   \
         const unsigned long long m = rot_step<PH>(lane, cb, cb + T.thr[PH], metric);             \
         write_lane<PH>(vm, int(unsigned(m)));                                                    \
         write_lane<32 + PH>(vm, int(unsigned(m >> 32)));                                         \
