@@ -1150,8 +1150,11 @@ int dabgpu_ofdm_demod_stream_frame(dabgpu_ctx *ctx, int stream_index, const floa
                           reinterpret_cast<int8_t *>(res), d_cyc, d_dq, reinterpret_cast<dabgpu_acquired_frame *>(res + off_fr),
                           reinterpret_cast<dabgpu_sync_result *>(res + off_sy), nullptr, s);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(res + off_st, st, sizeof(dabk::StreamState), hipMemcpyDeviceToDevice, s));
-    HIP_TRY(hipMemcpyAsync(ctx->h_bounce, d_res, nb_res, hipMemcpyDeviceToHost, s));        // one download
+    // one download, written by a kernel right behind the others: soft bits, frame and sync records, then the state
+    static_assert(sizeof(dabk::StreamState) % 16 == 0, "the state goes out in 16-byte words");
+    void *h_dev = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&h_dev, ctx->h_bounce, 0));
+    HIP_TRY(dabk::launch_results_to_host(h_dev, d_res, off_st, st, off_st, sizeof(dabk::StreamState), s));
     if (dqpsk) HIP_TRY(hipMemcpyAsync(dqpsk, d_dq, nb_dq, hipMemcpyDeviceToHost, s));       // (+ the constellation, when asked for)
     HIP_TRY(hipStreamSynchronize(s));                                                    // one synchronisation
     ctx->ev_states_pending = false;

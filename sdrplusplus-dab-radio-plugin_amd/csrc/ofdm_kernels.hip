@@ -710,6 +710,27 @@ hipError_t launch_placement_probe(const void *in, size_t in_bytes, void *out, si
     return hipGetLastError();
 }
 
+namespace {
+__global__ __launch_bounds__(256) void results_to_host_kernel(uint4 *dst, const uint4 *main_src, unsigned n_main, const uint4 *tail_src,
+                                                              unsigned tail_off, unsigned n_tail) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n_main) dst[i] = main_src[i];
+    else if (i - n_main < n_tail) dst[tail_off + (i - n_main)] = tail_src[i - n_main];
+}
+}  // namespace
+
+hipError_t launch_results_to_host(void *h_dst, const void *d_main, size_t n_main, const void *d_tail, size_t tail_off, size_t n_tail,
+                                  hipStream_t s) {
+    if (((n_main | n_tail | tail_off) & 15) || ((reinterpret_cast<uintptr_t>(h_dst) | reinterpret_cast<uintptr_t>(d_main) |
+                                                 reinterpret_cast<uintptr_t>(d_tail)) & 15))
+        return hipErrorInvalidValue;
+    const unsigned nm = unsigned(n_main / 16), nt = unsigned(n_tail / 16);
+    if (nm + nt == 0) return hipSuccess;
+    hipLaunchKernelGGL(results_to_host_kernel, dim3((nm + nt + 255) / 256), dim3(256), 0, s, static_cast<uint4 *>(h_dst),
+                       static_cast<const uint4 *>(d_main), nm, static_cast<const uint4 *>(d_tail), unsigned(tail_off / 16), nt);
+    return hipGetLastError();
+}
+
 hipError_t launch_fill_noise(void *p, size_t bytes, hipStream_t s) {
     if (bytes < 4) return hipSuccess;
     hipLaunchKernelGGL(fill_noise_kernel, dim3(4096), dim3(256), 0, s, static_cast<uint32_t *>(p), bytes / 4);
