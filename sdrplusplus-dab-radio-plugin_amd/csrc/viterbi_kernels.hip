@@ -40,14 +40,18 @@ __device__ __forceinline__ unsigned crc16_byte(unsigned crc, unsigned byte) {
 // ---- where a codeword's punctured soft bits come from -----------------------
 struct FetchFic {
     static constexpr int kBatch = 1;     // loads the rot kernel keeps in flight per lane while depuncturing
+    static constexpr bool kContiguous = true;   // a codeword's punctured bits lie side by side: 16 of them per load
     const int8_t *soft;
     size_t stride;
+    __device__ __forceinline__ bool aligned16() const { return ((reinterpret_cast<uintptr_t>(soft) | stride) & 15) == 0; }
+    __device__ __forceinline__ const int8_t *row(int cw) const { return soft + size_t(cw >> 2) * stride + size_t(cw & 3) * NB_FIC_GROUP_BITS; }
     __device__ __forceinline__ int8_t operator()(int cw, int i) const {
         return soft[size_t(cw >> 2) * stride + size_t(cw & 3) * NB_FIC_GROUP_BITS + i];
     }
 };
 struct FetchPlain {
     static constexpr int kBatch = 1;
+    static constexpr bool kContiguous = false;
     const int8_t *punct;
     int n_punct;
     __device__ __forceinline__ int8_t operator()(int cw, int i) const { return punct[size_t(cw) * n_punct + i]; }
@@ -56,6 +60,7 @@ struct FetchPlain {
 // t - 15 + d(i % 16); CIFs before the call come from the history ring.
 struct FetchMsc {
     static constexpr int kBatch = 8;
+    static constexpr bool kContiguous = false;
     const int8_t *soft;
     size_t stride;
     const int8_t *hist;
@@ -169,10 +174,12 @@ __global__ __launch_bounds__(WGV) void viterbi_wave_kernel(Fetch fetch, CodeTabl
 // differing in ONE bit position q = (5 - t) mod 6, so the ACS butterfly is a fixed
 // XOR exchange: DPP quad_perm / row_half_mirror / row_ror for 1,2,4,8 and
 // v_permlane16/32_swap for 16,32 -- all VALU latency, no LDS crossbar.  Branch
-// metrics are one v_dot4_i32_i8 of a per-lane sign vector with the (wave-uniform)
-// soft word fetched by v_readlane.  Each lane shifts its own survivor bit into a
-// register and spills one dword per 32 steps; traceback runs on the scalar unit in
-// the lane domain (the state update is "replace bit q of the lane index").
+// metrics are one v_dot4_i32_i8 of a per-lane sign vector with the step's soft word
+// (an LDS broadcast read, one phase cycle ahead), computed off the chain
+// metric -> exchange -> subtract -> max.  The 64 survivor bits of a step are one
+// ballot word, stored as one 8-byte LDS slot per step; the traceback runs on all
+// lanes at once, every lane its own segment of steps in the lane domain (the state
+// update is "replace bit q of the lane index"), and checks itself: see rot_decode.
 // Requires nsteps = 96k + 6, which every DAB codeword satisfies (FIC 768+6,
 // EEP 192n+6); other lengths use kernel 1.
 // ============================================================================
@@ -284,7 +291,26 @@ __device__ __forceinline__ void rot_decode(const Fetch &fetch, const CodeTables 
     for (int i = lane; i < mother_bytes / 4; i += 64) m4[i] = 0;
     if (lane < 16) reinterpret_cast<int *>(slab + L.zero_off)[lane] = 0;
     __syncthreads();
-    if constexpr (Fetch::kBatch > 1) {
+    bool wide = false;
+    if constexpr (Fetch::kContiguous) wide = fetch.aligned16() && (code.n_punct & 15) == 0;
+    if constexpr (Fetch::kContiguous) {
+        if (wide) {
+            // sixteen bits and their sixteen positions per lane and round trip (the FIC: 144 such pieces)
+            const uint4 *src = reinterpret_cast<const uint4 *>(fetch.row(cw));
+            const uint4 *ptab = reinterpret_cast<const uint4 *>(code.mother_pos);
+            const int pieces = code.n_punct >> 4;
+            for (int p0 = lane; p0 < pieces; p0 += 64) {
+                const uint4 v = src[p0], pa = ptab[2 * p0], pb = ptab[2 * p0 + 1];
+                const unsigned vb[4] = {v.x, v.y, v.z, v.w};
+                const unsigned pp[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
+#pragma unroll
+                for (int u = 0; u < 16; u++)
+                    mother[(pp[u >> 1] >> (16 * (u & 1))) & 0xFFFFu] = int8_t(vb[u >> 2] >> (8 * (u & 3)));
+            }
+        }
+    }
+    if (wide) {
+    } else if constexpr (Fetch::kBatch > 1) {
         // the de-interleaver's bytes come from sixteen CIFs at once: eight of them (and their positions) in flight per lane
         for (int i0 = lane; i0 < code.n_punct; i0 += 64 * Fetch::kBatch) {
             int8_t v[Fetch::kBatch];

@@ -180,6 +180,27 @@ def test_fic_strided_input_matches_contiguous(ctx, ensemble, ensemble_iq):
     assert ok.all() and (fib == ensemble.fibs).all()      # known answer: transmitted FIBs
 
 
+@pytest.mark.parametrize("offset,stride", [(0, 9216), (1, 9216), (16, 9217), (3, 230400 + 5)])
+def test_fic_from_unaligned_device_buffers(ctx, offset, stride):
+    """The small-batch kernel gathers the FIC's bits sixteen at a time when address and stride allow it and byte by byte
+    when they do not: the same bytes from any address and any stride (noise, so every bit matters)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    n = 5
+    rng = np.random.default_rng(100 + offset + stride)
+    noise = rng.integers(-127, 128, size=(n, 9216), dtype=np.int8)
+    buf = torch.zeros(offset + n * stride + 64, dtype=torch.int8, device=dev)
+    view = torch.as_strided(buf, (n, 9216), (stride, 1), offset)
+    view.copy_(torch.from_numpy(noise).to(dev))
+    fib = torch.zeros((n, 12, 32), dtype=torch.uint8, device=dev)
+    ok = torch.zeros((n, 12), dtype=torch.uint8, device=dev)
+    ctx.fic_decode_dev(buf.data_ptr() + offset, stride, n, fib.data_ptr(), ok.data_ptr(), None)
+    ctx.sync()
+    for f in range(n):
+        ofib, ook = O.fic_decode(noise[f])
+        assert (fib[f].cpu().numpy() == ofib).all() and (ok[f].cpu().numpy() == ook).all()
+
+
 @pytest.mark.parametrize("opt,lvl,br", PROFILES)
 def test_viterbi_bit_exact_golden(ctx, opt, lvl, br):
     d = np.load(golden_path("viterbi_cases.npz"))
