@@ -312,7 +312,8 @@ static int decode_subchannels(dabgpu_ctx *ctx, const dabgpu_subchannel *sc, int 
     }
     // the FIC with ONE sub-channel: together only when every codeword is resident at once (the launch then takes as long
     // as the sub-channel alone: 135 -> 101 us per call up to 256 frames); queued up in rounds, two launches are faster
-    if (group && n_subchannels == 1 && !dabk::wave_group_one_round(items[0].code.nsteps, 2 * cw_each)) group = false;
+    if (group && n_subchannels == 1 && !dabk::wave_group_one_round(std::max(items[0].code.nsteps, ctx->fic.prof.nsteps), 2 * cw_each))
+        group = false;
     if (group) {
         hipStream_t s = pick_stream(ctx, stream);
         ScopedTimer tm(ctx, 2, s);
