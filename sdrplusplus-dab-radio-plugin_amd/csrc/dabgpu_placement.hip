@@ -216,12 +216,12 @@ int dabgpu_alloc_frame_buffers(dabgpu_ctx *ctx, int n_frames, size_t frame_strid
     while (n_small > n_soft && size_t(n_big) * CH + size_t(n_small) * CS > may_take) n_small--;
     const size_t probe_bytes = size_t(n_big) * CH + size_t(n_small) * CS;
     if (probe_bytes > may_take || n_big + n_small > 96) return plain(DABGPU_PLAIN_NO_ROOM);
-    // the context's two address ranges: where chunks are probed, and where the pair is mapped (+ one chunk of addresses:
-    // the soft bits may end on a 1 GiB chunk)
+    // the context's two address ranges: where chunks are probed, and where the pair is mapped (+ two chunks of addresses:
+    // the samples and the soft bits may each end on a 1 GiB chunk)
     if (!ar.probe) {
         void *va = nullptr, *vb = nullptr;
         if ((herr = hipMemAddressReserve(&va, probe_bytes, 0, nullptr, 0)) != hipSuccess) { hstage = 1; (void)hipGetLastError(); return plain(DABGPU_PLAIN_NO_VMM); }
-        if ((herr = hipMemAddressReserve(&vb, need + CH, 0, nullptr, 0)) != hipSuccess) {
+        if ((herr = hipMemAddressReserve(&vb, need + 2 * CH, 0, nullptr, 0)) != hipSuccess) {
             hstage = 1;
             (void)hipMemAddressFree(va, probe_bytes);          // (nothing was ever mapped in it)
             (void)hipGetLastError();
@@ -230,8 +230,8 @@ int dabgpu_alloc_frame_buffers(dabgpu_ctx *ctx, int n_frames, size_t frame_strid
         ar.probe = static_cast<char *>(va);
         ar.pair = static_cast<char *>(vb);
         ar.probe_bytes = probe_bytes;
-        ar.pair_bytes = need + CH;
-    } else if (ar.probe_bytes < probe_bytes || ar.pair_bytes < need + CH) {
+        ar.pair_bytes = need + 2 * CH;
+    } else if (ar.probe_bytes < probe_bytes || ar.pair_bytes < need + 2 * CH) {
         return plain(DABGPU_PLAIN_ARENA_SMALL);              // (a larger request than the ranges were reserved for)
     }
     hipStream_t s = ctx->stream;
@@ -305,9 +305,11 @@ int dabgpu_alloc_frame_buffers(dabgpu_ctx *ctx, int n_frames, size_t frame_strid
             for (int i = 0; i < n_total && iq_mapped < iq_bytes; i++) {
                 if ((i < n_big) != (pass == 0) || used[size_t(i)] || p.c[size_t(i)].dom != order[k]) continue;
                 if (pass == 0 && iq_bytes - iq_mapped < CH) {
-                    // less than a whole big chunk is missing: small chunks of this domain first, if there are enough
+                    // less than a whole big chunk is missing: small chunks first (this domain's, then the others'), if there
+                    // are enough -- a big chunk here would leave the soft bits, which may have to take 1 GiB chunks
+                    // themselves, without room in the pair's range
                     size_t small_left = 0;
-                    for (int j = n_big; j < n_total; j++) if (!used[size_t(j)] && p.c[size_t(j)].dom == order[k]) small_left += CS;
+                    for (int j = n_big; j < n_total; j++) if (!used[size_t(j)]) small_left += CS;
                     if (small_left >= iq_bytes - iq_mapped) break;
                 }
                 iq_sel.push_back(i);

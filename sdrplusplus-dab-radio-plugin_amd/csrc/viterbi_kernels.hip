@@ -292,8 +292,8 @@ __device__ __forceinline__ void rot_decode(const Fetch &fetch, const CodeTables 
     if (lane < 16) reinterpret_cast<int *>(slab + L.zero_off)[lane] = 0;
     __syncthreads();
     bool wide = false;
-    if constexpr (Fetch::kContiguous) wide = fetch.aligned16() && (code.n_punct & 15) == 0;
     if constexpr (Fetch::kContiguous) {
+        wide = fetch.aligned16() && (code.n_punct & 15) == 0;
         if (wide) {
             // sixteen bits and their sixteen positions per lane and round trip (the FIC: 144 such pieces)
             const uint4 *src = reinterpret_cast<const uint4 *>(fetch.row(cw));
@@ -309,23 +309,24 @@ __device__ __forceinline__ void rot_decode(const Fetch &fetch, const CodeTables 
             }
         }
     }
-    if (wide) {
-    } else if constexpr (Fetch::kBatch > 1) {
-        // the de-interleaver's bytes come from sixteen CIFs at once: eight of them (and their positions) in flight per lane
-        for (int i0 = lane; i0 < code.n_punct; i0 += 64 * Fetch::kBatch) {
-            int8_t v[Fetch::kBatch];
-            uint16_t pos[Fetch::kBatch];
+    if (!wide) {
+        if constexpr (Fetch::kBatch > 1) {
+            // the de-interleaver's bytes come from sixteen CIFs at once: eight of them (and their positions) in flight per lane
+            for (int i0 = lane; i0 < code.n_punct; i0 += 64 * Fetch::kBatch) {
+                int8_t v[Fetch::kBatch];
+                uint16_t pos[Fetch::kBatch];
 #pragma unroll
-            for (int u = 0; u < Fetch::kBatch; u++) {
-                const int i = i0 + 64 * u;
-                if (i < code.n_punct) { v[u] = fetch(cw, i); pos[u] = code.mother_pos[i]; }
+                for (int u = 0; u < Fetch::kBatch; u++) {
+                    const int i = i0 + 64 * u;
+                    if (i < code.n_punct) { v[u] = fetch(cw, i); pos[u] = code.mother_pos[i]; }
+                }
+#pragma unroll
+                for (int u = 0; u < Fetch::kBatch; u++)
+                    if (i0 + 64 * u < code.n_punct) mother[pos[u]] = v[u];
             }
-#pragma unroll
-            for (int u = 0; u < Fetch::kBatch; u++)
-                if (i0 + 64 * u < code.n_punct) mother[pos[u]] = v[u];
+        } else {
+            for (int i = lane; i < code.n_punct; i += 64) mother[code.mother_pos[i]] = fetch(cw, i);
         }
-    } else {
-        for (int i = lane; i < code.n_punct; i += 64) mother[code.mother_pos[i]] = fetch(cw, i);
     }
     __syncthreads();
 
