@@ -14,6 +14,11 @@
  *   - `_dev` entry points take DEVICE pointers and a hipStream_t passed as void*
  *     (NULL = the context's own stream); they only enqueue work.  The variants
  *     without `_dev` take HOST pointers, copy, run and synchronise.
+ *   - the context's own stream is NON-BLOCKING (hipStreamNonBlocking): it is not
+ *     ordered behind the null stream or any other.  Device buffers handed to a
+ *     `_dev` call with stream == NULL must already hold their data (and no fill of
+ *     an output buffer may still be running); a caller that produces them on a
+ *     stream of its own passes THAT stream.
  *   - the caller owns every buffer; a context is thread-compatible (one caller
  *     at a time per context), contexts are independent.
  *   - work enqueued through ONE context must be stream-ordered: the entry points

@@ -47,7 +47,36 @@ def make_ctx(lane_mode=None, max_frames=64, ofdm_symbol_runs=0, unfused=False):
     flags = {None: 0, 0: dabgpu.FLAG_VITERBI_WAVE, 1: dabgpu.FLAG_VITERBI_LANE}[lane_mode]
     if unfused:
         flags |= dabgpu.FLAG_LANE_UNFUSED
-    return dabgpu.Context(device=0, max_frames=max_frames, flags=flags, ofdm_symbol_runs=ofdm_symbol_runs)
+    return _ordered_context()(device=0, max_frames=max_frames, flags=flags, ofdm_symbol_runs=ofdm_symbol_runs)
+
+
+_ORDERED = None
+
+
+def _ordered_context():
+    """dabgpu.Context whose device-pointer calls first wait for torch's stream.  The library's own stream is
+    non-blocking: a tensor a test has just created (its zero-fill, its random numbers) is written on torch's stream and
+    nothing orders a `_dev` call behind it.  Small test tensors are done long before Python gets to the call -- but that
+    is luck, and a large one loses the race (tools/decoder_fuzz.py did)."""
+    global _ORDERED
+    if _ORDERED is None:
+        import sys
+        import dabgpu
+
+        class OrderedContext(dabgpu.Context):
+            def __getattribute__(self, name):
+                attr = super().__getattribute__(name)
+                if name.endswith("_dev") and callable(attr):
+                    torch = sys.modules.get("torch")
+                    if torch is not None and torch.cuda.is_available():
+                        def ordered(*a, **kw):
+                            torch.cuda.synchronize()
+                            return attr(*a, **kw)
+                        return ordered
+                return attr
+
+        _ORDERED = OrderedContext
+    return _ORDERED
 
 
 @pytest.fixture(scope="session", params=["auto", "lane"])
