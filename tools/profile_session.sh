@@ -22,3 +22,4 @@ timeout 900 python3 tools/alloc_stress.py 300 100 > $o/alloc_stress.txt 2>&1; ta
 python3 tools/frame_latency.py > $o/frame_latency.txt 2>&1; tail -n 3 $o/frame_latency.txt
 python3 tools/loop_gate_table.py 4 > $o/loop_gate.txt 2>&1; tail -n 8 $o/loop_gate.txt
 python3 tools/single_time.py 1 4 64 256 1024 > $o/single_time.txt 2>&1; cat $o/single_time.txt     # one ensemble: each call of the step, per batch size
+python3 tools/decoder_fuzz.py 400 1024 > $o/decoder_fuzz.txt 2>&1; tail -n 1 $o/decoder_fuzz.txt       # the two decoders against each other (and the oracle)
