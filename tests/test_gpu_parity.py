@@ -220,6 +220,24 @@ def test_viterbi_bit_exact_random_batch(ctx):
         assert (got[i] == np.packbits(O.viterbi(O.depuncture(cw[i], mask)))).all(), i
 
 
+def test_viterbi_is_maximum_likelihood_by_exhaustive_search(ctx):
+    """16 information bits + 6 tail bits through dabgpu_viterbi: each output reaches the largest correlation any of the
+    65 536 codewords reaches with its input (noise; half erased; small integers full of ties) -- and equals the oracle's."""
+    k = 16
+    msgs = ((np.arange(1 << k)[:, None] >> np.arange(k - 1, -1, -1)) & 1).astype(np.uint8)
+    code = (np.stack([O.conv_encode(m) for m in msgs]).astype(np.int8) * 2 - 1)       # [65536][88], +-1
+    rng = np.random.default_rng(12)
+    n = 48
+    soft = rng.integers(-127, 128, (n, code.shape[1])).astype(np.int8)
+    soft[1::3][rng.random(soft[1::3].shape) < 0.5] = 0
+    soft[2::3] = rng.integers(-2, 3, soft[2::3].shape).astype(np.int8)
+    out = ctx.viterbi(soft, np.ones(code.shape[1], np.uint8))                          # [n][2] bytes, MSB first
+    corr = soft.astype(np.int32) @ code.T.astype(np.int32)
+    for i in range(n):
+        assert (np.unpackbits(out[i]) == O.viterbi(soft[i])).all(), i
+        assert corr[i, int(out[i, 0]) << 8 | int(out[i, 1])] == corr[i].max(), i
+
+
 def test_viterbi_unpunctured_mother_code(ctx):
     rng = np.random.default_rng(6)
     nsteps = 6 + 64

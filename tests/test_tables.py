@@ -82,6 +82,10 @@ def test_crc16():
     for _ in range(10):
         d = rng.integers(0, 256, 30, dtype=np.uint8)
         assert O.crc16(d) == synth.crc16(d)
+        # ... and the interpreter's own CCITT CRC (binascii.crc_hqx: x^16 + x^12 + x^5 + 1, MSB first), started from
+        # all ones and complemented as EN 300 401 5.2.1 asks: an implementation none of this repository's authors wrote
+        import binascii
+        assert O.crc16(d) == binascii.crc_hqx(d.tobytes(), 0xFFFF) ^ 0xFFFF
 
 
 def test_conv_code_generators():
@@ -94,6 +98,26 @@ def test_conv_code_generators():
     # impulse response = generator taps, MSB (current bit) first: 133,171,145,133 octal
     for p, g in enumerate((0o133, 0o171, 0o145, 0o133)):
         assert int("".join(map(str, imp[:, p])), 2) == g
+
+
+def test_viterbi_is_maximum_likelihood_by_exhaustive_search():
+    """12 information bits + 6 tail bits: the decoder's output must reach the LARGEST correlation any of the 4096
+    codewords reaches with the received soft bits (+127 = 1) -- on noise, with erasures, with small integers (ties: the
+    metric is compared, not the bits).  A property every exact soft-decision Viterbi shares, whoever wrote it."""
+    k = 12
+    msgs = ((np.arange(1 << k)[:, None] >> np.arange(k - 1, -1, -1)) & 1).astype(np.uint8)
+    code = np.stack([O.conv_encode(m) for m in msgs]).astype(np.int32) * 2 - 1          # [4096][4*(k+6)], +-1
+    rng = np.random.default_rng(11)
+    for trial in range(40):
+        soft = rng.integers(-127, 128, code.shape[1]).astype(np.int8)
+        if trial % 3 == 1:
+            soft[rng.random(soft.size) < 0.5] = 0                                        # punctured-like erasures
+        if trial % 3 == 2:
+            soft = rng.integers(-2, 3, code.shape[1]).astype(np.int8)                    # ties everywhere
+        corr = code @ soft.astype(np.int32)
+        got = O.viterbi(soft)
+        idx = int("".join(map(str, got)), 2)
+        assert corr[idx] == corr.max(), trial
 
 
 def test_libdabgpu_tables_match(built):
