@@ -30,6 +30,66 @@ def test_rs_and_firecode_agree_with_builder():
     assert O.rs_decode(e)[1] == -1 or not (O.rs_decode(e)[0] == cw).all()     # beyond t=5: flagged or miscorrected
 
 
+def test_rs_codewords_have_zero_syndromes_from_the_definition():
+    """ETSI TS 102 563 clause 6: RS(120,110) shortened from RS(255,245) over GF(2^8) with P(x) = x^8+x^4+x^3+x^2+1 and
+    generator prod_{i=0..9} (x + alpha^i).  Straight from that definition (bitwise field multiplication, no table shared
+    with the oracle or the builder): every encoded word, read as a polynomial with its first byte as the highest power,
+    vanishes at alpha^0 .. alpha^9; a word with one byte changed does not."""
+    def gmul(a, b):
+        r = 0
+        while b:
+            if b & 1:
+                r ^= a
+            a <<= 1
+            if a & 0x100:
+                a ^= 0x11D
+            b >>= 1
+        return r
+    def evaluate(word, x):
+        acc = 0
+        for byte in word:                                        # Horner, highest power first
+            acc = gmul(acc, x) ^ int(byte)
+        return acc
+    roots, a = [], 1
+    for _ in range(10):
+        roots.append(a)
+        a = gmul(a, 2)
+    rng = np.random.default_rng(5)
+    for _ in range(4):
+        d = rng.integers(0, 256, 110, dtype=np.uint8)
+        cw = np.concatenate([d, O.rs_encode(d)])
+        assert all(evaluate(cw, r) == 0 for r in roots)
+        cw[int(rng.integers(0, 120))] ^= 0x5A
+        assert any(evaluate(cw, r) != 0 for r in roots)
+
+
+def test_firecode_is_the_remainder_by_its_generator():
+    """TS 102 563 clause 5.2: the header's 16-bit Fire code word is computed over the 9 bytes that follow it with
+    G(x) = (x^11 + 1)(x^5 + x^3 + x^2 + x + 1) = x^16+x^14+x^13+x^12+x^11+x^5+x^3+x^2+x+1, register started at zero:
+    plain polynomial division over GF(2), written out bit by bit."""
+    G = (1 << 16) | (1 << 14) | (1 << 13) | (1 << 12) | (1 << 11) | (1 << 5) | (1 << 3) | (1 << 2) | (1 << 1) | 1
+    # (x^11 + 1)(x^5 + x^3 + x^2 + x + 1), multiplied out here rather than trusted
+    a, b, prod = (1 << 11) | 1, 0b101111, 0
+    for i in range(12):
+        if (a >> i) & 1:
+            prod ^= b << i
+    assert prod == G
+    rng = np.random.default_rng(6)
+    for _ in range(8):
+        d = rng.integers(0, 256, 9, dtype=np.uint8)
+        rem = 0
+        for byte in d:
+            for bit in range(7, -1, -1):
+                rem = (rem << 1) | ((int(byte) >> bit) & 1)
+                if rem & (1 << 16):
+                    rem ^= G
+        for _ in range(16):                                      # the message times x^16
+            rem <<= 1
+            if rem & (1 << 16):
+                rem ^= G
+        assert O.firecode(d) == rem
+
+
 @pytest.mark.parametrize("bitrate,dac_rate,sbr", CASES)
 def test_oracle_superframe(bitrate, dac_rate, sbr):
     rng = np.random.default_rng(bitrate)
