@@ -473,13 +473,22 @@ __device__ __forceinline__ void rot_decode(const Fetch &fetch, const CodeTables 
     }
 }
 
+// Workgroup b of `total` runs on XCD b % 8; this gives it the index whose neighbours (index +- 1) run on the same XCD.
+__device__ __forceinline__ int same_xcd(int b, int total) {
+    const int per = (total + 7) >> 3, x = b & 7, r = b >> 3;
+    const int full = total - (per - 1) * 8;               // XCDs that take `per` indices (the others per - 1)
+    return x < full ? x * per + r : full * per + (x - full) * (per - 1) + r;
+}
+
 template <class Fetch, Tail TAIL>
 __global__ __launch_bounds__(WGV) void viterbi_rot_kernel(Fetch fetch, CodeTables code, int n_codewords,
                                                           uint8_t *out, uint8_t *crc_ok, int lds_per_wave) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int cw_raw = __builtin_amdgcn_readfirstlane(blockIdx.x * int(blockDim.x >> 6) + wave);   // wave-uniform
+    // consecutive workgroups' codewords to the same XCD (see viterbi_rot_grouped_kernel)
+    const int wg = same_xcd(int(blockIdx.x), int(gridDim.x));
+    const int cw_raw = __builtin_amdgcn_readfirstlane(wg * int(blockDim.x >> 6) + wave);           // wave-uniform
     const bool active = cw_raw < n_codewords;
     rot_decode<Fetch, TAIL>(fetch, code, active ? cw_raw : n_codewords - 1, active, out, crc_ok,
                             smem + size_t(wave) * lds_per_wave, lane);
@@ -509,11 +518,6 @@ __global__ __launch_bounds__(64) void viterbi_rot_grouped_kernel(const WaveEntry
     // consecutive codewords to the same XCD (workgroup b runs on XCD b % 8): the sixteen CIFs a sub-channel codeword is
     // gathered from are the next codeword's too, and each XCD has an L2 of its own.  The FIC's (shorter) codewords and
     // the sub-channels' are spread separately, so that every XCD gets its share of both.
-    auto same_xcd = [](int b, int total) {
-        const int per = (total + 7) >> 3, x = b & 7, r = b >> 3;
-        const int full = total - (per - 1) * 8;               // XCDs that take `per` codewords (the others per - 1)
-        return x < full ? x * per + r : full * per + (x - full) * (per - 1) + r;
-    };
     int cw = blockIdx.x;
     if (cw < pack.n_fic) {            // one frame at a time the FIC's four codewords ride along with the sub-channels'
         rot_decode<FetchFic, Tail::kFic>(pack.fic_fetch, pack.fic_code, same_xcd(cw, pack.n_fic), true, pack.fib, pack.crc_ok, smem,
