@@ -291,6 +291,21 @@ def single_ensemble_leg(B):
         if scs:
             msc_h = msc.cpu().numpy()
             row["msc_bit_exact"] = all(bool((msc_h[0, t] == e.msc_bytes[(t - 15) % 16]).all()) for t in range(F * 4))
+        # device time of the two calls of a step (events on the stream; after the checks: these extra calls move the loop
+        # and the de-interleaver on)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        t_fe = t_dec = 0.0
+        for k in range(steps):
+            ev[0].record()
+            c1.ofdm_demod_streams_dev(B.d_iq, L, 1, F, B.BETA, soft.data_ptr(), None, None, stream)
+            ev[1].record()
+            c1.decode_frames_dev(soft.data_ptr(), dabgpu.NB_FRAME_BITS, 1, F, fib.data_ptr(), crc.data_ptr(), scs,
+                                 [hist[k & 1].data_ptr()] if scs else [], [hist[(k & 1) ^ 1].data_ptr()] if scs else [],
+                                 [msc.data_ptr()] if scs else [], stream)
+            ev[2].record()
+            torch.cuda.synchronize()
+            t_fe += ev[0].elapsed_time(ev[1]); t_dec += ev[1].elapsed_time(ev[2])
+        row["front_end_call_ms"], row["decode_call_ms"] = t_fe / steps, t_dec / steps
         res[name] = row
     c1.close()
 

@@ -221,6 +221,8 @@ def test_bench_line_keeps_the_contract():
     se = j["single_ensemble"]
     assert se["ofdm_fic"]["fic_bit_exact"] is True and se["ofdm_fic"]["value"] > 0 and se["ofdm_fic"]["frames_per_step"] == 16
     assert se["ofdm_fic_msc64"]["fic_bit_exact"] is True and se["ofdm_fic_msc64"]["msc_bit_exact"] is True
+    for row in (se["ofdm_fic"], se["ofdm_fic_msc64"]):         # device time of the step's two calls
+        assert 0 < row["front_end_call_ms"] and 0 < row["decode_call_ms"]
     hf = se["host_fed_per_frame"]
     assert hf["every_frame_locked"] is True and hf["fic_bit_exact"] is True and hf["msc_bit_exact"] is True
     assert hf["frame_ms"] > 0 and abs(hf["frame_ms"] - hf["ofdm_demod_stream_frame_ms"] - hf["decode_stream_frames_ms"]) < 1e-9
