@@ -570,6 +570,12 @@ static_assert(offsetof(dabgpu_stream_state, next_frame_start) == offsetof(dabk::
 // one, so that the host-side accessors can wait for exactly that work.
 }  // extern "C"
 namespace dabapi {
+void *device_alias_of_pinned(const void *host) {
+    hipPointerAttribute_t at{};
+    if (!host || hipPointerGetAttributes(&at, host) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return at.type == hipMemoryTypeHost ? at.devicePointer : nullptr;
+}
+
 int note_state_use(dabgpu_ctx *ctx, hipStream_t s) {
     if (!ctx->ev_states && hipEventCreateWithFlags(&ctx->ev_states, hipEventDisableTiming) != hipSuccess) return DABGPU_ERR_HIP;
     HIP_TRY(hipEventRecord(ctx->ev_states, s));
@@ -1144,7 +1150,16 @@ int dabgpu_ofdm_demod_stream_frame(dabgpu_ctx *ctx, int stream_index, const floa
     if ((rc = wait_state_use(ctx))) return rc;
     hipStream_t s = ctx->stream;
     char *res = static_cast<char *>(d_res);
-    HIP_TRY(hipMemcpyAsync(d_iq, iq, nb_iq, hipMemcpyHostToDevice, s));                    // one upload
+    // one upload: by a kernel when the frame lies in page-locked memory the device can address (the host mirror's does)
+    static_assert(nb_iq % 16 == 0 && NB_FRAME_BITS % 16 == 0, "whole 16-byte words");
+    void *iq_alias = device_alias_of_pinned(iq), *soft_alias = device_alias_of_pinned(soft);
+    if ((reinterpret_cast<uintptr_t>(iq_alias) | reinterpret_cast<uintptr_t>(soft_alias)) & 15) iq_alias = soft_alias = nullptr;
+    if (iq_alias) {
+        const dabk::CopyPiece up{d_iq, iq_alias, nb_iq};
+        HIP_TRY(dabk::launch_copy_pieces(&up, 1, s));
+    } else {
+        HIP_TRY(hipMemcpyAsync(d_iq, iq, nb_iq, hipMemcpyHostToDevice, s));
+    }
     dabk::StreamState *st = ctx->d_states + stream_index;
     rc = tracked_launches(ctx, st, d_iq, nb_iq / sizeof(float2), 1, int64_t(nb_iq / sizeof(float2)), 1, 0, c, 1, acquiring ? 1 : 0,
                           reinterpret_cast<int8_t *>(res), d_cyc, d_dq, reinterpret_cast<dabgpu_acquired_frame *>(res + off_fr),
@@ -1152,14 +1167,19 @@ int dabgpu_ofdm_demod_stream_frame(dabgpu_ctx *ctx, int stream_index, const floa
     if (rc) return rc;
     // one download, written by a kernel right behind the others: soft bits, frame and sync records, then the state
     static_assert(sizeof(dabk::StreamState) % 16 == 0, "the state goes out in 16-byte words");
+    // (the soft bits straight into the caller's buffer when that is page-locked too: no copy by the CPU afterwards)
     void *h_dev = nullptr;
     HIP_TRY(hipHostGetDevicePointer(&h_dev, ctx->h_bounce, 0));
-    HIP_TRY(dabk::launch_results_to_host(h_dev, d_res, off_st, st, off_st, sizeof(dabk::StreamState), s));
+    char *hd = static_cast<char *>(h_dev);
+    const dabk::CopyPiece down[3] = {{soft_alias ? soft_alias : static_cast<void *>(hd), d_res, size_t(NB_FRAME_BITS)},
+                                     {hd + off_fr, res + off_fr, off_st - off_fr},
+                                     {hd + off_st, st, sizeof(dabk::StreamState)}};
+    HIP_TRY(dabk::launch_copy_pieces(down, 3, s));
     if (dqpsk) HIP_TRY(hipMemcpyAsync(dqpsk, d_dq, nb_dq, hipMemcpyDeviceToHost, s));       // (+ the constellation, when asked for)
     HIP_TRY(hipStreamSynchronize(s));                                                    // one synchronisation
     ctx->ev_states_pending = false;
     const char *hb = static_cast<const char *>(ctx->h_bounce);
-    std::memcpy(soft, hb, NB_FRAME_BITS);
+    if (!soft_alias) std::memcpy(soft, hb, NB_FRAME_BITS);
     dabgpu_acquired_frame fr;
     std::memcpy(&fr, hb + off_fr, sizeof(fr));
     std::memcpy(&result->sync, hb + off_sy, sizeof(result->sync));

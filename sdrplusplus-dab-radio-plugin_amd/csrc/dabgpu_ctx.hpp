@@ -161,6 +161,9 @@ inline hipStream_t pick_stream(dabgpu_ctx *ctx, void *stream) {
 int stage(dabgpu_ctx *ctx, int slot, size_t bytes, void **out);
 int get_code(dabgpu_ctx *ctx, dab::PunctureProfile &&prof, DeviceCode **out);
 void free_device_code(DeviceCode &dc);
+// the address the device reaches page-locked host memory under (hipHostMalloc / hipHostRegister: dabgpu_host_alloc), or
+// nullptr for any other pointer
+void *device_alias_of_pinned(const void *host);
 int note_state_use(dabgpu_ctx *ctx, hipStream_t s);
 int wait_state_use(dabgpu_ctx *ctx);
 void stats_of(const dabk::StreamState &st, dabgpu_stats *out);

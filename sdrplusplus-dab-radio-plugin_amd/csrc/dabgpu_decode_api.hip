@@ -531,7 +531,14 @@ static int decode_stream_frames_body(dabgpu_ctx *ctx, const int8_t *soft, size_t
         if (hipHostMalloc(&ctx->h_bounce, res_total, hipHostMallocDefault) != hipSuccess) return DABGPU_ERR_NOMEM;
         ctx->h_bounce_bytes = res_total;
     }
-    HIP_TRY(hipMemcpyAsync(d_soft, soft, nb_soft, hipMemcpyHostToDevice, s));            // one upload
+    // one upload (by a kernel when the soft bits lie in page-locked memory the device can address)
+    void *soft_alias = (nb_soft & 15) ? nullptr : device_alias_of_pinned(soft);
+    if (soft_alias && !(reinterpret_cast<uintptr_t>(soft_alias) & 15)) {
+        const dabk::CopyPiece up{d_soft, soft_alias, nb_soft};
+        HIP_TRY(dabk::launch_copy_pieces(&up, 1, s));
+    } else {
+        HIP_TRY(hipMemcpyAsync(d_soft, soft, nb_soft, hipMemcpyHostToDevice, s));
+    }
     char *res = static_cast<char *>(d_res);
     std::vector<uint8_t *> p_out(n_subchannels, nullptr);
     for (int i = 0; i < n_subchannels; i++) p_out[i] = reinterpret_cast<uint8_t *>(res + out_off[i]);

@@ -79,11 +79,16 @@ hipError_t launch_fft_symbols(const OfdmTables &t, const OfdmArgs &a, int parts,
 // is below thr_null_start times the average so far.
 // noise-like floats in [0.5, 1) with random signs: timing probes must not run on zeros (they move ~6 % faster)
 hipError_t launch_fill_noise(void *p, size_t bytes, hipStream_t s);
-// One result block to page-locked host memory, written by a kernel (the device stores over the link): behind the
-// kernels of a one-frame call this starts at once, where a copy-engine download starts ~9 us later.  `n_main` bytes of
-// `d_main`, then `n_tail` bytes of `d_tail` at `tail_off` (multiples of 16; pointers 16-byte aligned).
-hipError_t launch_results_to_host(void *h_dst, const void *d_main, size_t n_main, const void *d_tail, size_t tail_off, size_t n_tail,
-                                  hipStream_t s);
+// Copies done by a kernel instead of the copy engine, for page-locked host memory the device can address: behind (or in
+// front of) the kernels of a one-frame call such a copy starts at once, where an engine copy costs ~8 us of hand-over on
+// either side.  Up to three pieces per launch; sizes multiples of 16, pointers 16-byte aligned (hipErrorInvalidValue
+// otherwise); a piece of 0 bytes is skipped.
+struct CopyPiece {
+    void *dst;
+    const void *src;
+    size_t bytes;
+};
+hipError_t launch_copy_pieces(const CopyPiece *pieces, int n, hipStream_t s);
 // reads `in` and writes `out` at the same time (streaming, both whole): the launch is slower when the two buffers
 // share an HBM domain -- what the placement helpers time
 hipError_t launch_placement_probe(const void *in, size_t in_bytes, void *out, size_t out_bytes, hipStream_t s);

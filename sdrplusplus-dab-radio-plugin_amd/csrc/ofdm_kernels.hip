@@ -712,23 +712,37 @@ hipError_t launch_placement_probe(const void *in, size_t in_bytes, void *out, si
 }
 
 namespace {
-__global__ __launch_bounds__(256) void results_to_host_kernel(uint4 *dst, const uint4 *main_src, unsigned n_main, const uint4 *tail_src,
-                                                              unsigned tail_off, unsigned n_tail) {
-    const unsigned i = blockIdx.x * 256u + threadIdx.x;
-    if (i < n_main) dst[i] = main_src[i];
-    else if (i - n_main < n_tail) dst[tail_off + (i - n_main)] = tail_src[i - n_main];
+struct CopyPieces16 {
+    uint4 *dst[3];
+    const uint4 *src[3];
+    unsigned n[3];                                             // in 16-byte words
+};
+__global__ __launch_bounds__(256) void copy_pieces_kernel(CopyPieces16 p) {
+    unsigned i = blockIdx.x * 256u + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        if (i < p.n[k]) { p.dst[k][i] = p.src[k][i]; return; }
+        i -= p.n[k];
+    }
 }
 }  // namespace
 
-hipError_t launch_results_to_host(void *h_dst, const void *d_main, size_t n_main, const void *d_tail, size_t tail_off, size_t n_tail,
-                                  hipStream_t s) {
-    if (((n_main | n_tail | tail_off) & 15) || ((reinterpret_cast<uintptr_t>(h_dst) | reinterpret_cast<uintptr_t>(d_main) |
-                                                 reinterpret_cast<uintptr_t>(d_tail)) & 15))
-        return hipErrorInvalidValue;
-    const unsigned nm = unsigned(n_main / 16), nt = unsigned(n_tail / 16);
-    if (nm + nt == 0) return hipSuccess;
-    hipLaunchKernelGGL(results_to_host_kernel, dim3((nm + nt + 255) / 256), dim3(256), 0, s, static_cast<uint4 *>(h_dst),
-                       static_cast<const uint4 *>(d_main), nm, static_cast<const uint4 *>(d_tail), unsigned(tail_off / 16), nt);
+hipError_t launch_copy_pieces(const CopyPiece *pieces, int n, hipStream_t s) {
+    if (n < 0 || n > 3) return hipErrorInvalidValue;
+    CopyPieces16 p{};
+    unsigned total = 0;
+    for (int k = 0; k < n; k++) {
+        const CopyPiece &c = pieces[k];
+        if (c.bytes == 0) continue;
+        if ((c.bytes & 15) || ((reinterpret_cast<uintptr_t>(c.dst) | reinterpret_cast<uintptr_t>(c.src)) & 15) || (c.bytes >> 4) > 0x7fffffffu)
+            return hipErrorInvalidValue;
+        p.dst[k] = static_cast<uint4 *>(c.dst);
+        p.src[k] = static_cast<const uint4 *>(c.src);
+        p.n[k] = unsigned(c.bytes >> 4);
+        total += p.n[k];
+    }
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(copy_pieces_kernel, dim3((total + 255) / 256), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 
