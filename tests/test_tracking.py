@@ -665,3 +665,50 @@ def test_gpu_frame_call_equals_the_three_call_sequence_and_the_oracle(tctx):
     _, res, _ = tctx.ofdm_demod_stream_frame(frame, 0, acquiring=False, cfg=cfg2)
     assert res.flags == 3 and res.stats.signal_average == pytest.approx(1.5 * before, rel=0.05)
     other.close()
+
+
+@pytest.mark.gpu
+def test_gpu_one_frame_calls_from_pageable_and_page_locked_buffers(tctx):
+    """dabgpu_ofdm_demod_stream_frame / dabgpu_decode_stream_frames copy by kernel when the caller's buffers are page-locked
+    and 16-byte aligned (the host mirror's are) and through the copy engine otherwise: pageable numpy arrays, page-locked
+    arrays, and page-locked arrays at an odd offset give the same soft bits, results, FIBs and sub-channel bytes."""
+    import ctypes as C
+    import dabgpu
+    from conftest import make_ctx
+    e = synth.Ensemble(seed=31, n_frames=4)
+    iq = synth.channel(e.iq().ravel(), snr_db=16.0, cfo=0.3 / 2048.0, rng=np.random.default_rng(31))
+    M = 64
+    cfg = dabgpu.track_cfg(timing_margin=M)
+    sc = dabgpu.subchannel(e.start_cu, 64, level=3)
+    lib = dabgpu.lib()
+    p_iq = dabgpu.PinnedArray((SYMS + 4,), np.complex64)           # + 4: room for the 8-byte (mis-aligning) offset below
+    p_soft = dabgpu.PinnedArray((dabgpu.NB_FRAME_BITS + 16,), np.int8)
+    outs = {}
+    for kind in ("pageable", "pinned", "pinned_odd"):
+        a, b = make_ctx(None, 1), make_ctx(None, 1)
+        a.streams_reset(1)
+        got = []
+        for f in range(4):
+            frame = np.ascontiguousarray(iq[f * L + NULL - M:f * L + NULL - M + SYMS])
+            if kind == "pageable":
+                src, soft = frame, np.zeros(dabgpu.NB_FRAME_BITS, np.int8)
+            else:
+                o = 0 if kind == "pinned" else 1                    # one complex sample = 8 bytes off; soft bits 1 byte off
+                src = p_iq.array[o:o + SYMS]; src[:] = frame
+                soft = p_soft.array[o:o + dabgpu.NB_FRAME_BITS]; soft[:] = 0
+            res = dabgpu.FrameResult()
+            assert lib.dabgpu_ofdm_demod_stream_frame(a._h, 0, src.ctypes.data, 1 if f == 0 else 0, C.byref(cfg), soft.ctypes.data,
+                                                      None, C.byref(res)) == 0
+            fib = np.zeros((1, 12, 32), np.uint8); ok = np.zeros((1, 12), np.uint8); out = np.zeros((4, 192), np.uint8)
+            arr = (dabgpu.Subchannel * 1)(sc); ptrs = (C.c_void_p * 1)(out.ctypes.data)
+            assert lib.dabgpu_decode_stream_frames(b._h, soft.ctypes.data, dabgpu.NB_FRAME_BITS, 1, fib.ctypes.data, ok.ctypes.data,
+                                                   arr, 1, ptrs) == 0
+            got.append((soft.copy(), res.flags, res.sync.time_offset, res.stats.fine_freq_offset, fib.copy(), ok.copy(), out.copy()))
+        outs[kind] = got
+        a.close(); b.close()
+    for kind in ("pinned", "pinned_odd"):
+        for f in range(4):
+            for x, y in zip(outs["pageable"][f], outs[kind][f]):
+                assert np.array_equal(np.asarray(x), np.asarray(y)), (kind, f)
+    assert all(g[5].all() for g in outs["pinned"]) and (outs["pinned"][2][4][0] == e.fibs[2]).all()
+    p_iq.close(); p_soft.close()
