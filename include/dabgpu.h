@@ -556,7 +556,9 @@ int dabgpu_ofdm_demod_tracked_dev(dabgpu_ctx *ctx, const void *d_iq, size_t stre
  * device: synchronisation on the PRS, the coarse-offset update, demodulation with the stream's offsets, fine loop,
  * counters, level; one download of {soft bits, sync result, statistics}; one synchronisation.
  *   iq         76 * 2552 cf32 as the caller assembled them: iq[0] is its guess of the first PRS prefix sample,
- *              `cfg->timing_margin` samples early
+ *              `cfg->timing_margin` samples early.  Any host memory; page-locked buffers (dabgpu_host_alloc) aligned to
+ *              16 bytes -- `iq` and `soft` both -- are read / written by kernels in line with the others (no copy-engine
+ *              hand-over, no copy by the CPU afterwards): ~10 % less time per call
  *   acquiring  != 0: first frame after a null-symbol detection -- the stream's fine offset is set from this PRS's own
  *              cyclic prefix (so that already this frame is demodulated with it) and the whole-carrier offset found on
  *              this PRS is STORED as its coarse offset (cfg->max_coarse_carriers > 0); 0: a residual of k carriers
