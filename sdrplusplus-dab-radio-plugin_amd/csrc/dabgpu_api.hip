@@ -1152,6 +1152,9 @@ int dabgpu_ofdm_demod_stream_frame(dabgpu_ctx *ctx, int stream_index, const floa
     char *res = static_cast<char *>(d_res);
     // one upload: by a kernel when the frame lies in page-locked memory the device can address (the host mirror's does)
     static_assert(nb_iq % 16 == 0 && NB_FRAME_BITS % 16 == 0, "whole 16-byte words");
+    // (every query first: once the upload is enqueued the host only enqueues, and stays ahead of the device)
+    void *h_dev = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&h_dev, ctx->h_bounce, 0));
     void *iq_alias = device_alias_of_pinned(iq), *soft_alias = device_alias_of_pinned(soft);
     if ((reinterpret_cast<uintptr_t>(iq_alias) | reinterpret_cast<uintptr_t>(soft_alias)) & 15) iq_alias = soft_alias = nullptr;
     if (iq_alias) {
@@ -1168,8 +1171,6 @@ int dabgpu_ofdm_demod_stream_frame(dabgpu_ctx *ctx, int stream_index, const floa
     // one download, written by a kernel right behind the others: soft bits, frame and sync records, then the state
     static_assert(sizeof(dabk::StreamState) % 16 == 0, "the state goes out in 16-byte words");
     // (the soft bits straight into the caller's buffer when that is page-locked too: no copy by the CPU afterwards)
-    void *h_dev = nullptr;
-    HIP_TRY(hipHostGetDevicePointer(&h_dev, ctx->h_bounce, 0));
     char *hd = static_cast<char *>(h_dev);
     const dabk::CopyPiece down[3] = {{soft_alias ? soft_alias : static_cast<void *>(hd), d_res, size_t(NB_FRAME_BITS)},
                                      {hd + off_fr, res + off_fr, off_st - off_fr},
