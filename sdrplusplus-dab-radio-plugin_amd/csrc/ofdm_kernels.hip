@@ -522,8 +522,6 @@ __global__ __launch_bounds__(SU_THREADS) void stream_update_kernel(StreamState *
     __shared__ float red[2][SU_THREADS / 64];
     __shared__ double red_dd[2][SU_THREADS / 64];
     const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    StreamState st{};
-    if (tid == 0) st = state[s];                                 // (asked for first: the only thread that needs it waits last)
     const float2 *c = cyc + size_t(s) * frames_per_stream * NB_FRAME_SYMBOLS;
     const int n = frames_per_stream * NB_FRAME_SYMBOLS;
     float acc = 0.f;
@@ -578,6 +576,7 @@ __global__ __launch_bounds__(SU_THREADS) void stream_update_kernel(StreamState *
         acc = 0.f; l1 = 0.f;
         for (int w = 0; w < SU_THREADS / 64; w++) { acc += red[0][w]; l1 += red[1][w]; }
         l1 *= 1.0f / 4096.0f;
+        StreamState st = state[s];
         float err = acc / float(n) * (1.0f / (6.283185307179586f * float(NB_FFT)));
         if (dd) {
             sx = 0.0; sy = 0.0;
