@@ -176,10 +176,11 @@ __global__ __launch_bounds__(WGV) void viterbi_wave_kernel(Fetch fetch, CodeTabl
 // v_permlane16/32_swap for 16,32 -- all VALU latency, no LDS crossbar.  Branch
 // metrics are one v_dot4_i32_i8 of a per-lane sign vector with the step's soft word
 // (an LDS broadcast read, one phase cycle ahead), computed off the chain
-// metric -> exchange -> subtract -> max.  The 64 survivor bits of a step are one
-// ballot word, stored as one 8-byte LDS slot per step; the traceback runs on all
-// lanes at once, every lane its own segment of steps in the lane domain (the state
-// update is "replace bit q of the lane index"), and checks itself: see rot_decode.
+// metric -> exchange -> subtract -> max.  Each lane shifts its own survivor bit
+// into a register straight from VCC; every 32 steps the 64 words are transposed
+// across the wave into one 8-byte LDS slot per step; the traceback runs on all lanes
+// at once, every lane its own segment of steps in the lane domain (the state update
+// is "flip bit q of the lane index"), and checks itself: see rot_decode.
 // Requires nsteps = 96k + 6, which every DAB codeword satisfies (FIC 768+6,
 // EEP 192n+6); other lengths use kernel 1.
 // ============================================================================
@@ -210,12 +211,6 @@ struct RotTables {
     int thr[6];       // 0 where bit q of the lane is 0, -1 where it is 1 (strict-compare threshold, see rot_step)
 };
 
-// lanes whose bit q is set, q = 0..5
-__device__ __forceinline__ constexpr unsigned long long qmask(int q) {
-    return q == 0 ? 0xAAAAAAAAAAAAAAAAull : q == 1 ? 0xCCCCCCCCCCCCCCCCull : q == 2 ? 0xF0F0F0F0F0F0F0F0ull
-         : q == 3 ? 0xFF00FF00FF00FF00ull : q == 4 ? 0xFFFF0000FFFF0000ull : 0xFFFFFFFF00000000ull;
-}
-
 __device__ __forceinline__ int pack_i8x4(int a, int b, int c, int d) {
     return (a & 0xFF) | ((b & 0xFF) << 8) | ((c & 0xFF) << 16) | ((d & 0xFF) << 24);
 }
@@ -225,32 +220,52 @@ __device__ __forceinline__ int pack_i8x4(int a, int b, int c, int d) {
 //   x = M_self + c, y = M_other - c are the two candidates of the state this lane holds next.
 //   Lanes with bit q clear are the older-bit-0 predecessor themselves: survivor bit = (y > x).
 //   Lanes with bit q set are the older-bit-1 predecessor:               survivor bit = (x > y) = !(y > x - 1).
-//   So one compare against x + threshold (0 / -1) and an XOR with a constant lane mask gives the strict-greater rule
-//   for both.  Returns the 64 survivor bits of the step.
+//   So ONE compare against x + threshold (0 / -1) gives r = survivor bit XOR (bit q of the lane) for both: r says whether
+//   the traceback FLIPS bit q of the lane index when it goes back over this step.  r is shifted into the lane's own
+//   32-step word straight from VCC (v_cmp + v_addc_co: 2.5 cycles on top of the compare for a wave that runs alone;
+//   bringing the step's 64 bits together at once -- v_cmp to an SGPR pair, s_xor, two v_writelane -- cost 13 to 27:
+//   tools/ubench/wave_step_cycles.hip, profiles/r04_wave_step_cycles.txt); the words are transposed 32 steps at a time.
 template <int PH>
-__device__ __forceinline__ unsigned long long rot_step(int lane, int c, int ct, int &metric) {
+__device__ __forceinline__ void rot_step(int lane, int c, int ct, int &metric, unsigned &dec) {
     constexpr int Q = 5 - PH;
     const int other = lane_xchg<(1 << Q)>(metric, lane);
     const int x = metric + c, xt = metric + ct;
     const int y = other - c;
     metric = max(x, y);
-    return __ballot(y > xt) ^ qmask(Q);
+    // (one statement, e32 forms with VCC implicit: the pair the compiler itself emits back to back)
+    asm("v_cmp_gt_i32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(dec) : "v"(y), "v"(xt) : "vcc");
 }
 
-// lane LANE of v = the wave-uniform word s
-template <int LANE>
-__device__ __forceinline__ void write_lane(int &v, int s) {
-    asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(s), "n"(LANE));
+// 32 x 32 bit transpose across each half of the wave: lane a of a half holds row a, bit c = element (a, c); afterwards
+// lane b holds the column b, bit a = element (a, b).  Five rounds of the block-swap transpose (block sizes 16 .. 1): a
+// lane exchanges with the lane 16 / 8 / .. / 1 away (the ACS's own XOR exchanges), rotates what it got by the block
+// size and merges under the round's column mask: three to six instructions a round, once per 32 trellis steps.
+template <int J>
+__device__ __forceinline__ unsigned transpose_round(unsigned x, int lane) {
+    constexpr unsigned M0 = J == 16 ? 0x0000FFFFu : J == 8 ? 0x00FF00FFu : J == 4 ? 0x0F0F0F0Fu : J == 2 ? 0x33333333u : 0x55555555u;
+    const bool upper = (lane & J) != 0;                           // the row index has bit J set: it gives its low blocks away
+    const unsigned p = unsigned(lane_xchg<J>(int(x), lane));
+    const unsigned rot = __builtin_amdgcn_alignbit(p, p, upper ? J : 32 - J);   // upper: p >> J, lower: p << J (the rest is masked)
+    const unsigned keep = upper ? ~M0 : M0;
+    return (x & keep) | (rot & ~keep);
+}
+__device__ __forceinline__ unsigned transpose32(unsigned x, int lane) {
+    x = transpose_round<16>(x, lane);
+    x = transpose_round<8>(x, lane);
+    x = transpose_round<4>(x, lane);
+    x = transpose_round<2>(x, lane);
+    return transpose_round<1>(x, lane);
 }
 
 // The per-wave LDS slab of the rot kernel (host and device agree through this one function).
-//   survivors: one 8-byte slot per trellis step t (bit l = the survivor bit of lane l), at slot t + (t - 6) / seg_steps
+//   survivors: one 8-byte slot per trellis step t (bit l = lane l's r of the step: flip bit q or not), at slot t + (t - 6) / seg_steps
 //              for t >= 6 -- one slot of skew per traceback segment, so that the lanes of the traceback, each reading
 //              its own segment, spread over the LDS banks (segments are 12..48 slots long: unskewed, 8- to 16-way conflicts)
 //   mother:    the depunctured codeword, consumed from a region that starts half-way up the survivors' final extent: a
 //              survivor row is only written after the codeword bytes it overlaps have been read (4 B/step consumed vs
 //              8 B/step produced); the skew slots are added to the offset
-//   out6:      the decoded bits, six per byte;  zero: six all-zero slots (what the traceback reads above the last step)
+//   out6:      the decoded bits, six per byte;  zero: six all-zero slots (what the traceback reads above the last step:
+//              nothing flips)
 struct RotLayout {
     int seg_cycles;       // six-step phase cycles per traceback lane
     int seg_steps;        // = 6 * seg_cycles
@@ -344,16 +359,18 @@ __device__ __forceinline__ void rot_decode(const Fetch &fetch, const CodeTables 
     }
 
     // ---- A9 forward pass ----
-    // The 64 survivor bits of a step are one ballot word; lane j & 31 of `vm` keeps its low half and lane 32 + (j & 31)
-    // its high half until a row of 32 steps goes to the survivor slots.
+    // Every lane collects its own r of 32 steps (bit 31 - k = step k of the row); a row is then transposed across the
+    // wave -- lane b of either half gets the bits of step 31 - b, bit a = lane a of that half -- and goes to the
+    // survivor slots: low half of a step's slot from lanes 0..31, high half from lanes 32..63.
     const unsigned seg_magic = unsigned((0x100000000ull + unsigned(L.seg_steps) - 1) / unsigned(L.seg_steps));
-    auto flush = [&](int row_t0, int vm) {
-        const int t = row_t0 + (lane & 31);
+    auto flush = [&](int row_t0, unsigned row_bits) {
+        const unsigned col = transpose32(row_bits, lane);
+        const int t = row_t0 + 31 - (lane & 31);
         const int skew = t >= 6 ? int(__umulhi(unsigned(t - 6), seg_magic)) : 0;    // (t - 6) / seg_steps, exact below 2^16
-        if (t < nsteps) *reinterpret_cast<int *>(slab + 8 * (t + skew) + 4 * (lane >> 5)) = vm;
+        if (t < nsteps) *reinterpret_cast<unsigned *>(slab + 8 * (t + skew) + 4 * (lane >> 5)) = col;
     };
     int metric = (lane == 0) ? 0 : -VITERBI_INIT_PENALTY;
-    int vm = 0;
+    unsigned dec = 0;
     // the step's four soft bits: one LDS word, the same address in every lane (a broadcast read), fetched one phase
     // cycle ahead of its use
     int wc[6];
@@ -367,10 +384,8 @@ __device__ __forceinline__ void rot_decode(const Fetch &fetch, const CodeTables 
         const int ct##PH = c##PH + T.thr[PH];
 #define DAB_ROT_STEP(PH)                                                                         \
     {                                                                                            \
-        const unsigned long long m = rot_step<PH>(lane, c##PH, ct##PH, metric);                  \
-        write_lane<(j##PH & 31)>(vm, int(unsigned(m)));                                          \
-        write_lane<32 + (j##PH & 31)>(vm, int(unsigned(m >> 32)));                               \
-        if ((j##PH & 31) == 31) flush(c * 96 + j##PH - 31, vm);                                  \
+        rot_step<PH>(lane, c##PH, ct##PH, metric, dec);                                          \
+        if constexpr ((j##PH & 31) == 31) flush(c * 96 + j##PH - 31, dec);                       \
     }
 #define DAB_ROT_CYCLE(I)                                                                         \
     {                                                                                            \
@@ -387,22 +402,22 @@ __device__ __forceinline__ void rot_decode(const Fetch &fetch, const CodeTables 
 #undef DAB_ROT_METRIC
     }
     {   // the six tail steps (zero tail bits): one more phase cycle (its words came with the last cycle above)
+        dec = 0;
 #define DAB_ROT_TAIL(PH)                                                                         \
     {                                                                                            \
         const int cb = __builtin_amdgcn_sdot4(T.tab_cs[PH], wc[PH], 0, false);                   \
-        const unsigned long long m = rot_step<PH>(lane, cb, cb + T.thr[PH], metric);             \
-        write_lane<PH>(vm, int(unsigned(m)));                                                    \
-        write_lane<32 + PH>(vm, int(unsigned(m >> 32)));                                         \
+        rot_step<PH>(lane, cb, cb + T.thr[PH], metric, dec);                                     \
     }
         DAB_ROT_TAIL(0) DAB_ROT_TAIL(1) DAB_ROT_TAIL(2) DAB_ROT_TAIL(3) DAB_ROT_TAIL(4) DAB_ROT_TAIL(5)
 #undef DAB_ROT_TAIL
-        flush(nchunks * 96, vm);                               // (only the six steps below nsteps are written)
+        flush(nchunks * 96, dec << 26);                        // (a row of six steps: only those below nsteps are written)
     }
     __syncthreads();
 
     // ---- traceback in the lane domain, all segments at once ----
-    // End state 0 sits in lane 0 in every layout.  Going back over step t replaces bit q_t of the lane index by the
-    // survivor bit h_t, and h_t is the input bit of step t-6 (it becomes the oldest bit of the earlier state).  After
+    // End state 0 sits in lane 0 in every layout.  Going back over step t flips bit q_t of the lane index l exactly when
+    // bit l of the step's slot says so (r, see rot_step): the bit then holds the survivor bit h_t, and h_t is the input
+    // bit of step t-6 (it becomes the oldest bit of the earlier state).  After
     // the six steps of one phase cycle (q = 0,1,..,5 going backwards) the lane index therefore IS six consecutive
     // decoded bits, earliest in bit 5: out6[g] = the index after the cycle of steps [6g+6, 6g+12).
     // Lane c owns the cycles of steps [6 + S c, 6 + S (c+1)) (S = seg_steps).  It starts ROT_WARM_CYCLES cycles above
@@ -429,8 +444,7 @@ __device__ __forceinline__ void rot_decode(const Fetch &fetch, const CodeTables 
 #pragma unroll
             for (int ph = 5; ph >= 0; ph--) {
                 const int q = 5 - ph;
-                const unsigned h = unsigned(M[ph] >> l) & 1u;
-                l = (l & ~(1 << q)) | int(h << q);
+                l ^= int((unsigned(M[ph] >> l) & 1u) << q);
             }
             if (emit && real) out6[(tb - 6) / 6] = uint8_t(l);
         };
