@@ -11,12 +11,16 @@ and torch.distributed (RCCL) for the barrier / max-reduce.
 Nothing on the GPU side is told the frequency offsets the synthetic channel applied: the front end runs closed loop.  Per
 ensemble the carrier offset is a whole number of carriers (|k| <= 3) plus a fraction (|f| <= 0.4); before the timed region
 the coarse part is found on the first frame's phase reference symbol (dabgpu_sync_prs_dev) and the fine loop settles over
-four untimed calls; during the timed steps every call corrects with the stream's state in HBM and updates it from the
-decision-directed sums the demodulation launch leaves (a small kernel after it, inside the timed region).
+four untimed calls; during the timed steps every call corrects with the stream's state in HBM and updates it from the 76
+cyclic-prefix correlations per frame the demodulation launch leaves (a small kernel after it, inside the timed region):
+THE REFERENCE'S DATA FLOW AND ESTIMATOR (fine_freq_update_beta, /root/reference/src/render_radio_block.cpp:216) -- the
+library's defaults.  `value` and `roofline` are that step.  The same step on the library's own decision-directed estimator
+(opt-in; 17 % fewer bytes: of a frame's prefixes only the PRS's is read) is the `with_decision_directed_loop` leg, copied to
+the top level as `value_own_estimator` / `roofline.frac_own_estimator`.
 
-Everything measured AFTER the timed region -- the same step on the reference's estimator, the sustained leg, the FFT
-stage, BASELINE configs 2 and 3 (one ensemble), the host-fed figures, unaligned captures, the CPU baseline -- lives in
-bench_legs.py and runs on rank 0 of a one-GPU run (`--legs all` forces it elsewhere, `--legs none` skips it).
+Everything measured AFTER the timed region -- that leg, the sustained leg, the FFT stage, BASELINE configs 2 and 3 (one
+ensemble), the host-fed figures, unaligned captures, the CPU baseline -- lives in bench_legs.py and runs on rank 0 of a
+one-GPU run (`--legs all` forces it elsewhere, `--legs none` skips it).
 
 Ensembles shard across GPUs with no data-path collective (weak scaling: 64 per rank; global ensemble ids
 `id % world == rank`).  Prints ONE JSON line on rank 0.
@@ -34,10 +38,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "sdrplusplus-dab-radio-plugin_amd"))
 sys.path.insert(0, ROOT)
 
-# algorithmic HBM bytes per frame (DESIGN.md "Measurement").  The closed-loop front end does not read the cyclic prefixes of
-# the data symbols (decision-directed fine-frequency loop): the useful 2048 samples of the 76 symbols and the prefix of the
-# PRS in, 230400 int8 soft bits out.  SURVEY 8(d)'s A_ofdm = 1 803 264 B also counts the 75 prefixes and the null symbol.
-A_OFDM = (76 * 2048 + 504) * 8 + 230400    # 1 479 616 B (the PRS keeps its prefix: it resolves the estimator's ambiguity)
+# algorithmic HBM bytes per frame (DESIGN.md "Measurement").  The timed step is the reference's data flow: all 76 symbol
+# periods of a frame (prefixes included: the fine-frequency loop runs on the cyclic-prefix correlations) in, 230400 int8
+# soft bits out.  SURVEY 8(d)'s A_ofdm = 1 803 264 B also counts the null symbol, which no launch reads.
+A_OFDM = 76 * 2552 * 8 + 230400            # 1 782 016 B
 A_OFDM_SURVEY = 196608 * 8 + 230400        # 1 803 264 B
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: 8 TB/s spec
 REALTIME_FPS = 1.0 / 0.096
@@ -123,7 +127,7 @@ def parse_args(argv=None):
                          "power-limited steady state is in the record (0 = skip)")
     for leg, what in (("fft-stage", "the unfused FFT-stage measurement"), ("selective", "the selective-soft-output measurement"),
                       ("closed-loop", "the unaligned-capture / tracking measurement"), ("sustained", "the sustained leg"),
-                      ("cp-leg", "the step on the cyclic-prefix correlations (the reference's estimator)"),
+                      ("dd-leg", "the step on the library's own decision-directed estimator (with_decision_directed_loop / value_own_estimator)"),
                       ("single-ensemble", "BASELINE configs 2 and 3 (one ensemble) and the one-frame host path"),
                       ("host-fed", "the host-fed ring (64 frames per call from page-locked memory)"),
                       ("traffic", "measuring roofline.traffic now (two rocprofv3 --pmc child processes, ~20 s); the tracked figure "
@@ -242,7 +246,7 @@ def main():
     for i in range(2 + 5):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        ctx.mover_frames_dev(d_iq, L, n_frames, soft.data_ptr(), False, stream)
+        ctx.mover_frames_dev(d_iq, L, n_frames, soft.data_ptr(), True, stream)      # with_prefixes: what the timed launch reads
         e1.record()
         if i >= 2:
             mover_ev.append((e0, e1))
@@ -262,7 +266,7 @@ def main():
         if timed:
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
             ev[0].record()
-        # (no correlation buffer passed: the fine loop runs decision-directed; of a frame's prefixes only the PRS's is read)
+        # (no correlation buffer passed: the 76 correlations per frame the loop runs on stay in the library's scratch)
         ctx.ofdm_demod_streams_dev(d_iq, L, E, F, BETA, soft.data_ptr(), None, None, stream)
         if timed:
             ev[1].record()
@@ -271,10 +275,8 @@ def main():
             ev[2].record()
             ofdm_ev.append((ev[0], ev[1])); dec_ev.append((ev[1], ev[2]))
 
-    # settle the fine-frequency loop (part of acquisition, untimed), decision-directed from the first call as the timed
-    # steps run: the fourth-power estimate is exact to 1e-4 carriers but repeats every 0.2, the cyclic prefix of each
-    # frame's PRS (the one prefix that is read) picks its branch, so the loop pulls in from +-half a carrier
-    ctx.set_stream_loop(decision_directed=True)      # calls without a correlation buffer skip the other 75 prefixes
+    # settle the fine-frequency loop (part of acquisition, untimed) on the estimator the timed steps run: the library's
+    # default, the cyclic-prefix correlations, which pull in from +-half a carrier
     for k in range(4):
         ctx.ofdm_demod_streams_dev(d_iq, L, E, F, BETA, soft.data_ptr(), None, None, stream)
     torch.cuda.synchronize()
@@ -316,6 +318,9 @@ def main():
                                                             [fic_ok, msc_ok])
 
     ofdm_call_ms = float(np.mean([a.elapsed_time(b) for a, b in ofdm_ev]))     # front-end call: kernel + state update
+    # every timed step's own device time (front-end call + decode call), so that the spread inside a run -- and, over the
+    # driver's records, between boxes -- is in the line
+    step_dev_ms = np.array([a.elapsed_time(c) for (a, _), (_, c) in zip(ofdm_ev, dec_ev)])
     dec_ms = float(np.mean([a.elapsed_time(b) for a, b in dec_ev]))
     ofdm_ms, ofdm_launches = ctx.mean_kernel_ms(0)                             # the fused kernel's launches alone
     ctx.set_timing(False)
@@ -341,7 +346,7 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("frames_per_launch") == n_frames and tj.get("mode") == "decision-directed, no cyclic prefix read":
+                if tj.get("frames_per_launch") == n_frames and tj.get("mode") == "with cyclic-prefix correlations":
                     traffic = tj.get("hbm_bytes_per_launch")
                     traffic_source = "profiles/pmc_traffic.json (rocprofv3 --pmc, separate run of this command: " \
                                      "TCC_EA0_RDREQ/WRREQ-derived FETCH_SIZE x 2 + WRITE_SIZE, tools/pmc_traffic.sh); not measured in this run"
@@ -353,35 +358,44 @@ def main():
             "per_rank": [{"rank": i, "frames_per_s": r[0], "front_end_kernel_ms": r[1], "decoder_ms": r[2], "device": int(r[3]),
                           "roofline_frac": r[4], "mover_same_geometry_ms": r[5]} for i, r in enumerate(per_rank)],
             "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "step_ms": {"min": float(step_dev_ms.min()), "median": float(np.median(step_dev_ms)), "max": float(step_dev_ms.max()),
+                        "what": "device time of each timed step on rank 0 (HIP events around the two calls)"},
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%d ensembles/GPU x %d frames/step, Mode-I OFDM + FIC Viterbi + one 64 kbps "
                                    "EEP-3A MSC subchannel, IQ resident in HBM" % (E, F),
                        "ensembles_per_gpu": E, "frames_per_step_per_gpu": n_frames, "snr_db": args.snr,
                        "carrier_offset": "unknown to the receiver: k + f carriers per ensemble, |k| <= 3, |f| <= 0.4",
-                       "frequency_correction": "closed loop on the device (dabgpu_ofdm_demod_streams_dev): coarse from the first PRS, "
-                                               "fine: decision-directed from the first (untimed) call on -- fourth power of the "
-                                               "differential symbols of the previous call, its 0.2-carrier ambiguity resolved by the "
-                                               "cyclic prefix of each frame's PRS, the only prefix that is read",
+                       "frequency_correction": "closed loop on the device (dabgpu_ofdm_demod_streams_dev, library defaults): coarse from "
+                                               "the first PRS, fine: the reference's estimator -- mean angle of the 76 cyclic-prefix "
+                                               "correlations of every frame of the previous call, fine_freq_update_beta 0.9",
+                       "estimator": "cyclic-prefix correlations (the reference's; the library's default).  The library's own "
+                                    "decision-directed loop is opt-in and reported as value_own_estimator / with_decision_directed_loop",
                        "sharding": "independent ensembles per rank (global id % world == rank), no data-path collective",
                        "buffer_placement": placement},
             "x_realtime": value / REALTIME_FPS,
             "fic_bit_exact": fic_ok, "msc_bit_exact": msc_ok,
             "fine_loop_residual_carriers": loop_residual,
-            "roofline": {"bound": "hbm", "kernel": "dabk::ofdm_wave_kernel<false,false,false,true> (fused A2..A6)", "achieved": achieved,
+            "value_own_estimator": None,
+            "roofline": {"bound": "hbm", "kernel": "dabk::ofdm_wave_kernel<false,false,false,true> (fused A2..A6, cyclic-prefix correlations out)",
+                         "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_source, "avg_launch_ms": ofdm_ms, "launches_timed": ofdm_launches,
                          "front_end_call_ms": ofdm_call_ms, "frames_per_launch": n_frames,
                          "algorithmic_bytes_per_frame": A_OFDM,
-                         "algorithmic_bytes_note": "76 x 2048 cf32 + the PRS's 504-sample prefix in, 230400 int8 out: the other 75 cyclic "
-                                                   "prefixes (19.5 % of the samples) are not read; priced on SURVEY 8(d)'s A_ofdm (1 803 264 B, prefixes "
-                                                   "and null symbol included) the same launch would read achieved_on_survey_bytes",
+                         "algorithmic_bytes_note": "76 x 2552 cf32 in (every symbol period, prefixes included), 230400 int8 out; priced on "
+                                                   "SURVEY 8(d)'s A_ofdm (1 803 264 B: + the null symbol, which is never read) the same "
+                                                   "launch would read achieved_on_survey_bytes",
                          "achieved_on_survey_bytes": A_OFDM_SURVEY * n_frames / (ofdm_ms * 1e-3) / 1e9,
                          # the practical ceiling: dabgpu_mover_frames_dev on the timed buffers -- the kernel's loads, stores,
                          # runs and occupancy without its arithmetic
                          "mover_same_geometry_ms": mover_ms,
                          "mover_same_geometry_GBps": A_OFDM * n_frames / (mover_ms * 1e-3) / 1e9,
-                         "kernel_over_mover": ofdm_ms / mover_ms},
+                         # this box's ceiling for this read / write mix, on the same scale as `frac`
+                         "box_mover_frac": A_OFDM * n_frames / (mover_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "kernel_over_mover": ofdm_ms / mover_ms,
+                         "frac_own_estimator": None},
             # the channel decoder is integer add-compare-select work, not bandwidth: report ACS/s
             "decoder": {"fic_and_msc_ms": dec_ms, "acs_per_s": (ACS_FIC + ACS_MSC64) * n_frames / (dec_ms * 1e-3),
                         "entry_point": "dabgpu_decode_frames_dev (FIC + sub-channel codewords in one grouped launch)"},

@@ -1,7 +1,9 @@
 """bench_legs.py -- everything bench.py measures AFTER its timed region, on rank 0, reported beside `value` and never as
 `value`.  Each leg adds one key to the JSON line:
 
-  with_cyclic_prefix_correlations  the timed step on the reference's estimator (the prefixes are read, 21 % more bytes)
+  with_decision_directed_loop      the timed step on the library's OWN fine-frequency estimator (opt-in: of a frame's 76
+                                   cyclic prefixes only the PRS's is read, 17 % fewer bytes); also copied to the top level
+                                   as value_own_estimator / roofline.frac_own_estimator
   sustained                        the timed step repeated for seconds (the package's power-limited steady state)
   roofline_fft_stage               the unfused FFT stage (north_star's 40 % bar, SURVEY 8d A_fft)
   selective_soft_output            the front end writing only what this workload decodes
@@ -19,8 +21,8 @@ import time
 
 import numpy as np
 
-A_OFDM = (76 * 2048 + 504) * 8 + 230400
-A_OFDM_CP = 76 * 2552 * 8 + 230400         # 1 782 016 B: what the kernel moves when it produces the cyclic-prefix correlations
+A_OFDM = 76 * 2552 * 8 + 230400            # 1 782 016 B: the timed step (the reference's data flow: every prefix is read)
+A_OFDM_DD = (76 * 2048 + 504) * 8 + 230400 # 1 479 616 B: the decision-directed step (the PRS keeps its prefix: it picks the branch)
 A_FFT = 76 * 2552 * 8 + 76 * 2048 * 8      # 2 796 800 B (unfused FFT stage, SURVEY 8(d): prefixes counted)
 A_FFT_MOVED = 2 * 76 * 2048 * 8            # 2 490 368 B (what the FFT-stage kernel reads and writes)
 HBM_PEAK_GBS = 8000.0
@@ -38,8 +40,11 @@ def run(B, out):
                                                  "counter) around tools/pmc_traffic.py at this launch shape, counters calibrated on "
                                                  "that process's 1 GiB device copy (read scale %.4f, write scale %.4f)"
                                                  % (t["read_scale_from_1GiB_copy"], t["write_scale_from_1GiB_copy"]))
-    if not a.no_cp_leg:
-        out["with_cyclic_prefix_correlations"] = cp_leg(B)
+    if not a.no_dd_leg:
+        leg = dd_leg(B)
+        out["with_decision_directed_loop"] = leg
+        out["value_own_estimator"] = leg["value"]
+        out["roofline"]["frac_own_estimator"] = leg["roofline_frac"]
     if not a.no_sustained and a.sustained_seconds > 0:
         out["sustained"] = sustained_leg(B)
     if not a.no_fft_stage:
@@ -62,26 +67,30 @@ def run(B, out):
 
 
 def measure_traffic(n_frames, root, timeout_s=240):
-    """HBM bytes per launch of the fused front end (decision-directed data flow) from the TCC counters, measured NOW: two child
-    processes `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 tools/pmc_traffic.py n dd` (counters cannot be
+    """HBM bytes per launch of the fused front end (the timed step's data flow: cyclic-prefix correlations out) from the TCC
+    counters, measured NOW: two child
+    processes `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 tools/pmc_traffic.py n cp` (counters cannot be
     read from inside a running process; one pass per counter, as MI355X_MICROARCH.md prescribes; the child does a 1 GiB
     device copy first, which calibrates the counters' unit).  Returns a dict, or None when the profiler is not there or a
-    pass fails -- the caller then falls back to the tracked figure."""
+    pass fails -- the caller then falls back to the tracked figure.  Never nested: when this process itself runs under a
+    profiler (tools/prof.sh without --legs none), the child launcher would inherit the outer profiler's preload and the
+    counters of a nested session mean nothing -- return None instead."""
     import csv
     import shutil
     import subprocess
     import tempfile
     prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
-    if not os.path.exists(prof):
+    if not os.path.exists(prof) or profiler_attached():
         return None
     out_dir = tempfile.mkdtemp(prefix="dabgpu_pmc_")
-    env = dict(os.environ, TMPDIR="/tmp")
+    env = {k: v for k, v in os.environ.items() if not is_profiler_variable(k, v)}
+    env["TMPDIR"] = "/tmp"
     res = {}
     try:
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(out_dir, c)
             r = subprocess.run([prof, "--pmc", c, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "t", "--",
-                                "python3", os.path.join(root, "tools", "pmc_traffic.py"), str(n_frames), "dd"],
+                                "python3", os.path.join(root, "tools", "pmc_traffic.py"), str(n_frames), "cp"],
                                cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
             path = os.path.join(d, "t_counter_collection.csv")
             if r.returncode != 0 or not os.path.exists(path):
@@ -111,49 +120,79 @@ def measure_traffic(n_frames, root, timeout_s=240):
             "read_scale_from_1GiB_copy": gib / (res["FETCH_SIZE"]["copy"] * 1024), "write_scale_from_1GiB_copy": gib / (res["WRITE_SIZE"]["copy"] * 1024)}
 
 
+def is_profiler_variable(k, v):
+    """environment a rocprofv3 session plants in its target (and which a child of ours must not inherit)"""
+    if k.startswith(("ROCP_", "ROCPROF", "ROCPROFILER_", "ROCTX_", "HSA_TOOLS_")):
+        return True
+    return k == "LD_PRELOAD" and ("rocprof" in v.lower() or "roctx" in v.lower())
+
+
+def profiler_attached():
+    return any(is_profiler_variable(k, v) for k, v in os.environ.items())
+
+
 def _events(torch):
     return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
 
-def cp_leg(B):
-    """The step as rounds 1-2 ran it: the caller asks for the cyclic-prefix correlations (the reference's estimator,
-    fine_freq_update_beta at /root/reference/src/render_radio_block.cpp:216), so the prefixes are read and the loop runs
-    on them -- 21 % more bytes through the same kernel."""
+def dd_leg(B):
+    """The timed step on the library's OWN estimator (opt-in, dabgpu_set_stream_loop(decision_directed = 1)): the fine loop
+    runs on the fourth powers of the differential symbols, its 0.2-carrier ambiguity resolved by the PRS's cyclic prefix --
+    the only one of a frame's 76 prefixes that is still read: 17 % fewer bytes through the same kernel.  Reported beside
+    `value`, never as `value`: the reference has no such loop.  The loop is switched back before the leg returns."""
     torch, ctx = B.torch, B.ctx
-    cyc = torch.zeros((B.n_frames, 76), dtype=torch.complex64, device=B.dev)
     torch.cuda.synchronize()
-    soft_dd = B.soft.clone()                                # the timed run's last soft bits, for the comparison below
-    evs = []
+    soft_cp = B.soft.clone()                                # the timed run's last soft bits, for the comparison below
+    ctx.set_stream_loop(decision_directed=True)
     steps = B.args.steps
-    t1 = time.perf_counter()
-    for k in range(2 + steps):
-        e0, e1 = _events(torch)
-        e0.record()
-        ctx.ofdm_demod_streams_dev(B.d_iq, B.L, B.E, B.F, B.BETA, B.soft.data_ptr(), cyc.data_ptr(), None, B.stream)
-        e1.record()
-        B.decode_into(B.soft, B.args.warmup + steps + k)
-        if k == 1:
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-        if k >= 2:
-            evs.append((e0, e1))
+    for k in range(2):                                      # the loop settles on the other estimator (untimed)
+        B.step(B.args.warmup + steps + k, False)
+    n_before = len(B.ofdm_ev)
     torch.cuda.synchronize()
-    cp_s = time.perf_counter() - t1
-    cp_ms = float(np.mean([x.elapsed_time(y) for x, y in evs]))
+    ctx.set_timing(True)
+    t1 = time.perf_counter()
+    for k in range(steps):
+        B.step(B.args.warmup + steps + 2 + k, True)
+    torch.cuda.synchronize()
+    dd_s = time.perf_counter() - t1
+    k_ms, k_launches = ctx.mean_kernel_ms(0)
+    ctx.set_timing(False)
+    call_ms = float(np.mean([x.elapsed_time(y) for x, y in B.ofdm_ev[n_before:]]))
+    dec_ms = float(np.mean([x.elapsed_time(y) for x, y in B.dec_ev[n_before:]]))
     fib_c, crc_c, msc_c = B.fib.cpu().numpy(), B.crc.cpu().numpy(), B.msc.cpu().numpy()
     # the two loops sit a few 1e-5 carriers apart, so a few soft bits land on the other side of a truncation
     n_diff, max_diff = 0, 0
     for lo in range(0, B.n_frames, 1024):                   # in slices: the int16 difference of 3.8 GB at once is 7.5 GB
-        dlt = (B.soft[lo:lo + 1024].to(torch.int16) - soft_dd[lo:lo + 1024].to(torch.int16)).abs()
+        dlt = (B.soft[lo:lo + 1024].to(torch.int16) - soft_cp[lo:lo + 1024].to(torch.int16)).abs()
         n_diff += int((dlt != 0).sum().item())
         max_diff = max(max_diff, int(dlt.max().item()))
-    del soft_dd, cyc
-    return {"value": B.n_frames * steps / cp_s, "unit": "frames/s", "ms_per_step": cp_s / steps * 1e3,
-            "front_end_call_ms": cp_ms, "algorithmic_bytes_per_frame": A_OFDM_CP,
-            "roofline_frac": A_OFDM_CP * B.n_frames / (cp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+    del soft_cp
+    # its own ceiling: the mover of the same geometry without the 75 prefixes (leaves meaningless bytes in `soft`)
+    mev = []
+    for i in range(2 + 5):
+        e0, e1 = _events(torch)
+        e0.record()
+        ctx.mover_frames_dev(B.d_iq, B.L, B.n_frames, B.soft.data_ptr(), False, B.stream)
+        e1.record()
+        if i >= 2:
+            mev.append((e0, e1))
+    torch.cuda.synchronize()
+    mover_ms = float(np.mean([x.elapsed_time(y) for x, y in mev]))
+    ctx.set_stream_loop(decision_directed=False)            # back to the library's default for every later leg
+    for k in range(2):
+        B.step(B.args.warmup + 2 * steps + 2 + k, False)
+    torch.cuda.synchronize()
+    return {"value": B.n_frames * steps / dd_s, "unit": "frames/s", "ms_per_step": dd_s / steps * 1e3,
+            "x_realtime": B.n_frames * steps / dd_s / REALTIME_FPS,
+            "front_end_call_ms": call_ms, "front_end_kernel_ms": k_ms, "launches_timed": k_launches, "decoder_ms": dec_ms,
+            "algorithmic_bytes_per_frame": A_OFDM_DD,
+            "roofline_frac": A_OFDM_DD * B.n_frames / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "mover_same_geometry_ms": mover_ms, "box_mover_frac": A_OFDM_DD * B.n_frames / (mover_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "kernel_over_mover": k_ms / mover_ms,
             "outputs_identical_to_timed_run": bool((fib_c == B.fib_h).all() and (crc_c == B.crc_h).all() and (msc_c == B.msc_h).all()),
             "soft_bits_differing_from_timed_run_per_million": n_diff / (B.n_frames * B.dabgpu.NB_FRAME_BITS) * 1e6,
-            "max_abs_soft_bit_difference": max_diff}
+            "max_abs_soft_bit_difference": max_diff,
+            "what": "dabgpu_set_stream_loop(decision_directed = 1): this library's own estimator, not the reference's"}
 
 
 def sustained_leg(B):
@@ -213,6 +252,9 @@ def selective_leg(B):
     torch, ctx, a, dabgpu = B.torch, B.ctx, B.args, B.dabgpu
     sel = dabgpu.soft_selection([B.sc])
     ctx.set_soft_selection(sel)
+    # (both are this library's own options, so they go together here: on the decision-directed loop a symbol nobody wants is
+    # not read at all; on the reference's loop its cyclic prefix would still be correlated)
+    ctx.set_stream_loop(decision_directed=True)
     B.soft.zero_(); B.fib.zero_(); B.crc.zero_(); B.msc.zero_()
     n_before = len(B.ofdm_ev)
     for k in range(2):
@@ -224,6 +266,7 @@ def selective_leg(B):
     torch.cuda.synchronize()
     sel_s = time.perf_counter() - t1
     ctx.set_soft_selection(None)
+    ctx.set_stream_loop(decision_directed=False)
     fib_s, crc_s, msc_s = B.fib.cpu().numpy(), B.crc.cpu().numpy(), B.msc.cpu().numpy()
     sel_ok = bool(crc_s.all()) and bool((fib_s == B.fib_h).all()) and bool((msc_s == B.msc_h).all())
     sel_ofdm = float(np.mean([x.elapsed_time(y) for x, y in B.ofdm_ev[n_before:]]))
@@ -241,7 +284,8 @@ def selective_leg(B):
             "soft_bits_written_per_frame": kept,
             "symbols_transformed_per_frame": int(need.sum()), "algorithmic_bytes_per_frame": a_sel,
             "ofdm_achieved_GBps": a_sel * B.n_frames / (sel_ofdm * 1e-3) / 1e9,
-            "outputs_identical_to_whole_frame_run": sel_ok}
+            "outputs_identical_to_whole_frame_run": sel_ok,
+            "estimator": "decision-directed (opt-in, as the selection itself)"}
 
 
 def single_ensemble_leg(B):
@@ -261,15 +305,18 @@ def single_ensemble_leg(B):
     c1 = dabgpu.Context(device=B.dev_index, max_frames=F)
     c1.streams_reset(1)
     c1.set_stream_offsets(0, fine=float(st0.fine_freq_offset), coarse=float(st0.coarse_freq_offset))   # acquisition is untimed, as above
-    c1.set_stream_loop(decision_directed=True)
     soft, fib, crc, msc = B.soft[:F], B.fib[:F], B.crc[:F], B.msc[:1]
     hist = [h[:1] for h in B.hist]
     for h in hist:
         h.zero_()
     e = B.ens[0]
     res = {}
-    for name, scs in (("ofdm_fic", []), ("ofdm_fic_msc64", [B.sc])):
+    # the rows BASELINE names run the library's defaults (the reference's estimator); `_own_estimator`: the same on the
+    # opt-in decision-directed loop
+    for name, scs, dd in (("ofdm_fic", [], False), ("ofdm_fic_msc64", [B.sc], False),
+                          ("ofdm_fic_own_estimator", [], True), ("ofdm_fic_msc64_own_estimator", [B.sc], True)):
         fib.zero_(); crc.zero_(); msc.zero_()
+        c1.set_stream_loop(decision_directed=dd)
 
         def one(k):
             c1.ofdm_demod_streams_dev(B.d_iq, L, 1, F, B.BETA, soft.data_ptr(), None, None, stream)
@@ -409,7 +456,6 @@ def host_fed_leg(B):
     sync_ok = bool(s0["ok"].array.all()) and all(bool((fib_ref[f] == e.fibs[f % 4]).all()) for f in range(n))
 
     # ---- the ring ----
-    c.set_stream_loop(decision_directed=True)                # (only the PRS's prefix is used; over the link all samples travel anyway)
     c.pipe_open(S, n, used)
     calls = 120
     tickets = [None] * (S + 1)

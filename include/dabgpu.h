@@ -42,7 +42,8 @@
 extern "C" {
 #endif
 
-#define DABGPU_ABI_VERSION 5   /* 5: one frame-buffer allocator (placement mode), host-fed ring (dabgpu_pipe_*), loop gate */
+#define DABGPU_ABI_VERSION 6   /* 6: every closed-loop call defaults to the reference's cyclic-prefix estimator (dabgpu_track_cfg.decision_directed */
+                               /*    defaults to 0 and the frame call honours it); 5: one frame-buffer allocator, host-fed ring, loop gate           */
 
 typedef enum dabgpu_status {
     DABGPU_OK = 0,
@@ -249,8 +250,10 @@ int dabgpu_ofdm_demod_frames(dabgpu_ctx *ctx, const float *iq, size_t frame_stri
  *        Entry 0 of a frame = the cyclic-prefix correlation of its PRS (symbol 0; the one prefix that IS read, 0.3 % of
  *        the frame): angle / (2 pi 2048) is the same residual, coarser but unambiguous within half a carrier -- it picks
  *        the branch: residual = e_dd + k / (4 * 2552), k = round((e_cp - e_dd) * 4 * 2552).
- * The tracked call below runs on this by default (dabgpu_track_cfg.decision_directed), the stream call after
- * dabgpu_set_stream_loop(..., decision_directed = 1), whenever the caller does not ask for the correlations (d_cyc == NULL). */
+ * OPT-IN everywhere: every closed-loop entry point runs the reference's loop (cyclic-prefix correlations) unless told
+ * otherwise -- the tracked and frame calls through dabgpu_track_cfg.decision_directed = 1, the stream call and the ring after
+ * dabgpu_set_stream_loop(..., decision_directed = 1) -- and only when the caller does not ask for the correlations
+ * (d_cyc == NULL). */
 int dabgpu_ofdm_demod_frames_dd_dev(dabgpu_ctx *ctx, const void *d_iq, size_t frame_stride, int n_frames,
                                     const float *d_freq_offset, int8_t *d_soft, void *d_dd4, void *stream);
 
@@ -340,8 +343,8 @@ int dabgpu_get_stats(dabgpu_ctx *ctx, int stream_index, dabgpu_stats *out);
  *   decision_directed != 0            the dd4 sums of dabgpu_ofdm_demod_frames_dd_dev: of the 76 cyclic prefixes of a frame
  *                                     only the PRS's is read (17 % fewer bytes); it resolves the sums' 0.2-carrier
  *                                     ambiguity, so this loop, too, pulls in from +-half a carrier and may run from
- *                                     the first call on.  (Off by default only so that callers written against ABI v3
- *                                     see the loop they know.) */
+ *                                     the first call on.  Off by default: the drop-in path keeps the reference's
+ *                                     data flow; this one is the library's own, opt-in. */
 int dabgpu_set_stream_loop(dabgpu_ctx *ctx, float signal_update_beta, float thr_null_start, int decision_directed);
 /* The decision-directed loop checks its own estimate before it moves (stream call here; tracked and frame calls:
  * dabgpu_track_cfg.dd_gate).  With S = the call's sum of unit fourth powers over n terms:
@@ -497,8 +500,8 @@ int dabgpu_ofdm_demod_acquired_dev(dabgpu_ctx *ctx, const void *d_iq, size_t str
 /* predicts inside the capture (start_i = next_frame_start + i*(196608+drift)) */
 /* are synchronised on their own PRS (impulse response -> exact start, lock),   */
 /* demodulated where they lie with the stream's fine + coarse offset, and the   */
-/* state is moved on: fine-frequency loop (decision-directed sums by default,    */
-/* cfg.decision_directed; the cyclic-prefix correlations when d_cyc is given),  */
+/* state is moved on: fine-frequency loop (on the cyclic-prefix correlations, as  */
+/* the reference's; cfg.decision_directed = 1 and d_cyc == NULL: on the dd4 sums), */
 /* next_frame_start and drift from a line through the measured starts.         */
 /*   n_samples  samples per stream in this capture                             */
 /*   advance    the next capture of every stream will begin this many samples   */
@@ -527,9 +530,12 @@ typedef struct dabgpu_track_cfg {
     int32_t timing_margin;                    /* 64 (batch calls); the frame call uses the host's own   */
     int32_t max_coarse_carriers;              /* frame call and auto-acquisition: whole-carrier search */
                                               /* range, 0 = off (204)                                  */
-    int32_t decision_directed;                /* tracked call with d_cyc == NULL: fine loop on the dd4 */
-                                              /* sums, only the PRS's cyclic prefix read (1);          */
-                                              /* 0 = on the cyclic-prefix correlations                 */
+    int32_t decision_directed;                /* 0 (default) = the fine loop runs on the cyclic-prefix */
+                                              /* correlations, the reference's estimator               */
+                                              /* (fine_freq_update_beta, render_radio_block.cpp:216);   */
+                                              /* 1 = tracked / frame call with d_cyc == NULL: on the    */
+                                              /* dd4 sums, only the PRS's cyclic prefix is read -- this */
+                                              /* library's own estimator, opt-in (ABI v6; v5: default 1) */
     int32_t auto_acquire;                     /* tracked call: != 0 = streams that are not tracking    */
                                               /* (never acquired, or lost) are ACQUIRED inside the     */
                                               /* call -- null-symbol search + PRS on their capture as  */

@@ -263,15 +263,17 @@ def stream_update(state, cyc, iq_last_frame, beta, thr_null_start=0.35, signal_b
     n = cyc.size
     frames = cyc.shape[0]
     new = dict(state)
-    if dd:                                                       # `cyc` holds dd4 sums: the decision-directed loop, gated
-        err, gate_state = dd_loop_error(cyc, state, dd_gate, terms_per_frame)
-        new.update(gate_state)
-    else:
-        err = np.float32(np.angle(cyc.astype(np.complex128)).sum() / n / (2.0 * np.pi * 2048.0))
     x = np.asarray(iq_last_frame[:4096])
     l1 = np.float32((np.abs(x.real).astype(np.float64) + np.abs(x.imag).astype(np.float64)).sum() / 4096.0)
     level_lost = bool(state["signal_average"] > 0 and l1 < np.float32(thr_null_start) * np.float32(state["signal_average"]))
-    if not (level_lost and frames == 1):                         # one frame whose level is gone steers nothing
+    steers = not (level_lost and frames == 1)                    # one frame whose level is gone steers nothing
+    if dd:                                                       # `cyc` holds dd4 sums: the decision-directed loop, gated
+        err, gate_state = dd_loop_error(cyc, state, dd_gate, terms_per_frame)
+        if steers:                                               # (an estimate that is not applied leaves the gate's memory alone)
+            new.update(gate_state)
+    else:
+        err = np.float32(np.angle(cyc.astype(np.complex128)).sum() / n / (2.0 * np.pi * 2048.0))
+    if steers:
         half = np.float32(0.5 / 2048.0)
         f = np.float32(state["fine_freq_offset"]) - np.float32(beta) * err
         if f > half:
@@ -506,17 +508,19 @@ def track_update(state, frames, cyc, iq, n_samples, max_frames, advance, fine_be
     desync = j0 + (count - n)
     level_lost = False
     if n > 0:
-        if dd:
-            err, gate_state = dd_loop_error(np.asarray(cyc)[locked], state, dd_gate, terms_per_frame)
-            st.update(gate_state)
-        else:
-            ang = np.angle(np.asarray(cyc)[locked].astype(np.complex128)).sum()
-            err = np.float32(np.float32(ang / (n * 76.0)) * np.float32(1.0 / (6.283185307179586 * 2048.0)))
         last = locked[-1]
         x = np.asarray(iq[frames[last]["start"]:frames[last]["start"] + 4096])
         l1 = np.float32((np.abs(x.real).astype(np.float64) + np.abs(x.imag).astype(np.float64)).sum() / 4096.0)
         level_lost = bool(state["signal_average"] > 0 and l1 < np.float32(thr_null_start) * np.float32(state["signal_average"]))
-        if not (level_lost and n == 1):                          # one locked frame whose level is gone steers nothing
+        steers = not (level_lost and n == 1)                     # one locked frame whose level is gone steers nothing
+        if dd:
+            err, gate_state = dd_loop_error(np.asarray(cyc)[locked], state, dd_gate, terms_per_frame)
+            if steers:                                           # (an estimate that is not applied leaves the gate's memory alone)
+                st.update(gate_state)
+        else:
+            ang = np.angle(np.asarray(cyc)[locked].astype(np.complex128)).sum()
+            err = np.float32(np.float32(ang / (n * 76.0)) * np.float32(1.0 / (6.283185307179586 * 2048.0)))
+        if steers:
             half = np.float32(0.5 / 2048.0)
             f = np.float32(state["fine_freq_offset"]) - np.float32(fine_beta) * err
             if f > half:
@@ -574,6 +578,7 @@ def track_start(state, frames, advance):
     st["fine_freq_offset"] = np.float32(sum(float(f.fine_offset) for f in locked) / n)
     st["coarse_freq_offset"] = np.float32(-float(locked[-1].coarse_carriers) / 2048.0)
     st["tracking"] = 1
+    st["dd_branch"] = st["dd_pending"] = DD_NO_BRANCH           # pulling in again: the first estimate is believed on any branch
     st["total_frames_read"] = state["total_frames_read"] + int(n)
     st["last_time_offset"] = 0
     st["last_peak_to_mean"] = np.float32(locked[-1].peak_to_mean)

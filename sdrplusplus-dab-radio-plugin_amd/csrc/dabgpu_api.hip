@@ -623,6 +623,10 @@ int dabgpu_set_stream_offsets(dabgpu_ctx *ctx, int stream_index, const float *fi
     dabk::StreamState *st = ctx->d_states + stream_index;
     if (fine) HIP_TRY(hipMemcpy(&st->fine_freq_offset, fine, sizeof(float), hipMemcpyHostToDevice));
     if (coarse) HIP_TRY(hipMemcpy(&st->coarse_freq_offset, coarse, sizeof(float), hipMemcpyHostToDevice));
+    // a re-seeded stream pulls in again: the decision-directed loop's gate forgets the branch it was holding
+    const int32_t pulling_in[2] = {dabk::DD_NO_BRANCH, dabk::DD_NO_BRANCH};
+    static_assert(offsetof(dabk::StreamState, dd_pending) == offsetof(dabk::StreamState, dd_branch) + 4, "branch, pending adjacent");
+    if (fine || coarse) HIP_TRY(hipMemcpy(&st->dd_branch, pulling_in, sizeof(pulling_in), hipMemcpyHostToDevice));
     return DABGPU_OK;
 }
 
@@ -974,7 +978,7 @@ void dabgpu_track_default_cfg(dabgpu_track_cfg *cfg) {
     cfg->coarse_freq_slow_beta = 0.1f;
     cfg->timing_margin = 64;
     cfg->max_coarse_carriers = 204;
-    cfg->decision_directed = 1;
+    cfg->decision_directed = 0;         // the reference's estimator (cyclic-prefix correlations); 1 = this library's own, opt-in
     cfg->auto_acquire = 0;
     cfg->dd_gate = 2.5f;
 }
@@ -1101,7 +1105,8 @@ int dabgpu_ofdm_demod_tracked_dev(dabgpu_ctx *ctx, const void *d_iq, size_t stre
     if (rc) return rc;
     if (n_streams == 0) return DABGPU_OK;
     hipStream_t s = pick_stream(ctx, stream);
-    // (no correlation output asked for: by default a decision-directed loop, the cyclic prefixes are not read -- see
+    // (no correlation output asked for: the loop's input stays in the library's scratch -- the cyclic-prefix correlations by
+    // default, as the reference's loop; cfg.decision_directed: the fourth-power sums, the cyclic prefixes are not read -- see
     // the stream call; acquisition leaves the fine offset well inside that estimator's range)
     void *d_dd = nullptr;
     if (!d_cyc && (rc = stage(ctx, 6, size_t(n_streams) * max_frames * NB_FRAME_SYMBOLS * sizeof(float2), c.decision_directed ? &d_dd : &d_cyc)))
@@ -1135,10 +1140,12 @@ int dabgpu_ofdm_demod_stream_frame(dabgpu_ctx *ctx, int stream_index, const floa
     // one result block: soft bits | acquired frame | sync result | state  (| constellation, in a buffer of its own)
     const size_t off_fr = al(NB_FRAME_BITS), off_sy = off_fr + al(sizeof(dabgpu_acquired_frame)),
                  off_st = off_sy + al(sizeof(dabgpu_sync_result)), nb_res = off_st + al(sizeof(dabk::StreamState));
-    void *d_iq, *d_res, *d_cyc, *d_dq = nullptr;
+    void *d_iq, *d_res, *d_cyc = nullptr, *d_dd = nullptr, *d_dq = nullptr;
     if ((rc = stage(ctx, 0, nb_iq, &d_iq))) return rc;
     if ((rc = stage(ctx, 1, nb_res, &d_res))) return rc;
-    if ((rc = stage(ctx, 6, NB_FRAME_SYMBOLS * sizeof(float2), &d_cyc))) return rc;
+    // the fine loop's input: the 76 cyclic-prefix correlations (the reference's estimator, the default), or -- opt-in,
+    // cfg->decision_directed -- the fourth-power sums
+    if ((rc = stage(ctx, 6, NB_FRAME_SYMBOLS * sizeof(float2), c.decision_directed ? &d_dd : &d_cyc))) return rc;
     if (dqpsk && (rc = stage(ctx, 4, nb_dq, &d_dq))) return rc;
     if (ctx->h_bounce_bytes < nb_res) {
         if (ctx->h_bounce) (void)hipHostFree(ctx->h_bounce);
@@ -1166,7 +1173,7 @@ int dabgpu_ofdm_demod_stream_frame(dabgpu_ctx *ctx, int stream_index, const floa
     dabk::StreamState *st = ctx->d_states + stream_index;
     rc = tracked_launches(ctx, st, d_iq, nb_iq / sizeof(float2), 1, int64_t(nb_iq / sizeof(float2)), 1, 0, c, 1, acquiring ? 1 : 0,
                           reinterpret_cast<int8_t *>(res), d_cyc, d_dq, reinterpret_cast<dabgpu_acquired_frame *>(res + off_fr),
-                          reinterpret_cast<dabgpu_sync_result *>(res + off_sy), nullptr, s);
+                          reinterpret_cast<dabgpu_sync_result *>(res + off_sy), nullptr, s, nullptr, d_dd);
     if (rc) return rc;
     // one download, written by a kernel right behind the others: soft bits, frame and sync records, then the state
     static_assert(sizeof(dabk::StreamState) % 16 == 0, "the state goes out in 16-byte words");

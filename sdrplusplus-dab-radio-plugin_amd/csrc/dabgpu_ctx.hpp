@@ -171,6 +171,22 @@ void stats_of(const dabk::StreamState &st, dabgpu_stats *out);
 void arena_destroy(dabgpu_ctx *ctx);
 void pipeline_destroy(dabgpu_ctx *ctx);
 
+// No capacity unit of the CIF used twice (and none outside it): the state-keeping entry points (dabgpu_decode_stream_frames,
+// dabgpu_pipe_submit) key their de-interleaver rings by (start, size), so a sub-channel listed twice would share one ring --
+// both entries reading and writing the same pair of buffers, the ring flipped twice -- and the NEXT call would continue from
+// a stale buffer.  Checked before any ring is touched: a refused call leaves the kept state as it was.
+inline bool subchannels_disjoint(const dabgpu_subchannel *sc, int n) {
+    char used[864] = {};
+    for (int i = 0; i < n; i++) {
+        if (sc[i].start_address < 0 || sc[i].length <= 0 || sc[i].start_address + sc[i].length > 864) return false;
+        for (int cu = sc[i].start_address; cu < sc[i].start_address + sc[i].length; cu++) {
+            if (used[cu]) return false;
+            used[cu] = 1;
+        }
+    }
+    return true;
+}
+
 // The codeword-per-lane Viterbi pays once a launch has enough codewords to give every SIMD a wave (one wave =
 // 64 codewords; its single-wave latency equals the wave-per-codeword kernels' time at ~24k codewords).
 constexpr int LANE_MIN_CODEWORDS = 24576;

@@ -471,6 +471,13 @@ int dabgpu_decode_stream_frames(dabgpu_ctx *ctx, const int8_t *soft, size_t soft
     if (n_subchannels > 0 && (!sc || !out)) return DABGPU_ERR_ARG;
     if (n_frames == 0) return DABGPU_OK;
     if (soft_stride < size_t(NB_FRAME_BITS) && n_frames > 1) return DABGPU_ERR_ARG;
+    // argument errors are refused before any ring is touched: the kept state survives them
+    for (int i = 0; i < n_subchannels; i++) {
+        const int nbytes = dabgpu_subchannel_bytes(&sc[i]);
+        if (nbytes < 0) return nbytes;
+        if (!out[i]) return DABGPU_ERR_ARG;
+    }
+    if (!subchannels_disjoint(sc, n_subchannels)) return DABGPU_ERR_ARG;
     const int rc = decode_stream_frames_body(ctx, soft, soft_stride, n_frames, fib, crc_ok, sc, n_subchannels, out);
     if (rc != DABGPU_OK) {
         // A call that failed part-way leaves rings that have missed this frame (and `live` marks on some of them): no

@@ -115,6 +115,10 @@ int dabgpu_pipe_reset(dabgpu_ctx *ctx) {
     return DABGPU_OK;
 }
 
+static int submit_body(dabgpu_ctx *ctx, const float *iq, int n_streams, int frames_per_stream, const float *freq_offset,
+                       float fine_freq_update_beta, const dabgpu_subchannel *sc, int n_subchannels, int8_t *soft, uint8_t *fib,
+                       uint8_t *crc_ok, uint8_t *const *out, int64_t *ticket);
+
 int dabgpu_pipe_submit(dabgpu_ctx *ctx, const float *iq, int n_streams, int frames_per_stream, const float *freq_offset,
                        float fine_freq_update_beta, const dabgpu_subchannel *sc, int n_subchannels, int8_t *soft, uint8_t *fib,
                        uint8_t *crc_ok, uint8_t *const *out, int64_t *ticket) {
@@ -127,7 +131,34 @@ int dabgpu_pipe_submit(dabgpu_ctx *ctx, const float *iq, int n_streams, int fram
         if (n_streams > ctx->n_states) return DABGPU_ERR_CAPACITY;              // closed loop: dabgpu_streams_reset first
         if (!(fine_freq_update_beta >= 0.f && fine_freq_update_beta <= 1.f)) return DABGPU_ERR_ARG;
     }
+    // argument errors are refused here, before a slot or a ring is touched: the ring's state survives them
+    for (int i = 0; i < n_subchannels; i++) {
+        const int nbytes = dabgpu_subchannel_bytes(&sc[i]);
+        if (nbytes < 0) return nbytes;
+        if (!out[i]) return DABGPU_ERR_ARG;
+    }
+    if (!subchannels_disjoint(sc, n_subchannels)) return DABGPU_ERR_ARG;
     DeviceGuard guard(ctx);
+    const int rc = submit_body(ctx, iq, n_streams, frames_per_stream, freq_offset, fine_freq_update_beta, sc, n_subchannels, soft, fib,
+                               crc_ok, out, ticket);
+    if (rc != DABGPU_OK) {
+        // A runtime call failed part-way: a ring may exist that was never zeroed, copies into the caller's buffers may be
+        // in flight behind a slot that is not marked busy, and every ring has missed this batch.  Everything enqueued so
+        // far is waited for (the caller's buffers are safe to reuse when this returns) and every ring goes: the next
+        // submit starts its sub-channels from erasures.
+        (void)hipStreamSynchronize(p->s_up);
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamSynchronize(p->s_down);
+        (void)hipGetLastError();
+        free_rings(p);
+    }
+    return rc;
+}
+
+static int submit_body(dabgpu_ctx *ctx, const float *iq, int n_streams, int frames_per_stream, const float *freq_offset,
+                       float fine_freq_update_beta, const dabgpu_subchannel *sc, int n_subchannels, int8_t *soft, uint8_t *fib,
+                       uint8_t *crc_ok, uint8_t *const *out, int64_t *ticket) {
+    Pipeline *p = ctx->pipe;
     const int n_frames = n_streams * frames_per_stream;
     // layout of the slot's result block: [fib | crc | out_0 | out_1 ...]
     auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
@@ -201,13 +232,7 @@ int dabgpu_pipe_submit(dabgpu_ctx *ctx, const float *iq, int n_streams, int fram
         rc = dabgpu_decode_frames_dev(ctx, static_cast<const int8_t *>(s.d_soft), NB_FRAME_BITS, n_streams, frames_per_stream, d_fib,
                                       d_crc, sc, n_subchannels, n_subchannels ? p_hi.data() : nullptr,
                                       n_subchannels ? p_ho.data() : nullptr, n_subchannels ? p_out.data() : nullptr, sc_stream);
-    if (rc) {
-        // the rings have missed this batch: none of them continues its streams any more
-        (void)hipStreamSynchronize(sc_stream);
-        (void)hipGetLastError();
-        free_rings(p);
-        return rc;
-    }
+    if (rc) return rc;                                          // (the caller of this body drops the rings)
     HIP_TRY(hipEventRecord(s.comp, sc_stream));
     for (int i = 0; i < n_subchannels; i++) p->rings[size_t(ring_of[size_t(i)])].cur ^= 1;
     {

@@ -364,8 +364,10 @@ int dabgpu_alloc_frame_buffers(dabgpu_ctx *ctx, int n_frames, size_t frame_strid
     for (const std::vector<int> *sel : {&iq_sel, &soft_sel})
         for (int i : *sel) {
             Chunk &x = p.c[size_t(i)];
+            // (a chunk whose unmap failed stays marked as mapped: the fallback's drop_all() then tries again before it
+            // releases the handle, instead of releasing a handle that still occupies its span of the probe range)
             if ((herr = hipMemUnmap(ar.probe + x.off, x.bytes)) != hipSuccess) { hstage = 5; mapped_ok = false; }
-            x.mapped = false;
+            else x.mapped = false;
         }
     size_t dst = 0, soft_off = 0;
     for (const std::vector<int> *sel : {&iq_sel, &soft_sel}) {

@@ -578,16 +578,20 @@ __global__ __launch_bounds__(SU_THREADS) void stream_update_kernel(StreamState *
         l1 *= 1.0f / 4096.0f;
         StreamState st = state[s];
         float err = acc / float(n) * (1.0f / (6.283185307179586f * float(NB_FFT)));
+        const bool level_lost = st.signal_average > 0.f && l1 < thr_null_start * st.signal_average;
+        // (a call of ONE frame whose level is gone -- a null symbol, a dropout -- has nothing to steer the loop with)
+        const bool steers = !(level_lost && frames_per_stream == 1);
         if (dd) {
             sx = 0.0; sy = 0.0;
             for (int w = 0; w < SU_THREADS / 64; w++) { sx += red_dd[0][w]; sy += red_dd[1][w]; }
-            // sum = -A exp(j 4 theta), theta = 2 pi r 2552: r modulo 1 / (4 2552); the branch from the PRS prefixes; gated
+            // sum = -A exp(j 4 theta), theta = 2 pi r 2552: r modulo 1 / (4 2552); the branch from the PRS prefixes; gated.
+            // An estimate that is not applied must not move the gate's memory either (branch, pending, gated count)
+            StreamState scratch = st;
             err = dd_loop_error(sx, sy, acc / float(frames_per_stream) * (1.0f / (6.283185307179586f * float(NB_FFT))),
-                                double(frames_per_stream) * double(dd_terms_per_frame), dd_gate, st.total_frames_read == 0, st);
+                                double(frames_per_stream) * double(dd_terms_per_frame), dd_gate, st.total_frames_read == 0,
+                                steers ? st : scratch);
         }
-        const bool level_lost = st.signal_average > 0.f && l1 < thr_null_start * st.signal_average;
-        // (a call of ONE frame whose level is gone -- a null symbol, a dropout -- has nothing to steer the loop with)
-        if (!(level_lost && frames_per_stream == 1)) {
+        if (steers) {
             constexpr float HALF = 0.5f / float(NB_FFT);
             float f = st.fine_freq_offset - beta * err;
             if (f > HALF) f -= 2.f * HALF;

@@ -450,12 +450,15 @@ __global__ __launch_bounds__(TU) void track_update_kernel(TrackUpdateArgs a) {
     if (n_locked > 0) {
         // fine-frequency loop
         float err = float(sang / (sn * double(NB_FRAME_SYMBOLS))) * (1.0f / (6.283185307179586f * float(NB_FFT)));
-        if (a.dd)
-            err = dd_loop_error(sang, sang2, float(ang0 / sn) * (1.0f / (6.283185307179586f * float(NB_FFT))),
-                                sn * double(a.dd_terms_per_frame), a.dd_gate, st.total_frames_read == 0, st);
         level_lost = st.signal_average > 0.f && l1 < a.thr_null_start * st.signal_average;
         // (ONE locked frame whose level is gone has nothing to steer the loop with)
-        if (!(level_lost && n_locked == 1)) {
+        const bool steers = !(level_lost && n_locked == 1);
+        if (a.dd) {
+            StreamState scratch = st;          // an estimate that is not applied does not move the gate's memory either
+            err = dd_loop_error(sang, sang2, float(ang0 / sn) * (1.0f / (6.283185307179586f * float(NB_FFT))),
+                                sn * double(a.dd_terms_per_frame), a.dd_gate, st.total_frames_read == 0, steers ? st : scratch);
+        }
+        if (steers) {
             constexpr float HALF = 0.5f / float(NB_FFT);
             float f = st.fine_freq_offset - a.fine_beta * err;
             if (f > HALF) f -= 2.f * HALF;
@@ -533,6 +536,10 @@ __global__ __launch_bounds__(64) void track_start_kernel(StreamState *state, con
     st.fine_freq_offset = float(sf / sn);
     st.coarse_freq_offset = -float(fr[last].coarse_carriers) / float(NB_FFT);
     st.tracking = only_lost ? 2 : 1;
+    // (re)started from an acquisition: the decision-directed loop's gate is "pulling in" again -- its first estimate, on
+    // whatever branch, is believed (a branch 0 remembered from before the loss would hold a correct +-1 back once)
+    st.dd_branch = DD_NO_BRANCH;
+    st.dd_pending = DD_NO_BRANCH;
     st.total_frames_read += int(sn);
     st.last_time_offset = 0;
     st.last_peak_to_mean = fr[last].peak_to_mean;

@@ -47,7 +47,7 @@ EXPORTS = [
     "dabgpu_ofdm_demod_stream_frame", "dabgpu_ofdm_demod_frames_dd_dev",
 ]
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 PLACE_PLAIN, PLACE_DOMAINS = 0, 1
 PLAIN_REASONS = {0: "plain requested", 1: "buffers too small (or too many chunks) for placement", 2: "virtual-memory API refused",
                  3: "no room for the chunks", 4: "the context's domain-aware pair is still alive",

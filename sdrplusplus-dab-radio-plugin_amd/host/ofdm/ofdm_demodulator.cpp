@@ -159,6 +159,7 @@ void OFDM_Demod::demodulate_frame() {
     cfg.impulse_peak_distance_probability = m_cfg.sync.impulse_peak_distance_probability;
     cfg.coarse_freq_slow_beta = m_cfg.sync.coarse_freq_slow_beta;
     cfg.timing_margin = int(TIMING_MARGIN);
+    cfg.decision_directed = m_cfg.sync.is_decision_directed_fine_freq ? 1 : 0;     // default: the reference's cyclic-prefix loop
     cfg.max_coarse_carriers = 0;
     if (m_cfg.sync.is_coarse_freq_correction && (m_is_acquiring || m_cfg.sync.coarse_freq_slow_beta > 0.0f))
         cfg.max_coarse_carriers = std::min(1023, int(m_cfg.sync.max_coarse_freq_correction_norm * float(m_params.nb_fft)));

@@ -48,6 +48,11 @@ struct OFDM_Demod_Config {
         // taps of the channel impulse response are scored |h|^2 w^2, w = 1 - (1 - p) |offset - expected| / 2552
         // (dabgpu_track_cfg; the GUI's slider at src/render_radio_block.cpp:225)
         float impulse_peak_distance_probability = 0.15f;
+        // extension, OFF by default: false = the fine-frequency loop runs on the 76 cyclic-prefix correlations of the
+        // frame, the reference's estimator (fine_freq_update_beta, src/render_radio_block.cpp:216); true = on this
+        // library's decision-directed estimator (dabgpu_track_cfg.decision_directed: fourth powers of the differential
+        // symbols, only the PRS's prefix read)
+        bool is_decision_directed_fine_freq = false;
     } sync;
 };
 

@@ -54,12 +54,18 @@ _ORDERED = None
 
 
 def _ordered_context():
-    """dabgpu.Context whose device-pointer calls first wait for torch's stream.  The library's own stream is
-    non-blocking: a tensor a test has just created (its zero-fill, its random numbers) is written on torch's stream and
-    nothing orders a `_dev` call behind it.  Small test tensors are done long before Python gets to the call -- but that
-    is luck, and a large one loses the race (tools/decoder_fuzz.py did)."""
+    """dabgpu.Context whose device-pointer calls are ordered behind the HARNESS's producer, and nothing else.  The library's
+    own stream is non-blocking: a tensor a test has just created (its zero-fill, its random numbers) is written on torch's
+    current stream and nothing orders a `_dev` call behind it (small tensors are done long before Python gets to the call --
+    but that is luck; tools/decoder_fuzz.py lost that race with a large one).  So before each `_dev` call an event is
+    recorded on torch's current stream and the stream the call will run on -- the context's own, or the one the test
+    passes -- waits for it ON THE DEVICE.  No host synchronisation: two library calls a test issues in a row reach the
+    device back to back, so the ordering the library itself must provide between its calls (state events across caller
+    streams, shared scratch, ring hand-over) is still what the tests exercise (the round-4 wrapper called
+    torch.cuda.synchronize() here and hid all of that)."""
     global _ORDERED
     if _ORDERED is None:
+        import inspect
         import sys
         import dabgpu
 
@@ -70,7 +76,13 @@ def _ordered_context():
                     torch = sys.modules.get("torch")
                     if torch is not None and torch.cuda.is_available():
                         def ordered(*a, **kw):
-                            torch.cuda.synchronize()
+                            ev = torch.cuda.current_stream().record_event()
+                            target = None
+                            try:
+                                target = inspect.signature(attr).bind(*a, **kw).arguments.get("stream")
+                            except TypeError:
+                                pass
+                            torch.cuda.ExternalStream(target if target else super(OrderedContext, self).__getattribute__("stream")).wait_event(ev)
                             return attr(*a, **kw)
                         return ordered
                 return attr

@@ -16,7 +16,7 @@ def test_header_symbols_are_all_exported(built):
     L = dabgpu.lib()
     for sym in declared:
         assert hasattr(L, sym), sym
-    assert L.dabgpu_abi_version() == dabgpu.ABI_VERSION == 5
+    assert L.dabgpu_abi_version() == dabgpu.ABI_VERSION == 6
     # the binding declares every entry point's argument types (an undeclared pointer argument would be passed as a C int)
     assert [n for n in dabgpu.EXPORTS if getattr(L, n).argtypes is None] == []
 
@@ -45,6 +45,21 @@ def test_strerror_and_argument_errors(built):
     bad = dabgpu.Subchannel(0, 47, 0, 0, 3, 64)           # length does not match the profile
     assert L.dabgpu_subchannel_bytes(bad) == -5
     assert L.dabgpu_subchannel_bytes(dabgpu.Subchannel(850, 48, 0, 0, 3, 64)) == -1   # beyond CU 863
+
+
+def test_closed_loop_defaults_are_the_reference_estimator(built):
+    """every closed-loop entry point defaults to the loop the reference has -- the cyclic-prefix
+    correlations (fine_freq_update_beta, /root/reference/src/render_radio_block.cpp:216); this library's decision-directed
+    estimator is the opt-in, in the ABI (dabgpu_track_cfg.decision_directed, dabgpu_set_stream_loop) and in the host
+    mirror (OFDM_Demod_Config.sync.is_decision_directed_fine_freq)."""
+    assert dabgpu.track_cfg().decision_directed == 0
+    assert dabgpu.track_cfg().dd_gate == 2.5
+    import inspect
+    assert inspect.signature(dabgpu.Context.set_stream_loop).parameters["decision_directed"].default is False
+    hdr = open(os.path.join(ROOT, "sdrplusplus-dab-radio-plugin_amd", "host", "ofdm", "ofdm_demodulator.h")).read()
+    assert "bool is_decision_directed_fine_freq = false;" in hdr
+    src = open(os.path.join(ROOT, "sdrplusplus-dab-radio-plugin_amd", "host", "ofdm", "ofdm_demodulator.cpp")).read()
+    assert "cfg.decision_directed = m_cfg.sync.is_decision_directed_fine_freq ? 1 : 0;" in src
 
 
 def test_no_cpu_fallback(built):

@@ -75,6 +75,18 @@ def test_ring_equals_the_synchronous_calls(built, ensemble, ensemble_iq, slots):
                       [p_out.array[:4 * batch]])
     c.pipe_wait(t)
     assert (p_out.array[:4 * batch] == first).all()
+    # a sub-channel listed twice would share one ring (keyed by start and size): refused before any ring is touched, and
+    # the stream continues -- the second batch after the refusal equals the reference's second batch
+    with pytest.raises(dabgpu.DabGpuError) as e:
+        c.pipe_submit(p_iq.array[:batch], 1, batch, p_fo.array[:batch], [sc, sc], None, p_fib.array[:batch], p_ok.array[:batch],
+                      [p_out.array[:4 * batch], p_out.array[:4 * batch]])
+    assert e.value.status == -1
+    second = p_out.array[4 * batch:8 * batch].copy()
+    p_out.array[4 * batch:8 * batch] = 0
+    t = c.pipe_submit(p_iq.array[batch:2 * batch], 1, batch, p_fo.array[batch:2 * batch], [sc], None, p_fib.array[batch:2 * batch],
+                      p_ok.array[batch:2 * batch], [p_out.array[4 * batch:8 * batch]])
+    c.pipe_wait(t)
+    assert (p_out.array[4 * batch:8 * batch] == second).all()
     with pytest.raises(dabgpu.DabGpuError):
         c.pipe_wait(t + 1)                                       # never issued
     with pytest.raises(dabgpu.DabGpuError):

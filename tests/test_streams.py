@@ -382,3 +382,75 @@ def test_alloc_frame_buffers_by_domain(built, ensemble_iq):
     c.close()
     torch.cuda.synchronize()
     assert free0 - torch.cuda.mem_get_info()[0] <= 64 << 20
+
+
+@pytest.mark.parametrize("caller_stream", [False, True])
+def test_dev_calls_issued_back_to_back_without_a_host_sync(built, ensemble, ensemble_iq, caller_stream):
+    """the library's own ordering between calls must hold with NOTHING from the host in between.  Six stream
+    calls and six decode calls (state carried from call to call in HBM, the loop input in the context's shared scratch slot,
+    the de-interleaver history ping-ponged, batch sizes that grow so the scratch is re-allocated while earlier launches are
+    still in flight) are enqueued in one go -- on the context's own stream, or on a caller stream -- then the accessors
+    are called at once (dabgpu_get_stats waits for the last state use on its own).  Everything must equal the same sequence
+    run on a second context with a host synchronisation after every call."""
+    import torch
+    dev = torch.device("cuda", 0)
+    cfo = 0.23 / 2048
+    rx = _rx(ensemble_iq[:4], 16.0, cfo)
+    sizes = [1, 2, 4, 4, 2, 4]                                              # frames per call, one stream
+    sc = dabgpu.subchannel(0, 64, level=3)
+    d_rx = torch.from_numpy(rx).to(dev)
+    L = rx.shape[1]
+
+    def run(c, sync_each, stream):
+        c.streams_reset(1)
+        softs = [torch.zeros((n, dabgpu.NB_FRAME_BITS), dtype=torch.int8, device=dev) for n in sizes]
+        fibs = [torch.zeros((n, 12, 32), dtype=torch.uint8, device=dev) for n in sizes]
+        oks = [torch.zeros((n, 12), dtype=torch.uint8, device=dev) for n in sizes]
+        mscs = [torch.zeros((1, 4 * n, 192), dtype=torch.uint8, device=dev) for n in sizes]
+        hist = [torch.zeros((1, 15, sc.length * 64), dtype=torch.int8, device=dev) for _ in range(2)]
+        torch.cuda.synchronize()                                            # the HARNESS's buffers exist; from here on: no sync
+        for k, n in enumerate(sizes):
+            c.ofdm_demod_streams_dev(d_rx.data_ptr(), L, 1, n, 0.8, softs[k].data_ptr(), None, None, stream)
+            if sync_each:
+                torch.cuda.synchronize()
+            c.decode_frames_dev(softs[k].data_ptr(), dabgpu.NB_FRAME_BITS, 1, n, fibs[k].data_ptr(), oks[k].data_ptr(), [sc],
+                                [hist[k & 1].data_ptr()], [hist[(k & 1) ^ 1].data_ptr()], [mscs[k].data_ptr()], stream)
+            if sync_each:
+                torch.cuda.synchronize()
+        st = c.get_stats(0)                                                 # waits for the last state use by itself
+        torch.cuda.synchronize()
+        return st, [t.cpu().numpy() for t in softs + fibs + oks + mscs]
+
+    a, b = dabgpu.Context(device=0, max_frames=1), dabgpu.Context(device=0, max_frames=1)    # (plain contexts: no harness ordering at all)
+    s = torch.cuda.Stream(device=dev) if caller_stream else None
+    st_a, out_a = run(a, False, s.cuda_stream if s else None)
+    st_b, out_b = run(b, True, None)
+    assert st_a.total_frames_read == st_b.total_frames_read == sum(sizes)
+    assert st_a.fine_freq_offset == st_b.fine_freq_offset and st_a.signal_average == st_b.signal_average
+    assert abs(st_a.net_freq_offset + cfo) * 2048 < 0.02
+    for x, y in zip(out_a, out_b):
+        assert np.array_equal(x, y)
+    n = len(sizes)
+    assert out_a[2 * n + n - 1].all() and (out_a[n + n - 1][0] == ensemble.fibs[0]).all()      # the last call's FIBs: CRC-clean, the transmitted ones
+    a.close(); b.close()
+
+
+def test_stream_decoder_refuses_a_subchannel_listed_twice_and_keeps_its_state(built, ensemble, ensemble_iq):
+    """the kept de-interleaver rings are keyed by (start, size) -- a sub-channel listed twice (or two that
+    overlap) would share one ring and flip it twice, and the NEXT call would continue from a stale buffer.  Such a call is
+    refused with DABGPU_ERR_ARG before any ring is touched: the stream continues as if it had not been made."""
+    frames = _rx(ensemble_iq[:3], 16.0, 0.0)
+    c = make_ctx(None, 8)
+    soft, _, _ = c.ofdm_demod_frames(frames)
+    a = dabgpu.subchannel(ensemble.start_cu, 64, level=3)
+    over = dabgpu.subchannel(ensemble.start_cu + 10, 32, level=2)              # overlaps `a`
+    ref = c.decode_frames(soft, 1, [a])[2][0][0]
+    c.decode_stream_frames(soft[0:1], [a])
+    for bad in ([a, a], [a, over]):
+        with pytest.raises(dabgpu.DabGpuError) as e:
+            c.decode_stream_frames(soft[1:2], bad)
+        assert e.value.status == -1
+    out1 = c.decode_stream_frames(soft[1:2], [a])[2][0][0]
+    out2 = c.decode_stream_frames(soft[2:3], [a])[2][0][0]
+    assert (out1 == ref[4:8]).all() and (out2 == ref[8:12]).all()
+    c.close()

@@ -212,10 +212,10 @@ def test_gpu_tracked_call_equals_the_oracle(tctx):
 
 @pytest.mark.gpu
 def test_gpu_tracked_call_decision_directed_loop_equals_the_oracle(tctx):
-    """The tracked call's default fine loop (no correlation buffer passed): decision-directed, no cyclic prefix read.  The
-    state after the call equals oracle.track_update(dd=True) fed with the oracle's own dd4 sums of the frames the call
-    found; with cfg.decision_directed = 0 the same call runs on the cyclic-prefix correlations and lands within 1e-3
-    carriers of it."""
+    """The tracked call's opt-in fine loop (cfg.decision_directed = 1, no correlation buffer passed): decision-directed, no
+    cyclic prefix read.  The state after the call equals oracle.track_update(dd=True) fed with the oracle's own dd4 sums of
+    the frames the call found; with the default cfg (decision_directed = 0, the reference's estimator) the same call runs
+    on the cyclic-prefix correlations and lands within 1e-3 carriers of it."""
     import torch
     import dabgpu
     dev = torch.device("cuda", 0)
@@ -227,7 +227,9 @@ def test_gpu_tracked_call_decision_directed_loop_equals_the_oracle(tctx):
     soft = torch.zeros((MF, dabgpu.NB_FRAME_BITS), dtype=torch.int8, device=dev)
     fines = {}
     # ("gated": a quality gate nobody's sum can pass forces track_update_kernel's fall-back branch -- the PRS prefixes alone)
-    for name, cfg in (("dd", None), ("gated", dabgpu.track_cfg(dd_gate=500.0)), ("cp", dabgpu.track_cfg(decision_directed=0))):
+    assert dabgpu.track_cfg().decision_directed == 0          # the default is the reference's loop
+    for name, cfg in (("dd", dabgpu.track_cfg(decision_directed=1)), ("gated", dabgpu.track_cfg(decision_directed=1, dd_gate=500.0)),
+                      ("cp", None)):
         tctx.streams_reset(1)
         torch.cuda.synchronize()
         tctx.acquire_dev(d_x.data_ptr(), x.size, 1, n_cap, MF, frames.data_ptr(), counts.data_ptr())

@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: HBM traffic of the fused OFDM kernel from the TCC counters, in two PMC passes (FETCH_SIZE needs 3 of the
 # 4 TCC slots, WRITE_SIZE 2), calibrated on a 1 GiB device copy in the same process as MI355X_MICROARCH.md prescribes.
-n=${1:-1024}; mode=${2:-dd}
+n=${1:-1024}; mode=${2:-cp}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $root/gpurun_out; cd /tmp; export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do

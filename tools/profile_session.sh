@@ -12,7 +12,7 @@ tools/prof.sh $tag --legs none > $o/prof.log 2>&1
 cp gpurun_out/${tag}_kernel_stats.csv $o/kernel_stats.csv; grep "^{" gpurun_out/prof_${tag}_bench.log | tail -n 1 > $o/kernel_stats_bench_line.json
 cat $o/kernel_stats.csv
 # HBM bytes of the fused front end from the TCC counters (two --pmc passes, calibrated on a 1 GiB copy)
-tools/pmc_traffic.sh 16384 dd > $o/pmc_traffic.log 2>&1; cp gpurun_out/pmc_traffic.json $o/pmc_traffic.json; tail -n 8 $o/pmc_traffic.json
+tools/pmc_traffic.sh 16384 cp > $o/pmc_traffic.log 2>&1; cp gpurun_out/pmc_traffic.json $o/pmc_traffic.json; tail -n 8 $o/pmc_traffic.json
 # SQ / LDS counters of every kernel of a bench run
 tools/pmc_ofdm.sh $tag > $o/pmc_ofdm.log 2>&1; cp gpurun_out/pmc_ofdm_$tag/summary.md $o/pmc_ofdm_summary.md
 # the front end's structural variants, the decoder alone, the mover ceiling, the allocator beside a 100 GiB holder
