@@ -27,6 +27,8 @@
 #include "ofdm/dab_prs_ref.h"
 #include "ofdm/ofdm_demodulator.h"
 
+static constexpr float SAMPLING_RATE_HZ = 2.048e6f;   // the offsets are in cycles per sample (src/render_radio_block.cpp:202)
+
 int main(int argc, char **argv) {
     if (argc < 3) {
         std::fprintf(stderr, "usage: %s iq.cf32 out_prefix [chunk] [coarse] [bitrate start_cu level]\n", argv[0]);
@@ -147,8 +149,8 @@ int main(int argc, char **argv) {
     }
     std::printf("state=%d frames_read=%d frames_desync=%d fine=%.6g net=%.6g level=%.4f fibs=%d fib_errors=%d\n",
                 int(demod->GetState()), demod->GetTotalFramesRead(), demod->GetTotalFramesDesync(),
-                demod->GetFineFrequencyOffset() * OFDM_DEMOD_SAMPLING_RATE,
-                demod->GetNetFrequencyOffset() * OFDM_DEMOD_SAMPLING_RATE, demod->GetSignalAverage(),
+                demod->GetFineFrequencyOffset() * SAMPLING_RATE_HZ,
+                demod->GetNetFrequencyOffset() * SAMPLING_RATE_HZ, demod->GetSignalAverage(),
                 radio->GetTotalFIBs(), radio->GetTotalFIBErrors());
     return 0;
 }

@@ -27,7 +27,8 @@
 #include "utility/span.h"
 #include "viterbi_config.h"
 
-constexpr float OFDM_DEMOD_SAMPLING_RATE = 2.048e6f;   // src/render_radio_block.cpp:202
+// (No OFDM_DEMOD_SAMPLING_RATE here: the plugin's GUI defines that name itself, /root/reference/src/render_radio_block.cpp:62,
+// and must compile unchanged against this header -- tests/test_host_mirror.py.)
 
 struct OFDM_Demod_Config {
     struct {

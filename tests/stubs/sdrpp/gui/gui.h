@@ -5,4 +5,8 @@ struct Menu {
     void registerEntry(const std::string &, void (*)(void *), void * = nullptr, void * = nullptr) {}
 };
 extern Menu menu;
+struct WaterFall {
+    std::string selectedVFO;
+};
+extern WaterFall waterfall;
 }

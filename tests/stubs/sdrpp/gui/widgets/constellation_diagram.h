@@ -1,2 +1,10 @@
 #pragma once   // TEST-ONLY stub (see README.md)
-namespace ImGui { class ConstellationDiagram {}; }
+#include "dsp/stream.h"
+namespace ImGui {
+class ConstellationDiagram {
+public:
+    dsp::complex_t *acquireBuffer();
+    void releaseBuffer();
+    void draw();
+};
+}

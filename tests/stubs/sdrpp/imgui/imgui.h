@@ -1,2 +1,2 @@
 #pragma once   // TEST-ONLY stub (see README.md)
-namespace ImGui {}
+#include "../imgui.h"
