@@ -58,6 +58,18 @@ def test_reference_render_formatters_compile_unchanged(host_built):
     assert r.returncode == 0, r.stderr[-2000:]
 
 
+@pytest.mark.skipif(not os.path.exists("/root/reference/src/render_radio_block.cpp"), reason="reference not mounted")
+def test_reference_render_radio_block_compiles_unchanged(host_built):
+    """the plugin's 918-line GUI translation unit -- the one consumer of the mirror's read-only API
+    (OFDM_Demod::GetConfig / GetFrameDataVec / GetState / the seven scalars; BasicRadio::GetDatabase / GetDatabaseStatistics
+    / GetMiscInfo / GetMutex / Get_Audio_Channel / Get_Data_Packet_Channel; Basic_DAB_Plus_Channel::GetSuperFrameHeader /
+    Is*Error / GetDynamicLabel; Basic_DAB_Channel::GetAudioParams; Basic_Slideshow_Manager; AudioPipeline::get_global_gain;
+    the FM / DRM / link-service entities) -- compiles UNCHANGED against the mirror's headers.  ImGui, SDR++'s gui:: /
+    tuner:: and {fmt} are TEST-ONLY declarations under tests/stubs written from its call sites; syntax only."""
+    r = subprocess.run(["make", "-C", HOST, "check_reference_render_radio_block"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+
+
 @pytest.mark.gpu
 def test_c_abi_from_plain_c(host_built):
     exe = os.path.join(HOST, "c_abi_smoke")
