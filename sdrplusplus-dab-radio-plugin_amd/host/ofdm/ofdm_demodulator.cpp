@@ -7,6 +7,14 @@
 #include <cstring>
 #include <stdexcept>
 
+// one relaxed atomic read of a knob the GUI thread may be writing (GetConfig(): plain fields, see the header)
+template <class T>
+static inline T knob(const T &v) {
+    T out;
+    __atomic_load(&v, &out, __ATOMIC_RELAXED);
+    return out;
+}
+
 OFDM_Demod::OFDM_Demod(const OFDM_Params &params, tcb::span<const std::complex<float>> prs_fft_ref,
                        tcb::span<const int> carrier_mapper, int /*nb_desired_threads*/)
     : m_params(params), m_state(State::FINDING_NULL_POWER_DIP), m_ctx(nullptr) {
@@ -33,12 +41,23 @@ OFDM_Demod::OFDM_Demod(const OFDM_Params &params, tcb::span<const std::complex<f
     m_frame.resize(params.nb_frame_symbols * params.nb_symbol_period);
     m_soft.resize(size_t(params.nb_frame_symbols - 1) * params.nb_data_carriers * 2);
     m_frame_data_vec.resize(size_t(params.nb_frame_symbols - 1) * params.nb_data_carriers);
-    Reset();
+    reset_now();
 }
 
 OFDM_Demod::~OFDM_Demod() { dabgpu_destroy(m_ctx); }
 
+// Any thread (the GUI's "Reset" button, /root/reference/src/render_radio_block.cpp:95-97): what the getters show starts
+// over at once; the buffers and the device-side state start over on the Process thread, at the top of its next call.
 void OFDM_Demod::Reset() {
+    m_reset_requested.store(true, std::memory_order_release);
+    m_state = State::FINDING_NULL_POWER_DIP;
+    m_freq_fine_offset = 0.0f;
+    m_freq_coarse_offset = 0.0f;
+    m_total_frames_read = 0;
+    m_total_frames_desync = 0;
+}
+
+void OFDM_Demod::reset_now() {
     m_state = State::FINDING_NULL_POWER_DIP;
     m_signal_l1_average = 0.0f;
     m_in_null = false;
@@ -60,6 +79,7 @@ void OFDM_Demod::Reset() {
 }
 
 void OFDM_Demod::Process(tcb::span<const std::complex<float>> block) {
+    if (m_reset_requested.exchange(false, std::memory_order_acquire)) reset_now();
     const std::complex<float> *x = block.data();
     size_t n = block.size();
     // feed whole L1 blocks; keep the remainder for the next call (chunks are arbitrary, dab_module.cpp:23-25)
@@ -108,17 +128,18 @@ void OFDM_Demod::push_sample_block(const std::complex<float> *x, size_t n) {
     if (m_history.size() > keep) m_history.erase(m_history.begin(), m_history.end() - keep);
 
     if (!m_in_null) {
-        if (m_signal_l1_average > 0.0f && l1 < m_cfg.null_l1_search.thresh_null_start * m_signal_l1_average) {
+        const float avg = m_signal_l1_average;
+        if (avg > 0.0f && l1 < knob(m_cfg.null_l1_search.thresh_null_start) * avg) {
             m_in_null = true;
             m_null_blocks = 1;
             m_state = State::READING_NULL_AND_PRS;
         } else {
-            const float beta = m_cfg.signal_l1.update_beta;
-            m_signal_l1_average = (m_signal_l1_average == 0.0f) ? l1 : beta * m_signal_l1_average + (1.0f - beta) * l1;
+            const float beta = knob(m_cfg.signal_l1.update_beta);
+            m_signal_l1_average = (avg == 0.0f) ? l1 : beta * avg + (1.0f - beta) * l1;
         }
         return;
     }
-    if (l1 > m_cfg.null_l1_search.thresh_null_end * m_signal_l1_average) {
+    if (l1 > knob(m_cfg.null_l1_search.thresh_null_end) * m_signal_l1_average) {
         // the PRS began somewhere inside this block (or the previous one): start TIMING_MARGIN samples
         // before the START of this block
         m_in_null = false;
@@ -152,24 +173,26 @@ void OFDM_Demod::demodulate_frame() {
     m_next_skip = m_params.nb_null_period;
     dabgpu_track_cfg cfg;
     dabgpu_track_default_cfg(&cfg);
-    cfg.fine_freq_update_beta = m_cfg.sync.fine_freq_update_beta;
-    cfg.signal_update_beta = m_cfg.signal_l1.update_beta;
-    cfg.thr_null_start = m_cfg.null_l1_search.thresh_null_start;
-    cfg.min_peak_to_mean = std::pow(10.0f, 0.1f * m_cfg.sync.impulse_peak_threshold_db);
-    cfg.impulse_peak_distance_probability = m_cfg.sync.impulse_peak_distance_probability;
-    cfg.coarse_freq_slow_beta = m_cfg.sync.coarse_freq_slow_beta;
+    // (every knob read once: the GUI thread may be moving a slider)
+    auto unit = [](float v) { return std::min(1.0f, std::max(0.0f, v)); };
+    cfg.fine_freq_update_beta = unit(knob(m_cfg.sync.fine_freq_update_beta));
+    cfg.signal_update_beta = unit(knob(m_cfg.signal_l1.update_beta));
+    cfg.thr_null_start = unit(knob(m_cfg.null_l1_search.thresh_null_start));
+    cfg.min_peak_to_mean = std::pow(10.0f, 0.1f * knob(m_cfg.sync.impulse_peak_threshold_db));
+    cfg.impulse_peak_distance_probability = unit(knob(m_cfg.sync.impulse_peak_distance_probability));
+    cfg.coarse_freq_slow_beta = unit(knob(m_cfg.sync.coarse_freq_slow_beta));
     cfg.timing_margin = int(TIMING_MARGIN);
-    cfg.decision_directed = m_cfg.sync.is_decision_directed_fine_freq ? 1 : 0;     // default: the reference's cyclic-prefix loop
+    cfg.decision_directed = knob(m_cfg.sync.is_decision_directed_fine_freq) ? 1 : 0;   // default: the reference's cyclic-prefix loop
     cfg.max_coarse_carriers = 0;
-    if (m_cfg.sync.is_coarse_freq_correction && (m_is_acquiring || m_cfg.sync.coarse_freq_slow_beta > 0.0f))
-        cfg.max_coarse_carriers = std::min(1023, int(m_cfg.sync.max_coarse_freq_correction_norm * float(m_params.nb_fft)));
+    if (knob(m_cfg.sync.is_coarse_freq_correction) && (m_is_acquiring || cfg.coarse_freq_slow_beta > 0.0f))
+        cfg.max_coarse_carriers = std::max(0, std::min(1023, int(knob(m_cfg.sync.max_coarse_freq_correction_norm) * float(m_params.nb_fft))));
     m_state = m_is_acquiring ? State::RUNNING_COARSE_FREQ_SYNC : State::RUNNING_FINE_TIME_SYNC;
     dabgpu_frame_result res{};
     const int rc = dabgpu_ofdm_demod_stream_frame(m_ctx, 0, reinterpret_cast<const float *>(m_frame.data()), m_is_acquiring ? 1 : 0,
                                                   &cfg, m_soft.data(), reinterpret_cast<float *>(m_frame_data_vec.data()), &res);
     if (rc != DABGPU_OK) {   // no exceptions on the streaming path: count it as a lost frame
         m_host_desyncs++;
-        m_total_frames_desync++;
+        m_total_frames_desync.fetch_add(1, std::memory_order_relaxed);
         m_state = State::FINDING_NULL_POWER_DIP;
         m_in_null = false;
         return;

@@ -16,7 +16,17 @@
 // frame.  The frame and soft-bit buffers are page-locked (dabgpu_host_alloc).  Differential
 // demodulation is insensitive to a constant timing offset inside the cyclic prefix, so the FFT windows are kept
 // `TIMING_MARGIN` samples early.
+//
+// Threads (the GUI polls this object lock-free while the OFDM thread runs Process): every scalar a getter
+// returns is a relaxed std::atomic written by the Process thread; Reset() may be called from any thread -- it only raises
+// a flag, the Process thread starts over at the top of its next call (the buffers it would have to clear are that
+// thread's); the knobs of GetConfig() are plain fields the GUI writes through ImGui's float* / bool* -- Process reads each
+// of them ONCE per use with a relaxed atomic load, so a torn or half-updated configuration cannot be observed;
+// GetFrameDataVec() is display-only data that the next frame overwrites (as upstream's: it may tear, nothing else).
+// tests/test_host_sanitizers.py runs the plugin's wiring under ThreadSanitizer and ASan / UBSan with a third thread
+// hammering all of this.
 #pragma once
+#include <atomic>
 #include <complex>
 #include <cstdint>
 #include <vector>
@@ -77,25 +87,26 @@ public:
     void Reset();
 
     OFDM_Params GetOFDMParams() const { return m_params; }
-    State GetState() const { return m_state; }
-    float GetFineFrequencyOffset() const { return m_freq_fine_offset; }
-    float GetCoarseFrequencyOffset() const { return m_freq_coarse_offset; }
-    float GetNetFrequencyOffset() const { return m_freq_fine_offset + m_freq_coarse_offset; }
-    float GetSignalAverage() const { return m_signal_l1_average; }
-    int GetTotalFramesRead() const { return m_total_frames_read; }
-    int GetTotalFramesDesync() const { return m_total_frames_desync; }
+    State GetState() const { return m_state.load(std::memory_order_relaxed); }
+    float GetFineFrequencyOffset() const { return m_freq_fine_offset.load(std::memory_order_relaxed); }
+    float GetCoarseFrequencyOffset() const { return m_freq_coarse_offset.load(std::memory_order_relaxed); }
+    float GetNetFrequencyOffset() const { return GetFineFrequencyOffset() + GetCoarseFrequencyOffset(); }
+    float GetSignalAverage() const { return m_signal_l1_average.load(std::memory_order_relaxed); }
+    int GetTotalFramesRead() const { return m_total_frames_read.load(std::memory_order_relaxed); }
+    int GetTotalFramesDesync() const { return m_total_frames_desync.load(std::memory_order_relaxed); }
     OFDM_Demod_Config &GetConfig() { return m_cfg; }
     tcb::span<const std::complex<float>> GetFrameDataVec() const { return {m_frame_data_vec.data(), m_frame_data_vec.size()}; }
     Observable<tcb::span<const viterbi_bit_t>> &On_OFDM_Frame() { return m_obs_on_ofdm_frame; }
 
     // extension: apply a known coarse offset (cycles/sample); it goes to the device-side state the demodulation reads
-    // (with is_coarse_freq_correction on, the next acquisition overwrites it)
+    // (with is_coarse_freq_correction on, the next acquisition overwrites it).  Process thread / before streaming only:
+    // it talks to the context.
     void SetCoarseFrequencyOffset(float f) {
-        m_freq_coarse_offset = f;
+        m_freq_coarse_offset.store(f, std::memory_order_relaxed);
         (void)dabgpu_set_stream_offsets(m_ctx, 0, nullptr, &f);
     }
-    int GetFineTimeOffset() const { return m_last_time_offset; }
-    float GetImpulsePeakDb() const { return m_last_peak_db; }
+    int GetFineTimeOffset() const { return m_last_time_offset.load(std::memory_order_relaxed); }
+    float GetImpulsePeakDb() const { return m_last_peak_db.load(std::memory_order_relaxed); }
 
 private:
     static constexpr size_t L1_BLOCK = 64;         // power measured in blocks of 64 samples
@@ -103,13 +114,15 @@ private:
 
     void push_sample_block(const std::complex<float> *x, size_t n);
     void demodulate_frame();
+    void reset_now();                               // on the Process thread (or before it exists)
 
     const OFDM_Params m_params;
     OFDM_Demod_Config m_cfg;
-    State m_state;
+    std::atomic<State> m_state;
+    std::atomic<bool> m_reset_requested{false};
     dabgpu_ctx *m_ctx;
     // sync state
-    float m_signal_l1_average;
+    std::atomic<float> m_signal_l1_average;
     bool m_in_null;
     size_t m_null_blocks;
     std::vector<std::complex<float>> m_history;     // last TIMING_MARGIN + block samples, to start a frame early
@@ -118,12 +131,12 @@ private:
     size_t m_skip;                                  // samples to drop before the next frame starts
     size_t m_next_skip;                             // null-symbol gap to the next frame incl. timing correction
     bool m_is_acquiring;                            // first frame after a null detection: coarse sync + lock check
-    int m_last_time_offset;
-    float m_last_peak_db;
+    std::atomic<int> m_last_time_offset;
+    std::atomic<float> m_last_peak_db;
     std::vector<std::complex<float>> m_carry;       // partial L1 block between Process calls
     // tracking
-    float m_freq_fine_offset, m_freq_coarse_offset;
-    int m_total_frames_read, m_total_frames_desync;
+    std::atomic<float> m_freq_fine_offset, m_freq_coarse_offset;
+    std::atomic<int> m_total_frames_read, m_total_frames_desync;
     int m_host_desyncs = 0;            // lost frames the device never saw (failed calls)
     int m_device_desyncs_seen = 0;
     // outputs
