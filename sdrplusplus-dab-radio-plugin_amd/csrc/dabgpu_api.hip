@@ -31,6 +31,18 @@ int build_device_code(DeviceCode &dc) {
     if (int(pos.size()) != dc.prof.n_punct) return DABGPU_ERR_PROFILE;
     int rc = DABGPU_OK;
     if (dabk::viterbi_fits(dc.prof.nsteps)) {                  // (only the wave-per-codeword kernels read this table)
+        // ... and behind it, for codewords of 96 k + 6 steps, where each 96-step chunk's punctured bits begin (CodeTables)
+        const int n_punct = dc.prof.n_punct, nsteps = dc.prof.nsteps;
+        if (nsteps >= 102 && (nsteps - 6) % 96 == 0) {
+            const int k = (nsteps - 6) / 96;
+            pos.resize(size_t(dabk::code_chunk_table_offset(n_punct)), 0);
+            for (int c = 0; c <= k; c++) {
+                int below = 0;
+                while (below < n_punct && int(pos[size_t(below)]) < 4 * 96 * c) below++;
+                pos.push_back(uint16_t(below));
+            }
+            pos.push_back(uint16_t(n_punct));
+        }
         if ((rc = upload(&dc.d_mother_pos, pos))) return rc;
     }
     std::vector<int32_t> pidx(dc.prof.mask.size(), -1);
@@ -319,6 +331,8 @@ void dabgpu_destroy(dabgpu_ctx *ctx) {
     pipeline_destroy(ctx);
     arena_destroy(ctx);
     if (ctx->ev_states) (void)hipEventDestroy(ctx->ev_states);
+    if (ctx->ev_aux) (void)hipEventDestroy(ctx->ev_aux);
+    if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     }
     delete ctx;
@@ -1023,7 +1037,8 @@ static int tracked_launches(dabgpu_ctx *ctx, dabk::StreamState *states, const vo
                             int64_t n_samples, int max_frames, int64_t advance, const dabgpu_track_cfg &c, int fixed_start,
                             int acquiring, int8_t *d_soft, void *d_cyc, void *d_dqpsk, dabgpu_acquired_frame *d_frames,
                             dabgpu_sync_result *d_sync, int32_t *d_counts, hipStream_t s, const dabk::AcquireArgs *auto_acq = nullptr,
-                            void *d_dd4 = nullptr) {
+                            void *d_dd4 = nullptr, const void *sync_iq = nullptr, hipStream_t sync_stream = nullptr,
+                            bool note_states = true) {
     dabk::SyncTables stab{ctx->d_twiddle, ctx->d_prs_qt, ctx->d_sync_pairs, ctx->n_sync_pairs, ctx->d_sync_fs};
     dabk::TrackArgs t{};
     t.state = states;
@@ -1042,7 +1057,17 @@ static int tracked_launches(dabgpu_ctx *ctx, dabk::StreamState *states, const vo
     t.coarse_slow_beta = c.coarse_freq_slow_beta;
     t.out = reinterpret_cast<dabk::AcquiredFrame *>(d_frames);
     t.sync_out = reinterpret_cast<dabk::SyncResult *>(d_sync);
-    HIP_TRY(dabk::launch_track_sync(stab, t, s));
+    if (sync_stream && sync_stream != s) {
+        // the synchronisation reads its PRS from `sync_iq` (the caller's page-locked frame itself) on a stream of its own,
+        // beside whatever `s` is doing meanwhile (the frame's upload); `s` goes on once it is done
+        t.iq = static_cast<const float2 *>(sync_iq);
+        HIP_TRY(dabk::launch_track_sync(stab, t, sync_stream));
+        HIP_TRY(hipEventRecord(ctx->ev_aux, sync_stream));
+        HIP_TRY(hipStreamWaitEvent(s, ctx->ev_aux, 0));
+        t.iq = static_cast<const float2 *>(d_iq);
+    } else {
+        HIP_TRY(dabk::launch_track_sync(stab, t, s));
+    }
     // streams that are not tracking: acquired here (their rows of d_frames / d_counts; the pass above left them empty)
     if (auto_acq) HIP_TRY(dabk::launch_acquire(stab, *auto_acq, s));
     dabk::OfdmTables tab{ctx->d_twiddle, ctx->d_bin_of_n, ctx->d_n_of_vj};
@@ -1086,7 +1111,7 @@ static int tracked_launches(dabgpu_ctx *ctx, dabk::StreamState *states, const vo
     if (auto_acq)
         HIP_TRY(dabk::launch_track_start(states, t.out, d_counts, n_streams, max_frames, advance, 1, s));
     HIP_TRY(dabk::launch_track_update(u, s));
-    return note_state_use(ctx, s);
+    return note_states ? note_state_use(ctx, s) : DABGPU_OK;
 }
 
 int dabgpu_ofdm_demod_tracked_dev(dabgpu_ctx *ctx, const void *d_iq, size_t stream_stride, int n_streams,
@@ -1164,6 +1189,15 @@ int dabgpu_ofdm_demod_stream_frame(dabgpu_ctx *ctx, int stream_index, const floa
     HIP_TRY(hipHostGetDevicePointer(&h_dev, ctx->h_bounce, 0));
     void *iq_alias = device_alias_of_pinned(iq), *soft_alias = device_alias_of_pinned(soft);
     if ((reinterpret_cast<uintptr_t>(iq_alias) | reinterpret_cast<uintptr_t>(soft_alias)) & 15) iq_alias = soft_alias = nullptr;
+    if (iq_alias && !ctx->aux_stream) {
+        if (hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->ev_aux, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
+            ctx->aux_stream = nullptr;
+            ctx->ev_aux = nullptr;
+        }
+    }
     if (iq_alias) {
         const dabk::CopyPiece up{d_iq, iq_alias, nb_iq};
         HIP_TRY(dabk::launch_copy_pieces(&up, 1, s));
@@ -1171,15 +1205,22 @@ int dabgpu_ofdm_demod_stream_frame(dabgpu_ctx *ctx, int stream_index, const floa
         HIP_TRY(hipMemcpyAsync(d_iq, iq, nb_iq, hipMemcpyHostToDevice, s));
     }
     dabk::StreamState *st = ctx->d_states + stream_index;
+    // Page-locked buffers (the host mirror's): the 1.55 MB upload is the longest single piece of the call, and the PRS
+    // synchronisation only needs the frame's first symbol -- it reads those 20 KB straight from the caller's buffer on a
+    // second stream while the upload runs; the demodulation then writes the soft bits straight into the caller's buffer
+    // (no second copy of 230 kB behind it), and the call ends in its own synchronisation, so no state event is recorded.
+    const bool beside = iq_alias && ctx->aux_stream;
+    int8_t *soft_dst = soft_alias ? static_cast<int8_t *>(soft_alias) : reinterpret_cast<int8_t *>(res);
     rc = tracked_launches(ctx, st, d_iq, nb_iq / sizeof(float2), 1, int64_t(nb_iq / sizeof(float2)), 1, 0, c, 1, acquiring ? 1 : 0,
-                          reinterpret_cast<int8_t *>(res), d_cyc, d_dq, reinterpret_cast<dabgpu_acquired_frame *>(res + off_fr),
-                          reinterpret_cast<dabgpu_sync_result *>(res + off_sy), nullptr, s, nullptr, d_dd);
+                          soft_dst, d_cyc, d_dq, reinterpret_cast<dabgpu_acquired_frame *>(res + off_fr),
+                          reinterpret_cast<dabgpu_sync_result *>(res + off_sy), nullptr, s, nullptr, d_dd, beside ? iq_alias : nullptr,
+                          beside ? ctx->aux_stream : nullptr, false);
     if (rc) return rc;
-    // one download, written by a kernel right behind the others: soft bits, frame and sync records, then the state
+    // one download, written by a kernel right behind the others: (the soft bits, unless they are already there,) the frame
+    // and sync records, then the state
     static_assert(sizeof(dabk::StreamState) % 16 == 0, "the state goes out in 16-byte words");
-    // (the soft bits straight into the caller's buffer when that is page-locked too: no copy by the CPU afterwards)
     char *hd = static_cast<char *>(h_dev);
-    const dabk::CopyPiece down[3] = {{soft_alias ? soft_alias : static_cast<void *>(hd), d_res, size_t(NB_FRAME_BITS)},
+    const dabk::CopyPiece down[3] = {{hd, d_res, soft_alias ? size_t(0) : size_t(NB_FRAME_BITS)},
                                      {hd + off_fr, res + off_fr, off_st - off_fr},
                                      {hd + off_st, st, sizeof(dabk::StreamState)}};
     HIP_TRY(dabk::launch_copy_pieces(down, 3, s));

@@ -23,7 +23,9 @@ struct DeviceCode {
     int32_t *d_fused_desc = nullptr, *d_fused_tiles = nullptr;   // fused lane forward pass (build_lane_fused_tables)
     dabk::LaneTables lane_tables() const { return dabk::LaneTables{d_punct_idx, d_fused_desc, d_fused_tiles}; }
     dabk::CodeTables tables(bool descramble) const {
-        return dabk::CodeTables{d_mother_pos, prof.n_punct, prof.nsteps, descramble ? d_prbs : nullptr};
+        const bool chunked = d_mother_pos && prof.nsteps >= 102 && (prof.nsteps - 6) % 96 == 0;
+        return dabk::CodeTables{d_mother_pos, prof.n_punct, prof.nsteps, descramble ? d_prbs : nullptr,
+                                chunked ? d_mother_pos + dabk::code_chunk_table_offset(prof.n_punct) : nullptr};
     }
 };
 
@@ -59,6 +61,10 @@ struct dabgpu_ctx {
     int device = 0;
     int max_frames = 0;
     hipStream_t stream = nullptr;
+    // the one-frame call (dabgpu_ofdm_demod_stream_frame) runs the PRS synchronisation beside the frame's upload: a
+    // second stream and the event that joins it (created by the first such call)
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_aux = nullptr;
     float2 *d_twiddle = nullptr;
     uint16_t *d_bin_of_n = nullptr;
     uint16_t *d_n_of_vj = nullptr;

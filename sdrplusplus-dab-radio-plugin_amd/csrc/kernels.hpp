@@ -88,7 +88,8 @@ struct CopyPiece {
     const void *src;
     size_t bytes;
 };
-hipError_t launch_copy_pieces(const CopyPiece *pieces, int n, hipStream_t s);
+hipError_t launch_copy_pieces(const CopyPiece *pieces, int n, hipStream_t s);   // n <= copy_pieces_max()
+int copy_pieces_max();
 // reads `in` and writes `out` at the same time (streaming, both whole): the launch is slower when the two buffers
 // share an HBM domain -- what the placement helpers time
 hipError_t launch_placement_probe(const void *in, size_t in_bytes, void *out, size_t out_bytes, hipStream_t s);
@@ -296,7 +297,13 @@ struct CodeTables {
     int n_punct;
     int nsteps;                  // trellis steps (info bits + 6)
     const uint8_t *prbs_bytes;   // [(nsteps-6)/8] energy-dispersal bytes, or nullptr = no descramble
+    // codewords of 96 k + 6 steps (the rot kernel's): [k + 2] -- chunk_first[c] = punctured bits whose mother position lies
+    // below step 96 c (c <= k), chunk_first[k + 1] = n_punct: the punctured bits of the 96-step chunk c are
+    // [chunk_first[c], chunk_first[c + 1]), the last entry's the six tail steps'.  nullptr for other lengths.
+    const uint16_t *chunk_first = nullptr;
 };
+// where build_device_code puts the chunk table: behind the positions, in the same allocation
+__host__ __device__ inline int code_chunk_table_offset(int n_punct) { return (n_punct + 7) & ~7; }
 
 // A8..A11: FIC of n_frames frames.
 hipError_t launch_fic_decode(const CodeTables &c, const int8_t *soft, size_t soft_stride, int n_frames,

@@ -715,23 +715,26 @@ hipError_t launch_placement_probe(const void *in, size_t in_bytes, void *out, si
 }
 
 namespace {
+constexpr int COPY_PIECES_MAX = 24;
 struct CopyPieces16 {
-    uint4 *dst[3];
-    const uint4 *src[3];
-    unsigned n[3];                                             // in 16-byte words
+    uint4 *dst[COPY_PIECES_MAX];
+    const uint4 *src[COPY_PIECES_MAX];
+    unsigned n[COPY_PIECES_MAX];                               // in 16-byte words
+    int count;
 };
 __global__ __launch_bounds__(256) void copy_pieces_kernel(CopyPieces16 p) {
     unsigned i = blockIdx.x * 256u + threadIdx.x;
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
+    for (int k = 0; k < p.count; k++) {
         if (i < p.n[k]) { p.dst[k][i] = p.src[k][i]; return; }
         i -= p.n[k];
     }
 }
 }  // namespace
 
+int copy_pieces_max() { return COPY_PIECES_MAX; }
+
 hipError_t launch_copy_pieces(const CopyPiece *pieces, int n, hipStream_t s) {
-    if (n < 0 || n > 3) return hipErrorInvalidValue;
+    if (n < 0 || n > COPY_PIECES_MAX) return hipErrorInvalidValue;
     CopyPieces16 p{};
     unsigned total = 0;
     for (int k = 0; k < n; k++) {
@@ -739,10 +742,11 @@ hipError_t launch_copy_pieces(const CopyPiece *pieces, int n, hipStream_t s) {
         if (c.bytes == 0) continue;
         if ((c.bytes & 15) || ((reinterpret_cast<uintptr_t>(c.dst) | reinterpret_cast<uintptr_t>(c.src)) & 15) || (c.bytes >> 4) > 0x7fffffffu)
             return hipErrorInvalidValue;
-        p.dst[k] = static_cast<uint4 *>(c.dst);
-        p.src[k] = static_cast<const uint4 *>(c.src);
-        p.n[k] = unsigned(c.bytes >> 4);
-        total += p.n[k];
+        p.dst[p.count] = static_cast<uint4 *>(c.dst);
+        p.src[p.count] = static_cast<const uint4 *>(c.src);
+        p.n[p.count] = unsigned(c.bytes >> 4);
+        total += p.n[p.count];
+        p.count++;
     }
     if (total == 0) return hipSuccess;
     hipLaunchKernelGGL(copy_pieces_kernel, dim3((total + 255) / 256), dim3(256), 0, s, p);

@@ -78,6 +78,18 @@ struct FetchMsc {
         if (!hist) return 0;
         return hist[(size_t(s) * 15 + (15 + src)) * nbits + i];
     }
+    // the same as an address, branch-free (for loads that are issued long before their values are used): `erased` = there
+    // is no such byte (a CIF before the call and no history), the address is then just a valid one
+    __device__ __forceinline__ const int8_t *addr(int cw, int i, bool &erased) const {
+        const int cifs = frames_per_stream * NB_CIFS;
+        const int s = cw / cifs, t = cw - s * cifs;
+        const int src = t - 15 + int(__brev(unsigned(i) & 15u) >> 28);
+        const size_t f = size_t(s) * frames_per_stream + size_t(max(src, 0) >> 2);
+        const int8_t *from_soft = soft + f * stride + NB_FIC_BITS + size_t(max(src, 0) & 3) * NB_CIF_BITS + start_bit + i;
+        const int8_t *from_hist = hist ? hist + (size_t(s) * 15 + size_t(15 + min(src, -1))) * nbits + i : from_soft;
+        erased = src < 0 && !hist;
+        return src >= 0 ? from_soft : from_hist;
+    }
 };
 
 enum class Tail { kBytes, kFic };
@@ -324,20 +336,30 @@ __device__ __forceinline__ void rot_decode(const Fetch &fetch, const CodeTables 
             }
         }
     }
+    // The sub-channel's gather -- every byte from one of sixteen CIFs, latency-bound: 13-20 us of an 80 us call when done
+    // up front -- runs BESIDE the forward pass instead: only the punctured bits of the first two 96-step chunks are fetched
+    // before the first step; at the top of chunk c the loads of chunk c + 2 are issued, at its bottom (2 us of add-compare-
+    // select later) they are scattered into the codeword in LDS, one chunk before the forward pass reads them (it fetches
+    // its soft words one phase cycle ahead: chunk c's last cycle already touches chunk c + 1).  CodeTables::chunk_first
+    // says where a chunk's punctured bits begin.
+    constexpr bool kStream = Fetch::kBatch > 1;
+    constexpr int RB = 6;                                      // loads per lane per chunk: 96 steps keep at most 384 bits
+    const bool stream = kStream && !wide && code.chunk_first != nullptr;
+    const int gather_end = stream ? int(code.chunk_first[min(2, nchunks + 1)]) : code.n_punct;
     if (!wide) {
         if constexpr (Fetch::kBatch > 1) {
             // the de-interleaver's bytes come from sixteen CIFs at once: eight of them (and their positions) in flight per lane
-            for (int i0 = lane; i0 < code.n_punct; i0 += 64 * Fetch::kBatch) {
+            for (int i0 = lane; i0 < gather_end; i0 += 64 * Fetch::kBatch) {
                 int8_t v[Fetch::kBatch];
                 uint16_t pos[Fetch::kBatch];
 #pragma unroll
                 for (int u = 0; u < Fetch::kBatch; u++) {
                     const int i = i0 + 64 * u;
-                    if (i < code.n_punct) { v[u] = fetch(cw, i); pos[u] = code.mother_pos[i]; }
+                    if (i < gather_end) { v[u] = fetch(cw, i); pos[u] = code.mother_pos[i]; }
                 }
 #pragma unroll
                 for (int u = 0; u < Fetch::kBatch; u++)
-                    if (i0 + 64 * u < code.n_punct) mother[pos[u]] = v[u];
+                    if (i0 + 64 * u < gather_end) mother[pos[u]] = v[u];
             }
         } else {
             for (int i = lane; i < code.n_punct; i += 64) mother[code.mother_pos[i]] = fetch(cw, i);
@@ -376,8 +398,31 @@ __device__ __forceinline__ void rot_decode(const Fetch &fetch, const CodeTables 
     int wc[6];
 #pragma unroll
     for (int ph = 0; ph < 6; ph++) wc[ph] = m4[ph];
+    int8_t gv[RB];
+    uint16_t gp[RB];
+    unsigned g_skip = 0;                                       // bit u: load u of the batch in flight carries nothing
     for (int c = 0; c < nchunks; c++) {
         const int *mw = m4 + 96 * c;
+        int g_lo = 0, g_hi = 0;                                // punctured bits of chunk c + 2 (the last one: + the tail's)
+        if constexpr (kStream) {
+            if (stream && c + 2 <= nchunks) {
+                g_lo = int(code.chunk_first[c + 2]);
+                g_hi = int(code.chunk_first[c + 3 <= nchunks + 1 ? c + 3 : nchunks + 1]);
+                // (straight-line: every lane loads from a valid address -- its own, or the chunk's last one -- and decides
+                // at the bottom of the chunk what to keep; a branch around a load would bring its s_waitcnt up here)
+                g_skip = 0;
+#pragma unroll
+                for (int u = 0; u < RB; u++) {
+                    const int i = g_lo + lane + 64 * u;
+                    const int ic = min(i, g_hi - 1);
+                    bool erased = false;
+                    if constexpr (kStream) gv[u] = *fetch.addr(cw, ic, erased);
+                    gp[u] = code.mother_pos[ic];
+                    g_skip |= unsigned(i >= g_hi || erased) << u;
+                }
+                __builtin_amdgcn_sched_barrier(0);             // the loads leave before the chunk's first step, not after its last
+            }
+        }
 #define DAB_ROT_METRIC(I, PH)                                                                    \
         constexpr int j##PH = 6 * (I) + (PH);                                                    \
         const int c##PH = __builtin_amdgcn_sdot4(T.tab_cs[PH], wc[PH], 0, false);                \
@@ -400,6 +445,17 @@ __device__ __forceinline__ void rot_decode(const Fetch &fetch, const CodeTables 
 #undef DAB_ROT_CYCLE
 #undef DAB_ROT_STEP
 #undef DAB_ROT_METRIC
+        if constexpr (kStream) {
+            if (stream && c + 2 <= nchunks) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < RB; u++)
+                    if (!((g_skip >> u) & 1u)) mother[gp[u]] = gv[u];
+                // (wave-private LDS: the wave's own DS operations execute in order; the fences pin the compiler's)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        }
     }
     {   // the six tail steps (zero tail bits): one more phase cycle (its words came with the last cycle above)
         dec = 0;
