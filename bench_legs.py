@@ -354,52 +354,7 @@ def single_ensemble_leg(B):
             t_fe += ev[0].elapsed_time(ev[1]); t_dec += ev[1].elapsed_time(ev[2])
         row["front_end_call_ms"], row["decode_call_ms"] = t_fe / steps, t_dec / steps
         res[name] = row
-    # ---- the same two calls as the plugin runs them: on two threads with a 2-frame ring between them
-    # (/root/reference/src/radio_block.cpp:23-44) -- here two contexts (as the host mirror holds them: one for OFDM_Demod,
-    # one for BasicRadio), two streams and two soft-bit buffers: batch k is decoded while batch k+1 is demodulated.  Neither
-    # call fills the chip at 256 frames (both are latency-bound), so they overlap almost completely.
-    c2 = dabgpu.Context(device=B.dev_index, max_frames=F)
-    c1.set_stream_loop(decision_directed=False)
-    s_fe, s_dec = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
-    soft2 = [soft, B.soft[F:2 * F] if B.n_frames >= 2 * F else torch.empty_like(soft)]
-    fib.zero_(); crc.zero_(); msc.zero_()
-    for h in hist:
-        h.zero_()
-    torch.cuda.synchronize()
-
-    def piped(n_steps, k0):
-        demod_done = [torch.cuda.Event(), torch.cuda.Event()]
-        decoded = [None, None]
-        for k in range(n_steps):
-            b = k & 1
-            with torch.cuda.stream(s_fe):
-                if decoded[b] is not None:
-                    s_fe.wait_event(decoded[b])                 # the decoder has finished reading this buffer (two batches ago)
-                c1.ofdm_demod_streams_dev(B.d_iq, L, 1, F, B.BETA, soft2[b].data_ptr(), None, None, s_fe.cuda_stream)
-                demod_done[b].record(s_fe)
-            with torch.cuda.stream(s_dec):
-                s_dec.wait_event(demod_done[b])
-                kk = k0 + k
-                c2.decode_frames_dev(soft2[b].data_ptr(), dabgpu.NB_FRAME_BITS, 1, F, fib.data_ptr(), crc.data_ptr(), [B.sc],
-                                     [hist[kk & 1].data_ptr()], [hist[(kk & 1) ^ 1].data_ptr()], [msc.data_ptr()], s_dec.cuda_stream)
-                decoded[b] = torch.cuda.Event()
-                decoded[b].record(s_dec)
-    piped(4, 0)
-    torch.cuda.synchronize()
-    n_p = 4 * steps
-    t0 = time.perf_counter()
-    piped(n_p, 4)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    fib_h, crc_h, msc_h = fib.cpu().numpy(), crc.cpu().numpy(), msc.cpu().numpy()
-    res["ofdm_fic_msc64_two_contexts_pipelined"] = {
-        "value": F * n_p / dt, "unit": "frames/s", "x_realtime": F * n_p / dt / REALTIME_FPS, "ms_per_step": dt / n_p * 1e3,
-        "frames_per_step": F, "steps": n_p,
-        "fic_bit_exact": bool(crc_h.all()) and all(bool((fib_h[f] == e.fibs[f % 4]).all()) for f in range(F)),
-        "msc_bit_exact": all(bool((msc_h[0, t] == e.msc_bytes[(t - 15) % 16]).all()) for t in range(F * 4)),
-        "what": "config 3 with the demodulation of batch k+1 running beside the decode of batch k: two contexts, two streams, two "
-                "soft-bit buffers -- the plugin's own structure (OFDM thread, ring, radio thread)"}
-    c1.close(); c2.close()
+    c1.close()
 
     # ---- one frame at a time from host memory ----
     M = 64                                                   # samples the host assembles its frames early (timing_margin)

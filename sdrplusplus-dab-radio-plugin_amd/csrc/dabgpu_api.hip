@@ -331,8 +331,6 @@ void dabgpu_destroy(dabgpu_ctx *ctx) {
     pipeline_destroy(ctx);
     arena_destroy(ctx);
     if (ctx->ev_states) (void)hipEventDestroy(ctx->ev_states);
-    if (ctx->ev_aux) (void)hipEventDestroy(ctx->ev_aux);
-    if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     }
     delete ctx;
@@ -1037,8 +1035,8 @@ static int tracked_launches(dabgpu_ctx *ctx, dabk::StreamState *states, const vo
                             int64_t n_samples, int max_frames, int64_t advance, const dabgpu_track_cfg &c, int fixed_start,
                             int acquiring, int8_t *d_soft, void *d_cyc, void *d_dqpsk, dabgpu_acquired_frame *d_frames,
                             dabgpu_sync_result *d_sync, int32_t *d_counts, hipStream_t s, const dabk::AcquireArgs *auto_acq = nullptr,
-                            void *d_dd4 = nullptr, const void *sync_iq = nullptr, hipStream_t sync_stream = nullptr,
-                            bool note_states = true) {
+                            void *d_dd4 = nullptr, const void *upload_from = nullptr, size_t upload_bytes = 0,
+                            bool note_states = true, const dabk::CopyPiece *down2 = nullptr, dabk::StreamState *state_out = nullptr) {
     dabk::SyncTables stab{ctx->d_twiddle, ctx->d_prs_qt, ctx->d_sync_pairs, ctx->n_sync_pairs, ctx->d_sync_fs};
     dabk::TrackArgs t{};
     t.state = states;
@@ -1057,17 +1055,15 @@ static int tracked_launches(dabgpu_ctx *ctx, dabk::StreamState *states, const vo
     t.coarse_slow_beta = c.coarse_freq_slow_beta;
     t.out = reinterpret_cast<dabk::AcquiredFrame *>(d_frames);
     t.sync_out = reinterpret_cast<dabk::SyncResult *>(d_sync);
-    if (sync_stream && sync_stream != s) {
-        // the synchronisation reads its PRS from `sync_iq` (the caller's page-locked frame itself) on a stream of its own,
-        // beside whatever `s` is doing meanwhile (the frame's upload); `s` goes on once it is done
-        t.iq = static_cast<const float2 *>(sync_iq);
-        HIP_TRY(dabk::launch_track_sync(stab, t, sync_stream));
-        HIP_TRY(hipEventRecord(ctx->ev_aux, sync_stream));
-        HIP_TRY(hipStreamWaitEvent(s, ctx->ev_aux, 0));
-        t.iq = static_cast<const float2 *>(d_iq);
-    } else {
-        HIP_TRY(dabk::launch_track_sync(stab, t, s));
+    if (upload_from) {
+        // the one-frame call: the frame's upload rides in this launch, and the synchronisation reads its PRS straight
+        // from the caller's page-locked buffer meanwhile (TrackArgs::copy_*)
+        t.sync_iq = static_cast<const float2 *>(upload_from);
+        t.copy_dst = static_cast<uint4 *>(const_cast<void *>(d_iq));
+        t.copy_src = static_cast<const uint4 *>(upload_from);
+        t.copy_n16 = unsigned(upload_bytes >> 4);
     }
+    HIP_TRY(dabk::launch_track_sync(stab, t, s));
     // streams that are not tracking: acquired here (their rows of d_frames / d_counts; the pass above left them empty)
     if (auto_acq) HIP_TRY(dabk::launch_acquire(stab, *auto_acq, s));
     dabk::OfdmTables tab{ctx->d_twiddle, ctx->d_bin_of_n, ctx->d_n_of_vj};
@@ -1107,6 +1103,8 @@ static int tracked_launches(dabgpu_ctx *ctx, dabk::StreamState *states, const vo
     u.counts = d_counts;
     u.dd_gate = c.dd_gate;
     u.dd_terms_per_frame = 256 * ((a.keep && !a.dqpsk) ? ctx->keep_symbols : NB_DATA_SYMBOLS);
+    if (down2) { u.down[0] = down2[0]; u.down[1] = down2[1]; }
+    u.state_out = state_out;
     // ... and their tracking starts from what the acquisition found (marked 2; the update launch makes it 1)
     if (auto_acq)
         HIP_TRY(dabk::launch_track_start(states, t.out, d_counts, n_streams, max_frames, advance, 1, s));
@@ -1189,41 +1187,27 @@ int dabgpu_ofdm_demod_stream_frame(dabgpu_ctx *ctx, int stream_index, const floa
     HIP_TRY(hipHostGetDevicePointer(&h_dev, ctx->h_bounce, 0));
     void *iq_alias = device_alias_of_pinned(iq), *soft_alias = device_alias_of_pinned(soft);
     if ((reinterpret_cast<uintptr_t>(iq_alias) | reinterpret_cast<uintptr_t>(soft_alias)) & 15) iq_alias = soft_alias = nullptr;
-    if (iq_alias && !ctx->aux_stream) {
-        if (hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&ctx->ev_aux, hipEventDisableTiming) != hipSuccess) {
-            (void)hipGetLastError();
-            if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
-            ctx->aux_stream = nullptr;
-            ctx->ev_aux = nullptr;
-        }
-    }
-    if (iq_alias) {
-        const dabk::CopyPiece up{d_iq, iq_alias, nb_iq};
-        HIP_TRY(dabk::launch_copy_pieces(&up, 1, s));
-    } else {
-        HIP_TRY(hipMemcpyAsync(d_iq, iq, nb_iq, hipMemcpyHostToDevice, s));
-    }
+    if (!iq_alias) HIP_TRY(hipMemcpyAsync(d_iq, iq, nb_iq, hipMemcpyHostToDevice, s));
     dabk::StreamState *st = ctx->d_states + stream_index;
-    // Page-locked buffers (the host mirror's): the 1.55 MB upload is the longest single piece of the call, and the PRS
-    // synchronisation only needs the frame's first symbol -- it reads those 20 KB straight from the caller's buffer on a
-    // second stream while the upload runs; the demodulation then writes the soft bits straight into the caller's buffer
-    // (no second copy of 230 kB behind it), and the call ends in its own synchronisation, so no state event is recorded.
-    const bool beside = iq_alias && ctx->aux_stream;
-    int8_t *soft_dst = soft_alias ? static_cast<int8_t *>(soft_alias) : reinterpret_cast<int8_t *>(res);
-    rc = tracked_launches(ctx, st, d_iq, nb_iq / sizeof(float2), 1, int64_t(nb_iq / sizeof(float2)), 1, 0, c, 1, acquiring ? 1 : 0,
-                          soft_dst, d_cyc, d_dq, reinterpret_cast<dabgpu_acquired_frame *>(res + off_fr),
-                          reinterpret_cast<dabgpu_sync_result *>(res + off_sy), nullptr, s, nullptr, d_dd, beside ? iq_alias : nullptr,
-                          beside ? ctx->aux_stream : nullptr, false);
-    if (rc) return rc;
-    // one download, written by a kernel right behind the others: (the soft bits, unless they are already there,) the frame
-    // and sync records, then the state
+    // Page-locked buffers (the host mirror's): the 1.55 MB upload is the longest single piece of the call (37 us), and the
+    // PRS synchronisation (20 us) only needs the frame's first symbol -- so the upload rides in the synchronisation's own
+    // launch: its extra workgroups copy the frame while the first one reads its 20 kB straight from the caller's buffer.
+    // The call ends in its own synchronisation, so no state event is recorded (an event record between two launches
+    // cost 5.6 us of idle device).  Measured and rejected on the way (profiles/r05_frame_path.md): the synchronisation
+    // on a second stream (the cross-stream event: 11 us of idle device), soft bits written by the demodulation launch
+    // straight into the caller's buffer (the launch 3.4 us slower, the copy behind it only 1.6 us shorter).
+    // ... and the download rides in the LAST launch (the state update's): soft bits (straight into the caller's buffer when
+    // that is page-locked too: no copy by the CPU afterwards), frame and sync records; the updating workgroup writes the
+    // new state to the landing area itself.  Three launches per call: upload + synchronisation, demodulation, update + download.
     static_assert(sizeof(dabk::StreamState) % 16 == 0, "the state goes out in 16-byte words");
     char *hd = static_cast<char *>(h_dev);
-    const dabk::CopyPiece down[3] = {{hd, d_res, soft_alias ? size_t(0) : size_t(NB_FRAME_BITS)},
-                                     {hd + off_fr, res + off_fr, off_st - off_fr},
-                                     {hd + off_st, st, sizeof(dabk::StreamState)}};
-    HIP_TRY(dabk::launch_copy_pieces(down, 3, s));
+    const dabk::CopyPiece down[2] = {{soft_alias ? soft_alias : static_cast<void *>(hd), d_res, size_t(NB_FRAME_BITS)},
+                                     {hd + off_fr, res + off_fr, off_st - off_fr}};
+    rc = tracked_launches(ctx, st, d_iq, nb_iq / sizeof(float2), 1, int64_t(nb_iq / sizeof(float2)), 1, 0, c, 1, acquiring ? 1 : 0,
+                          reinterpret_cast<int8_t *>(res), d_cyc, d_dq, reinterpret_cast<dabgpu_acquired_frame *>(res + off_fr),
+                          reinterpret_cast<dabgpu_sync_result *>(res + off_sy), nullptr, s, nullptr, d_dd, iq_alias, iq_alias ? nb_iq : 0,
+                          false, down, reinterpret_cast<dabk::StreamState *>(hd + off_st));
+    if (rc) return rc;
     if (dqpsk) HIP_TRY(hipMemcpyAsync(dqpsk, d_dq, nb_dq, hipMemcpyDeviceToHost, s));       // (+ the constellation, when asked for)
     HIP_TRY(hipStreamSynchronize(s));                                                    // one synchronisation
     ctx->ev_states_pending = false;

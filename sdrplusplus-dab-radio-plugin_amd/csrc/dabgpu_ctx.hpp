@@ -61,10 +61,6 @@ struct dabgpu_ctx {
     int device = 0;
     int max_frames = 0;
     hipStream_t stream = nullptr;
-    // the one-frame call (dabgpu_ofdm_demod_stream_frame) runs the PRS synchronisation beside the frame's upload: a
-    // second stream and the event that joins it (created by the first such call)
-    hipStream_t aux_stream = nullptr;
-    hipEvent_t ev_aux = nullptr;
     float2 *d_twiddle = nullptr;
     uint16_t *d_bin_of_n = nullptr;
     uint16_t *d_n_of_vj = nullptr;

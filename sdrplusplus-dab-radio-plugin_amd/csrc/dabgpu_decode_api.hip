@@ -541,6 +541,9 @@ static int decode_stream_frames_body(dabgpu_ctx *ctx, const int8_t *soft, size_t
     // one upload (by a kernel when the soft bits lie in page-locked memory the device can address).  One frame with a
     // handful of sub-channels -- the plugin's call -- sends only what will be read: the FIC and the sub-channels' ranges
     // of the four CIFs (21.5 kB of the 230 kB for one 64 kbit/s service)
+    // (every query first: once the upload is enqueued the host only enqueues, and stays ahead of the device)
+    void *h_dev = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&h_dev, ctx->h_bounce, 0));
     void *soft_alias = (nb_soft & 15) ? nullptr : device_alias_of_pinned(soft);
     if (soft_alias && !(reinterpret_cast<uintptr_t>(soft_alias) & 15)) {
         std::vector<dabk::CopyPiece> up;
@@ -562,8 +565,6 @@ static int decode_stream_frames_body(dabgpu_ctx *ctx, const int8_t *soft, size_t
     }
     // the results -- a few hundred bytes per frame -- are written by the decoder's kernels straight into the page-locked
     // landing area (no copy behind them); one synchronisation
-    void *h_dev = nullptr;
-    HIP_TRY(hipHostGetDevicePointer(&h_dev, ctx->h_bounce, 0));
     (void)d_res;
     char *res = static_cast<char *>(h_dev);
     std::vector<uint8_t *> p_out(n_subchannels, nullptr);

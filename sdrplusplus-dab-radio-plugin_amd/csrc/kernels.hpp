@@ -194,6 +194,15 @@ struct TrackArgs {
     float coarse_slow_beta;
     AcquiredFrame *out;        // [n_streams][max_out]
     SyncResult *sync_out;      // [n_streams][max_out] or nullptr
+    // an upload riding in the same launch (the one-frame call): extra workgroups copy copy_n16 16-byte words from copy_src
+    // (page-locked host memory) to copy_dst while the first ones synchronise on `sync_iq` -- the PRS read straight from
+    // the host buffer -- so the 20 us of the synchronisation disappear inside the 37 us of the upload without a second
+    // stream (a cross-stream event costs ~11 us on this runtime: profiles/r05_frame_path.md)
+    const float2 *sync_iq = nullptr;     // where the synchronisation reads its samples (nullptr: `iq`)
+    uint4 *copy_dst = nullptr;
+    const uint4 *copy_src = nullptr;
+    unsigned copy_n16 = 0;
+    int copy_blocks = 0;                 // set by the launcher
 };
 hipError_t launch_track_sync(const SyncTables &t, const TrackArgs &a, hipStream_t s);
 
@@ -267,6 +276,12 @@ struct TrackUpdateArgs {
     int settle_only = 0;       // only turn "started in this call" marks (tracking == 2) into 1
     float dd_gate = 2.5f;      // dd_loop_error's quality gate
     int dd_terms_per_frame = 19200;   // unit terms one frame adds to the sums (256 carriers x the symbols that are demodulated)
+    // the one-frame call's download riding in this launch: workgroups behind the n_streams updating ones copy `down` (what
+    // the launches before this one produced: soft bits, frame and sync records); the updating workgroup writes the new state
+    // to `state_out` as well (page-locked host memory) -- one launch instead of two at the end of the call
+    CopyPiece down[2] = {{nullptr, nullptr, 0}, {nullptr, nullptr, 0}};
+    StreamState *state_out = nullptr;
+    int copy_blocks = 0;       // set by the launcher
 };
 hipError_t launch_track_update(const TrackUpdateArgs &a, hipStream_t s);
 // Start tracking from an acquisition result (dabgpu_acquire_dev on the same capture): per stream, a least-squares line

@@ -139,6 +139,30 @@ __global__ __launch_bounds__(WG) void prs_sync_kernel(SyncTables tab, const floa
     using Lds = typename std::conditional<LITE, SyncLdsLite, SyncLds>::type;
     __shared__ Lds sm;
     const int tid = threadIdx.x;
+    // workgroups behind the synchronising ones: the upload that rides in this launch (TrackArgs::copy_*)
+    int n_sync_blocks = int(gridDim.x);
+    if constexpr (MODE == MODE_TRACK) {
+        n_sync_blocks -= trk.copy_blocks;
+        if (int(blockIdx.x) >= n_sync_blocks) {
+            const unsigned stride = unsigned(trk.copy_blocks) * WG;
+            for (unsigned i = unsigned(int(blockIdx.x) - n_sync_blocks) * WG + unsigned(tid); i < trk.copy_n16; i += stride)
+                trk.copy_dst[i] = trk.copy_src[i];
+            return;
+        }
+    }
+    // With an upload riding in this launch the synchronising workgroup asks for its 2048 samples BEFORE anything else: they
+    // come over the same link as the upload's 1.5 MB, and a request issued after the copying workgroups have queued theirs
+    // is served behind all of them (measured: the launch took upload + synchronisation, 55 us instead of 37).
+    float2 pre[8];
+    bool prefetched = false;
+    if constexpr (MODE == MODE_TRACK && !LITE) {
+        if (trk.copy_n16 != 0 && trk.sync_iq != nullptr) {
+            prefetched = true;
+#pragma unroll
+            for (int r = 0; r < 8; r++) pre[r] = trk.sync_iq[NB_CP + tid + r * WG];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
     // the tables go to LDS once per workgroup; a workgroup then takes every gridDim.x-th candidate
     const float2 *tw;
     float *pw;                                                 // |h|^2 of every tap (a buffer that is idle by then)
@@ -152,7 +176,7 @@ __global__ __launch_bounds__(WG) void prs_sync_kernel(SyncTables tab, const floa
     }
     for (int i = tid; i < NB_FFT; i += WG) sm.qt[i] = tab.prs_qt[i];
     __syncthreads();
-    for (int frame = blockIdx.x; frame < n_total; frame += gridDim.x) {
+    for (int frame = blockIdx.x; frame < n_total; frame += n_sync_blocks) {
     int max_coarse = max_coarse_arg;
     const float2 *sym;
     uint32_t dphi;
@@ -189,7 +213,7 @@ __global__ __launch_bounds__(WG) void prs_sync_kernel(SyncTables tab, const floa
             }
             continue;
         }
-        sym = trk.iq + size_t(st) * trk.stream_stride + cand;
+        sym = (trk.sync_iq ? trk.sync_iq : trk.iq) + size_t(st) * trk.stream_stride + cand;
         fine = ss.fine_freq_offset;
         // first frame after a null-symbol detection: the fine offset starts from this PRS's own cyclic prefix, so that
         // the frame is already demodulated with it (the loop then refines it)
@@ -210,7 +234,7 @@ __global__ __launch_bounds__(WG) void prs_sync_kernel(SyncTables tab, const floa
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const int n = tid + r * WG;
-            v[r] = sym[NB_CP + n];
+            v[r] = prefetched ? pre[r] : sym[NB_CP + n];
             if (dphi != 0u) v[r] = cmul(v[r], nco(uint32_t(n), dphi));
         }
         block_fft2048(v, sm.t1, sm.x, tw, tid);
@@ -365,6 +389,16 @@ __global__ __launch_bounds__(TU) void track_update_kernel(TrackUpdateArgs a) {
     __shared__ int red_last[TU];
     __shared__ StreamState st_in;
     const int s = blockIdx.x, tid = threadIdx.x;
+    if (s >= a.n_streams) {                                    // the download that rides in this launch (TrackUpdateArgs::down)
+        unsigned i = unsigned(s - a.n_streams) * TU + unsigned(tid);
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const unsigned n16 = unsigned(a.down[k].bytes >> 4);
+            if (i < n16) { static_cast<uint4 *>(a.down[k].dst)[i] = static_cast<const uint4 *>(a.down[k].src)[i]; return; }
+            i -= n16;
+        }
+        return;
+    }
     // one thread reads the state for everybody: thread 0 writes it back further down (and at once in the branch below),
     // and a wavefront scheduled late must not see that write
     if (tid == 0) st_in = a.state[s];
@@ -493,6 +527,7 @@ __global__ __launch_bounds__(TU) void track_update_kernel(TrackUpdateArgs a) {
     st.total_frames_read += n_locked - (level_lost ? 1 : 0);      // (a frame whose level is gone counts as lost, not as read)
     st.total_frames_desync += desync;
     a.state[s] = st;
+    if (a.state_out) a.state_out[s] = st;
     if (a.counts) a.counts[s] = count;
 }
 
@@ -804,7 +839,19 @@ hipError_t launch_track_sync(const SyncTables &t, const TrackArgs &a, hipStream_
     if (a.max_coarse < 0 || a.max_coarse > 1023 || (a.fixed_start && a.max_out != 1)) return hipErrorInvalidValue;
     TrackArgs b = a;
     b.rule.expected = a.margin;
-    if (!a.fixed_start && a.max_coarse == 0)
+    b.copy_blocks = 0;
+    if (a.copy_n16) {
+        if (!a.copy_dst || !a.copy_src || !a.fixed_start) return hipErrorInvalidValue;
+        b.copy_blocks = int(std::min<unsigned>(1024u, (a.copy_n16 + WG - 1) / WG));
+    } else {
+        b.copy_dst = nullptr;
+        b.copy_src = nullptr;
+    }
+    if (a.copy_n16)
+        hipLaunchKernelGGL(prs_sync_kernel<MODE_TRACK>, dim3(sync_grid(a.n_streams * a.max_out) + unsigned(b.copy_blocks)), dim3(WG), 0, s,
+                           t, static_cast<const float2 *>(nullptr), size_t(0), static_cast<const float *>(nullptr), 0,
+                           static_cast<SyncResult *>(nullptr), AcquireArgs{}, b, a.n_streams * a.max_out);
+    else if (!a.fixed_start && a.max_coarse == 0)
         hipLaunchKernelGGL((prs_sync_kernel<MODE_TRACK, true>), dim3(sync_grid(a.n_streams * a.max_out)), dim3(WG), 0, s, t,
                            static_cast<const float2 *>(nullptr), size_t(0), static_cast<const float *>(nullptr), 0,
                            static_cast<SyncResult *>(nullptr), AcquireArgs{}, b, a.n_streams * a.max_out);
@@ -817,7 +864,14 @@ hipError_t launch_track_sync(const SyncTables &t, const TrackArgs &a, hipStream_
 
 hipError_t launch_track_update(const TrackUpdateArgs &a, hipStream_t s) {
     if (a.n_streams <= 0 || a.max_out <= 0) return hipSuccess;
-    hipLaunchKernelGGL(track_update_kernel, dim3(unsigned(a.n_streams)), dim3(TU), 0, s, a);
+    TrackUpdateArgs b = a;
+    unsigned words = 0;
+    for (const CopyPiece &c : b.down) {
+        if ((c.bytes & 15) || ((reinterpret_cast<uintptr_t>(c.dst) | reinterpret_cast<uintptr_t>(c.src)) & 15)) return hipErrorInvalidValue;
+        words += unsigned(c.bytes >> 4);
+    }
+    b.copy_blocks = int((words + TU - 1) / TU);
+    hipLaunchKernelGGL(track_update_kernel, dim3(unsigned(a.n_streams + b.copy_blocks)), dim3(TU), 0, s, b);
     return hipGetLastError();
 }
 

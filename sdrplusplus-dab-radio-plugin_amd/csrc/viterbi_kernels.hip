@@ -337,15 +337,19 @@ __device__ __forceinline__ void rot_decode(const Fetch &fetch, const CodeTables 
         }
     }
     // The sub-channel's gather -- every byte from one of sixteen CIFs, latency-bound: 13-20 us of an 80 us call when done
-    // up front -- runs BESIDE the forward pass instead: only the punctured bits of the first two 96-step chunks are fetched
-    // before the first step; at the top of chunk c the loads of chunk c + 2 are issued, at its bottom (2 us of add-compare-
-    // select later) they are scattered into the codeword in LDS, one chunk before the forward pass reads them (it fetches
-    // its soft words one phase cycle ahead: chunk c's last cycle already touches chunk c + 1).  CodeTables::chunk_first
-    // says where a chunk's punctured bits begin.
+    // up front -- runs BESIDE the forward pass instead.  Lane l always takes the punctured bits l, l + 64, l + 128, ...:
+    // their CIF (bit i comes from CIF t - 15 + bitrev4(i mod 16)) is the same for all of them, so a lane's source is ONE
+    // base pointer for the whole codeword and a load costs an add.  Only the rows (of 64 bits) that cover the first two
+    // 96-step chunks are fetched before the first step (CodeTables::chunk_first); at the top of every later chunk the
+    // next RB rows leave (a chunk consumes at most six), at its bottom -- 2 us of add-compare-select later -- they are
+    // scattered into the codeword in LDS, at least one chunk before the forward pass reads them (it fetches its soft
+    // words one phase cycle ahead: chunk c's last cycle already touches chunk c + 1).
     constexpr bool kStream = Fetch::kBatch > 1;
-    constexpr int RB = 6;                                      // loads per lane per chunk: 96 steps keep at most 384 bits
+    constexpr int RB = 7;
     const bool stream = kStream && !wide && code.chunk_first != nullptr;
-    const int gather_end = stream ? int(code.chunk_first[min(2, nchunks + 1)]) : code.n_punct;
+    const int total_rows = (code.n_punct + 63) >> 6;
+    const int first_rows = stream ? min(total_rows, (int(code.chunk_first[min(2, nchunks + 1)]) + 63) >> 6) : total_rows;
+    const int gather_end = min(code.n_punct, first_rows << 6);
     if (!wide) {
         if constexpr (Fetch::kBatch > 1) {
             // the de-interleaver's bytes come from sixteen CIFs at once: eight of them (and their positions) in flight per lane
@@ -400,25 +404,24 @@ __device__ __forceinline__ void rot_decode(const Fetch &fetch, const CodeTables 
     for (int ph = 0; ph < 6; ph++) wc[ph] = m4[ph];
     int8_t gv[RB];
     uint16_t gp[RB];
-    unsigned g_skip = 0;                                       // bit u: load u of the batch in flight carries nothing
+    int k_next = first_rows;                                   // first row of 64 punctured bits not fetched yet
+    const int8_t *g_base = nullptr;                            // byte i of this lane's rows is g_base[i]
+    bool g_erased = false;                                     // ... or nothing at all (a CIF before the call, no history)
+    if constexpr (kStream) {
+        if (stream) g_base = fetch.addr(cw, lane, g_erased) - lane;
+    }
     for (int c = 0; c < nchunks; c++) {
         const int *mw = m4 + 96 * c;
-        int g_lo = 0, g_hi = 0;                                // punctured bits of chunk c + 2 (the last one: + the tail's)
+        const bool more = stream && k_next < total_rows;       // (wave-uniform)
         if constexpr (kStream) {
-            if (stream && c + 2 <= nchunks) {
-                g_lo = int(code.chunk_first[c + 2]);
-                g_hi = int(code.chunk_first[c + 3 <= nchunks + 1 ? c + 3 : nchunks + 1]);
-                // (straight-line: every lane loads from a valid address -- its own, or the chunk's last one -- and decides
-                // at the bottom of the chunk what to keep; a branch around a load would bring its s_waitcnt up here)
-                g_skip = 0;
+            if (more) {
+                // (straight-line: every lane loads from a valid address and decides at the bottom of the chunk what to
+                // keep; a branch around a load would bring its s_waitcnt up here)
 #pragma unroll
                 for (int u = 0; u < RB; u++) {
-                    const int i = g_lo + lane + 64 * u;
-                    const int ic = min(i, g_hi - 1);
-                    bool erased = false;
-                    if constexpr (kStream) gv[u] = *fetch.addr(cw, ic, erased);
+                    const int ic = min(lane + ((k_next + u) << 6), code.n_punct - 1);
+                    gv[u] = g_base[ic];
                     gp[u] = code.mother_pos[ic];
-                    g_skip |= unsigned(i >= g_hi || erased) << u;
                 }
                 __builtin_amdgcn_sched_barrier(0);             // the loads leave before the chunk's first step, not after its last
             }
@@ -446,11 +449,12 @@ __device__ __forceinline__ void rot_decode(const Fetch &fetch, const CodeTables 
 #undef DAB_ROT_STEP
 #undef DAB_ROT_METRIC
         if constexpr (kStream) {
-            if (stream && c + 2 <= nchunks) {
+            if (more) {
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int u = 0; u < RB; u++)
-                    if (!((g_skip >> u) & 1u)) mother[gp[u]] = gv[u];
+                    if (!g_erased && lane + ((k_next + u) << 6) < code.n_punct) mother[gp[u]] = gv[u];
+                k_next += RB;
                 // (wave-private LDS: the wave's own DS operations execute in order; the fences pin the compiler's)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -564,50 +568,6 @@ __global__ __launch_bounds__(WGV) void viterbi_rot_kernel(Fetch fetch, CodeTable
                             smem + size_t(wave) * lds_per_wave, lane);
 }
 
-// Grouped launch for small batches (the plugin's one frame at a time): the codewords of several sub-channels, each
-// with its own profile and length, in ONE launch -- one wavefront (= one workgroup) per codeword, the entry table by
-// value in the kernel arguments.  A whole multiplex is then three launches (FIC, sub-channels, history rings)
-// instead of one pair per sub-channel queueing up behind each other on the stream.
-constexpr int WAVE_GROUP_MAX = 24;
-struct WaveEntry {
-    FetchMsc fetch;
-    CodeTables code;
-    uint8_t *out;
-    int first_cw;
-};
-struct WaveEntryPack {
-    int n;
-    int n_fic;                        // FIC codewords (4 per frame) decoded by the first n_fic workgroups, or 0
-    FetchFic fic_fetch;
-    CodeTables fic_code;
-    uint8_t *fib, *crc_ok;
-    WaveEntry e[WAVE_GROUP_MAX];
-};
-__global__ __launch_bounds__(64) void viterbi_rot_grouped_kernel(const WaveEntryPack pack) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // consecutive codewords to the same XCD (workgroup b runs on XCD b % 8): the sixteen CIFs a sub-channel codeword is
-    // gathered from are the next codeword's too, and each XCD has an L2 of its own.  The FIC's (shorter) codewords and
-    // the sub-channels' are spread separately, so that every XCD gets its share of both.
-    int cw = blockIdx.x;
-    if (cw < pack.n_fic) {            // one frame at a time the FIC's four codewords ride along with the sub-channels'
-        rot_decode<FetchFic, Tail::kFic>(pack.fic_fetch, pack.fic_code, same_xcd(cw, pack.n_fic), true, pack.fib, pack.crc_ok, smem,
-                                         int(threadIdx.x));
-        return;
-    }
-    cw = same_xcd(cw - pack.n_fic, int(gridDim.x) - pack.n_fic);
-    int k = 0;
-    while (k + 1 < pack.n && cw >= pack.e[k + 1].first_cw) k++;
-    const WaveEntry &en = pack.e[k];
-    rot_decode<FetchMsc, Tail::kBytes>(en.fetch, en.code, cw - en.first_cw, true, en.out, nullptr, smem, int(threadIdx.x));
-}
-
-struct HistoryPack {
-    int n;
-    MscArgs a[WAVE_GROUP_MAX];
-};
-
-inline size_t viterbi_rot_lds_bytes(int nsteps) { return size_t(rot_layout(nsteps).total); }
-
 // history ring update: hist_out[s][h] = CIF (4F - 15 + h), h = 0..14
 __device__ __forceinline__ void msc_history_body(const MscArgs &a, size_t first, size_t step) {
     const int cifs = a.frames_per_stream * NB_CIFS;
@@ -627,6 +587,67 @@ __device__ __forceinline__ void msc_history_body(const MscArgs &a, size_t first,
         a.hist_out[idx] = v;
     }
 }
+// Grouped launch for small batches (the plugin's one frame at a time): the codewords of several sub-channels, each
+// with its own profile and length, in ONE launch -- one wavefront (= one workgroup) per codeword, the entry table by
+// value in the kernel arguments.  A whole multiplex is then three launches (FIC, sub-channels, history rings)
+// instead of one pair per sub-channel queueing up behind each other on the stream.
+constexpr int WAVE_GROUP_MAX = 24;
+struct WaveEntry {
+    FetchMsc fetch;
+    CodeTables code;
+    uint8_t *out;
+    int first_cw;
+    int n_streams;                    // (with fetch: everything the entry's history ring update needs)
+    int8_t *hist_out;
+};
+constexpr int HIST_BLOCKS = 32;       // workgroups per entry that write its history ring, behind the decoding ones
+struct WaveEntryPack {
+    int n;
+    int n_dec;                        // workgroups that decode (FIC + sub-channel codewords); the rest update history rings
+    int n_fic;                        // FIC codewords (4 per frame) decoded by the first n_fic workgroups, or 0
+    FetchFic fic_fetch;
+    CodeTables fic_code;
+    uint8_t *fib, *crc_ok;
+    WaveEntry e[WAVE_GROUP_MAX];
+};
+__global__ __launch_bounds__(64) void viterbi_rot_grouped_kernel(const WaveEntryPack pack) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // consecutive codewords to the same XCD (workgroup b runs on XCD b % 8): the sixteen CIFs a sub-channel codeword is
+    // gathered from are the next codeword's too, and each XCD has an L2 of its own.  The FIC's (shorter) codewords and
+    // the sub-channels' are spread separately, so that every XCD gets its share of both.
+    int cw = blockIdx.x;
+    if (cw >= pack.n_dec) {
+        // The sub-channels' history rings (the time de-interleaver's state for the next call: soft bits and old rings in,
+        // new rings out -- nothing the decoding workgroups write) ride in this launch instead of one of their own behind it
+        // (4 us of the plugin's 70 us decode call): HIST_BLOCKS workgroups per entry.
+        const int hb = cw - pack.n_dec, k = hb / HIST_BLOCKS;
+        const WaveEntry &en = pack.e[k];
+        if (en.hist_out) {
+            const MscArgs a{en.fetch.soft, en.fetch.stride, en.n_streams, en.fetch.frames_per_stream, en.fetch.start_bit, en.fetch.nbits,
+                            en.fetch.hist, en.hist_out, en.out};
+            msc_history_body(a, size_t(hb - k * HIST_BLOCKS) * 64 + threadIdx.x, size_t(HIST_BLOCKS) * 64);
+        }
+        return;
+    }
+    if (cw < pack.n_fic) {            // one frame at a time the FIC's four codewords ride along with the sub-channels'
+        rot_decode<FetchFic, Tail::kFic>(pack.fic_fetch, pack.fic_code, same_xcd(cw, pack.n_fic), true, pack.fib, pack.crc_ok, smem,
+                                         int(threadIdx.x));
+        return;
+    }
+    cw = same_xcd(cw - pack.n_fic, pack.n_dec - pack.n_fic);
+    int k = 0;
+    while (k + 1 < pack.n && cw >= pack.e[k + 1].first_cw) k++;
+    const WaveEntry &en = pack.e[k];
+    rot_decode<FetchMsc, Tail::kBytes>(en.fetch, en.code, cw - en.first_cw, true, en.out, nullptr, smem, int(threadIdx.x));
+}
+
+struct HistoryPack {
+    int n;
+    MscArgs a[WAVE_GROUP_MAX];
+};
+
+inline size_t viterbi_rot_lds_bytes(int nsteps) { return size_t(rot_layout(nsteps).total); }
+
 __global__ void msc_history_kernel(MscArgs a) {
     msc_history_body(a, size_t(blockIdx.x) * blockDim.x + threadIdx.x, size_t(gridDim.x) * blockDim.x);
 }
@@ -717,14 +738,20 @@ hipError_t launch_msc_decode_group(const WaveGroupItem *items, int n, hipStream_
             pack.e[i].code = it.code;
             pack.e[i].out = a.out;
             pack.e[i].first_cw = total;
+            pack.e[i].n_streams = a.n_streams;
+            pack.e[i].hist_out = a.hist_out;
             total += a.n_streams * a.frames_per_stream * NB_CIFS;
             lds = std::max(lds, (viterbi_rot_lds_bytes(it.code.nsteps) + 255) & ~size_t(255));
             hp.a[i] = a;
             if (a.hist_out) hist_items = std::max(hist_items, size_t(a.n_streams) * 15 * a.nbits);
         }
         if (total + pack.n_fic <= 0) continue;
-        hipLaunchKernelGGL(viterbi_rot_grouped_kernel, dim3(unsigned(total + pack.n_fic)), dim3(64), lds, s, pack);
-        if (hist_items)
+        pack.n_dec = total + pack.n_fic;
+        // small rings (the plugin's one stream) ride in the decoding launch; large ones keep a launch of their own, whose
+        // 256-thread workgroups move bytes faster than 64-thread ones sharing CUs with the decoder
+        const bool ride = hist_items > 0 && hist_items <= size_t(1) << 20;
+        hipLaunchKernelGGL(viterbi_rot_grouped_kernel, dim3(unsigned(pack.n_dec + (ride ? m * HIST_BLOCKS : 0))), dim3(64), lds, s, pack);
+        if (hist_items && !ride)
             hipLaunchKernelGGL(msc_history_grouped_kernel, dim3(unsigned(std::min<size_t>((hist_items + 255) / 256, 256)), unsigned(m)),
                                dim3(256), 0, s, hp);
     }

@@ -714,3 +714,45 @@ def test_gpu_one_frame_calls_from_pageable_and_page_locked_buffers(tctx):
                 assert np.array_equal(np.asarray(x), np.asarray(y)), (kind, f)
     assert all(g[5].all() for g in outs["pinned"]) and (outs["pinned"][2][4][0] == e.fibs[2]).all()
     p_iq.close(); p_soft.close()
+
+
+@pytest.mark.gpu
+def test_gpu_frame_call_honours_the_opt_in_decision_directed_loop(tctx):
+    """ABI v6: dabgpu_ofdm_demod_stream_frame runs the reference's loop (cyclic-prefix correlations) by default and this
+    library's decision-directed one only when cfg.decision_directed = 1.  Both on the same frames: the opt-in call's state
+    equals oracle.stream_update(dd=True) fed with the oracle's own fourth-power sums, the default call's equals the
+    cyclic-prefix restatement, the two fine offsets sit within 2e-3 carriers of each other and every frame decodes."""
+    import dabgpu
+    e = synth.Ensemble(seed=91, n_frames=4)
+    cfo = 0.33 / 2048.0
+    iq = synth.channel(e.iq().ravel(), snr_db=16.0, cfo=cfo, rng=np.random.default_rng(91))
+    M = 64
+    fines = {}
+    for dd in (0, 1):
+        cfg = dabgpu.track_cfg(timing_margin=M, decision_directed=dd, max_coarse_carriers=0)
+        tctx.streams_reset(1)
+        state = None
+        for f in range(4):
+            frame = np.ascontiguousarray(iq[f * L + NULL - M:f * L + NULL - M + SYMS])
+            soft, res, _ = tctx.ofdm_demod_stream_frame(frame, 0, acquiring=(f == 0), cfg=cfg)
+            assert res.flags == 3
+            if f == 0:
+                a, b = frame[M:M + 376], frame[M + 2048:M + 2048 + 376]
+                cr = (a.real * b.real + a.imag * b.imag).astype(np.float64).sum()
+                ci = (a.real * b.imag - a.imag * b.real).astype(np.float64).sum()
+                state = {"fine_freq_offset": np.float32(-np.arctan2(ci, cr) / (2.0 * np.pi * 2048.0)), "coarse_freq_offset": np.float32(0),
+                         "signal_average": np.float32(0), "total_frames_read": 0, "total_frames_desync": 0}
+            net = float(np.float32(state["fine_freq_offset"]))
+            if dd:
+                _, odd4 = O.ofdm_demod_frame_dd(frame, net)
+                state = O.stream_update(state, odd4[None, :], frame, 0.9, dd=True)
+            else:
+                _, _, ocyc, _ = O.ofdm_demod_frame(frame, net, want_cyc=True)
+                state = O.stream_update(state, ocyc[None, :], frame, 0.9)
+            assert abs(res.stats.fine_freq_offset - state["fine_freq_offset"]) <= 2e-9, (dd, f)
+            assert res.stats.total_frames_read == f + 1 and res.stats.loop_gated == state.get("loop_gated", 0)
+            fib, ok = tctx.fic_decode(soft[None, :])
+            assert ok.all() and (fib[0] == e.fibs[f]).all()
+        fines[dd] = float(res.stats.fine_freq_offset)
+        assert abs(fines[dd] + cfo) * 2048 < 5e-3
+    assert abs(fines[0] - fines[1]) * 2048 < 2e-3
