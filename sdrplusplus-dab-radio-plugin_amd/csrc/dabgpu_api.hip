@@ -1209,7 +1209,7 @@ int dabgpu_ofdm_demod_stream_frame(dabgpu_ctx *ctx, int stream_index, const floa
                           false, down, reinterpret_cast<dabk::StreamState *>(hd + off_st));
     if (rc) return rc;
     if (dqpsk) HIP_TRY(hipMemcpyAsync(dqpsk, d_dq, nb_dq, hipMemcpyDeviceToHost, s));       // (+ the constellation, when asked for)
-    HIP_TRY(hipStreamSynchronize(s));                                                    // one synchronisation
+    HIP_TRY(hipStreamSynchronize(s));                                                           // one synchronisation
     ctx->ev_states_pending = false;
     const char *hb = static_cast<const char *>(ctx->h_bounce);
     if (!soft_alias) std::memcpy(soft, hb, NB_FRAME_BITS);

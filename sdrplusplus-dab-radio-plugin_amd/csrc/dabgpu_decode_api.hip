@@ -574,7 +574,7 @@ static int decode_stream_frames_body(dabgpu_ctx *ctx, const int8_t *soft, size_t
                                   n_subchannels ? p_hi.data() : nullptr, n_subchannels ? p_ho.data() : nullptr,
                                   n_subchannels ? p_out.data() : nullptr, s);
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(s));                                                   // one synchronisation
+    HIP_TRY(hipStreamSynchronize(s));                                                          // one synchronisation
     const char *hb = static_cast<const char *>(ctx->h_bounce);
     std::memcpy(fib, hb, nb_fib);
     std::memcpy(crc_ok, hb + al(nb_fib), nb_crc);
