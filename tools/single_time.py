@@ -26,9 +26,10 @@ def timed(fn, reps=20):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
+print("(front end on the default loop: all 76 prefixes read; files before r05_single_time.txt used the decision-directed one)")
 print("frames  front_end_us  fic_us  fic+msc64_us  step(cfg2)_us  step(cfg3)_us   frames/s cfg2   cfg3")
 for F in sizes:
-    c = dabgpu.Context(0, F); c.streams_reset(1); c.set_stream_loop(decision_directed=True)
+    c = dabgpu.Context(0, F); c.streams_reset(1)          # (the library's default loop: cyclic-prefix correlations)
     fe = lambda: c.ofdm_demod_streams_dev(iq.data_ptr(), L, 1, F, 0.1, soft.data_ptr(), None, None, s)
     d2 = lambda: c.decode_frames_dev(soft.data_ptr(), dabgpu.NB_FRAME_BITS, 1, F, fib.data_ptr(), ok.data_ptr(), [], [], [], [], s)
     d3 = lambda: c.decode_frames_dev(soft.data_ptr(), dabgpu.NB_FRAME_BITS, 1, F, fib.data_ptr(), ok.data_ptr(), [sc],
