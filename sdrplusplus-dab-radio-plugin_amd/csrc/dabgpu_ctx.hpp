@@ -70,6 +70,10 @@ struct dabgpu_ctx {
     float2 *d_sync_fs = nullptr;         // FFT of the PRS's adjacent-carrier differential (coarse search by FFT)
     dabapi::DeviceCode fic;
     std::map<std::vector<uint8_t>, std::unique_ptr<dabapi::DeviceCode>> codes;   // keyed by puncture mask
+    // ... and found again by the sub-channel's descriptor (form, profile, level, bit rate, size) without building the
+    // 4 x (24 x bitrate + 6) flags of its puncture mask first: the plugin's per-frame decode call built it three times
+    // per sub-channel (validation, grouping, code look-up), ~10 us of host time in front of and between its launches
+    std::map<uint64_t, dabapi::DeviceCode *> code_by_descriptor;
     // slots 0..5: staging of the host-pointer entry points; slot 6: the stream / tracked / frame calls' own loop input
     // (correlations or decision-directed sums).  One caller stream at a time per context (dabgpu.h, conventions).
     void *d_stage[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};

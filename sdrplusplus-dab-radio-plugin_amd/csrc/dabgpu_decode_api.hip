@@ -97,6 +97,30 @@ static int subchannel_profile(const dabgpu_subchannel *sc, dab::PunctureProfile 
     return DABGPU_OK;
 }
 
+// the sub-channel's code tables through the context's descriptor cache (see dabgpu_ctx::code_by_descriptor); the same
+// checks and status codes as subchannel_profile
+static int lookup_code(dabgpu_ctx *ctx, const dabgpu_subchannel *sc, DeviceCode **out) {
+    if (!sc) return DABGPU_ERR_ARG;
+    const uint64_t key = (uint64_t(sc->is_uep != 0) << 63) | (uint64_t(uint32_t(sc->eep_type) & 0xFu) << 56) |
+                         (uint64_t(uint32_t(sc->protection_level) & 0xFFu) << 48) | (uint64_t(uint32_t(sc->bitrate_kbps) & 0xFFFFFFu) << 16) |
+                         uint64_t(uint32_t(sc->length) & 0xFFFFu);
+    auto it = ctx->code_by_descriptor.find(key);
+    if (it == ctx->code_by_descriptor.end() || sc->eep_type < 0 || sc->eep_type > 15 || sc->protection_level < 0 ||
+        sc->protection_level > 255 || sc->bitrate_kbps < 0 || sc->bitrate_kbps > 0xFFFFFF || sc->length < 0 || sc->length > 0xFFFF) {
+        dab::PunctureProfile prof;
+        int rc = subchannel_profile(sc, prof);
+        if (rc) return rc;
+        DeviceCode *dc = nullptr;
+        if ((rc = get_code(ctx, std::move(prof), &dc))) return rc;
+        ctx->code_by_descriptor[key] = dc;
+        *out = dc;
+        return DABGPU_OK;
+    }
+    if (sc->start_address < 0 || sc->start_address + sc->length > 864) return DABGPU_ERR_ARG;
+    *out = it->second;
+    return DABGPU_OK;
+}
+
 int dabgpu_soft_selection(const dabgpu_subchannel *subchannels, int n_subchannels, int with_fic,
                           dabgpu_bit_range *out, int max_out) {
     if (n_subchannels < 0 || (n_subchannels > 0 && !subchannels) || max_out < 0 || (max_out > 0 && !out)) return DABGPU_ERR_ARG;
@@ -144,14 +168,12 @@ int dabgpu_msc_decode_dev(dabgpu_ctx *ctx, const dabgpu_subchannel *sc, const in
     DeviceGuard guard(ctx);
     if (d_history_in && d_history_in == d_history_out) return DABGPU_ERR_ARG;
     if (soft_stride < size_t(NB_FRAME_BITS) && size_t(n_streams) * frames_per_stream > 1) return DABGPU_ERR_ARG;
-    dab::PunctureProfile prof;
-    int rc = subchannel_profile(sc, prof);
+    DeviceCode *dc = nullptr;
+    int rc = lookup_code(ctx, sc, &dc);
     if (rc) return rc;
     if (n_streams == 0 || frames_per_stream == 0) return DABGPU_OK;
-    const bool too_long = !dabk::viterbi_fits(prof.nsteps);   // above ~800 kbit/s: only the lane kernels hold it
-    if (too_long && !dabk::lane_supported(prof.nsteps)) return DABGPU_ERR_CAPACITY;
-    DeviceCode *dc = nullptr;
-    if ((rc = get_code(ctx, std::move(prof), &dc))) return rc;
+    const bool too_long = !dabk::viterbi_fits(dc->prof.nsteps);   // above ~800 kbit/s: only the lane kernels hold it
+    if (too_long && !dabk::lane_supported(dc->prof.nsteps)) return DABGPU_ERR_CAPACITY;
     hipStream_t s = pick_stream(ctx, stream);
     dabk::MscArgs a{};
     a.soft = d_soft;
@@ -236,11 +258,9 @@ static int decode_grouped(dabgpu_ctx *ctx, uint8_t *d_fib, uint8_t *d_crc_ok, co
         items.push_back(it);
     }
     for (int i = 0; i < n_subchannels; i++) {
-        dab::PunctureProfile prof;
-        int rc = subchannel_profile(&sc[i], prof);
-        if (rc) return rc;
         DeviceCode *dc = nullptr;
-        if ((rc = get_code(ctx, std::move(prof), &dc))) return rc;
+        const int rc = lookup_code(ctx, &sc[i], &dc);
+        if (rc) return rc;
         dabk::LaneGroupItem it{};
         it.code = dc->tables(true);
         it.tables = dc->lane_tables();
@@ -290,12 +310,10 @@ static int decode_subchannels(dabgpu_ctx *ctx, const dabgpu_subchannel *sc, int 
                  (ctx->lane_mode == 0 || cw_each < LANE_MIN_CODEWORDS) && d_soft && n_streams > 0 && frames_per_stream > 0;
     std::vector<dabk::WaveGroupItem> items;
     for (int i = 0; group && i < n_subchannels; i++) {
-        dab::PunctureProfile prof;
-        int rc = subchannel_profile(&sc[i], prof);
-        if (rc) return rc;
-        if (!dabk::wave_group_supported(prof.nsteps)) { group = false; break; }
         DeviceCode *dc = nullptr;
-        if ((rc = get_code(ctx, std::move(prof), &dc))) return rc;
+        const int rc = lookup_code(ctx, &sc[i], &dc);
+        if (rc) return rc;
+        if (!dabk::wave_group_supported(dc->prof.nsteps)) { group = false; break; }
         dabk::WaveGroupItem it{};
         it.code = dc->tables(true);
         it.args.soft = d_soft;
@@ -345,8 +363,8 @@ int dabgpu_msc_decode_multi_dev(dabgpu_ctx *ctx, const dabgpu_subchannel *sc, in
     // validate everything before enqueueing anything: profiles, bounds, no overlap inside the CIF
     std::vector<char> used(864, 0);
     for (int i = 0; i < n_subchannels; i++) {
-        dab::PunctureProfile prof;
-        const int rc = subchannel_profile(&sc[i], prof);
+        DeviceCode *dc = nullptr;
+        const int rc = lookup_code(ctx, &sc[i], &dc);
         if (rc) return rc;
         if (!d_out[i]) return DABGPU_ERR_ARG;
         for (int cu = sc[i].start_address; cu < sc[i].start_address + sc[i].length; cu++) {
@@ -373,8 +391,8 @@ int dabgpu_decode_frames_dev(dabgpu_ctx *ctx, const int8_t *d_soft, size_t soft_
     if (soft_stride < size_t(NB_FRAME_BITS) && size_t(n_streams) * frames_per_stream > 1) return DABGPU_ERR_ARG;
     std::vector<char> used(864, 0);
     for (int i = 0; i < n_subchannels; i++) {
-        dab::PunctureProfile prof;
-        const int rc = subchannel_profile(&sc[i], prof);
+        DeviceCode *dc = nullptr;
+        const int rc = lookup_code(ctx, &sc[i], &dc);
         if (rc) return rc;
         if (!d_out[i]) return DABGPU_ERR_ARG;
         for (int cu = sc[i].start_address; cu < sc[i].start_address + sc[i].length; cu++) {
@@ -406,8 +424,10 @@ int dabgpu_decode_frames(dabgpu_ctx *ctx, const int8_t *soft, size_t soft_stride
     const size_t nb_fib = nframes * NB_FIBS * 32, nb_crc = nframes * NB_FIBS;
     size_t res_total = al(nb_fib) + al(nb_crc), hist_total = 0;
     for (int i = 0; i < n_subchannels; i++) {
-        const int nbytes = dabgpu_subchannel_bytes(&sc[i]);
-        if (nbytes < 0) return nbytes;
+        DeviceCode *dc = nullptr;
+        const int lrc = lookup_code(ctx, &sc[i], &dc);
+        if (lrc) return lrc;
+        const int nbytes = (dc->prof.nsteps - 6) / 8;
         if (!out[i]) return DABGPU_ERR_ARG;
         out_off[i] = res_total;
         out_bytes[i] = nframes * NB_CIFS * size_t(nbytes);
@@ -473,8 +493,9 @@ int dabgpu_decode_stream_frames(dabgpu_ctx *ctx, const int8_t *soft, size_t soft
     if (soft_stride < size_t(NB_FRAME_BITS) && n_frames > 1) return DABGPU_ERR_ARG;
     // argument errors are refused before any ring is touched: the kept state survives them
     for (int i = 0; i < n_subchannels; i++) {
-        const int nbytes = dabgpu_subchannel_bytes(&sc[i]);
-        if (nbytes < 0) return nbytes;
+        DeviceCode *dc = nullptr;
+        const int lrc = lookup_code(ctx, &sc[i], &dc);
+        if (lrc) return lrc;
         if (!out[i]) return DABGPU_ERR_ARG;
     }
     if (!subchannels_disjoint(sc, n_subchannels)) return DABGPU_ERR_ARG;
@@ -501,8 +522,10 @@ static int decode_stream_frames_body(dabgpu_ctx *ctx, const int8_t *soft, size_t
     std::vector<int> hist_index(n_subchannels, -1);
     hipStream_t s = ctx->stream;
     for (int i = 0; i < n_subchannels; i++) {
-        const int nbytes = dabgpu_subchannel_bytes(&sc[i]);
-        if (nbytes < 0) return nbytes;
+        DeviceCode *dc = nullptr;
+        const int lrc = lookup_code(ctx, &sc[i], &dc);
+        if (lrc) return lrc;
+        const int nbytes = (dc->prof.nsteps - 6) / 8;
         if (!out[i]) return DABGPU_ERR_ARG;
         out_off[i] = res_total;
         out_bytes[i] = size_t(n_frames) * NB_CIFS * size_t(nbytes);

@@ -132,6 +132,9 @@ struct Predictor {
 //             for any candidate within +-64 samples), then the same search; AcquiredFrame out.
 // MODE_TRACK: candidates predicted from the stream states (TrackArgs); correction = the state's fine + coarse offset;
 //             the whole-carrier search only when asked for (max_coarse > 0); AcquiredFrame out.
+// geometry of an upload riding in a synchronisation launch (see the kernel's head): measured over eight streams of a process,
+// 256 x 2: 81-92 us per frame call, 128 x 4: 70-80, 64 x 8 / 48 x 8 / 32 x 16: 68-70 on every stream
+constexpr int RIDE_BLOCKS = 64, RIDE_UNROLL = 8;
 template <int MODE, bool LITE = false>
 __global__ __launch_bounds__(WG) void prs_sync_kernel(SyncTables tab, const float2 *iq, size_t frame_stride,
                                                       const float *freq_offset, int max_coarse_arg, SyncResult *out,
@@ -144,9 +147,20 @@ __global__ __launch_bounds__(WG) void prs_sync_kernel(SyncTables tab, const floa
     if constexpr (MODE == MODE_TRACK) {
         n_sync_blocks -= trk.copy_blocks;
         if (int(blockIdx.x) >= n_sync_blocks) {
+            // (few, fat workgroups: this kernel's workgroups carry the synchronisation's 50 kB of LDS, so only two or three
+            // fit a CU, and how the dispatcher spreads several hundred of them over the XCDs turned out to depend on the
+            // hardware queue the stream was given -- 37 / 42 / 52 us for the same upload on three streams of one process.
+            // 64 workgroups are one per CU on any queue; each thread keeps eight 16-byte loads in flight)
             const unsigned stride = unsigned(trk.copy_blocks) * WG;
-            for (unsigned i = unsigned(int(blockIdx.x) - n_sync_blocks) * WG + unsigned(tid); i < trk.copy_n16; i += stride)
-                trk.copy_dst[i] = trk.copy_src[i];
+            for (unsigned i0 = unsigned(int(blockIdx.x) - n_sync_blocks) * WG + unsigned(tid); i0 < trk.copy_n16; i0 += RIDE_UNROLL * stride) {
+                uint4 v[RIDE_UNROLL];
+#pragma unroll
+                for (int u = 0; u < RIDE_UNROLL; u++)
+                    if (i0 + u * stride < trk.copy_n16) v[u] = trk.copy_src[i0 + u * stride];
+#pragma unroll
+                for (int u = 0; u < RIDE_UNROLL; u++)
+                    if (i0 + u * stride < trk.copy_n16) trk.copy_dst[i0 + u * stride] = v[u];
+            }
             return;
         }
     }
@@ -842,7 +856,7 @@ hipError_t launch_track_sync(const SyncTables &t, const TrackArgs &a, hipStream_
     b.copy_blocks = 0;
     if (a.copy_n16) {
         if (!a.copy_dst || !a.copy_src || !a.fixed_start) return hipErrorInvalidValue;
-        b.copy_blocks = int(std::min<unsigned>(1024u, (a.copy_n16 + WG - 1) / WG));
+        b.copy_blocks = int(std::min<unsigned>(unsigned(RIDE_BLOCKS), (a.copy_n16 + WG - 1) / WG));
     } else {
         b.copy_dst = nullptr;
         b.copy_src = nullptr;

@@ -12,6 +12,11 @@ sys.path.insert(0, os.path.join(ROOT, "sdrplusplus-dab-radio-plugin_amd")); sys.
 def work():
     import ctypes as C
     import numpy as np, dabgpu
+    if os.environ.get("WITH_TORCH"):                          # (the bench's process has torch's runtime state in it: does that matter?)
+        import torch
+        torch.zeros(16, device="cuda").sum().item()
+        if os.environ.get("WITH_TORCH") == "big":
+            keep = torch.empty(int(20e9), dtype=torch.uint8, device="cuda")
     from dabgpu import synth
     rng = np.random.default_rng(0)
     e = synth.Ensemble(seed=1, n_frames=4)
