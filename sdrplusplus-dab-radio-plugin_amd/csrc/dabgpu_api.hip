@@ -1170,12 +1170,13 @@ int dabgpu_ofdm_demod_stream_frame(dabgpu_ctx *ctx, int stream_index, const floa
     // cfg->decision_directed -- the fourth-power sums
     if ((rc = stage(ctx, 6, NB_FRAME_SYMBOLS * sizeof(float2), c.decision_directed ? &d_dd : &d_cyc))) return rc;
     if (dqpsk && (rc = stage(ctx, 4, nb_dq, &d_dq))) return rc;
-    if (ctx->h_bounce_bytes < nb_res) {
+    if (ctx->h_bounce_bytes < nb_res + 64) {
         if (ctx->h_bounce) (void)hipHostFree(ctx->h_bounce);
         ctx->h_bounce = nullptr;
         ctx->h_bounce_bytes = 0;
-        if (hipHostMalloc(&ctx->h_bounce, nb_res, hipHostMallocDefault) != hipSuccess) return DABGPU_ERR_NOMEM;
-        ctx->h_bounce_bytes = nb_res;
+        if (hipHostMalloc(&ctx->h_bounce, nb_res + 64, hipHostMallocDefault) != hipSuccess) return DABGPU_ERR_NOMEM;
+        ctx->h_bounce_bytes = nb_res + 64;
+        std::memset(ctx->h_bounce, 0, nb_res + 64);
     }
     if ((rc = wait_state_use(ctx))) return rc;
     hipStream_t s = ctx->stream;
@@ -1208,8 +1209,16 @@ int dabgpu_ofdm_demod_stream_frame(dabgpu_ctx *ctx, int stream_index, const floa
                           reinterpret_cast<dabgpu_sync_result *>(res + off_sy), nullptr, s, nullptr, d_dd, iq_alias, iq_alias ? nb_iq : 0,
                           false, down, reinterpret_cast<dabk::StreamState *>(hd + off_st));
     if (rc) return rc;
-    if (dqpsk) HIP_TRY(hipMemcpyAsync(dqpsk, d_dq, nb_dq, hipMemcpyDeviceToHost, s));       // (+ the constellation, when asked for)
-    HIP_TRY(hipStreamSynchronize(s));                                                           // one synchronisation
+    if (dqpsk) {
+        HIP_TRY(hipMemcpyAsync(dqpsk, d_dq, nb_dq, hipMemcpyDeviceToHost, s));           // (+ the constellation, when asked for:
+        HIP_TRY(hipStreamSynchronize(s));                                                // a copy-engine transfer ends the usual way)
+    } else {
+        // one synchronisation: the word behind the landing area's payload (the area is at least nb_res + 64 bytes)
+        const size_t off_flag = ctx->h_bounce_bytes - 64;
+        if ((rc = wait_for_signal(s, reinterpret_cast<volatile unsigned long long *>(static_cast<char *>(ctx->h_bounce) + off_flag),
+                                  reinterpret_cast<unsigned long long *>(hd + off_flag), ++ctx->signal_seq)))
+            return rc;
+    }
     ctx->ev_states_pending = false;
     const char *hb = static_cast<const char *>(ctx->h_bounce);
     if (!soft_alias) std::memcpy(soft, hb, NB_FRAME_BITS);

@@ -109,8 +109,9 @@ struct dabgpu_ctx {
         bool live;                       // decoded in the current call (a ring that misses a frame is stale: dropped)
     };
     std::vector<SubHistory> sub_history;
-    void *h_bounce = nullptr;            // page-locked landing area of that call's single download
-    size_t h_bounce_bytes = 0;
+    void *h_bounce = nullptr;            // page-locked landing area of that call's single download (+ 64 bytes: the
+    size_t h_bounce_bytes = 0;           // word wait_for_signal watches sits behind the payload)
+    unsigned long long signal_seq = 0;   // number of the last one-frame call that ended through wait_for_signal
     dabapi::Arena arena;                 // dabgpu_alloc_frame_buffers(DABGPU_PLACE_DOMAINS)
     dabapi::Pipeline *pipe = nullptr;    // dabgpu_pipe_open
 };
@@ -158,6 +159,25 @@ struct ScopedTimer {
         }
     }
 };
+
+// The end of a one-frame call (dabgpu_ofdm_demod_stream_frame, dabgpu_decode_stream_frames): ~55 us of device work are in
+// flight and the caller can do nothing until they are done.  hipStreamSynchronize puts the thread to sleep and pays the
+// wake-up; instead a one-thread launch behind the call's last kernel stores the call's number into a word of the page-locked
+// landing area and the host watches that word (bounded: after ~5 ms of watching -- no frame call takes that long -- it
+// sleeps on the stream after all).  `flag_host` / `flag_dev`: the two addresses of the word; `seq`: this call's number.
+inline int wait_for_signal(hipStream_t s, volatile unsigned long long *flag_host, unsigned long long *flag_dev, unsigned long long seq) {
+    if (dabk::launch_signal(flag_dev, seq, s) != hipSuccess) return DABGPU_ERR_HIP;
+    for (long i = 0; i < 2000000; i++) {
+        if (*flag_host == seq) {
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            return DABGPU_OK;
+        }
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#endif
+    }
+    return hipStreamSynchronize(s) == hipSuccess ? DABGPU_OK : DABGPU_ERR_HIP;
+}
 
 inline hipStream_t pick_stream(dabgpu_ctx *ctx, void *stream) {
     return stream ? reinterpret_cast<hipStream_t>(stream) : ctx->stream;

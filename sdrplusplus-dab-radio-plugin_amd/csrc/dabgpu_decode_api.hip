@@ -554,12 +554,13 @@ static int decode_stream_frames_body(dabgpu_ctx *ctx, const int8_t *soft, size_t
     int rc;
     if ((rc = stage(ctx, 1, nb_soft, &d_soft))) return rc;
     if ((rc = stage(ctx, 3, res_total, &d_res))) return rc;
-    if (ctx->h_bounce_bytes < res_total) {
+    if (ctx->h_bounce_bytes < res_total + 64) {
         if (ctx->h_bounce) (void)hipHostFree(ctx->h_bounce);
         ctx->h_bounce = nullptr;
         ctx->h_bounce_bytes = 0;
-        if (hipHostMalloc(&ctx->h_bounce, res_total, hipHostMallocDefault) != hipSuccess) return DABGPU_ERR_NOMEM;
-        ctx->h_bounce_bytes = res_total;
+        if (hipHostMalloc(&ctx->h_bounce, res_total + 64, hipHostMallocDefault) != hipSuccess) return DABGPU_ERR_NOMEM;
+        ctx->h_bounce_bytes = res_total + 64;
+        std::memset(ctx->h_bounce, 0, res_total + 64);
     }
     // one upload (by a kernel when the soft bits lie in page-locked memory the device can address).  One frame with a
     // handful of sub-channels -- the plugin's call -- sends only what will be read: the FIC and the sub-channels' ranges
@@ -597,7 +598,12 @@ static int decode_stream_frames_body(dabgpu_ctx *ctx, const int8_t *soft, size_t
                                   n_subchannels ? p_hi.data() : nullptr, n_subchannels ? p_ho.data() : nullptr,
                                   n_subchannels ? p_out.data() : nullptr, s);
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(s));                                                          // one synchronisation
+    {   // one synchronisation: the word behind the landing area's payload
+        const size_t off_flag = ctx->h_bounce_bytes - 64;
+        if ((rc = wait_for_signal(s, reinterpret_cast<volatile unsigned long long *>(static_cast<char *>(ctx->h_bounce) + off_flag),
+                                  reinterpret_cast<unsigned long long *>(res + off_flag), ++ctx->signal_seq)))
+            return rc;
+    }
     const char *hb = static_cast<const char *>(ctx->h_bounce);
     std::memcpy(fib, hb, nb_fib);
     std::memcpy(crc_ok, hb + al(nb_fib), nb_crc);

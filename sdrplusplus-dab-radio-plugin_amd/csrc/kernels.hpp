@@ -89,6 +89,9 @@ struct CopyPiece {
     size_t bytes;
 };
 hipError_t launch_copy_pieces(const CopyPiece *pieces, int n, hipStream_t s);   // n <= copy_pieces_max()
+// one thread stores `value` to `flag` (page-locked host memory, through its device alias): enqueued behind a call's last
+// launch it tells a host that is watching the word that everything before it on the stream is done and visible
+hipError_t launch_signal(unsigned long long *flag, unsigned long long value, hipStream_t s);
 int copy_pieces_max();
 // reads `in` and writes `out` at the same time (streaming, both whole): the launch is slower when the two buffers
 // share an HBM domain -- what the placement helpers time

@@ -733,6 +733,17 @@ __global__ __launch_bounds__(256) void copy_pieces_kernel(CopyPieces16 p) {
 
 int copy_pieces_max() { return COPY_PIECES_MAX; }
 
+namespace {
+__global__ void signal_kernel(unsigned long long *flag, unsigned long long value) {
+    __threadfence_system();
+    __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+}  // namespace
+hipError_t launch_signal(unsigned long long *flag, unsigned long long value, hipStream_t s) {
+    hipLaunchKernelGGL(signal_kernel, dim3(1), dim3(1), 0, s, flag, value);
+    return hipGetLastError();
+}
+
 hipError_t launch_copy_pieces(const CopyPiece *pieces, int n, hipStream_t s) {
     if (n < 0 || n > COPY_PIECES_MAX) return hipErrorInvalidValue;
     CopyPieces16 p{};
