@@ -20,7 +20,10 @@ public:
             m_cv.wait(lock, [&] { return m_closed || m_count < m_buf.size(); });
             if (m_closed) break;
             const size_t n = std::min(src.size() - done, m_buf.size() - m_count);
-            for (size_t i = 0; i < n; i++) m_buf[(m_head + m_count + i) % m_buf.size()] = src[done + i];
+            // (at most two contiguous pieces: element-by-element with a modulo per element cost ~1 ms per 230 400-bit frame)
+            const size_t at = (m_head + m_count) % m_buf.size(), first = std::min(n, m_buf.size() - at);
+            std::copy(src.data() + done, src.data() + done + first, m_buf.data() + at);
+            std::copy(src.data() + done + first, src.data() + done + n, m_buf.data());
             m_count += n;
             done += n;
             m_cv.notify_all();
@@ -34,7 +37,9 @@ public:
             m_cv.wait(lock, [&] { return m_closed || m_count > 0; });
             if (m_count == 0 && m_closed) break;
             const size_t n = std::min(dst.size() - done, m_count);
-            for (size_t i = 0; i < n; i++) dst[done + i] = m_buf[(m_head + i) % m_buf.size()];
+            const size_t first = std::min(n, m_buf.size() - m_head);
+            std::copy(m_buf.data() + m_head, m_buf.data() + m_head + first, dst.data() + done);
+            std::copy(m_buf.data(), m_buf.data() + (n - first), dst.data() + done + first);
             m_head = (m_head + n) % m_buf.size();
             m_count -= n;
             done += n;

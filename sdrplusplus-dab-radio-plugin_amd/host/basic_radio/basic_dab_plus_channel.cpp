@@ -6,6 +6,7 @@ Basic_DAB_Plus_Channel::Basic_DAB_Plus_Channel(dabgpu_ctx *ctx, const Subchannel
     : m_ctx(ctx), m_subchannel(subchannel), m_bitrate(bitrate_kbps), m_lf_bytes(size_t(bitrate_kbps) * 3) {
     m_window.resize(5 * m_lf_bytes);
     m_data.resize(size_t(110) * (bitrate_kbps / 8));
+    m_status.resize(1);
 }
 
 void Basic_DAB_Plus_Channel::Process(tcb::span<const uint8_t> lf) {
@@ -13,7 +14,7 @@ void Basic_DAB_Plus_Channel::Process(tcb::span<const uint8_t> lf) {
     std::memcpy(m_window.data() + size_t(m_frames_in_window) * m_lf_bytes, lf.data(), m_lf_bytes);
     if (++m_frames_in_window < 5) return;
     // five logical frames: a super-frame if we are aligned; the Fire code (checked after RS correction) says so
-    dabgpu_superframe_status st{};
+    dabgpu_superframe_status &st = m_status[0];
     const int rc = dabgpu_dabplus_superframes(m_ctx, m_window.data(), m_window.size(), 1, m_bitrate, m_data.data(), &st);
     if (rc != DABGPU_OK || !st.firecode_ok) {
         // not aligned (or a lost super-frame): slide by one logical frame and try again with the next one

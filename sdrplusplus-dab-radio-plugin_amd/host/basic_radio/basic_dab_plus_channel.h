@@ -12,6 +12,7 @@
 #include "basic_radio/basic_audio_channel.h"
 #include "dab/audio/aac_frame_processor.h"
 #include "dabgpu.h"
+#include "utility/gpu_buffers.h"
 
 struct SuperFrameHeader {                  // TS 102 563 clause 5.2; fields as the GUI prints them
     uint32_t sampling_rate = 0;            // AAC core output rate, 0 until a super-frame was decoded
@@ -45,10 +46,12 @@ private:
     const Subchannel m_subchannel;
     const int m_bitrate;
     const size_t m_lf_bytes;
-    std::vector<uint8_t> m_window;         // up to 5 logical frames
+    // (page-locked: the super-frame kernel reads the window and writes data + status in place, no copies)
+    PinnedBuffer<uint8_t> m_window;        // up to 5 logical frames
     int m_frames_in_window = 0;
     bool m_synced = false;
-    std::vector<uint8_t> m_data;           // corrected super-frame (110*s bytes)
+    PinnedBuffer<uint8_t> m_data;          // corrected super-frame (110*s bytes)
+    PinnedBuffer<dabgpu_superframe_status> m_status;
     SuperFrameHeader m_header;
     bool m_firecode_error = true, m_rs_error = false, m_au_error = false;
     int m_total_superframes = 0, m_total_aus = 0, m_total_au_errors = 0;

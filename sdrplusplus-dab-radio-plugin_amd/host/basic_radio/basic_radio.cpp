@@ -5,6 +5,17 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#ifdef DABHOST_TIMING
+#include <chrono>
+#include <cstdio>
+static double g_t[6];
+static long g_n;
+struct Tick { std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+              void lap(int i) { auto n = std::chrono::steady_clock::now(); g_t[i] += std::chrono::duration<double>(n - t).count(); t = n; } };
+#define LAP(i) tick.lap(i)
+#else
+#define LAP(i)
+#endif
 
 BasicRadio::BasicRadio(const DAB_Parameters &params, size_t /*nb_threads*/) : m_params(params), m_ctx(nullptr) {
     dabgpu_cfg cfg{};
@@ -18,7 +29,13 @@ BasicRadio::BasicRadio(const DAB_Parameters &params, size_t /*nb_threads*/) : m_
     m_frame.resize(size_t(params.nb_frame_bits));
 }
 
-BasicRadio::~BasicRadio() { dabgpu_destroy(m_ctx); }
+BasicRadio::~BasicRadio() {
+#ifdef DABHOST_TIMING
+    if (g_n) std::fprintf(stderr, "BasicRadio::Process per frame, us: set-up + copy %.1f | decode call %.1f | FIBs + FIG parser %.1f | sub-channel observers + channels %.1f | channel update %.1f (%ld frames)\n",
+                          g_t[0] / g_n * 1e6, g_t[1] / g_n * 1e6, g_t[2] / g_n * 1e6, g_t[3] / g_n * 1e6, g_t[4] / g_n * 1e6, g_n);
+#endif
+    dabgpu_destroy(m_ctx);
+}
 
 int BasicRadio::AddSubchannel(const dabgpu_subchannel &sc) {
     std::lock_guard<std::mutex> lock(m_mutex);
@@ -46,6 +63,10 @@ int BasicRadio::add_subchannel_locked(const dabgpu_subchannel &sc) {
 void BasicRadio::Process(tcb::span<const viterbi_bit_t> buf) {
     if (buf.size() != size_t(m_params.nb_frame_bits)) return;   // the reference drops short frames the same way
     std::lock_guard<std::mutex> lock(m_mutex);
+#ifdef DABHOST_TIMING
+    Tick tick;
+    g_n++;
+#endif
     // A7..A12 in one call: the frame goes up once, the FIC and every registered sub-channel are decoded from that
     // copy, FIBs / CRC flags / logical frames / de-interleaver state come back together
     const size_t n_sub = m_subchannels.size();
@@ -56,6 +77,7 @@ void BasicRadio::Process(tcb::span<const viterbi_bit_t> buf) {
         m_call_out[i] = m_subchannels[i].out.data();
     }
     std::memcpy(m_frame.data(), buf.data(), buf.size());
+    LAP(0);
     // (the time de-interleaver state of every sub-channel stays on the device between frames)
     const int rc = dabgpu_decode_stream_frames(m_ctx, m_frame.data(), m_frame.size(), 1, m_fib.data(), m_crc.data(),
                                                m_call_sc.data(), int(n_sub), m_call_out.data());
@@ -70,7 +92,9 @@ void BasicRadio::Process(tcb::span<const viterbi_bit_t> buf) {
         if (m_auto_channels) update_channels_from_database();
         return;
     }
+    LAP(1);
     process_fibs_locked();
+    LAP(2);
     for (size_t i = 0; i < n_sub; i++) {
         Subchannel &s = m_subchannels[i];
         for (int c = 0; c < m_params.nb_cifs; c++) {
@@ -82,8 +106,10 @@ void BasicRadio::Process(tcb::span<const viterbi_bit_t> buf) {
             if (s.dab) s.dab->Process(lf);
         }
     }
+    LAP(3);
     // sub-channels the FIC has announced by now join the call from the next frame on
     if (m_auto_channels) update_channels_from_database();
+    LAP(4);
 }
 
 // FIB counters, the On_FIC observers and the FIG parser (mutex held)

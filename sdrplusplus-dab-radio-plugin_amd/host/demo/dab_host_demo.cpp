@@ -8,6 +8,7 @@
 //
 //   dab_host_demo <iq.cf32> <out_prefix> [chunk_samples] [coarse_offset_cycles_per_sample] [bitrate start_cu level] [signal_l1.update_beta]
 #include <algorithm>
+#include <chrono>
 #include <complex>
 #include <cstdio>
 #include <cstdlib>
@@ -98,26 +99,50 @@ int main(int argc, char **argv) {
 
     auto ring = std::make_shared<ThreadedRingBuffer<viterbi_bit_t>>(size_t(dab_params.nb_frame_bits) * 2);
     demod->On_OFDM_Frame().Attach([ring](tcb::span<const viterbi_bit_t> buf) { ring->write(buf); });
+    double t_radio = 0.0, t_ofdm = 0.0;                        // seconds spent inside the two Process calls
     std::thread radio_thread([&]() {
         auto data = std::vector<viterbi_bit_t>(size_t(dab_params.nb_frame_bits));
         while (true) {
             const size_t n = ring->read(data);
             if (n != data.size()) break;
+            const auto t0 = std::chrono::steady_clock::now();
             radio->Process(data);
+            t_radio += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         }
     });
 
     std::ifstream in(argv[1], std::ios::binary);
     if (!in) { std::fprintf(stderr, "cannot open %s\n", argv[1]); return 5; }
+    // DAB_DEMO_PRELOAD=1: the whole file is read into memory first and only the processing is timed -- what the plugin's two
+    // threads cost per frame when the samples are already there (SDR++ hands over blocks in memory), without this demo's
+    // file reads in the OFDM thread
+    const bool preload = std::getenv("DAB_DEMO_PRELOAD") != nullptr;
+    std::vector<std::complex<float>> all;
+    if (preload) {
+        in.seekg(0, std::ios::end);
+        all.resize(size_t(in.tellg()) / sizeof(all[0]));
+        in.seekg(0);
+        in.read(reinterpret_cast<char *>(all.data()), std::streamsize(all.size() * sizeof(all[0])));
+    }
+    const auto t_begin = std::chrono::steady_clock::now();
     std::vector<std::complex<float>> buf(chunk);
-    while (in) {
-        in.read(reinterpret_cast<char *>(buf.data()), std::streamsize(chunk * sizeof(buf[0])));
-        const size_t got = size_t(in.gcount()) / sizeof(buf[0]);
-        if (!got) break;
-        demod->Process(tcb::span<std::complex<float>>(buf.data(), got));   // non-const span, as dab_module.cpp does
+    if (preload) {
+        for (size_t at = 0; at < all.size(); at += chunk) {
+            const auto t0 = std::chrono::steady_clock::now();
+            demod->Process(tcb::span<std::complex<float>>(all.data() + at, std::min(chunk, all.size() - at)));
+            t_ofdm += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        }
+    } else {
+        while (in) {
+            in.read(reinterpret_cast<char *>(buf.data()), std::streamsize(chunk * sizeof(buf[0])));
+            const size_t got = size_t(in.gcount()) / sizeof(buf[0]);
+            if (!got) break;
+            demod->Process(tcb::span<std::complex<float>>(buf.data(), got));   // non-const span, as dab_module.cpp does
+        }
     }
     ring->close();
     radio_thread.join();
+    const double t_proc = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     {
         auto lock = std::scoped_lock(radio->GetMutex());
         const auto &db = radio->GetDatabase();
@@ -147,6 +172,7 @@ int main(int argc, char **argv) {
             std::fclose(f);
         }
     }
+    std::printf("processing_s=%.6f ofdm_process_s=%.6f radio_process_s=%.6f\n", t_proc, t_ofdm, t_radio);
     std::printf("state=%d frames_read=%d frames_desync=%d fine=%.6g net=%.6g level=%.4f fibs=%d fib_errors=%d\n",
                 int(demod->GetState()), demod->GetTotalFramesRead(), demod->GetTotalFramesDesync(),
                 demod->GetFineFrequencyOffset() * SAMPLING_RATE_HZ,

@@ -82,7 +82,7 @@ void OFDM_Demod::Process(tcb::span<const std::complex<float>> block) {
     if (m_reset_requested.exchange(false, std::memory_order_acquire)) reset_now();
     const std::complex<float> *x = block.data();
     size_t n = block.size();
-    // feed whole L1 blocks; keep the remainder for the next call (chunks are arbitrary, dab_module.cpp:23-25)
+    // a partial L1 block carried over from the last call (chunks are arbitrary, dab_module.cpp:23-25) is completed first
     if (!m_carry.empty()) {
         const size_t need = std::min(n, L1_BLOCK - m_carry.size());
         m_carry.insert(m_carry.end(), x, x + need);
@@ -92,31 +92,51 @@ void OFDM_Demod::Process(tcb::span<const std::complex<float>> block) {
         push_sample_block(m_carry.data(), L1_BLOCK);
         m_carry.clear();
     }
-    const size_t whole = n - n % L1_BLOCK;
-    for (size_t i = 0; i < whole; i += L1_BLOCK) push_sample_block(x + i, L1_BLOCK);
-    m_carry.assign(x + whole, x + n);
+    // While locked, samples go straight into the frame buffer in whole pieces (gap skipped, frame filled, frame
+    // demodulated): 64 samples at a time was 3 072 small copies and calls per frame.  The power detector -- and with it the
+    // 64-sample blocks and the carry -- only runs while searching for a null symbol.
+    while (n > 0) {
+        if (m_state.load(std::memory_order_relaxed) == State::READING_SYMBOLS) {
+            const size_t took = take_locked(x, n);
+            x += took;
+            n -= took;
+        } else if (n >= L1_BLOCK) {
+            push_sample_block(x, L1_BLOCK);
+            x += L1_BLOCK;
+            n -= L1_BLOCK;
+        } else {
+            break;
+        }
+    }
+    m_carry.assign(x, x + n);
+}
+
+// READING_SYMBOLS: consume up to n samples -- the rest of the gap before the frame, then as much of the frame as there is;
+// a completed frame is demodulated and the gap to the next one set up.  Returns how many samples were consumed (> 0).
+size_t OFDM_Demod::take_locked(const std::complex<float> *x, size_t n) {
+    const size_t frame_len = m_frame.size();
+    size_t i = 0;
+    if (m_skip) {
+        const size_t d = std::min(m_skip, n);
+        m_skip -= d;
+        i = d;
+    }
+    const size_t take = std::min(n - i, frame_len - m_frame_fill);
+    std::memcpy(m_frame.data() + m_frame_fill, x + i, take * sizeof(*x));
+    m_frame_fill += take;
+    if (m_frame_fill == frame_len) {
+        demodulate_frame();
+        // locked: the next PRS starts one null symbol (+/- the timing correction) after this frame's symbols
+        m_frame_fill = 0;
+        m_skip = m_next_skip;
+    }
+    return i + take;
 }
 
 void OFDM_Demod::push_sample_block(const std::complex<float> *x, size_t n) {
-    const size_t frame_len = m_frame.size();
     if (m_state == State::READING_SYMBOLS) {
-        size_t i = 0;
-        if (m_skip) {
-            const size_t d = std::min(m_skip, n);
-            m_skip -= d;
-            i = d;
-        }
-        const size_t take = std::min(n - i, frame_len - m_frame_fill);
-        std::memcpy(m_frame.data() + m_frame_fill, x + i, take * sizeof(*x));
-        m_frame_fill += take;
-        if (m_frame_fill == frame_len) {
-            demodulate_frame();
-            // locked: the next PRS starts one null symbol (+/- the timing correction) after this frame's symbols
-            m_frame_fill = 0;
-            const size_t used = n - i - take;                  // rest of this block already belongs to the gap
-            m_skip = m_next_skip > used ? m_next_skip - used : 0;
-        }
-        return;
+        for (size_t done = 0; done < n && m_state == State::READING_SYMBOLS;) done += take_locked(x + done, n - done);
+        return;                                                // (a frame that lost lock drops the rest of its 64-sample block)
     }
     // ---- acquisition: null-symbol power dip on the L1 norm ----
     float l1 = 0.0f;

@@ -113,6 +113,7 @@ private:
     static constexpr size_t TIMING_MARGIN = 128;   // place FFT windows this many samples early (inside the CP)
 
     void push_sample_block(const std::complex<float> *x, size_t n);
+    size_t take_locked(const std::complex<float> *x, size_t n);
     void demodulate_frame();
     void reset_now();                               // on the Process thread (or before it exists)
 
