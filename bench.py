@@ -130,6 +130,7 @@ def parse_args(argv=None):
                       ("dd-leg", "the step on the library's own decision-directed estimator (with_decision_directed_loop / value_own_estimator)"),
                       ("single-ensemble", "BASELINE configs 2 and 3 (one ensemble) and the one-frame host path"),
                       ("host-fed", "the host-fed ring (64 frames per call from page-locked memory)"),
+                      ("host-mirror", "the C++ host mirror end to end (dab_host_demo over three DAB+ services)"),
                       ("traffic", "measuring roofline.traffic now (two rocprofv3 --pmc child processes, ~20 s); the tracked figure "
                                   "of profiles/pmc_traffic.json is reported instead")):
         ap.add_argument("--no-" + leg, action="store_true", help="skip " + what)

@@ -11,6 +11,9 @@
                                    frame at a time from host memory through the two calls the host mirror makes
   host_fed                         BASELINE.md section 4 item 5: 64 frames per call from page-locked host memory, synchronous
                                    calls and the pipelined ring (dabgpu_pipe_*)
+  host_mirror_end_to_end           the host mirror as the plugin runs it: dab_host_demo (OFDM_Demod::Process on one thread, the
+                                   2-frame ring, BasicRadio::Process on the radio thread, FIG database, DAB+ channels) over a
+                                   stream of three DAB+ services, samples in memory
   closed_loop                      the same samples as unaligned captures: acquisition every step, and tracking
   cpu_baseline                     the oracle and the SIMD port on the box's host cores (a bounded sample)
 and `measure_traffic` replaces roofline.traffic (a figure from a tracked file) by one measured while the bench runs.
@@ -55,6 +58,8 @@ def run(B, out):
         out["single_ensemble"] = single_ensemble_leg(B)
     if not a.no_host_fed:
         out["host_fed"] = host_fed_leg(B)
+    if not a.no_host_mirror:
+        out["host_mirror_end_to_end"] = host_mirror_leg(B)
     if not a.no_closed_loop:
         out["closed_loop"] = closed_loop_leg(B)
     if a.cpu_seconds > 0:
@@ -511,6 +516,50 @@ def host_fed_leg(B):
                         what="dabgpu_pipe_submit / dabgpu_pipe_wait, soft bits + FIBs + sub-channel bytes back in host memory"),
            "ring_without_soft_bit_download": row(ring_nosoft_s)}
     return out
+
+
+def host_mirror_leg(B, n_frames=400):
+    """The C++ host mirror end to end, in a process of its own: `dab_host_demo` wires OFDM_Demod -> ThreadedRingBuffer ->
+    radio thread -> BasicRadio exactly as /root/reference/src/radio_block.cpp:11-49 does and is fed in chunks of 65 536
+    samples as /root/reference/src/dab_module.cpp:20-28 feeds it; the multiplex (three DAB+ services, 64 / 48 / 32 kbit/s)
+    is unknown to it: the FIC is parsed, the services opened, their sub-channels decoded, super-frames checked (Fire code,
+    RS(120,110), AU CRCs) and access units handed out.  The samples are read into memory first (DAB_DEMO_PRELOAD: SDR++ hands
+    over blocks in memory); timed: the two threads from the first chunk to the last access unit."""
+    import subprocess
+    import tempfile
+    synth = B.synth
+    root = os.path.dirname(os.path.abspath(__file__))
+    exe = os.path.join(root, "sdrplusplus-dab-radio-plugin_amd", "host", "dab_host_demo")
+    if not os.path.exists(exe):
+        return "not available: %s is not built" % exe
+    services = [("Radio One", 0xC221, 3, 0, 3, 64, 0), ("Jazz 24", 0xC222, 7, 0, 2, 48, 48), ("News", 0xC223, 9, 1, 2, 32, 200)]
+    ens = synth.ServiceEnsemble(1, services, n_frames=5)
+    base = synth.channel(np.tile(ens.iq().ravel(), 4), snr_db=20.0, cfo=1.2 / 2048, rng=np.random.default_rng(8)).astype(np.complex64)
+    reps = (n_frames + 19) // 20
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "iq.cf32")
+        with open(path, "wb") as f:
+            f.write(base[-30000:].tobytes())
+            for _ in range(reps):
+                f.write(base.tobytes())                          # 20 frames per repeat: the multiplex continues seamlessly
+            f.write(base[:synth.NB_NULL + 5000].tobytes())
+        r = None
+        for _ in range(2):                                       # (the first run warms the file cache and the device)
+            r = subprocess.run([exe, path, os.path.join(d, "out"), "65536"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
+                               timeout=300, env=dict(os.environ, DAB_DEMO_PRELOAD="1"))
+            if r.returncode != 0:
+                return "not available: dab_host_demo returned %d" % r.returncode
+        db = open(os.path.join(d, "out.db")).read()
+    kv = dict(t.split("=") for t in r.stdout.split() if "=" in t)
+    frames, dt = int(kv["frames_read"]), float(kv["processing_s"])
+    chans = [l for l in db.splitlines() if l.startswith("channel")]
+    return {"value": frames / dt, "unit": "frames/s", "x_realtime": frames / dt / REALTIME_FPS, "us_per_frame": dt / frames * 1e6,
+            "frames": frames, "frames_desync": int(kv["frames_desync"]), "fibs": int(kv["fibs"]), "fib_errors": int(kv["fib_errors"]),
+            "seconds_in_ofdm_process": float(kv["ofdm_process_s"]), "seconds_in_radio_process": float(kv["radio_process_s"]),
+            "dab_plus_services_decoded": len(chans),
+            "all_superframes_clean": bool(chans) and all("firecode_error=0" in l and "rs_error=0" in l for l in chans),
+            "what": "dab_host_demo, samples in memory, chunks of 65536: OFDM_Demod::Process on one thread, BasicRadio::Process on "
+                    "the radio thread (FIC -> database -> three DAB+ services -> access units)"}
 
 
 def closed_loop_leg(B):

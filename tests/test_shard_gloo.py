@@ -237,6 +237,9 @@ def test_bench_line_keeps_the_contract():
     assert hfed["synchronous_calls"]["fic_bit_exact"] is True and hfed["ring"]["fic_bit_exact"] is True
     assert hfed["ring"]["msc_bit_exact"] is True and hfed["ring"]["outputs_identical_to_synchronous_calls"] is True
     assert hfed["ring"]["value"] > 0 and hfed["ring_without_soft_bit_download"]["value"] > 0
+    hm = j["host_mirror_end_to_end"]                          # the C++ mirror end to end: locked throughout, every FIB right, three services
+    assert hm["frames"] >= 390 and hm["frames_desync"] == 0 and hm["fib_errors"] == 0 and hm["dab_plus_services_decoded"] == 3
+    assert hm["all_superframes_clean"] is True and hm["value"] > 0
     cb = j["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "frames/s" and cb["value"] > 0 and cb["cores"] >= 1 and "frames" in cb["sample"]
     assert cb["simd_port"]["kind"] == "simd_port" and cb["simd_port"]["decodes_bench_inputs_to_transmitted_fibs"] is True
