@@ -163,8 +163,8 @@ struct ScopedTimer {
 // The end of a one-frame call (dabgpu_ofdm_demod_stream_frame, dabgpu_decode_stream_frames): ~55 us of device work are in
 // flight and the caller can do nothing until they are done.  hipStreamSynchronize puts the thread to sleep and pays the
 // wake-up; instead a one-thread launch behind the call's last kernel stores the call's number into a word of the page-locked
-// landing area and the host watches that word (bounded: after ~5 ms of watching -- no frame call takes that long -- it
-// sleeps on the stream after all).  `flag_host` / `flag_dev`: the two addresses of the word; `seq`: this call's number.
+// landing area and the host watches that word (bounded: after two million looks, some tens of milliseconds -- no frame call
+// takes that long -- it sleeps on the stream after all).  `flag_host` / `flag_dev`: the two addresses of the word; `seq`: this call's number.
 inline int wait_for_signal(hipStream_t s, volatile unsigned long long *flag_host, unsigned long long *flag_dev, unsigned long long seq) {
     if (dabk::launch_signal(flag_dev, seq, s) != hipSuccess) return DABGPU_ERR_HIP;
     for (long i = 0; i < 2000000; i++) {
