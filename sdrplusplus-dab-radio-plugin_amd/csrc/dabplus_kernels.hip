@@ -19,6 +19,23 @@ struct GfLds {
     uint8_t exp[512];
     uint8_t log[256];
 };
+// GF(2^8) tables, x^8 + x^4 + x^3 + x^2 + 1, alpha = 2: made by the compiler, copied into LDS by all lanes (one thread
+// building them with a 512-step loop at the head of every launch was ~3 us of a ~40 us kernel)
+constexpr GfLds make_gf_tables() {
+    GfLds g{};
+    unsigned x = 1;
+    for (int i = 0; i < 255; i++) {
+        g.exp[i] = uint8_t(x);
+        g.log[x] = uint8_t(i);
+        x <<= 1;
+        if (x & 0x100u) x ^= 0x11Du;
+    }
+    for (int i = 255; i < 512; i++) g.exp[i] = g.exp[i - 255];
+    g.log[0] = 0;
+    return g;
+}
+__device__ const GfLds GF_TABLES = make_gf_tables();
+static_assert(sizeof(GfLds) == 768, "copied as 192 words");
 
 __device__ __forceinline__ unsigned gmul(const GfLds &g, unsigned a, unsigned b) {
     return (a && b) ? g.exp[g.log[a] + g.log[b]] : 0u;
@@ -159,19 +176,8 @@ __global__ __launch_bounds__(64) void dabplus_superframe_kernel(const uint8_t *i
     const int tid = threadIdx.x;
     const int nbytes = 120 * s;
     const uint8_t *src = in + size_t(blockIdx.x) * in_stride;
-    // GF(2^8) tables: x^8 + x^4 + x^3 + x^2 + 1, alpha = 2
-    if (tid == 0) {
-        unsigned x = 1;
-        for (int i = 0; i < 255; i++) {
-            g.exp[i] = uint8_t(x);
-            g.log[x] = uint8_t(i);
-            x <<= 1;
-            if (x & 0x100u) x ^= 0x11Du;
-        }
-        for (int i = 255; i < 512; i++) g.exp[i] = g.exp[i - 255];
-        g.log[0] = 0;
-        sh_corrected = 0; sh_bad = 0; sh_mask = 0; sh_naus = 0;
-    }
+    for (int i = tid; i < 192; i += 64) reinterpret_cast<uint32_t *>(&g)[i] = reinterpret_cast<const uint32_t *>(&GF_TABLES)[i];
+    if (tid == 0) { sh_corrected = 0; sh_bad = 0; sh_mask = 0; sh_naus = 0; }
     // the super-frame into LDS: 16 bytes per lane and trip when the source allows (one or two round trips -- the source
     // may be the caller's page-locked host buffer), bytes otherwise
     if (((reinterpret_cast<uintptr_t>(src) | size_t(nbytes)) & 15) == 0) {
