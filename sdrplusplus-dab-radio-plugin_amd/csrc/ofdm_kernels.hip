@@ -26,8 +26,6 @@
 // loaded: a wave only talks to itself.  Soft bits are scattered as bytes into the (then idle) exchange buffer and
 // leave as three coalesced 16-byte stores per lane.
 #include <algorithm>
-#include <cstdio>
-#include <cstdlib>
 
 #include "kernels.hpp"
 #include "dab_tables.hpp"
@@ -695,132 +693,12 @@ __global__ __launch_bounds__(64 * WAVES, 3) void geometry_mover_kernel(const flo
 }
 }  // namespace
 
-namespace {
-// Experiment (tools/phased_mover.py, profiles/r05_write_bursts.md): the same mover with the whole chip writing in bursts.  A wave
-// holds the output of up to `hold` symbols back and stores it only while the chip-wide 100 MHz clock (s_memrealtime) is inside a
-// window of W ticks every P ticks; no wave starts a symbol's loads inside the window.  The waits are bounded.
-__device__ __forceinline__ bool burst_window_open(unsigned P, unsigned W) { return unsigned(wall_clock64() % P) < W; }
-template <bool PREFIXES>
-__global__ __launch_bounds__(64 * WAVES, 3) void geometry_mover_bursts_kernel(const float2 *iq, size_t frame_stride, int8_t *soft,
-                                                                               int uncut_frames, int parts, int n_items, unsigned P,
-                                                                               unsigned W, int hold) {
-    __shared__ char occupancy[sizeof(WaveLds)];
-    const int lane = threadIdx.x & 63;
-    if (n_items < 0) occupancy[threadIdx.x] = 1;               // (never: keeps the array)
-    const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES + (threadIdx.x >> 6));
-    if (item >= n_items) return;
-    int frame = item, part = 0;
-    if (item >= uncut_frames) {
-        const int j = item - uncut_frames;
-        frame = uncut_frames + j / parts;
-        part = j - (frame - uncut_frames) * parts;
-    } else {
-        parts = 1;
-    }
-    const float2 *fiq = iq + size_t(frame) * frame_stride;
-    const int l_first = (NB_DATA_SYMBOLS * part) / parts, l_last = (NB_DATA_SYMBOLS * (part + 1)) / parts;
-    uint4 acc = make_uint4(1u, 2u, 3u, 4u);
-    int pending = 0;
-    for (int l = l_first; l <= l_last; l++) {
-        for (int spin = 0; spin < 2048 && burst_window_open(P, W); spin++) __builtin_amdgcn_s_sleep(4);
-        const float2 *sym = fiq + size_t(l) * NB_SYM_PERIOD;
-        const uint4 *rows = reinterpret_cast<const uint4 *>(sym + NB_CP) + lane;
-        uint4 v[16];
-#pragma unroll
-        for (int i = 0; i < 16; i++) v[i] = ld_stream(rows + 64 * i);
-        if (PREFIXES ? (l > l_first || l == 0) : l == 0) {
-            const uint4 *cp = reinterpret_cast<const uint4 *>(sym + 2 * (lane - 4));
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-                if (i > 0 || lane >= 4) { const uint4 c = ld_stream(cp + 64 * i); acc.x += c.x; acc.y ^= c.y; acc.z += c.z; acc.w ^= c.w; }
-        }
-#pragma unroll
-        for (int i = 0; i < 16; i++) { acc.x += v[i].x; acc.y ^= v[i].y; acc.z += v[i].z; acc.w ^= v[i].w; }
-        if (l > l_first) pending++;
-        if (pending == hold || (l == l_last && pending)) {
-            for (int spin = 0; spin < 2048 && !burst_window_open(P, W); spin++) __builtin_amdgcn_s_sleep(4);
-            for (int k = pending - 1; k >= 0; k--) {
-                uint4 *o = reinterpret_cast<uint4 *>(soft + size_t(frame) * NB_FRAME_BITS + size_t(l - 1 - k) * NB_SYM_BITS) + lane;
-                st_stream(o, acc); st_stream(o + 64, acc); st_stream(o + 128, acc);
-            }
-            pending = 0;
-        }
-    }
-}
-}  // namespace
-
-namespace {
-// Second form of the experiment: nothing is held back by the waves; the stores are ordinary write-back stores that stay dirty in the
-// XCD's L2, and when the window opens one wave in `every` writes the L2 back (buffer_wbl2) -- the burst comes out of the cache.
-__global__ __launch_bounds__(64 * WAVES, 3) void geometry_mover_l2_bursts_kernel(const float2 *iq, size_t frame_stride, int8_t *soft,
-                                                                                  int uncut_frames, int parts, int n_items, unsigned P,
-                                                                                  unsigned W, int every, int gate_loads) {
-    __shared__ char occupancy[sizeof(WaveLds)];
-    const int lane = threadIdx.x & 63;
-    if (n_items < 0) occupancy[threadIdx.x] = 1;
-    const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES + (threadIdx.x >> 6));
-    if (item >= n_items) return;
-    int frame = item, part = 0;
-    if (item >= uncut_frames) {
-        const int j = item - uncut_frames;
-        frame = uncut_frames + j / parts;
-        part = j - (frame - uncut_frames) * parts;
-    } else {
-        parts = 1;
-    }
-    const float2 *fiq = iq + size_t(frame) * frame_stride;
-    const int l_first = (NB_DATA_SYMBOLS * part) / parts, l_last = (NB_DATA_SYMBOLS * (part + 1)) / parts;
-    uint4 acc = make_uint4(1u, 2u, 3u, 4u);
-    const bool flusher = (item % every) == 0;
-    unsigned long long flushed = ~0ull;
-    for (int l = l_first; l <= l_last; l++) {
-        const unsigned long long now = wall_clock64();
-        if (unsigned(now % P) < W) {
-            if (flusher && now / P != flushed) { asm volatile("buffer_wbl2 sc1\n\ts_waitcnt vmcnt(0)" ::: "memory"); flushed = now / P; }
-            if (gate_loads) for (int spin = 0; spin < 2048 && burst_window_open(P, W); spin++) __builtin_amdgcn_s_sleep(4);
-        }
-        const float2 *sym = fiq + size_t(l) * NB_SYM_PERIOD;
-        const uint4 *rows = reinterpret_cast<const uint4 *>(sym + NB_CP) + lane;
-        uint4 v[16];
-#pragma unroll
-        for (int i = 0; i < 16; i++) v[i] = ld_stream(rows + 64 * i);
-        if (l > l_first || l == 0) {
-            const uint4 *cp = reinterpret_cast<const uint4 *>(sym + 2 * (lane - 4));
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-                if (i > 0 || lane >= 4) { const uint4 c = ld_stream(cp + 64 * i); acc.x += c.x; acc.y ^= c.y; acc.z += c.z; acc.w ^= c.w; }
-        }
-#pragma unroll
-        for (int i = 0; i < 16; i++) { acc.x += v[i].x; acc.y ^= v[i].y; acc.z += v[i].z; acc.w ^= v[i].w; }
-        if (l > l_first) {
-            uint4 *o = reinterpret_cast<uint4 *>(soft + size_t(frame) * NB_FRAME_BITS + size_t(l - 1) * NB_SYM_BITS) + lane;
-            o[0] = acc; o[64] = acc; o[128] = acc;
-        }
-    }
-}
-}  // namespace
-
 hipError_t launch_geometry_mover(const float2 *iq, size_t frame_stride, int n_frames, int8_t *soft, int uncut_frames, int parts,
                                  bool prefixes, hipStream_t s) {
     if (n_frames <= 0) return hipSuccess;
     if (parts <= 0 || parts > NB_DATA_SYMBOLS || uncut_frames < 0 || uncut_frames > n_frames) return hipErrorInvalidValue;
     const int items = uncut_frames + (n_frames - uncut_frames) * parts;
     const dim3 grid(unsigned((items + WAVES - 1) / WAVES)), block(64 * WAVES);
-    if (const char *e = std::getenv("DABGPU_MOVER_BURSTS")) {   // "period_us,window_percent,hold": the experiment above, never set by the library
-        float p_us = 0.f, w_pct = 0.f; int hold = 0, every = 0, gate = 0;
-        const int got = std::sscanf(e, "%f,%f,%d,%d,%d", &p_us, &w_pct, &hold, &every, &gate);
-        if (got == 5 && hold == 0 && every > 0 && p_us > 0.f && w_pct > 0.f && w_pct < 100.f) {   // "period_us,window_percent,0,every,gate_loads"
-            const unsigned P = unsigned(p_us * 100.f), W = std::max(1u, unsigned(p_us * w_pct));
-            hipLaunchKernelGGL(geometry_mover_l2_bursts_kernel, grid, block, 0, s, iq, frame_stride, soft, uncut_frames, parts, items, P, W, every, gate);
-            return hipGetLastError();
-        }
-        if (got >= 3 && p_us > 0.f && w_pct > 0.f && w_pct < 100.f && hold > 0) {
-            const unsigned P = unsigned(p_us * 100.f), W = std::max(1u, unsigned(p_us * w_pct));
-            if (prefixes) hipLaunchKernelGGL(geometry_mover_bursts_kernel<true>, grid, block, 0, s, iq, frame_stride, soft, uncut_frames, parts, items, P, W, hold);
-            else hipLaunchKernelGGL(geometry_mover_bursts_kernel<false>, grid, block, 0, s, iq, frame_stride, soft, uncut_frames, parts, items, P, W, hold);
-            return hipGetLastError();
-        }
-    }
     if (prefixes) hipLaunchKernelGGL(geometry_mover_kernel<true>, grid, block, 0, s, iq, frame_stride, soft, uncut_frames, parts, items);
     else hipLaunchKernelGGL(geometry_mover_kernel<false>, grid, block, 0, s, iq, frame_stride, soft, uncut_frames, parts, items);
     return hipGetLastError();

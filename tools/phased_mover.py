@@ -6,6 +6,10 @@ on the bench's buffers (64 x 256 frames, the placed IQ / soft-bit pair and a pla
 DABGPU_MOVER_BURSTS=period_us,window_percent,hold (csrc/ofdm_kernels.hip: output held back for up to `hold` symbols and
 stored only inside a chip-wide clock window; no loads start inside the window).  One process, alternating launches.
 
+The DABGPU_MOVER_BURSTS hook and its two kernels exist in the library of commit 0791219 only (the experiment was rejected,
+profiles/r05_write_bursts.md, and the product library reads no environment); check that commit out and `make -C
+sdrplusplus-dab-radio-plugin_amd/csrc` to run this again.  tools/ubench/phased_rw.hip shows the effect without the library.
+
 usage: python3 tools/phased_mover.py [--frames 16384] > gpurun_out/phased_mover.txt
 """
 import argparse
