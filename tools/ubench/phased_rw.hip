@@ -89,6 +89,40 @@ __global__ __launch_bounds__(256) void lockstep(const v4 *in, v4 *out, size_t n_
     }
 }
 
+// lock step with the front end's arithmetic emulated: `work` rounds of 80 independent FMAs on the loaded registers per symbol
+// (27 rounds ~ 4 300 VALU cycles per symbol-wave, what the fused kernel spends), so that a sleeping wave costs arithmetic too
+__global__ __launch_bounds__(256) void lockstep_work(const v4 *in, v4 *out, size_t n_chunks, int cpw, unsigned P, unsigned W, int nb, int work) {
+    extern __shared__ char lds[];
+    const int lane = threadIdx.x & 63;
+    const size_t wave = size_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    v4 acc = {0, 0, 0, 0};
+    int pending = 0;
+    for (int c = 0; c < cpw; c++) {
+        const size_t chunk = wave * cpw + c;
+        if (chunk >= n_chunks) break;
+        if (W) for (int spin = 0; spin < 4096 && unsigned(wall_clock64() % P) < W; spin++) __builtin_amdgcn_s_sleep(4);
+        const v4 *p = in + chunk * (20 * 64) + lane;
+        v4 v[20];
+#pragma unroll
+        for (int i = 0; i < 20; i++) v[i] = ld_nt(p + 64 * i);
+        for (int r = 0; r < work; r++) {
+#pragma unroll
+            for (int i = 0; i < 20; i++) v[i] = v[i] * 1.0001f + 0.5f;
+        }
+#pragma unroll
+        for (int i = 0; i < 20; i++) acc += v[i];
+        pending++;
+        if (pending == nb || c == cpw - 1 || chunk + 1 >= n_chunks) {
+            if (W) for (int spin = 0; spin < 4096 && unsigned(wall_clock64() % P) >= W; spin++) __builtin_amdgcn_s_sleep(4);
+            for (int k = pending - 1; k >= 0; k--) {
+                v4 *o = out + (chunk - k) * 192 + lane;
+                st_nt(o, acc); st_nt(o + 64, acc); st_nt(o + 128, acc);
+            }
+            pending = 0;
+        }
+    }
+}
+
 static float time_it(void (*launch)(void *), void *arg) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float best = 1e9f;
@@ -104,6 +138,11 @@ struct Args { const v4 *in; v4 *out; size_t n_chunks; int cpw; unsigned P, W; in
 template <int NB> static void launch_gated(void *a_) {
     Args &a = *static_cast<Args *>(a_);
     hipLaunchKernelGGL((gated<NB>), dim3(a.grid), dim3(256), a.lds, 0, a.in, a.out, a.n_chunks, a.cpw, a.P, a.W, a.mode, a.stat);
+}
+static int g_work = 27;
+static void launch_lock_work(void *a_) {
+    Args &a = *static_cast<Args *>(a_);
+    hipLaunchKernelGGL(lockstep_work, dim3(a.grid), dim3(256), a.lds, 0, a.in, a.out, a.n_chunks, a.cpw, a.P, a.W, a.nb, g_work);
 }
 static void launch_lock(void *a_) {
     Args &a = *static_cast<Args *>(a_);
@@ -131,7 +170,8 @@ int main(int argc, char **argv) {
         if (stats) printf("   flushes in window %llu forced %llu sleeps %llu", h[0], h[1], h[2]);
         printf("\n");
     };
-    for (int mode : {1, 2})
+    const bool full = argc > 1;
+    if (full) for (int mode : {1, 2})
         for (unsigned P_us : {4u, 10u, 20u, 40u, 80u, 160u})
             for (double share : {0.15, 0.3}) {
                 a.mode = mode; a.P = P_us * 100; a.W = unsigned(a.P * share);
@@ -140,12 +180,25 @@ int main(int argc, char **argv) {
                 hipMemset(stat, 0, 24); float t4 = time_it(launch_gated<4>, &a); hipMemset(stat, 0, 24); launch_gated<4>(&a); hipDeviceSynchronize(); row(what, 4, P_us, share, t4, true);
                 hipMemset(stat, 0, 24); float t8 = time_it(launch_gated<8>, &a); hipMemset(stat, 0, 24); launch_gated<8>(&a); hipDeviceSynchronize(); row(what, 8, P_us, share, t8, true);
             }
-    for (int nb : {1, 2, 4, 8})
+    if (full) for (int nb : {1, 2, 4, 8})
         for (unsigned P_us : {10u, 20u, 40u, 80u, 160u})
             for (double share : {0.15, 0.25}) {
                 a.nb = nb; a.P = P_us * 100; a.W = unsigned(a.P * share);
                 row("lock step", nb, P_us, share, time_it(launch_lock, &a), false);
             }
+    for (int work : {14, 27, 40}) {
+        g_work = work;
+        a.nb = 1; a.P = 1000; a.W = 0;
+        const float wbase = time_it(launch_lock_work, &a);
+        printf("with %d rounds of 80 FMAs per symbol, no gating: %.3f ms  %.0f GB/s\n", work, wbase, gb / wbase * 1e3);
+        for (int nb : {2, 3, 4, 8})
+            for (unsigned P_us : {12u, 16u, 20u, 24u, 32u, 40u, 60u})
+                for (double share : {0.15, 0.25}) {
+                    a.nb = nb; a.P = P_us * 100; a.W = unsigned(a.P * share);
+                    const float ms = time_it(launch_lock_work, &a);
+                    printf("  lock step + work %d  hold <= %d  period %4u us  window %2.0f %%   %.3f ms  (%+.1f %%)\n", work, nb, P_us, share * 100, ms, (ms / wbase - 1) * 100);
+                }
+    }
     a.mode = 0;
     float again = time_it(launch_gated<1>, &a);
     printf("plain again                                                      %.3f ms\n", again);
