@@ -7,7 +7,9 @@
 //   thread j < s     RS(120,110) decode of byte-interleaved column j: syndromes by Horner, and only if one is
 //                    non-zero Berlekamp-Massey + Chien + Forney (<= 5 byte errors), GF(2^8)/0x11D via log tables
 //   thread 0         Fire code over header bytes 2..10, AU table (2/3/4/6 access units, 12-bit starts)
-//   thread a < n_au  CRC16-CCITT of access unit a
+//   all 64 threads   CRC16-CCITT of each access unit in turn: every lane takes a contiguous piece from register state 0 (the first
+//                    piece from 0xFFFF), multiplies it by x^(8 * bytes behind the piece) mod the generator, and the wave XORs
+//                    the sixty-four results -- the CRC is linear over GF(2)
 // Byte-serial integer work at kB/s rates: one LDS-resident super-frame, no attempt at a roofline.
 #include "kernels.hpp"
 
@@ -36,6 +38,34 @@ constexpr GfLds make_gf_tables() {
 }
 __device__ const GfLds GF_TABLES = make_gf_tables();
 static_assert(sizeof(GfLds) == 768, "copied as 192 words");
+
+// x^(8 k) mod x^16 + x^12 + x^5 + 1 for k = 0 .. 110 * 64 + 65: what a CRC register that has taken a piece of an access unit still
+// has to be multiplied by when k more bytes follow the piece
+constexpr int CRC_Z_MAX = 110 * 64 + 66;
+struct CrcShift {
+    uint16_t z[CRC_Z_MAX];
+};
+constexpr CrcShift make_crc_shift() {
+    CrcShift t{};
+    unsigned v = 1;
+    for (int k = 0; k < CRC_Z_MAX; k++) {
+        t.z[k] = uint16_t(v);
+        for (int b = 0; b < 8; b++) v = (v & 0x8000u) ? (((v << 1) ^ 0x1021u) & 0xFFFFu) : (v << 1);
+    }
+    return t;
+}
+__device__ const CrcShift CRC_SHIFT = make_crc_shift();
+
+// a(x) b(x) mod x^16 + x^12 + x^5 + 1 (16-bit operands)
+__device__ __forceinline__ unsigned crc_mulmod(unsigned a, unsigned b) {
+    unsigned r = 0;
+#pragma unroll
+    for (int bit = 15; bit >= 0; bit--) {
+        r = (r & 0x8000u) ? (((r << 1) ^ 0x1021u) & 0xFFFFu) : (r << 1);
+        if ((a >> bit) & 1u) r ^= b;
+    }
+    return r;
+}
 
 __device__ __forceinline__ unsigned gmul(const GfLds &g, unsigned a, unsigned b) {
     return (a && b) ? g.exp[g.log[a] + g.log[b]] : 0u;
@@ -170,13 +200,23 @@ __global__ __launch_bounds__(64) void dabplus_superframe_kernel(const uint8_t *i
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     GfLds &g = *reinterpret_cast<GfLds *>(smem);
     uint8_t *sf = smem + sizeof(GfLds);
+    const int n_z = 110 * s + 66;                                  // shift table entries this super-frame can ask for
+    uint16_t *zt = reinterpret_cast<uint16_t *>(smem + sizeof(GfLds) + ((size_t(120) * s + 15) & ~size_t(15)));
     __shared__ int sh_corrected, sh_bad, sh_mask, sh_naus;
     __shared__ int sh_start[8];
     __shared__ unsigned sh_syn[64][10];
     const int tid = threadIdx.x;
     const int nbytes = 120 * s;
     const uint8_t *src = in + size_t(blockIdx.x) * in_stride;
+#ifdef DABPLUS_PHASE_TIMING
+    const long long t0 = wall_clock64();
+    long long t1 = 0, t2 = 0, t3 = 0;
+#define STAMP(v) v = wall_clock64()
+#else
+#define STAMP(v)
+#endif
     for (int i = tid; i < 192; i += 64) reinterpret_cast<uint32_t *>(&g)[i] = reinterpret_cast<const uint32_t *>(&GF_TABLES)[i];
+    for (int i = tid; i < n_z / 2; i += 64) reinterpret_cast<uint32_t *>(zt)[i] = reinterpret_cast<const uint32_t *>(&CRC_SHIFT)[i];
     if (tid == 0) { sh_corrected = 0; sh_bad = 0; sh_mask = 0; sh_naus = 0; }
     // the super-frame into LDS: 16 bytes per lane and trip when the source allows (one or two round trips -- the source
     // may be the caller's page-locked host buffer), bytes otherwise
@@ -188,6 +228,7 @@ __global__ __launch_bounds__(64) void dabplus_superframe_kernel(const uint8_t *i
     if (tid < 8) sh_start[tid] = 0;
     for (int i = tid; i < 64 * 10; i += 64) (&sh_syn[0][0])[i] = 0;
     __syncthreads();
+    STAMP(t1);
     rs_syndromes(g, sf, s, tid, sh_syn);
     __syncthreads();
     if (tid < s) {
@@ -196,6 +237,7 @@ __global__ __launch_bounds__(64) void dabplus_superframe_kernel(const uint8_t *i
         else if (r > 0) atomicAdd(&sh_corrected, r);
     }
     __syncthreads();
+    STAMP(t2);
     int fire_ok = 0;
     if (tid == 0) {
         unsigned crc = 0, any = unsigned(sf[0]) | sf[1];
@@ -211,27 +253,39 @@ __global__ __launch_bounds__(64) void dabplus_superframe_kernel(const uint8_t *i
             const int dac_rate = (sf[2] >> 6) & 1, sbr = (sf[2] >> 5) & 1;
             const int naus = dac_rate ? (sbr ? 3 : 6) : (sbr ? 2 : 4);
             sh_start[0] = naus == 2 ? 5 : naus == 3 ? 6 : naus == 4 ? 8 : 11;
-            int bitpos = 24;
-            for (int a = 1; a < naus; a++) {
-                int v = 0;
-                for (int b = 0; b < 12; b++, bitpos++) v = (v << 1) | ((sf[bitpos >> 3] >> (7 - (bitpos & 7))) & 1);
-                sh_start[a] = v;
-            }
+            // the 12-bit start addresses follow the header byte back to back: bytes 3 .. 10 as one 64-bit word
+            unsigned long long w = 0;
+            for (int i = 3; i < 11; i++) w = (w << 8) | sf[i];
+            for (int a = 1; a < naus; a++) sh_start[a] = int((w >> (64 - 12 * a)) & 0xFFFu);
             sh_start[naus] = 110 * s;
             sh_naus = naus;
         }
     }
     __syncthreads();
-    if (tid < sh_naus) {
-        const int b0 = sh_start[tid], b1 = sh_start[tid + 1];
-        if (b0 >= 3 && b1 <= 110 * s && b1 - b0 >= 3) {
-            unsigned crc = 0xFFFFu;
-            for (int i = b0; i < b1 - 2; i++) crc = crc_ccitt_byte(crc, sf[i]);
+    {
+        const int naus = sh_naus;
+        for (int a = 0; a < naus; a++) {
+            const int b0 = sh_start[a], b1 = sh_start[a + 1];                 // (the same for every lane)
+            if (!(b0 >= 3 && b1 <= 110 * s && b1 - b0 >= 3)) continue;
+            // len payload bytes, cut into 64 pieces of m, padded AT THE FRONT: lane l takes the padded positions
+            // [l m, (l + 1) m), and (63 - l) m bytes follow its piece
+            const int len = b1 - 2 - b0, m = (len + 63) >> 6, pad = 64 * m - len;
+            int lo = tid * m - pad;
+            const int hi = lo + m;
+            unsigned crc = 0;
+            if (hi > 0) {
+                if (lo <= 0) { lo = 0; crc = 0xFFFFu; }                        // the piece the message starts in
+                for (int i = lo; i < hi; i++) crc = crc_ccitt_byte(crc, sf[b0 + i]);
+                crc = crc_mulmod(crc, zt[(63 - tid) * m]);
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) crc ^= unsigned(__shfl_xor(int(crc), off));
             crc ^= 0xFFFFu;
-            if (crc == ((unsigned(sf[b1 - 2]) << 8) | sf[b1 - 1])) atomicOr(&sh_mask, 1 << tid);
+            if (tid == 0 && crc == ((unsigned(sf[b1 - 2]) << 8) | sf[b1 - 1])) sh_mask |= 1 << a;
         }
     }
     __syncthreads();
+    STAMP(t3);
     uint8_t *dst = out + size_t(blockIdx.x) * size_t(110 * s);
     for (int i = tid; i < 110 * s; i += 64) dst[i] = sf[i];
     if (tid == 0) {
@@ -243,6 +297,9 @@ __global__ __launch_bounds__(64) void dabplus_superframe_kernel(const uint8_t *i
         st.au_crc_mask = sh_mask;
         for (int a = 0; a < 8; a++) st.au_start[a] = sh_start[a];
         st.reserved[0] = st.reserved[1] = st.reserved[2] = 0;
+#ifdef DABPLUS_PHASE_TIMING
+        st.reserved[0] = int(t1 - t0); st.reserved[1] = int(t2 - t1); st.reserved[2] = int(t3 - t2);   // 100 MHz ticks: staging | RS | header + CRCs
+#endif
         status[blockIdx.x] = st;
     }
 }
@@ -253,7 +310,7 @@ hipError_t launch_dabplus_superframes(const uint8_t *in, size_t in_stride, int n
                                       SuperframeStatus *status, hipStream_t stream) {
     if (n_superframes <= 0) return hipSuccess;
     if (s < 1 || s > 64) return hipErrorInvalidValue;
-    const size_t lds = sizeof(GfLds) + size_t(120) * s;
+    const size_t lds = sizeof(GfLds) + ((size_t(120) * s + 15) & ~size_t(15)) + (((size_t(110) * s + 66) * 2 + 3) & ~size_t(3));
     hipLaunchKernelGGL(dabplus_superframe_kernel, dim3(unsigned(n_superframes)), dim3(64), lds, stream, in, in_stride,
                        s, out, status);
     return hipGetLastError();

@@ -29,6 +29,12 @@ with tempfile.TemporaryDirectory() as d:
         r = subprocess.run([exe, path, os.path.join(d, "out"), chunk], stdout=subprocess.PIPE, text=True, timeout=600,
                            env=dict(os.environ, DAB_DEMO_PRELOAD="1"))
         assert r.returncode == 0, r.stderr
+    if os.environ.get("DEMO_RATE_TRACE"):
+        # kernel durations of the same run (rocprofv3 starts the demo itself; this process never touches the GPU)
+        td = os.environ["DEMO_RATE_TRACE"]
+        subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", td, "-o", "demo", "--", exe, path,
+                        os.path.join(d, "out"), chunk], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900,
+                       env=dict(os.environ, DAB_DEMO_PRELOAD="1", TMPDIR="/tmp"), cwd="/tmp")
     line = r.stdout.strip().splitlines()[-1]
     read = int(line.split("frames_read=")[1].split()[0])
     dt = float(r.stdout.split("processing_s=")[1].split()[0])
