@@ -124,12 +124,15 @@ int main(int argc, char **argv) {
         in.seekg(0);
         in.read(reinterpret_cast<char *>(all.data()), std::streamsize(all.size() * sizeof(all[0])));
     }
+    // DAB_DEMO_CONSTELLATION=1: poll GetFrameDataVec() once per chunk, as the GUI's constellation view does
+    const bool look = std::getenv("DAB_DEMO_CONSTELLATION") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
     std::vector<std::complex<float>> buf(chunk);
     if (preload) {
         for (size_t at = 0; at < all.size(); at += chunk) {
             const auto t0 = std::chrono::steady_clock::now();
             demod->Process(tcb::span<std::complex<float>>(all.data() + at, std::min(chunk, all.size() - at)));
+            if (look) (void)demod->GetFrameDataVec();
             t_ofdm += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         }
     } else {
@@ -138,6 +141,7 @@ int main(int argc, char **argv) {
             const size_t got = size_t(in.gcount()) / sizeof(buf[0]);
             if (!got) break;
             demod->Process(tcb::span<std::complex<float>>(buf.data(), got));   // non-const span, as dab_module.cpp does
+            if (look) (void)demod->GetFrameDataVec();
         }
     }
     ring->close();
@@ -171,6 +175,13 @@ int main(int argc, char **argv) {
             }
             std::fclose(f);
         }
+    }
+    {
+        // what the constellation holds at the end: unit-power differential symbols when somebody looked, nothing otherwise
+        double p = 0.0;
+        const auto vec = look ? demod->GetFrameDataVec() : tcb::span<const std::complex<float>>();
+        for (const auto &d : vec) p += double(std::norm(d));
+        std::printf("constellation_mean_power=%.6g\n", vec.empty() ? 0.0 : p / double(vec.size()));
     }
     std::printf("processing_s=%.6f ofdm_process_s=%.6f radio_process_s=%.6f\n", t_proc, t_ofdm, t_radio);
     std::printf("state=%d frames_read=%d frames_desync=%d fine=%.6g net=%.6g level=%.4f fibs=%d fib_errors=%d\n",

@@ -7,6 +7,22 @@
 #include <cstring>
 #include <stdexcept>
 
+#ifdef DABHOST_TIMING
+#include <chrono>
+#include <cstdio>
+static double g_ofdm_t[3];
+static long g_ofdm_n;
+struct OfdmLap {
+    int i;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    explicit OfdmLap(int k) : i(k) {}
+    ~OfdmLap() { g_ofdm_t[i] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); }
+};
+#define OFDM_LAP(i) OfdmLap lap_##i(i)
+#else
+#define OFDM_LAP(i)
+#endif
+
 // one relaxed atomic read of a knob the GUI thread may be writing (GetConfig(): plain fields, see the header)
 template <class T>
 static inline T knob(const T &v) {
@@ -44,7 +60,13 @@ OFDM_Demod::OFDM_Demod(const OFDM_Params &params, tcb::span<const std::complex<f
     reset_now();
 }
 
-OFDM_Demod::~OFDM_Demod() { dabgpu_destroy(m_ctx); }
+OFDM_Demod::~OFDM_Demod() {
+#ifdef DABHOST_TIMING
+    if (g_ofdm_n) std::fprintf(stderr, "OFDM_Demod per frame, us: copy into the frame buffer %.1f | frame call %.1f | On_OFDM_Frame observers %.1f (%ld frames)\n",
+                               g_ofdm_t[0] / g_ofdm_n * 1e6, g_ofdm_t[1] / g_ofdm_n * 1e6, g_ofdm_t[2] / g_ofdm_n * 1e6, g_ofdm_n);
+#endif
+    dabgpu_destroy(m_ctx);
+}
 
 // Any thread (the GUI's "Reset" button, /root/reference/src/render_radio_block.cpp:95-97): what the getters show starts
 // over at once; the buffers and the device-side state start over on the Process thread, at the top of its next call.
@@ -122,7 +144,10 @@ size_t OFDM_Demod::take_locked(const std::complex<float> *x, size_t n) {
         i = d;
     }
     const size_t take = std::min(n - i, frame_len - m_frame_fill);
-    std::memcpy(m_frame.data() + m_frame_fill, x + i, take * sizeof(*x));
+    {
+        OFDM_LAP(0);
+        std::memcpy(m_frame.data() + m_frame_fill, x + i, take * sizeof(*x));
+    }
     m_frame_fill += take;
     if (m_frame_fill == frame_len) {
         demodulate_frame();
@@ -208,8 +233,22 @@ void OFDM_Demod::demodulate_frame() {
         cfg.max_coarse_carriers = std::max(0, std::min(1023, int(knob(m_cfg.sync.max_coarse_freq_correction_norm) * float(m_params.nb_fft))));
     m_state = m_is_acquiring ? State::RUNNING_COARSE_FREQ_SYNC : State::RUNNING_FINE_TIME_SYNC;
     dabgpu_frame_result res{};
+#ifdef DABHOST_TIMING
+    g_ofdm_n++;
+    const auto t_call = std::chrono::steady_clock::now();
+#endif
+    // the constellation only while a display asks for it (GetFrameDataVec): 0.9 MB of download and a slower launch otherwise saved
+    bool want_dqpsk = false;
+    if (m_frame_data_wanted.load(std::memory_order_relaxed) > 0) {
+        m_frame_data_wanted.fetch_sub(1, std::memory_order_relaxed);
+        want_dqpsk = true;
+    }
     const int rc = dabgpu_ofdm_demod_stream_frame(m_ctx, 0, reinterpret_cast<const float *>(m_frame.data()), m_is_acquiring ? 1 : 0,
-                                                  &cfg, m_soft.data(), reinterpret_cast<float *>(m_frame_data_vec.data()), &res);
+                                                  &cfg, m_soft.data(),
+                                                  want_dqpsk ? reinterpret_cast<float *>(m_frame_data_vec.data()) : nullptr, &res);
+#ifdef DABHOST_TIMING
+    g_ofdm_t[1] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_call).count();
+#endif
     if (rc != DABGPU_OK) {   // no exceptions on the streaming path: count it as a lost frame
         m_host_desyncs++;
         m_total_frames_desync.fetch_add(1, std::memory_order_relaxed);
@@ -245,5 +284,6 @@ void OFDM_Demod::demodulate_frame() {
         m_in_null = false;
         return;
     }
+    OFDM_LAP(2);
     m_obs_on_ofdm_frame.Notify(tcb::span<const viterbi_bit_t>(m_soft.data(), m_soft.size()));
 }

@@ -95,7 +95,15 @@ public:
     int GetTotalFramesRead() const { return m_total_frames_read.load(std::memory_order_relaxed); }
     int GetTotalFramesDesync() const { return m_total_frames_desync.load(std::memory_order_relaxed); }
     OFDM_Demod_Config &GetConfig() { return m_cfg; }
-    tcb::span<const std::complex<float>> GetFrameDataVec() const { return {m_frame_data_vec.data(), m_frame_data_vec.size()}; }
+    // The differential symbols of the last frame (the GUI's constellation, /root/reference/src/render_radio_block.cpp:109).  They
+    // are 0.9 MB per frame that nothing but a display reads: the frame call brings them along only while somebody is looking --
+    // every call here asks for the next FRAME_DATA_KEEP frames' worth (a GUI polls at its refresh rate; the first look after a
+    // pause shows the last frame fetched, the next DAB frame, <= 96 ms later, is fresh).
+    static constexpr int FRAME_DATA_KEEP = 32;
+    tcb::span<const std::complex<float>> GetFrameDataVec() const {
+        m_frame_data_wanted.store(FRAME_DATA_KEEP, std::memory_order_relaxed);
+        return {m_frame_data_vec.data(), m_frame_data_vec.size()};
+    }
     Observable<tcb::span<const viterbi_bit_t>> &On_OFDM_Frame() { return m_obs_on_ofdm_frame; }
 
     // extension: apply a known coarse offset (cycles/sample); it goes to the device-side state the demodulation reads
@@ -143,5 +151,6 @@ private:
     // outputs
     PinnedBuffer<viterbi_bit_t> m_soft;             // page-locked: downloaded every frame
     PinnedBuffer<std::complex<float>> m_frame_data_vec;
+    mutable std::atomic<int> m_frame_data_wanted{0};   // frames that still take the constellation along (GetFrameDataVec)
     Observable<tcb::span<const viterbi_bit_t>> m_obs_on_ofdm_frame;
 };

@@ -116,6 +116,31 @@ def test_demo_recovers_transmitted_data(host_built, tmp_path, chunk, cfo):
 
 
 @pytest.mark.gpu
+def test_demo_constellation_only_while_somebody_looks(host_built, tmp_path):
+    """OFDM_Demod::GetFrameDataVec() (the GUI's constellation, render_radio_block.cpp:109): the 0.9 MB of differential symbols per
+    frame come back from the device only while the getter is being polled; what the demodulator hands on is the same either
+    way."""
+    ens = synth.Ensemble(seed=78, n_frames=8)
+    iq = synth.channel(ens.iq().ravel(), snr_db=18.0, cfo=0.1 / 2048, rng=np.random.default_rng(6))
+    path = tmp_path / "iq.cf32"
+    np.concatenate([iq[-30000:], iq, iq[:synth.NB_NULL + 5000]]).astype(np.complex64).tofile(path)
+    fibs = []
+    for look in (False, True):
+        prefix = str(tmp_path / ("out%d" % look))
+        env = dict(os.environ)
+        env.pop("DAB_DEMO_CONSTELLATION", None)
+        if look:
+            env["DAB_DEMO_CONSTELLATION"] = "1"
+        r = subprocess.run([os.path.join(HOST, "dab_host_demo"), str(path), prefix, "65536"], capture_output=True, text=True,
+                           timeout=300, env=env)
+        assert r.returncode == 0, r.stderr
+        power = float(r.stdout.split("constellation_mean_power=")[1].split()[0])
+        assert (power > 0.0 and np.isfinite(power)) if look else power == 0.0, r.stdout
+        fibs.append(np.fromfile(prefix + ".fib", np.uint8))
+    assert fibs[0].size == 8 * 12 * 32 and (fibs[0] == fibs[1]).all()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name,kw", [
     ("echoes", dict(paths=[(0, 1.0), (60, 0.6 * np.exp(1j)), (210, 0.4 * np.exp(-2j))])),
     ("late_echo_stronger", dict(paths=[(0, 1.0), (180, 1.3 * np.exp(0.3j))])),
