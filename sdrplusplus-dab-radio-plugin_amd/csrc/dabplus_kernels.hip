@@ -17,7 +17,7 @@ namespace dabk {
 
 namespace {
 
-struct GfLds {
+struct alignas(16) GfLds {
     uint8_t exp[512];
     uint8_t log[256];
 };
@@ -42,8 +42,8 @@ static_assert(sizeof(GfLds) == 768, "copied as 192 words");
 // x^(8 k) mod x^16 + x^12 + x^5 + 1 for k = 0 .. 110 * 64 + 65: what a CRC register that has taken a piece of an access unit still
 // has to be multiplied by when k more bytes follow the piece
 constexpr int CRC_Z_MAX = 110 * 64 + 66;
-struct CrcShift {
-    uint16_t z[CRC_Z_MAX];
+struct alignas(16) CrcShift {
+    uint16_t z[CRC_Z_MAX];                                     // (copied into LDS as 32-bit words)
 };
 constexpr CrcShift make_crc_shift() {
     CrcShift t{};

@@ -7,7 +7,7 @@ import pytest
 from dabgpu import synth
 from oracle import oracle as O
 
-CASES = [(64, 1, 0), (32, 0, 1), (96, 1, 1), (128, 0, 0), (8, 0, 1), (192, 1, 0)]
+CASES = [(64, 1, 0), (32, 0, 1), (96, 1, 1), (128, 0, 0), (8, 0, 1), (192, 1, 0), (288, 0, 1), (256, 1, 0)]   # (12-bit AU start addresses: 110 s <= 4095)
 
 
 def test_rs_and_firecode_agree_with_builder():
