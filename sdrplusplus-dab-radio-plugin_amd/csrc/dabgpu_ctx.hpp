@@ -165,8 +165,10 @@ struct ScopedTimer {
 // wake-up; instead a one-thread launch behind the call's last kernel stores the call's number into a word of the page-locked
 // landing area and the host watches that word (bounded: after two million looks, some tens of milliseconds -- no frame call
 // takes that long -- it sleeps on the stream after all).  `flag_host` / `flag_dev`: the two addresses of the word; `seq`: this call's number.
-inline int wait_for_signal(hipStream_t s, volatile unsigned long long *flag_host, unsigned long long *flag_dev, unsigned long long seq) {
-    if (dabk::launch_signal(flag_dev, seq, s) != hipSuccess) return DABGPU_ERR_HIP;
+// (already_signalled: the last kernel of the call stores the word itself -- a single-workgroup launch can)
+inline int wait_for_signal(hipStream_t s, volatile unsigned long long *flag_host, unsigned long long *flag_dev, unsigned long long seq,
+                           bool already_signalled = false) {
+    if (!already_signalled && dabk::launch_signal(flag_dev, seq, s) != hipSuccess) return DABGPU_ERR_HIP;
     for (long i = 0; i < 2000000; i++) {
         if (*flag_host == seq) {
             __atomic_thread_fence(__ATOMIC_ACQUIRE);

@@ -666,12 +666,20 @@ int dabgpu_dabplus_superframes(dabgpu_ctx *ctx, const uint8_t *in, size_t in_str
             void *h_dev = nullptr;
             HIP_TRY(hipHostGetDevicePointer(&h_dev, ctx->h_bounce, 0));
             hipStream_t st = ctx->stream;
+            const size_t off_flag = ctx->h_bounce_bytes - 64;
+            volatile unsigned long long *flag_host = reinterpret_cast<volatile unsigned long long *>(static_cast<char *>(ctx->h_bounce) + off_flag);
+            unsigned long long *flag_dev = reinterpret_cast<unsigned long long *>(static_cast<char *>(h_dev) + off_flag);
+            const unsigned long long seq = ++ctx->signal_seq;
+            if (n_superframes == 1) {
+                // ONE super-frame (the host mirror's call) is ONE workgroup: it stores the watched word itself, behind its results
+                HIP_TRY(dabk::launch_dabplus_superframes(static_cast<const uint8_t *>(a_in), in_stride, 1, s, static_cast<uint8_t *>(a_out),
+                                                         reinterpret_cast<dabk::SuperframeStatus *>(a_st), st, flag_dev, seq));
+                return wait_for_signal(st, flag_host, flag_dev, seq, true);
+            }
             const int rc0 = dabgpu_dabplus_superframes_dev(ctx, static_cast<const uint8_t *>(a_in), in_stride, n_superframes, bitrate_kbps,
                                                            static_cast<uint8_t *>(a_out), static_cast<dabgpu_superframe_status *>(a_st), st);
             if (rc0) return rc0;
-            const size_t off_flag = ctx->h_bounce_bytes - 64;
-            return wait_for_signal(st, reinterpret_cast<volatile unsigned long long *>(static_cast<char *>(ctx->h_bounce) + off_flag),
-                                   reinterpret_cast<unsigned long long *>(static_cast<char *>(h_dev) + off_flag), ++ctx->signal_seq);
+            return wait_for_signal(st, flag_host, flag_dev, seq);
         }
     }
     void *d_in, *d_out, *d_st;

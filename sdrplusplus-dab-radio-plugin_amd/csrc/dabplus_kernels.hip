@@ -196,7 +196,8 @@ __device__ int rs_decode_column(const GfLds &g, uint8_t *sf, int j, int s, const
 }
 
 __global__ __launch_bounds__(64) void dabplus_superframe_kernel(const uint8_t *in, size_t in_stride, int s,
-                                                                uint8_t *out, SuperframeStatus *status) {
+                                                                uint8_t *out, SuperframeStatus *status,
+                                                                unsigned long long *done_flag, unsigned long long done_seq) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     GfLds &g = *reinterpret_cast<GfLds *>(smem);
     uint8_t *sf = smem + sizeof(GfLds);
@@ -302,17 +303,25 @@ __global__ __launch_bounds__(64) void dabplus_superframe_kernel(const uint8_t *i
 #endif
         status[blockIdx.x] = st;
     }
+    if (done_flag) {
+        // (a launch of ONE workgroup: launch_dabplus_superframes.)  Every lane's stores -- the corrected bytes, lane 0's status
+        // record -- are out at system scope before the barrier; only then is the word stored that the host is watching.
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 }  // namespace
 
 hipError_t launch_dabplus_superframes(const uint8_t *in, size_t in_stride, int n_superframes, int s, uint8_t *out,
-                                      SuperframeStatus *status, hipStream_t stream) {
+                                      SuperframeStatus *status, hipStream_t stream, unsigned long long *done_flag,
+                                      unsigned long long done_seq) {
     if (n_superframes <= 0) return hipSuccess;
-    if (s < 1 || s > 64) return hipErrorInvalidValue;
+    if (s < 1 || s > 64 || (done_flag && n_superframes != 1)) return hipErrorInvalidValue;
     const size_t lds = sizeof(GfLds) + ((size_t(120) * s + 15) & ~size_t(15)) + (((size_t(110) * s + 66) * 2 + 3) & ~size_t(3));
     hipLaunchKernelGGL(dabplus_superframe_kernel, dim3(unsigned(n_superframes)), dim3(64), lds, stream, in, in_stride,
-                       s, out, status);
+                       s, out, status, done_flag, done_seq);
     return hipGetLastError();
 }
 

@@ -306,8 +306,11 @@ struct SuperframeStatus {      // == dabgpu_superframe_status
     int32_t au_start[8];
     int32_t reserved[3];
 };
+// `done_flag` (optional, ONE super-frame only): the launch's single workgroup stores `done_seq` there behind its results --
+// the word a host thread watches (dabgpu_ctx.hpp wait_for_signal) -- instead of a launch of its own behind the kernel
 hipError_t launch_dabplus_superframes(const uint8_t *in, size_t in_stride, int n_superframes, int s, uint8_t *out,
-                                      SuperframeStatus *status, hipStream_t stream);
+                                      SuperframeStatus *status, hipStream_t stream, unsigned long long *done_flag = nullptr,
+                                      unsigned long long done_seq = 0);
 
 // ---- channel decoder (viterbi_kernels.hip) ---------------------------------
 struct CodeTables {
