@@ -531,13 +531,16 @@ def firecode16(data):
     return crc
 
 
-def build_superframe(rng, bitrate, dac_rate=1, sbr=0, channel_mode=1, ps=0):
-    """-> (sf uint8[120*s], au_start list with the end appended, list of AU payloads incl. CRC)."""
+def build_superframe(rng, bitrate, dac_rate=1, sbr=0, channel_mode=1, ps=0, cuts=None):
+    """-> (sf uint8[120*s], au_start list with the end appended, list of AU payloads incl. CRC).
+    cuts: the start addresses of access units 1 .. n-1 (default: drawn at random)."""
     s = bitrate // 8
     size = 110 * s
     num_aus = {(0, 1): 2, (1, 1): 3, (0, 0): 4, (1, 0): 6}[(dac_rate, sbr)]
     first = {2: 5, 3: 6, 4: 8, 6: 11}[num_aus]
-    cuts = np.sort(rng.choice(np.arange(first + 8, size - 8, 4), num_aus - 1, replace=False))
+    if cuts is None:
+        cuts = np.sort(rng.choice(np.arange(first + 8, size - 8, 4), num_aus - 1, replace=False))
+    assert len(cuts) == num_aus - 1 and all(first + 3 <= c for c in cuts) and all(b - a >= 3 for a, b in zip(cuts, list(cuts[1:]) + [size]))
     starts = [first] + [int(c) for c in cuts] + [size]
     sf = np.zeros(120 * s, np.uint8)
     sf[2] = (dac_rate << 6) | (sbr << 5) | (channel_mode << 4) | (ps << 3)

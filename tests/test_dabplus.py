@@ -167,6 +167,31 @@ def test_gpu_superframe_profiles(ctx, bitrate, dac_rate, sbr):
 
 
 @pytest.mark.gpu
+def test_gpu_access_unit_crcs_at_extreme_lengths(ctx):
+    """The kernel checks an access unit's CRC on all 64 lanes (pieces of ceil(len / 64) bytes, padded at the front): units of 1, 2,
+    64, 65 and 128 payload bytes and one long one, each clean and each with one byte wrong, against the oracle."""
+    rng = np.random.default_rng(11)
+    first = 11                                                    # six access units at 48 kHz without SBR
+    cuts = [first + 3, first + 3 + 4, first + 7 + 66, first + 73 + 67, first + 140 + 130]
+    sf, starts, aus = synth.build_superframe(rng, 64, 1, 0, cuts=cuts)
+    assert [b - a - 2 for a, b in zip(starts, starts[1:])] == [1, 2, 64, 65, 128, 880 - starts[5] - 2]
+    batch = [sf]
+    for a in range(6):
+        e = sf.copy()
+        e[starts[a] + (starts[a + 1] - starts[a] - 2) // 2] ^= 0x40   # inside unit a's payload; the RS parity is made to agree
+        for j in range(8):                                            # (the code would repair a lone error)
+            e[110 * 8 + j::8] = synth.rs_parity(e[j:110 * 8:8])
+        batch.append(e)
+    out, st = ctx.dabplus_superframes(np.stack(batch), 64)
+    for i in range(len(batch)):
+        c, ost, oau = O.dabplus_superframe(batch[i], 8)
+        got = [int(st["firecode_ok"][i]), int(st["rs_corrected"][i]), int(st["rs_uncorrectable"][i]), int(st["num_aus"][i]),
+               int(st["au_crc_mask"][i])]
+        assert got == ost.tolist() and (out[i] == c[:880]).all(), (i, got, ost)
+        assert got[4] == (0x3F if i == 0 else 0x3F ^ (1 << (i - 1))), (i, got)
+
+
+@pytest.mark.gpu
 def test_end_to_end_iq_to_access_units(ctx):
     """IQ -> OFDM -> MSC Viterbi -> super-frame: the subchannel carries real DAB+ super-frames."""
     import dabgpu
