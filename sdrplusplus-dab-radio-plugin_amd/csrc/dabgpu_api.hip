@@ -234,10 +234,15 @@ int dabgpu_create(const dabgpu_cfg *cfg, dabgpu_ctx **out) {
             rc = DABGPU_ERR_HIP;
             break;
         }
-        std::vector<float2> tw(NB_FFT);
+        std::vector<float2> tw(NB_FFT + 64 + 512);
         for (int m = 0; m < NB_FFT; m++) {
             const double a = -2.0 * M_PI * double(m) / double(NB_FFT);
             tw[m] = make_float2(float(std::cos(a)), float(std::sin(a)));
+        }
+        // ... and the same values again in the order the synchronisation's block FFT reads them (fft_common.hpp TWC8_OFF / TWC64_OFF)
+        for (int r = 0; r < 8; r++) {
+            for (int k = 0; k < 8; k++) tw[NB_FFT + r * 8 + k] = tw[32 * r * k];
+            for (int k = 0; k < 64; k++) tw[NB_FFT + 64 + r * 64 + k] = tw[4 * r * k];
         }
         if ((rc = upload(&ctx->d_twiddle, tw))) break;
         const std::vector<int32_t> mapper = make_mapper();

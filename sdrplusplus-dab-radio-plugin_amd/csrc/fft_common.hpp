@@ -99,33 +99,52 @@ __device__ __forceinline__ uint32_t dphi_of(const float *freq_offset, int frame)
     return uint32_t(q);
 }
 
-// One Stockham pass with radix 8 from LDS to LDS.
-template <int NS>
-__device__ __forceinline__ void pass8(const float2 *src, float2 *dst, const float2 *tw, int j) {
+// Where entry L of an intermediate buffer lives.  A float2 takes two of the 64 LDS banks, so the 32 lanes of one pass of a
+// ds_write_b64 must hit 32 different slots modulo 32.  The first stage writes L = 8 tid + r (lanes 64 bytes apart: sixteen
+// lanes per slot pair as it stood), the second L = 64 (j >> 3) + (j & 7) + 8 r (four groups on the same slots): an XOR with
+// bits that are CONSTANT over the 32 / 64 consecutive entries a read takes keeps the reads conflict-free and spreads the writes.
+__device__ __forceinline__ int swz1(int L) { return L ^ ((L >> 5) & 7); }
+__device__ __forceinline__ int swz2(int L) { return L ^ (((L >> 6) & 3) << 3); }
+
+// The twiddles of the two radix-8 passes, behind the natural table exp(-2 pi i m / 2048), m < 2048, in the order the lanes read
+// them: pass NS = 8 takes W^(32 r k), k = j & 7 (eight lanes a bank pair apart as it stood: 256-byte stride), pass NS = 64
+// W^(4 r k), k = j & 63 (32-byte stride) -- here [r][k], consecutive lanes on consecutive entries.
+constexpr int TWC8_OFF = NB_FFT, TWC64_OFF = NB_FFT + 64, TW_TOTAL = NB_FFT + 64 + 512;
+
+// One Stockham pass with radix 8 from LDS to LDS (SRC / DST: 0 natural, 1 swz1, 2 swz2); twc: this pass's compact twiddles [8][NS].
+template <int NS, int SRC, int DST>
+__device__ __forceinline__ void pass8(const float2 *src, float2 *dst, const float2 *twc, int j) {
     float2 v[8];
     const int k = j & (NS - 1);
 #pragma unroll
-    for (int r = 0; r < 8; r++) v[r] = src[j + r * (NB_FFT / 8)];
+    for (int r = 0; r < 8; r++) {
+        const int L = j + r * (NB_FFT / 8);
+        v[r] = src[SRC == 1 ? swz1(L) : SRC == 2 ? swz2(L) : L];
+    }
 #pragma unroll
-    for (int r = 1; r < 8; r++) v[r] = cmul(v[r], tw[r * k * (NB_FFT / (NS * 8))]);
+    for (int r = 1; r < 8; r++) v[r] = cmul(v[r], twc[r * NS + k]);
     fft8(v);
     const int j0 = (j - k) * 8 + k;
 #pragma unroll
-    for (int r = 0; r < 8; r++) dst[j0 + r * NS] = v[r];
+    for (int r = 0; r < 8; r++) {
+        const int L = j0 + r * NS;
+        dst[DST == 1 ? swz1(L) : DST == 2 ? swz2(L) : L] = v[r];
+    }
 }
 
 
 // 2048-point forward FFT by one 256-thread workgroup.  Each thread passes its eight inputs x[tid + 256*r]
 // in v[]; the result lands in `out` (natural order).  t1 and out are 2048-entry LDS buffers (distinct), tw the
-// exp(-2*pi*i*m/2048) table in LDS.  Ends with a barrier.
-__device__ __forceinline__ void block_fft2048(float2 (&v)[8], float2 *t1, float2 *out, const float2 *tw, int tid) {
+// exp(-2*pi*i*m/2048) table (LDS or global), twc8 / twc64 the compact tables of the two radix-8 passes.  Ends with a barrier.
+__device__ __forceinline__ void block_fft2048(float2 (&v)[8], float2 *t1, float2 *out, const float2 *tw, const float2 *twc8,
+                                              const float2 *twc64, int tid) {
     fft8(v);
 #pragma unroll
-    for (int r = 0; r < 8; r++) t1[tid * 8 + r] = v[r];
+    for (int r = 0; r < 8; r++) t1[swz1(tid * 8 + r)] = v[r];
     __syncthreads();
-    pass8<8>(t1, out, tw, tid);
+    pass8<8, 1, 2>(t1, out, twc8, tid);
     __syncthreads();
-    pass8<64>(out, t1, tw, tid);
+    pass8<64, 2, 0>(out, t1, twc64, tid);
     __syncthreads();
 #pragma unroll
     for (int h = 0; h < 2; h++) {

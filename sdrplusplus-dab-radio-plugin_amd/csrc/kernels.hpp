@@ -107,7 +107,7 @@ hipError_t launch_stream_update(StreamState *state, const float2 *cyc, const flo
 
 // ---- synchronisation on the PRS (sync_kernels.hip) -----------------------------
 struct SyncTables {
-    const float2 *twiddle;     // [2048]
+    const float2 *twiddle;     // [2048 + 576]: natural order, then the block FFT's compact tables (fft_common.hpp TW_TOTAL)
     const int8_t *prs_qt;      // [2048] quarter turns of the PRS per bin, -1 = not a carrier
     const uint16_t *pairs;     // [n_pairs] adjacent carrier pairs: bin | ((qt[bin+1]-qt[bin])&3) << 11
     int n_pairs;

@@ -27,7 +27,7 @@ namespace {
 
 struct SyncLds {
     double red_d[2][WG];        // acquisition: cyclic-prefix correlation
-    float2 tw[NB_FFT];
+    float2 tw[TW_TOTAL];        // natural table + the radix-8 passes' compact ones (fft_common.hpp)
     float2 t1[NB_FFT];
     float2 x[NB_FFT];
     float2 y[NB_FFT];           // coarse search: spectrum of Q, then the correlation over all 2048 shifts
@@ -58,29 +58,35 @@ __device__ __forceinline__ float2 rot_mq(float2 v, int q) {
     }
 }
 
-// block-wide argmax with "first maximum" semantics (smaller index wins ties) and the sum of all values
+// block-wide argmax with "first maximum" semantics (smaller index wins ties) and the sum of all values.  Inside a wave the
+// reduction is a butterfly of lane exchanges (no barrier); the four waves' results meet in LDS: two barriers per call instead
+// of the ten of a 256-wide LDS tree -- this kernel is all barriers and latency.
 template <class Lds>
 __device__ __forceinline__ void block_argmax_sum(Lds &sm, int tid, float m, int idx, float s, float &best_m,
                                                  int &best_i, float &total) {
-    sm.red_m[tid] = m;
-    sm.red_i[tid] = idx;
-    sm.red_s[tid] = s;
-    __syncthreads();
-    for (int off = WG / 2; off > 0; off >>= 1) {
-        if (tid < off) {
-            const float m2 = sm.red_m[tid + off];
-            const int i2 = sm.red_i[tid + off];
-            if (m2 > sm.red_m[tid] || (m2 == sm.red_m[tid] && i2 < sm.red_i[tid])) {
-                sm.red_m[tid] = m2;
-                sm.red_i[tid] = i2;
-            }
-            sm.red_s[tid] += sm.red_s[tid + off];
-        }
-        __syncthreads();
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float m2 = __shfl_xor(m, off);
+        const int i2 = __shfl_xor(idx, off);
+        s += __shfl_xor(s, off);
+        if (m2 > m || (m2 == m && i2 < idx)) { m = m2; idx = i2; }
     }
+    if ((tid & 63) == 0) {
+        sm.red_m[tid >> 6] = m;
+        sm.red_i[tid >> 6] = idx;
+        sm.red_s[tid >> 6] = s;
+    }
+    __syncthreads();
     best_m = sm.red_m[0];
     best_i = sm.red_i[0];
     total = sm.red_s[0];
+#pragma unroll
+    for (int w = 1; w < WG / 64; w++) {
+        const float m2 = sm.red_m[w];
+        const int i2 = sm.red_i[w];
+        if (m2 > best_m || (m2 == best_m && i2 < best_i)) { best_m = m2; best_i = i2; }
+        total += sm.red_s[w];
+    }
     __syncthreads();
 }
 
@@ -184,10 +190,11 @@ __global__ __launch_bounds__(WG) void prs_sync_kernel(SyncTables tab, const floa
         tw = tab.twiddle;
         pw = reinterpret_cast<float *>(sm.t1);
     } else {
-        for (int i = tid; i < NB_FFT; i += WG) sm.tw[i] = tab.twiddle[i];
+        for (int i = tid; i < TW_TOTAL; i += WG) sm.tw[i] = tab.twiddle[i];
         tw = sm.tw;
         pw = reinterpret_cast<float *>(sm.y);
     }
+    const float2 *const twc8 = tw + TWC8_OFF, *const twc64 = tw + TWC64_OFF;
     for (int i = tid; i < NB_FFT; i += WG) sm.qt[i] = tab.prs_qt[i];
     __syncthreads();
     for (int frame = blockIdx.x; frame < n_total; frame += n_sync_blocks) {
@@ -251,7 +258,7 @@ __global__ __launch_bounds__(WG) void prs_sync_kernel(SyncTables tab, const floa
             v[r] = prefetched ? pre[r] : sym[NB_CP + n];
             if (dphi != 0u) v[r] = cmul(v[r], nco(uint32_t(n), dphi));
         }
-        block_fft2048(v, sm.t1, sm.x, tw, tid);
+        block_fft2048(v, sm.t1, sm.x, tw, twc8, twc64, tid);
     }
     float best_m, total;
     int khat = 0;
@@ -273,7 +280,7 @@ __global__ __launch_bounds__(WG) void prs_sync_kernel(SyncTables tab, const floa
 #pragma unroll
             for (int r = 0; r < 8; r++) v[r] = sm.t1[tid + r * WG];
             __syncthreads();                                   // t1 is the transform's scratch from here on
-            block_fft2048(v, sm.t1, sm.y, sm.tw, tid);
+            block_fft2048(v, sm.t1, sm.y, sm.tw, twc8, twc64, tid);
 #pragma unroll
             for (int r = 0; r < 8; r++) {
                 const int b = tid + r * WG;
@@ -281,7 +288,7 @@ __global__ __launch_bounds__(WG) void prs_sync_kernel(SyncTables tab, const floa
                 v[r] = make_float2(z.x, -z.y);
             }
             __syncthreads();
-            block_fft2048(v, sm.t1, sm.y, sm.tw, tid);
+            block_fft2048(v, sm.t1, sm.y, sm.tw, twc8, twc64, tid);
         }
         float my_m = -1.0f, my_s = 0.0f;
         int my_k = 0x7fffffff;
@@ -312,7 +319,7 @@ __global__ __launch_bounds__(WG) void prs_sync_kernel(SyncTables tab, const floa
             v[r] = z;
         }
         __syncthreads();          // everyone has read x[] before the FFT overwrites it
-        block_fft2048(v, sm.t1, sm.x, tw, tid);
+        block_fft2048(v, sm.t1, sm.x, tw, twc8, twc64, tid);
     }
     // power of every tap into pw[] (kept for the first-path scan), weighted score for the peak choice (PeakRule)
     float my_m = -1.0f, my_s = 0.0f;

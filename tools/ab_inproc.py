@@ -5,7 +5,7 @@ usage: tools/ab_inproc.py <mode> <n_frames> <rounds> <reps> lib1.so lib2.so ... 
 modes: ofdm (fused front end, NCO + cyc) | dd (the same with decision-directed sums, no cyclic prefix read) |
        select_dd (dd with a soft-bit selection) | bare (no estimator output at all) | fft (FFT stage only) | select (front end with a soft-bit selection) |
        acquire (null search + PRS sync on unaligned captures) | decode (FIC + one sub-channel, grouped launch) |
-       multiplex (FIC + 18 sub-channels)"""
+       multiplex (FIC + 18 sub-channels) | sync (PRS synchronisation of every frame, fine time only) | sync_coarse (with the +-200 carrier search)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "sdrplusplus-dab-radio-plugin_amd")); sys.path.insert(0, ROOT)
@@ -16,7 +16,7 @@ dev = torch.device("cuda", 0)
 L, NB = dabgpu.NB_FRAME_SAMPLES, dabgpu.NB_FRAME_BITS
 st = torch.cuda.Stream(); torch.cuda.set_stream(st); s = st.cuda_stream
 E = 64; F = max(1, n // E)
-if mode in ("ofdm", "fft", "select", "acquire", "dd", "select_dd", "bare"):
+if mode in ("ofdm", "fft", "select", "acquire", "dd", "select_dd", "bare", "sync", "sync_coarse"):
     iq = torch.empty((n, L, 2), dtype=torch.float32, device=dev).normal_()
     fo = torch.full((n,), 1.0e-4, dtype=torch.float32, device=dev)
 if mode in ("ofdm", "select"):
@@ -32,6 +32,9 @@ elif mode in ("dd", "select_dd", "bare"):
         def run(c): c.ofdm_demod_frames_dev(iq.data_ptr(), L, n, fo.data_ptr(), soft.data_ptr(), None, None, s)
     else:
         def run(c): c.ofdm_demod_frames_dd_dev(iq.data_ptr(), L, n, fo.data_ptr(), soft.data_ptr(), dd4.data_ptr(), s)
+elif mode in ("sync", "sync_coarse"):
+    sres = torch.zeros((n, 4), dtype=torch.int32, device=dev); outs = [sres]; sel = None
+    def run(c): c.sync_prs_dev(iq.data_ptr() + 2656 * 8, L, n, fo.data_ptr(), 200 if mode == "sync_coarse" else 0, sres.data_ptr(), s)
 elif mode == "fft":
     spec = torch.zeros((n, 76, 2048, 2), dtype=torch.float32, device=dev); outs = [spec]; sel = None
     def run(c): c.fft_symbols_dev(iq.data_ptr(), L, n, fo.data_ptr(), spec.data_ptr(), s)
