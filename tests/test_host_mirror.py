@@ -4,6 +4,7 @@ against the mirror headers (only where /root/reference is mounted).  GPU: the de
 ring buffer -> BasicRadio like Radio_Block does recovers the transmitted FIBs / MSC bytes from a cf32 file fed in
 arbitrary chunks."""
 import os
+import shutil
 import subprocess
 
 import numpy as np
@@ -68,6 +69,31 @@ def test_reference_render_radio_block_compiles_unchanged(host_built):
     tuner:: and {fmt} are TEST-ONLY declarations under tests/stubs written from its call sites; syntax only."""
     r = subprocess.run(["make", "-C", HOST, "check_reference_render_radio_block"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/src/radio_block.cpp") or shutil.which("cmake") is None,
+                    reason="reference not mounted / no cmake")
+def test_cmake_targets_carry_the_plugins_own_names(host_built, tmp_path):
+    """host/CMakeLists.txt defines `ofdm_core`, `dab_core` and `basic_radio` -- the names the plugin's src/CMakeLists.txt links
+    (/root/reference/src/CMakeLists.txt:23-26) -- with their include directories attached: a project written like that file
+    (sources from src/, include directories that point into the absent DAB-Radio sub-module, the same three names) builds the
+    reference's unchanged radio_block.cpp into a shared library with no undefined symbol left.  Nothing is copied or run."""
+    (tmp_path / "CMakeLists.txt").write_text(
+        "cmake_minimum_required(VERSION 3.13)\nproject(plug CXX)\nadd_compile_options(-fPIC)\n"
+        "add_subdirectory(%s dabgpu_host)\n"
+        "set(SRC_DIR /root/reference/src)\nset(DAB_RADIO_DIR /root/reference/vendor/DAB-Radio)\n"
+        "add_library(dab_plugin SHARED ${SRC_DIR}/radio_block.cpp)\n"
+        "set_target_properties(dab_plugin PROPERTIES CXX_STANDARD 17)\n"
+        "target_include_directories(dab_plugin PRIVATE ${SRC_DIR} ${DAB_RADIO_DIR}/src ${DAB_RADIO_DIR}/examples)\n"
+        "target_link_libraries(dab_plugin PRIVATE ofdm_core dab_core basic_radio)\n"
+        "target_link_options(dab_plugin PRIVATE -Wl,--no-undefined)\n" % HOST)
+    build = tmp_path / "build"
+    gen = ["-G", "Ninja"] if shutil.which("ninja") else []
+    r = subprocess.run(["cmake", "-S", str(tmp_path), "-B", str(build)] + gen, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    r = subprocess.run(["cmake", "--build", str(build)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert (build / "libdab_plugin.so").exists()
 
 
 @pytest.mark.gpu
