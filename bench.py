@@ -134,6 +134,10 @@ def parse_args(argv=None):
                       ("traffic", "measuring roofline.traffic now (two rocprofv3 --pmc child processes, ~20 s); the tracked figure "
                                   "of profiles/pmc_traffic.json is reported instead")):
         ap.add_argument("--no-" + leg, action="store_true", help="skip " + what)
+    ap.add_argument("--placement-recheck-above", type=float, default=0.985,
+                    help="with --placement domains: when the allocator's own check (mover on the placed pair over the mover inside one "
+                         "domain) is at or above this, the box behaves as one domain -- the mover is then timed on the placed pair and "
+                         "on a plain pair and the faster one is kept (0 = always time both, 2 = never)")
     ap.add_argument("--placement", choices=["plain", "domains"], default="domains",
                     help="how the IQ / soft-bit buffers are allocated (dabgpu_alloc_frame_buffers): two hipMallocs, or placed by "
                          "HBM domain (six plain / domains pairs on three boxes, profiles/r04_placement_ab.txt: front end 0.8-3.9 %% "
@@ -216,6 +220,40 @@ def main():
     # ---- the IQ / soft-bit pair (untimed set-up, reported in config.buffer_placement) ----
     d_iq_base, d_soft_base, rep = ctx.alloc_frame_buffers(n_frames, L, dabgpu.PLACE_DOMAINS if args.placement == "domains"
                                                           else dabgpu.PLACE_PLAIN)
+    # A box that "behaves as one HBM domain" (the placed pair no faster than a pair inside one domain: 2 of the 14 fresh boxes of
+    # profiles/r05_box_spread.txt) gets nothing from the placement; there the data mover is timed on the placed pair and on two
+    # plain hipMallocs and the faster pair stays (untimed set-up, ~0.1 s; the line says which and why).  No allocator code: the
+    # choice is made here, through the public entry points, as any caller could.
+    recheck = None
+    if args.placement == "domains" and rep.method == 1 and float(rep.pair_over_same_domain) >= args.placement_recheck_above:
+        def mover_min_ms(a_iq, a_soft):
+            best = None
+            for _ in range(4):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                ctx.mover_frames_dev(a_iq + synth.NB_NULL * 8, L, n_frames, a_soft, True, stream)
+                e1.record()
+                torch.cuda.synchronize()
+                t = e0.elapsed_time(e1)
+                best = t if best is None else min(best, t)
+            return best
+        rep_first = rep
+        t_placed = mover_min_ms(d_iq_base, d_soft_base)
+        ctx.free_frame_buffers(d_iq_base, d_soft_base)
+        p_iq, p_soft, rep_plain = ctx.alloc_frame_buffers(n_frames, L, dabgpu.PLACE_PLAIN)
+        t_plain = mover_min_ms(p_iq, p_soft)
+        recheck = {"why": "the placed pair is no faster than a pair inside one domain (%.3f >= %.3f)" % (float(rep.pair_over_same_domain),
+                                                                                                   args.placement_recheck_above),
+                   "mover_ms_on_the_placed_pair": round(t_placed, 3), "mover_ms_on_two_plain_allocations": round(t_plain, 3)}
+        if t_plain < 0.985 * t_placed:
+            d_iq_base, d_soft_base, rep = p_iq, p_soft, rep_plain
+            recheck["kept"] = "plain"
+            recheck["placed_pair_was"] = {"domains_seen": int(rep_first.n_domains),
+                                          "mover_on_pair_over_mover_in_one_domain": round(float(rep_first.pair_over_same_domain), 3)}
+        else:
+            ctx.free_frame_buffers(p_iq, p_soft)
+            d_iq_base, d_soft_base, rep = ctx.alloc_frame_buffers(n_frames, L, dabgpu.PLACE_DOMAINS)
+            recheck["kept"] = "placed"
     final_bytes = n_frames * (L * 8 + dabgpu.NB_FRAME_BITS)
     placement = {"requested": args.placement,
                  "method": "domain-aware pair (address ranges reserved once per context)" if rep.method == 1 else "plain hipMalloc pair",
@@ -227,8 +265,12 @@ def main():
                           "soft_bits_written_beside_same_domain_reads_per_mille": rep.conflicts,
                           "classify_ms": round(rep.classify_ms, 2),
                           "mover_on_pair_over_mover_in_one_domain": round(float(rep.pair_over_same_domain), 3)})
-    elif args.placement == "domains":
+    elif args.placement == "domains" and not (recheck and recheck["kept"] == "plain"):
         placement["fallback_reason"] = dabgpu.PLAIN_REASONS.get(rep.fallback_reason, str(rep.fallback_reason))
+    if recheck is not None:
+        placement["one_domain_box_recheck"] = recheck
+        if recheck["kept"] == "plain":
+            placement["method"] = "plain hipMalloc pair (measured faster than the placed pair on this box)"
     iq = dabgpu.device_tensor(torch, d_iq_base, (n_frames, L), torch.complex64, dev)
     soft = dabgpu.device_tensor(torch, d_soft_base, (n_frames, dabgpu.NB_FRAME_BITS), torch.int8, dev)
     cfo_true, ens = make_streams(torch, dev, ids, F, min(args.unique, E * world), args.snr, iq)

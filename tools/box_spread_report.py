@@ -9,24 +9,46 @@ import sys
 
 d = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/box_spread"
 rows = [json.load(open(f)) for f in sorted(glob.glob(d + "/*.json"))]
+
+
+def placed_ratio(r):
+    """mover on the placed pair over the mover inside one domain, of the FIRST placement (a re-check reports it inside its record)"""
+    rc = r.get("recheck") or {}
+    if "placed_pair_was" in rc:
+        return rc["placed_pair_was"]["mover_on_pair_over_mover_in_one_domain"]
+    return r["pair_over_one_domain"]
+
+
 print("The bench's timed step (reference-shaped loop, 64 x 256 frames) on fresh pool boxes, one gpurun call each (tools/box_spread.sh;")
 print("this table: tools/box_spread_report.py); `domains` = HBM domains the placement probe saw among its chunks; `pair/one` = a mover on")
-print("the placed pair over the same mover inside one domain (~0.9: the pair lies apart; ~1.0: the box behaves as ONE domain whatever the")
-print("probe's small timing differences said); `mover_frac` = roofline.box_mover_frac (the box's own ceiling for this read / write mix on")
-print("the scale of 8 TB/s); `frac` = roofline.frac.")
+print("the placed pair over the same mover inside one domain (~0.9: the pair lies apart; ~1.0: the virtual-memory API handed out")
+print("chunks of ONE domain only -- the box \"behaves as one domain\"); `mover_frac` = roofline.box_mover_frac (the ceiling for this")
+print("read / write mix on the buffers the run used, on the scale of 8 TB/s); `frac` = roofline.frac.  Rows 1-14: before bench.py")
+print("re-checked one-domain boxes; from row 15 on: when pair/one >= 0.985 the mover is timed on the placed pair and on two plain")
+print("hipMallocs and the faster pair is kept (`re-check`).")
 print()
-print("box domains  pair/one  mover ms  mover_frac  kernel ms  frac    k/mover   decoder ms  frames/s   step ms min/median/max")
+print("box domains  pair/one  mover ms  mover_frac  kernel ms  frac    k/mover   decoder ms  frames/s   step ms min/median/max   re-check")
 for i, r in enumerate(rows, 1):
     s = r["step_ms"]
-    print(f"{i:<3} {r['domains_seen']:<8} {r['pair_over_one_domain']:<9.3f} {r['mover_ms']:<9.3f} {r['box_mover_frac']:<11.4f} "
+    rc = r.get("recheck")
+    note = ""
+    if rc:
+        note = "placed %.3f ms, plain %.3f ms: kept %s" % (rc["mover_ms_on_the_placed_pair"], rc["mover_ms_on_two_plain_allocations"], rc["kept"])
+    dom = r["domains_seen"] if r["domains_seen"] is not None else (rc or {}).get("placed_pair_was", {}).get("domains_seen")
+    print(f"{i:<3} {str(dom):<8} {placed_ratio(r):<9.3f} {r['mover_ms']:<9.3f} {r['box_mover_frac']:<11.4f} "
           f"{r['kernel_ms']:<10.3f} {r['frac']:<7.4f} {r['kernel_over_mover']:<9.3f} {r['decoder_ms']:<11.3f} {r['value']:<10d} "
-          f"{s['min']:.2f} / {s['median']:.2f} / {s['max']:.2f}")
-one = [r for r in rows if r["pair_over_one_domain"] >= 0.985]
-two = [r for r in rows if r["pair_over_one_domain"] < 0.985]
+          f"{s['min']:.2f} / {s['median']:.2f} / {s['max']:.2f}     {note}")
+one = [r for r in rows if placed_ratio(r) >= 0.985]
+two = [r for r in rows if placed_ratio(r) < 0.985]
+kept_plain = [r for r in one if (r.get("recheck") or {}).get("kept") == "plain"]
+stuck = [r for r in one if r not in kept_plain and not r.get("recheck")]
 rng = lambda xs, k, f="{:.3f}": (f + "-" + f).format(min(x[k] for x in xs), max(x[k] for x in xs))
 print()
-print(f"{len(rows)} boxes; {len(one)} of them behave as one domain (pair/one >= 0.985): mover_frac {rng(one, 'box_mover_frac') if one else '-'} there against "
-      f"{rng(two, 'box_mover_frac')} on the others;")
-print(f"kernel / mover {rng(rows, 'kernel_over_mover')} on every box: the kernel follows its box's ceiling; frames/s "
-      f"{min(r['value'] for r in rows) / 1e6:.3f}-{max(r['value'] for r in rows) / 1e6:.3f} M "
-      f"({min(r['value'] for r in two) / 1e6:.3f}-{max(r['value'] for r in two) / 1e6:.3f} M on the boxes whose pair lies apart).")
+print(f"{len(rows)} boxes; on {len(one)} of them the first placement was no better than one domain (pair/one >= 0.985).  Without the re-check "
+      f"({len(stuck)} boxes): mover_frac {rng(stuck, 'box_mover_frac') if stuck else '-'}, frames/s "
+      f"{min(r['value'] for r in stuck) / 1e6:.3f}-{max(r['value'] for r in stuck) / 1e6:.3f} M;" if stuck else "")
+if kept_plain:
+    print(f"with it, on two plain allocations ({len(kept_plain)} box(es)): mover_frac {rng(kept_plain, 'box_mover_frac')}, frames/s "
+          f"{min(r['value'] for r in kept_plain) / 1e6:.3f}-{max(r['value'] for r in kept_plain) / 1e6:.3f} M.")
+print(f"The others: mover_frac {rng(two, 'box_mover_frac')}, frames/s {min(r['value'] for r in two) / 1e6:.3f}-{max(r['value'] for r in two) / 1e6:.3f} M.  "
+      f"kernel / mover {rng(rows, 'kernel_over_mover')} on every box: the kernel follows its buffers' ceiling.")
