@@ -220,7 +220,7 @@ def main():
     # ---- the IQ / soft-bit pair (untimed set-up, reported in config.buffer_placement) ----
     d_iq_base, d_soft_base, rep = ctx.alloc_frame_buffers(n_frames, L, dabgpu.PLACE_DOMAINS if args.placement == "domains"
                                                           else dabgpu.PLACE_PLAIN)
-    # A box that "behaves as one HBM domain" (the placed pair no faster than a pair inside one domain: 2 of the 14 fresh boxes of
+    # A box that "behaves as one HBM domain" (the placed pair no faster than a pair inside one domain: 3 of the 38 fresh boxes of
     # profiles/r05_box_spread.txt) gets nothing from the placement; there the data mover is timed on the placed pair and on two
     # plain hipMallocs and the faster pair stays (untimed set-up, ~0.1 s; the line says which and why).  No allocator code: the
     # choice is made here, through the public entry points, as any caller could.
