@@ -239,20 +239,19 @@ def main():
             return best
         rep_first = rep
         t_placed = mover_min_ms(d_iq_base, d_soft_base)
-        ctx.free_frame_buffers(d_iq_base, d_soft_base)
-        p_iq, p_soft, rep_plain = ctx.alloc_frame_buffers(n_frames, L, dabgpu.PLACE_PLAIN)
+        p_iq, p_soft, rep_plain = ctx.alloc_frame_buffers(n_frames, L, dabgpu.PLACE_PLAIN)      # (both pairs alive: 2 x 30 GB of 288)
         t_plain = mover_min_ms(p_iq, p_soft)
         recheck = {"why": "the placed pair is no faster than a pair inside one domain (%.3f >= %.3f)" % (float(rep.pair_over_same_domain),
                                                                                                    args.placement_recheck_above),
                    "mover_ms_on_the_placed_pair": round(t_placed, 3), "mover_ms_on_two_plain_allocations": round(t_plain, 3)}
         if t_plain < 0.985 * t_placed:
+            ctx.free_frame_buffers(d_iq_base, d_soft_base)
             d_iq_base, d_soft_base, rep = p_iq, p_soft, rep_plain
             recheck["kept"] = "plain"
             recheck["placed_pair_was"] = {"domains_seen": int(rep_first.n_domains),
                                           "mover_on_pair_over_mover_in_one_domain": round(float(rep_first.pair_over_same_domain), 3)}
         else:
             ctx.free_frame_buffers(p_iq, p_soft)
-            d_iq_base, d_soft_base, rep = ctx.alloc_frame_buffers(n_frames, L, dabgpu.PLACE_DOMAINS)
             recheck["kept"] = "placed"
     final_bytes = n_frames * (L * 8 + dabgpu.NB_FRAME_BITS)
     placement = {"requested": args.placement,
