@@ -12,6 +12,6 @@ row = {'host': socket.gethostname(), 'domains_seen': bp.get('domains_seen'), 'me
        'pair_over_one_domain': bp.get('mover_on_pair_over_mover_in_one_domain'),
        'mover_ms': round(ro['mover_same_geometry_ms'], 3), 'box_mover_frac': round(ro['box_mover_frac'], 4), 'kernel_ms': round(ro['avg_launch_ms'], 3),
        'frac': round(ro['frac'], 4), 'kernel_over_mover': round(ro['kernel_over_mover'], 3), 'decoder_ms': round(d['decoder']['fic_and_msc_ms'], 3),
-       'recheck': bp.get('one_domain_box_recheck'), 'value': round(d['value']), 'step_ms': {k: round(v, 3) for k, v in d['step_ms'].items() if k != 'what'}}
+       'recheck': bp.get('placed_vs_plain') or bp.get('one_domain_box_recheck'), 'value': round(d['value']), 'step_ms': {k: round(v, 3) for k, v in d['step_ms'].items() if k != 'what'}}
 print(json.dumps(row))
 " | tee $root/gpurun_out/box_spread/$(date +%s).json

@@ -24,8 +24,8 @@ print("this table: tools/box_spread_report.py); `domains` = HBM domains the plac
 print("the placed pair over the same mover inside one domain (~0.9: the pair lies apart; ~1.0: the virtual-memory API handed out")
 print("chunks of ONE domain only -- the box \"behaves as one domain\"); `mover_frac` = roofline.box_mover_frac (the ceiling for this")
 print("read / write mix on the buffers the run used, on the scale of 8 TB/s); `frac` = roofline.frac.  Rows 1-14: before bench.py")
-print("re-checked one-domain boxes; from row 15 on: when pair/one >= 0.985 the mover is timed on the placed pair and on two plain")
-print("hipMallocs and the faster pair is kept (`re-check`).")
+print("held the placed pair against plain allocations; rows 15-51: only when pair/one >= 0.985; from row 52 on: always -- the mover")
+print("is timed on the placed pair and on two plain hipMallocs and the faster pair is kept (`re-check`).")
 print()
 print("box domains  pair/one  mover ms  mover_frac  kernel ms  frac    k/mover   decoder ms  frames/s   step ms min/median/max   re-check")
 for i, r in enumerate(rows, 1):
