@@ -271,6 +271,7 @@ def main():
     elif args.placement == "domains" and not (recheck and recheck["kept"] == "plain"):
         placement["fallback_reason"] = dabgpu.PLAIN_REASONS.get(rep.fallback_reason, str(rep.fallback_reason))
     if recheck is not None:
+        recheck["bytes_held_while_both_pairs_were_alive"] = int(2 * final_bytes)
         placement["placed_vs_plain"] = recheck
         if recheck["kept"] == "plain":
             placement["method"] = "plain hipMalloc pair (measured faster than the placed pair on this box)"
