@@ -242,20 +242,29 @@ def main():
             return best
         rep_first = rep
         t_placed = mover_min_ms(d_iq_base, d_soft_base)
-        p_iq, p_soft, rep_plain = ctx.alloc_frame_buffers(n_frames, L, dabgpu.PLACE_PLAIN)      # (both pairs alive: 2 x 30 GB of 288)
+        # A check near 1.00 says the placed pair IS the worst case (both buffers in one domain): it is given back first, so that
+        # the plain pair is not allocated around it (5.07 ms that way on the first such box, 5.47 ms beside the placed pair on the
+        # second); otherwise both pairs stay alive while they are timed (2 x 30 GB of 288) and no second placement is needed.
+        one_domain = float(rep.pair_over_same_domain) >= 0.985
+        if one_domain:
+            ctx.free_frame_buffers(d_iq_base, d_soft_base)
+        p_iq, p_soft, rep_plain = ctx.alloc_frame_buffers(n_frames, L, dabgpu.PLACE_PLAIN)
         t_plain = mover_min_ms(p_iq, p_soft)
         recheck = {"allocators_own_check": round(float(rep.pair_over_same_domain), 3),
                    "what": "mover timed on the placed pair and on two plain hipMallocs, the faster pair kept (a check near 1.00 = the "
                            "virtual-memory API handed out chunks of one HBM domain only)",
                    "mover_ms_on_the_placed_pair": round(t_placed, 3), "mover_ms_on_two_plain_allocations": round(t_plain, 3)}
         if t_plain < 0.985 * t_placed:
-            ctx.free_frame_buffers(d_iq_base, d_soft_base)
+            if not one_domain:
+                ctx.free_frame_buffers(d_iq_base, d_soft_base)
             d_iq_base, d_soft_base, rep = p_iq, p_soft, rep_plain
             recheck["kept"] = "plain"
             recheck["placed_pair_was"] = {"domains_seen": int(rep_first.n_domains),
                                           "mover_on_pair_over_mover_in_one_domain": round(float(rep_first.pair_over_same_domain), 3)}
         else:
             ctx.free_frame_buffers(p_iq, p_soft)
+            if one_domain:                                     # (never seen: a plain pair no better than one domain's worst case)
+                d_iq_base, d_soft_base, rep = ctx.alloc_frame_buffers(n_frames, L, dabgpu.PLACE_DOMAINS)
             recheck["kept"] = "placed"
     final_bytes = n_frames * (L * 8 + dabgpu.NB_FRAME_BITS)
     placement = {"requested": args.placement,
