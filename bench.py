@@ -254,6 +254,7 @@ def main():
                    "what": "mover timed on the placed pair and on two plain hipMallocs, the faster pair kept (a check near 1.00 = the "
                            "virtual-memory API handed out chunks of one HBM domain only)",
                    "mover_ms_on_the_placed_pair": round(t_placed, 3), "mover_ms_on_two_plain_allocations": round(t_plain, 3)}
+        recheck["_one_domain"] = one_domain
         if t_plain < 0.985 * t_placed:
             if not one_domain:
                 ctx.free_frame_buffers(d_iq_base, d_soft_base)
@@ -280,7 +281,10 @@ def main():
     elif args.placement == "domains" and not (recheck and recheck["kept"] == "plain"):
         placement["fallback_reason"] = dabgpu.PLAIN_REASONS.get(rep.fallback_reason, str(rep.fallback_reason))
     if recheck is not None:
-        recheck["bytes_held_while_both_pairs_were_alive"] = int(2 * final_bytes)
+        if not recheck.pop("_one_domain"):
+            recheck["bytes_held_while_both_pairs_were_alive"] = int(2 * final_bytes)
+        else:
+            recheck["placed_pair_given_back_before_the_plain_one_was_allocated"] = True
         placement["placed_vs_plain"] = recheck
         if recheck["kept"] == "plain":
             placement["method"] = "plain hipMalloc pair (measured faster than the placed pair on this box)"
