@@ -187,10 +187,10 @@ typedef struct dabgpu_placement_report {
     float pair_over_same_domain; /* check of the result: a mover reading the first GiB of the samples and writing  */
                                 /* the start of the soft-bit buffer, over the same mover writing into the samples' */
                                 /* own buffer instead (same domain by construction): ~0.9 when the two buffers     */
-                                /* lie apart, ~1.0 when they do not (0 = not measured).  Near 1.0 the virtual-   */
-                                /* memory API has handed out chunks of one domain only (about one box in twelve):  */
-                                /* two plain allocations of this size then do better -- time dabgpu_mover_frames_  */
-                                /* dev on both pairs and keep the faster, as bench.py does                         */
+                                /* lie apart, ~1.0 when they do not (0 = not measured).  Near 1.0 (about one box */
+                                /* in ten) two plain allocations of this size MAY do better -- where only the      */
+                                /* virtual-memory API's chunks come from one domain: time dabgpu_mover_frames_dev  */
+                                /* on both pairs and keep the faster, as bench.py does                             */
     char domains[100];          /* one letter per chunk in allocation order: 'A' 'B' 'C' for the 1 GiB chunks, */
                                 /* 'a' 'b' 'c' for the 256 MiB ones; NUL-terminated, cut at 95                  */
     char iq_map[72];            /* the chunks of the IQ buffer in address order, same letters                  */

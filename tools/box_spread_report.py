@@ -41,14 +41,18 @@ for i, r in enumerate(rows, 1):
 one = [r for r in rows if placed_ratio(r) >= 0.985]
 two = [r for r in rows if placed_ratio(r) < 0.985]
 kept_plain = [r for r in one if (r.get("recheck") or {}).get("kept") == "plain"]
-stuck = [r for r in one if r not in kept_plain and not r.get("recheck")]
+no_better = [r for r in one if (r.get("recheck") or {}).get("kept") == "placed"]
+stuck = [r for r in one if not r.get("recheck")]
+cmp_two = [r for r in two if r.get("recheck")]
 rng = lambda xs, k, f="{:.3f}": (f + "-" + f).format(min(x[k] for x in xs), max(x[k] for x in xs))
+val = lambda xs: "%.3f-%.3f M" % (min(r["value"] for r in xs) / 1e6, max(r["value"] for r in xs) / 1e6)
 print()
-print(f"{len(rows)} boxes; on {len(one)} of them the first placement was no better than one domain (pair/one >= 0.985).  Without the re-check "
-      f"({len(stuck)} boxes): mover_frac {rng(stuck, 'box_mover_frac') if stuck else '-'}, frames/s "
-      f"{min(r['value'] for r in stuck) / 1e6:.3f}-{max(r['value'] for r in stuck) / 1e6:.3f} M;" if stuck else "")
+print(f"{len(rows)} runs (a pool machine can come up more than once: rows 70-74 are one machine by every number).  On {len(one)} of them the placed pair was no")
+print(f"better than one domain (pair/one >= 0.985): {len(stuck)} before bench.py compared (mover_frac {rng(stuck, 'box_mover_frac')}, {val(stuck)} frames/s);")
 if kept_plain:
-    print(f"with it, on two plain allocations ({len(kept_plain)} box(es)): mover_frac {rng(kept_plain, 'box_mover_frac')}, frames/s "
-          f"{min(r['value'] for r in kept_plain) / 1e6:.3f}-{max(r['value'] for r in kept_plain) / 1e6:.3f} M.")
-print(f"The others: mover_frac {rng(two, 'box_mover_frac')}, frames/s {min(r['value'] for r in two) / 1e6:.3f}-{max(r['value'] for r in two) / 1e6:.3f} M.  "
-      f"kernel / mover {rng(rows, 'kernel_over_mover')} on every box: the kernel follows its buffers' ceiling.")
+    print(f"{len(kept_plain)} where two plain allocations were faster and were kept (mover_frac {rng(kept_plain, 'box_mover_frac')}, {val(kept_plain)}: the virtual-memory API's chunks came")
+    print(f"from one domain, plain allocations did not);")
+if no_better:
+    print(f"{len(no_better)} where plain allocations were just as slow (mover_frac {rng(no_better, 'box_mover_frac')}, {val(no_better)}: whatever is allocated on such a machine behaves as one domain).")
+print(f"The other {len(two)}: mover_frac {rng(two, 'box_mover_frac')}, {val(two)}; of the {len(cmp_two)} compared, the placed pair was kept on "
+      f"{sum(1 for r in cmp_two if r['recheck']['kept'] == 'placed')}.  kernel / mover {rng(rows, 'kernel_over_mover')} on every run: the kernel follows its buffers' ceiling.")
