@@ -223,9 +223,9 @@ def main():
                                                           else dabgpu.PLACE_PLAIN)
     # The placed pair is then held against two plain hipMallocs: the data mover is timed on both (both alive: 2 x 30 GB of 288) and
     # the faster pair stays (untimed set-up, ~0.15 s; the line says what was measured and kept).  It matters on the boxes whose
-    # virtual-memory chunks all come from ONE HBM domain (2 of 74 runs on fresh boxes, profiles/r05_box_spread.txt: the
+    # virtual-memory chunks all come from ONE HBM domain (2 of 100 runs on fresh boxes, profiles/r05_box_spread.txt: the
     # allocator's own check reads ~1.00 there, the placed pair is the slow case and plain allocations span the domains by
-    # themselves: 5.80 vs 5.07 ms) and costs nothing elsewhere (the placed pair has won 16 of the 18 other comparisons on record; a plain pair that wins replaces a weak placement; on a machine where everything behaves as one domain both pairs are equally slow).  No
+    # themselves: 5.80 vs 5.07 ms) and costs nothing elsewhere (the placed pair has won 42 of the 44 other comparisons on record; a plain pair that wins replaces a weak placement; on a machine where everything behaves as one domain both pairs are equally slow).  No
     # allocator code: the choice is made here, through the public entry points, as any caller could.
     recheck = None
     if args.placement == "domains" and rep.method == 1 and float(rep.pair_over_same_domain) >= args.placement_recheck_above:

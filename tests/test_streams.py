@@ -340,10 +340,10 @@ def test_alloc_frame_buffers_by_domain(built, ensemble_iq):
     if rep.conflicts == 0 and rep.n_domains > 1:
         assert not set(rep.soft_map.decode().upper()) & set(rep.iq_map.decode().upper()[:2])
         # ... and the mover agrees: writing the soft-bit buffer beside reads of the samples is faster than writing into
-        # the samples' own buffer beside the same reads (~0.9) -- on most boxes.  Nine of 74 runs on fresh boxes
+        # the samples' own buffer beside the same reads (~0.9) -- on most boxes.  Nine of 100 runs on fresh boxes
         # behave as ONE domain whatever the classification's small timing differences said (ratio 0.99-1.00,
         # profiles/r05_box_spread.txt): the pair is then no better than a plain one and no worse, which is all that
-        # can be asked of it there.  (One run in 74 misjudged its chunks: 1.085 -- bench.py re-checks any box at 0.985 and above.)
+        # can be asked of it there.  (One run in 100 misjudged its chunks: 1.085 -- bench.py re-checks any box at 0.985 and above.)
         assert 0.5 < rep.pair_over_same_domain < 1.2, rep.pair_over_same_domain
     held = free0 - torch.cuda.mem_get_info()[0]
     assert final <= held <= final + (2 << 30) + (64 << 20), held   # the chunks nobody took were released (whole chunks are kept)
