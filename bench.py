@@ -134,15 +134,10 @@ def parse_args(argv=None):
                       ("traffic", "measuring roofline.traffic now (two rocprofv3 --pmc child processes, ~20 s); the tracked figure "
                                   "of profiles/pmc_traffic.json is reported instead")):
         ap.add_argument("--no-" + leg, action="store_true", help="skip " + what)
-    ap.add_argument("--placement-recheck-above", type=float, default=0.0,
-                    help="with --placement domains: when the allocator's own check (mover on the placed pair over the mover inside one "
-                         "domain; ~0.92 when the pair lies apart, ~1.00 on a box whose virtual-memory chunks come from one domain) is at "
-                         "or above this, the mover is timed on the placed pair and on a plain pair and the faster one is kept "
-                         "(0 = always, the default; 2 = never)")
     ap.add_argument("--placement", choices=["plain", "domains"], default="domains",
-                    help="how the IQ / soft-bit buffers are allocated (dabgpu_alloc_frame_buffers): two hipMallocs, or placed by "
-                         "HBM domain (six plain / domains pairs on three boxes, profiles/r04_placement_ab.txt: front end 0.8-3.9 %% "
-                         "faster, never slower; <= 1.5 x the pair held for ~0.1 s at set-up; any failure ends in a plain pair)")
+                    help="what dabgpu_alloc_frame_buffers is asked for: two hipMallocs, or placement by HBM domain (<= 1.5 x the "
+                         "pair held for ~0.1 s at set-up; the library itself ends in a plain pair on any failure and on a box "
+                         "whose chunks share one domain -- config.buffer_placement is its report)")
     args = ap.parse_args(argv)
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -218,76 +213,12 @@ def main():
         ctx.decode_frames_dev(soft_buf.data_ptr(), dabgpu.NB_FRAME_BITS, E, F, fib.data_ptr(), crc.data_ptr(), [sc],
                               [hist[k & 1].data_ptr()], [hist[(k & 1) ^ 1].data_ptr()], [msc.data_ptr()], stream)
 
-    # ---- the IQ / soft-bit pair (untimed set-up, reported in config.buffer_placement) ----
+    # ---- the IQ / soft-bit pair: ONE library call, no policy here (untimed set-up; config.buffer_placement is the
+    # library's report verbatim, dabgpu.placement_report_dict).  Whether the pair is domain-aware or plain is the allocator's
+    # decision (include/dabgpu.h, DABGPU_PLAIN_*): any caller of dabgpu_alloc_frame_buffers gets exactly these buffers.
     d_iq_base, d_soft_base, rep = ctx.alloc_frame_buffers(n_frames, L, dabgpu.PLACE_DOMAINS if args.placement == "domains"
                                                           else dabgpu.PLACE_PLAIN)
-    # The placed pair is then held against two plain hipMallocs: the data mover is timed on both (both alive: 2 x 30 GB of 288) and
-    # the faster pair stays (untimed set-up, ~0.15 s; the line says what was measured and kept).  It matters on the boxes whose
-    # virtual-memory chunks all come from ONE HBM domain (2 of 100 runs on fresh boxes, profiles/r05_box_spread.txt: the
-    # allocator's own check reads ~1.00 there, the placed pair is the slow case and plain allocations span the domains by
-    # themselves: 5.80 vs 5.07 ms) and costs nothing elsewhere (the placed pair has won 42 of the 44 other comparisons on record; a plain pair that wins replaces a weak placement; on a machine where everything behaves as one domain both pairs are equally slow).  No
-    # allocator code: the choice is made here, through the public entry points, as any caller could.
-    recheck = None
-    if args.placement == "domains" and rep.method == 1 and float(rep.pair_over_same_domain) >= args.placement_recheck_above:
-        def mover_min_ms(a_iq, a_soft):
-            best = None
-            for _ in range(4):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                ctx.mover_frames_dev(a_iq + synth.NB_NULL * 8, L, n_frames, a_soft, True, stream)
-                e1.record()
-                torch.cuda.synchronize()
-                t = e0.elapsed_time(e1)
-                best = t if best is None else min(best, t)
-            return best
-        rep_first = rep
-        t_placed = mover_min_ms(d_iq_base, d_soft_base)
-        # A check near 1.00 says the placed pair IS the worst case (both buffers in one domain): it is given back first, so that
-        # the plain pair is not allocated around it (5.07 ms that way on the first such box, 5.47 ms beside the placed pair on the
-        # second); otherwise both pairs stay alive while they are timed (2 x 30 GB of 288) and no second placement is needed.
-        one_domain = float(rep.pair_over_same_domain) >= 0.985
-        if one_domain:
-            ctx.free_frame_buffers(d_iq_base, d_soft_base)
-        p_iq, p_soft, rep_plain = ctx.alloc_frame_buffers(n_frames, L, dabgpu.PLACE_PLAIN)
-        t_plain = mover_min_ms(p_iq, p_soft)
-        recheck = {"allocators_own_check": round(float(rep.pair_over_same_domain), 3),
-                   "what": "mover timed on the placed pair and on two plain hipMallocs, the faster pair kept (a check near 1.00 = the "
-                           "virtual-memory API handed out chunks of one HBM domain only)",
-                   "mover_ms_on_the_placed_pair": round(t_placed, 3), "mover_ms_on_two_plain_allocations": round(t_plain, 3)}
-        recheck["_one_domain"] = one_domain
-        if t_plain < 0.985 * t_placed:
-            if not one_domain:
-                ctx.free_frame_buffers(d_iq_base, d_soft_base)
-            d_iq_base, d_soft_base, rep = p_iq, p_soft, rep_plain
-            recheck["kept"] = "plain"
-            recheck["placed_pair_was"] = {"domains_seen": int(rep_first.n_domains),
-                                          "mover_on_pair_over_mover_in_one_domain": round(float(rep_first.pair_over_same_domain), 3)}
-        else:
-            ctx.free_frame_buffers(p_iq, p_soft)
-            if one_domain:                                     # (never seen: a plain pair no better than one domain's worst case)
-                d_iq_base, d_soft_base, rep = ctx.alloc_frame_buffers(n_frames, L, dabgpu.PLACE_DOMAINS)
-            recheck["kept"] = "placed"
-    final_bytes = n_frames * (L * 8 + dabgpu.NB_FRAME_BITS)
-    placement = {"requested": args.placement,
-                 "method": "domain-aware pair (address ranges reserved once per context)" if rep.method == 1 else "plain hipMalloc pair",
-                 "setup_peak_bytes": int(rep.setup_peak_bytes),
-                 "setup_peak_over_final_footprint": round(rep.setup_peak_bytes / final_bytes, 3)}
-    if rep.method == 1:
-        placement.update({"chunks_taken": rep.n_chunks, "chunk_domains": rep.domains.decode(), "iq_chunk_domains": rep.iq_map.decode(),
-                          "soft_chunk_domains": rep.soft_map.decode(), "domains_seen": rep.n_domains,
-                          "soft_bits_written_beside_same_domain_reads_per_mille": rep.conflicts,
-                          "classify_ms": round(rep.classify_ms, 2),
-                          "mover_on_pair_over_mover_in_one_domain": round(float(rep.pair_over_same_domain), 3)})
-    elif args.placement == "domains" and not (recheck and recheck["kept"] == "plain"):
-        placement["fallback_reason"] = dabgpu.PLAIN_REASONS.get(rep.fallback_reason, str(rep.fallback_reason))
-    if recheck is not None:
-        if not recheck.pop("_one_domain"):
-            recheck["bytes_held_while_both_pairs_were_alive"] = int(2 * final_bytes)
-        else:
-            recheck["placed_pair_given_back_before_the_plain_one_was_allocated"] = True
-        placement["placed_vs_plain"] = recheck
-        if recheck["kept"] == "plain":
-            placement["method"] = "plain hipMalloc pair (measured faster than the placed pair on this box)"
+    placement = dabgpu.placement_report_dict(rep, requested=args.placement, final_bytes=n_frames * (L * 8 + dabgpu.NB_FRAME_BITS))
     iq = dabgpu.device_tensor(torch, d_iq_base, (n_frames, L), torch.complex64, dev)
     soft = dabgpu.device_tensor(torch, d_soft_base, (n_frames, dabgpu.NB_FRAME_BITS), torch.int8, dev)
     cfo_true, ens = make_streams(torch, dev, ids, F, min(args.unique, E * world), args.snr, iq)
@@ -386,8 +317,10 @@ def main():
     ctx.set_timing(False)
     achieved = A_OFDM * n_frames / (ofdm_ms * 1e-3) / 1e9
     # one row per rank, so that an imbalance between the GPUs of a node is visible in the line
+    # (+ what the allocator gave this rank and the mover's time on it: a slow rank of an 8-GPU node explains itself)
     per_rank = gather_per_rank(dist, red_dev, [n_frames * args.steps / elapsed_rank, ofdm_ms, dec_ms, dev_index,
-                                               achieved / HBM_PEAK_GBS, mover_ms])
+                                               achieved / HBM_PEAK_GBS, mover_ms, rep.method, rep.fallback_reason,
+                                               rep.pair_over_same_domain, rep.n_domains])
     collective = "none (one rank)"
     if dist is not None:
         collective = "nccl (RCCL)" if backend == "nccl" else backend + " (test ranks sharing a GPU: NOT RCCL)"
@@ -416,7 +349,13 @@ def main():
             "metric": "DAB Mode-I frames/sec (OFDM+Viterbi)", "value": value, "unit": "frames/s",
             "n_gpus": world, "world": dist_world, "collective_backend": collective,
             "per_rank": [{"rank": i, "frames_per_s": r[0], "front_end_kernel_ms": r[1], "decoder_ms": r[2], "device": int(r[3]),
-                          "roofline_frac": r[4], "mover_same_geometry_ms": r[5]} for i, r in enumerate(per_rank)],
+                          "roofline_frac": r[4], "mover_same_geometry_ms": r[5],
+                          "mover_source": "dabgpu_mover_frames_dev on this rank's timed buffers, mean of 5 launches after 2 (set-up, untimed)",
+                          "kernel_over_mover": r[1] / r[5] if r[5] > 0 else None,
+                          "buffer_placement": {"method": "domain-aware pair" if int(r[6]) == 1 else "plain hipMalloc pair",
+                                               "fallback_reason": None if int(r[6]) == 1 else dabgpu.PLAIN_REASONS.get(int(r[7]), str(int(r[7]))),
+                                               "pair_over_same_domain": round(r[8], 3), "domains_seen": int(r[9])}}
+                         for i, r in enumerate(per_rank)],
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "step_ms": {"min": float(step_dev_ms.min()), "median": float(np.median(step_dev_ms)), "max": float(step_dev_ms.max()),

@@ -120,6 +120,9 @@ typedef struct dabgpu_cfg {
                                            /* above ~680 kbit/s do not fit its LDS slab: those go per lane)      */
 #define DABGPU_FLAG_VITERBI_LANE  (1 << 1) /* one codeword per lane wherever the length allows, any batch size */
 #define DABGPU_FLAG_LANE_UNFUSED  (1 << 2) /* lane decoder: separate depuncture pass before the forward pass   */
+/* Test hooks (tests/ only; they change no result, they force a branch that hardware takes rarely): */
+#define DABGPU_FLAG_TEST_ONE_DOMAIN (1 << 30) /* dabgpu_alloc_frame_buffers(DABGPU_PLACE_DOMAINS): the check of the  */
+                                           /* placed pair is taken as 1.00 (a box whose chunks share one domain)   */
 
 /* Replaces the construction in Radio_Block::Radio_Block
  * (/root/reference/src/radio_block.cpp:11-22: params + PRS + mapper + OFDM_Demod). */
@@ -171,6 +174,9 @@ void dabgpu_host_free(void *p);
 #define DABGPU_PLAIN_ARENA_BUSY   4  /* the context's domain-aware pair is still alive                        */
 #define DABGPU_PLAIN_ARENA_SMALL  5  /* larger than the address range the context reserved on its first call   */
 #define DABGPU_PLAIN_PROBE_FAILED 6  /* a probe launch or its timing failed                                    */
+#define DABGPU_PLAIN_ONE_DOMAIN   7  /* the placed pair's own check read >= 0.985 (it behaves as one domain: the   */
+                                     /* worst case); it was given back and two plain allocations made instead;   */
+                                     /* pair_over_same_domain, n_domains, domains describe the pair given back    */
 typedef struct dabgpu_placement_report {
     int32_t method;             /* 0 = plain hipMalloc pair, 1 = domain-aware pair                              */
     int32_t fallback_reason;    /* method 0: DABGPU_PLAIN_*                                                     */
@@ -187,10 +193,9 @@ typedef struct dabgpu_placement_report {
     float pair_over_same_domain; /* check of the result: a mover reading the first GiB of the samples and writing  */
                                 /* the start of the soft-bit buffer, over the same mover writing into the samples' */
                                 /* own buffer instead (same domain by construction): ~0.9 when the two buffers     */
-                                /* lie apart, ~1.0 when they do not (0 = not measured).  Near 1.0 (about one box */
-                                /* in ten) two plain allocations of this size MAY do better -- where only the      */
-                                /* virtual-memory API's chunks come from one domain: time dabgpu_mover_frames_dev  */
-                                /* on both pairs and keep the faster, as bench.py does                             */
+                                /* lie apart, ~1.0 when they do not (0 = not measured).  A domain-aware pair is   */
+                                /* only ever handed out below 0.985; at or above it the pair goes back and the    */
+                                /* call ends in a plain pair (DABGPU_PLAIN_ONE_DOMAIN): the caller decides nothing */
     char domains[100];          /* one letter per chunk in allocation order: 'A' 'B' 'C' for the 1 GiB chunks, */
                                 /* 'a' 'b' 'c' for the 256 MiB ones; NUL-terminated, cut at 95                  */
     char iq_map[72];            /* the chunks of the IQ buffer in address order, same letters                  */

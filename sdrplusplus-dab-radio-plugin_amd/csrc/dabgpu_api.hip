@@ -207,7 +207,7 @@ int dabgpu_create(const dabgpu_cfg *cfg, dabgpu_ctx **out) {
     if (!cfg || !out) return DABGPU_ERR_ARG;
     *out = nullptr;
     if (cfg->transmission_mode != 1) return DABGPU_ERR_PROFILE;
-    constexpr int KNOWN_FLAGS = DABGPU_FLAG_VITERBI_WAVE | DABGPU_FLAG_VITERBI_LANE | DABGPU_FLAG_LANE_UNFUSED;
+    constexpr int KNOWN_FLAGS = DABGPU_FLAG_VITERBI_WAVE | DABGPU_FLAG_VITERBI_LANE | DABGPU_FLAG_LANE_UNFUSED | DABGPU_FLAG_TEST_ONE_DOMAIN;
     if ((cfg->flags & ~KNOWN_FLAGS) || ((cfg->flags & DABGPU_FLAG_VITERBI_WAVE) && (cfg->flags & DABGPU_FLAG_VITERBI_LANE)))
         return DABGPU_ERR_ARG;
     if (cfg->ofdm_symbol_runs < 0 || cfg->ofdm_symbol_runs > NB_DATA_SYMBOLS) return DABGPU_ERR_ARG;
@@ -226,6 +226,7 @@ int dabgpu_create(const dabgpu_cfg *cfg, dabgpu_ctx **out) {
     ctx->ofdm_parts_override = cfg->ofdm_symbol_runs;
     ctx->lane_mode = (cfg->flags & DABGPU_FLAG_VITERBI_LANE) ? 1 : (cfg->flags & DABGPU_FLAG_VITERBI_WAVE) ? 0 : -1;
     ctx->lane_unfused = (cfg->flags & DABGPU_FLAG_LANE_UNFUSED) != 0;
+    ctx->test_one_domain = (cfg->flags & DABGPU_FLAG_TEST_ONE_DOMAIN) != 0;
     ctx->wave_slots = prop.multiProcessorCount > 0 ? prop.multiProcessorCount * 12 : 3072;   // 3 workgroups x 4 waves per CU
     int rc = DABGPU_OK;
     do {

@@ -89,6 +89,7 @@ struct dabgpu_ctx {
     size_t lane_scratch_bytes = 0;
     int lane_mode = -1;                  // 1 = DABGPU_FLAG_VITERBI_LANE, 0 = DABGPU_FLAG_VITERBI_WAVE, -1 by batch size
     bool lane_unfused = false;           // DABGPU_FLAG_LANE_UNFUSED
+    bool test_one_domain = false;        // DABGPU_FLAG_TEST_ONE_DOMAIN (dabgpu_placement.hip)
     int wave_slots = 3072;               // resident OFDM wavefronts: 12 per CU
     std::vector<dabgpu_bit_range> keep_ranges;           // the current selection, merged, for the host-pointer copy-back
     dabk::StreamState *d_states = nullptr;               // per-stream tracking state (dabgpu_streams_reset)

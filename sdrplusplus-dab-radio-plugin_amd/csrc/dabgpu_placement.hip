@@ -15,6 +15,8 @@
 //     a clean placement, the pair is placed as well as they do and the report says so (conflicts): not chased.
 //   * every failure on the way -- no virtual-memory API, no room, a failed map, a failed probe launch -- ends in two
 //     plain hipMallocs (report.method = 0); an error is returned only when those fail too.
+//   * so does a placed pair whose own check says it behaves as one domain (DABGPU_PLAIN_ONE_DOMAIN): the caller always gets
+//     the better of what this file can know without timing the caller's launch -- no policy is left to the caller.
 #include "dabgpu_ctx.hpp"
 
 #include <algorithm>
@@ -408,6 +410,19 @@ int dabgpu_alloc_frame_buffers(dabgpu_ctx *ctx, int n_frames, size_t frame_strid
         }
         if (ta < 1e29f && tb < 1e29f) rep.pair_over_same_domain = ta / tb;
         (void)hipGetLastError();
+    }
+    if (ctx->test_one_domain) rep.pair_over_same_domain = 1.0f;        // DABGPU_FLAG_TEST_ONE_DOMAIN: drives the branch below
+    // A check at ~1.00 says the pair behaves as ONE domain whatever the classification's small timing differences said: the
+    // virtual-memory API handed out chunks of one domain only (2-9 % of this pool's boxes), and both buffers in one domain
+    // is the worst case -- two plain allocations of this size span the domains by themselves there (5.07 against 5.80 ms per
+    // front-end launch, profiles/r05_placed_vs_plain.txt).  The placed pair goes back FIRST, so that the plain pair is not
+    // allocated around it; the report keeps what was seen (domains, the check) and says why the pair is plain.
+    if (rep.pair_over_same_domain >= 0.985f) {
+        unmap_pieces(ctx);
+        rep.iq_chunks = rep.soft_chunks = 0;
+        rep.iq_map[0] = rep.soft_map[0] = 0;
+        rep.conflicts = 0;
+        return plain(DABGPU_PLAIN_ONE_DOMAIN);
     }
     if (report) *report = rep;
     return DABGPU_OK;

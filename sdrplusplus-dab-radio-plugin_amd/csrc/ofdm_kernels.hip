@@ -217,15 +217,18 @@ __global__ __launch_bounds__(64 * WAVES, 3) void ofdm_wave_kernel(OfdmTables tab
     float2 *const qout = a.cyc;
     const bool dd = !FFT_ONLY && a.cyc == nullptr && a.dd4 != nullptr;
     float2 ddacc = make_float2(0.f, 0.f);                       // decision-directed frequency-error sum of the run (wave-uniform: scalar registers)
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);    // (scalar: the row's address costs no VGPR across the loop)
     auto put_cyc = [&](const int l, const float2 c) {
         const int slot = (l - l_first) & 31;                    // wave-uniform
-        if (lane == 0) sm.cyc[wave][slot] = c;
+        if (lane == 0) sm.cyc[wave_u][slot] = c;
         if (slot == 31 || l == l_last) {
             lds_stores_done();
             lds_loads_may_start();
-            const int li = l - slot + lane;                     // symbol whose value lane `lane` carries out
-            if (lane <= slot && (FFT_ONLY || li > l_first || li == 0))
-                st_stream(qout + size_t(frame) * NB_FRAME_SYMBOLS + li, sm.cyc[wave][lane]);
+            int lq = lane;                                      // opaque copy: the row address is formed here, every 32nd
+            asm volatile("" : "+v"(lq));                        // symbol, instead of living in a VGPR across the loop
+            const int li = l - slot + lq;                       // symbol whose value lane `lane` carries out
+            if (lq <= slot && (FFT_ONLY || li > l_first || li == 0))
+                st_stream(qout + size_t(frame) * NB_FRAME_SYMBOLS + li, sm.cyc[wave_u][lq]);
         }
     };
 

@@ -49,12 +49,16 @@ EXPORTS = [
 
 ABI_VERSION = 6
 PLACE_PLAIN, PLACE_DOMAINS = 0, 1
+PLAIN_ONE_DOMAIN = 7
 PLAIN_REASONS = {0: "plain requested", 1: "buffers too small (or too many chunks) for placement", 2: "virtual-memory API refused",
                  3: "no room for the chunks", 4: "the context's domain-aware pair is still alive",
-                 5: "larger than the context's reserved address range", 6: "probe launch failed"}
+                 5: "larger than the context's reserved address range", 6: "probe launch failed",
+                 7: "the placed pair's own check read >= 0.985 (one HBM domain behind the virtual-memory API on this box): "
+                    "given back, two plain allocations made instead"}
 FLAG_VITERBI_WAVE = 1 << 0
 FLAG_VITERBI_LANE = 1 << 1
 FLAG_LANE_UNFUSED = 1 << 2
+FLAG_TEST_ONE_DOMAIN = 1 << 30          # test hook: the allocator's check of a placed pair reads 1.00
 
 
 class DabGpuError(RuntimeError):
@@ -381,6 +385,26 @@ def _close_live_contexts():
 
 
 atexit.register(_close_live_contexts)
+
+
+def placement_report_dict(rep, requested=None, final_bytes=None):
+    """dabgpu_placement_report as a plain dict, field for field (what bench.py prints as config.buffer_placement and every
+    rank's row carries): nothing is decided or measured here."""
+    d = {"method": "domain-aware pair" if rep.method == 1 else "plain hipMalloc pair",
+         "fallback_reason": None if rep.method == 1 else PLAIN_REASONS.get(rep.fallback_reason, str(rep.fallback_reason)),
+         "runtime_error": int(rep.runtime_error), "chunks_taken": int(rep.n_chunks), "chunk_bytes": int(rep.chunk_bytes),
+         "chunk_domains": rep.domains.decode(), "domains_seen": int(rep.n_domains),
+         "iq_chunks": int(rep.iq_chunks), "soft_chunks": int(rep.soft_chunks),
+         "iq_chunk_domains": rep.iq_map.decode(), "soft_chunk_domains": rep.soft_map.decode(),
+         "soft_bits_written_beside_same_domain_reads_per_mille": int(rep.conflicts),
+         "classify_ms": round(float(rep.classify_ms), 2),
+         "pair_over_same_domain": round(float(rep.pair_over_same_domain), 3),
+         "setup_peak_bytes": int(rep.setup_peak_bytes)}
+    if requested is not None:
+        d = dict({"requested": requested}, **d)
+    if final_bytes:
+        d["setup_peak_over_final_footprint"] = round(rep.setup_peak_bytes / final_bytes, 3)
+    return d
 
 
 class Context:

@@ -121,6 +121,11 @@ def test_plain_bench_gpus_2_reports_two_ranks():
     assert "gloo" in j["collective_backend"] and "NOT RCCL" in j["collective_backend"]      # the line says what carried the reductions
     assert [p["rank"] for p in j["per_rank"]] == [0, 1] and all(p["frames_per_s"] > 0 for p in j["per_rank"])
     assert all(0 < p["roofline_frac"] < 1 and p["mover_same_geometry_ms"] > 0 for p in j["per_rank"])
+    # every rank's row says what the allocator gave it and where its ceiling figure comes from
+    for p in j["per_rank"]:
+        bp = p["buffer_placement"]
+        assert bp["method"] == "plain hipMalloc pair" and "too small" in bp["fallback_reason"]      # (this small shape)
+        assert "dabgpu_mover_frames_dev" in p["mover_source"] and abs(p["kernel_over_mover"] - p["front_end_kernel_ms"] / p["mover_same_geometry_ms"]) < 1e-9
     assert j["cpu_baseline"] is None and j["legs"].startswith("skipped")                     # world > 1: the timed step only
     assert j["fic_bit_exact"] is True and j["msc_bit_exact"] is True
     assert abs(j["value"] * j["ms_per_step"] * 1e-3 - 128) < 1e-3

@@ -327,26 +327,34 @@ def test_alloc_frame_buffers_by_domain(built, ensemble_iq):
     n = 3000                                                   # 4.4 GiB of samples, 0.64 GiB of soft bits
     final = n * (L * 8 + dabgpu.NB_FRAME_BITS)
     d_iq, d_soft, rep = c.alloc_frame_buffers(n, L, dabgpu.PLACE_DOMAINS)
-    assert rep.method == 1, (rep.method, rep.fallback_reason)
-    assert 5 <= rep.iq_chunks <= rep.n_chunks - 1 and 1 <= rep.soft_chunks <= 3 and rep.n_chunks >= 8 and rep.chunk_bytes == 1 << 30
+    # a domain-aware pair -- or, on the 2-9 % of boxes whose virtual-memory chunks all come from one HBM domain, the plain
+    # pair the allocator falls back to by itself (test_one_domain_box_gets_a_plain_pair drives that branch everywhere)
+    placed = rep.method == 1
+    assert placed or rep.fallback_reason == dabgpu.PLAIN_ONE_DOMAIN, (rep.method, rep.fallback_reason, rep.runtime_error)
+    assert rep.n_chunks >= 8 and rep.chunk_bytes == 1 << 30
     doms = rep.domains.decode()
     assert len(doms) == min(95, rep.n_chunks) and set(doms.upper()) <= set("ABC") and 1 <= rep.n_domains <= 3
     n_big = len(doms) - len(doms.lstrip("ABC"))
     assert n_big >= 5 and doms[n_big:].islower() and len(doms) - n_big >= 3
     assert rep.setup_peak_bytes == (n_big << 30) + ((len(doms) - n_big) << 28)
     assert rep.setup_peak_bytes <= 1.5 * final                       # never more than 1.5 x the buffers during set-up
-    assert len(rep.iq_map.decode()) == rep.iq_chunks and len(rep.soft_map.decode()) == rep.soft_chunks
     assert rep.classify_ms > 0 and 0 <= rep.conflicts <= 1000
-    if rep.conflicts == 0 and rep.n_domains > 1:
-        assert not set(rep.soft_map.decode().upper()) & set(rep.iq_map.decode().upper()[:2])
-        # ... and the mover agrees: writing the soft-bit buffer beside reads of the samples is faster than writing into
-        # the samples' own buffer beside the same reads (~0.9) -- on most boxes.  Nine of 100 runs on fresh boxes
-        # behave as ONE domain whatever the classification's small timing differences said (ratio 0.99-1.00,
-        # profiles/r05_box_spread.txt): the pair is then no better than a plain one and no worse, which is all that
-        # can be asked of it there.  (One run in 100 misjudged its chunks: 1.085 -- bench.py re-checks any box at 0.985 and above.)
-        assert 0.5 < rep.pair_over_same_domain < 1.2, rep.pair_over_same_domain
+    if placed:
+        assert 5 <= rep.iq_chunks <= rep.n_chunks - 1 and 1 <= rep.soft_chunks <= 3
+        assert len(rep.iq_map.decode()) == rep.iq_chunks and len(rep.soft_map.decode()) == rep.soft_chunks
+        if rep.conflicts == 0 and rep.n_domains > 1:
+            assert not set(rep.soft_map.decode().upper()) & set(rep.iq_map.decode().upper()[:2])
+        # the mover agrees (the strict bound is back): a domain-aware pair is only ever handed out when writing
+        # the soft-bit buffer beside reads of the samples is faster than writing into the samples' own buffer beside the
+        # same reads; at 0.985 and above the allocator gives the pair back itself
+        assert 0.5 < rep.pair_over_same_domain < 0.985, rep.pair_over_same_domain
+    else:
+        assert rep.pair_over_same_domain >= 0.985 and rep.iq_chunks == 0 and rep.soft_chunks == 0
     held = free0 - torch.cuda.mem_get_info()[0]
-    assert final <= held <= final + (2 << 30) + (64 << 20), held   # the chunks nobody took were released (whole chunks are kept)
+    if placed:
+        assert final <= held <= final + (2 << 30) + (64 << 20), held   # the chunks nobody took were released (whole chunks are kept)
+    else:
+        assert final <= held <= final + (64 << 20), held
     # one domain-aware pair per context at a time: the second request is a plain pair and says why
     e_iq, e_soft, rep2 = c.alloc_frame_buffers(16, L, dabgpu.PLACE_DOMAINS)
     assert rep2.method == 0 and rep2.fallback_reason in (1, 4)
@@ -365,16 +373,17 @@ def test_alloc_frame_buffers_by_domain(built, ensemble_iq):
     for base in (0, 680, n - k):
         assert (soft[base:base + k].cpu().numpy() == ref).all(), base
     del iq, soft
-    with pytest.raises(dabgpu.DabGpuError):                   # the two buffers of a mapped pair go back together
-        c.free_frame_buffers(d_iq, None)
+    if placed:
+        with pytest.raises(dabgpu.DabGpuError):               # the two buffers of a mapped pair go back together
+            c.free_frame_buffers(d_iq, None)
     c.free_frame_buffers(d_iq, d_soft)
     torch.cuda.synchronize()
     assert free0 - torch.cuda.mem_get_info()[0] <= 64 << 20
     # the same ranges serve the next pair (same addresses); a larger one than they were reserved for is a plain pair
     f_iq, f_soft, rep3 = c.alloc_frame_buffers(n, L, dabgpu.PLACE_DOMAINS)
-    assert rep3.method == 1 and f_iq == d_iq
+    assert rep3.method == rep.method and (not placed or f_iq == d_iq)
     g_iq, g_soft, rep4 = c.alloc_frame_buffers(2 * n, L, dabgpu.PLACE_DOMAINS)
-    assert rep4.method == 0 and rep4.fallback_reason == 4
+    assert rep4.method == 0 and rep4.fallback_reason == (4 if placed else 5)
     c.free_frame_buffers(g_iq, g_soft)
     c.free_frame_buffers(f_iq, f_soft)
     g_iq, g_soft, rep4 = c.alloc_frame_buffers(2 * n, L, dabgpu.PLACE_DOMAINS)
@@ -382,6 +391,48 @@ def test_alloc_frame_buffers_by_domain(built, ensemble_iq):
     c.free_frame_buffers(g_iq, g_soft)
     with pytest.raises(dabgpu.DabGpuError):
         c.alloc_frame_buffers(0, L, dabgpu.PLACE_DOMAINS)
+    c.close()
+    torch.cuda.synchronize()
+    assert free0 - torch.cuda.mem_get_info()[0] <= 64 << 20
+
+
+def test_one_domain_box_gets_a_plain_pair(built, ensemble_iq):
+    """the placed-versus-plain decision is the LIBRARY's.  When the allocator's own check of a placed pair
+    reads >= 0.985 (a box whose virtual-memory chunks share one HBM domain: both buffers in one domain is the worst case)
+    dabgpu_alloc_frame_buffers gives the pair back and hands out two plain allocations, and the report says so.  The branch is
+    taken on 2-9 % of boxes; DABGPU_FLAG_TEST_ONE_DOMAIN makes the check read 1.00 so that it runs on every box.  The buffers
+    work like any others, nothing stays mapped in the context's ranges, and the next request goes through the same ranges."""
+    import torch
+    L = dabgpu.NB_FRAME_SAMPLES
+    dev = torch.device("cuda", 0)
+    c = dabgpu.Context(device=0, max_frames=8, flags=dabgpu.FLAG_TEST_ONE_DOMAIN)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    n = 3000
+    final = n * (L * 8 + dabgpu.NB_FRAME_BITS)
+    for round_ in range(2):
+        d_iq, d_soft, rep = c.alloc_frame_buffers(n, L, dabgpu.PLACE_DOMAINS)
+        assert rep.method == 0 and rep.fallback_reason == dabgpu.PLAIN_ONE_DOMAIN, (rep.method, rep.fallback_reason, rep.runtime_error)
+        assert rep.pair_over_same_domain == 1.0 and rep.runtime_error == 0
+        assert rep.n_chunks >= 8 and 1 <= rep.n_domains <= 3 and len(rep.domains.decode()) == rep.n_chunks     # what was seen stays in the report
+        assert rep.iq_chunks == 0 and rep.soft_chunks == 0 and rep.iq_map == b"" and rep.soft_map == b""
+        assert final <= rep.setup_peak_bytes <= 1.5 * final
+        held = free0 - torch.cuda.mem_get_info()[0]
+        assert final <= held <= final + (64 << 20), held      # every chunk of the pair that was given back is released
+        rx = synth.channel(ensemble_iq.ravel(), snr_db=18.0, cfo=0.0, rng=np.random.default_rng(6)).reshape(ensemble_iq.shape)
+        k = rx.shape[0]
+        ref, _, _ = c.ofdm_demod_frames(np.ascontiguousarray(rx[:, synth.NB_NULL:]))
+        iq = dabgpu.device_tensor(torch, d_iq, (n, L), torch.complex64, dev)
+        soft = dabgpu.device_tensor(torch, d_soft, (n, dabgpu.NB_FRAME_BITS), torch.int8, dev)
+        iq[n - k:].copy_(torch.from_numpy(rx.astype(np.complex64)).to(dev))
+        torch.cuda.synchronize()
+        c.ofdm_demod_frames_dev(d_iq + (n - k) * L * 8 + synth.NB_NULL * 8, L, k, None, d_soft + (n - k) * dabgpu.NB_FRAME_BITS)
+        c.sync()
+        assert (soft[n - k:].cpu().numpy() == ref).all()
+        del iq, soft
+        c.free_frame_buffers(d_iq, d_soft)
+        torch.cuda.synchronize()
+        assert free0 - torch.cuda.mem_get_info()[0] <= 64 << 20
     c.close()
     torch.cuda.synchronize()
     assert free0 - torch.cuda.mem_get_info()[0] <= 64 << 20
