@@ -134,6 +134,10 @@ def parse_args(argv=None):
                       ("traffic", "measuring roofline.traffic now (two rocprofv3 --pmc child processes, ~20 s); the tracked figure "
                                   "of profiles/pmc_traffic.json is reported instead")):
         ap.add_argument("--no-" + leg, action="store_true", help="skip " + what)
+    ap.add_argument("--decoder", choices=["auto", "lane", "wave"], default="auto",
+                    help="which kernels decode (dabgpu_cfg.flags; results are identical): auto = by batch size, the library's default "
+                         "(codeword-per-lane from 24 576 codewords per launch: the default shape); lane / wave pin one (tests: "
+                         "the lane decoder's roofline record at a small shape)")
     ap.add_argument("--placement", choices=["plain", "domains"], default="domains",
                     help="what dabgpu_alloc_frame_buffers is asked for: two hipMallocs, or placement by HBM domain (<= 1.5 x the "
                          "pair held for ~0.1 s at set-up; the library itself ends in a plain pair on any failure and on a box "
@@ -197,7 +201,8 @@ def main():
     n_frames = E * F
     L = synth.NB_FRAME_SAMPLES
     ids = ensembles_of_rank(E * world, world, rank)              # this rank's share of the global ensemble list
-    ctx = dabgpu.Context(device=dev_index, max_frames=n_frames)
+    ctx = dabgpu.Context(device=dev_index, max_frames=n_frames,
+                         flags={"auto": 0, "lane": dabgpu.FLAG_VITERBI_LANE, "wave": dabgpu.FLAG_VITERBI_WAVE}[args.decoder])
     torch.cuda.synchronize()
     tstream = torch.cuda.Stream(device=dev)      # non-null handle: the C ABI treats NULL as "context stream"
     torch.cuda.set_stream(tstream)
@@ -314,6 +319,10 @@ def main():
     step_dev_ms = np.array([a.elapsed_time(c) for (a, _), (_, c) in zip(ofdm_ev, dec_ev)])
     dec_ms = float(np.mean([a.elapsed_time(b) for a, b in dec_ev]))
     ofdm_ms, ofdm_launches = ctx.mean_kernel_ms(0)                             # the fused kernel's launches alone
+    try:                                                                       # the grouped lane decode's kernels, one by one
+        dec_parts = (ctx.mean_kernel_ms(4)[0], ctx.mean_kernel_ms(5)[0], ctx.mean_kernel_ms(6)[0], ctx.mean_kernel_ms(4)[1])
+    except dabgpu.DabGpuError:
+        dec_parts = None                                                       # (a batch below the lane decoder's threshold)
     ctx.set_timing(False)
     achieved = A_OFDM * n_frames / (ofdm_ms * 1e-3) / 1e9
     # one row per rank, so that an imbalance between the GPUs of a node is visible in the line
@@ -397,11 +406,27 @@ def main():
                          "frac_own_estimator": None},
             # the channel decoder is integer add-compare-select work, not bandwidth: report ACS/s
             "decoder": {"fic_and_msc_ms": dec_ms, "acs_per_s": (ACS_FIC + ACS_MSC64) * n_frames / (dec_ms * 1e-3),
-                        "entry_point": "dabgpu_decode_frames_dev (FIC + sub-channel codewords in one grouped launch)"},
+                        "entry_point": "dabgpu_decode_frames_dev (FIC + sub-channel codewords in one grouped launch)",
+                        "kernels": args.decoder,
+                        # the lane decoder against its bounds: forward pass VALU issue, traceback HBM (bench_legs.decoder_roofline);
+                        # null when the batch is decoded by the wave-per-codeword kernels (below 24 576 codewords per launch)
+                        "roofline": None},
             "cpu_baseline": None,
         }
+        import bench_legs
+        if dec_parts is not None:
+            dr = bench_legs.decoder_roofline(dec_parts, n_frames, [(4 * n_frames, 774), (4 * n_frames, 1542)])
+            dpath = os.path.join(ROOT, "profiles", "pmc_traffic_decoder.json")          # the tracked figure, until a leg measures it now
+            try:
+                dj = json.load(open(dpath))
+                if dj.get("frames_per_call") == n_frames:
+                    bench_legs.decoder_traffic(dr, {k.replace("dabk::", ""): v for k, v in dj["kernels"].items()},
+                                               "profiles/pmc_traffic_decoder.json (rocprofv3 --pmc, a separate run: tools/pmc_decoder.sh); "
+                                               "not measured in this run")
+            except Exception:
+                pass
+            out["decoder"]["roofline"] = dr
         if run_legs:
-            import bench_legs
             B = SimpleNamespace(torch=torch, dabgpu=dabgpu, synth=synth, ctx=ctx, dev=dev, stream=stream, args=args, E=E, F=F, L=L,
                                 n_frames=n_frames, iq=iq, soft=soft, fib=fib, crc=crc, msc=msc, hist=hist, sc=sc, ens=ens,
                                 d_iq=d_iq, BETA=BETA, step=step, decode_into=decode_into, ofdm_ev=ofdm_ev, dec_ev=dec_ev, net=net,

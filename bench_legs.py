@@ -35,7 +35,11 @@ REALTIME_FPS = 1.0 / 0.096
 def run(B, out):
     a = B.args
     if not a.no_traffic:
-        t = measure_traffic(B.n_frames, os.path.dirname(os.path.abspath(__file__)))
+        t = measure_traffic(B.n_frames, os.path.dirname(os.path.abspath(__file__)), decoder=a.decoder)
+        if t is not None and t.get("decoder") and out["decoder"].get("roofline"):
+            decoder_traffic(out["decoder"]["roofline"], t["decoder"],
+                            "measured in this run: the same two rocprofv3 --pmc child processes as roofline.traffic (the child decodes "
+                            "the soft bits its front end left: noise in, every survivor path exercised)")
         if t is not None:
             out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
             out["roofline"]["traffic_over_algorithmic"] = t["ratio_to_algorithmic"]
@@ -71,7 +75,7 @@ def run(B, out):
                                            truth_fibs=[B.ens[0].fibs[f % 4] for f in range(4)])
 
 
-def measure_traffic(n_frames, root, timeout_s=240):
+def measure_traffic(n_frames, root, timeout_s=240, decoder="auto"):
     """HBM bytes per launch of the fused front end (the timed step's data flow: cyclic-prefix correlations out) from the TCC
     counters, measured NOW: two child
     processes `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 tools/pmc_traffic.py n cp` (counters cannot be
@@ -95,12 +99,13 @@ def measure_traffic(n_frames, root, timeout_s=240):
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(out_dir, c)
             r = subprocess.run([prof, "--pmc", c, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "t", "--",
-                                "python3", os.path.join(root, "tools", "pmc_traffic.py"), str(n_frames), "cp"],
+                                "python3", os.path.join(root, "tools", "pmc_traffic.py"), str(n_frames), "cp", decoder],
                                cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
             path = os.path.join(d, "t_counter_collection.csv")
             if r.returncode != 0 or not os.path.exists(path):
                 return None
             acc = {"ofdm": [], "copy": []}
+            acc.update({k: [] for k in DECODER_KERNELS})
             for row in csv.DictReader(open(path)):
                 if row["Counter_Name"] != c:
                     continue
@@ -110,9 +115,13 @@ def measure_traffic(n_frames, root, timeout_s=240):
                     acc["ofdm"].append(v)
                 elif ("copy" in k.lower() or "clone" in k.lower()) and v > 1e5:
                     acc["copy"].append(v)
+                else:
+                    for dk in DECODER_KERNELS:
+                        if dk in k:
+                            acc[dk].append(v)
             if not acc["ofdm"] or not acc["copy"]:
                 return None
-            res[c] = {k: sum(v[-3:]) / len(v[-3:]) for k, v in acc.items()}
+            res[c] = {k: sum(v[-3:]) / len(v[-3:]) for k, v in acc.items() if v}
     except Exception:
         return None
     finally:
@@ -120,9 +129,65 @@ def measure_traffic(n_frames, root, timeout_s=240):
     gib = 1024 ** 3
     rd = res["FETCH_SIZE"]["ofdm"] * gib / res["FETCH_SIZE"]["copy"]          # the copy read 1 GiB and wrote 1 GiB
     wr = res["WRITE_SIZE"]["ofdm"] * gib / res["WRITE_SIZE"]["copy"]
-    return {"hbm_bytes_per_launch": rd + wr, "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr,
-            "ratio_to_algorithmic": (rd + wr) / (A_OFDM * n_frames),
-            "read_scale_from_1GiB_copy": gib / (res["FETCH_SIZE"]["copy"] * 1024), "write_scale_from_1GiB_copy": gib / (res["WRITE_SIZE"]["copy"] * 1024)}
+    out = {"hbm_bytes_per_launch": rd + wr, "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr,
+           "ratio_to_algorithmic": (rd + wr) / (A_OFDM * n_frames),
+           "read_scale_from_1GiB_copy": gib / (res["FETCH_SIZE"]["copy"] * 1024), "write_scale_from_1GiB_copy": gib / (res["WRITE_SIZE"]["copy"] * 1024)}
+    # the channel decoder's kernels, out of the same two passes (the child decodes the soft bits its front end left)
+    if all(dk in res["FETCH_SIZE"] and dk in res["WRITE_SIZE"] for dk in DECODER_KERNELS):
+        out["decoder"] = {dk: {"hbm_read_bytes_per_launch": res["FETCH_SIZE"][dk] * gib / res["FETCH_SIZE"]["copy"],
+                               "hbm_write_bytes_per_launch": res["WRITE_SIZE"][dk] * gib / res["WRITE_SIZE"]["copy"]}
+                          for dk in DECODER_KERNELS}
+    return out
+
+
+DECODER_KERNELS = ("lane_forward_grouped_kernel", "lane_traceback_grouped_kernel", "msc_history_kernel")
+# static VALU count of the lane decoder's forward pass per trellis step of one wave (64 codewords), DESIGN.md 4.2b
+LANE_VALU_PER_STEP, LANE_ACS_VALU_PER_STEP = 202, 96
+# a packed-int16 VALU instruction of one wave occupies its SIMD for 4 cycles at saturation (profiles/r01_ubench_pk_rate.txt:
+# v_pk_add_u16 / v_pk_max_i16 4.24, v_and / v_perm 3.94 with 4 waves per SIMD); 1024 SIMDs at 2.4 GHz
+PK_I16_CYCLES, N_SIMDS, CLOCK_HZ = 4.0, 1024, 2.4e9
+A_DECODER = 9216 + 396 + 37632             # A_fic + A_msc64 = 47 244 B per frame
+
+
+def decoder_roofline(parts_ms, n_frames, codeword_steps):
+    """The channel decoder's place against its two bounds, from the library's own HIP-event timers
+    around the kernels of the timed steps (parts_ms = dabgpu_mean_kernel_ms 4 / 5 / 6: forward pass | traceback | history
+    copy, + the launches they average over):
+      forward pass -- VALU issue: wave-steps x instructions x 4 cycles / (1024 SIMDs x 2.4 GHz), priced on its 96 ACS
+                      instructions alone (frac_of_acs_bound) and on all 202 (frac_of_valu_issue_bound);
+      traceback    -- HBM: the survivor words it reads back (8 B per codeword-step), and the measured bytes once
+                      decoder_traffic() has them.
+    codeword_steps: [(codewords per launch, trellis steps)] of the launch's entries."""
+    fwd_ms, tb_ms, hist_ms, n_fwd = parts_ms
+    wave_steps = sum(((cw + 63) // 64) * steps for cw, steps in codeword_steps)
+    acs_ms = wave_steps * LANE_ACS_VALU_PER_STEP * PK_I16_CYCLES / (N_SIMDS * CLOCK_HZ) * 1e3
+    valu_ms = wave_steps * LANE_VALU_PER_STEP * PK_I16_CYCLES / (N_SIMDS * CLOCK_HZ) * 1e3
+    survivor_bytes = sum(((cw + 63) // 64) * 64 * steps * 8 for cw, steps in codeword_steps)      # written once, read once
+    return {"bound": "valu", "kernel": "dabk::lane_forward_grouped_kernel (forward pass; the traceback behind it is HBM-bound)",
+            "valu_per_step": LANE_VALU_PER_STEP, "acs_valu_per_step": LANE_ACS_VALU_PER_STEP,
+            "acs_share_of_valu": LANE_ACS_VALU_PER_STEP / LANE_VALU_PER_STEP,
+            "wave_steps_per_launch": wave_steps, "cycles_per_packed_int16_instruction": PK_I16_CYCLES, "simds": N_SIMDS,
+            "clock_GHz": CLOCK_HZ / 1e9,
+            "acs_only_bound_ms": acs_ms, "valu_issue_bound_ms": valu_ms,
+            "forward_ms": fwd_ms, "launches_timed": n_fwd,
+            "frac_of_acs_bound": acs_ms / fwd_ms, "frac_of_valu_issue_bound": valu_ms / fwd_ms,
+            "traceback_ms": tb_ms, "history_ms": hist_ms,
+            "survivor_bytes_per_launch": survivor_bytes,
+            "traceback_GBps_on_survivor_bytes": survivor_bytes / (tb_ms * 1e-3) / 1e9,
+            "algorithmic_bytes_per_frame": A_DECODER, "frames_per_launch": n_frames,
+            "traffic": None, "traffic_over_algorithmic": None, "traceback_GBps": None, "traffic_source": "not measured in this run"}
+
+
+def decoder_traffic(r, traffic, source):
+    """HBM bytes of the decoder's kernels (measure_traffic()["decoder"], or the tracked profiles/pmc_traffic_decoder.json)
+    into the record decoder_roofline() made."""
+    tot = sum(v["hbm_read_bytes_per_launch"] + v["hbm_write_bytes_per_launch"] for v in traffic.values())
+    tb = traffic["lane_traceback_grouped_kernel"]
+    tb_bytes = tb["hbm_read_bytes_per_launch"] + tb["hbm_write_bytes_per_launch"]
+    r.update({"traffic": tot, "traffic_over_algorithmic": tot / (A_DECODER * r["frames_per_launch"]), "traffic_source": source,
+              "traffic_by_kernel": {k: {"read": v["hbm_read_bytes_per_launch"], "write": v["hbm_write_bytes_per_launch"]} for k, v in traffic.items()},
+              "traceback_GBps": tb_bytes / (r["traceback_ms"] * 1e-3) / 1e9,
+              "traceback_frac_of_hbm_peak": tb_bytes / (r["traceback_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS})
 
 
 def is_profiler_variable(k, v):

@@ -190,9 +190,9 @@ typedef struct dabgpu_placement_report {
     uint64_t chunk_bytes;
     uint64_t setup_peak_bytes;  /* device memory held at the peak of the set-up (<= 1.5 x the pair)            */
     float classify_ms;          /* time spent finding the domains                                              */
-    float pair_over_same_domain; /* check of the result: a mover reading the first GiB of the samples and writing  */
-                                /* the start of the soft-bit buffer, over the same mover writing into the samples' */
-                                /* own buffer instead (same domain by construction): ~0.9 when the two buffers     */
+    float pair_over_same_domain; /* check of the result: a mover reading 3/4 of the samples' first chunk and writing */
+                                /* the start of the soft-bit buffer, over the same mover writing into the last 1/4 */
+                                /* of that chunk instead (same domain by construction): ~0.9 when the two buffers  */
                                 /* lie apart, ~1.0 when they do not (0 = not measured).  A domain-aware pair is   */
                                 /* only ever handed out below 0.985; at or above it the pair goes back and the    */
                                 /* call ends in a plain pair (DABGPU_PLAIN_ONE_DOMAIN): the caller decides nothing */
@@ -775,7 +775,10 @@ int dabgpu_viterbi(dabgpu_ctx *ctx, const int8_t *punct, int n_codewords, const 
 /* decode (dabgpu_decode_frames*: the FIC is part of the grouped launch),        */
 /* 3 = fft stage.  _last_ = the most recent launch; _mean_ = the mean over the  */
 /* launches since timing was switched on (at most the last 32) and how many     */
-/* that were.  Both wait for the launches they read.                            */
+/* that were.  Both wait for the launches they read.  _mean_ only: 4 / 5 / 6 =  */
+/* the parts of 2 when it was the grouped codeword-per-lane launch (batches of  */
+/* >= 24 576 codewords): forward pass | traceback | de-interleaver history copy */
+/* (DABGPU_ERR_ARG when no timed call took that path).                          */
 /* ------------------------------------------------------------------------ */
 int dabgpu_set_timing(dabgpu_ctx *ctx, int enable);
 int dabgpu_last_kernel_ms(dabgpu_ctx *ctx, int which, float *ms);

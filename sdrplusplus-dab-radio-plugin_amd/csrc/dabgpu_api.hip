@@ -333,6 +333,8 @@ void dabgpu_destroy(dabgpu_ctx *ctx) {
         for (int i = 0; i < TIMER_RING; i++) {
             if (t.start[i]) (void)hipEventDestroy(t.start[i]);
             if (t.stop[i]) (void)hipEventDestroy(t.stop[i]);
+            for (hipEvent_t e : t.mid[i])
+                if (e) (void)hipEventDestroy(e);
         }
     pipeline_destroy(ctx);
     arena_destroy(ctx);
@@ -379,21 +381,27 @@ int dabgpu_last_kernel_ms(dabgpu_ctx *ctx, int which, float *ms) {
 }
 
 int dabgpu_mean_kernel_ms(dabgpu_ctx *ctx, int which, float *mean_ms, int *launches) {
-    if (!ctx || !mean_ms || which < 0 || which > 3) return DABGPU_ERR_ARG;
+    if (!ctx || !mean_ms || which < 0 || which > 6) return DABGPU_ERR_ARG;
     DeviceGuard guard(ctx);
-    Timer &t = ctx->timers[which];
+    // 4 / 5 / 6: the parts of slot 2's grouped lane decode (forward pass | traceback | history copy), where it recorded them
+    const int part = which >= 4 ? which - 4 : -1;
+    Timer &t = ctx->timers[part >= 0 ? 2 : which];
     const int n = int(std::min<long>(t.recorded, TIMER_RING));
-    if (n == 0) return DABGPU_ERR_ARG;
     double sum = 0.0;
+    int used = 0;
     for (int k = 0; k < n; k++) {
         const int i = int((t.recorded - 1 - k) % TIMER_RING);
+        if (part >= 0 && !t.has_mid[i]) continue;
         float ms = 0.f;
         HIP_TRY(hipEventSynchronize(t.stop[i]));
-        HIP_TRY(hipEventElapsedTime(&ms, t.start[i], t.stop[i]));
+        hipEvent_t a = part <= 0 ? t.start[i] : t.mid[i][part - 1], b = part < 0 || part == 2 ? t.stop[i] : t.mid[i][part];
+        HIP_TRY(hipEventElapsedTime(&ms, a, b));
         sum += double(ms);
+        used++;
     }
-    *mean_ms = float(sum / n);
-    if (launches) *launches = n;
+    if (used == 0) return DABGPU_ERR_ARG;
+    *mean_ms = float(sum / used);
+    if (launches) *launches = used;
     return DABGPU_OK;
 }
 

@@ -34,6 +34,10 @@ struct DeviceCode {
 constexpr int TIMER_RING = 32;
 struct Timer {
     hipEvent_t start[TIMER_RING] = {}, stop[TIMER_RING] = {};
+    // the grouped lane decode is two kernels (+ the history copy) inside one timed call: two more events split it into
+    // forward pass | traceback | history (dabgpu_mean_kernel_ms 4 / 5 / 6 read slot 2 through them)
+    hipEvent_t mid[TIMER_RING][2] = {};
+    bool has_mid[TIMER_RING] = {};
     long recorded = 0;                   // launches timed since timing was switched on
 };
 
@@ -149,8 +153,19 @@ struct ScopedTimer {
             Timer &t = ctx->timers[which];
             const int i = int(t.recorded % TIMER_RING);
             if (!t.start[i]) { (void)hipEventCreate(&t.start[i]); (void)hipEventCreate(&t.stop[i]); }
+            t.has_mid[i] = false;
             (void)hipEventRecord(t.start[i], s);
         }
+    }
+    // the two events a launch sequence records between its kernels (nullptr while timing is off)
+    hipEvent_t *mids() {
+        if (!ctx->timing) return nullptr;
+        Timer &t = ctx->timers[which];
+        const int i = int(t.recorded % TIMER_RING);
+        for (hipEvent_t &e : t.mid[i])
+            if (!e && hipEventCreate(&e) != hipSuccess) return nullptr;
+        t.has_mid[i] = true;
+        return t.mid[i];
     }
     ~ScopedTimer() {
         if (ctx->timing) {

@@ -292,7 +292,7 @@ static int decode_grouped(dabgpu_ctx *ctx, uint8_t *d_fib, uint8_t *d_crc_ok, co
     }
     ScopedTimer tm(ctx, 2, s);
     dabk::LaneScratch lsc{ctx->d_lane_scratch, ctx->lane_scratch_bytes};
-    HIP_TRY(dabk::launch_lane_group(items.data(), n_items, lsc, s));
+    HIP_TRY(dabk::launch_lane_group(items.data(), n_items, lsc, s, tm.mids()));
     for (const dabk::LaneGroupItem &it : items)
         if (!it.is_fic) HIP_TRY(dabk::launch_msc_history(it.args, s));
     return 0;

@@ -395,16 +395,19 @@ int dabgpu_alloc_frame_buffers(dabgpu_ctx *ctx, int n_frames, size_t frame_strid
     *d_iq = ar.d_iq;
     *d_soft = static_cast<int8_t *>(ar.d_soft);
     rep.method = 1;
-    // check of the result, independent of the classification: the mover reads the first GiB of the samples and writes
-    // (a) the start of the soft-bit buffer, (b) into the samples' own buffer two GiB further on (same domain by
-    // construction); alternated, so that drift hits both alike.  Leaves noise-like words in both buffers.
+    // check of the result, independent of the classification: the mover reads the first three quarters of the samples' first
+    // chunk and writes (a) the start of the soft-bit buffer, (b) the last quarter of that same chunk -- one physical chunk,
+    // the same domain by construction whatever the map looks like (round 5 wrote two GiB further on, which is another domain
+    // whenever a small pair's map changes domain there: a false "one domain" reading); alternated, so that drift hits
+    // both alike.  Leaves noise-like words in both buffers.
     {
-        const size_t out_b = std::min(soft_mapped, CH / 6);
+        const size_t c0 = p.c[size_t(iq_sel[0])].bytes, in_b = c0 / 4 * 3;
+        const size_t out_b = std::min(soft_mapped, c0 / 8);
         char *iq0 = static_cast<char *>(*d_iq);
         float ta = 1e30f, tb = 1e30f;
         for (int r = 0; r < 3; r++) {
-            const float a = mover_ms(p, iq0, CH, *d_soft, out_b);
-            const float b = mover_ms(p, iq0, CH, iq0 + 2 * CH, out_b);
+            const float a = mover_ms(p, iq0, in_b, *d_soft, out_b);
+            const float b = mover_ms(p, iq0, in_b, iq0 + in_b, out_b);
             if (a > 0.f) ta = std::min(ta, a);
             if (b > 0.f) tb = std::min(tb, b);
         }

@@ -401,7 +401,8 @@ struct LaneGroupItem {
 };
 bool lane_group_fusable(const MscArgs &a);
 size_t lane_group_scratch_bytes(const LaneGroupItem *items, int n);
-hipError_t launch_lane_group(const LaneGroupItem *items, int n, const LaneScratch &sc, hipStream_t s);
+// mid (optional, timing only): two events, recorded behind the forward pass and behind the traceback of the last pack
+hipError_t launch_lane_group(const LaneGroupItem *items, int n, const LaneScratch &sc, hipStream_t s, hipEvent_t *mid = nullptr);
 // Dynamic-LDS request (>= lds) that makes every CU hold the same number of workgroups of a `grid`-workgroup
 // launch when at most `o_cap` fit per CU otherwise (the dispatcher fills CUs greedily).
 size_t balanced_lds_bytes(unsigned grid, size_t lds, unsigned o_cap);

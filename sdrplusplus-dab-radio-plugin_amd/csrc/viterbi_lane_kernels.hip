@@ -824,7 +824,7 @@ static int resident_cus() {
     return n;
 }
 
-hipError_t launch_lane_group(const LaneGroupItem *items, int n, const LaneScratch &sc, hipStream_t s) {
+hipError_t launch_lane_group(const LaneGroupItem *items, int n, const LaneScratch &sc, hipStream_t s, hipEvent_t *mid) {
     if (n <= 0) return hipSuccess;
     if (!sc.base || sc.bytes < lane_group_scratch_bytes(items, n)) return hipErrorInvalidValue;
     char *p = static_cast<char *>(sc.base);
@@ -867,9 +867,12 @@ hipError_t launch_lane_group(const LaneGroupItem *items, int n, const LaneScratc
             for (int i = 0; i < pack.n; i++) { longest = std::max(longest, pack.e[i].nsteps); shortest = std::min(shortest, pack.e[i].nsteps); }
             pack.prio_nsteps = (pack.total_groups <= 2 * 4 * resident_cus() && longest > shortest) ? longest : 0;
         }
+        const bool timed = mid && i0 + LANE_GROUP_MAX >= n;
         hipLaunchKernelGGL(lane_forward_grouped_kernel, dim3(fgrid), dim3(256), lds, s, pack);
+        if (timed) (void)hipEventRecord(mid[0], s);
         const size_t tb_lds = size_t(64) * (max_nwords | 1) * 4;
         hipLaunchKernelGGL(lane_traceback_grouped_kernel, dim3(unsigned(pack.total_groups)), dim3(64), tb_lds, s, pack);
+        if (timed) (void)hipEventRecord(mid[1], s);
     }
     return hipGetLastError();
 }

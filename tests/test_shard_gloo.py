@@ -224,6 +224,9 @@ def test_bench_line_keeps_the_contract():
     # the stated ceiling: a mover of the kernel's own geometry on the timed buffers (the kernel cannot beat its own bytes)
     assert ro["mover_same_geometry_ms"] > 0 and "copy_ceiling" not in ro
     assert abs(ro["kernel_over_mover"] - ro["avg_launch_ms"] / ro["mover_same_geometry_ms"]) < 1e-9
+    # (64 frames are decoded by the wave-per-codeword kernels: the lane decoder's record is null here and asserted by
+    # test_bench_line_carries_the_decoder_roofline)
+    assert j["decoder"]["kernels"] == "auto" and j["decoder"]["roofline"] is None and j["decoder"]["acs_per_s"] > 0
     bp = j["config"]["buffer_placement"]
     assert bp["requested"] == "domains" and bp["setup_peak_over_final_footprint"] <= 1.5   # the default; this small shape falls back to a plain pair
     assert bp["method"] == "plain hipMalloc pair" and "too small" in bp["fallback_reason"]
@@ -296,3 +299,42 @@ print('ok')
         env.pop(k, None)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env, cwd=ROOT)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout + r.stderr)[-2000:]
+
+
+@pytest.mark.gpu
+def test_bench_line_carries_the_decoder_roofline():
+    """the 19 % of the step the channel decoder takes has a tracked fraction.  `decoder.roofline` is built
+    from the library's own HIP-event timers around the lane decoder's kernels during the timed steps (forward pass | traceback |
+    history copy) and, when rocprofv3 is there, from the TCC counters of the same two child passes that give roofline.traffic.
+    Run at a small shape with the lane kernels pinned (--decoder lane; the default shape takes them by itself) and every leg
+    but the traffic measurement switched off."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--ensembles", "4", "--frames", "16", "--steps", "3", "--warmup", "1",
+           "--decoder", "lane", "--legs", "all", "--cpu-seconds", "0", "--sustained-seconds", "0", "--no-dd-leg", "--no-fft-stage",
+           "--no-selective", "--no-closed-loop", "--no-single-ensemble", "--no-host-fed", "--no-host-mirror"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ), cwd=ROOT)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert j["fic_bit_exact"] is True and j["msc_bit_exact"] is True and j["decoder"]["kernels"] == "lane"
+    d = j["decoder"]["roofline"]
+    assert d["bound"] == "valu" and d["valu_per_step"] == 202 and d["acs_valu_per_step"] == 96 and "lane_forward_grouped_kernel" in d["kernel"]
+    assert d["frames_per_launch"] == 64 and d["wave_steps_per_launch"] == 4 * (774 + 1542) and d["launches_timed"] == 3
+    assert d["algorithmic_bytes_per_frame"] == 9216 + 396 + 37632 == 47244          # SURVEY 8(d): A_fic + A_msc64
+    assert d["survivor_bytes_per_launch"] == 256 * (774 + 1542) * 8
+    bound = d["wave_steps_per_launch"] * 96 * d["cycles_per_packed_int16_instruction"] / (d["simds"] * d["clock_GHz"] * 1e9) * 1e3
+    assert abs(d["acs_only_bound_ms"] - bound) < 1e-12 and abs(d["valu_issue_bound_ms"] - bound * 202 / 96) < 1e-12
+    assert abs(d["frac_of_acs_bound"] - d["acs_only_bound_ms"] / d["forward_ms"]) < 1e-12 and 0 < d["frac_of_acs_bound"] < d["frac_of_valu_issue_bound"] < 1
+    # the three parts are what the decode call's device time is made of (the events between them cost a few microseconds)
+    assert 0 < d["history_ms"] < d["traceback_ms"] < d["forward_ms"]
+    parts = d["forward_ms"] + d["traceback_ms"] + d["history_ms"]
+    assert parts <= j["decoder"]["fic_and_msc_ms"] * 1.02 and parts >= 0.5 * j["decoder"]["fic_and_msc_ms"]
+    assert abs(d["traceback_GBps_on_survivor_bytes"] - d["survivor_bytes_per_launch"] / (d["traceback_ms"] * 1e-3) / 1e9) < 1e-6
+    if j["roofline"]["traffic"] is not None and j["roofline"]["traffic_source"].startswith("measured in this run"):
+        assert d["traffic_source"].startswith("measured in this run")
+        tk = d["traffic_by_kernel"]
+        assert set(tk) == {"lane_forward_grouped_kernel", "lane_traceback_grouped_kernel", "msc_history_kernel"}
+        assert abs(d["traffic"] - sum(v["read"] + v["write"] for v in tk.values())) < 1.0
+        assert abs(d["traffic_over_algorithmic"] - d["traffic"] / (47244 * 64)) < 1e-9
+        # (no physical lower bound is asserted at this toy shape: 4.7 MB of survivors may never leave the L2; at the default
+        # shape the forward pass writes and the traceback reads 1.21 GB each, profiles/r06_pmc_traffic_decoder.json)
+        assert tk["lane_forward_grouped_kernel"]["write"] > 0 and tk["lane_traceback_grouped_kernel"]["read"] > 0
+        assert d["traffic_over_algorithmic"] > 0 and d["traceback_GBps"] > 0

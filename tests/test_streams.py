@@ -381,7 +381,7 @@ def test_alloc_frame_buffers_by_domain(built, ensemble_iq):
     assert free0 - torch.cuda.mem_get_info()[0] <= 64 << 20
     # the same ranges serve the next pair (same addresses); a larger one than they were reserved for is a plain pair
     f_iq, f_soft, rep3 = c.alloc_frame_buffers(n, L, dabgpu.PLACE_DOMAINS)
-    assert rep3.method == rep.method and (not placed or f_iq == d_iq)
+    assert rep3.method == rep.method and (not placed or f_iq == d_iq), (rep3.method, rep3.fallback_reason, rep3.runtime_error, rep3.pair_over_same_domain, rep3.domains, rep3.iq_map, rep3.soft_map)
     g_iq, g_soft, rep4 = c.alloc_frame_buffers(2 * n, L, dabgpu.PLACE_DOMAINS)
     assert rep4.method == 0 and rep4.fallback_reason == (4 if placed else 5)
     c.free_frame_buffers(g_iq, g_soft)
