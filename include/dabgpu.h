@@ -143,6 +143,17 @@ void *dabgpu_stream(dabgpu_ctx *ctx);
  * optimisation for callers that own their buffers, e.g. the host mirror's frame and soft-bit buffers. */
 void *dabgpu_host_alloc(size_t bytes);
 void dabgpu_host_free(void *p);
+/* (The one-frame calls -- dabgpu_ofdm_demod_stream_frame, dabgpu_decode_stream_frames, dabgpu_dabplus_superframes -- let
+ * their kernels write results straight into page-locked caller buffers and end on a watched word instead of a stream
+ * synchronisation ONLY for buffers obtained here, which are coherent; results written into any other page-locked memory
+ * (hipHostRegister, non-coherent allocations) are followed by hipStreamSynchronize: HIP promises host visibility of kernel
+ * writes to such memory only there.) */
+
+/* Test hook (tests/ only; changes no result): the nth one-frame call of this context from now on
+ * (dabgpu_ofdm_demod_stream_frame or dabgpu_decode_stream_frames, whichever the context serves) returns DABGPU_ERR_HIP
+ * before any launch, once; 0 disarms.  What the host mirror must survive: /root/reference/src/radio_block.cpp:27, 37
+ * (the two Process calls run on threads nobody can throw to). */
+int dabgpu_test_fail_frame_call(dabgpu_ctx *ctx, int nth);
 
 /* Device buffers for a batch user's IQ samples ([n_frames][frame_stride] cf32, frame_stride >= 196608 samples) and
  * soft bits ([n_frames][230400] int8).  Any device buffer is accepted by the _dev entry points; this call exists for

@@ -9,12 +9,18 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <utility>
 
 using namespace dab;
 using namespace dabapi;
 
 namespace {
+
+// allocations of dabgpu_host_alloc: coherent page-locked memory (known_coherent_host); process-wide, any thread
+std::mutex g_host_mutex;
+std::vector<std::pair<const char *, size_t>> g_host_ranges;
 
 template <class T>
 int upload(T **dst, const std::vector<T> &src) {
@@ -346,13 +352,35 @@ void dabgpu_destroy(dabgpu_ctx *ctx) {
 
 void *dabgpu_host_alloc(size_t bytes) {
     void *p = nullptr;
-    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    if (bytes == 0) return nullptr;
+    // coherent page-locked memory, asked for by name (the runtime's default can be switched by its environment)
+    if (hipHostMalloc(&p, bytes, hipHostMallocCoherent) == hipSuccess) {
+        std::lock_guard<std::mutex> lock(g_host_mutex);
+        g_host_ranges.emplace_back(static_cast<const char *>(p), bytes);
+        return p;
+    }
+    (void)hipGetLastError();
+    // (not registered: the one-frame calls then end in a stream synchronisation instead of the watched word)
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     return p;
 }
 
 void dabgpu_host_free(void *p) {
-    if (p) (void)hipHostFree(p);
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lock(g_host_mutex);
+        for (size_t i = 0; i < g_host_ranges.size(); i++)
+            if (g_host_ranges[i].first == p) { g_host_ranges[i] = g_host_ranges.back(); g_host_ranges.pop_back(); break; }
+    }
+    (void)hipHostFree(p);
 }
+
+int dabgpu_test_fail_frame_call(dabgpu_ctx *ctx, int nth) {
+    if (!ctx || nth < 0) return DABGPU_ERR_ARG;
+    ctx->test_fail_in = nth;
+    return DABGPU_OK;
+}
+
 int dabgpu_sync(dabgpu_ctx *ctx) {
     if (!ctx) return DABGPU_ERR_ARG;
     DeviceGuard guard(ctx);
@@ -596,6 +624,30 @@ static_assert(offsetof(dabgpu_stream_state, next_frame_start) == offsetof(dabk::
 // one, so that the host-side accessors can wait for exactly that work.
 }  // extern "C"
 namespace dabapi {
+bool known_coherent_host(const void *host, size_t bytes) {
+    const char *p = static_cast<const char *>(host);
+    std::lock_guard<std::mutex> lock(g_host_mutex);
+    for (const auto &r : g_host_ranges)
+        if (p >= r.first && p + bytes <= r.first + r.second) return true;
+    return false;
+}
+
+int ensure_bounce(dabgpu_ctx *ctx, size_t bytes) {
+    if (ctx->h_bounce_bytes >= bytes + 64) return DABGPU_OK;
+    if (ctx->h_bounce) (void)hipHostFree(ctx->h_bounce);
+    ctx->h_bounce = nullptr;
+    ctx->h_bounce_bytes = 0;
+    const size_t want = std::max<size_t>(bytes + 64, 256);
+    if (hipHostMalloc(&ctx->h_bounce, want, hipHostMallocCoherent) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->h_bounce = nullptr;
+        return DABGPU_ERR_NOMEM;
+    }
+    ctx->h_bounce_bytes = want;
+    std::memset(ctx->h_bounce, 0, want);
+    return DABGPU_OK;
+}
+
 void *device_alias_of_pinned(const void *host) {
     hipPointerAttribute_t at{};
     if (!host || hipPointerGetAttributes(&at, host) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
@@ -1184,15 +1236,9 @@ int dabgpu_ofdm_demod_stream_frame(dabgpu_ctx *ctx, int stream_index, const floa
     // cfg->decision_directed -- the fourth-power sums
     if ((rc = stage(ctx, 6, NB_FRAME_SYMBOLS * sizeof(float2), c.decision_directed ? &d_dd : &d_cyc))) return rc;
     if (dqpsk && (rc = stage(ctx, 4, nb_dq, &d_dq))) return rc;
-    if (ctx->h_bounce_bytes < nb_res + 64) {
-        if (ctx->h_bounce) (void)hipHostFree(ctx->h_bounce);
-        ctx->h_bounce = nullptr;
-        ctx->h_bounce_bytes = 0;
-        if (hipHostMalloc(&ctx->h_bounce, nb_res + 64, hipHostMallocDefault) != hipSuccess) return DABGPU_ERR_NOMEM;
-        ctx->h_bounce_bytes = nb_res + 64;
-        std::memset(ctx->h_bounce, 0, nb_res + 64);
-    }
+    if ((rc = ensure_bounce(ctx, nb_res))) return rc;
     if ((rc = wait_state_use(ctx))) return rc;
+    if (injected_failure(ctx)) return DABGPU_ERR_HIP;            // (test hook: a device call that fails before any launch)
     hipStream_t s = ctx->stream;
     char *res = static_cast<char *>(d_res);
     // one upload: by a kernel when the frame lies in page-locked memory the device can address (the host mirror's does)
@@ -1229,8 +1275,10 @@ int dabgpu_ofdm_demod_stream_frame(dabgpu_ctx *ctx, int stream_index, const floa
     } else {
         // one synchronisation: the word behind the landing area's payload (the area is at least nb_res + 64 bytes)
         const size_t off_flag = ctx->h_bounce_bytes - 64;
+        // (the soft bits may have gone straight into the caller's buffer: the word is watched only when that buffer is coherent)
         if ((rc = wait_for_signal(s, reinterpret_cast<volatile unsigned long long *>(static_cast<char *>(ctx->h_bounce) + off_flag),
-                                  reinterpret_cast<unsigned long long *>(hd + off_flag), ++ctx->signal_seq)))
+                                  reinterpret_cast<unsigned long long *>(hd + off_flag), ++ctx->signal_seq, false,
+                                  !soft_alias || known_coherent_host(soft, NB_FRAME_BITS))))
             return rc;
     }
     ctx->ev_states_pending = false;

@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <map>
 #include <memory>
 #include <vector>
@@ -94,6 +95,7 @@ struct dabgpu_ctx {
     int lane_mode = -1;                  // 1 = DABGPU_FLAG_VITERBI_LANE, 0 = DABGPU_FLAG_VITERBI_WAVE, -1 by batch size
     bool lane_unfused = false;           // DABGPU_FLAG_LANE_UNFUSED
     bool test_one_domain = false;        // DABGPU_FLAG_TEST_ONE_DOMAIN (dabgpu_placement.hip)
+    int test_fail_in = 0;                // dabgpu_test_fail_frame_call: one-frame calls left until one reports DABGPU_ERR_HIP
     int wave_slots = 3072;               // resident OFDM wavefronts: 12 per CU
     std::vector<dabgpu_bit_range> keep_ranges;           // the current selection, merged, for the host-pointer copy-back
     dabk::StreamState *d_states = nullptr;               // per-stream tracking state (dabgpu_streams_reset)
@@ -179,22 +181,39 @@ struct ScopedTimer {
 // The end of a one-frame call (dabgpu_ofdm_demod_stream_frame, dabgpu_decode_stream_frames): ~55 us of device work are in
 // flight and the caller can do nothing until they are done.  hipStreamSynchronize puts the thread to sleep and pays the
 // wake-up; instead a one-thread launch behind the call's last kernel stores the call's number into a word of the page-locked
-// landing area and the host watches that word (bounded: after two million looks, some tens of milliseconds -- no frame call
-// takes that long -- it sleeps on the stream after all).  `flag_host` / `flag_dev`: the two addresses of the word; `seq`: this call's number.
+// landing area and the host watches that word -- for at most SIGNAL_SPIN_US (no frame call takes that long on an idle
+// device; a core is never held longer), then it sleeps on the stream after all.
+// `flag_host` / `flag_dev`: the two addresses of the word; `seq`: this call's number.
 // (already_signalled: the last kernel of the call stores the word itself -- a single-workgroup launch can)
+// results_coherent: the kernels of these calls write their results straight into page-locked HOST memory, and
+// a watched word orders nothing for memory the device does not write coherently: HIP guarantees host visibility of kernel
+// writes to hipHostRegister'ed or non-coherent allocations only at a stream / event synchronisation.  The word is watched
+// only when every such buffer is KNOWN to be coherent -- the context's own landing area and buffers from dabgpu_host_alloc
+// (known_coherent_host) -- and the call ends in hipStreamSynchronize otherwise.
+constexpr long SIGNAL_SPIN_US = 200;
 inline int wait_for_signal(hipStream_t s, volatile unsigned long long *flag_host, unsigned long long *flag_dev, unsigned long long seq,
-                           bool already_signalled = false) {
+                           bool already_signalled = false, bool results_coherent = true) {
+    if (!results_coherent) return hipStreamSynchronize(s) == hipSuccess ? DABGPU_OK : DABGPU_ERR_HIP;
     if (!already_signalled && dabk::launch_signal(flag_dev, seq, s) != hipSuccess) return DABGPU_ERR_HIP;
-    for (long i = 0; i < 2000000; i++) {
-        if (*flag_host == seq) {
-            __atomic_thread_fence(__ATOMIC_ACQUIRE);
-            return DABGPU_OK;
-        }
+    const auto give_up = std::chrono::steady_clock::now() + std::chrono::microseconds(SIGNAL_SPIN_US);
+    for (;;) {
+        for (int i = 0; i < 64; i++) {
+            if (*flag_host == seq) {
+                __atomic_thread_fence(__ATOMIC_ACQUIRE);
+                return DABGPU_OK;
+            }
 #if defined(__x86_64__) || defined(__i386__)
-        __builtin_ia32_pause();
+            __builtin_ia32_pause();
 #endif
+        }
+        if (std::chrono::steady_clock::now() >= give_up) break;
     }
     return hipStreamSynchronize(s) == hipSuccess ? DABGPU_OK : DABGPU_ERR_HIP;
+}
+
+// dabgpu_test_fail_frame_call: true exactly once, on the armed one-frame call
+inline bool injected_failure(dabgpu_ctx *ctx) {
+    return ctx->test_fail_in > 0 && --ctx->test_fail_in == 0;
 }
 
 inline hipStream_t pick_stream(dabgpu_ctx *ctx, void *stream) {
@@ -208,6 +227,11 @@ void free_device_code(DeviceCode &dc);
 // the address the device reaches page-locked host memory under (hipHostMalloc / hipHostRegister: dabgpu_host_alloc), or
 // nullptr for any other pointer
 void *device_alias_of_pinned(const void *host);
+// [host, host + bytes) lies inside one allocation of dabgpu_host_alloc (coherent page-locked memory: a kernel's writes to it
+// are visible to a host that watched a word the kernel stored afterwards)
+bool known_coherent_host(const void *host, size_t bytes);
+// the context's page-locked landing area (coherent), at least `bytes` + the 64 bytes of the watched word, zeroed when (re)allocated
+int ensure_bounce(dabgpu_ctx *ctx, size_t bytes);
 int note_state_use(dabgpu_ctx *ctx, hipStream_t s);
 int wait_state_use(dabgpu_ctx *ctx);
 void stats_of(const dabk::StreamState &st, dabgpu_stats *out);

@@ -554,14 +554,8 @@ static int decode_stream_frames_body(dabgpu_ctx *ctx, const int8_t *soft, size_t
     int rc;
     if ((rc = stage(ctx, 1, nb_soft, &d_soft))) return rc;
     if ((rc = stage(ctx, 3, res_total, &d_res))) return rc;
-    if (ctx->h_bounce_bytes < res_total + 64) {
-        if (ctx->h_bounce) (void)hipHostFree(ctx->h_bounce);
-        ctx->h_bounce = nullptr;
-        ctx->h_bounce_bytes = 0;
-        if (hipHostMalloc(&ctx->h_bounce, res_total + 64, hipHostMallocDefault) != hipSuccess) return DABGPU_ERR_NOMEM;
-        ctx->h_bounce_bytes = res_total + 64;
-        std::memset(ctx->h_bounce, 0, res_total + 64);
-    }
+    if ((rc = ensure_bounce(ctx, res_total))) return rc;
+    if (injected_failure(ctx)) return DABGPU_ERR_HIP;            // (test hook: the caller's failure path drops every ring)
     // one upload (by a kernel when the soft bits lie in page-locked memory the device can address).  One frame with a
     // handful of sub-channels -- the plugin's call -- sends only what will be read: the FIC and the sub-channels' ranges
     // of the four CIFs (21.5 kB of the 230 kB for one 64 kbit/s service)
@@ -655,14 +649,10 @@ int dabgpu_dabplus_superframes(dabgpu_ctx *ctx, const uint8_t *in, size_t in_str
     if (n_superframes <= 8) {
         void *a_in = device_alias_of_pinned(in), *a_out = device_alias_of_pinned(out), *a_st = device_alias_of_pinned(status);
         if (a_in && a_out && a_st && !(reinterpret_cast<uintptr_t>(a_st) & 7)) {
-            if (ctx->h_bounce_bytes < 64) {
-                if (ctx->h_bounce) (void)hipHostFree(ctx->h_bounce);
-                ctx->h_bounce = nullptr;
-                ctx->h_bounce_bytes = 0;
-                if (hipHostMalloc(&ctx->h_bounce, 256, hipHostMallocDefault) != hipSuccess) return DABGPU_ERR_NOMEM;
-                ctx->h_bounce_bytes = 256;
-                std::memset(ctx->h_bounce, 0, 256);
-            }
+            const int brc = ensure_bounce(ctx, 0);
+            if (brc) return brc;
+            // the kernel writes the caller's buffers: the word is watched only when they are known to be coherent
+            const bool coherent = known_coherent_host(out, nb_out) && known_coherent_host(status, sizeof(dabgpu_superframe_status) * size_t(n_superframes));
             void *h_dev = nullptr;
             HIP_TRY(hipHostGetDevicePointer(&h_dev, ctx->h_bounce, 0));
             hipStream_t st = ctx->stream;
@@ -674,12 +664,12 @@ int dabgpu_dabplus_superframes(dabgpu_ctx *ctx, const uint8_t *in, size_t in_str
                 // ONE super-frame (the host mirror's call) is ONE workgroup: it stores the watched word itself, behind its results
                 HIP_TRY(dabk::launch_dabplus_superframes(static_cast<const uint8_t *>(a_in), in_stride, 1, s, static_cast<uint8_t *>(a_out),
                                                          reinterpret_cast<dabk::SuperframeStatus *>(a_st), st, flag_dev, seq));
-                return wait_for_signal(st, flag_host, flag_dev, seq, true);
+                return wait_for_signal(st, flag_host, flag_dev, seq, true, coherent);
             }
             const int rc0 = dabgpu_dabplus_superframes_dev(ctx, static_cast<const uint8_t *>(a_in), in_stride, n_superframes, bitrate_kbps,
                                                            static_cast<uint8_t *>(a_out), static_cast<dabgpu_superframe_status *>(a_st), st);
             if (rc0) return rc0;
-            return wait_for_signal(st, flag_host, flag_dev, seq);
+            return wait_for_signal(st, flag_host, flag_dev, seq, false, coherent);
         }
     }
     void *d_in, *d_out, *d_st;

@@ -405,11 +405,14 @@ int dabgpu_alloc_frame_buffers(dabgpu_ctx *ctx, int n_frames, size_t frame_strid
         const size_t out_b = std::min(soft_mapped, c0 / 8);
         char *iq0 = static_cast<char *>(*d_iq);
         float ta = 1e30f, tb = 1e30f;
-        for (int r = 0; r < 3; r++) {
+        // (noise only ever makes a launch slower: the fastest of each side is kept, and a reading that would send the pair
+        // back gets six more rounds before it is believed)
+        for (int r = 0; r < 9; r++) {
             const float a = mover_ms(p, iq0, in_b, *d_soft, out_b);
             const float b = mover_ms(p, iq0, in_b, iq0 + in_b, out_b);
             if (a > 0.f) ta = std::min(ta, a);
             if (b > 0.f) tb = std::min(tb, b);
+            if (r >= 2 && ta < 0.97f * tb) break;
         }
         if (ta < 1e29f && tb < 1e29f) rep.pair_over_same_domain = ta / tb;
         (void)hipGetLastError();

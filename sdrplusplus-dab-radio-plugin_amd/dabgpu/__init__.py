@@ -44,7 +44,7 @@ EXPORTS = [
     "dabgpu_decode_stream_reset", "dabgpu_alloc_frame_buffers", "dabgpu_free_frame_buffers",
     "dabgpu_mover_frames_dev", "dabgpu_pipe_open", "dabgpu_pipe_submit", "dabgpu_pipe_wait", "dabgpu_pipe_reset", "dabgpu_pipe_close",
     "dabgpu_set_stream_loop", "dabgpu_set_loop_gate", "dabgpu_track_default_cfg", "dabgpu_track_start_dev", "dabgpu_ofdm_demod_tracked_dev",
-    "dabgpu_ofdm_demod_stream_frame", "dabgpu_ofdm_demod_frames_dd_dev",
+    "dabgpu_ofdm_demod_stream_frame", "dabgpu_ofdm_demod_frames_dd_dev", "dabgpu_test_fail_frame_call",
 ]
 
 ABI_VERSION = 6
@@ -199,6 +199,7 @@ def load_library(path):
     L.dabgpu_ofdm_demod_frames_dev.argtypes = [vp, vp, sz, i, vp, vp, vp, vp, vp]
     L.dabgpu_ofdm_demod_frames.argtypes = [vp, vp, sz, i, vp, vp, vp, vp]
     L.dabgpu_ofdm_demod_frames_dd_dev.argtypes = [vp, vp, sz, i, vp, vp, vp, vp]
+    L.dabgpu_test_fail_frame_call.argtypes = [vp, i]
     L.dabgpu_fft_symbols_dev.argtypes = [vp, vp, sz, i, vp, vp, vp]
     L.dabgpu_fft_symbols.argtypes = [vp, vp, sz, i, vp, vp]
     L.dabgpu_fic_decode_dev.argtypes = [vp, vp, sz, i, vp, vp, vp]
@@ -470,6 +471,10 @@ class Context:
         _check(self._lib.dabgpu_alloc_frame_buffers(self._h, n_frames, frame_stride, placement, C.byref(d_iq), C.byref(d_soft),
                                                     C.byref(rep)), "dabgpu_alloc_frame_buffers")
         return d_iq.value, d_soft.value, rep
+
+    def test_fail_frame_call(self, nth):
+        """Test hook: the nth one-frame call from now on reports DABGPU_ERR_HIP before any launch (0 disarms)."""
+        _check(self._lib.dabgpu_test_fail_frame_call(self._h, nth), "dabgpu_test_fail_frame_call")
 
     def mover_frames_dev(self, d_iq, frame_stride, n_frames, d_soft, with_prefixes=False, stream=None):
         """The front end's loads and stores without its arithmetic (dabgpu_mover_frames_dev); overwrites d_soft."""

@@ -64,6 +64,8 @@ public:
     int GetTotalFIBErrors() const { return m_total_fib_errors; }
     // frames whose sub-channels could not be decoded (the per-frame GPU call failed; the FIC was decoded on its own)
     int GetTotalFramesLost() const { return m_total_frames_lost; }
+    // test hook (host/demo/dab_host_multi.cpp): the nth decode call into libdabgpu from now on reports a device failure
+    void TestFailDeviceCall(int nth) { (void)dabgpu_test_fail_frame_call(m_ctx, nth); }
 
 private:
     struct Subchannel {

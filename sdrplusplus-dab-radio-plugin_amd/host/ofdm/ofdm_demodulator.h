@@ -113,6 +113,8 @@ public:
         m_freq_coarse_offset.store(f, std::memory_order_relaxed);
         (void)dabgpu_set_stream_offsets(m_ctx, 0, nullptr, &f);
     }
+    // test hook (host/demo/dab_host_multi.cpp): the nth frame call into libdabgpu from now on reports a device failure
+    void TestFailDeviceCall(int nth) { (void)dabgpu_test_fail_frame_call(m_ctx, nth); }
     int GetFineTimeOffset() const { return m_last_time_offset.load(std::memory_order_relaxed); }
     float GetImpulsePeakDb() const { return m_last_peak_db.load(std::memory_order_relaxed); }
 

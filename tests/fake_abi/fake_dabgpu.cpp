@@ -55,6 +55,7 @@ int profile_of(const dabgpu_subchannel &sc, Profile &p) {
 struct dabgpu_ctx {
     std::vector<dabgpu_stream_state> states;
     std::map<std::pair<int, int>, Ring> rings;
+    int test_fail_in = 0;          // dabgpu_test_fail_frame_call: the library's hook, same meaning
 };
 
 extern "C" {
@@ -90,6 +91,11 @@ int dabgpu_create(const dabgpu_cfg *cfg, dabgpu_ctx **out) {
     return DABGPU_OK;
 }
 void dabgpu_destroy(dabgpu_ctx *ctx) { delete ctx; }
+int dabgpu_test_fail_frame_call(dabgpu_ctx *ctx, int nth) {
+    if (!ctx || nth < 0) return DABGPU_ERR_ARG;
+    ctx->test_fail_in = nth;
+    return DABGPU_OK;
+}
 void *dabgpu_host_alloc(size_t bytes) { return std::calloc(1, (bytes + 63) & ~size_t(63)); }
 void dabgpu_host_free(void *p) { std::free(p); }
 
@@ -123,6 +129,7 @@ void dabgpu_track_default_cfg(dabgpu_track_cfg *c) {
 int dabgpu_ofdm_demod_stream_frame(dabgpu_ctx *ctx, int idx, const float *iq, int acquiring, const dabgpu_track_cfg *cfg,
                                    int8_t *soft, float *dqpsk, dabgpu_frame_result *res) {
     if (!ctx || !iq || !soft || !res || !cfg || idx < 0 || size_t(idx) >= ctx->states.size()) return DABGPU_ERR_ARG;
+    if (ctx->test_fail_in > 0 && --ctx->test_fail_in == 0) return DABGPU_ERR_HIP;
     dabgpu_stream_state &st = ctx->states[size_t(idx)];
     const std::complex<float> *x = reinterpret_cast<const std::complex<float> *>(iq);
     const float TWO_PI = 6.283185307179586f;
@@ -218,6 +225,10 @@ int dabgpu_decode_stream_frames(dabgpu_ctx *ctx, const int8_t *soft, size_t stri
     for (int i = 0; i < nsc; i++) {
         const int rc = profile_of(sc[i], prof[size_t(i)]);
         if (rc) return rc;
+    }
+    if (ctx->test_fail_in > 0 && --ctx->test_fail_in == 0) {     // as the library: a failed call drops every ring
+        ctx->rings.clear();
+        return DABGPU_ERR_HIP;
     }
     for (auto &kv : ctx->rings) kv.second.live = false;
     for (int i = 0; i < nsc; i++) {

@@ -381,9 +381,11 @@ def test_alloc_frame_buffers_by_domain(built, ensemble_iq):
     assert free0 - torch.cuda.mem_get_info()[0] <= 64 << 20
     # the same ranges serve the next pair (same addresses); a larger one than they were reserved for is a plain pair
     f_iq, f_soft, rep3 = c.alloc_frame_buffers(n, L, dabgpu.PLACE_DOMAINS)
-    assert rep3.method == rep.method and (not placed or f_iq == d_iq), (rep3.method, rep3.fallback_reason, rep3.runtime_error, rep3.pair_over_same_domain, rep3.domains, rep3.iq_map, rep3.soft_map)
+    placed3 = rep3.method == 1
+    assert (placed3 and f_iq == d_iq) or rep3.fallback_reason == dabgpu.PLAIN_ONE_DOMAIN, \
+        (rep3.method, rep3.fallback_reason, rep3.runtime_error, rep3.pair_over_same_domain, rep3.domains, rep3.iq_map, rep3.soft_map)
     g_iq, g_soft, rep4 = c.alloc_frame_buffers(2 * n, L, dabgpu.PLACE_DOMAINS)
-    assert rep4.method == 0 and rep4.fallback_reason == (4 if placed else 5)
+    assert rep4.method == 0 and rep4.fallback_reason == (4 if placed3 else 5)
     c.free_frame_buffers(g_iq, g_soft)
     c.free_frame_buffers(f_iq, f_soft)
     g_iq, g_soft, rep4 = c.alloc_frame_buffers(2 * n, L, dabgpu.PLACE_DOMAINS)
