@@ -772,6 +772,16 @@ int dabgpu_dabplus_superframes(dabgpu_ctx *ctx, const uint8_t *in, size_t in_str
 /* punct     [n_codewords][n_punct] int8 punctured soft bits                   */
 /* mask      HOST pointer, 4*nsteps flags (1 = transmitted)                    */
 /* out_bits  [n_codewords][(nsteps-6)/8] bytes, MSB first, NOT descrambled     */
+/*                                                                            */
+/* A DIAGNOSTIC entry point: no call of the reference's path reaches it (the  */
+/* FIC and every sub-channel go through dabgpu_fic_decode* / dabgpu_msc_decode* */
+/* / dabgpu_decode_*frames*, whose codewords all have nsteps = 96 k + 6 and run */
+/* on viterbi_rot_kernel or the lane kernels).  Lengths that are NOT 96 k + 6  */
+/* are decoded by a fourth implementation, viterbi_wave_kernel, which no DAB    */
+/* profile uses and which exists for this call alone: it lets the tests hold    */
+/* the decoder to an exhaustive maximum-likelihood search on short codewords    */
+/* (tests/test_gpu_parity.py) and tools/decoder_fuzz.py hold all implementations */
+/* to each other.  Not tuned, not part of any measured figure.                  */
 /* ------------------------------------------------------------------------ */
 int dabgpu_viterbi_dev(dabgpu_ctx *ctx, const int8_t *d_punct, int n_codewords, const uint8_t *mask,
                        int nsteps, uint8_t *d_out_bytes, void *stream);

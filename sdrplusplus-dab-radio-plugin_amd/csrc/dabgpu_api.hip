@@ -1095,14 +1095,43 @@ int dabgpu_track_start_dev(dabgpu_ctx *ctx, const dabgpu_acquired_frame *d_frame
     return note_state_use(ctx, s);
 }
 
+// What a tracked call launches (tracked_launches): where the streams lie, where the results go, and the riders the
+// one-frame call adds.  Value-initialised: everything optional is off.
+struct TrackedCall {
+    dabk::StreamState *states = nullptr;             // the streams' tracking state (device)
+    const void *d_iq = nullptr;                      // [n_streams][stream_stride] cf32
+    size_t stream_stride = 0;
+    int n_streams = 0;
+    int64_t n_samples = 0;                           // samples per stream in this call
+    int max_frames = 1;                              // output rows per stream
+    int64_t advance = 0;                             // samples the streams move on by after the call
+    int fixed_start = 0;                             // the frame starts at sample 0 of its stream (one-frame call)
+    int acquiring = 0;                               // ... and is the first after a null detection (coarse search, lock check)
+    int8_t *d_soft = nullptr;
+    void *d_cyc = nullptr, *d_dd4 = nullptr;         // the fine loop's input: cyclic-prefix correlations, or fourth-power sums
+    void *d_dqpsk = nullptr;
+    dabgpu_acquired_frame *d_frames = nullptr;
+    dabgpu_sync_result *d_sync = nullptr;
+    int32_t *d_counts = nullptr;
+    const dabk::AcquireArgs *auto_acq = nullptr;     // streams that are not tracking are acquired in the same call
+    // riders of the one-frame call: the frame's upload inside the synchronisation launch, the download inside the update's
+    const void *upload_from = nullptr;
+    size_t upload_bytes = 0;
+    const dabk::CopyPiece *down2 = nullptr;          // two pieces
+    dabk::StreamState *state_out = nullptr;          // the new state, written to page-locked memory by the updating workgroup
+    bool note_states = true;                         // record the state event behind the call (off: the call synchronises itself)
+};
+
 // the three launches of a tracked call on `s`: PRS synchronisation at the predicted positions, demodulation of the frames
 // where they lie, state update
-static int tracked_launches(dabgpu_ctx *ctx, dabk::StreamState *states, const void *d_iq, size_t stream_stride, int n_streams,
-                            int64_t n_samples, int max_frames, int64_t advance, const dabgpu_track_cfg &c, int fixed_start,
-                            int acquiring, int8_t *d_soft, void *d_cyc, void *d_dqpsk, dabgpu_acquired_frame *d_frames,
-                            dabgpu_sync_result *d_sync, int32_t *d_counts, hipStream_t s, const dabk::AcquireArgs *auto_acq = nullptr,
-                            void *d_dd4 = nullptr, const void *upload_from = nullptr, size_t upload_bytes = 0,
-                            bool note_states = true, const dabk::CopyPiece *down2 = nullptr, dabk::StreamState *state_out = nullptr) {
+static int tracked_launches(dabgpu_ctx *ctx, const TrackedCall &k, const dabgpu_track_cfg &c, hipStream_t s) {
+    dabk::StreamState *const states = k.states;
+    const void *const d_iq = k.d_iq;
+    const size_t stream_stride = k.stream_stride;
+    const int n_streams = k.n_streams, max_frames = k.max_frames, fixed_start = k.fixed_start;
+    const int64_t n_samples = k.n_samples, advance = k.advance;
+    const dabk::AcquireArgs *const auto_acq = k.auto_acq;
+    int32_t *const d_counts = k.d_counts;
     dabk::SyncTables stab{ctx->d_twiddle, ctx->d_prs_qt, ctx->d_sync_pairs, ctx->n_sync_pairs, ctx->d_sync_fs};
     dabk::TrackArgs t{};
     t.state = states;
@@ -1117,17 +1146,17 @@ static int tracked_launches(dabgpu_ctx *ctx, dabk::StreamState *states, const vo
     t.rule.first_path_rel = c.first_path_rel;
     t.fixed_start = fixed_start;
     t.max_coarse = fixed_start ? c.max_coarse_carriers : 0;
-    t.acquiring = acquiring;
+    t.acquiring = k.acquiring;
     t.coarse_slow_beta = c.coarse_freq_slow_beta;
-    t.out = reinterpret_cast<dabk::AcquiredFrame *>(d_frames);
-    t.sync_out = reinterpret_cast<dabk::SyncResult *>(d_sync);
-    if (upload_from) {
+    t.out = reinterpret_cast<dabk::AcquiredFrame *>(k.d_frames);
+    t.sync_out = reinterpret_cast<dabk::SyncResult *>(k.d_sync);
+    if (k.upload_from) {
         // the one-frame call: the frame's upload rides in this launch, and the synchronisation reads its PRS straight
         // from the caller's page-locked buffer meanwhile (TrackArgs::copy_*)
-        t.sync_iq = static_cast<const float2 *>(upload_from);
+        t.sync_iq = static_cast<const float2 *>(k.upload_from);
         t.copy_dst = static_cast<uint4 *>(const_cast<void *>(d_iq));
-        t.copy_src = static_cast<const uint4 *>(upload_from);
-        t.copy_n16 = unsigned(upload_bytes >> 4);
+        t.copy_src = static_cast<const uint4 *>(k.upload_from);
+        t.copy_n16 = unsigned(k.upload_bytes >> 4);
     }
     HIP_TRY(dabk::launch_track_sync(stab, t, s));
     // streams that are not tracking: acquired here (their rows of d_frames / d_counts; the pass above left them empty)
@@ -1137,11 +1166,11 @@ static int tracked_launches(dabgpu_ctx *ctx, dabk::StreamState *states, const vo
     a.iq = static_cast<const float2 *>(d_iq);
     a.frame_stride = stream_stride;
     a.n_frames = n_streams * max_frames;
-    a.soft = d_soft;
-    a.cyc = static_cast<float2 *>(d_cyc);
-    a.dd4 = static_cast<float2 *>(d_dd4);
-    a.dqpsk = static_cast<float2 *>(d_dqpsk);
-    a.acq = reinterpret_cast<const dabk::AcquiredFrame *>(d_frames);
+    a.soft = k.d_soft;
+    a.cyc = static_cast<float2 *>(k.d_cyc);
+    a.dd4 = static_cast<float2 *>(k.d_dd4);
+    a.dqpsk = static_cast<float2 *>(k.d_dqpsk);
+    a.acq = reinterpret_cast<const dabk::AcquiredFrame *>(k.d_frames);
     a.acq_per_stream = max_frames;
     a.keep = ctx->d_keep;
     {
@@ -1169,13 +1198,13 @@ static int tracked_launches(dabgpu_ctx *ctx, dabk::StreamState *states, const vo
     u.counts = d_counts;
     u.dd_gate = c.dd_gate;
     u.dd_terms_per_frame = 256 * ((a.keep && !a.dqpsk) ? ctx->keep_symbols : NB_DATA_SYMBOLS);
-    if (down2) { u.down[0] = down2[0]; u.down[1] = down2[1]; }
-    u.state_out = state_out;
+    if (k.down2) { u.down[0] = k.down2[0]; u.down[1] = k.down2[1]; }
+    u.state_out = k.state_out;
     // ... and their tracking starts from what the acquisition found (marked 2; the update launch makes it 1)
     if (auto_acq)
         HIP_TRY(dabk::launch_track_start(states, t.out, d_counts, n_streams, max_frames, advance, 1, s));
     HIP_TRY(dabk::launch_track_update(u, s));
-    return note_states ? note_state_use(ctx, s) : DABGPU_OK;
+    return k.note_states ? note_state_use(ctx, s) : DABGPU_OK;
 }
 
 int dabgpu_ofdm_demod_tracked_dev(dabgpu_ctx *ctx, const void *d_iq, size_t stream_stride, int n_streams,
@@ -1212,8 +1241,22 @@ int dabgpu_ofdm_demod_tracked_dev(dabgpu_ctx *ctx, const void *d_iq, size_t stre
         if ((rc = acquire_args(ctx, d_iq, stream_stride, n_streams, n_samples, ac, max_frames, d_frames, d_counts, s, acq))) return rc;
         acq.skip_tracked = ctx->d_states;
     }
-    return tracked_launches(ctx, ctx->d_states, d_iq, stream_stride, n_streams, n_samples, max_frames, advance, c, 0, 0, d_soft,
-                            d_cyc, d_dqpsk, d_frames, nullptr, d_counts, s, (c.auto_acquire && n_samples >= 64) ? &acq : nullptr, d_dd);
+    TrackedCall k;
+    k.states = ctx->d_states;
+    k.d_iq = d_iq;
+    k.stream_stride = stream_stride;
+    k.n_streams = n_streams;
+    k.n_samples = n_samples;
+    k.max_frames = max_frames;
+    k.advance = advance;
+    k.d_soft = d_soft;
+    k.d_cyc = d_cyc;
+    k.d_dd4 = d_dd;
+    k.d_dqpsk = d_dqpsk;
+    k.d_frames = d_frames;
+    k.d_counts = d_counts;
+    k.auto_acq = (c.auto_acquire && n_samples >= 64) ? &acq : nullptr;
+    return tracked_launches(ctx, k, c, s);
 }
 
 int dabgpu_ofdm_demod_stream_frame(dabgpu_ctx *ctx, int stream_index, const float *iq, int acquiring,
@@ -1264,11 +1307,26 @@ int dabgpu_ofdm_demod_stream_frame(dabgpu_ctx *ctx, int stream_index, const floa
     char *hd = static_cast<char *>(h_dev);
     const dabk::CopyPiece down[2] = {{soft_alias ? soft_alias : static_cast<void *>(hd), d_res, size_t(NB_FRAME_BITS)},
                                      {hd + off_fr, res + off_fr, off_st - off_fr}};
-    rc = tracked_launches(ctx, st, d_iq, nb_iq / sizeof(float2), 1, int64_t(nb_iq / sizeof(float2)), 1, 0, c, 1, acquiring ? 1 : 0,
-                          reinterpret_cast<int8_t *>(res), d_cyc, d_dq, reinterpret_cast<dabgpu_acquired_frame *>(res + off_fr),
-                          reinterpret_cast<dabgpu_sync_result *>(res + off_sy), nullptr, s, nullptr, d_dd, iq_alias, iq_alias ? nb_iq : 0,
-                          false, down, reinterpret_cast<dabk::StreamState *>(hd + off_st));
-    if (rc) return rc;
+    TrackedCall k;
+    k.states = st;
+    k.d_iq = d_iq;
+    k.stream_stride = nb_iq / sizeof(float2);
+    k.n_streams = 1;
+    k.n_samples = int64_t(nb_iq / sizeof(float2));
+    k.fixed_start = 1;
+    k.acquiring = acquiring ? 1 : 0;
+    k.d_soft = reinterpret_cast<int8_t *>(res);
+    k.d_cyc = d_cyc;
+    k.d_dd4 = d_dd;
+    k.d_dqpsk = d_dq;
+    k.d_frames = reinterpret_cast<dabgpu_acquired_frame *>(res + off_fr);
+    k.d_sync = reinterpret_cast<dabgpu_sync_result *>(res + off_sy);
+    k.upload_from = iq_alias;
+    k.upload_bytes = iq_alias ? nb_iq : 0;
+    k.down2 = down;
+    k.state_out = reinterpret_cast<dabk::StreamState *>(hd + off_st);
+    k.note_states = false;
+    if ((rc = tracked_launches(ctx, k, c, s))) return rc;
     if (dqpsk) {
         HIP_TRY(hipMemcpyAsync(dqpsk, d_dq, nb_dq, hipMemcpyDeviceToHost, s));           // (+ the constellation, when asked for:
         HIP_TRY(hipStreamSynchronize(s));                                                // a copy-engine transfer ends the usual way)

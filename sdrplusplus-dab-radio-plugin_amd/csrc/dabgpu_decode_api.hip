@@ -104,15 +104,20 @@ static int lookup_code(dabgpu_ctx *ctx, const dabgpu_subchannel *sc, DeviceCode 
     const uint64_t key = (uint64_t(sc->is_uep != 0) << 63) | (uint64_t(uint32_t(sc->eep_type) & 0xFu) << 56) |
                          (uint64_t(uint32_t(sc->protection_level) & 0xFFu) << 48) | (uint64_t(uint32_t(sc->bitrate_kbps) & 0xFFFFFFu) << 16) |
                          uint64_t(uint32_t(sc->length) & 0xFFFFu);
-    auto it = ctx->code_by_descriptor.find(key);
-    if (it == ctx->code_by_descriptor.end() || sc->eep_type < 0 || sc->eep_type > 15 || sc->protection_level < 0 ||
-        sc->protection_level > 255 || sc->bitrate_kbps < 0 || sc->bitrate_kbps > 0xFFFFFF || sc->length < 0 || sc->length > 0xFFFF) {
+    // (the key holds the fields masked: only a descriptor whose fields fit their masks may use -- or fill -- the cache)
+    const bool in_range = sc->eep_type >= 0 && sc->eep_type <= 15 && sc->protection_level >= 0 && sc->protection_level <= 255 &&
+                          sc->bitrate_kbps >= 0 && sc->bitrate_kbps <= 0xFFFFFF && sc->length >= 0 && sc->length <= 0xFFFF;
+    auto it = in_range ? ctx->code_by_descriptor.find(key) : ctx->code_by_descriptor.end();
+    if (it == ctx->code_by_descriptor.end()) {
         dab::PunctureProfile prof;
         int rc = subchannel_profile(sc, prof);
         if (rc) return rc;
+        // a length no decoder holds gets no device tables (they would stay allocated for the context's lifetime)
+        if (!dabk::viterbi_fits(prof.nsteps) && !dabk::lane_supported(prof.nsteps)) return DABGPU_ERR_CAPACITY;
         DeviceCode *dc = nullptr;
         if ((rc = get_code(ctx, std::move(prof), &dc))) return rc;
-        ctx->code_by_descriptor[key] = dc;
+        // (ctx->codes only ever grows until dabgpu_destroy frees it: the pointers kept here stay valid for the context's life)
+        if (in_range) ctx->code_by_descriptor[key] = dc;
         *out = dc;
         return DABGPU_OK;
     }

@@ -899,7 +899,8 @@ hipError_t launch_track_sync(const SyncTables &t, const TrackArgs &a, hipStream_
     b.rule.expected = a.margin;
     b.copy_blocks = 0;
     if (a.copy_n16) {
-        if (!a.copy_dst || !a.copy_src || !a.fixed_start) return hipErrorInvalidValue;
+        // the riding upload's prefetch reads stream 0 at candidate 0 for the whole workgroup: one stream, one frame only
+        if (!a.copy_dst || !a.copy_src || !a.fixed_start || a.n_streams * a.max_out != 1) return hipErrorInvalidValue;
         b.copy_blocks = int(std::min<unsigned>(unsigned(RIDE_BLOCKS), (a.copy_n16 + WG - 1) / WG));
     } else {
         b.copy_dst = nullptr;
