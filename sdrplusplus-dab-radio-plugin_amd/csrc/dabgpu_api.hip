@@ -1117,7 +1117,8 @@ struct TrackedCall {
     // riders of the one-frame call: the frame's upload inside the synchronisation launch, the download inside the update's
     const void *upload_from = nullptr;
     size_t upload_bytes = 0;
-    const dabk::CopyPiece *down2 = nullptr;          // two pieces
+    const dabk::CopyPiece *down = nullptr;           // n_down (<= 3) pieces
+    int n_down = 0;
     dabk::StreamState *state_out = nullptr;          // the new state, written to page-locked memory by the updating workgroup
     bool note_states = true;                         // record the state event behind the call (off: the call synchronises itself)
 };
@@ -1198,7 +1199,7 @@ static int tracked_launches(dabgpu_ctx *ctx, const TrackedCall &k, const dabgpu_
     u.counts = d_counts;
     u.dd_gate = c.dd_gate;
     u.dd_terms_per_frame = 256 * ((a.keep && !a.dqpsk) ? ctx->keep_symbols : NB_DATA_SYMBOLS);
-    if (k.down2) { u.down[0] = k.down2[0]; u.down[1] = k.down2[1]; }
+    for (int i = 0; i < k.n_down && i < 3; i++) u.down[i] = k.down[i];
     u.state_out = k.state_out;
     // ... and their tracking starts from what the acquisition found (marked 2; the update launch makes it 1)
     if (auto_acq)
@@ -1305,8 +1306,13 @@ int dabgpu_ofdm_demod_stream_frame(dabgpu_ctx *ctx, int stream_index, const floa
     // new state to the landing area itself.  Three launches per call: upload + synchronisation, demodulation, update + download.
     static_assert(sizeof(dabk::StreamState) % 16 == 0, "the state goes out in 16-byte words");
     char *hd = static_cast<char *>(h_dev);
-    const dabk::CopyPiece down[2] = {{soft_alias ? soft_alias : static_cast<void *>(hd), d_res, size_t(NB_FRAME_BITS)},
-                                     {hd + off_fr, res + off_fr, off_st - off_fr}};
+    // ... and the constellation, when a display asks for it and its buffer is coherent page-locked memory (the host mirror's
+    // is): 0.9 MB more in the same launch instead of a copy-engine transfer and a sleep behind it
+    void *dq_alias = (dqpsk && known_coherent_host(dqpsk, nb_dq)) ? device_alias_of_pinned(dqpsk) : nullptr;
+    if (reinterpret_cast<uintptr_t>(dq_alias) & 15) dq_alias = nullptr;
+    const dabk::CopyPiece down[3] = {{soft_alias ? soft_alias : static_cast<void *>(hd), d_res, size_t(NB_FRAME_BITS)},
+                                     {hd + off_fr, res + off_fr, off_st - off_fr},
+                                     {dq_alias, d_dq, dq_alias ? nb_dq : 0}};
     TrackedCall k;
     k.states = st;
     k.d_iq = d_iq;
@@ -1323,12 +1329,13 @@ int dabgpu_ofdm_demod_stream_frame(dabgpu_ctx *ctx, int stream_index, const floa
     k.d_sync = reinterpret_cast<dabgpu_sync_result *>(res + off_sy);
     k.upload_from = iq_alias;
     k.upload_bytes = iq_alias ? nb_iq : 0;
-    k.down2 = down;
+    k.down = down;
+    k.n_down = 3;
     k.state_out = reinterpret_cast<dabk::StreamState *>(hd + off_st);
     k.note_states = false;
     if ((rc = tracked_launches(ctx, k, c, s))) return rc;
-    if (dqpsk) {
-        HIP_TRY(hipMemcpyAsync(dqpsk, d_dq, nb_dq, hipMemcpyDeviceToHost, s));           // (+ the constellation, when asked for:
+    if (dqpsk && !dq_alias) {
+        HIP_TRY(hipMemcpyAsync(dqpsk, d_dq, nb_dq, hipMemcpyDeviceToHost, s));           // (the constellation into any other memory:
         HIP_TRY(hipStreamSynchronize(s));                                                // a copy-engine transfer ends the usual way)
     } else {
         // one synchronisation: the word behind the landing area's payload (the area is at least nb_res + 64 bytes)

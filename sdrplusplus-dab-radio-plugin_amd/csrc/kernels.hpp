@@ -282,7 +282,7 @@ struct TrackUpdateArgs {
     // the one-frame call's download riding in this launch: workgroups behind the n_streams updating ones copy `down` (what
     // the launches before this one produced: soft bits, frame and sync records); the updating workgroup writes the new state
     // to `state_out` as well (page-locked host memory) -- one launch instead of two at the end of the call
-    CopyPiece down[2] = {{nullptr, nullptr, 0}, {nullptr, nullptr, 0}};
+    CopyPiece down[3] = {{nullptr, nullptr, 0}, {nullptr, nullptr, 0}, {nullptr, nullptr, 0}};   // (the third: the constellation, when asked for)
     StreamState *state_out = nullptr;
     int copy_blocks = 0;       // set by the launcher
 };

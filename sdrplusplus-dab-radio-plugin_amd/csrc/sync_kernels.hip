@@ -423,7 +423,7 @@ __global__ __launch_bounds__(TU) void track_update_kernel(TrackUpdateArgs a) {
     if (s >= a.n_streams) {                                    // the download that rides in this launch (TrackUpdateArgs::down)
         unsigned i = unsigned(s - a.n_streams) * TU + unsigned(tid);
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
+        for (int k = 0; k < 3; k++) {
             const unsigned n16 = unsigned(a.down[k].bytes >> 4);
             if (i < n16) { static_cast<uint4 *>(a.down[k].dst)[i] = static_cast<const uint4 *>(a.down[k].src)[i]; return; }
             i -= n16;

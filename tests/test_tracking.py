@@ -756,3 +756,58 @@ def test_gpu_frame_call_honours_the_opt_in_decision_directed_loop(tctx):
         fines[dd] = float(res.stats.fine_freq_offset)
         assert abs(fines[dd] + cfo) * 2048 < 5e-3
     assert abs(fines[0] - fines[1]) * 2048 < 2e-3
+
+
+@pytest.mark.gpu
+def test_gpu_frame_call_on_page_locked_buffers(tctx):
+    """The host mirror's shape of dabgpu_ofdm_demod_stream_frame: frame, soft bits and the constellation in page-locked buffers
+    from dabgpu_host_alloc.  The upload rides in the synchronisation launch, soft bits AND (round 6) the 0.9 MB constellation
+    ride in the update launch, and the call ends on the watched word -- which is only allowed because these buffers are
+    coherent.  Same soft bits, constellation and state as the same call on pageable numpy buffers (copy-engine
+    transfers, stream synchronisation), frame after frame; the constellation within 2e-4 of the oracle's."""
+    import ctypes as C
+    import dabgpu
+    from conftest import make_ctx
+    e = synth.Ensemble(seed=78, n_frames=4)
+    iq = synth.channel(e.iq().ravel(), snr_db=15.0, cfo=0.31 / 2048.0, rng=np.random.default_rng(78))
+    M = 128
+    cfg = dabgpu.track_cfg(timing_margin=M, min_peak_to_mean=100.0)
+    other = make_ctx(None, 4)
+    tctx.streams_reset(1)
+    other.streams_reset(1)
+    p_iq = dabgpu.PinnedArray((SYMS,), np.complex64)
+    p_soft = dabgpu.PinnedArray((dabgpu.NB_FRAME_BITS,), np.int8)
+    p_dq = dabgpu.PinnedArray((75, 1536), np.complex64)
+    lib = dabgpu.lib()
+    for f in range(4):
+        frame = iq[f * L + NULL - M:f * L + NULL - M + SYMS]
+        p_iq.array[:] = frame
+        p_soft.array[:] = 0
+        p_dq.array[:] = 0
+        res = dabgpu.FrameResult()
+        want_dq = f in (1, 2)
+        rc = lib.dabgpu_ofdm_demod_stream_frame(tctx._h, 0, p_iq.array.ctypes.data, int(f == 0), C.byref(cfg), p_soft.array.ctypes.data,
+                                                p_dq.array.ctypes.data if want_dq else None, C.byref(res))
+        assert rc == 0
+        soft, res2, dq = other.ofdm_demod_stream_frame(frame, 0, acquiring=(f == 0), cfg=cfg, want_dqpsk=want_dq)
+        assert (p_soft.array == soft).all() and res.flags == res2.flags == 3
+        assert res.stats.fine_freq_offset == res2.stats.fine_freq_offset and res.stats.total_frames_read == f + 1
+        assert (res.sync.coarse_carriers, res.sync.time_offset) == (res2.sync.coarse_carriers, res2.sync.time_offset)
+        if want_dq:
+            assert (p_dq.array == dq).all() and np.abs(dq).max() > 0
+        else:
+            assert not p_dq.array.any()                           # nothing is written when nobody asked
+    # the constellation against the oracle, at the offset the call applied (the state before the frame)
+    tctx.streams_reset(1)
+    frame = iq[NULL - M:NULL - M + SYMS]
+    p_iq.array[:] = frame
+    res = dabgpu.FrameResult()
+    tctx.set_stream_offsets(0, fine=-0.31 / 2048.0, coarse=0.0)
+    cfg2 = dabgpu.track_cfg(timing_margin=M, min_peak_to_mean=100.0, max_coarse_carriers=0)
+    assert lib.dabgpu_ofdm_demod_stream_frame(tctx._h, 0, p_iq.array.ctypes.data, 0, C.byref(cfg2), p_soft.array.ctypes.data,
+                                              p_dq.array.ctypes.data, C.byref(res)) == 0
+    _, _, _, odq = O.ofdm_demod_frame(frame, float(np.float32(-0.31 / 2048.0)), want_dqpsk=True)
+    assert np.abs(p_dq.array - odq).max() <= 2e-4 * np.abs(odq).max()
+    for p in (p_iq, p_soft, p_dq):
+        p.close()
+    other.close()
