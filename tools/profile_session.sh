@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box, from the repo root: one profile session of a round -- everything profiles/README.md cites for it.
-#   tools/profile_session.sh <tag>        (e.g. r05)      results under gpurun_out/<tag>/
-tag=${1:-r05}
+#   tools/profile_session.sh <tag>        (e.g. r06)      results under gpurun_out/<tag>/
+tag=${1:-r06}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 o=$root/gpurun_out/$tag; mkdir -p $o
 cd $root
