@@ -18,6 +18,10 @@ library's defaults.  `value` and `roofline` are that step.  The same step on the
 (opt-in; 17 % fewer bytes: of a frame's prefixes only the PRS's is read) is the `with_decision_directed_loop` leg, copied to
 the top level as `value_own_estimator` / `roofline.frac_own_estimator`.
 
+The IQ / soft-bit buffers are what the library gives any caller: ONE dabgpu_alloc_frame_buffers call, no policy here
+(`config.buffer_placement` = its report).  `decoder.roofline` = the channel decoder against its own bounds (forward pass:
+VALU issue; traceback: HBM), from the library's HIP events between its kernels during the timed steps.
+
 Everything measured AFTER the timed region -- that leg, the sustained leg, the FFT stage, BASELINE configs 2 and 3 (one
 ensemble), the host-fed figures, unaligned captures, the CPU baseline -- lives in bench_legs.py and runs on rank 0 of a
 one-GPU run (`--legs all` forces it elsewhere, `--legs none` skips it).

@@ -808,6 +808,21 @@ def test_gpu_frame_call_on_page_locked_buffers(tctx):
                                               p_dq.array.ctypes.data, C.byref(res)) == 0
     _, _, _, odq = O.ofdm_demod_frame(frame, float(np.float32(-0.31 / 2048.0)), want_dqpsk=True)
     assert np.abs(p_dq.array - odq).max() <= 2e-4 * np.abs(odq).max()
+    # ... and page-locked memory that did NOT come from dabgpu_host_alloc (torch's pinned allocator: the device can address it,
+    # but nothing says it is coherent): the kernels still write straight into it, the call ends in a stream synchronisation
+    # instead of the watched word, the bytes are the same
+    import torch
+    t_iq = torch.empty(SYMS, dtype=torch.complex64).pin_memory()
+    t_soft = torch.zeros(dabgpu.NB_FRAME_BITS, dtype=torch.int8).pin_memory()
+    t_dq = torch.zeros((75, 1536), dtype=torch.complex64).pin_memory()
+    t_iq.numpy()[:] = frame
+    tctx.streams_reset(1)
+    tctx.set_stream_offsets(0, fine=-0.31 / 2048.0, coarse=0.0)
+    res3 = dabgpu.FrameResult()
+    assert lib.dabgpu_ofdm_demod_stream_frame(tctx._h, 0, t_iq.data_ptr(), 0, C.byref(cfg2), t_soft.data_ptr(), t_dq.data_ptr(),
+                                              C.byref(res3)) == 0
+    assert (t_soft.numpy() == p_soft.array).all() and (t_dq.numpy() == p_dq.array).all()
+    assert res3.stats.fine_freq_offset == res.stats.fine_freq_offset and res3.flags == res.flags
     for p in (p_iq, p_soft, p_dq):
         p.close()
     other.close()
