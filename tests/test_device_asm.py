@@ -89,3 +89,41 @@ def test_the_scratch_free_claim_holds_for_the_decoders_too():
             assert md, obj
             for k, v in md.items():
                 assert v["vgpr_spill_count"] == 0 and v["private_segment_fixed_size"] == 0, (obj, k, v)
+
+
+def test_lane_forward_pass_instruction_count_matches_the_bench_lines_constants(tmp_path):
+    """`decoder.roofline` prices the lane decoder's forward pass on two static counts (bench_legs.LANE_VALU_PER_STEP = 202
+    VALU instructions per trellis step of one wave, LANE_ACS_VALU_PER_STEP = 96 of them the add-compare-select proper; DESIGN.md
+    4.2b).  They are read here from the compiler's listing of lane_forward_grouped_kernel: its 6-step loop body is the
+    kernel's largest basic block; 32 `v_pk_max_i16` per step (one per register of packed metric pairs), 64 packed adds /
+    subtracts feeding them, and everything else the table in DESIGN.md itemises."""
+    import collections
+    import bench_legs
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    mk = open(os.path.join(CSRC, "Makefile")).read()
+    flags = re.search(r"^CXXFLAGS\s*\?=\s*(.*)$", mk, re.M).group(1).replace("$(ARCH)", "gfx950").replace("$(EXTRA)", "").split()
+    out = tmp_path / "viterbi_lane_kernels.s"
+    subprocess.check_call([hipcc] + flags + ["-S", "--cuda-device-only", os.path.join(CSRC, "viterbi_lane_kernels.hip"), "-o", str(out)],
+                          stderr=subprocess.DEVNULL)
+    asm = out.read_text()
+    m = re.search(r"^(_ZN4dabk\S*lane_forward_grouped_kernel\S*):[^\n]*\n(.*?)\n\s*s_endpgm", asm, re.S | re.M)
+    assert m, "lane_forward_grouped_kernel not found in the listing"
+    blocks, cur = [], []
+    for line in m.group(2).split("\n"):
+        if re.match(r"^\.LBB\d+_\d+:", line):
+            blocks.append(cur)
+            cur = []
+        else:
+            cur.append(line)
+    blocks.append(cur)
+    valu = lambda b: [l.split()[0] for l in b if re.match(r"^\s+v_", l)]
+    body = max(blocks, key=lambda b: len(valu(b)))
+    ops = collections.Counter(valu(body))
+    steps = 6                                                            # one pass through the six phases of the rotating layout
+    assert ops["v_pk_max_i16"] == 32 * steps                             # the select of every ACS: exact
+    assert ops["v_pk_add_u16"] + ops["v_pk_sub_i16"] >= 64 * steps       # the two candidates of every butterfly (+ branch metrics, renormalisation)
+    assert bench_legs.LANE_ACS_VALU_PER_STEP == 32 + 64
+    per_step = sum(ops.values()) / steps
+    # the constant also carries the per-24-step staging around the body (~5 per step): it may exceed the body's own count by
+    # that much and must never be below it
+    assert per_step <= bench_legs.LANE_VALU_PER_STEP <= per_step + 8, (per_step, bench_legs.LANE_VALU_PER_STEP)
