@@ -382,8 +382,11 @@ def test_alloc_frame_buffers_by_domain(built, ensemble_iq):
     # the same ranges serve the next pair (same addresses); a larger one than they were reserved for is a plain pair
     f_iq, f_soft, rep3 = c.alloc_frame_buffers(n, L, dabgpu.PLACE_DOMAINS)
     placed3 = rep3.method == 1
-    assert (placed3 and f_iq == d_iq) or rep3.fallback_reason == dabgpu.PLAIN_ONE_DOMAIN, \
+    # (on a box that hands out one domain the check can read either side of 0.985 from one allocation to the next: each
+    # request is judged on its own; two placed pairs of one context share the ranges, hence the address)
+    assert placed3 or rep3.fallback_reason == dabgpu.PLAIN_ONE_DOMAIN, \
         (rep3.method, rep3.fallback_reason, rep3.runtime_error, rep3.pair_over_same_domain, rep3.domains, rep3.iq_map, rep3.soft_map)
+    assert not (placed and placed3) or f_iq == d_iq
     g_iq, g_soft, rep4 = c.alloc_frame_buffers(2 * n, L, dabgpu.PLACE_DOMAINS)
     assert rep4.method == 0 and rep4.fallback_reason == (4 if placed3 else 5)
     c.free_frame_buffers(g_iq, g_soft)
