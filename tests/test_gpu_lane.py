@@ -300,3 +300,43 @@ def test_more_sub_channels_than_one_grouped_launch_holds():
     for i in range(len(scs)):
         assert (np.concatenate(streamed[i]) == res[0][0][i][0]).all(), i
     c.close()
+
+
+def test_timer_splits_the_grouped_lane_decode_into_its_kernels():
+    """dabgpu_mean_kernel_ms 4 / 5 / 6 (what `decoder.roofline` in the bench line is built from): while timing is on, the
+    grouped codeword-per-lane decode records two events between its kernels, and the three parts -- forward pass,
+    traceback, history copy -- add up to the whole call's slot 2 (but for the events' own few microseconds); a context whose
+    decode took the wave-per-codeword kernels has no such parts and says so (DABGPU_ERR_ARG), never a stale figure."""
+    dev = torch.device("cuda", 0)
+    E, F = 4, 16
+    n = E * F
+    g = torch.Generator(device=dev); g.manual_seed(9)
+    soft = torch.randint(-127, 128, (n, dabgpu.NB_FRAME_BITS), dtype=torch.int8, device=dev, generator=g)
+    fib = torch.zeros((n, 12, 32), dtype=torch.uint8, device=dev)
+    ok = torch.zeros((n, 12), dtype=torch.uint8, device=dev)
+    sc = dabgpu.subchannel(0, 64, level=3)
+    msc = torch.zeros((E, F * 4, 192), dtype=torch.uint8, device=dev)
+    hist = [torch.zeros((E, 15, sc.length * 64), dtype=torch.int8, device=dev) for _ in range(2)]
+    torch.cuda.synchronize()
+    for mode in (1, 0):
+        c = make_ctx(mode, max_frames=n)
+        c.set_timing(True)
+        for k in range(3):
+            c.decode_frames_dev(soft.data_ptr(), dabgpu.NB_FRAME_BITS, E, F, fib.data_ptr(), ok.data_ptr(), [sc],
+                                [hist[k & 1].data_ptr()], [hist[(k & 1) ^ 1].data_ptr()], [msc.data_ptr()], None)
+        c.sync()
+        whole, n_whole = c.mean_kernel_ms(2)
+        assert n_whole == 3 and whole > 0
+        if mode == 1:
+            parts = [c.mean_kernel_ms(w) for w in (4, 5, 6)]
+            assert all(cnt == 3 and ms > 0 for ms, cnt in parts)
+            fwd, tb, hi = (ms for ms, _ in parts)
+            assert hi < tb < fwd and 0.9 * whole <= fwd + tb + hi <= whole * 1.001
+        else:
+            for w in (4, 5, 6):
+                with pytest.raises(dabgpu.DabGpuError):
+                    c.mean_kernel_ms(w)
+        with pytest.raises(dabgpu.DabGpuError):
+            c.mean_kernel_ms(7)
+        c.set_timing(False)
+        c.close()
