@@ -162,17 +162,21 @@ int dabgpu_test_fail_frame_call(dabgpu_ctx *ctx, int nth);
  *              DABGPU_PLACE_DOMAINS  MI355X's HBM behaves as three domains of 96 GB, and a launch that reads its
  *                samples from the domain it writes its soft bits to runs up to ~10 % slower than one whose two streams
  *                lie apart (profiles/r02_hbm_domains.txt; against a plain pair the front end
- *                gained 0.8-3.9 % in six of six trials, profiles/r04_placement_ab.txt).  Physical memory is taken in chunks through the virtual-memory API (1 GiB for the
- *                samples, 256 MiB for the soft bits; never more than 1.5 x the pair's size held during set-up), every
- *                chunk's domain is found with a small data mover (two passes, ~40 ms), the IQ buffer is mapped over
- *                chunks of the most plentiful domain(s) and every 256 MiB of the soft-bit buffer over a chunk whose
- *                domain differs from the ~1.7 GiB of samples read WHILE it is written; the chunks left over go back.
- *                All of it happens inside two address ranges per context (one to probe in, one for the pair), reserved by
- *                the first such call and released by dabgpu_destroy: one domain-aware pair per context at a time; a second request while the first is
- *                alive, a request larger than the range was reserved for, buffers below ~4 GiB, a device without the
- *                virtual-memory API or without room, and any failure on the way all end in a PLAIN pair
- *                (report->method = 0, report->fallback_reason says why).  A set-up call: it synchronises, takes
- *                ~0.1 s and leaves noise in both buffers.
+ *                gained 0.8-3.9 % in six of six trials, profiles/r04_placement_ab.txt).  Physical memory is taken in
+ *                chunks through the virtual-memory API (1 GiB for the samples, 256 MiB for the soft bits; never more
+ *                than 1.5 x the pair's size held during set-up), every chunk's domain is found with a small data
+ *                mover (two passes, ~40-110 ms), the IQ buffer is mapped over chunks of the most plentiful domain(s)
+ *                and every 256 MiB of the soft-bit buffer over a chunk whose domain differs from the ~1.7 GiB of
+ *                samples read WHILE it is written; the chunks left over go back.  All of it happens inside two
+ *                address ranges per context (one to probe in, one for the pair), reserved by the first such call and
+ *                released by dabgpu_destroy: one domain-aware pair per context at a time.  The call then CHECKS its
+ *                own result (report->pair_over_same_domain) and, where the pair behaves as one domain -- a box whose
+ *                virtual-memory chunks all come from one: the worst case, 2-9 % of the boxes seen --, gives it back
+ *                and allocates a plain pair instead: the caller never has to compare.  That case, a second request
+ *                while the first pair is alive, a request larger than the range was reserved for, buffers below
+ *                ~4 GiB, a device without the virtual-memory API or without room, and any failure on the way all end
+ *                in a PLAIN pair (report->method = 0, report->fallback_reason says why).  A set-up call: it
+ *                synchronises, takes ~0.1-0.2 s and leaves noise in both buffers.
  * Returns an error only when the plain allocation fails too.  Release with dabgpu_free_frame_buffers (both pointers of
  * a domain-aware pair together). */
 #define DABGPU_PLACE_PLAIN   0
